@@ -1,0 +1,218 @@
+/*
+ * psdr_hip.h -- C ABI of the MI355X-native differentiable wavefront renderer.
+ *
+ * This is the drop-in boundary for the hot path of uci-rendering/psdr-cuda
+ * (Integrator.renderC / renderD and everything below it).  The reference has
+ * no C ABI of its own: its boundary is the pybind11 module `psdr_cuda`
+ * (reference src/psdr.cpp:40-295).  Every entry point below names the
+ * reference interface it replaces (file:line relative to the reference tree).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no C++/torch types.
+ *   - every function returns 0 on success, non-zero on failure;
+ *     psdr_last_error() returns the message (the reference throws
+ *     psdr::Exception : std::runtime_error, include/misc/Exception.h:86-132).
+ *   - all table pointers are CALLER-OWNED.  For libpsdr_hip.so they are
+ *     DEVICE pointers (HBM); for the CPU oracle (oracle/psdr_oracle.cpp, test
+ *     infrastructure only) the same structs carry HOST pointers.
+ *   - float = IEEE fp32, indices = int32, images are interleaved RGB
+ *     [H*W][3], pixel i = y*W + x, row 0 = top (reference
+ *     src/integrator/integrator.cpp:76-88, docs/python_render.rst).
+ *
+ * The AD graph of the reference (Enoki DiffArray) is cut at the "scene
+ * tables" built by Scene::configure (reference src/scene/scene.cpp:56-278):
+ * kernels consume the tables (+ tangent tables in forward mode) and produce
+ * the image (+ derivative image), or consume an adjoint image and scatter-add
+ * into gradient tables (reverse mode).
+ */
+#ifndef PSDR_HIP_H
+#define PSDR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- table strides (in 4-byte words) ------------------------------------ */
+#define PSDR_TRI_STRIDE   24 /* p0 e1 e2 n0 n1 n2 face_normal (7x3) face_area, 2 pad
+                                = TriangleInfo_, include/psdr/types.h:135-146 */
+#define PSDR_TRIUV_STRIDE  8 /* uv0 uv1 uv2 (3x2), 2 pad = TriangleUV, types.h:154-155 */
+#define PSDR_SEDGE_STRIDE 16 /* p0 e1 n0 n1 p2 (5x3) is_boundary(0/1)
+                                = SecondaryEdgeInfo_, include/psdr/edge/edge.h:49-65 */
+#define PSDR_PEDGE_STRIDE  8 /* p0(2) p1(2) edge_normal(2) edge_length, 1 pad
+                                = PrimaryEdgeInfo_, edge.h:27-40 */
+#define PSDR_BSDF_STRIDE  16 /* int32: type, then 5 x (texel offset, width, height) */
+#define PSDR_EMITTER_F_STRIDE 8 /* radiance rgb, sampling_weight (normalised),
+                                   inv_total_area, face pmf sum, 2 pad
+                                   (src/emitter/area.cpp:10-62, src/shape/mesh.cpp:239-249) */
+#define PSDR_EMITTER_I_STRIDE 4 /* mesh id, first global tri id, num faces, offset into face_cmf/pmf */
+#define PSDR_CAM_WORDS    64 /* see below */
+
+/* tri_mesh[t] = mesh id | PSDR_TRI_FACE_NORMALS if the mesh uses face normals
+   (scene.cpp:205-216 m_triangle_face_normals) */
+#define PSDR_TRI_FACE_NORMALS 0x40000000
+
+/* BSDF types (src/bsdf/diffuse.cpp, src/bsdf/roughconductor.cpp) */
+#define PSDR_BSDF_DIFFUSE        0
+#define PSDR_BSDF_ROUGHCONDUCTOR 1
+/* bsdf_rec parameter slots: slot s occupies words 1+3*s .. 3+3*s */
+#define PSDR_SLOT_REFLECTANCE 0 /* Diffuse::m_reflectance / RoughConductor::m_specular_reflectance (3 ch) */
+#define PSDR_SLOT_ALPHA_U     1 /* 1 ch */
+#define PSDR_SLOT_ALPHA_V     2 /* 1 ch */
+#define PSDR_SLOT_ETA         3 /* 3 ch */
+#define PSDR_SLOT_K           4 /* 3 ch */
+
+/* cam[] layout (PerspectiveCamera, src/sensor/perspective.cpp:11-33), row-major 4x4 */
+#define PSDR_CAM_SAMPLE_TO_CAMERA  0
+#define PSDR_CAM_TO_WORLD         16
+#define PSDR_CAM_WORLD_TO_SAMPLE  32
+#define PSDR_CAM_POS              48
+#define PSDR_CAM_DIR              51
+#define PSDR_CAM_INV_AREA         54
+
+/* integrators (src/psdr.cpp:282-294; PathTracer is build-defined) */
+#define PSDR_INTEGRATOR_DIRECT 0
+#define PSDR_INTEGRATOR_PATH   1
+#define PSDR_INTEGRATOR_FIELD  2
+/* FieldExtractionIntegrator fields (src/integrator/field.cpp:10-54) */
+#define PSDR_FIELD_SILHOUETTE 0
+#define PSDR_FIELD_POSITION   1
+#define PSDR_FIELD_DEPTH      2
+#define PSDR_FIELD_GEONORMAL  3
+#define PSDR_FIELD_SHNORMAL   4
+#define PSDR_FIELD_UV         5
+
+/* Scene tables = everything Scene::configure() leaves on the device
+   (reference src/scene/scene.cpp:56-278). */
+typedef struct psdr_scene_desc {
+    int32_t width, height;               /* RenderOption, types.h:171-182 */
+    int32_t num_tris, num_meshes, num_bsdfs, num_emitters;
+    int32_t num_sec_edges, num_prim_edges, num_texels, num_guide_cells;
+
+    const float   *tri_info;             /* [T][PSDR_TRI_STRIDE]   scene.cpp:205-216 */
+    const float   *tri_uv;               /* [T][PSDR_TRIUV_STRIDE] or NULL (all zero) */
+    const int32_t *tri_mesh;             /* [T] */
+    const int32_t *mesh_bsdf;            /* [M] bsdf id (Mesh::m_bsdf) */
+    const int32_t *mesh_emitter;         /* [M] emitter id or -1 (Mesh::m_emitter) */
+    const int32_t *bsdf_rec;             /* [Nb][PSDR_BSDF_STRIDE] */
+    const float   *texels;               /* pool of Bitmap data; 3-ch textures interleaved RGB */
+    const float   *emitter_f;            /* [Ne][PSDR_EMITTER_F_STRIDE] */
+    const int32_t *emitter_i;            /* [Ne][PSDR_EMITTER_I_STRIDE] */
+    const float   *face_cmf, *face_pmf;  /* per-emitter-mesh face distributions, mesh.cpp:248-249 */
+    const float   *emitter_cmf, *emitter_pmf; /* [Ne] Scene::m_emitters_distrb, scene.cpp:183-196 */
+    float          emitter_sum;
+    const float   *cam;                  /* [PSDR_CAM_WORDS] */
+    const float   *sec_edge;             /* [E][PSDR_SEDGE_STRIDE] scene.cpp:219-244 */
+    const float   *sec_cmf, *sec_pmf;    /* [E] pmf = |e1| */
+    float          sec_sum;
+    const float   *prim_edge;            /* [Ep][PSDR_PEDGE_STRIDE] perspective.cpp:39-111 */
+    const float   *prim_cmf, *prim_pmf;  /* [Ep] pmf = screen length */
+    float          prim_sum;
+    int32_t        guide_reso[3];        /* HyperCubeDistribution3f, src/core/cube_distrb.cpp */
+    const float   *guide_cmf, *guide_pmf;/* [num_guide_cells] or NULL (no guiding) */
+    float          guide_sum;
+} psdr_scene_desc;
+
+/* One render call = Integrator::renderC / renderD on one shard of the sample
+   slots (src/integrator/integrator.cpp:13-119, src/integrator/direct.cpp). */
+typedef struct psdr_render_opts {
+    int32_t integrator;                  /* PSDR_INTEGRATOR_* */
+    int32_t bsdf_samples, light_samples; /* DirectIntegrator ctor, direct.cpp:32-34 */
+    int32_t max_depth;                   /* PathTracer */
+    int32_t hide_emitters;               /* DirectIntegrator::m_hide_emitters */
+    int32_t field;                       /* PSDR_FIELD_* */
+    int32_t spp, sppe, sppse;            /* GLOBAL counts: normalisation + RNG stream index */
+    int32_t spp_begin, spp_end;          /* this call evaluates s in [begin,end) of every pixel */
+    int32_t sppe_begin, sppe_end;        /* slots [W*H*begin, W*H*end) of sampler 1 */
+    int32_t sppse_begin, sppse_end;      /* slots [W*H*begin, W*H*end) of sampler 2 */
+    int32_t reserved;
+    uint64_t rng_offset[3];              /* draws already consumed per stream of sampler 0/1/2:
+                                            the reference keeps the PCG32 states alive across
+                                            render calls (scene.cpp:65-79) */
+} psdr_render_opts;
+
+/* Forward-mode tangent tables (d table / d P); any pointer may be NULL (= 0). */
+typedef struct psdr_tangents {
+    const float *d_tri_info;             /* [T][PSDR_TRI_STRIDE] */
+    const float *d_texels;               /* [num_texels] */
+    const float *d_emitter_rad;          /* [Ne][3] */
+    const float *d_cam_to_world;         /* [16] row-major */
+    const float *d_sec_edge;             /* [E][PSDR_SEDGE_STRIDE] (p0, e1 used... all 15) */
+    const float *d_prim_edge;            /* [Ep][PSDR_PEDGE_STRIDE] (p0, p1 used) */
+} psdr_tangents;
+
+/* Reverse-mode gradient tables (accumulated with +=); NULL = not wanted. */
+typedef struct psdr_grads {
+    float *g_tri_info;
+    float *g_texels;
+    float *g_emitter_rad;
+    float *g_cam_to_world;
+    float *g_sec_edge;
+    float *g_prim_edge;
+} psdr_grads;
+
+typedef struct psdr_scene_s *psdr_scene_t;
+
+/* error text of the last failing call on this thread */
+const char *psdr_last_error(void);
+/* "psdr-hip <version> gfx950" */
+const char *psdr_version(void);
+
+/* Scene handle; replaces Scene() / ~Scene() (src/scene/scene.cpp:19-41). */
+int psdr_scene_create(psdr_scene_t *out);
+int psdr_scene_destroy(psdr_scene_t h);
+
+/* Replaces the table-publishing tail of Scene::configure (scene.cpp:199-244):
+   remembers the caller-owned device tables. */
+int psdr_scene_set_tables(psdr_scene_t h, const psdr_scene_desc *desc);
+
+/* Replaces Scene_OptiX::configure + the OptiX GAS build
+   (src/scene/scene_optix.cpp:34-72, include/psdr/scene/optix.h:277-340):
+   builds the BVH over tri_info (p0,e1,e2) of the current tables. */
+int psdr_bvh_build(psdr_scene_t h, void *stream);
+
+/* Replaces Scene_OptiX::ray_intersect + the OptiX programs
+   (scene_optix.cpp:81-126, cuda/psdr_cuda.cu:9-45): closest hit with
+   t in [1e-3, tmax] for m rays given as 7 SoA streams; writes mesh id,
+   GLOBAL triangle id (-1 on miss) and the barycentrics of vertex 1 and 2. */
+int psdr_trace(psdr_scene_t h, int32_t m,
+               const float *ox, const float *oy, const float *oz,
+               const float *dx, const float *dy, const float *dz,
+               const float *tmax,
+               int32_t *out_shape, int32_t *out_tri, float *out_u, float *out_v,
+               void *stream);
+
+/* Replaces Integrator::renderC (integrator.cpp:13-29): out_img [H*W*3],
+   overwritten with (1/spp) * sum over this shard's slots. */
+int psdr_render_c(psdr_scene_t h, const psdr_render_opts *opts,
+                  float *out_img, void *stream);
+
+/* Replaces Integrator::renderD followed by enoki forward(P)
+   (integrator.cpp:32-60, examples/run_test.py:126-129): interior +
+   primary-edge + secondary-edge terms; out_dimg [K][H*W*3]. */
+int psdr_render_d_fwd(psdr_scene_t h, const psdr_render_opts *opts,
+                      int32_t K, const psdr_tangents *tangents,
+                      float *out_img, float *out_dimg, void *stream);
+
+/* Replaces Integrator::renderD followed by enoki backward(loss)
+   (docs/inverse_diff_render.rst): adj_img [H*W*3] = dLoss/dImage; gradients
+   are scatter-added into `grads`. out_img may be NULL. */
+int psdr_render_d_rev(psdr_scene_t h, const psdr_render_opts *opts,
+                      const float *adj_img, float *out_img,
+                      const psdr_grads *grads, void *stream);
+
+/* Replaces DirectIntegrator::preprocess_secondary_edges (direct.cpp:166-204):
+   out_mass [reso0*reso1*reso2] = mean over nrounds of per-cell max-RGB. */
+int psdr_guide_build(psdr_scene_t h, const psdr_render_opts *opts,
+                     const int32_t reso[4], int32_t nrounds,
+                     float *out_mass, void *stream);
+
+/* Counters of the last render call on this handle (host values):
+   [0] rays traced, [1] camera slots, [2] primary-edge slots, [3] secondary-edge slots. */
+int psdr_get_counters(psdr_scene_t h, uint64_t out[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PSDR_HIP_H */

@@ -1,0 +1,695 @@
+// psdr_device.h -- scene views, BVH traversal, hit reconstruction, BSDFs, emitter sampling, camera
+// and the per-sample estimators (Li, primary/secondary edge samples) of the gfx950 renderer.
+//
+// Mirrors, function by function, the reference hot path; each routine cites
+// the reference file:line it implements.  Scalar type R is float (renderC) or Dual<K> (renderD,
+// forward mode).
+#pragma once
+#include "psdr_math.h"
+#include "../../include/psdr_hip.h"
+
+namespace psdr {
+
+// ------------------------------------------------------------------------------ BVH
+// BVH2, 64-byte nodes holding BOTH children's boxes so one 64 B fetch decides the descent.
+// child >= 0: inner node index.  child < 0: leaf, ~child = (first << 3) | (count - 1) into the
+// reordered triangle array `btris` (3 x float4 per triangle: p0|tri_id, e1, e2).
+struct __attribute__((aligned(16))) BvhNode {
+    float lo0[3], hi0[3];
+    float lo1[3], hi1[3];
+    int32_t c0, c1;
+    int32_t pad[2];
+};
+static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
+
+constexpr int kBvhStack = 40;     // builder guarantees depth <= kBvhStack - 2
+constexpr int kBlock = 256;
+
+struct SceneView {
+    psdr_scene_desc d;
+    const BvhNode *nodes;
+    const float4 *btris;
+    int32_t root;          // encoded like a child (negative = single leaf)
+};
+
+// K sets of forward-mode tangent tables (struct of K pointer groups)
+template <int K> struct TangentView { psdr_tangents t[K > 0 ? K : 1]; };
+
+struct Hit { int tri; float u, v, t; };
+
+// Traversal stack: LDS on the device (one column per lane: conflict-free, no scratch traffic),
+// a plain array on the host (tests).
+struct TraversalStack {
+#if defined(__HIP_DEVICE_COMPILE__)
+    int32_t *base;   // &lds[threadIdx.x], stride kBlock
+    __device__ __forceinline__ void put(int i, int32_t v) { base[i * kBlock] = v; }
+    __device__ __forceinline__ int32_t get(int i) const { return base[i * kBlock]; }
+#else
+    int32_t a[kBvhStack];
+    void put(int i, int32_t v) { a[i] = v; }
+    int32_t get(int i) const { return a[i]; }
+#endif
+};
+
+PSDR_HD int __float_as_int_hd(float f) { union { float f; int i; } c; c.f = f; return c.i; }
+
+PSDR_HD float slab(const float *lo, const float *hi, const Vec3f &o, const Vec3f &inv, float tmax) {
+    // returns entry distance or +inf if the box is missed.  NaNs (0*inf) drop out of fmin/fmax.
+    const float ax = (lo[0] - o.x) * inv.x, bx = (hi[0] - o.x) * inv.x;
+    const float ay = (lo[1] - o.y) * inv.y, by = (hi[1] - o.y) * inv.y;
+    const float az = (lo[2] - o.z) * inv.z, bz = (hi[2] - o.z) * inv.z;
+    const float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.f));
+    const float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax));
+    return t0 <= t1 ? t0 : INFINITY;
+}
+
+// Replaces __raygen__/__closesthit__/__miss__ (cuda/psdr_cuda.cu:9-45): closest hit with
+// t in [RayEpsilon, tmax], both faces; (u,v) = barycentric weights of vertex 1 and 2.
+PSDR_HD Hit closest_hit(const SceneView &sc, TraversalStack &st, const Vec3f &o, const Vec3f &d, float tmax) {
+    Hit best; best.tri = -1; best.u = best.v = -1.f; best.t = tmax;
+    const Vec3f inv{1.f / d.x, 1.f / d.y, 1.f / d.z};
+    int sp = 0;
+    int32_t cur = sc.root;
+    for (;;) {
+        if (cur < 0) {
+            const int enc = ~cur, first = enc >> 3, cnt = (enc & 7) + 1;
+            for (int i = 0; i < cnt; ++i) {
+                const float4 a = sc.btris[(first + i) * 3 + 0], b = sc.btris[(first + i) * 3 + 1], c = sc.btris[(first + i) * 3 + 2];
+                // Moeller-Trumbore (the OptiX built-in triangle test is closed source)
+                const Vec3f e1{b.x, b.y, b.z}, e2{c.x, c.y, c.z};
+                const Vec3f h = cross(d, e2);
+                const float det = dot(e1, h);
+                const float f = 1.f / det;
+                const Vec3f s{o.x - a.x, o.y - a.y, o.z - a.z};
+                const float u = f * dot(s, h);
+                const Vec3f q = cross(s, e1);
+                const float v = f * dot(d, q);
+                const float t = f * dot(e2, q);
+                if (det != 0.f && u >= 0.f && u <= 1.f && v >= 0.f && u + v <= 1.f && t >= kRayEpsilon && t <= best.t &&
+                    (t < best.t || best.tri < 0)) {
+                    best.t = t; best.u = u; best.v = v; best.tri = __float_as_int_hd(a.w);
+                }
+            }
+            if (sp == 0) break;
+            cur = st.get(--sp);
+            continue;
+        }
+        const BvhNode &n = sc.nodes[cur];
+        const float t0 = slab(n.lo0, n.hi0, o, inv, best.t), t1 = slab(n.lo1, n.hi1, o, inv, best.t);
+        const bool h0 = t0 < INFINITY, h1 = t1 < INFINITY;
+        if (h0 && h1) {
+            const bool first0 = t0 <= t1;
+            st.put(sp++, first0 ? n.c1 : n.c0);
+            cur = first0 ? n.c0 : n.c1;
+        } else if (h0 || h1) {
+            cur = h0 ? n.c0 : n.c1;
+        } else {
+            if (sp == 0) break;
+            cur = st.get(--sp);
+        }
+    }
+    return best;
+}
+
+// ------------------------------------------------------------------------ table loads
+template <class R> struct Loader;
+template <> struct Loader<float> {
+    template <int KK> static PSDR_HD float f(const float *tab, const TangentView<KK> &, const float *const psdr_tangents::*, size_t i) { return tab[i]; }
+};
+template <int K> struct Loader<Dual<K>> {
+    static PSDR_HD Dual<K> f(const float *tab, const TangentView<K> &tv, const float *const psdr_tangents::*m, size_t i) {
+        Dual<K> r; r.v = tab[i];
+#pragma unroll
+        for (int k = 0; k < K; ++k) { const float *p = tv.t[k].*m; r.d[k] = p ? p[i] : 0.f; }
+        return r;
+    }
+};
+template <class R> using TV = TangentView<ad_traits<R>::K>;
+template <class R> PSDR_HD R ldf(const float *tab, const TV<R> &tv, const float *const psdr_tangents::*m, size_t i) {
+    return Loader<R>::f(tab, tv, m, i);
+}
+template <class R> PSDR_HD Vec3<R> ld3(const float *tab, const TV<R> &tv, const float *const psdr_tangents::*m, size_t i) {
+    return {ldf<R>(tab, tv, m, i), ldf<R>(tab, tv, m, i + 1), ldf<R>(tab, tv, m, i + 2)};
+}
+
+// TriangleInfo_ row (include/psdr/types.h:135-146), gathered by global triangle id (scene.cpp:300)
+template <class R> struct TriRow { Vec3<R> p0, e1, e2, n0, n1, n2, fn; R area; };
+template <class R> PSDR_HD TriRow<R> load_tri(const SceneView &sc, const TV<R> &tv, int id) {
+    const size_t o = (size_t) id * PSDR_TRI_STRIDE;
+    const float *a = sc.d.tri_info;
+    constexpr auto m = &psdr_tangents::d_tri_info;
+    TriRow<R> t;
+    t.p0 = ld3<R>(a, tv, m, o); t.e1 = ld3<R>(a, tv, m, o + 3); t.e2 = ld3<R>(a, tv, m, o + 6);
+    t.n0 = ld3<R>(a, tv, m, o + 9); t.n1 = ld3<R>(a, tv, m, o + 12); t.n2 = ld3<R>(a, tv, m, o + 15);
+    t.fn = ld3<R>(a, tv, m, o + 18); t.area = ldf<R>(a, tv, m, o + 21);
+    return t;
+}
+
+// ---------------------------------------------------------------------- intersection
+// Intersection_ (include/psdr/core/intersection.h:24-52)
+template <class R> struct Its {
+    bool valid;
+    int tri, mesh;
+    Vec3<R> wi, p, n;
+    R t, J, uvx, uvy;
+    Frame<R> sh;
+};
+template <class R> struct RayT { Vec3<R> o, d; };
+
+// ray_intersect_triangle (include/psdr/utils.h:66-77), no range tests
+template <class R> PSDR_HD void moeller_trumbore(const Vec3<R> &p0, const Vec3<R> &e1, const Vec3<R> &e2, const RayT<R> &ray,
+                                                 R &u, R &v, R &t) {
+    const Vec3<R> h = cross(ray.d, e2);
+    const R f = 1.f / dot(e1, h);
+    const Vec3<R> s = ray.o - p0;
+    u = f * dot(s, h);
+    const Vec3<R> q = cross(s, e1);
+    v = f * dot(ray.d, q);
+    t = f * dot(e2, q);
+}
+
+enum HitForm { kDetached = 0, kPathSpace = 1, kSolidAngle = 2 };
+
+// Scene::ray_intersect<ad, path_space> (src/scene/scene.cpp:290-384)
+//   kDetached  : C types; barycentrics from the traversal, J = 1
+//   kPathSpace : D types, barycentrics DETACHED (point rides on the moving triangle), J = A/detach(A)
+//   kSolidAngle: D types, differentiable Moeller-Trumbore on the chosen triangle, J = 1
+template <class R> PSDR_HD Its<R> intersect(const SceneView &sc, const TV<R> &tv, TraversalStack &st, const RayT<R> &ray,
+                                            bool active, HitForm form, uint32_t &nrays) {
+    Its<R> its;
+    its.valid = false; its.tri = its.mesh = -1; its.J = R(1.f); its.t = R(INFINITY);
+    if (!active) return its;
+    nrays++;
+    const Hit h = closest_hit(sc, st, val(ray.o), val(ray.d), INFINITY);
+    if (h.tri < 0) return its;
+    its.valid = true; its.tri = h.tri;
+    const int tm = sc.d.tri_mesh[h.tri];
+    its.mesh = tm & ~PSDR_TRI_FACE_NORMALS;
+    const TriRow<R> T = load_tri<R>(sc, tv, h.tri);
+    its.n = T.fn;
+    R bu, bv;
+    if (form != kSolidAngle) {
+        bu = R(h.u); bv = R(h.v);
+        if (is_ad<R>() && form == kPathSpace) its.J = T.area / detach(T.area);
+        its.p = bary_point(T.p0, T.e1, T.e2, bu, bv);
+        Vec3<R> dir = its.p - ray.o;
+        its.t = norm(dir);
+        dir = dir / its.t;
+        Vec3<R> sh_n = (tm & PSDR_TRI_FACE_NORMALS) ? its.n : normalize(bary_point(T.n0, T.n1 - T.n0, T.n2 - T.n0, bu, bv));
+        its.sh = Frame<R>(sh_n);
+        its.wi = its.sh.to_local(-dir);
+    } else {
+        R t;
+        moeller_trumbore(T.p0, T.e1, T.e2, ray, bu, bv, t);
+        Vec3<R> sh_n = (tm & PSDR_TRI_FACE_NORMALS) ? its.n : normalize(bary_point(T.n0, T.n1 - T.n0, T.n2 - T.n0, bu, bv));
+        its.p = ray.o + ray.d * t;
+        its.t = t;
+        its.sh = Frame<R>(sh_n);
+        its.wi = its.sh.to_local(-ray.d);
+    }
+    if (sc.d.tri_uv) {
+        const float *q = sc.d.tri_uv + (size_t) h.tri * PSDR_TRIUV_STRIDE;
+        its.uvx = (q[2] - q[0]) * bu + ((q[4] - q[0]) * bv + q[0]);
+        its.uvy = (q[3] - q[1]) * bu + ((q[5] - q[1]) * bv + q[1]);
+    } else { its.uvx = R(0.f); its.uvy = R(0.f); }
+    return its;
+}
+
+template <class R> PSDR_HD int emitter_of(const SceneView &sc, const Its<R> &its) { return its.valid ? sc.d.mesh_emitter[its.mesh] : -1; }
+
+template <class R> PSDR_HD Vec3<R> radiance(const SceneView &sc, const TV<R> &tv, int e) {
+    const float *f = sc.d.emitter_f + (size_t) e * PSDR_EMITTER_F_STRIDE;
+    Vec3<R> r = {R(f[0]), R(f[1]), R(f[2])};
+    if constexpr (is_ad<R>()) {
+#pragma unroll
+        for (int k = 0; k < ad_traits<R>::K; ++k) {
+            const float *p = tv.t[k].d_emitter_rad;
+            if (p) { r.x.d[k] = p[e * 3]; r.y.d[k] = p[e * 3 + 1]; r.z.d[k] = p[e * 3 + 2]; }
+        }
+    }
+    return r;
+}
+// Intersection::Le -> AreaLight::eval (src/emitter/area.cpp:20-29)
+template <class R> PSDR_HD Vec3<R> Le(const SceneView &sc, const TV<R> &tv, const Its<R> &its, bool active) {
+    const int e = active ? emitter_of(sc, its) : -1;
+    if (e < 0 || !(val(its.wi.z) > 0.f)) return zero3<R>();
+    return radiance<R>(sc, tv, e);
+}
+
+// ------------------------------------------------------------------------------ BSDF
+// Bitmap<c>::eval (src/core/bitmap.cpp:41-89); 3-channel textures are stored interleaved RGB
+template <class R, int C> PSDR_HD void bitmap_eval(const SceneView &sc, const TV<R> &tv, const int32_t *slot, R u, R v, R *out) {
+    const int off = slot[0], w = slot[1], h = slot[2];
+    const float *tx = sc.d.texels;
+    constexpr auto m = &psdr_tangents::d_texels;
+    if (w == 1 && h == 1) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) out[c] = ldf<R>(tx, tv, m, off + c);
+        return;
+    }
+    v = -v;
+    u = u - floorf(val(u)); v = v - floorf(val(v));
+    u = u * (float) (w - 1); v = v * (float) (h - 1);
+    int px = (int) floorf(val(u)), py = (int) floorf(val(v));
+    const R w1x = u - (float) px, w1y = v - (float) py;
+    const R w0x = 1.f - w1x, w0y = 1.f - w1y;
+    px = px < w - 2 ? px : w - 2; py = py < h - 2 ? py : h - 2;
+    const size_t idx = (size_t) py * w + px;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const R v00 = ldf<R>(tx, tv, m, off + idx * C + c), v10 = ldf<R>(tx, tv, m, off + (idx + 1) * C + c);
+        const R v01 = ldf<R>(tx, tv, m, off + (idx + w) * C + c), v11 = ldf<R>(tx, tv, m, off + (idx + w + 1) * C + c);
+        out[c] = w0y * (w0x * v00 + w1x * v10) + w1y * (w0x * v01 + w1x * v11);
+    }
+}
+
+// GGXDistribution (src/bsdf/ggx.cpp:9-106)
+template <class R> struct GGX {
+    R au, av;
+    PSDR_HD R eval(const Vec3<R> &m) const {
+        const R r = 1.f / (kPi * au * av * sqr(sqr(m.x / au) + sqr(m.y / av) + sqr(m.z)));
+        return val(r) * val(m.z) > 1e-5f ? r : R(0.f);
+    }
+    PSDR_HD R smith_g1(const Vec3<R> &v, const Vec3<R> &m) const {
+        const R xy = sqr(au * v.x) + sqr(av * v.y);
+        R r = 2.f / (1.f + sqrt_(1.f + xy / sqr(v.z)));
+        if (val(xy) == 0.f) r = R(1.f);
+        if (val(dot(v, m)) * val(v.z) <= 0.f) r = R(0.f);
+        return r;
+    }
+    // sample_visible_11, ggx.cpp:96-106
+    PSDR_HD void visible11(const R &cos_i, float sx, float sy, R &ox, R &oy) const {
+        float px, py;
+        concentric_disk(sx, sy, px, py);
+        const R s = 0.5f * (1.f + cos_i);
+        const R y = sqrtf(fmaxf(1.f - px * px, 0.f)) * (1.f - s) + py * s;
+        const R z = safe_sqrt(1.f - (px * px + y * y));
+        const R sin_i = safe_sqrt(1.f - sqr(cos_i));
+        const R nrm = 1.f / (sin_i * y + cos_i * z);
+        ox = (cos_i * y - sin_i * z) * nrm; oy = px * nrm;
+    }
+    // ggx.cpp:34-76 with Frame::sin_phi / cos_phi (frame.h:100-116)
+    PSDR_HD Vec3<R> sample(const Vec3<R> &wi, float sx, float sy) const {
+        const Vec3<R> wp = normalize(Vec3<R>(au * wi.x, av * wi.y, wi.z));
+        const R st2 = wp.x * wp.x + wp.y * wp.y;
+        R sin_phi(0.f), cos_phi(1.f);
+        if (!(fabsf(val(st2)) <= 4.f * kEpsilon)) {
+            const R inv = 1.f / sqrt_(st2);
+            sin_phi = clamp_(wp.y * inv, -1.f, 1.f); cos_phi = clamp_(wp.x * inv, -1.f, 1.f);
+        }
+        R slx, sly;
+        visible11(wp.z, sx, sy, slx, sly);
+        const R s0 = (cos_phi * slx - sin_phi * sly) * au, s1 = (sin_phi * slx + cos_phi * sly) * av;
+        return normalize(Vec3<R>(-s0, -s1, R(1.f)));
+    }
+};
+
+// conductor Fresnel (include/psdr/utils.h:148-164), one channel
+template <class R> PSDR_HD R fresnel_conductor(const R &eta, const R &k, const R &cos_i) {
+    const R c2 = sqr(cos_i), s2 = 1.f - c2, s4 = sqr(s2);
+    const R t1 = sqr(eta) - sqr(k) - s2;
+    const R a2pb2 = safe_sqrt(sqr(t1) + 4.f * sqr(k * eta));
+    const R a = safe_sqrt(0.5f * (a2pb2 + t1));
+    const R T1 = a2pb2 + c2, T2 = 2.f * cos_i * a;
+    const R rs = (T1 - T2) / (T1 + T2);
+    const R T3 = a2pb2 * c2 + s4, T4 = T2 * s2;
+    return 0.5f * (rs + rs * (T3 - T4) / (T3 + T4));
+}
+
+template <class R> struct Bsdf {
+    const int32_t *rec;
+    PSDR_HD Bsdf(const SceneView &sc, int id) : rec(sc.d.bsdf_rec + (size_t) (id < 0 ? 0 : id) * PSDR_BSDF_STRIDE) {}
+    PSDR_HD int type() const { return rec[0]; }
+    PSDR_HD const int32_t *slot(int s) const { return rec + 1 + 3 * s; }
+    PSDR_HD Vec3<R> tex3(const SceneView &sc, const TV<R> &tv, int s, const Its<R> &its) const {
+        R o[3]; bitmap_eval<R, 3>(sc, tv, slot(s), its.uvx, its.uvy, o); return {o[0], o[1], o[2]};
+    }
+    PSDR_HD R tex1(const SceneView &sc, const TV<R> &tv, int s, const Its<R> &its) const {
+        R o[1]; bitmap_eval<R, 1>(sc, tv, slot(s), its.uvx, its.uvy, o); return o[0];
+    }
+    // Diffuse::__eval (diffuse.cpp:25-35) / RoughConductor::__eval (roughconductor.cpp:40-58); value = f * cos(theta_o)
+    PSDR_HD Vec3<R> eval(const SceneView &sc, const TV<R> &tv, const Its<R> &its, const Vec3<R> &wo, bool active) const {
+        if (!(active && val(its.wi.z) > 0.f && val(wo.z) > 0.f)) return zero3<R>();
+        if (type() == PSDR_BSDF_DIFFUSE) return tex3(sc, tv, PSDR_SLOT_REFLECTANCE, its) * (wo.z * kInvPi);
+        const GGX<R> g{tex1(sc, tv, PSDR_SLOT_ALPHA_U, its), tex1(sc, tv, PSDR_SLOT_ALPHA_V, its)};
+        const Vec3<R> H = normalize(wo + its.wi);
+        const R D = g.eval(H);
+        if (val(D) == 0.f) return zero3<R>();
+        const R res = D * (g.smith_g1(its.wi, H) * g.smith_g1(wo, H)) / (4.f * its.wi.z);
+        const Vec3<R> eta = tex3(sc, tv, PSDR_SLOT_ETA, its), k = tex3(sc, tv, PSDR_SLOT_K, its);
+        const R c = dot(its.wi, H);
+        const Vec3<R> F{fresnel_conductor(eta.x, k.x, c), fresnel_conductor(eta.y, k.y, c), fresnel_conductor(eta.z, k.z, c)};
+        return F * res * tex3(sc, tv, PSDR_SLOT_REFLECTANCE, its);
+    }
+    // Diffuse::__pdf (diffuse.cpp:70-81: detached) / RoughConductor::__pdf (roughconductor.cpp:61-75: mask not applied)
+    PSDR_HD R pdf(const SceneView &sc, const TV<R> &tv, const Its<R> &its, const Vec3<R> &wo, bool active) const {
+        if (type() == PSDR_BSDF_DIFFUSE) {
+            const float ci = val(its.wi.z), co = val(wo.z);
+            return R((active && ci > 0.f && co > 0.f) ? kInvPi * co : 0.f);
+        }
+        const Vec3<R> m = normalize(wo + its.wi);
+        const GGX<R> g{tex1(sc, tv, PSDR_SLOT_ALPHA_U, its), tex1(sc, tv, PSDR_SLOT_ALPHA_V, its)};
+        return g.eval(m) * g.smith_g1(its.wi, m) / (4.f * its.wi.z);
+    }
+    // Diffuse::__sample (diffuse.cpp:48-57, uses tail<2>) / RoughConductor::__sample (roughconductor.cpp:78-92)
+    PSDR_HD bool sample(const SceneView &sc, const TV<R> &tv, const Its<R> &its, const float s[3], bool active, Vec3<R> &wo, R &pdf_) const {
+        if (type() == PSDR_BSDF_DIFFUSE) {
+            const Vec3f w = cosine_hemisphere(s[1], s[2]);
+            wo = lift<R>(w); pdf_ = R(kInvPi * w.z);
+            return active && val(its.wi.z) > 0.f;
+        }
+        const GGX<R> g{tex1(sc, tv, PSDR_SLOT_ALPHA_U, its), tex1(sc, tv, PSDR_SLOT_ALPHA_V, its)};
+        const Vec3<R> m = g.sample(its.wi, s[0], s[1]);
+        wo = m * (2.f * dot(its.wi, m)) - its.wi;
+        pdf_ = pdf(sc, tv, its, wo, active);
+        return active && val(its.wi.z) > 0.f && val(pdf_) != 0.f && val(wo.z) > 0.f;
+    }
+};
+
+// -------------------------------------------------------------------------- emitters
+template <class R> struct PosSample { Vec3<R> p, n; R J; float pdf; bool valid; };
+
+// Scene::sample_emitter_position (scene.cpp:427-447) -> AreaLight::sample_position (area.cpp:32-46)
+// -> Mesh::__sample_position (mesh.cpp:306-330)
+template <class R> PSDR_HD PosSample<R> sample_emitter_position(const SceneView &sc, const TV<R> &tv, float s0, float s1, bool with_J) {
+    PosSample<R> ps;
+    int e = 0; float epdf = 1.f;
+    if (sc.d.num_emitters > 1) e = sample_reuse(sc.d.emitter_cmf, sc.d.emitter_pmf, sc.d.emitter_sum, sc.d.num_emitters, s1, epdf);
+    const float *ef = sc.d.emitter_f + (size_t) e * PSDR_EMITTER_F_STRIDE;
+    const int32_t *ei = sc.d.emitter_i + (size_t) e * PSDR_EMITTER_I_STRIDE;
+    float fp;
+    const int f = sample_reuse(sc.d.face_cmf + ei[3], sc.d.face_pmf + ei[3], ef[5], ei[2], s0, fp);
+    const float t = sqrtf(fmaxf(1.f - s0, 0.f));           // warp::square_to_uniform_triangle, warp.h:76-80
+    const TriRow<R> T = load_tri<R>(sc, tv, ei[1] + f);
+    ps.J = R(1.f);
+    if (is_ad<R>() && with_J) ps.J = T.area / detach(T.area);
+    ps.p = bary_point(T.p0, T.e1, T.e2, R(1.f - t), R(t * s1));
+    ps.n = T.fn;
+    ps.pdf = ef[4] * epdf;
+    ps.valid = true;
+    return ps;
+}
+// Scene::emitter_position_pdf (scene.cpp:451-453) -> area.cpp:60-62 -> mesh.cpp:333-342
+template <class R> PSDR_HD float emitter_position_pdf(const SceneView &sc, const Its<R> &its) {
+    const int e = emitter_of(sc, its);
+    if (e < 0) return 0.f;
+    const float *ef = sc.d.emitter_f + (size_t) e * PSDR_EMITTER_F_STRIDE;
+    return ef[3] * ef[4];
+}
+
+// ---------------------------------------------------------------------------- camera
+// PerspectiveCamera::sample_primary_ray (src/sensor/perspective.cpp:120-136)
+template <class R> PSDR_HD RayT<R> primary_ray(const SceneView &sc, const TV<R> &tv, float sx, float sy) {
+    const float *m = sc.d.cam + PSDR_CAM_SAMPLE_TO_CAMERA;
+    float v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = m[r * 4] * sx + m[r * 4 + 1] * sy + m[r * 4 + 3];
+    const float iw = 1.f / v[3];
+    const Vec3f d = normalize(Vec3f{v[0] * iw, v[1] * iw, v[2] * iw});
+    const float *c = sc.d.cam + PSDR_CAM_TO_WORLD;
+    constexpr auto tm = &psdr_tangents::d_cam_to_world;
+    auto tw = [&](int r, int col) { return ldf<R>(c, tv, tm, r * 4 + col); };
+    RayT<R> ray;
+    const R w = tw(3, 3);
+    ray.o = Vec3<R>(tw(0, 3) / w, tw(1, 3) / w, tw(2, 3) / w);
+    ray.d = Vec3<R>(tw(0, 0) * d.x + tw(0, 1) * d.y + tw(0, 2) * d.z, tw(1, 0) * d.x + tw(1, 1) * d.y + tw(1, 2) * d.z,
+                    tw(2, 0) * d.x + tw(2, 1) * d.y + tw(2, 2) * d.z);
+    return ray;
+}
+// PerspectiveCamera::sample_direct (perspective.cpp:139-155), all detached
+PSDR_HD bool sample_direct(const SceneView &sc, const Vec3f &p, int &pixel, float &qx, float &qy, float &sensor_val) {
+    const float *m = sc.d.cam + PSDR_CAM_WORLD_TO_SAMPLE;
+    float v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = m[r * 4] * p.x + m[r * 4 + 1] * p.y + m[r * 4 + 2] * p.z + m[r * 4 + 3];
+    qx = v[0] / v[3]; qy = v[1] / v[3];
+    const int W = sc.d.width, H = sc.d.height;
+    const int ix = (int) floorf(qx * (float) W), iy = (int) floorf(qy * (float) H);
+    const bool ok = ix >= 0 && ix < W && iy >= 0 && iy < H;
+    pixel = ok ? iy * W + ix : -1;
+    const float *c = sc.d.cam;
+    Vec3f dir{p.x - c[PSDR_CAM_POS], p.y - c[PSDR_CAM_POS + 1], p.z - c[PSDR_CAM_POS + 2]};
+    const float d2 = dot(dir, dir);
+    dir = dir / sqrtf(fmaxf(d2, 0.f));
+    const float ict = 1.f / (c[PSDR_CAM_DIR] * dir.x + c[PSDR_CAM_DIR + 1] * dir.y + c[PSDR_CAM_DIR + 2] * dir.z);
+    sensor_val = (1.f / d2) * (ict * ict * ict) * c[PSDR_CAM_INV_AREA];
+    return ok;
+}
+
+// ------------------------------------------------------------------------ integrators
+template <class R> PSDR_HD R mis_weight(const R &p1, const R &p2) { const R a = sqr(p1), b = sqr(p2); return a / (a + b); }  // direct.cpp:18-21
+
+struct LiParams {                 // uniform per launch
+    int integrator, bsdf_samples, light_samples, max_depth, hide_emitters, field;
+};
+
+// The loop bodies of DirectIntegrator::__Li (src/integrator/direct.cpp:64-160) evaluated at `its`.
+// next_* report the FIRST BSDF-sampled vertex so the build-defined PathTracer can
+// continue the path from it.
+template <class R>
+PSDR_HD Vec3<R> direct_step(const SceneView &sc, const TV<R> &tv, TraversalStack &st, Rng &rng, const Its<R> &its, bool active, int nB,
+                            int nL, uint32_t &nrays, Its<R> *next_its, Vec3<R> *next_f, bool *next_valid) {
+    constexpr bool ad = is_ad<R>();
+    Vec3<R> result = zero3<R>();
+    const Bsdf<R> bsdf(sc, active ? sc.d.mesh_bsdf[its.mesh] : 0);
+    for (int i = 0; i < nB; ++i) {
+        const float s[3] = {rng.next(), rng.next(), rng.next()};
+        if (!active) continue;
+        Vec3<R> wo_s; R pdf_s;
+        bool a1 = bsdf.sample(sc, tv, its, s, active, wo_s, pdf_s);
+        const RayT<R> ray1{its.p, its.sh.to_world(wo_s)};
+        const Its<R> its1 = intersect<R>(sc, tv, st, ray1, a1, ad ? kPathSpace : kDetached, nrays);
+        const bool a_hit = a1 && its1.valid;
+        a1 = a_hit && emitter_of(sc, its1) >= 0;
+        Vec3<R> bsdf_val = zero3<R>(); R pdf0(0.f);
+        if (a_hit) {
+            if constexpr (ad) {
+                const Vec3<R> wo = (its1.p - its.p) / its1.t;
+                bsdf_val = bsdf.eval(sc, tv, its, its.sh.to_local(wo), true);
+                const R G = abs_(dot(its1.n, -wo)) / sqr(its1.t);
+                pdf0 = pdf_s * detach(G);
+                bsdf_val = bsdf_val * (G * its1.J / pdf0);
+            } else {
+                bsdf_val = bsdf.eval(sc, tv, its, wo_s, true);
+                const R G = abs_(dot(its1.n, -ray1.d)) / sqr(its1.t);
+                pdf0 = pdf_s * G;
+                bsdf_val = bsdf_val / pdf_s;
+            }
+        }
+        if (a1) {
+            R w(1.f / (float) nB);
+            if (nL > 0) w = w * mis_weight(pdf0, R(emitter_position_pdf(sc, its1)));
+            result = result + Le(sc, tv, its1, true) * bsdf_val * w;
+        }
+        if (next_its && i == 0) { *next_its = its1; *next_f = bsdf_val; *next_valid = a_hit; }
+    }
+    for (int i = 0; i < nL; ++i) {
+        const float s0 = rng.next(), s1 = rng.next();
+        if (!active) continue;
+        const PosSample<R> ps = sample_emitter_position<R>(sc, tv, s0, s1, ad);
+        Vec3<R> wo = ps.p - its.p;
+        const R d2 = dot(wo, wo), dist = safe_sqrt(d2);
+        wo = wo / dist;
+        const RayT<R> ray1{its.p, wo};
+        const Its<R> its1 = intersect<R>(sc, tv, st, ray1, ps.valid, ad ? kPathSpace : kDetached, nrays);
+        if (!(its1.valid && val(its1.t) > val(dist) - kShadowEpsilon && emitter_of(sc, its1) >= 0)) continue;
+        const R G = abs_(dot(its1.n, -wo)) / d2;
+        const Vec3<R> wl = its.sh.to_local(wo);
+        Vec3<R> bsdf_val = bsdf.eval(sc, tv, its, wl, true) * (G * ps.J / ps.pdf);
+        const R pdf1 = bsdf.pdf(sc, tv, its, wl, true) * (ad ? detach(G) : G);
+        R w(1.f / (float) nL);
+        if (nB > 0) w = w * mis_weight(R(ps.pdf), pdf1);
+        result = result + Le(sc, tv, its1, true) * bsdf_val * w;
+    }
+    return result;
+}
+
+// DirectIntegrator::__Li (direct.cpp:47-163); FieldExtractionIntegrator::__Li (field.cpp:34-54);
+// PathTracer = iterated direct step (no reference implementation; depth 1 == DirectIntegrator(1,1)).
+template <class R>
+PSDR_HD Vec3<R> Li(const SceneView &sc, const TV<R> &tv, TraversalStack &st, const LiParams &lp, Rng &rng, const RayT<R> &ray, bool active,
+                   uint32_t &nrays) {
+    constexpr bool ad = is_ad<R>();
+    Its<R> its = intersect<R>(sc, tv, st, ray, active, ad ? kSolidAngle : kDetached, nrays);
+    active = active && its.valid;
+    if (lp.integrator == PSDR_INTEGRATOR_FIELD) {
+        if (!active) return zero3<R>();
+        switch (lp.field) {
+            case PSDR_FIELD_SILHOUETTE: return Vec3<R>(1.f);
+            case PSDR_FIELD_POSITION: return its.p;
+            case PSDR_FIELD_DEPTH: return Vec3<R>(its.t, its.t, its.t);
+            case PSDR_FIELD_GEONORMAL: return its.n;
+            case PSDR_FIELD_SHNORMAL: return its.sh.n;
+            default: return Vec3<R>(its.uvx, its.uvy, R(0.f));
+        }
+    }
+    Vec3<R> result = lp.hide_emitters ? zero3<R>() : Le(sc, tv, its, active);
+    if (lp.integrator == PSDR_INTEGRATOR_DIRECT)
+        return result + direct_step<R>(sc, tv, st, rng, its, active, lp.bsdf_samples, lp.light_samples, nrays, nullptr, nullptr, nullptr);
+    Vec3<R> beta(1.f);
+    for (int depth = 0; depth < lp.max_depth; ++depth) {
+        Its<R> nits; Vec3<R> nf; bool nvalid = false;
+        const Vec3<R> c = direct_step<R>(sc, tv, st, rng, its, active, 1, 1, nrays, &nits, &nf, &nvalid);
+        if (active) {
+            result = result + beta * c;
+            active = nvalid;
+            if (active) {
+                beta = beta * nf; its = nits;
+                const Vec3f b = val(beta);
+                if (!(b.x != 0.f || b.y != 0.f || b.z != 0.f)) active = false;
+            }
+        }
+    }
+    return result;
+}
+
+// masked(value, ~isfinite(value)) = 0 (integrator.cpp:87), per component; a non-finite tangent is
+// dropped with it (the reference's harness zeroes those afterwards, run_test.py:130).
+PSDR_HD float zero_nonfinite(float x) { return isfinite(x) ? x : 0.f; }
+template <int K> PSDR_HD Dual<K> zero_nonfinite(const Dual<K> &x) {
+    Dual<K> r; const bool fv = isfinite(x.v); r.v = fv ? x.v : 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) r.d[k] = (fv && isfinite(x.d[k])) ? x.d[k] : 0.f;
+    return r;
+}
+template <class R> PSDR_HD Vec3<R> zero_nonfinite(const Vec3<R> &v) { return {zero_nonfinite(v.x), zero_nonfinite(v.y), zero_nonfinite(v.z)}; }
+
+// One camera sample slot: Integrator::__render (src/integrator/integrator.cpp:64-95), before the splat
+template <class R>
+PSDR_HD Vec3<R> camera_sample(const SceneView &sc, const TV<R> &tv, TraversalStack &st, const LiParams &lp, const RngJump &jump,
+                              int pixel, uint64_t slot, uint32_t &nrays) {
+    Rng rng; rng.init(slot, jump);
+    const float j0 = rng.next(), j1 = rng.next();
+    const int W = sc.d.width;
+    const int px = pixel % W, py = pixel / W;
+    const float sx = ((float) px + j0) / (float) W, sy = ((float) py + j1) / (float) sc.d.height;
+    const RayT<R> ray = primary_ray<R>(sc, tv, sx, sy);
+    return zero_nonfinite(Li<R>(sc, tv, st, lp, rng, ray, true, nrays));
+}
+
+// One primary-edge slot: Integrator::render_primary_edges (integrator.cpp:98-119) +
+// PerspectiveCamera::sample_primary_edge (perspective.cpp:158-200).  Returns the pixel (or -1);
+// tan[k][c] = d value / d P_k (the primal part is exactly zero: value -= detach(value)).
+template <int K>
+PSDR_HD int primary_edge_sample(const SceneView &sc, const TangentView<K> &tv, TraversalStack &st, const LiParams &lp, const RngJump &jump,
+                                uint64_t slot, float inv_sppe, float tan[K][3], uint32_t &nrays) {
+    Rng rng; rng.init(slot, jump);
+    float u = rng.next(), pmf;
+    const int k = sample_reuse(sc.d.prim_cmf, sc.d.prim_pmf, sc.d.prim_sum, sc.d.num_prim_edges, u, pmf);
+    const float *pe = sc.d.prim_edge + (size_t) k * PSDR_PEDGE_STRIDE;
+    const float nx = pe[4], ny = pe[5];
+    const float pdf = pmf / pe[6];
+    const float px = pe[0] * (1.f - u) + pe[2] * u, py = pe[1] * (1.f - u) + pe[3] * u;
+    const int W = sc.d.width, H = sc.d.height;
+    const int ix = (int) floorf(px * (float) W), iy = (int) floorf(py * (float) H);
+    const bool valid = ix >= 0 && ix < W && iy >= 0 && iy < H;
+    const TangentView<0> tv0{};
+    const RayT<float> ray_p = primary_ray<float>(sc, tv0, px + kEdgeEpsilon * nx, py + kEdgeEpsilon * ny);
+    const RayT<float> ray_n = primary_ray<float>(sc, tv0, px - kEdgeEpsilon * nx, py - kEdgeEpsilon * ny);
+    const Vec3f Ln = Li<float>(sc, tv0, st, lp, rng, ray_n, valid, nrays);
+    const Vec3f Lp = Li<float>(sc, tv0, st, lp, rng, ray_p, valid, nrays);
+    if (!valid) return -1;
+    const Vec3f dL{(Ln.x - Lp.x) / pdf, (Ln.y - Lp.y) / pdf, (Ln.z - Lp.z) / pdf};
+    const float xdn = px * nx + py * ny;
+    const bool fin[3] = {isfinite(xdn * dL.x), isfinite(xdn * dL.y), isfinite(xdn * dL.z)};
+#pragma unroll
+    for (int t = 0; t < K; ++t) {
+        const float *dp = tv.t[t].d_prim_edge ? tv.t[t].d_prim_edge + (size_t) k * PSDR_PEDGE_STRIDE : nullptr;
+        const float dxdn = dp ? ((dp[0] * (1.f - u) + dp[2] * u) * nx + (dp[1] * (1.f - u) + dp[3] * u) * ny) : 0.f;
+        const float g[3] = {dxdn * dL.x, dxdn * dL.y, dxdn * dL.z};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) tan[t][c] = (fin[c] && isfinite(g[c])) ? g[c] * inv_sppe : 0.f;
+    }
+    return iy * W + ix;
+}
+
+// HyperCubeDistribution<3>::sample_reuse (src/core/cube_distrb.cpp:41-48)
+PSDR_HD float guide_sample_reuse(const SceneView &sc, float s[3]) {
+    float pmf;
+    const int n = sc.d.num_guide_cells;
+    const int idx = sample_reuse(sc.d.guide_cmf, sc.d.guide_pmf, sc.d.guide_sum, n, s[2], pmf);
+    const int r1 = sc.d.guide_reso[1], r2 = sc.d.guide_reso[2];
+    const int c0 = idx / (r1 * r2), rem = idx - c0 * r1 * r2, c1 = rem / r2, c2 = rem - c1 * r2;
+    s[0] = (s[0] + (float) c0) * (1.f / (float) sc.d.guide_reso[0]);
+    s[1] = (s[1] + (float) c1) * (1.f / (float) r1);
+    s[2] = (s[2] + (float) c2) * (1.f / (float) r2);
+    return pmf * (float) n;
+}
+
+// DirectIntegrator::eval_secondary_edge (direct.cpp:225-316) + Scene::sample_boundary_segment_direct
+// (scene.cpp:456-492).  R = float: returns value0 (guiding, pixel -1); R = Dual<K>: tangent-only value.
+template <class R>
+PSDR_HD int secondary_edge_sample(const SceneView &sc, const TV<R> &tv, TraversalStack &st, const float s3[3], Vec3<R> &out, uint32_t &nrays) {
+    constexpr bool ad = is_ad<R>();
+    out = zero3<R>();
+    const TangentView<0> tv0{};
+    // -- sample_boundary_segment_direct
+    float s1 = s3[0], pdf0;
+    const int k = sample_reuse(sc.d.sec_cmf, sc.d.sec_pmf, sc.d.sec_sum, sc.d.num_sec_edges, s1, pdf0);
+    const size_t off = (size_t) k * PSDR_SEDGE_STRIDE;
+    const float *se = sc.d.sec_edge + off;
+    constexpr auto sm = &psdr_tangents::d_sec_edge;
+    const Vec3<R> ep0 = ld3<R>(sc.d.sec_edge, tv, sm, off), ee1 = ld3<R>(sc.d.sec_edge, tv, sm, off + 3);
+    const Vec3f n0{se[6], se[7], se[8]}, n1{se[9], se[10], se[11]}, ep2{se[12], se[13], se[14]};
+    const bool is_boundary = se[15] != 0.f;
+    const Vec3<R> bp0 = ee1 * R(s1) + ep0;
+    const Vec3f e1v = val(ee1);
+    const float e1len = norm(e1v);
+    const Vec3f edge = e1v / e1len, edge2 = ep2 - val(ep0), p0 = val(bp0);
+    pdf0 /= e1len;
+    const PosSample<float> ps2 = sample_emitter_position<float>(sc, tv0, s3[1], s3[2], false);
+    const Vec3f p2 = ps2.p, bn = ps2.n;
+    Vec3f e = p2 - p0;
+    const float distSqr = dot(e, e);
+    e = e / sqrtf(fmaxf(distSqr, 0.f));
+    const float cosTheta = -dot(bn, e);
+    const float d0n = dot(n0, e), d1n = dot(n1, e);
+    const int sgn0 = d0n > kEdgeEpsilon ? 1 : (d0n < -kEdgeEpsilon ? -1 : 0), sgn1 = d1n > kEdgeEpsilon ? 1 : (d1n < -kEdgeEpsilon ? -1 : 0);
+    bool valid = cosTheta > kEpsilon && (is_boundary ? sgn0 != 0 : sgn0 * sgn1 < 0);
+    const float bpdf = pdf0 * ps2.pdf * (distSqr / cosTheta);
+    // -- eval_secondary_edge
+    const Vec3f dir = normalize(p2 - p0);
+    const Its<float> its2 = intersect<float>(sc, tv0, st, RayT<float>{p0, dir}, valid, kDetached, nrays);
+    valid = valid && its2.valid && norm(its2.p - p2) < kShadowEpsilon;
+    const Its<float> its1c = intersect<float>(sc, tv0, st, RayT<float>{p0, -dir}, valid, kDetached, nrays);
+    valid = valid && its1c.valid;
+    if (!valid) return -1;
+    const Vec3f p1 = its1c.p;
+    int pixel; float qx, qy, sensor_val;
+    if (!sample_direct(sc, p1, pixel, qx, qy, sensor_val)) return -1;
+    const RayT<R> camera_ray = primary_ray<R>(sc, tv, qx, qy);
+    const Its<R> its1 = intersect<R>(sc, tv, st, camera_ray, true, ad ? kSolidAngle : kDetached, nrays);
+    if (!(its1.valid && norm(val(its1.p) - p1) < kShadowEpsilon)) return -1;
+    const float dist = norm(p2 - p1), cos2 = fabsf(dot(bn, dir));
+    const Vec3f ev = cross(edge, dir);
+    const float sinphi = norm(ev);
+    const Vec3f proj = normalize(cross(ev, bn));
+    const float sinphi2 = norm(cross(dir, proj));
+    const float base_v = (its1c.t / dist) * (sinphi / sinphi2) * cos2;
+    if (!(sinphi > kEpsilon && sinphi2 > kEpsilon)) return -1;
+    const Vec3f d0 = -val(camera_ray.d);
+    const Vec3f d0_local = its1c.sh.to_local(d0);
+    const Bsdf<float> bsdf(sc, sc.d.mesh_bsdf[its1c.mesh]);
+    Vec3f bsdf_val = bsdf.eval(sc, tv0, its1c, d0_local, true);
+    const float correction = fabsf((its1c.wi.z * dot(d0, its1c.n)) / (d0_local.z * dot(dir, its1c.n)));
+    bsdf_val = bsdf_val * correction;
+    Vec3f value0 = bsdf_val * Le<float>(sc, tv0, its2, true) * (base_v * sensor_val / bpdf);
+    if constexpr (ad) {
+        const Vec3f n = normalize(cross(bn, proj));
+        value0 = value0 * (copysignf(1.f, dot(ev, edge2)) * copysignf(1.f, dot(ev, n)));
+        const TriRow<R> T = load_tri<R>(sc, tv, its2.tri);
+        const RayT<R> shadow{its1.p, normalize(bp0 - its1.p)};
+        R u, v, t;
+        moeller_trumbore(T.p0, T.e1, T.e2, shadow, u, v, t);
+        const Vec3<R> u2 = bary_point(detach(T.p0), detach(T.e1), detach(T.e2), u, v);
+        const R dn = dot(lift<R>(n), u2);
+        const Vec3<R> res{dn * value0.x, dn * value0.y, dn * value0.z};
+        out = res - detach(res);
+        return pixel;
+    } else {
+        out = value0;
+        return -1;
+    }
+}
+
+}  // namespace psdr

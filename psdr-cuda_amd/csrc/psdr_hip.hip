@@ -1,0 +1,451 @@
+// psdr_hip.hip -- gfx950 kernels and the C ABI of include/psdr_hip.h.
+//
+// Kernel inventory (all hand-written HIP for CDNA4, wave64):
+//   k_trace            closest-hit BVH traversal over SoA ray streams       (replaces OptiX launch)
+//   k_camera<R>        one lane = one camera sample slot: raygen + Li + segmented wave splat
+//   k_primary_edge<K>  one lane = one primary-edge slot (two detached Li evaluations)
+//   k_secondary_edge<R> one lane = one secondary-edge slot (3 rays + boundary integrand)
+//   k_guide            guiding-grid mass accumulation
+// Traversal stacks live in LDS (one column per lane); image accumulation uses a segmented
+// wave reduction followed by one hardware f32 atomic per (pixel run, channel).
+#include "psdr_device.h"
+#include "psdr_bvh_build.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace psdr;
+
+// ============================================================================ device helpers
+namespace {
+
+__device__ __forceinline__ float wave_shfl_down(float v, int off) { return __shfl_down(v, off, 64); }
+
+// Segmented sum over a wave for NON-DECREASING integer keys (camera slots are pixel-major, so a
+// wave covers a few consecutive pixels).  After the loop the first lane of every key run holds
+// the run total.  All 64 lanes must call this.
+template <int N> __device__ __forceinline__ bool wave_segmented_sum(int key, float (&v)[N]) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int okey = __shfl_down(key, off, 64);
+        const bool take = (lane + off < 64) && (okey == key);
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const float o = wave_shfl_down(v[i], off);
+            if (take) v[i] += o;
+        }
+    }
+    const int pkey = __shfl_up(key, 1, 64);
+    return lane == 0 || pkey != key;
+}
+
+__device__ __forceinline__ void count_rays(unsigned long long *counters, uint32_t nrays) {
+    uint32_t s = nrays;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0 && s) atomicAdd(counters, (unsigned long long) s);
+}
+
+__device__ __forceinline__ void bind_stack(TraversalStack &st, int32_t *lds) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    st.base = lds + threadIdx.x;
+#else
+    (void) st; (void) lds;
+#endif
+}
+
+struct LaunchCtx {
+    SceneView sc;
+    LiParams lp;
+    RngJump jump;
+};
+
+// ------------------------------------------------------------------------------- k_trace
+__global__ __launch_bounds__(kBlock) void k_trace(SceneView sc, int m, const float *__restrict__ ox, const float *__restrict__ oy,
+                                                  const float *__restrict__ oz, const float *__restrict__ dx,
+                                                  const float *__restrict__ dy, const float *__restrict__ dz,
+                                                  const float *__restrict__ tmax, int32_t *__restrict__ out_shape,
+                                                  int32_t *__restrict__ out_tri, float *__restrict__ out_u, float *__restrict__ out_v) {
+    __shared__ int32_t lds[kBvhStack * kBlock];
+    TraversalStack st; bind_stack(st, lds);
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < m; i += gridDim.x * kBlock) {
+        const Hit h = closest_hit(sc, st, Vec3f{ox[i], oy[i], oz[i]}, Vec3f{dx[i], dy[i], dz[i]}, tmax[i]);
+        out_tri[i] = h.tri;
+        out_shape[i] = h.tri >= 0 ? (sc.d.tri_mesh[h.tri] & ~PSDR_TRI_FACE_NORMALS) : -1;
+        out_u[i] = h.u; out_v[i] = h.v;
+    }
+}
+
+// ------------------------------------------------------------------------------ k_camera
+// n = W*H*nsp slots of this shard, pixel-major: slot j -> pixel j / nsp, sample s_begin + j % nsp.
+template <class R>
+__global__ __launch_bounds__(kBlock) void k_camera(LaunchCtx cx, TV<R> tv, int spp, int s_begin, int nsp, long long n, float inv_spp,
+                                                   float *__restrict__ img, float *__restrict__ dimg, long long plane,
+                                                   unsigned long long *counters) {
+    constexpr int K = ad_traits<R>::K;
+    constexpr int NV = 3 * (1 + K);
+    __shared__ int32_t lds[kBvhStack * kBlock];
+    TraversalStack st; bind_stack(st, lds);
+    uint32_t nrays = 0;
+    const long long nceil = (n + kBlock - 1) / kBlock * kBlock;
+    for (long long j = (long long) blockIdx.x * kBlock + threadIdx.x; j < nceil; j += (long long) gridDim.x * kBlock) {
+        const bool in = j < n;
+        const int pixel = in ? (int) (j / nsp) : 0x7fffffff;
+        float v[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = 0.f;
+        if (in) {
+            const int s = s_begin + (int) (j % nsp);
+            const uint64_t slot = (uint64_t) pixel * (uint64_t) spp + (uint64_t) s;
+            const Vec3<R> r = camera_sample<R>(cx.sc, tv, st, cx.lp, cx.jump, pixel, slot, nrays);
+            v[0] = val(r.x) * inv_spp; v[1] = val(r.y) * inv_spp; v[2] = val(r.z) * inv_spp;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                v[3 + 3 * k] = tangent(r.x, k) * inv_spp; v[4 + 3 * k] = tangent(r.y, k) * inv_spp; v[5 + 3 * k] = tangent(r.z, k) * inv_spp;
+            }
+        }
+        const bool head = wave_segmented_sum<NV>(pixel, v);
+        if (head && in) {
+            float *p = img + (size_t) pixel * 3;
+            if (v[0] != 0.f) atomicAdd(p, v[0]);
+            if (v[1] != 0.f) atomicAdd(p + 1, v[1]);
+            if (v[2] != 0.f) atomicAdd(p + 2, v[2]);
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                float *q = dimg + (size_t) k * plane + (size_t) pixel * 3;
+                if (v[3 + 3 * k] != 0.f) atomicAdd(q, v[3 + 3 * k]);
+                if (v[4 + 3 * k] != 0.f) atomicAdd(q + 1, v[4 + 3 * k]);
+                if (v[5 + 3 * k] != 0.f) atomicAdd(q + 2, v[5 + 3 * k]);
+            }
+        }
+    }
+    count_rays(counters, nrays);
+}
+
+// ------------------------------------------------------------------------ k_primary_edge
+template <int K>
+__global__ __launch_bounds__(kBlock) void k_primary_edge(LaunchCtx cx, TangentView<K> tv, long long i0, long long n, float inv_sppe,
+                                                         float *__restrict__ dimg, long long plane, unsigned long long *counters) {
+    __shared__ int32_t lds[kBvhStack * kBlock];
+    TraversalStack st; bind_stack(st, lds);
+    uint32_t nrays = 0;
+    for (long long j = (long long) blockIdx.x * kBlock + threadIdx.x; j < n; j += (long long) gridDim.x * kBlock) {
+        float tan[K][3];
+        const int pixel = primary_edge_sample<K>(cx.sc, tv, st, cx.lp, cx.jump, (uint64_t) (i0 + j), inv_sppe, tan, nrays);
+        if (pixel >= 0) {
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    if (tan[k][c] != 0.f) atomicAdd(dimg + (size_t) k * plane + (size_t) pixel * 3 + c, tan[k][c]);
+        }
+    }
+    count_rays(counters, nrays);
+}
+
+// ---------------------------------------------------------------------- k_secondary_edge
+template <int K>
+__global__ __launch_bounds__(kBlock) void k_secondary_edge(LaunchCtx cx, TangentView<K> tv, long long i0, long long n, float inv_sppse,
+                                                           float *__restrict__ dimg, long long plane, unsigned long long *counters) {
+    using R = Dual<K>;
+    __shared__ int32_t lds[kBvhStack * kBlock];
+    TraversalStack st; bind_stack(st, lds);
+    uint32_t nrays = 0;
+    const bool guided = cx.sc.d.guide_cmf != nullptr && cx.sc.d.num_guide_cells > 0;
+    for (long long j = (long long) blockIdx.x * kBlock + threadIdx.x; j < n; j += (long long) gridDim.x * kBlock) {
+        Rng rng; rng.init((uint64_t) (i0 + j), cx.jump);
+        float s3[3] = {rng.next(), rng.next(), rng.next()};
+        const float pdf0 = guided ? guide_sample_reuse(cx.sc, s3) : 1.f;
+        Vec3<R> value;
+        const int pixel = secondary_edge_sample<R>(cx.sc, tv, st, s3, value, nrays);
+        if (pixel >= 0) {
+            value = zero_nonfinite(value);
+            const float scale = (pdf0 > kEpsilon ? 1.f / pdf0 : 1.f) * inv_sppse;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const float g[3] = {value.x.d[k] * scale, value.y.d[k] * scale, value.z.d[k] * scale};
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    if (g[c] != 0.f) atomicAdd(dimg + (size_t) k * plane + (size_t) pixel * 3 + c, g[c]);
+            }
+        }
+    }
+    count_rays(counters, nrays);
+}
+
+// ------------------------------------------------------------------------------- k_guide
+// DirectIntegrator::preprocess_secondary_edges (direct.cpp:166-204): one lane = one (cell, j) sample
+// stream; nrounds evaluations each; mass[cell] += hmax(value0 / reso3) / nrounds.
+__global__ __launch_bounds__(kBlock) void k_guide(LaunchCtx cx, int r0, int r1, int r2, int per, int nrounds, long long n,
+                                                  float *__restrict__ mass, unsigned long long *counters) {
+    __shared__ int32_t lds[kBvhStack * kBlock];
+    TraversalStack st; bind_stack(st, lds);
+    uint32_t nrays = 0;
+    const TangentView<0> tv0{};
+    const RngJump nojump{1ull, 0ull};
+    for (long long j = (long long) blockIdx.x * kBlock + threadIdx.x; j < n; j += (long long) gridDim.x * kBlock) {
+        const int cell = (int) (j / per);
+        const int c0 = cell / (r1 * r2), rem = cell - c0 * r1 * r2, c1 = rem / r2, c2 = rem - c1 * r2;
+        Rng rng; rng.init((uint64_t) j, nojump);
+        float acc = 0.f;
+        for (int r = 0; r < nrounds; ++r) {
+            float s3[3] = {rng.next(), rng.next(), rng.next()};
+            s3[0] = (s3[0] + (float) c0) * (1.f / (float) r0);
+            s3[1] = (s3[1] + (float) c1) * (1.f / (float) r1);
+            s3[2] = (s3[2] + (float) c2) * (1.f / (float) r2);
+            Vec3f v;
+            secondary_edge_sample<float>(cx.sc, tv0, st, s3, v, nrays);
+            v = zero_nonfinite(v);
+            if (per > 1) v = v / (float) per;
+            acc += fmaxf(v.x, fmaxf(v.y, v.z));
+        }
+        if (nrounds > 1) acc /= (float) nrounds;
+        if (acc != 0.f) atomicAdd(mass + cell, acc);
+    }
+    count_rays(counters, nrays);
+}
+
+// ============================================================================ host side
+thread_local std::string g_err;
+int fail(const std::string &m) { g_err = m; return 1; }
+#define HIP_TRY(expr)                                                                              \
+    do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
+
+}  // namespace
+
+struct psdr_scene_s {
+    psdr_scene_desc desc{};
+    bool have_tables = false;
+    BvhNode *d_nodes = nullptr;
+    float4 *d_btris = nullptr;
+    size_t cap_nodes = 0, cap_btris = 0;
+    int32_t root = 0;
+    bool have_bvh = false;
+    unsigned long long *d_counters = nullptr;
+    uint64_t slots[3] = {0, 0, 0};
+    int num_cus = 256;
+};
+
+namespace {
+
+int launch_blocks(const psdr_scene_s *h, long long n) {
+    const long long need = (n + kBlock - 1) / kBlock;
+    const long long cap = (long long) h->num_cus * 16;      // grid-stride beyond 16 resident-ish blocks per CU
+    return (int) std::max(1LL, std::min(need, cap));
+}
+
+int make_ctx(psdr_scene_s *h, const psdr_render_opts *o, int sampler, LaunchCtx &cx) {
+    if (!h->have_tables) return fail("Scene not loaded yet!");
+    if (!h->have_bvh) return fail("Input scene must be configured!");
+    if (o->integrator != PSDR_INTEGRATOR_FIELD && h->desc.num_emitters <= 0) return fail("No Emitter!");
+    if (o->integrator == PSDR_INTEGRATOR_DIRECT && !(o->bsdf_samples >= 0 && o->light_samples >= 0 && o->bsdf_samples + o->light_samples > 0))
+        return fail("DirectIntegrator: bsdf_samples + light_samples must be positive");
+    cx.sc.d = h->desc; cx.sc.nodes = h->d_nodes; cx.sc.btris = h->d_btris; cx.sc.root = h->root;
+    cx.lp = LiParams{o->integrator, o->bsdf_samples, o->light_samples, o->max_depth, o->hide_emitters, o->field};
+    cx.jump = make_rng_jump(o->rng_offset[sampler]);
+    return 0;
+}
+
+int check_counts(const psdr_scene_s *h, const psdr_render_opts *o) {
+    const long long WH = (long long) h->desc.width * h->desc.height;
+    if (WH <= 0) return fail("Invalid film resolution");
+    if (WH * std::max(o->spp, 1) > 0x7fffffffLL) return fail("Too many samples (width*height*spp > INT_MAX)");   // integrator.cpp:74
+    if (o->spp_begin < 0 || o->spp_end > o->spp || o->spp_begin > o->spp_end) return fail("Invalid spp shard range");
+    if (o->sppe_begin < 0 || o->sppe_end > o->sppe || o->sppe_begin > o->sppe_end) return fail("Invalid sppe shard range");
+    if (o->sppse_begin < 0 || o->sppse_end > o->sppse || o->sppse_begin > o->sppse_end) return fail("Invalid sppse shard range");
+    return 0;
+}
+
+template <class R>
+int run_camera(psdr_scene_s *h, const psdr_render_opts *o, const TV<R> &tv, float *img, float *dimg, hipStream_t s) {
+    const long long WH = (long long) h->desc.width * h->desc.height;
+    const int nsp = o->spp_end - o->spp_begin;
+    if (o->spp <= 0 || nsp <= 0) return 0;
+    LaunchCtx cx;
+    if (int rc = make_ctx(h, o, 0, cx)) return rc;
+    const long long n = WH * nsp;
+    h->slots[0] += (uint64_t) n;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_camera<R>), dim3(launch_blocks(h, n)), dim3(kBlock), 0, s, cx, tv, o->spp, o->spp_begin, nsp, n,
+                       1.f / (float) o->spp, img, dimg, WH * 3, h->d_counters);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+template <int K>
+int render_fwd(psdr_scene_s *h, const psdr_render_opts *o, const psdr_tangents *tangents, float *img, float *dimg, hipStream_t s) {
+    const long long WH = (long long) h->desc.width * h->desc.height;
+    TangentView<K> tv;
+    for (int k = 0; k < K; ++k) tv.t[k] = tangents[k];
+    HIP_TRY(hipMemsetAsync(img, 0, sizeof(float) * WH * 3, s));
+    HIP_TRY(hipMemsetAsync(dimg, 0, sizeof(float) * WH * 3 * K, s));
+    if (int rc = run_camera<Dual<K>>(h, o, tv, img, dimg, s)) return rc;
+    if (o->sppe > 0 && o->sppe_end > o->sppe_begin && h->desc.num_prim_edges > 0) {
+        LaunchCtx cx;
+        if (int rc = make_ctx(h, o, 1, cx)) return rc;
+        const long long i0 = WH * o->sppe_begin, n = WH * (o->sppe_end - o->sppe_begin);
+        h->slots[1] += (uint64_t) n;
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_primary_edge<K>), dim3(launch_blocks(h, n)), dim3(kBlock), 0, s, cx, tv, i0, n,
+                           1.f / (float) o->sppe, dimg, WH * 3, h->d_counters);
+        HIP_TRY(hipGetLastError());
+    }
+    if (o->sppse > 0 && o->sppse_end > o->sppse_begin && h->desc.num_sec_edges > 0 && o->integrator == PSDR_INTEGRATOR_DIRECT) {
+        LaunchCtx cx;
+        if (int rc = make_ctx(h, o, 2, cx)) return rc;
+        const long long i0 = WH * o->sppse_begin, n = WH * (o->sppse_end - o->sppse_begin);
+        h->slots[2] += (uint64_t) n;
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_secondary_edge<K>), dim3(launch_blocks(h, n)), dim3(kBlock), 0, s, cx, tv, i0, n,
+                           1.f / (float) o->sppse, dimg, WH * 3, h->d_counters);
+        HIP_TRY(hipGetLastError());
+    }
+    return 0;
+}
+
+int begin_call(psdr_scene_s *h, hipStream_t s) {
+    h->slots[0] = h->slots[1] = h->slots[2] = 0;
+    HIP_TRY(hipMemsetAsync(h->d_counters, 0, sizeof(unsigned long long) * 4, s));
+    return 0;
+}
+
+}  // namespace
+
+// ================================================================================= C ABI
+extern "C" {
+
+const char *psdr_last_error(void) { return g_err.c_str(); }
+const char *psdr_version(void) { return "psdr-hip 0.1 gfx950"; }
+
+int psdr_scene_create(psdr_scene_t *out) {
+    if (!out) return fail("psdr_scene_create: null output");
+    psdr_scene_s *h = new psdr_scene_s();
+    hipError_t e = hipMalloc(&h->d_counters, sizeof(unsigned long long) * 4);
+    if (e != hipSuccess) { delete h; return fail(std::string("hipMalloc: ") + hipGetErrorString(e)); }
+    int dev = 0; hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) h->num_cus = prop.multiProcessorCount;
+    *out = h;
+    return 0;
+}
+
+int psdr_scene_destroy(psdr_scene_t h) {
+    if (!h) return 0;
+    if (h->d_nodes) (void) hipFree(h->d_nodes);
+    if (h->d_btris) (void) hipFree(h->d_btris);
+    if (h->d_counters) (void) hipFree(h->d_counters);
+    delete h;
+    return 0;
+}
+
+int psdr_scene_set_tables(psdr_scene_t h, const psdr_scene_desc *desc) {
+    if (!h || !desc) return fail("psdr_scene_set_tables: null argument");
+    if (desc->num_tris <= 0 || !desc->tri_info || !desc->tri_mesh) return fail("Missing meshes!");
+    if (!desc->cam) return fail("Missing sensor!");
+    if (h->have_tables && (desc->tri_info != h->desc.tri_info || desc->num_tris != h->desc.num_tris)) h->have_bvh = false;
+    h->desc = *desc;
+    h->have_tables = true;
+    return 0;
+}
+
+int psdr_bvh_build(psdr_scene_t h, void *stream) {
+    if (!h || !h->have_tables) return fail("Scene not loaded yet!");
+    hipStream_t s = (hipStream_t) stream;
+    const int T = h->desc.num_tris;
+    std::vector<float> rows((size_t) T * PSDR_TRI_STRIDE);
+    HIP_TRY(hipMemcpyAsync(rows.data(), h->desc.tri_info, rows.size() * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    Builder b;
+    int32_t root = 0;
+    if (const char *err = b.run(rows.data(), T, root)) return fail(err);
+    if (b.nodes.size() > h->cap_nodes) {
+        if (h->d_nodes) (void) hipFree(h->d_nodes);
+        h->cap_nodes = std::max<size_t>(b.nodes.size(), 16);
+        HIP_TRY(hipMalloc(&h->d_nodes, h->cap_nodes * sizeof(BvhNode)));
+    }
+    if (b.btris.size() > h->cap_btris) {
+        if (h->d_btris) (void) hipFree(h->d_btris);
+        h->cap_btris = b.btris.size();
+        HIP_TRY(hipMalloc(&h->d_btris, h->cap_btris * sizeof(float4)));
+    }
+    if (!b.nodes.empty()) HIP_TRY(hipMemcpyAsync(h->d_nodes, b.nodes.data(), b.nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(h->d_btris, b.btris.data(), b.btris.size() * sizeof(float4), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));     // host vectors die at return
+    h->root = root;
+    h->have_bvh = true;
+    return 0;
+}
+
+int psdr_trace(psdr_scene_t h, int32_t m, const float *ox, const float *oy, const float *oz, const float *dx, const float *dy,
+               const float *dz, const float *tmax, int32_t *out_shape, int32_t *out_tri, float *out_u, float *out_v, void *stream) {
+    if (!h || !h->have_tables) return fail("Scene not loaded yet!");
+    if (!h->have_bvh) return fail("Input scene must be configured!");
+    if (m <= 0) return 0;
+    SceneView sc; sc.d = h->desc; sc.nodes = h->d_nodes; sc.btris = h->d_btris; sc.root = h->root;
+    hipLaunchKernelGGL(k_trace, dim3(launch_blocks(h, m)), dim3(kBlock), 0, (hipStream_t) stream, sc, m, ox, oy, oz, dx, dy, dz, tmax,
+                       out_shape, out_tri, out_u, out_v);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int psdr_render_c(psdr_scene_t h, const psdr_render_opts *o, float *out_img, void *stream) {
+    if (!h || !o || !out_img) return fail("psdr_render_c: null argument");
+    if (!h->have_tables) return fail("Scene not loaded yet!");
+    if (int rc = check_counts(h, o)) return rc;
+    hipStream_t s = (hipStream_t) stream;
+    if (int rc = begin_call(h, s)) return rc;
+    const long long WH = (long long) h->desc.width * h->desc.height;
+    HIP_TRY(hipMemsetAsync(out_img, 0, sizeof(float) * WH * 3, s));
+    const TangentView<0> tv0{};
+    return run_camera<float>(h, o, tv0, out_img, nullptr, s);
+}
+
+int psdr_render_d_fwd(psdr_scene_t h, const psdr_render_opts *o, int32_t K, const psdr_tangents *tangents, float *out_img,
+                      float *out_dimg, void *stream) {
+    if (!h || !o || !out_img || !out_dimg || !tangents) return fail("psdr_render_d_fwd: null argument");
+    if (!h->have_tables) return fail("Scene not loaded yet!");
+    if (int rc = check_counts(h, o)) return rc;
+    hipStream_t s = (hipStream_t) stream;
+    if (int rc = begin_call(h, s)) return rc;
+    switch (K) {
+        case 1: return render_fwd<1>(h, o, tangents, out_img, out_dimg, s);
+        case 3: return render_fwd<3>(h, o, tangents, out_img, out_dimg, s);
+        default: return fail("psdr_render_d_fwd: K must be 1 or 3");
+    }
+}
+
+int psdr_render_d_rev(psdr_scene_t h, const psdr_render_opts *o, const float *adj_img, float *out_img, const psdr_grads *grads,
+                      void *stream) {
+    (void) h; (void) o; (void) adj_img; (void) out_img; (void) grads; (void) stream;
+    return fail("psdr_render_d_rev: reverse-mode kernels are not built yet (use psdr_render_d_fwd)");
+}
+
+int psdr_guide_build(psdr_scene_t h, const psdr_render_opts *o, const int32_t reso[4], int32_t nrounds, float *out_mass, void *stream) {
+    if (!h || !o || !reso || !out_mass) return fail("psdr_guide_build: null argument");
+    if (nrounds <= 0) return fail("psdr_guide_build: nrounds must be positive");
+    if (h->desc.num_sec_edges <= 0) return fail("psdr_guide_build: scene has no secondary edges");
+    hipStream_t s = (hipStream_t) stream;
+    if (int rc = begin_call(h, s)) return rc;
+    LaunchCtx cx;
+    if (int rc = make_ctx(h, o, 2, cx)) return rc;
+    cx.sc.d.guide_cmf = nullptr; cx.sc.d.num_guide_cells = 0;
+    const long long cells = (long long) reso[0] * reso[1] * reso[2];
+    const long long n = cells * reso[3];
+    if (n <= 0 || n > 0x7fffffffLL) return fail("psdr_guide_build: invalid resolution");
+    HIP_TRY(hipMemsetAsync(out_mass, 0, sizeof(float) * cells, s));
+    hipLaunchKernelGGL(k_guide, dim3(launch_blocks(h, n)), dim3(kBlock), 0, s, cx, reso[0], reso[1], reso[2], reso[3], nrounds, n, out_mass,
+                       h->d_counters);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int psdr_get_counters(psdr_scene_t h, uint64_t out[4]) {
+    if (!h || !out) return fail("psdr_get_counters: null argument");
+    unsigned long long c[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpy(c, h->d_counters, sizeof(c), hipMemcpyDeviceToHost));
+    out[0] = c[0]; out[1] = h->slots[0]; out[2] = h->slots[1]; out[3] = h->slots[2];
+    return 0;
+}
+
+}  // extern "C"

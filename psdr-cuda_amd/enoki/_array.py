@@ -1,0 +1,391 @@
+"""Array types of the enoki shim (see package docstring)."""
+import weakref
+
+import numpy as np
+import torch
+
+_builtin_abs = abs
+
+
+def default_device():
+    return torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+
+
+_CLASSES = {}          # (kind, ad) -> class ; kind in {"f", "v2", "v3", "v4", "m4", "i", "b"}
+_KIND_COLS = {"f": 0, "i": 0, "b": 0, "v2": 2, "v3": 3, "v4": 4}
+_render_nodes = []     # weakrefs to arrays returned by Integrator.renderD
+
+
+def _cls(kind, ad):
+    return _CLASSES[(kind, bool(ad) and kind not in ("i", "b"))]
+
+
+def _as_tensor(x, dtype=torch.float32):
+    if isinstance(x, ArrayBase):
+        return x.t
+    if isinstance(x, torch.Tensor):
+        return x
+    return torch.as_tensor(np.asarray(x), dtype=dtype, device=default_device())
+
+
+class ArrayBase:
+    _kind = "f"
+    _ad = False
+    _dtype = torch.float32
+
+    def __init__(self, *args, literal=True):
+        k = self._kind
+        dev = default_device()
+        if len(args) == 0:
+            t = torch.zeros((1,) + self._tail(), dtype=self._dtype, device=dev)
+        elif len(args) == 1:
+            a = args[0]
+            if isinstance(a, ArrayBase):
+                t = a.t if (self._ad or not a.t.requires_grad) else a.t.detach()
+                if a._kind != k:
+                    t = self._coerce(t, a._kind)
+            elif isinstance(a, torch.Tensor):
+                t = a.to(self._dtype) if a.dtype != self._dtype else a
+                t = self._coerce(t, None)
+            else:
+                arr = np.asarray(a, dtype=np.float64 if self._dtype.is_floating_point else None)
+                t = torch.as_tensor(arr, device=dev).to(self._dtype)
+                t = self._coerce(t, None)
+        else:
+            cols = _KIND_COLS.get(k, 0)
+            if cols and len(args) == cols:
+                comps = [_as_tensor(a, self._dtype).to(self._dtype).reshape(-1) for a in args]
+                n = max(c.shape[0] for c in comps)
+                comps = [c.expand(n) if c.shape[0] == 1 else c for c in comps]
+                t = torch.stack(comps, dim=-1)
+            elif k == "m4" and len(args) == 16:
+                t = torch.stack([_as_tensor(a).reshape(()) for a in args]).reshape(4, 4)
+            else:
+                raise TypeError("%s: unsupported constructor arguments" % type(self).__name__)
+        if not self._ad and t.requires_grad:
+            t = t.detach()
+        self.t = t
+
+    # ---- helpers
+    @classmethod
+    def _tail(cls):
+        c = _KIND_COLS.get(cls._kind, 0)
+        return (4, 4) if cls._kind == "m4" else ((c,) if c else ())
+
+    def _coerce(self, t, src_kind):
+        k = self._kind
+        if k == "m4":
+            return t.reshape(4, 4) if t.numel() == 16 else t
+        cols = _KIND_COLS[k]
+        if cols == 0:
+            return t.reshape(-1)
+        if t.dim() == 1:
+            if t.shape[0] == cols:
+                return t.reshape(1, cols)
+            return t.reshape(-1, 1).expand(-1, cols)
+        if t.dim() == 0:
+            return t.reshape(1, 1).expand(1, cols)
+        if t.shape[-1] != cols and t.shape[0] == cols:
+            return t.transpose(0, 1)
+        return t
+
+    @classmethod
+    def _wrap(cls, t):
+        o = cls.__new__(cls)
+        o.t = t if (cls._ad or not t.requires_grad) else t.detach()
+        return o
+
+    # ---- enoki-style API
+    def numpy(self):
+        return self.t.detach().cpu().numpy()
+
+    def torch(self):
+        return self.t
+
+    @classmethod
+    def zero(cls, n=1):
+        return cls._wrap(torch.zeros((n,) + cls._tail(), dtype=cls._dtype, device=default_device()))
+
+    @classmethod
+    def full(cls, value, n=1):
+        return cls._wrap(torch.full((n,) + cls._tail(), value, dtype=cls._dtype, device=default_device()))
+
+    @classmethod
+    def arange(cls, n):
+        return cls._wrap(torch.arange(n, device=default_device()).to(cls._dtype))
+
+    @classmethod
+    def copy(cls, data, n=None):
+        return cls(data)
+
+    def __len__(self):
+        return self.t.shape[0] if self._kind != "m4" else 4
+
+    def __repr__(self):
+        return "%s(%s)" % (type(self).__name__, self.numpy().tolist() if self.t.numel() <= 24 else
+                           "<%d slices>" % self.t.shape[0])
+
+    # component access for vectors
+    def _comp(self, i):
+        return _cls("f", self._ad)._wrap(self.t[..., i])
+
+    def __getitem__(self, i):
+        if self._kind in ("v2", "v3", "v4"):
+            return self._comp(i)
+        if self._kind == "m4":
+            return self.t[i]
+        return self.t[i].item() if isinstance(i, int) else type(self)._wrap(self.t[i])
+
+    def __setitem__(self, i, value):
+        v = value.t if isinstance(value, ArrayBase) else value
+        t = self.t.clone()
+        if self._kind in ("v2", "v3", "v4"):
+            t[..., i] = v
+        else:
+            t[i] = v
+        self.t = t
+
+    x = property(lambda s: s._comp(0))
+    y = property(lambda s: s._comp(1))
+    z = property(lambda s: s._comp(2))
+    w = property(lambda s: s._comp(3))
+
+    # ---- arithmetic
+    def _bin(self, other, fn, reverse=False):
+        a, b = self, other
+        if not isinstance(b, ArrayBase):
+            if isinstance(b, (int, float, bool, np.floating, np.integer)):
+                bt, bk, bad = b, "f", False
+            else:
+                b = (_cls(a._kind if np.asarray(b).ndim > 1 else "f", False))(b)
+                bt, bk, bad = b.t, b._kind, b._ad
+        else:
+            bt, bk, bad = b.t, b._kind, b._ad
+        at, ak = a.t, a._kind
+        kind = ak
+        if ak in ("f", "i", "b") and bk not in ("f", "i", "b"):
+            kind = bk
+        if kind in ("v2", "v3", "v4"):
+            if ak in ("f", "i", "b"):
+                at = at.unsqueeze(-1)
+            if bk in ("f", "i", "b") and isinstance(bt, torch.Tensor):
+                bt = bt.unsqueeze(-1)
+        if kind == "i" and (bk == "f" or isinstance(bt, float)):
+            kind = "f"
+        r = fn(bt, at) if reverse else fn(at, bt)
+        if r.dtype == torch.bool:
+            return _cls("b", False)._wrap(r)
+        return _cls(kind, a._ad or bad)._wrap(r)
+
+    def __add__(self, o): return self._bin(o, torch.add)
+    def __radd__(self, o): return self._bin(o, torch.add, True)
+    def __sub__(self, o): return self._bin(o, torch.sub)
+    def __rsub__(self, o): return self._bin(o, lambda x, y: torch.sub(torch.as_tensor(x, device=y.device) if not isinstance(x, torch.Tensor) else x, y), True)
+    def __mul__(self, o):
+        if self._kind == "m4" and isinstance(o, ArrayBase) and o._kind == "m4":
+            return _cls("m4", self._ad or o._ad)._wrap(self.t @ o.t)
+        return self._bin(o, torch.mul)
+    def __rmul__(self, o): return self._bin(o, torch.mul, True)
+    def __matmul__(self, o): return _cls("m4", self._ad or o._ad)._wrap(self.t @ o.t)
+    def __truediv__(self, o): return self._bin(o, torch.div)
+    def __rtruediv__(self, o): return self._bin(o, lambda x, y: torch.div(torch.as_tensor(x, device=y.device, dtype=y.dtype) if not isinstance(x, torch.Tensor) else x, y), True)
+    def __neg__(self): return type(self)._wrap(-self.t)
+    def __lt__(self, o): return self._bin(o, torch.lt)
+    def __le__(self, o): return self._bin(o, torch.le)
+    def __gt__(self, o): return self._bin(o, torch.gt)
+    def __ge__(self, o): return self._bin(o, torch.ge)
+    def __and__(self, o): return self._bin(o, torch.logical_and)
+    def __or__(self, o): return self._bin(o, torch.logical_or)
+    def __invert__(self): return type(self)._wrap(~self.t)
+    def __iadd__(self, o): return self.__add__(o)
+    def __isub__(self, o): return self.__sub__(o)
+    def __imul__(self, o): return self.__mul__(o)
+    def __itruediv__(self, o): return self.__truediv__(o)
+
+
+def _make(kind, ad, name, dtype=torch.float32, extra=None):
+    ns = {"_kind": kind, "_ad": ad, "_dtype": dtype}
+    if extra:
+        ns.update(extra)
+    c = type(name, (ArrayBase,), ns)
+    _CLASSES[(kind, ad)] = c
+    return c
+
+
+def _m4_translate(cls, v):
+    v = v if isinstance(v, ArrayBase) else _cls("v3", False)(v)
+    t = v.t.reshape(-1)[:3]
+    m = torch.eye(4, dtype=torch.float32, device=t.device)
+    m = torch.cat([torch.cat([m[:3, :3], t.reshape(3, 1)], dim=1), m[3:4]], dim=0)
+    return cls._wrap(m)
+
+
+def _m4_scale(cls, v):
+    v = v if isinstance(v, ArrayBase) else _cls("v3", False)(v)
+    t = v.t.reshape(-1)[:3]
+    return cls._wrap(torch.diag(torch.cat([t, torch.ones(1, device=t.device)])))
+
+
+def _m4_rotate(cls, axis, angle):
+    """enoki::rotate(axis, angle_radians) (the Python binding takes radians)."""
+    axis = axis if isinstance(axis, ArrayBase) else _cls("v3", False)(axis)
+    a = axis.t.reshape(-1)[:3]
+    ang = _as_tensor(angle).reshape(())
+    if isinstance(angle, ArrayBase):
+        ang = angle.t.reshape(-1)[0]
+    ang = ang.to(a.device)
+    s, c = torch.sin(ang), torch.cos(ang)
+    x, y, z = a[0], a[1], a[2]
+    one = torch.ones((), device=a.device)
+    zero_ = torch.zeros((), device=a.device)
+    cm = one - c
+    rows = [
+        torch.stack([c + x * x * cm, x * y * cm - z * s, x * z * cm + y * s, zero_]),
+        torch.stack([y * x * cm + z * s, c + y * y * cm, y * z * cm - x * s, zero_]),
+        torch.stack([z * x * cm - y * s, z * y * cm + x * s, c + z * z * cm, zero_]),
+        torch.stack([zero_, zero_, zero_, one]),
+    ]
+    return cls._wrap(torch.stack(rows))
+
+
+def _m4_identity(cls, n=1):
+    return cls._wrap(torch.eye(4, dtype=torch.float32, device=default_device()))
+
+
+_M4_EXTRA = {"translate": classmethod(_m4_translate), "scale": classmethod(_m4_scale),
+             "rotate": classmethod(_m4_rotate), "identity": classmethod(_m4_identity)}
+
+for _ad, _sfx in ((False, "C"), (True, "D")):
+    _make("f", _ad, "Float32" + _sfx)
+    _make("v2", _ad, "Vector2f" + _sfx)
+    _make("v3", _ad, "Vector3f" + _sfx)
+    _make("v4", _ad, "Vector4f" + _sfx)
+    _make("m4", _ad, "Matrix4f" + _sfx, extra=_M4_EXTRA)
+_make("i", False, "Int32", dtype=torch.int32)
+_make("b", False, "Mask", dtype=torch.bool)
+
+
+# ------------------------------------------------------------------ free functions
+def _u(x, fn):
+    return type(x)._wrap(fn(x.t)) if isinstance(x, ArrayBase) else fn(torch.as_tensor(x)).item()
+
+
+def detach(x):
+    return _cls(x._kind, False)._wrap(x.t.detach())
+
+
+def set_requires_gradient(x, value=True):
+    if not x.t.is_leaf:
+        x.t = x.t.detach()
+    if not x.t.is_floating_point():
+        raise RuntimeError("set_requires_gradient: floating point array expected")
+    x.t.requires_grad_(bool(value))
+    x._fwd_grad = None
+
+
+def requires_gradient(x):
+    return bool(x.t.requires_grad)
+
+
+def slices(x):
+    return x.t.shape[0] if x._kind != "m4" else 1
+
+
+def sqrt(x): return _u(x, torch.sqrt)
+def sqr(x): return _u(x, lambda t: t * t)
+def abs(x): return _u(x, torch.abs) if isinstance(x, ArrayBase) else _builtin_abs(x)
+def isfinite(x): return _cls("b", False)._wrap(torch.isfinite(x.t))
+def hsum(x): return _cls("f", x._ad)._wrap(x.t.sum(dim=0, keepdim=True)) if x._kind == "f" else _cls("f", x._ad)._wrap(x.t.sum(dim=-1))
+def hmean(x): return _cls("f", x._ad)._wrap(x.t.mean(dim=0, keepdim=True)) if x._kind == "f" else _cls("f", x._ad)._wrap(x.t.mean(dim=-1))
+def hmax(x): return _cls("f", x._ad)._wrap(x.t.max(dim=0, keepdim=True)[0]) if x._kind == "f" else _cls("f", x._ad)._wrap(x.t.max(dim=-1)[0])
+def hmin(x): return _cls("f", x._ad)._wrap(x.t.min(dim=0, keepdim=True)[0]) if x._kind == "f" else _cls("f", x._ad)._wrap(x.t.min(dim=-1)[0])
+def squared_norm(x): return _cls("f", x._ad)._wrap((x.t * x.t).sum(dim=-1))
+def norm(x): return _cls("f", x._ad)._wrap(torch.sqrt((x.t * x.t).sum(dim=-1)))
+def normalize(x): return type(x)._wrap(x.t / torch.sqrt((x.t * x.t).sum(dim=-1, keepdim=True)))
+def dot(a, b): return _cls("f", a._ad or b._ad)._wrap((a.t * b.t).sum(dim=-1))
+def cross(a, b): return _cls("v3", a._ad or b._ad)._wrap(torch.cross(a.t.expand_as(torch.broadcast_tensors(a.t, b.t)[0]), b.t.expand_as(torch.broadcast_tensors(a.t, b.t)[0]), dim=-1))
+
+
+def select(m, a, b):
+    mt = m.t
+    ref = a if isinstance(a, ArrayBase) else b
+    at = a.t if isinstance(a, ArrayBase) else torch.as_tensor(a, dtype=ref.t.dtype, device=ref.t.device)
+    bt = b.t if isinstance(b, ArrayBase) else torch.as_tensor(b, dtype=ref.t.dtype, device=ref.t.device)
+    if ref._kind in ("v2", "v3", "v4") and mt.dim() == 1:
+        mt = mt.unsqueeze(-1)
+    return type(ref)._wrap(torch.where(mt, at, bt))
+
+
+def zero(cls, n=1): return cls.zero(n)
+def full(cls, v, n=1): return cls.full(v, n)
+def arange(cls, n): return cls.arange(n)
+def cuda_eval(): pass
+def cuda_malloc_trim(): pass
+
+
+def cuda_sync():
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+
+
+# ------------------------------------------------------------------ autodiff
+def register_render_node(img):
+    """Called by Integrator.renderD: `img` is the returned array; img._node knows how to push a
+    forward-mode tangent through the renderer (psdr_render_d_fwd)."""
+    _render_nodes.append(weakref.ref(img))
+
+
+def _jvp_wrt(outputs, P):
+    """d outputs / d P for a scalar leaf P through a (cheap, pure-torch) graph, using the
+    double-backward trick.  Returns one tensor (or None) per output."""
+    idx = [i for i, y in enumerate(outputs) if y is not None and y.requires_grad]
+    if not idx:
+        return [None] * len(outputs)
+    ys = [outputs[i] for i in idx]
+    vs = [torch.zeros_like(y, requires_grad=True) for y in ys]
+    g = torch.autograd.grad(ys, P, grad_outputs=vs, create_graph=True, allow_unused=True)[0]
+    res = [None] * len(outputs)
+    if g is None:
+        return res
+    ts = torch.autograd.grad(g.sum(), vs, allow_unused=True)
+    for i, t in zip(idx, ts):
+        res[i] = t
+    return res
+
+
+def forward(P, free_graph=True):
+    """enoki.forward(P): propagate dP = 1 to every live renderD result
+    (reference examples/run_test.py:127)."""
+    global _render_nodes
+    alive = []
+    for ref in _render_nodes:
+        img = ref()
+        if img is None:
+            continue
+        alive.append(ref)
+        node = getattr(img, "_node", None)
+        if node is None:
+            continue
+        tangents = _jvp_wrt(node.input_tensors(), P.t)
+        img._fwd_grad = node.render_forward(tangents)
+        if free_graph:
+            node.release()
+    _render_nodes = alive
+
+
+def backward(x, free_graph=True):
+    """enoki.backward(loss) (reference docs/inverse_diff_render.rst)."""
+    x.t.sum().backward(retain_graph=not free_graph)
+
+
+def gradient(x):
+    g = getattr(x, "_fwd_grad", None)
+    if g is not None:
+        return _cls(x._kind, False)._wrap(g)
+    if x.t.grad is not None:
+        return _cls(x._kind, False)._wrap(x.t.grad)
+    return _cls(x._kind, False)._wrap(torch.zeros_like(x.t))
+
+
+def set_gradient(x, g):
+    x.t.grad = g.t if isinstance(g, ArrayBase) else g

@@ -1,0 +1,952 @@
+"""Scene objects and Scene::configure(): builds every device table the HIP kernels gather from.
+
+Host-side mirror of the reference's L2/L3 layers.  All O(V+T) work that the
+reference does with Enoki DiffArrays (world transform, per-face info, vertex normals, edge
+records, camera matrices, distributions) is done here with torch ops on the render device, so the
+chain  user parameters -> tables  stays differentiable by torch autograd, while the O(W*H*spp)
+work is done by the hand-written HIP kernels behind include/psdr_hip.h.
+"""
+import math
+import os
+import time
+import xml.etree.ElementTree as ET
+
+import numpy as np
+import torch
+
+import enoki as ek
+from . import _abi
+from .core import (Object, RenderOption, Bitmap1fD, Bitmap3fD, DiscreteDistribution, psdr_assert,
+                   FloatC, FloatD, Vector2fD, Vector3fC, Vector3fD, Matrix4fD, IntC)
+
+Epsilon = 1e-5
+EdgeEpsilon = 1e-5
+
+
+def _dev():
+    return ek.default_device()
+
+
+def _mat(x):
+    """4x4 float32 tensor on the render device from a shim matrix / tensor / nested list."""
+    if isinstance(x, ek.ArrayBase):
+        t = x.t
+    elif isinstance(x, torch.Tensor):
+        t = x
+    else:
+        t = torch.as_tensor(np.asarray(x, dtype=np.float32))
+    return t.to(device=_dev(), dtype=torch.float32).reshape(4, 4)
+
+
+def transform_pos(m, v):
+    """reference include/psdr/core/transform.h:84-88"""
+    h = v @ m[:3, :3].T + m[:3, 3]
+    w = v @ m[3, :3] + m[3, 3]
+    return h / w.unsqueeze(-1)
+
+
+def transform_dir(m, v):
+    return v @ m[:3, :3].T
+
+
+def _normalize(v):
+    return v / torch.sqrt((v * v).sum(dim=-1, keepdim=True))
+
+
+# ------------------------------------------------------------------------------ BSDFs
+class BSDF(Object):
+    _type_name = "BSDF"
+
+    def anisotropic(self):
+        return False
+
+
+class Diffuse(BSDF):
+    """reference include/psdr/bsdf/diffuse.h, src/bsdf/diffuse.cpp"""
+    _type_name = "DiffuseBSDF"
+
+    def __init__(self, reflectance=None):
+        super().__init__()
+        self.reflectance = reflectance if isinstance(reflectance, Bitmap3fD) else Bitmap3fD(
+            0.5 if reflectance is None else reflectance)
+
+    def to_string(self):
+        return "Diffuse[id=%s]" % self.id
+
+
+DiffuseBSDF = Diffuse
+
+
+class RoughConductor(BSDF):
+    """reference include/psdr/bsdf/roughconductor.h, src/bsdf/roughconductor.cpp"""
+    _type_name = "RoughConductorBSDF"
+
+    def __init__(self, alpha=0.1, eta=(0.0, 0.0, 0.0), k=(1.0, 1.0, 1.0)):
+        super().__init__()
+        self.alpha_u = Bitmap1fD(alpha)
+        self.alpha_v = Bitmap1fD(alpha)
+        self.eta = Bitmap3fD(eta)
+        self.k = Bitmap3fD(k)
+        self.specular_reflectance = Bitmap3fD(1.0)
+        self.m_anisotropic = False     # roughconductor.h:12-18: single-alpha constructors are isotropic
+
+    def anisotropic(self):
+        return self.m_anisotropic
+
+    def to_string(self):
+        return "RoughConductor[id=%s]" % self.id
+
+
+RoughConductorBSDF = RoughConductor
+
+
+# ---------------------------------------------------------------------------- emitters
+class Emitter(Object):
+    _type_name = "Emitter"
+
+
+class AreaLight(Emitter):
+    """reference include/psdr/emitter/area.h, src/emitter/area.cpp:10-62"""
+    _type_name = "AreaLight"
+
+    def __init__(self, radiance, mesh):
+        super().__init__()
+        r = np.asarray(radiance, dtype=np.float32).reshape(-1)
+        if r.size == 1:
+            r = np.repeat(r, 3)
+        self.radiance = Vector3fD([float(r[0]), float(r[1]), float(r[2])])
+        self.m_mesh = mesh
+        self.m_sampling_weight = 1.0
+        self.m_ready = False
+
+    def configure(self):
+        psdr_assert(self.m_mesh is not None and self.m_mesh.m_ready)
+        psdr_assert(ek.slices(self.radiance) == 1)
+        r = self.radiance.t.detach().reshape(3)
+        lum = float((r[0] * .2126 + r[1] * .7152 + r[2] * .0722).item())
+        self.m_sampling_weight = self.m_mesh.m_total_area * lum
+        self.m_ready = True
+
+    def to_string(self):
+        return "AreaLight[radiance = %s, sampling_weight = %g]" % (self.radiance.numpy().tolist(), self.m_sampling_weight)
+
+
+# ----------------------------------------------------------------------------- sensors
+class Sensor(Object):
+    _type_name = "Sensor"
+
+    def __init__(self):
+        super().__init__()
+        self._to_world = torch.eye(4, dtype=torch.float32, device=_dev())
+        self.m_enable_edges = False
+
+    @property
+    def to_world(self):
+        return Matrix4fD._wrap(self._to_world)
+
+    @to_world.setter
+    def to_world(self, m):
+        self._to_world = _mat(m)
+
+
+def perspective(fov, near_, far_):
+    """reference include/psdr/core/transform.h:45-60"""
+    recip = 1.0 / (far_ - near_)
+    cot = 1.0 / math.tan(math.radians(fov * 0.5))
+    m = np.diag([cot, cot, far_ * recip, 0.0])
+    m[2, 3] = -near_ * far_ * recip
+    m[3, 2] = 1.0
+    return m
+
+
+def look_at(origin, target, up):
+    """reference transform.h:68-79"""
+    o, t, u = (np.asarray(x, dtype=np.float64) for x in (origin, target, up))
+    d = (t - o) / np.linalg.norm(t - o)
+    left = np.cross(u, d); left /= np.linalg.norm(left)
+    new_up = np.cross(d, left)
+    m = np.eye(4)
+    m[:3, 0], m[:3, 1], m[:3, 2], m[:3, 3] = left, new_up, d, o
+    return m
+
+
+class PerspectiveCamera(Sensor):
+    """reference include/psdr/sensor/perspective.h, src/sensor/perspective.cpp"""
+    _type_name = "PerspectiveCamera"
+
+    def __init__(self, fov_x, near=0.1, far=1e4):
+        super().__init__()
+        self.m_fov_x, self.m_near_clip, self.m_far_clip = float(fov_x), float(near), float(far)
+
+    def to_string(self):
+        return "PerspectiveCamera"
+
+    def configure(self, scene):
+        """perspective.cpp:11-112 -> dict of tensors for this sensor."""
+        W, H = scene.opts.width, scene.opts.height
+        aspect = float(W) / float(H)
+        tw = self._to_world
+        det = torch.det(tw[:3, :3].detach().double()).item()
+        psdr_assert(abs(det - 1.0) < 1e-4, "Sensor transformation should not involve scaling!")   # sensor.cpp:8-12
+        c2s = (np.diag([-0.5, -0.5 * aspect, 1.0, 1.0]) @
+               np.array([[1, 0, 0, -1.0], [0, 1, 0, -1.0 / aspect], [0, 0, 1, 0], [0, 0, 0, 1.0]]) @
+               perspective(self.m_fov_x, self.m_near_clip, self.m_far_clip))
+        s2c = np.linalg.inv(c2s)
+        c2s_t = torch.as_tensor(c2s, dtype=torch.float32, device=tw.device)
+        s2c_t = torch.as_tensor(s2c, dtype=torch.float32, device=tw.device)
+        w2s = c2s_t @ torch.linalg.inv(tw)
+        cam_pos = transform_pos(tw, torch.zeros(1, 3, device=tw.device))[0]
+        cam_dir = transform_dir(tw, torch.tensor([[0., 0., 1.]], device=tw.device))[0]
+
+        def tp(x, y):
+            v = np.array([x, y, 0.0, 1.0]); r = s2c @ v
+            return r[:3] / r[3]
+        v00, v10, v11, vc = tp(0, 0), tp(1, 0), tp(1, 1), tp(.5, .5)
+        inv_area = float(np.dot(vc, vc) / (np.linalg.norm(v00 - v10) * np.linalg.norm(v11 - v10)))
+        cam = torch.zeros(_abi.CAM_WORDS, dtype=torch.float32, device=tw.device)
+        cam[0:16] = s2c_t.reshape(-1)
+        cam[16:32] = tw.detach().reshape(-1)
+        cam[32:48] = w2s.detach().reshape(-1)
+        cam[48:51] = cam_pos.detach()
+        cam[51:54] = cam_dir.detach()
+        cam[54] = inv_area
+        out = {"cam": cam.contiguous(), "cam_to_world": tw, "prim_edge": None, "prim_cmf": None, "prim_pmf": None,
+               "prim_sum": 0.0, "num_prim_edges": 0}
+
+        # ---- primary-edge list, perspective.cpp:39-111
+        self.m_enable_edges = False
+        if scene.opts.sppe > 0:
+            rows = []
+            for mesh in scene.m_meshes:
+                if not mesh.enable_edges or mesh._edge_indices is None or mesh._edge_indices.shape[0] == 0:
+                    continue
+                ei = mesh._edge_indices_dev
+                tinfo = mesh._triangle_info
+                psdr_assert(bool((ei[:, 2] >= 0).all()))
+                valid = ei[:, 3] >= 0
+                f1 = torch.where(valid, ei[:, 3], torch.zeros_like(ei[:, 3])).long()
+                f0 = ei[:, 2].long()
+                vm = valid.unsqueeze(-1).to(torch.float32)
+                e0 = _normalize(cam_pos - tinfo[f0, 0:3])
+                # masked gather reads zeros for invalid lanes: normalize(cam_pos - 0)
+                e1 = _normalize(cam_pos - tinfo[f1, 0:3] * vm)
+                n0 = tinfo[f0, 18:21]
+                n1 = tinfo[f1, 18:21] * vm
+                d0, d1, dn = (e0 * n0).sum(-1), (e1 * n1).sum(-1), (n0 * n1).sum(-1)
+                if mesh.use_face_normals:
+                    skip = valid & (((d0 < Epsilon) & (d1 < Epsilon)) | (dn > 1.0 - Epsilon))
+                    keep = ~skip
+                else:
+                    keep = (~valid) | ((d0 > Epsilon) ^ (d1 > Epsilon))
+                info = ei[keep.detach()]
+                psdr_assert(info.shape[0] > 0)
+                p0 = mesh._vertex_positions[info[:, 0].long()]
+                p1 = mesh._vertex_positions[info[:, 1].long()]
+                q0 = transform_pos(w2s, p0)[:, :2]
+                q1 = transform_pos(w2s, p1)[:, :2]
+                e = (q1 - q0).detach()
+                ln = torch.sqrt((e * e).sum(-1))
+                e = e / ln.unsqueeze(-1)
+                nrm = torch.stack([-e[:, 1], e[:, 0]], dim=-1)
+                rows.append(torch.cat([q0, q1, nrm, ln.unsqueeze(-1), torch.zeros_like(ln).unsqueeze(-1)], dim=-1))
+            if rows:
+                pe = torch.cat(rows, dim=0).contiguous()
+                d = DiscreteDistribution(); d.init(pe[:, 6].detach())
+                out.update(prim_edge=pe, prim_cmf=d.m_cmf, prim_pmf=d.m_pmf, prim_sum=d.m_sum,
+                           num_prim_edges=int(pe.shape[0]))
+                self.m_enable_edges = True
+        return out
+
+
+# ------------------------------------------------------------------------------- mesh
+def load_obj(fname):
+    """Minimal OBJ reader standing in for tinyobj::LoadObj(triangulate=true)
+    (reference src/shape/mesh.cpp:62-138): v / vt / f with v, v/vt, v//vn, v/vt/vn corner
+    forms, negative indices, polygons fan-triangulated as (a,b,c),(a,c,d) like tinyobj does
+    for convex quads.  Returns (verts [V,3] f32, uvs [n,2] f32 or None, faces [F,3] i32, uv_faces or None)."""
+    verts, uvs, faces, uvfaces = [], [], [], []
+    with open(fname, "r") as f:
+        for line in f:
+            if not line or line[0] == "#":
+                continue
+            parts = line.split()
+            if not parts:
+                continue
+            tag = parts[0]
+            if tag == "v":
+                verts.append((float(parts[1]), float(parts[2]), float(parts[3])))
+            elif tag == "vt":
+                uvs.append((float(parts[1]), float(parts[2]) if len(parts) > 2 else 0.0))
+            elif tag == "f":
+                vi, ti = [], []
+                for c in parts[1:]:
+                    sp = c.split("/")
+                    i = int(sp[0]); vi.append(i - 1 if i > 0 else len(verts) + i)
+                    if len(sp) > 1 and sp[1]:
+                        j = int(sp[1]); ti.append(j - 1 if j > 0 else len(uvs) + j)
+                    else:
+                        ti.append(-1)
+                for k in range(1, len(vi) - 1):
+                    faces.append((vi[0], vi[k], vi[k + 1]))
+                    uvfaces.append((ti[0], ti[k], ti[k + 1]))
+    v = np.asarray(verts, dtype=np.float32).reshape(-1, 3)
+    fa = np.asarray(faces, dtype=np.int32).reshape(-1, 3)
+    if uvs:
+        return v, np.asarray(uvs, dtype=np.float32).reshape(-1, 2), fa, np.asarray(uvfaces, dtype=np.int32).reshape(-1, 3)
+    return v, None, fa, None
+
+
+def build_edge_indices(faces, fname="<mesh>"):
+    """Edge topology, reference src/shape/mesh.cpp:154-196: std::map keyed by the sorted vertex
+    pair (iteration = lexicographic order); value = [opposite vertex of the first face, face ids].
+    Returns int32 [E,5] = v0, v1, face0, face1 (-1 on boundary), opposite vertex of face0."""
+    F = faces.shape[0]
+    if F == 0:
+        return np.zeros((0, 5), dtype=np.int32)
+    a = faces[:, [0, 1, 2]].reshape(-1)
+    b = faces[:, [1, 2, 0]].reshape(-1)
+    c = faces[:, [2, 0, 1]].reshape(-1)
+    fid = np.repeat(np.arange(F, dtype=np.int64), 3)
+    k0, k1 = np.minimum(a, b).astype(np.int64), np.maximum(a, b).astype(np.int64)
+    order = np.lexsort((np.arange(3 * F), k1, k0))           # stable within a key: insertion order
+    k0s, k1s, cs, fs = k0[order], k1[order], c[order], fid[order]
+    new = np.ones(3 * F, dtype=bool)
+    new[1:] = (k0s[1:] != k0s[:-1]) | (k1s[1:] != k1s[:-1])
+    start = np.nonzero(new)[0]
+    count = np.diff(np.append(start, 3 * F))
+    if (count > 2).any():
+        raise RuntimeError("Edge shared by more than 2 faces: " + fname)
+    E = start.shape[0]
+    out = np.empty((E, 5), dtype=np.int32)
+    out[:, 0], out[:, 1] = k0s[start], k1s[start]
+    out[:, 2] = fs[start]
+    out[:, 4] = cs[start]
+    two = count == 2
+    out[:, 3] = -1
+    out[two, 3] = fs[start[two] + 1]
+    if (out[two, 2] == out[two, 3]).any():
+        raise RuntimeError("Duplicated faces: " + fname)
+    return out
+
+
+def process_mesh(verts, faces):
+    """reference src/shape/mesh.cpp:20-51 -> (triangle_info [F,22], vertex_normals [V,3])."""
+    f0, f1, f2 = faces[:, 0].long(), faces[:, 1].long(), faces[:, 2].long()
+    p0 = verts[f0]
+    e1 = verts[f1] - p0
+    e2 = verts[f2] - p0
+    fn = torch.cross(e1, e2, dim=-1)
+    fa = torch.sqrt((fn * fn).sum(-1))
+    vn = torch.zeros_like(verts)
+    vw = torch.zeros(verts.shape[0], dtype=verts.dtype, device=verts.device)
+    for fi in (f0, f1, f2):
+        vn = vn.index_add(0, fi, fn)
+        vw = vw.index_add(0, fi, fa)
+    vn = _normalize(vn / vw.unsqueeze(-1))
+    n0, n1, n2 = vn[f0], vn[f1], vn[f2]
+    fn = fn / fa.unsqueeze(-1)
+    fa = fa * 0.5
+    return torch.cat([p0, e1, e2, n0, n1, n2, fn, fa.unsqueeze(-1)], dim=-1), vn
+
+
+class Mesh(Object):
+    """reference include/psdr/shape/mesh.h, src/shape/mesh.cpp"""
+    _type_name = "Mesh"
+
+    def __init__(self):
+        super().__init__()
+        self.m_ready = False
+        self.use_face_normals = False
+        self.m_has_uv = False
+        self.enable_edges = True
+        d = _dev()
+        self._to_world_raw = torch.eye(4, device=d)
+        self._to_world_left = torch.eye(4, device=d)
+        self._to_world_right = torch.eye(4, device=d)
+        self.bsdf = None
+        self.m_emitter = None
+        self.num_vertices = 0
+        self.num_faces = 0
+        self._vertex_positions_raw = None
+        self._vertex_normals_raw = None
+        self._vertex_uv = None
+        self._face_indices = None
+        self._face_uv_indices = None
+        self._edge_indices = None       # numpy [E,5]
+        self._edge_indices_dev = None
+        self.m_total_area = 0.0
+        self.m_inv_total_area = 0.0
+        self._triangle_info = None
+        self._vertex_positions = None
+        self._sec_edge_info = None
+        self._face_distrb = None
+
+    # -- loading ---------------------------------------------------------------
+    def load(self, filename, verbose=False):
+        if not os.path.exists(filename):
+            raise RuntimeError("Failed to load OBJ from: " + filename)
+        v, uv, f, uvf = load_obj(filename)
+        self.set_geometry(v, f, uv, uvf, fname=filename)
+        if verbose:
+            print("Loaded %d vertices, %d faces, %d edges. " % (self.num_vertices, self.num_faces,
+                                                              0 if self._edge_indices is None else len(self._edge_indices)))
+
+    def set_geometry(self, verts, faces, uv=None, uv_faces=None, fname="<mesh>"):
+        d = _dev()
+        verts = np.ascontiguousarray(verts, dtype=np.float32).reshape(-1, 3)
+        faces = np.ascontiguousarray(faces, dtype=np.int32).reshape(-1, 3)
+        self.num_vertices, self.num_faces = verts.shape[0], faces.shape[0]
+        self._vertex_positions_raw = torch.as_tensor(verts, device=d)
+        self._face_indices = torch.as_tensor(faces, device=d)
+        self.m_has_uv = uv is not None and len(uv) > 0
+        if self.m_has_uv:
+            self._vertex_uv = torch.as_tensor(np.asarray(uv, dtype=np.float32), device=d)
+            self._face_uv_indices = torch.as_tensor(np.asarray(uv_faces, dtype=np.int32), device=d)
+        self._edge_indices = build_edge_indices(faces, fname) if self.enable_edges else None
+        self._edge_indices_dev = None if self._edge_indices is None else torch.as_tensor(self._edge_indices, device=d)
+        self.m_ready = False
+
+    # -- python surface (src/psdr.cpp:242-265) ----------------------------------
+    def set_transform(self, mat, set_left=True):
+        if set_left:
+            self._to_world_left = _mat(mat)
+        else:
+            self._to_world_right = _mat(mat)
+        self.m_ready = False
+
+    def append_transform(self, mat, append_left=True):
+        if append_left:
+            self._to_world_left = _mat(mat) @ self._to_world_left
+        else:
+            self._to_world_right = self._to_world_right @ _mat(mat)
+        self.m_ready = False
+
+    @property
+    def to_world(self):
+        return Matrix4fD._wrap(self._to_world_raw)
+
+    @property
+    def vertex_positions(self):
+        return Vector3fD._wrap(self._vertex_positions_raw)
+
+    @vertex_positions.setter
+    def vertex_positions(self, v):
+        t = v.t if isinstance(v, ek.ArrayBase) else torch.as_tensor(np.asarray(v, dtype=np.float32), device=_dev())
+        psdr_assert(t.shape == (self.num_vertices, 3), "vertex_positions: wrong size")
+        self._vertex_positions_raw = t
+        self.m_ready = False
+
+    @property
+    def vertex_normals(self):
+        return Vector3fD._wrap(self._vertex_normals_raw)
+
+    @property
+    def vertex_uv(self):
+        return None if self._vertex_uv is None else Vector2fD._wrap(self._vertex_uv)
+
+    @vertex_uv.setter
+    def vertex_uv(self, v):
+        self._vertex_uv = v.t if isinstance(v, ek.ArrayBase) else torch.as_tensor(v, device=_dev())
+
+    @property
+    def face_indices(self):
+        return self._face_indices
+
+    @property
+    def face_uv_indices(self):
+        return self._face_uv_indices
+
+    def edge_indices(self):
+        return None if self._edge_indices is None else self._edge_indices[:, :4].copy()
+
+    def to_string(self):
+        return "Mesh[nv=%d, nf=%d, id=%s]" % (self.num_vertices, self.num_faces, self.id)
+
+    # -- configure, mesh.cpp:215-274 -------------------------------------------
+    def configure(self):
+        if self.bsdf is not None:
+            psdr_assert(not self.bsdf.anisotropic() or not self.use_face_normals)
+        if self.enable_edges and self._edge_indices is None:
+            self._edge_indices = build_edge_indices(self._face_indices.cpu().numpy())
+            self._edge_indices_dev = torch.as_tensor(self._edge_indices, device=_dev())
+        _, self._vertex_normals_raw = process_mesh(self._vertex_positions_raw, self._face_indices)
+        to_world = self._to_world_left @ self._to_world_raw @ self._to_world_right
+        self._vertex_positions = transform_pos(to_world, self._vertex_positions_raw)
+        self._triangle_info, _ = process_mesh(self._vertex_positions, self._face_indices)
+        face_areas = self._triangle_info[:, 21]
+        self.m_total_area = float(face_areas.detach().sum().item())
+        self.m_inv_total_area = 1.0 / self.m_total_area
+        self._triangle_uv = None
+        if self.m_has_uv:
+            fu = self._face_uv_indices.long()
+            self._triangle_uv = torch.cat([self._vertex_uv[fu[:, 0]], self._vertex_uv[fu[:, 1]],
+                                           self._vertex_uv[fu[:, 2]]], dim=-1)
+        self._face_distrb = DiscreteDistribution()
+        self._face_distrb.init(face_areas.detach())
+        self._sec_edge_info = None
+        if self.enable_edges and self._edge_indices is not None and self._edge_indices.shape[0] > 0:
+            ei = self._edge_indices_dev
+            is_b = ei[:, 3] < 0
+            vp, ti = self._vertex_positions, self._triangle_info
+            p0 = vp[ei[:, 0].long()]
+            e1 = vp[ei[:, 1].long()] - p0
+            n0 = ti[ei[:, 2].long(), 18:21]
+            f1 = torch.where(is_b, torch.zeros_like(ei[:, 3]), ei[:, 3]).long()
+            n1 = ti[f1, 18:21] * (~is_b).unsqueeze(-1).to(torch.float32)
+            p2 = vp[ei[:, 4].long()]
+            keep = ((n0 * n1).sum(-1) < 1.0 - EdgeEpsilon).detach()
+            info = torch.cat([p0, e1, n0, n1, p2, is_b.to(torch.float32).unsqueeze(-1)], dim=-1)
+            self._sec_edge_info = info[keep]
+        self.m_ready = True
+
+    def dump(self, fname):
+        """OBJ writer, reference mesh.cpp:354-418 (raw vertices, 1-based faces)."""
+        v = self._vertex_positions_raw.detach().cpu().numpy()
+        f = self._face_indices.cpu().numpy()
+        with open(fname, "w") as o:
+            for p in v:
+                o.write("v %.9g %.9g %.9g\n" % (p[0], p[1], p[2]))
+            if self.m_has_uv:
+                for t in self._vertex_uv.detach().cpu().numpy():
+                    o.write("vt %.9g %.9g\n" % (t[0], t[1]))
+                fu = self._face_uv_indices.cpu().numpy()
+                for a, b in zip(f, fu):
+                    o.write("f %d/%d %d/%d %d/%d\n" % (a[0] + 1, b[0] + 1, a[1] + 1, b[1] + 1, a[2] + 1, b[2] + 1))
+            else:
+                for a in f:
+                    o.write("f %d %d %d\n" % (a[0] + 1, a[1] + 1, a[2] + 1))
+
+
+# ------------------------------------------------------------------------------ scene
+def _parse_vector(s, length, allow_empty=False):
+    vals = [float(x) for x in s.replace(",", " ").split()]
+    psdr_assert(len(vals) <= length)
+    if len(vals) < length:
+        if not allow_empty:
+            raise RuntimeError("Vector too short: [%s]" % s)
+        vals = vals + [vals[-1] if vals else 0.0] * (length - len(vals))
+    return vals
+
+
+def _rotate_deg(axis, angle_deg):
+    a = np.asarray(axis, dtype=np.float64)
+    a = a / np.linalg.norm(a)        # enoki::rotate normalises nothing; XML axes are unit vectors
+    ang = math.radians(angle_deg)
+    s, c = math.sin(ang), math.cos(ang)
+    x, y, z = a
+    cm = 1 - c
+    return np.array([[c + x * x * cm, x * y * cm - z * s, x * z * cm + y * s, 0],
+                     [y * x * cm + z * s, c + y * y * cm, y * z * cm - x * s, 0],
+                     [z * x * cm - y * s, z * y * cm + x * s, c + z * z * cm, 0],
+                     [0, 0, 0, 1.0]])
+
+
+def _load_transform(node):
+    """reference src/scene/scene_loader.cpp:80-127: result = T_child * result in document order."""
+    result = np.eye(4)
+    if node is None:
+        return result
+    name = node.get("name", "")
+    psdr_assert(name in ("to_world", "toWorld"), "Invalid transformation name: " + name)
+    for c in node:
+        if c.tag == "translate":
+            m = np.eye(4); m[:3, 3] = [float(c.get("x", 0)), float(c.get("y", 0)), float(c.get("z", 0))]
+        elif c.tag == "rotate":
+            m = _rotate_deg([float(c.get("x", 0)), float(c.get("y", 0)), float(c.get("z", 0))], float(c.get("angle", 0)))
+        elif c.tag == "scale":
+            m = np.diag([float(c.get("x", 1)), float(c.get("y", 1)), float(c.get("z", 1)), 1.0])
+        elif c.tag in ("look_at", "lookAt", "lookat"):
+            m = look_at(_parse_vector(c.get("origin"), 3), _parse_vector(c.get("target"), 3), _parse_vector(c.get("up"), 3))
+        elif c.tag == "matrix":
+            m = np.asarray(_parse_vector(c.get("value"), 16)).reshape(4, 4)
+        else:
+            raise RuntimeError("Unsupported transformation: " + c.tag)
+        result = m @ result
+    return result
+
+
+def _find_child(node, names, allow_empty=False):
+    for c in node:
+        if c.get("name") in names:
+            return c
+    if not allow_empty:
+        raise RuntimeError("Missing child node: " + sorted(names)[0])
+    return None
+
+
+def _load_rgb(node):
+    if node.tag == "float":
+        return [float(node.get("value"))] * 3
+    if node.tag == "rgb":
+        return _parse_vector(node.get("value"), 3, True)
+    raise RuntimeError("Unsupported RGB type: " + node.tag)
+
+
+def _load_texture(node, bitmap, base_dir):
+    if node.tag == "texture":
+        psdr_assert(node.get("type") == "bitmap", "Unsupported texture type: %s" % node.get("type"))
+        fn = node.find("string")
+        psdr_assert(fn is not None and fn.get("name") == "filename", "Failed to retrieve bitmap filename")
+        bitmap.load_openexr(_resolve(fn.get("value"), base_dir))
+    elif bitmap.channels == 1:
+        bitmap.fill(float(node.get("value")))
+    else:
+        bitmap.fill(_load_rgb(node))
+
+
+def _resolve(path, base_dir):
+    """Scene files name assets relative to the process cwd (reference behaviour); fall back to
+    the XML's directory and its parents so fixtures load from anywhere."""
+    if os.path.isabs(path) or os.path.exists(path):
+        return path
+    d = base_dir
+    for _ in range(4):
+        if d is None:
+            break
+        cand = os.path.normpath(os.path.join(d, path))
+        if os.path.exists(cand):
+            return cand
+        d = os.path.dirname(d)
+    return path
+
+
+class Scene(Object):
+    """reference include/psdr/scene/scene.h, src/scene/scene.cpp"""
+    _type_name = "Scene"
+
+    def __init__(self):
+        super().__init__()
+        self.opts = RenderOption(0, 0, 0, 0, 0)
+        self.m_loaded = False
+        self.m_sensors, self.m_emitters, self.m_bsdfs, self.m_meshes = [], [], [], []
+        self.param_map = {}
+        self.num_sensors = 0
+        self.num_meshes = 0
+        self._tables = None
+        self._sensor_tables = []
+        self._native = None            # psdr_scene_t
+        self._sample_count = [0, 0, 0]
+        self._rng_offset = [0, 0, 0]
+        self._configured = False
+        self._version = 0
+
+    def __del__(self):
+        try:
+            if self._native is not None:
+                _abi.load_hip().psdr_scene_destroy(self._native)
+        except Exception:
+            pass
+
+    # -- loading (src/scene/scene_loader.cpp) -----------------------------------
+    def load_file(self, file_name, auto_configure=True):
+        try:
+            root = ET.parse(file_name).getroot()
+        except (ET.ParseError, OSError):
+            raise RuntimeError("XML parsing failed")
+        self._load_scene(root, os.path.dirname(os.path.abspath(file_name)))
+        if auto_configure:
+            self.configure()
+
+    def load_string(self, scene_xml, auto_configure=True):
+        try:
+            root = ET.fromstring(scene_xml)
+        except ET.ParseError:
+            raise RuntimeError("XML parsing failed")
+        self._load_scene(root, None)
+        if auto_configure:
+            self.configure()
+
+    def _load_scene(self, root, base_dir):
+        psdr_assert(not self.m_loaded, "Scene already loaded!")
+        if root.tag != "scene":
+            root = root.find("scene")
+        for node in root.findall("sensor"):
+            self._load_sensor(node)
+        for node in root.findall("bsdf"):
+            self._load_bsdf(node, base_dir)
+        for node in root.findall("emitter"):
+            raise RuntimeError("Unsupported emitter: " + str(node.get("type")))   # envmap: SURVEY 8(f) N2
+        for node in root.findall("shape"):
+            self._load_shape(node, base_dir)
+        self._build_param_map()
+        self.num_sensors, self.num_meshes = len(self.m_sensors), len(self.m_meshes)
+        self.m_loaded = True
+
+    def _build_param_map(self):
+        for name, arr in (("Mesh", self.m_meshes), ("Emitter", self.m_emitters), ("Sensor", self.m_sensors)):
+            for i, obj in enumerate(arr):
+                self.param_map["%s[%d]" % (name, i)] = obj
+                if obj.id:
+                    key = "%s[id=%s]" % (name, obj.id)
+                    psdr_assert(key not in self.param_map, "Duplicate id: " + obj.id)
+                    self.param_map[key] = obj
+
+    def _load_sensor(self, node):
+        film, sampler = node.find("film"), node.find("sampler")
+        if not self.m_sensors:
+            psdr_assert(film is not None, "Missing film node")
+            psdr_assert(sampler is not None, "Missing sampler node")
+            self.opts.width = int(_find_child(film, {"width"}).get("value"))
+            self.opts.height = int(_find_child(film, {"height"}).get("value"))
+            spp = int(sampler.find("integer").get("value"))
+            self.opts.spp = self.opts.sppe = self.opts.sppse = spp
+        else:
+            psdr_assert(film is None, "Duplicate film node")
+            psdr_assert(sampler is None, "Duplicate sampler node")
+        if node.get("type") != "perspective":
+            raise RuntimeError("Unsupported sensor: " + str(node.get("type")))
+        to_world = _load_transform(node.find("transform"))
+        fov_x = float(_find_child(node, {"fov"}).get("value"))
+        ax = _find_child(node, {"fov_axis", "fovAxis"}, True)
+        if ax is not None and ax.get("value") != "x":
+            raise RuntimeError("Unsupported fov-axis: " + ax.get("value"))
+        nn = _find_child(node, {"near_clip", "nearClip"}, True)
+        ff = _find_child(node, {"far_clip", "farClip"}, True)
+        s = PerspectiveCamera(fov_x, float(nn.get("value", 0.1)) if nn is not None else 0.1,
+                              float(ff.get("value", 1e4)) if ff is not None else 1e4)
+        s.to_world = to_world
+        self.m_sensors.append(s)
+
+    def _load_bsdf(self, node, base_dir):
+        bid = node.get("id")
+        psdr_assert(bid, "BSDF must have an id")
+        t = node.get("type")
+        if t == "diffuse":
+            b = Diffuse()
+            _load_texture(_find_child(node, {"reflectance"}), b.reflectance, base_dir)
+        elif t == "roughconductor":
+            b = RoughConductor()
+            alpha, eta, k = (_find_child(node, {n}) for n in ("alpha", "eta", "k"))
+            _load_texture(alpha, b.alpha_u, base_dir); _load_texture(alpha, b.alpha_v, base_dir)
+            _load_texture(eta, b.eta, base_dir); _load_texture(k, b.k, base_dir)
+        else:
+            raise RuntimeError("Unsupported BSDF: " + str(t))
+        b.id = bid
+        self.add_bsdf(b)
+
+    def add_bsdf(self, b):
+        self.m_bsdfs.append(b)
+        self.param_map["BSDF[%d]" % (len(self.m_bsdfs) - 1)] = b
+        key = "BSDF[id=%s]" % b.id
+        psdr_assert(key not in self.param_map, "Duplicate BSDF id: " + b.id)
+        self.param_map[key] = b
+
+    def _load_shape(self, node, base_dir):
+        if node.get("type") != "obj":
+            raise RuntimeError("Unsupported shape: " + str(node.get("type")))
+        name = node.find("string")
+        psdr_assert(name is not None and name.get("name") == "filename")
+        mesh = Mesh()
+        mesh.load(_resolve(name.get("value"), base_dir))
+        ref = node.find("ref")
+        psdr_assert(ref is not None, "Missing BSDF reference")
+        key = "BSDF[id=%s]" % ref.get("id")
+        psdr_assert(key in self.param_map, "Unknown BSDF id: " + str(ref.get("id")))
+        mesh.bsdf = self.param_map[key]
+        psdr_assert(node.find("bsdf") is None, "BSDFs declared under shapes are not supported.")
+        fn = _find_child(node, {"face_normals", "faceNormals"}, True)
+        mesh.use_face_normals = fn is not None and fn.get("value") == "true"
+        if node.get("id"):
+            mesh.id = node.get("id")
+        em = node.find("emitter")
+        if em is not None:
+            psdr_assert(em.get("type") == "area", "Unsupported emitter: " + str(em.get("type")))
+            e = AreaLight(_load_rgb(_find_child(em, {"radiance"})), mesh)
+            self.m_emitters.append(e)
+            mesh.m_emitter = e
+        mesh._to_world_raw = torch.as_tensor(_load_transform(node.find("transform")), dtype=torch.float32, device=_dev())
+        self.m_meshes.append(mesh)
+
+    # programmatic construction (used by fixtures / tests)
+    def add_mesh(self, mesh, bsdf, emitter_radiance=None):
+        mesh.bsdf = bsdf
+        if emitter_radiance is not None:
+            e = AreaLight(emitter_radiance, mesh)
+            self.m_emitters.append(e)
+            mesh.m_emitter = e
+        self.m_meshes.append(mesh)
+
+    def add_sensor(self, sensor):
+        self.m_sensors.append(sensor)
+
+    def finalize(self):
+        self._build_param_map()
+        self.num_sensors, self.num_meshes = len(self.m_sensors), len(self.m_meshes)
+        self.m_loaded = True
+
+    # -- configure (src/scene/scene.cpp:56-278) ---------------------------------
+    def configure(self):
+        psdr_assert(self.m_loaded, "Scene not loaded yet!")
+        t_start = time.perf_counter()
+        o = self.opts
+        d = _dev()
+        # samplers: re-seed (offset 0) only when the slot count changed, scene.cpp:65-79
+        for k, n in enumerate((o.spp, o.sppe, o.sppse)):
+            if n > 0:
+                count = o.height * o.width * n
+                if self._sample_count[k] != count:
+                    self._sample_count[k] = count
+                    self._rng_offset[k] = 0
+        psdr_assert(self.m_meshes, "Missing meshes!")
+        psdr_assert(self.m_sensors, "Missing sensor!")
+        tri_rows, uv_rows, tri_mesh, sec_rows = [], [], [], []
+        has_uv = any(m.m_has_uv for m in self.m_meshes)
+        face_offset = [0]
+        for i, mesh in enumerate(self.m_meshes):
+            mesh.configure()
+            tri_rows.append(mesh._triangle_info)
+            flag = _abi.TRI_FACE_NORMALS if mesh.use_face_normals else 0
+            tri_mesh.append(torch.full((mesh.num_faces,), i | flag, dtype=torch.int32, device=d))
+            if has_uv:
+                uv_rows.append(mesh._triangle_uv if mesh._triangle_uv is not None
+                               else torch.zeros(mesh.num_faces, 6, device=d))
+            if o.sppse > 0 and mesh.enable_edges and mesh._sec_edge_info is not None:
+                sec_rows.append(mesh._sec_edge_info)
+            face_offset.append(face_offset[-1] + mesh.num_faces)
+        T = face_offset[-1]
+        tri_info = torch.cat([torch.cat(tri_rows, dim=0), torch.zeros(T, 2, device=d)], dim=-1).contiguous()
+        tb = {"tri_info": tri_info, "tri_mesh": torch.cat(tri_mesh).contiguous(), "num_tris": T,
+              "tri_uv": None, "face_offset": face_offset}
+        if has_uv:
+            tb["tri_uv"] = torch.cat([torch.cat(uv_rows, dim=0).detach(), torch.zeros(T, 2, device=d)], dim=-1).contiguous()
+        # AABB (log only)
+        allv = torch.cat([m._vertex_positions.detach() for m in self.m_meshes], dim=0)
+        self.m_lower, self.m_upper = allv.min(dim=0)[0], allv.max(dim=0)[0]
+
+        # sensors
+        self._sensor_tables = [s.configure(self) for s in self.m_sensors]
+
+        # BSDF records + texel pool
+        bsdf_ids = {id(b): i for i, b in enumerate(self.m_bsdfs)}
+        pool, rec, off = [], [], 0
+
+        def put(bm):
+            nonlocal off
+            t = bm.tensor()
+            w, h = bm.resolution
+            pool.append(t.reshape(-1))
+            o_ = off
+            off += t.numel()
+            return [o_, w, h]
+        for b in self.m_bsdfs:
+            if isinstance(b, Diffuse):
+                r = [_abi.BSDF_DIFFUSE] + put(b.reflectance) + [0, 1, 1] * 4
+            elif isinstance(b, RoughConductor):
+                r = ([_abi.BSDF_ROUGHCONDUCTOR] + put(b.specular_reflectance) + put(b.alpha_u) + put(b.alpha_v) +
+                     put(b.eta) + put(b.k))
+            else:
+                raise RuntimeError("Unsupported BSDF: " + b.type_name())
+            rec.append(r)
+        tb["bsdf_rec"] = torch.tensor(rec if rec else [[0] * 16], dtype=torch.int32, device=d).contiguous()
+        tb["texels"] = (torch.cat(pool) if pool else torch.zeros(1, device=d)).to(torch.float32).contiguous()
+        tb["mesh_bsdf"] = torch.tensor([bsdf_ids.get(id(m.bsdf), -1) for m in self.m_meshes], dtype=torch.int32, device=d)
+
+        # emitters, scene.cpp:183-196 + area.cpp:10-16
+        em_ids = {id(e): i for i, e in enumerate(self.m_emitters)}
+        tb["mesh_emitter"] = torch.tensor([em_ids.get(id(m.m_emitter), -1) for m in self.m_meshes], dtype=torch.int32, device=d)
+        Ne = len(self.m_emitters)
+        ef = torch.zeros(max(Ne, 1), _abi.EMITTER_F_STRIDE, device=d)
+        ei = torch.zeros(max(Ne, 1), _abi.EMITTER_I_STRIDE, dtype=torch.int32, device=d)
+        rad = torch.zeros(max(Ne, 1), 3, device=d)
+        cmfs, pmfs, coff = [], [], 0
+        if Ne:
+            weights = []
+            for e in self.m_emitters:
+                e.configure()
+                weights.append(e.m_sampling_weight)
+            ed = DiscreteDistribution(); ed.init(torch.tensor(weights, dtype=torch.float32, device=d))
+            inv_total = np.float32(1.0) / np.float32(ed.m_sum)
+            rads = []
+            for i, e in enumerate(self.m_emitters):
+                e.m_sampling_weight = float(np.float32(e.m_sampling_weight) * inv_total)
+                mi = self.m_meshes.index(e.m_mesh)
+                fd = e.m_mesh._face_distrb
+                ef[i, 3], ef[i, 4], ef[i, 5] = e.m_sampling_weight, e.m_mesh.m_inv_total_area, fd.m_sum
+                ei[i] = torch.tensor([mi, face_offset[mi], e.m_mesh.num_faces, coff], dtype=torch.int32)
+                cmfs.append(fd.m_cmf); pmfs.append(fd.m_pmf); coff += fd.m_size
+                rads.append(e.radiance.t.reshape(3))
+            rad = torch.stack(rads)
+            ef = torch.cat([rad.detach(), ef[:, 3:]], dim=-1)
+            tb["emitter_cmf"], tb["emitter_pmf"], tb["emitter_sum"] = ed.m_cmf, ed.m_pmf, ed.m_sum
+        else:
+            z = torch.zeros(1, device=d)
+            tb["emitter_cmf"], tb["emitter_pmf"], tb["emitter_sum"] = z, z, 0.0
+        tb["emitter_f"], tb["emitter_i"], tb["emitter_rad"] = ef.contiguous(), ei.contiguous(), rad
+        tb["face_cmf"] = torch.cat(cmfs).contiguous() if cmfs else torch.zeros(1, device=d)
+        tb["face_pmf"] = torch.cat(pmfs).contiguous() if pmfs else torch.zeros(1, device=d)
+        tb["num_emitters"] = Ne
+
+        # secondary edges, scene.cpp:219-244
+        if o.sppse > 0 and sec_rows:
+            se = torch.cat(sec_rows, dim=0).contiguous()
+            e1 = se[:, 3:6].detach()
+            sd = DiscreteDistribution(); sd.init(torch.sqrt((e1 * e1).sum(-1)))
+            tb.update(sec_edge=se, sec_cmf=sd.m_cmf, sec_pmf=sd.m_pmf, sec_sum=sd.m_sum, num_sec_edges=int(se.shape[0]))
+        else:
+            tb.update(sec_edge=None, sec_cmf=None, sec_pmf=None, sec_sum=0.0, num_sec_edges=0)
+        self._tables = tb
+        self._version += 1
+        self._configured = True
+        self._bvh_version = -1
+        if o.log_level > 0:
+            self.log("AABB: [lower = %s, upper = %s]" % (self.m_lower.tolist(), self.m_upper.tolist()))
+            if o.sppe > 0:
+                self.log("(%s) primary edges initialized." % ", ".join(str(s["num_prim_edges"]) for s in self._sensor_tables))
+            if o.sppse > 0:
+                self.log("%d secondary edges initialized." % tb["num_sec_edges"])
+            self.log("Configured in %g seconds." % (time.perf_counter() - t_start))
+
+    def is_ready(self):
+        return self._configured and all(m.m_ready for m in self.m_meshes)
+
+    def to_string(self):
+        return "Scene[\n  # Sensors\n%s\n  # BSDFs\n%s\n  # Meshes\n%s\n]" % tuple(
+            "\n".join("  " + x.to_string() for x in arr) for arr in (self.m_sensors, self.m_bsdfs, self.m_meshes))
+
+    # -- descriptor for the C ABI ------------------------------------------------
+    def tables(self, sensor_id=0):
+        """Flat dict of tensors for one sensor (scene tables + that sensor's camera/primary edges)."""
+        psdr_assert(self._configured, "Input scene must be configured!")
+        psdr_assert(0 <= sensor_id < self.num_sensors, "Invalid sensor id!")
+        t = dict(self._tables)
+        t.update(self._sensor_tables[sensor_id])
+        t["width"], t["height"] = self.opts.width, self.opts.height
+        t["num_meshes"], t["num_bsdfs"] = len(self.m_meshes), len(self.m_bsdfs)
+        return t
+
+
+def make_desc(tb, guide=None, device=None):
+    """SceneDesc (+ list of tensors kept alive) from a tables dict.  Pointers are device pointers
+    if the tensors live on the GPU, host pointers otherwise (oracle)."""
+    keep = []
+
+    def p(x, dtype=torch.float32):
+        if x is None:
+            return None
+        x = x.detach()
+        if device is not None:
+            x = x.to(device)
+        x = x.to(dtype).contiguous()
+        keep.append(x)
+        return x.data_ptr()
+    d = _abi.SceneDesc()
+    d.width, d.height = tb["width"], tb["height"]
+    d.num_tris, d.num_meshes, d.num_bsdfs, d.num_emitters = tb["num_tris"], tb["num_meshes"], tb["num_bsdfs"], tb["num_emitters"]
+    d.num_sec_edges, d.num_prim_edges = tb["num_sec_edges"], tb["num_prim_edges"]
+    d.num_texels = int(tb["texels"].numel())
+    d.tri_info, d.tri_uv = p(tb["tri_info"]), p(tb["tri_uv"])
+    i32 = torch.int32
+    d.tri_mesh, d.mesh_bsdf, d.mesh_emitter = p(tb["tri_mesh"], i32), p(tb["mesh_bsdf"], i32), p(tb["mesh_emitter"], i32)
+    d.bsdf_rec, d.texels = p(tb["bsdf_rec"], i32), p(tb["texels"])
+    d.emitter_f, d.emitter_i = p(tb["emitter_f"]), p(tb["emitter_i"], i32)
+    d.face_cmf, d.face_pmf = p(tb["face_cmf"]), p(tb["face_pmf"])
+    d.emitter_cmf, d.emitter_pmf, d.emitter_sum = p(tb["emitter_cmf"]), p(tb["emitter_pmf"]), tb["emitter_sum"]
+    d.cam = p(tb["cam"])
+    d.sec_edge, d.sec_cmf, d.sec_pmf, d.sec_sum = p(tb["sec_edge"]), p(tb["sec_cmf"]), p(tb["sec_pmf"]), tb["sec_sum"]
+    d.prim_edge, d.prim_cmf, d.prim_pmf, d.prim_sum = p(tb["prim_edge"]), p(tb["prim_cmf"]), p(tb["prim_pmf"]), tb["prim_sum"]
+    if guide is not None:
+        reso, cmf, pmf, s = guide
+        d.guide_reso[0], d.guide_reso[1], d.guide_reso[2] = int(reso[0]), int(reso[1]), int(reso[2])
+        d.num_guide_cells = int(reso[0]) * int(reso[1]) * int(reso[2])
+        d.guide_cmf, d.guide_pmf, d.guide_sum = p(cmf), p(pmf), float(s)
+    return d, keep

@@ -1,0 +1,174 @@
+"""Shared helpers for the test-suite: scene set-up, oracle / hostcheck / GPU render front-ends."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import torch
+
+import enoki as ek
+import psdr_cuda
+from enoki._array import _jvp_wrt
+from enoki.cuda_autodiff import Float32 as FloatD, Vector3f as Vector3fD, Matrix4f as Matrix4fD
+from psdr_cuda import _abi
+from psdr_cuda.fixtures import scene_path
+from psdr_cuda.scene import make_desc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+AD_KEYS = list(_abi.TANGENT_FIELDS)
+
+
+def rel_l2(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def load_scene(name, res=32, spp=8, sppe=0, sppse=0, translate=None, device=None):
+    """Scene fixture at a small resolution.  translate = (mesh_id, direction): returns a scalar
+    parameter P (FloatD, requires grad) that translates that mesh by direction * P."""
+    sc = psdr_cuda.Scene()
+    sc.load_file(scene_path(name), False)
+    sc.opts.width = sc.opts.height = res
+    sc.opts.spp, sc.opts.sppe, sc.opts.sppse, sc.opts.log_level = spp, sppe, sppse, 0
+    P = None
+    if translate is not None:
+        P = FloatD(0.)
+        ek.set_requires_gradient(P)
+        sc.param_map["Mesh[%d]" % translate[0]].set_transform(Matrix4fD.translate(Vector3fD(list(translate[1])) * P))
+    sc.configure()
+    return sc, P
+
+
+def tangents_wrt(tb, P):
+    return dict(zip(AD_KEYS, _jvp_wrt([tb.get(k) for k in AD_KEYS], P.t)))
+
+
+# ---------------------------------------------------------------- hostcheck (product code on the CPU)
+_hostcheck = None
+
+
+def hostcheck_lib():
+    global _hostcheck
+    if _hostcheck is None:
+        d = os.path.join(ROOT, "tests", "hostcheck")
+        so = os.path.join(d, "libhostcheck.so")
+        src = os.path.join(d, "hostcheck.cpp")
+        hdrs = [os.path.join(ROOT, "psdr-cuda_amd", "csrc", f) for f in ("psdr_math.h", "psdr_device.h", "psdr_bvh_build.h")]
+        if not os.path.exists(so) or any(os.path.getmtime(f) > os.path.getmtime(so) for f in [src] + hdrs):
+            subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread",
+                                   src, "-o", so])
+        _hostcheck = C.CDLL(so)
+    return _hostcheck
+
+
+def host_render(tb, opts, mode=0, tangents=None, guide=None, nthreads=None):
+    H = hostcheck_lib()
+    tbc = {k: (v.detach().cpu() if isinstance(v, torch.Tensor) else v) for k, v in tb.items()}
+    if guide is not None:
+        guide = (guide[0], guide[1].cpu(), guide[2].cpu(), guide[3])
+    desc, keep = make_desc(tbc, guide, device="cpu")
+    n = tb["width"] * tb["height"] * 3
+    img, dimg = np.zeros(n, np.float32), np.zeros(n, np.float32)
+    tan = _abi.Tangents()
+    for k, t in (tangents or {}).items():
+        if t is not None:
+            t = t.detach().cpu().float().contiguous()
+            keep.append(t)
+            setattr(tan, "d_" + k, t.data_ptr())
+    rc = H.hostcheck_render(C.byref(desc), C.byref(opts), mode, C.byref(tan), C.c_void_p(img.ctypes.data),
+                            C.c_void_p(dimg.ctypes.data), nthreads or os.cpu_count())
+    assert rc == 0
+    return (img.reshape(-1, 3), dimg.reshape(-1, 3)) if mode else img.reshape(-1, 3)
+
+
+# ---------------------------------------------------------------- GPU through the C ABI
+class GpuScene:
+    """Thin ctypes driver of libpsdr_hip.so (exactly what a foreign-language binding would do)."""
+
+    def __init__(self, tb, guide=None):
+        self.lib = _abi.load_hip()
+        self.h = C.c_void_p()
+        _abi.check(self.lib, self.lib.psdr_scene_create(C.byref(self.h)))
+        self.tb = {k: (v.detach().cuda() if isinstance(v, torch.Tensor) else v) for k, v in tb.items()}
+        self.set_guide(guide)
+        _abi.check(self.lib, self.lib.psdr_bvh_build(self.h, None))
+
+    def set_guide(self, guide):
+        if guide is not None:
+            guide = (guide[0], torch.as_tensor(guide[1]).cuda(), torch.as_tensor(guide[2]).cuda(), guide[3])
+        self.desc, self.keep = make_desc(self.tb, guide)
+        _abi.check(self.lib, self.lib.psdr_scene_set_tables(self.h, C.byref(self.desc)))
+
+    def close(self):
+        if self.h:
+            self.lib.psdr_scene_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    @property
+    def n(self):
+        return self.tb["width"] * self.tb["height"] * 3
+
+    def render_c(self, opts):
+        img = torch.empty(self.n, dtype=torch.float32, device="cuda")
+        _abi.check(self.lib, self.lib.psdr_render_c(self.h, C.byref(opts), img.data_ptr(), None))
+        torch.cuda.synchronize()
+        return img.cpu().numpy().reshape(-1, 3)
+
+    def render_d_fwd(self, opts, tangent_sets):
+        K = len(tangent_sets)
+        img = torch.empty(self.n, dtype=torch.float32, device="cuda")
+        dimg = torch.empty(K * self.n, dtype=torch.float32, device="cuda")
+        tarr = (_abi.Tangents * K)()
+        keep = []
+        for k, ts in enumerate(tangent_sets):
+            for name, t in ts.items():
+                if t is not None:
+                    t = t.detach().cuda().float().contiguous()
+                    keep.append(t)
+                    setattr(tarr[k], "d_" + name, t.data_ptr())
+        _abi.check(self.lib, self.lib.psdr_render_d_fwd(self.h, C.byref(opts), K, tarr, img.data_ptr(), dimg.data_ptr(), None))
+        torch.cuda.synchronize()
+        return img.cpu().numpy().reshape(-1, 3), dimg.cpu().numpy().reshape(K, -1, 3)
+
+    def trace(self, o, d, tmax=None):
+        o = torch.as_tensor(np.ascontiguousarray(o, dtype=np.float32)).cuda()
+        d = torch.as_tensor(np.ascontiguousarray(d, dtype=np.float32)).cuda()
+        m = o.shape[0]
+        cols = [o[:, i].contiguous() for i in range(3)] + [d[:, i].contiguous() for i in range(3)]
+        tm = torch.full((m,), float("inf"), device="cuda") if tmax is None else torch.as_tensor(tmax, dtype=torch.float32).cuda()
+        shape = torch.empty(m, dtype=torch.int32, device="cuda"); tri = torch.empty_like(shape)
+        u = torch.empty(m, dtype=torch.float32, device="cuda"); v = torch.empty_like(u)
+        _abi.check(self.lib, self.lib.psdr_trace(self.h, m, *[c.data_ptr() for c in cols], tm.data_ptr(), shape.data_ptr(),
+                                                 tri.data_ptr(), u.data_ptr(), v.data_ptr(), None))
+        torch.cuda.synchronize()
+        return shape.cpu().numpy(), tri.cpu().numpy(), u.cpu().numpy(), v.cpu().numpy()
+
+    def guide_build(self, opts, reso, nrounds):
+        cells = int(reso[0]) * int(reso[1]) * int(reso[2])
+        mass = torch.zeros(cells, dtype=torch.float32, device="cuda")
+        r = (C.c_int32 * 4)(*[int(x) for x in reso])
+        _abi.check(self.lib, self.lib.psdr_guide_build(self.h, C.byref(opts), r, int(nrounds), mass.data_ptr(), None))
+        torch.cuda.synchronize()
+        return mass.cpu().numpy()
+
+    def counters(self):
+        c = (C.c_uint64 * 4)()
+        _abi.check(self.lib, self.lib.psdr_get_counters(self.h, c))
+        return tuple(int(x) for x in c)
+
+
+def camera_rays(tb, n, seed=0):
+    """n random primary rays of the scene's camera (numpy)."""
+    rng = np.random.default_rng(seed)
+    cam = tb["cam"].detach().cpu().numpy().astype(np.float64)
+    s2c, tw = cam[0:16].reshape(4, 4), cam[16:32].reshape(4, 4)
+    s = rng.random((n, 2))
+    v = np.concatenate([s, np.zeros((n, 1)), np.ones((n, 1))], axis=1) @ s2c.T
+    d = v[:, :3] / v[:, 3:4]
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    dw = d @ tw[:3, :3].T
+    o = np.broadcast_to(tw[:3, 3], (n, 3))
+    return o.astype(np.float32), dw.astype(np.float32)

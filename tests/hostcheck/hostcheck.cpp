@@ -1,0 +1,153 @@
+// hostcheck.cpp -- TEST-ONLY harness: runs the PRODUCT's estimator code (csrc/psdr_device.h, PSDR_HD
+// functions) on the host, sample by sample, so that `-m "not gpu"` tests can compare it with the
+// oracle where no GPU exists.  It is never imported by the psdr_cuda package and is not a fallback:
+// the render path (libpsdr_hip.so) only ever executes these functions inside HIP kernels.
+#include "../../psdr-cuda_amd/csrc/psdr_bvh_build.h"
+
+#include <thread>
+#include <vector>
+
+using namespace psdr;
+
+namespace {
+struct HostScene {
+    SceneView sc;
+    Builder b;
+};
+bool setup(HostScene &hs, const psdr_scene_desc *d) {
+    hs.sc.d = *d;
+    int32_t root = 0;
+    if (hs.b.run(d->tri_info, d->num_tris, root)) return false;
+    hs.sc.nodes = hs.b.nodes.data(); hs.sc.btris = hs.b.btris.data(); hs.sc.root = root;
+    return true;
+}
+template <class F> void pfor(long long n, int nt, F f) {
+    std::vector<std::thread> th;
+    long long chunk = (n + nt - 1) / nt;
+    for (int t = 0; t < nt; ++t) {
+        long long a = t * chunk, b = std::min(n, a + chunk);
+        if (a >= b) break;
+        th.emplace_back([=] { f(a, b, t); });
+    }
+    for (auto &x : th) x.join();
+}
+}  // namespace
+
+extern "C" {
+
+int hostcheck_trace(const psdr_scene_desc *d, int m, const float *o, const float *dir, int *tri, float *u, float *v) {
+    HostScene hs;
+    if (!setup(hs, d)) return 1;
+    TraversalStack st;
+    for (int i = 0; i < m; ++i) {
+        Hit h = closest_hit(hs.sc, st, Vec3f{o[3 * i], o[3 * i + 1], o[3 * i + 2]}, Vec3f{dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]}, INFINITY);
+        tri[i] = h.tri; u[i] = h.u; v[i] = h.v;
+    }
+    return 0;
+}
+
+// mode 0: renderC; mode 1: renderD forward (K = 1), all three terms
+int hostcheck_render(const psdr_scene_desc *d, const psdr_render_opts *o, int mode, const psdr_tangents *tan, float *img, float *dimg,
+                     int nthreads) {
+    HostScene hs;
+    if (!setup(hs, d)) return 1;
+    const int W = d->width, H = d->height;
+    const long long WH = (long long) W * H;
+    const size_t n3 = (size_t) WH * 3;
+    nthreads = std::max(1, nthreads);
+    std::vector<std::vector<double>> acc(nthreads, std::vector<double>(n3, 0.0)), dacc(nthreads, std::vector<double>(mode ? n3 : 0, 0.0));
+    LiParams lp{o->integrator, o->bsdf_samples, o->light_samples, o->max_depth, o->hide_emitters, o->field};
+    TangentView<1> tv1; tv1.t[0] = tan ? *tan : psdr_tangents{};
+    const TangentView<0> tv0{};
+    const int nsp = o->spp_end - o->spp_begin;
+    if (o->spp > 0 && nsp > 0) {
+        const RngJump jump = make_rng_jump(o->rng_offset[0]);
+        pfor(WH * nsp, nthreads, [&](long long a, long long b, int t) {
+            TraversalStack st; uint32_t nr = 0;
+            for (long long j = a; j < b; ++j) {
+                const int pixel = (int) (j / nsp), s = o->spp_begin + (int) (j % nsp);
+                const uint64_t slot = (uint64_t) pixel * o->spp + s;
+                if (mode == 0) {
+                    Vec3f r = camera_sample<float>(hs.sc, tv0, st, lp, jump, pixel, slot, nr);
+                    acc[t][pixel * 3] += r.x / o->spp; acc[t][pixel * 3 + 1] += r.y / o->spp; acc[t][pixel * 3 + 2] += r.z / o->spp;
+                } else {
+                    Vec3<Dual<1>> r = camera_sample<Dual<1>>(hs.sc, tv1, st, lp, jump, pixel, slot, nr);
+                    acc[t][pixel * 3] += r.x.v / o->spp; acc[t][pixel * 3 + 1] += r.y.v / o->spp; acc[t][pixel * 3 + 2] += r.z.v / o->spp;
+                    dacc[t][pixel * 3] += r.x.d[0] / o->spp; dacc[t][pixel * 3 + 1] += r.y.d[0] / o->spp; dacc[t][pixel * 3 + 2] += r.z.d[0] / o->spp;
+                }
+            }
+        });
+    }
+    if (mode == 1 && o->sppe > 0 && o->sppe_end > o->sppe_begin && d->num_prim_edges > 0) {
+        const RngJump jump = make_rng_jump(o->rng_offset[1]);
+        const long long i0 = WH * o->sppe_begin, n = WH * (o->sppe_end - o->sppe_begin);
+        pfor(n, nthreads, [&](long long a, long long b, int t) {
+            TraversalStack st; uint32_t nr = 0;
+            for (long long j = a; j < b; ++j) {
+                float tg[1][3];
+                int pix = primary_edge_sample<1>(hs.sc, tv1, st, lp, jump, (uint64_t) (i0 + j), 1.f / o->sppe, tg, nr);
+                if (pix >= 0) for (int c = 0; c < 3; ++c) dacc[t][pix * 3 + c] += tg[0][c];
+            }
+        });
+    }
+    if (mode == 1 && o->sppse > 0 && o->sppse_end > o->sppse_begin && d->num_sec_edges > 0 && o->integrator == PSDR_INTEGRATOR_DIRECT) {
+        const RngJump jump = make_rng_jump(o->rng_offset[2]);
+        const long long i0 = WH * o->sppse_begin, n = WH * (o->sppse_end - o->sppse_begin);
+        const bool guided = d->guide_cmf && d->num_guide_cells > 0;
+        pfor(n, nthreads, [&](long long a, long long b, int t) {
+            TraversalStack st; uint32_t nr = 0;
+            for (long long j = a; j < b; ++j) {
+                Rng rng; rng.init((uint64_t) (i0 + j), jump);
+                float s3[3] = {rng.next(), rng.next(), rng.next()};
+                const float pdf0 = guided ? guide_sample_reuse(hs.sc, s3) : 1.f;
+                Vec3<Dual<1>> v;
+                int pix = secondary_edge_sample<Dual<1>>(hs.sc, tv1, st, s3, v, nr);
+                if (pix >= 0) {
+                    v = zero_nonfinite(v);
+                    const float scale = (pdf0 > kEpsilon ? 1.f / pdf0 : 1.f) / o->sppse;
+                    dacc[t][pix * 3] += v.x.d[0] * scale; dacc[t][pix * 3 + 1] += v.y.d[0] * scale; dacc[t][pix * 3 + 2] += v.z.d[0] * scale;
+                }
+            }
+        });
+    }
+    for (size_t i = 0; i < n3; ++i) {
+        double s = 0, ds = 0;
+        for (int t = 0; t < nthreads; ++t) { s += acc[t][i]; if (mode) ds += dacc[t][i]; }
+        img[i] = (float) s;
+        if (mode && dimg) dimg[i] = (float) ds;
+    }
+    return 0;
+}
+
+int hostcheck_guide(const psdr_scene_desc *d, const int *reso, int nrounds, float *mass, int nthreads) {
+    HostScene hs;
+    if (!setup(hs, d)) return 1;
+    hs.sc.d.guide_cmf = nullptr; hs.sc.d.num_guide_cells = 0;
+    const long long cells = (long long) reso[0] * reso[1] * reso[2], n = cells * reso[3];
+    std::vector<double> m(cells, 0.0);
+    const TangentView<0> tv0{};
+    const RngJump nojump{1ull, 0ull};
+    pfor(cells, std::max(1, nthreads), [&](long long a, long long b, int) {
+        TraversalStack st; uint32_t nr = 0;
+        for (long long cell = a; cell < b; ++cell) for (int q = 0; q < reso[3]; ++q) {
+            const long long j = cell * reso[3] + q;
+            const int c0 = (int) (cell / (reso[1] * reso[2])), rem = (int) (cell - (long long) c0 * reso[1] * reso[2]), c1 = rem / reso[2], c2 = rem - c1 * reso[2];
+            Rng rng; rng.init((uint64_t) j, nojump);
+            float accv = 0.f;
+            for (int r = 0; r < nrounds; ++r) {
+                float s3[3] = {rng.next(), rng.next(), rng.next()};
+                s3[0] = (s3[0] + c0) * (1.f / reso[0]); s3[1] = (s3[1] + c1) * (1.f / reso[1]); s3[2] = (s3[2] + c2) * (1.f / reso[2]);
+                Vec3f v; secondary_edge_sample<float>(hs.sc, tv0, st, s3, v, nr);
+                v = zero_nonfinite(v);
+                if (reso[3] > 1) v = v / (float) reso[3];
+                accv += fmaxf(v.x, fmaxf(v.y, v.z));
+            }
+            if (nrounds > 1) accv /= (float) nrounds;
+            m[cell] += accv;
+        }
+    });
+    (void) n;
+    for (long long c = 0; c < cells; ++c) mass[c] = (float) m[c];
+    return 0;
+}
+}
