@@ -158,6 +158,9 @@ typedef struct psdr_scene_s *psdr_scene_t;
 const char *psdr_last_error(void);
 /* "psdr-hip <version> gfx950" */
 const char *psdr_version(void);
+/* sizeof(psdr_scene_desc), sizeof(psdr_render_opts), sizeof(psdr_tangents), sizeof(psdr_grads):
+   lets a foreign-language binding verify its struct mirrors before the first call */
+int psdr_abi_struct_sizes(int32_t out[4]);
 
 /* Scene handle; replaces Scene() / ~Scene() (src/scene/scene.cpp:19-41). */
 int psdr_scene_create(psdr_scene_t *out);

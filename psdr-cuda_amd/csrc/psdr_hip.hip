@@ -318,6 +318,11 @@ extern "C" {
 
 const char *psdr_last_error(void) { return g_err.c_str(); }
 const char *psdr_version(void) { return "psdr-hip 0.1 gfx950"; }
+int psdr_abi_struct_sizes(int32_t out[4]) {
+    out[0] = (int32_t) sizeof(psdr_scene_desc); out[1] = (int32_t) sizeof(psdr_render_opts);
+    out[2] = (int32_t) sizeof(psdr_tangents); out[3] = (int32_t) sizeof(psdr_grads);
+    return 0;
+}
 
 int psdr_scene_create(psdr_scene_t *out) {
     if (!out) return fail("psdr_scene_create: null output");

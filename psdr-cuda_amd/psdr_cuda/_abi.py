@@ -77,7 +77,7 @@ TANGENT_FIELDS = ("tri_info", "texels", "emitter_rad", "cam_to_world", "sec_edge
 
 # every symbol include/psdr_hip.h declares (checked by tests/test_abi.py)
 HIP_SYMBOLS = (
-    "psdr_last_error", "psdr_version", "psdr_scene_create", "psdr_scene_destroy", "psdr_scene_set_tables",
+    "psdr_last_error", "psdr_version", "psdr_abi_struct_sizes", "psdr_scene_create", "psdr_scene_destroy", "psdr_scene_set_tables",
     "psdr_bvh_build", "psdr_trace", "psdr_render_c", "psdr_render_d_fwd", "psdr_render_d_rev",
     "psdr_guide_build", "psdr_get_counters",
 )
@@ -114,6 +114,11 @@ def load_hip():
     for name in HIP_SYMBOLS:
         if name not in ("psdr_last_error", "psdr_version"):
             getattr(lib, name).restype = C.c_int
+    sizes = (C.c_int32 * 4)()
+    lib.psdr_abi_struct_sizes(sizes)
+    mine = (C.sizeof(SceneDesc), C.sizeof(RenderOpts), C.sizeof(Tangents), C.sizeof(Grads))
+    if tuple(sizes) != mine:
+        raise RuntimeError("psdr_cuda/_abi.py is out of sync with include/psdr_hip.h: %s vs %s" % (tuple(sizes), mine))
     _hip = lib
     return lib
 

@@ -607,7 +607,8 @@ def _resolve(path, base_dir):
         if os.path.exists(cand):
             return cand
         d = os.path.dirname(d)
-    return path
+    cand = os.path.normpath(os.path.join(_abi.PKG_ROOT, path))      # bundled fixtures (./data/...)
+    return cand if os.path.exists(cand) else path
 
 
 class Scene(Object):

@@ -1,0 +1,60 @@
+#!/usr/bin/env python
+"""Generates tests/golden/*.npz: small input/output vectors of the CPU oracle (fp32 arithmetic, the
+reference's type).  The reference itself ships no golden vectors and cannot run here,
+so these are REGRESSION fixtures of this build's own restatement ("parity unpinned"): they freeze the
+oracle's behaviour so that later edits to oracle/ or to the table builder cannot drift unnoticed, and
+they give the GPU tests a fixed target that does not need the oracle to be rebuilt.
+
+Run from the repo root:  python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+for p in ("psdr-cuda_amd", "oracle", "tests"):
+    sys.path.insert(0, os.path.join(ROOT, p))
+
+import oracle  # noqa: E402
+from helpers import load_scene, tangents_wrt  # noqa: E402
+from psdr_cuda import _abi  # noqa: E402
+
+CASES = {
+    # name: (scene, res, spp, sppe, sppse, translate, opts kwargs)
+    "cbox_direct11_c": ("cbox", 32, 4, 0, 0, None, dict(bsdf_samples=1, light_samples=1)),
+    "cbox_rough_direct22_c": ("cbox_rough", 32, 2, 0, 0, None, dict(bsdf_samples=2, light_samples=2)),
+    "cbox_path3_c": ("cbox", 32, 4, 0, 0, None, dict(integrator=_abi.INTEGRATOR_PATH, max_depth=3)),
+    "cbox_occluder_direct11_d": ("cbox_occluder", 24, 4, 4, 4, (1, (1.0, 0.5, 0.0)), dict(bsdf_samples=1, light_samples=1)),
+    "cbox_field_depth_c": ("cbox", 32, 1, 0, 0, None, dict(integrator=_abi.INTEGRATOR_FIELD, field=_abi.FIELDS["depth"])),
+}
+
+
+def run_case(name):
+    scene, res, spp, sppe, sppse, tr, kw = CASES[name]
+    sc, P = load_scene(scene, res=res, spp=spp, sppe=sppe, sppse=sppse, translate=tr)
+    tb = sc.tables(0)
+    o = _abi.make_opts(spp=spp, sppe=sppe, sppse=sppse, **kw)
+    if tr is None:
+        return tb, o, None, oracle.render(tb, o), None
+    tan = tangents_wrt(tb, P)
+    img, dimg = oracle.render(tb, o, mode=1, tangents=tan)
+    return tb, o, tan, img, dimg
+
+
+def main():
+    out_dir = os.path.dirname(os.path.abspath(__file__))
+    for name in CASES:
+        tb, o, tan, img, dimg = run_case(name)
+        data = {"img": img, "tri_info": tb["tri_info"].detach().numpy(), "cam": tb["cam"].numpy()}
+        if dimg is not None:
+            data["dimg"] = dimg
+            data["d_tri_info"] = tan["tri_info"].numpy()
+        np.savez_compressed(os.path.join(out_dir, name + ".npz"), **data)
+        print(name, img.shape, float(img.mean()))
+    data = {"rng_slot7_off3": oracle.rng(7, 3, 16), "rng_slot0": oracle.rng(0, 0, 16), "rng_slot_big": oracle.rng(2 ** 31 + 5, 11, 16)}
+    np.savez_compressed(os.path.join(out_dir, "rng_streams.npz"), **data)
+
+
+if __name__ == "__main__":
+    main()

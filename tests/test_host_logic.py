@@ -1,0 +1,169 @@
+"""Host-side mirror of the reference's loader / configure / Python surface (no GPU, no kernels)."""
+import numpy as np
+import pytest
+import torch
+
+import enoki as ek
+import psdr_cuda
+from enoki.cuda_autodiff import Float32 as FloatD, Vector3f as Vector3fD, Matrix4f as Matrix4fD
+from helpers import load_scene, tangents_wrt
+from psdr_cuda import _abi
+from psdr_cuda.fixtures import scene_path
+from psdr_cuda.integrator import shard_range
+from psdr_cuda.scene import build_edge_indices, load_obj, process_mesh
+
+
+def test_cbox_tables_match_appendix_c():
+    sc, _ = load_scene("cbox", res=16, spp=2, sppe=2, sppse=2)
+    tb = sc.tables(0)
+    assert tb["num_tris"] == 12 and sc.num_meshes == 6 and tb["num_emitters"] == 1
+    assert tb["tri_info"].shape == (12, _abi.TRI_STRIDE)
+    # every quad keeps its 4 boundary edges; the coplanar diagonal is dropped (mesh.cpp:261)
+    assert tb["num_sec_edges"] == 24
+    assert sorted(sc.param_map) == sorted(
+        ["Mesh[%d]" % i for i in range(6)] + ["BSDF[%d]" % i for i in range(4)] +
+        ["BSDF[id=%s]" % n for n in ("white", "red", "green", "absorption_only")] + ["Emitter[0]", "Sensor[0]"])
+    # emitter: 80x80 quad, radiance (20,20,8)
+    ef = tb["emitter_f"][0].numpy()
+    assert np.allclose(ef[:3], [20, 20, 8]) and np.isclose(ef[4], 1 / 6400.0) and np.isclose(ef[3], 1.0)
+    # face areas sum to the quad area, normals are unit
+    info = tb["tri_info"].numpy()
+    assert np.isclose(info[:2, 21].sum(), 6400.0)
+    assert np.allclose(np.linalg.norm(info[:, 18:21], axis=1), 1.0, atol=1e-6)
+    # emitter faces down (f 4 3 2 1 winding)
+    assert np.allclose(info[0, 18:21], [0, -1, 0], atol=1e-6)
+
+
+def test_bunny_edge_topology():
+    v, uv, f, uvf = load_obj(scene_path("cbox").replace("scenes/cbox.xml", "objects/bunny/bunny_low.obj"))
+    assert v.shape == (2503, 3) and f.shape == (4968, 3) and uv is None
+    e = build_edge_indices(f)
+    assert e.shape == (7473, 5) and (e[:, 3] < 0).sum() == 42
+    assert (e[:, 0] < e[:, 1]).all()
+    # lexicographic (std::map) order
+    key = e[:, 0].astype(np.int64) * 10000 + e[:, 1]
+    assert (np.diff(key) > 0).all()
+    # the opposite vertex belongs to face0 and is not an endpoint
+    f0 = f[e[:, 2]]
+    assert all(e[i, 4] in f0[i] and e[i, 4] not in (e[i, 0], e[i, 1]) for i in range(0, len(e), 97))
+
+
+def test_non_manifold_edge_is_rejected():
+    f = np.array([[0, 1, 2], [0, 1, 3], [0, 1, 4]], dtype=np.int32)
+    with pytest.raises(RuntimeError, match="more than 2 faces"):
+        build_edge_indices(f)
+
+
+def test_process_mesh_area_weighted_normals():
+    v = torch.tensor([[0., 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]])
+    f = torch.tensor([[0, 1, 2], [0, 3, 1]], dtype=torch.int32)
+    info, vn = process_mesh(v, f)
+    assert torch.allclose(info[0, 18:21], torch.tensor([0., 0, 1])) and torch.isclose(info[0, 21], torch.tensor(0.5))
+    assert torch.allclose(info[1, 18:21], torch.tensor([0., 1, 0]))
+    assert torch.allclose(vn[0], torch.tensor([0., 1, 1]) / 2 ** 0.5, atol=1e-6)
+    assert torch.allclose(vn[2], torch.tensor([0., 0, 1]))
+
+
+def test_error_messages_follow_the_reference():
+    s = psdr_cuda.Scene()
+    with pytest.raises(RuntimeError, match="Scene not loaded yet!"):
+        s.configure()
+    with pytest.raises(RuntimeError, match="XML parsing failed"):
+        s.load_string("<scene><oops></scene>")
+    xml = open(scene_path("cbox")).read()
+    with pytest.raises(RuntimeError, match="Unknown BSDF id"):
+        psdr_cuda.Scene().load_string(xml.replace('<ref id="red"/>', '<ref id="nope"/>'))
+    with pytest.raises(RuntimeError, match="Missing BSDF reference"):
+        psdr_cuda.Scene().load_string(xml.replace('<ref id="red"/>', ''))
+    with pytest.raises(RuntimeError, match="Unsupported BSDF"):
+        psdr_cuda.Scene().load_string(xml.replace('type="diffuse" id="red"', 'type="plastic" id="red"'))
+    s2 = psdr_cuda.Scene()
+    s2.load_file(scene_path("cbox"), False)
+    with pytest.raises(RuntimeError, match="Scene already loaded!"):
+        s2.load_file(scene_path("cbox"), False)
+    with pytest.raises(RuntimeError, match="Input scene must be configured!"):
+        psdr_cuda.DirectIntegrator().renderC(s2)
+    with pytest.raises(RuntimeError):
+        psdr_cuda.DirectIntegrator(0, 0)
+    with pytest.raises(RuntimeError, match="Unsupported field"):
+        psdr_cuda.FieldExtractionIntegrator("albedo")
+
+
+def test_render_without_gpu_fails_loudly():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    sc, _ = load_scene("cbox", res=8, spp=1)
+    with pytest.raises(RuntimeError, match="no GPU|hip"):
+        psdr_cuda.DirectIntegrator().renderC(sc)
+
+
+def test_xml_transform_order_and_lookat():
+    sc, _ = load_scene("cbox", res=8, spp=1)
+    em = sc.param_map["Mesh[0]"]
+    m = em.to_world.numpy()
+    assert np.allclose(m[:3, 3], [50, 190, 0]) and np.allclose(m[:3, :3], np.eye(3))
+    cam = sc.tables(0)["cam"].numpy()
+    assert np.allclose(cam[48:51], [0, 125, 1000]) and cam[53] < -0.99        # looks down -z
+    # world_to_sample maps the camera axis to the film centre
+    w2s = cam[32:48].reshape(4, 4)
+    p = np.array([0, 125, 1000]) + 500 * cam[51:54]
+    q = w2s @ np.append(p, 1.0)
+    assert np.allclose(q[:2] / q[3], [0.5, 0.5], atol=1e-4)
+
+
+def test_rng_offsets_persist_across_renders_and_reset_on_resize():
+    sc, _ = load_scene("cbox", res=8, spp=2)
+    integ = psdr_cuda.DirectIntegrator(2, 1)
+    o = integ._opts(sc, with_edges=False)
+    assert list(o.rng_offset) == [0, 0, 0]
+    integ._advance_rng(sc, o)
+    assert sc._rng_offset == [2 + 3 * 2 + 2 * 1, 0, 0]
+    sc.configure()                       # same slot count: streams continue (scene.cpp:65-79)
+    assert sc._rng_offset[0] == 10
+    sc.opts.spp = 4
+    sc.configure()                       # slot count changed: re-seeded
+    assert sc._rng_offset[0] == 0
+
+
+def test_shard_ranges_partition_the_samples():
+    for n in (1, 7, 64, 513):
+        for w in (1, 2, 3, 8):
+            r = [shard_range(n, k, w) for k in range(w)]
+            assert r[0][0] == 0 and r[-1][1] == n and all(r[i][1] == r[i + 1][0] for i in range(w - 1))
+            assert max(b - a for a, b in r) - min(b - a for a, b in r) <= 1
+
+
+def test_forward_tangent_tables_through_the_shim():
+    """d tables / dP for a translated mesh: p0 rows move by the direction, e1/e2/normals do not."""
+    sc, P = load_scene("cbox", res=8, spp=1, sppe=1, sppse=1, translate=(0, (1.0, 2.0, 3.0)))
+    tb = sc.tables(0)
+    tan = tangents_wrt(tb, P)
+    d = tan["tri_info"].numpy()
+    assert np.allclose(d[:2, 0:3], [1, 2, 3]) and np.allclose(d[:2, 3:], 0, atol=1e-5) and np.allclose(d[2:], 0)
+    assert tan["texels"] is None and tan["prim_edge"] is not None and np.abs(tan["prim_edge"].numpy()).max() > 0
+    assert np.allclose(tan["sec_edge"].numpy()[:4, 0:3], [1, 2, 3])
+
+
+def test_enoki_shim_basics():
+    P = FloatD(0.5)
+    ek.set_requires_gradient(P)
+    v = Vector3fD([1.0, 2.0, 3.0]) * P
+    assert np.allclose(v.numpy(), [[0.5, 1.0, 1.5]])
+    loss = ek.hsum(ek.squared_norm(v))
+    ek.backward(loss)
+    assert np.allclose(ek.gradient(P).numpy(), [2 * 0.5 * 14])
+    m = Matrix4fD.rotate(Vector3fD([0., 0., 1.]), FloatD(np.pi / 2))
+    assert np.allclose(m.numpy()[:2, :2], [[0, -1], [1, 0]], atol=1e-6)
+    x = Vector3fD([0., 1.], [2., 3.], [4., 5.])
+    assert ek.slices(x) == 2 and np.allclose(ek.detach(x).numpy(), [[0, 2, 4], [1, 3, 5]])
+    assert np.allclose(ek.sqrt(ek.sqr(FloatD([3.0]))).numpy(), [3.0])
+
+
+def test_bitmap_eval_follows_the_reference():
+    b = psdr_cuda.Bitmap1fD(2, 2, FloatD([0.0, 1.0, 2.0, 3.0]))
+    from enoki.cuda_autodiff import Vector2f as Vector2fD
+    # flip_v: v -> -v -> wrap; (u,v) = (0.25, 0.75) -> v' = 0.25
+    out = b.eval(Vector2fD([0.25], [0.75]), True).numpy()
+    assert np.allclose(out, [0.25 * 1 + 0.25 * 2], atol=1e-6)
+    c = psdr_cuda.Bitmap3fD([0.1, 0.2, 0.3])
+    assert np.allclose(c.eval(Vector2fD([0.3], [0.9])).numpy(), [[0.1, 0.2, 0.3]])

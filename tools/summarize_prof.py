@@ -1,0 +1,28 @@
+#!/usr/bin/env python
+"""Condense gpurun_out/prof/<tag>/ into profiles/<tag>_summary.txt (our kernels only)."""
+import csv, glob, os, sys
+tag = sys.argv[1]
+src = os.path.join("gpurun_out", "prof", tag)
+out = [("# rocprofv3 summary '%s' (bench.py; kernel-trace --stats run = 5 timed steps + 2 warmup; each PMC pass = separate 1-step run)" % tag)]
+ks = os.path.join(src, "kernel_stats.csv")
+if os.path.exists(ks):
+    out.append("\n## kernel-trace --stats (Name, Calls, TotalDurationNs, AverageNs, Percentage, MinNs, MaxNs, StdDev)")
+    for r in csv.reader(open(ks)):
+        if r and ("k_" in r[0] or r[0] == "Name"):
+            name = r[0].replace("void (anonymous namespace)::", "").split("((anonymous")[0].split("(psdr::SceneView")[0]
+            out.append("%-40s %s" % (name, " ".join(r[1:])))
+out.append("\n## PMC (per dispatch; FETCH_SIZE / WRITE_SIZE in KiB as rocprofv3 reports them; on gfx950 FETCH_SIZE counts 64 B per 128 B request -> double it for wide reads, MI355X_MICROARCH.md)")
+for f in sorted(glob.glob(os.path.join(src, "pmc_*.txt"))):
+    for line in open(f):
+        if "k_" in line and "namespace" in line:
+            parts = line.split()
+            name = line.split("(anonymous namespace)::")[1].split("((anonymous")[0].split("(")[0] if "(anonymous namespace)::" in line else parts[0]
+            i = [k for k, p in enumerate(parts) if p.startswith("dispatches=")][0]
+            out.append("%-28s %-22s %s %s" % (name, parts[i - 1], parts[i], parts[i + 2]))
+for f in sorted(glob.glob(os.path.join(src, "*bench.log"))):
+    for line in open(f):
+        if line.startswith("{"):
+            out.append("\n## bench line of the kernel-trace run\n" + line.strip())
+os.makedirs("profiles", exist_ok=True)
+open(os.path.join("profiles", tag + "_summary.txt"), "w").write("\n".join(out) + "\n")
+print("\n".join(out))
