@@ -153,6 +153,7 @@ template <class R> struct Its {
     Vec3<R> wi, p, n;
     R t, J, uvx, uvy;
     Frame<R> sh;
+    float hu, hv;   // traversal barycentrics (detached), kept for the reverse pass
 };
 template <class R> struct RayT { Vec3<R> o, d; };
 
@@ -182,7 +183,7 @@ template <class R> PSDR_HD Its<R> intersect(const SceneView &sc, const TV<R> &tv
     nrays++;
     const Hit h = closest_hit(sc, st, val(ray.o), val(ray.d), INFINITY);
     if (h.tri < 0) return its;
-    its.valid = true; its.tri = h.tri;
+    its.valid = true; its.tri = h.tri; its.hu = h.u; its.hv = h.v;
     const int tm = sc.d.tri_mesh[h.tri];
     its.mesh = tm & ~PSDR_TRI_FACE_NORMALS;
     const TriRow<R> T = load_tri<R>(sc, tv, h.tri);

@@ -9,6 +9,7 @@
 // Traversal stacks live in LDS (one column per lane); image accumulation uses a segmented
 // wave reduction followed by one hardware f32 atomic per (pixel run, channel).
 #include "psdr_device.h"
+#include "psdr_reverse.h"
 #include "psdr_bvh_build.h"
 
 #include <algorithm>
@@ -206,6 +207,80 @@ __global__ __launch_bounds__(kBlock) void k_guide(LaunchCtx cx, int r0, int r1, 
         }
         if (nrounds > 1) acc /= (float) nrounds;
         if (acc != 0.f) atomicAdd(mass + cell, acc);
+    }
+    count_rays(counters, nrays);
+}
+
+// ------------------------------------------------------------------------ reverse mode
+// Gradient sink of the reverse kernels: the "per-parameter gradient scatter-add".  Every add is a
+// hardware f32 atomic on the gradient table (NULL table = gradient not requested).  Non-finite
+// pieces are dropped (forward mode zeroes non-finite tangents, psdr_device.h zero_nonfinite).
+struct DeviceSink {
+    psdr_grads g;
+    __device__ __forceinline__ void put(float *base, size_t i, float v) const {
+        if (base != nullptr && v != 0.f && isfinite(v)) atomicAdd(base + i, v);
+    }
+    __device__ __forceinline__ void add_tri(int tri, int word, float v) const { put(g.g_tri_info, (size_t) tri * PSDR_TRI_STRIDE + word, v); }
+    __device__ __forceinline__ void add_texel(int idx, float v) const { put(g.g_texels, (size_t) idx, v); }
+    __device__ __forceinline__ void add_rad(int e, int c, float v) const { put(g.g_emitter_rad, (size_t) e * 3 + c, v); }
+    __device__ __forceinline__ void add_cam(int word, float v) const { put(g.g_cam_to_world, (size_t) word, v); }
+    __device__ __forceinline__ void add_sedge(int e, int word, float v) const { put(g.g_sec_edge, (size_t) e * PSDR_SEDGE_STRIDE + word, v); }
+    __device__ __forceinline__ void add_pedge(int e, int word, float v) const { put(g.g_prim_edge, (size_t) e * PSDR_PEDGE_STRIDE + word, v); }
+};
+
+__global__ __launch_bounds__(kBlock) void k_camera_rev(LaunchCtx cx, DeviceSink sink, int spp, int s_begin, int nsp, long long n, float inv_spp,
+                                                       const float *__restrict__ adj_img, float *__restrict__ img,
+                                                       unsigned long long *counters) {
+    __shared__ int32_t lds[kBvhStack * kBlock];
+    TraversalStack st; bind_stack(st, lds);
+    uint32_t nrays = 0;
+    const long long nceil = (n + kBlock - 1) / kBlock * kBlock;
+    for (long long j = (long long) blockIdx.x * kBlock + threadIdx.x; j < nceil; j += (long long) gridDim.x * kBlock) {
+        const bool in = j < n;
+        const int pixel = in ? (int) (j / nsp) : 0x7fffffff;
+        float v[3] = {0.f, 0.f, 0.f};
+        if (in) {
+            const int s = s_begin + (int) (j % nsp);
+            const uint64_t slot = (uint64_t) pixel * (uint64_t) spp + (uint64_t) s;
+            const float *a = adj_img + (size_t) pixel * 3;
+            const Vec3f adj{a[0] * inv_spp, a[1] * inv_spp, a[2] * inv_spp};
+            const Vec3f r = camera_sample_reverse(sink, cx.sc, st, cx.lp, cx.jump, pixel, slot, adj, nrays);
+            v[0] = r.x * inv_spp; v[1] = r.y * inv_spp; v[2] = r.z * inv_spp;
+        }
+        if (img != nullptr) {
+            const bool head = wave_segmented_sum<3>(pixel, v);
+            if (head && in) {
+                float *p = img + (size_t) pixel * 3;
+                if (v[0] != 0.f) atomicAdd(p, v[0]);
+                if (v[1] != 0.f) atomicAdd(p + 1, v[1]);
+                if (v[2] != 0.f) atomicAdd(p + 2, v[2]);
+            }
+        }
+    }
+    count_rays(counters, nrays);
+}
+
+__global__ __launch_bounds__(kBlock) void k_primary_edge_rev(LaunchCtx cx, DeviceSink sink, long long i0, long long n, float inv_sppe,
+                                                             const float *__restrict__ adj_img, unsigned long long *counters) {
+    __shared__ int32_t lds[kBvhStack * kBlock];
+    TraversalStack st; bind_stack(st, lds);
+    uint32_t nrays = 0;
+    for (long long j = (long long) blockIdx.x * kBlock + threadIdx.x; j < n; j += (long long) gridDim.x * kBlock)
+        primary_edge_reverse(sink, cx.sc, st, cx.lp, cx.jump, (uint64_t) (i0 + j), inv_sppe, adj_img, nrays);
+    count_rays(counters, nrays);
+}
+
+__global__ __launch_bounds__(kBlock) void k_secondary_edge_rev(LaunchCtx cx, DeviceSink sink, long long i0, long long n, float inv_sppse,
+                                                               const float *__restrict__ adj_img, unsigned long long *counters) {
+    __shared__ int32_t lds[kBvhStack * kBlock];
+    TraversalStack st; bind_stack(st, lds);
+    uint32_t nrays = 0;
+    const bool guided = cx.sc.d.guide_cmf != nullptr && cx.sc.d.num_guide_cells > 0;
+    for (long long j = (long long) blockIdx.x * kBlock + threadIdx.x; j < n; j += (long long) gridDim.x * kBlock) {
+        Rng rng; rng.init((uint64_t) (i0 + j), cx.jump);
+        float s3[3] = {rng.next(), rng.next(), rng.next()};
+        const float pdf0 = guided ? guide_sample_reuse(cx.sc, s3) : 1.f;
+        secondary_edge_reverse(sink, cx.sc, st, s3, (pdf0 > kEpsilon ? 1.f / pdf0 : 1.f) * inv_sppse, adj_img, nrays);
     }
     count_rays(counters, nrays);
 }
@@ -422,8 +497,44 @@ int psdr_render_d_fwd(psdr_scene_t h, const psdr_render_opts *o, int32_t K, cons
 
 int psdr_render_d_rev(psdr_scene_t h, const psdr_render_opts *o, const float *adj_img, float *out_img, const psdr_grads *grads,
                       void *stream) {
-    (void) h; (void) o; (void) adj_img; (void) out_img; (void) grads; (void) stream;
-    return fail("psdr_render_d_rev: reverse-mode kernels are not built yet (use psdr_render_d_fwd)");
+    if (!h || !o || !adj_img || !grads) return fail("psdr_render_d_rev: null argument");
+    if (!h->have_tables) return fail("Scene not loaded yet!");
+    if (int rc = check_counts(h, o)) return rc;
+    if (o->integrator == PSDR_INTEGRATOR_PATH && o->max_depth > kMaxRevDepth) return fail("psdr_render_d_rev: max_depth > 8 is not supported");
+    hipStream_t s = (hipStream_t) stream;
+    if (int rc = begin_call(h, s)) return rc;
+    const long long WH = (long long) h->desc.width * h->desc.height;
+    if (out_img) HIP_TRY(hipMemsetAsync(out_img, 0, sizeof(float) * WH * 3, s));
+    DeviceSink sink; sink.g = *grads;
+    const int nsp = o->spp_end - o->spp_begin;
+    if (o->spp > 0 && nsp > 0) {
+        LaunchCtx cx;
+        if (int rc = make_ctx(h, o, 0, cx)) return rc;
+        const long long n = WH * nsp;
+        h->slots[0] += (uint64_t) n;
+        hipLaunchKernelGGL(k_camera_rev, dim3(launch_blocks(h, n)), dim3(kBlock), 0, s, cx, sink, o->spp, o->spp_begin, nsp, n,
+                           1.f / (float) o->spp, adj_img, out_img, h->d_counters);
+        HIP_TRY(hipGetLastError());
+    }
+    if (o->sppe > 0 && o->sppe_end > o->sppe_begin && h->desc.num_prim_edges > 0 && grads->g_prim_edge) {
+        LaunchCtx cx;
+        if (int rc = make_ctx(h, o, 1, cx)) return rc;
+        const long long i0 = WH * o->sppe_begin, n = WH * (o->sppe_end - o->sppe_begin);
+        h->slots[1] += (uint64_t) n;
+        hipLaunchKernelGGL(k_primary_edge_rev, dim3(launch_blocks(h, n)), dim3(kBlock), 0, s, cx, sink, i0, n, 1.f / (float) o->sppe, adj_img,
+                           h->d_counters);
+        HIP_TRY(hipGetLastError());
+    }
+    if (o->sppse > 0 && o->sppse_end > o->sppse_begin && h->desc.num_sec_edges > 0 && o->integrator == PSDR_INTEGRATOR_DIRECT) {
+        LaunchCtx cx;
+        if (int rc = make_ctx(h, o, 2, cx)) return rc;
+        const long long i0 = WH * o->sppse_begin, n = WH * (o->sppse_end - o->sppse_begin);
+        h->slots[2] += (uint64_t) n;
+        hipLaunchKernelGGL(k_secondary_edge_rev, dim3(launch_blocks(h, n)), dim3(kBlock), 0, s, cx, sink, i0, n, 1.f / (float) o->sppse,
+                           adj_img, h->d_counters);
+        HIP_TRY(hipGetLastError());
+    }
+    return 0;
 }
 
 int psdr_guide_build(psdr_scene_t h, const psdr_render_opts *o, const int32_t reso[4], int32_t nrounds, float *out_mass, void *stream) {

@@ -1,0 +1,730 @@
+// psdr_reverse.h -- reverse-mode (adjoint) evaluation of the interior and boundary estimators.
+//
+// The reference obtains parameter gradients by letting Enoki walk an N-wide tape backwards
+// (enoki.backward(loss), docs/inverse_diff_render.rst): every gather<TriangleInfoD> (scene.cpp:300),
+// bitmap gather (bitmap.cpp:72-75) and radiance read turns into an atomic scatter_add.  Here the
+// adjoint of one sample is written out by hand and evaluated in registers: forward re-evaluation of
+// the sample, then the chain rule backwards, then a scatter-add of the per-sample gradient into the
+// gradient tables through a GradSink.  No tape ever touches HBM.
+//
+// Path structure (DirectIntegrator == one vertex with B/L loops; PathTracer == max_depth vertices):
+//   L = Le_0 + T_0,   T_k = c_k + f_k * T_{k+1}
+// with c_k the emitter terms gathered at vertex k and f_k the BSDF-sampled throughput.  The adjoint of
+// T_k is a * beta_k (known going forward), the adjoint of f_k needs the suffix radiance T_{k+1}, so a
+// first sweep records (c_k, f_k) per vertex and a second sweep replays the same random numbers and
+// differentiates vertex by vertex.
+//
+// RoughConductor: the BSDF-internal partials (eval / pdf / sample w.r.t. wi, wo, alpha, eta, k) are
+// taken with small local dual numbers (Dual<K> over the handful of BSDF inputs); everything
+// geometric is hand-derived.
+#pragma once
+#include "psdr_device.h"
+
+namespace psdr {
+
+// ---------------------------------------------------------------------- adjoint helpers
+PSDR_HD Vec3f operator*(float s, const Vec3f &a) { return {a.x * s, a.y * s, a.z * s}; }
+PSDR_HD void acc(Vec3f &d, const Vec3f &v) { d.x += v.x; d.y += v.y; d.z += v.z; }
+PSDR_HD float hsum3(const Vec3f &a) { return a.x + a.y + a.z; }
+
+// n = normalize(v)
+PSDR_HD Vec3f normalize_vjp(const Vec3f &v, const Vec3f &n, const Vec3f &an) {
+    const float inv = 1.f / norm(v);
+    return (an - n * dot(n, an)) * inv;
+}
+// Frame(n) = (s, t, n): adjoint of coordinate_system w.r.t. n
+PSDR_HD Vec3f frame_vjp(const Vec3f &n, const Vec3f &as, const Vec3f &at) {
+    const float sg = copysignf(1.f, n.z);
+    const float a = -1.f / (sg + n.z);
+    const float ab = as.y * sg + at.x;
+    const float aa = as.x * n.x * n.x * sg + at.y * n.y * n.y + ab * n.x * n.y;
+    Vec3f an;
+    an.x = as.x * 2.f * n.x * a * sg - as.z * sg + ab * n.y * a;
+    an.y = at.y * 2.f * n.y * a - at.z + ab * n.x * a;
+    an.z = aa * a * a;
+    return an;
+}
+
+// Adjoint accumulators of one path vertex (the quantities later terms read)
+struct VertexAdj {
+    Vec3f p, s, t, n, wi;     // position, shading frame, local incident direction
+    float u, v;               // texture coordinates
+    PSDR_HD void clear() { p = s = t = n = wi = Vec3f(0.f); u = v = 0.f; }
+};
+
+// Gradient sink interface (duck-typed): add_tri(tri, word, g), add_texel(idx, g), add_rad(e, c, g),
+// add_cam(word, g), add_sedge(edge, word, g), add_pedge(edge, word, g).
+
+template <class Sink> PSDR_HD void scatter_point(Sink &sink, int tri, float u, float v, const Vec3f &ap) {
+    // p = p0 + u e1 + v e2 (barycentrics detached)
+    sink.add_tri(tri, 0, ap.x); sink.add_tri(tri, 1, ap.y); sink.add_tri(tri, 2, ap.z);
+    sink.add_tri(tri, 3, u * ap.x); sink.add_tri(tri, 4, u * ap.y); sink.add_tri(tri, 5, u * ap.z);
+    sink.add_tri(tri, 6, v * ap.x); sink.add_tri(tri, 7, v * ap.y); sink.add_tri(tri, 8, v * ap.z);
+}
+template <class Sink> PSDR_HD void scatter_vec(Sink &sink, int tri, int word, const Vec3f &a) {
+    sink.add_tri(tri, word, a.x); sink.add_tri(tri, word + 1, a.y); sink.add_tri(tri, word + 2, a.z);
+}
+
+// shading normal of a triangle at (bu, bv): forward + adjoint (returns d sh_n/d(bu,bv) contributions)
+struct ShNormal { Vec3f v, n; bool face; };
+PSDR_HD ShNormal shading_normal(const TriRow<float> &T, bool face, float bu, float bv) {
+    ShNormal r; r.face = face;
+    if (face) { r.v = r.n = T.fn; return r; }
+    r.v = bary_point(T.n0, T.n1 - T.n0, T.n2 - T.n0, bu, bv);
+    r.n = normalize(r.v);
+    return r;
+}
+template <class Sink>
+PSDR_HD void shading_normal_vjp(Sink &sink, int tri, const TriRow<float> &T, const ShNormal &sn, float bu, float bv, const Vec3f &an,
+                                float &abu, float &abv) {
+    if (sn.face) { scatter_vec(sink, tri, 18, an); return; }
+    const Vec3f av = normalize_vjp(sn.v, sn.n, an);
+    scatter_vec(sink, tri, 9, av * (1.f - bu - bv));
+    scatter_vec(sink, tri, 12, av * bu);
+    scatter_vec(sink, tri, 15, av * bv);
+    abu += dot(av, T.n1 - T.n0); abv += dot(av, T.n2 - T.n0);
+}
+
+// ------------------------------------------------------------------ BSDF with adjoints
+// Texture lookup adjoint: scatter a_out (C channels) to the texels, return d/d(u,v).
+template <class Sink, int C>
+PSDR_HD void bitmap_vjp(Sink &sink, const SceneView &sc, const int32_t *slot, float u, float v, const float *a_out, float &au, float &av) {
+    const int off = slot[0], w = slot[1], h = slot[2];
+    if (w == 1 && h == 1) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) sink.add_texel(off + c, a_out[c]);
+        return;
+    }
+    const float *tx = sc.d.texels;
+    float vv = -v;
+    u = u - floorf(u); vv = vv - floorf(vv);
+    u = u * (float) (w - 1); vv = vv * (float) (h - 1);
+    int px = (int) floorf(u), py = (int) floorf(vv);
+    const float w1x = u - (float) px, w1y = vv - (float) py, w0x = 1.f - w1x, w0y = 1.f - w1y;
+    px = px < w - 2 ? px : w - 2; py = py < h - 2 ? py : h - 2;
+    const size_t idx = (size_t) py * w + px;
+    float du = 0.f, dv = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const size_t i00 = off + idx * C + c, i10 = off + (idx + 1) * C + c, i01 = off + (idx + w) * C + c, i11 = off + (idx + w + 1) * C + c;
+        const float a = a_out[c];
+        sink.add_texel((int) i00, a * w0y * w0x); sink.add_texel((int) i10, a * w0y * w1x);
+        sink.add_texel((int) i01, a * w1y * w0x); sink.add_texel((int) i11, a * w1y * w1x);
+        const float v00 = tx[i00], v10 = tx[i10], v01 = tx[i01], v11 = tx[i11];
+        du += a * (w0y * (v10 - v00) + w1y * (v11 - v01));
+        dv += a * ((w0x * v01 + w1x * v11) - (w0x * v00 + w1x * v10));
+    }
+    au += du * (float) (w - 1);
+    av += -dv * (float) (h - 1);        // v was negated (flip_v)
+}
+
+// value and partials of one RoughConductor quantity w.r.t. the packed inputs
+//   [0..2] wi, [3..5] wo, [6] alpha_u, [7] alpha_v   (Dual<8>)
+using D8 = Dual<8>;
+PSDR_HD D8 seed8(float v, int i) { D8 r(v); r.d[i] = 1.f; return r; }
+
+struct RcParams { float au, av; Vec3f eta, k, spec; };
+
+template <class Sink> struct BsdfRev {
+    const SceneView &sc;
+    Bsdf<float> b;
+    PSDR_HD BsdfRev(const SceneView &s, int id) : sc(s), b(s, id) {}
+
+    PSDR_HD RcParams rc_params(const TangentView<0> &tv0, const Its<float> &its) const {
+        RcParams p;
+        p.au = b.tex1(sc, tv0, PSDR_SLOT_ALPHA_U, its); p.av = b.tex1(sc, tv0, PSDR_SLOT_ALPHA_V, its);
+        p.eta = b.tex3(sc, tv0, PSDR_SLOT_ETA, its); p.k = b.tex3(sc, tv0, PSDR_SLOT_K, its);
+        p.spec = b.tex3(sc, tv0, PSDR_SLOT_REFLECTANCE, its);
+        return p;
+    }
+
+    // adjoint of value = eval(its, wo): a_f (RGB) -> a_wi, a_wo, texels, a_uv
+    PSDR_HD void eval_vjp(Sink &sink, const TangentView<0> &tv0, const Its<float> &its, const Vec3f &wo, const Vec3f &af, Vec3f &awi,
+                          Vec3f &awo, float &auvx, float &auvy) const {
+        if (!(its.wi.z > 0.f && wo.z > 0.f)) return;
+        if (b.type() == PSDR_BSDF_DIFFUSE) {
+            const Vec3f rho = b.tex3(sc, tv0, PSDR_SLOT_REFLECTANCE, its);
+            const float c = wo.z * kInvPi;
+            const float ar[3] = {af.x * c, af.y * c, af.z * c};
+            bitmap_vjp<Sink, 3>(sink, sc, b.slot(PSDR_SLOT_REFLECTANCE), its.uvx, its.uvy, ar, auvx, auvy);
+            awo.z += dot(af, rho) * kInvPi;
+            return;
+        }
+        const RcParams p = rc_params(tv0, its);
+        // geometric part g(wi, wo, alpha) = D*G/(4 cos_i) and cos = wi.H by local duals
+        const Vec3<D8> dwi{seed8(its.wi.x, 0), seed8(its.wi.y, 1), seed8(its.wi.z, 2)};
+        const Vec3<D8> dwo{seed8(wo.x, 3), seed8(wo.y, 4), seed8(wo.z, 5)};
+        const GGX<D8> g{seed8(p.au, 6), seed8(p.av, 7)};
+        const Vec3<D8> H = normalize(dwo + dwi);
+        const D8 D = g.eval(H);
+        if (D.v == 0.f) return;
+        const D8 geo = D * (g.smith_g1(dwi, H) * g.smith_g1(dwo, H)) / (4.f * dwi.z);
+        const D8 c = dot(dwi, H);
+        // Fresnel per channel with Dual<3> over (cos, eta, k)
+        using D3 = Dual<3>;
+        const float *eta = &p.eta.x, *kk = &p.k.x, *spec = &p.spec.x, *afp = &af.x;
+        float a_geo = 0.f, a_cos = 0.f, a_eta[3], a_k[3], a_spec[3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            D3 dc(c.v); dc.d[0] = 1.f;
+            D3 de(eta[ch]); de.d[1] = 1.f;
+            D3 dk(kk[ch]); dk.d[2] = 1.f;
+            const D3 F = fresnel_conductor(de, dk, dc);
+            // value_ch = F * geo * spec
+            const float a = afp[ch];
+            a_spec[ch] = a * F.v * geo.v;
+            a_geo += a * F.v * spec[ch];
+            const float aF = a * geo.v * spec[ch];
+            a_cos += aF * F.d[0]; a_eta[ch] = aF * F.d[1]; a_k[ch] = aF * F.d[2];
+        }
+        float g8[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) g8[i] = a_geo * geo.d[i] + a_cos * c.d[i];
+        awi.x += g8[0]; awi.y += g8[1]; awi.z += g8[2];
+        awo.x += g8[3]; awo.y += g8[4]; awo.z += g8[5];
+        bitmap_vjp<Sink, 1>(sink, sc, b.slot(PSDR_SLOT_ALPHA_U), its.uvx, its.uvy, &g8[6], auvx, auvy);
+        bitmap_vjp<Sink, 1>(sink, sc, b.slot(PSDR_SLOT_ALPHA_V), its.uvx, its.uvy, &g8[7], auvx, auvy);
+        bitmap_vjp<Sink, 3>(sink, sc, b.slot(PSDR_SLOT_ETA), its.uvx, its.uvy, a_eta, auvx, auvy);
+        bitmap_vjp<Sink, 3>(sink, sc, b.slot(PSDR_SLOT_K), its.uvx, its.uvy, a_k, auvx, auvy);
+        bitmap_vjp<Sink, 3>(sink, sc, b.slot(PSDR_SLOT_REFLECTANCE), its.uvx, its.uvy, a_spec, auvx, auvy);
+    }
+
+    // adjoint of pdf(its, wo) (only RoughConductor carries derivatives; Diffuse::__pdf is detached)
+    PSDR_HD void pdf_vjp(Sink &sink, const TangentView<0> &tv0, const Its<float> &its, const Vec3f &wo, float apdf, Vec3f &awi, Vec3f &awo,
+                         float &auvx, float &auvy) const {
+        if (b.type() == PSDR_BSDF_DIFFUSE || apdf == 0.f) return;
+        const RcParams p = rc_params(tv0, its);
+        const Vec3<D8> dwi{seed8(its.wi.x, 0), seed8(its.wi.y, 1), seed8(its.wi.z, 2)};
+        const Vec3<D8> dwo{seed8(wo.x, 3), seed8(wo.y, 4), seed8(wo.z, 5)};
+        const GGX<D8> g{seed8(p.au, 6), seed8(p.av, 7)};
+        const Vec3<D8> m = normalize(dwo + dwi);
+        const D8 r = g.eval(m) * g.smith_g1(dwi, m) / (4.f * dwi.z);
+        awi.x += apdf * r.d[0]; awi.y += apdf * r.d[1]; awi.z += apdf * r.d[2];
+        awo.x += apdf * r.d[3]; awo.y += apdf * r.d[4]; awo.z += apdf * r.d[5];
+        const float a6 = apdf * r.d[6], a7 = apdf * r.d[7];
+        bitmap_vjp<Sink, 1>(sink, sc, b.slot(PSDR_SLOT_ALPHA_U), its.uvx, its.uvy, &a6, auvx, auvy);
+        bitmap_vjp<Sink, 1>(sink, sc, b.slot(PSDR_SLOT_ALPHA_V), its.uvx, its.uvy, &a7, auvx, auvy);
+    }
+
+    // adjoint of the SAMPLED pdf: pdf_s = pdf(its, wo_s(wi, alpha; xi))  (roughconductor.cpp:79-92 keeps this
+    // dependency alive; Diffuse: constant)
+    PSDR_HD void sampled_pdf_vjp(Sink &sink, const TangentView<0> &tv0, const Its<float> &its, const float s[3], float apdf, Vec3f &awi,
+                                 float &auvx, float &auvy) const {
+        if (b.type() == PSDR_BSDF_DIFFUSE || apdf == 0.f) return;
+        using D5 = Dual<5>;
+        const RcParams p = rc_params(tv0, its);
+        auto sd = [](float v, int i) { D5 r(v); r.d[i] = 1.f; return r; };
+        const Vec3<D5> dwi{sd(its.wi.x, 0), sd(its.wi.y, 1), sd(its.wi.z, 2)};
+        const GGX<D5> g{sd(p.au, 3), sd(p.av, 4)};
+        const Vec3<D5> m = g.sample(dwi, s[0], s[1]);
+        const Vec3<D5> wo = m * (2.f * dot(dwi, m)) - dwi;
+        const Vec3<D5> h = normalize(wo + dwi);
+        const D5 r = g.eval(h) * g.smith_g1(dwi, h) / (4.f * dwi.z);
+        awi.x += apdf * r.d[0]; awi.y += apdf * r.d[1]; awi.z += apdf * r.d[2];
+        const float a3 = apdf * r.d[3], a4 = apdf * r.d[4];
+        bitmap_vjp<Sink, 1>(sink, sc, b.slot(PSDR_SLOT_ALPHA_U), its.uvx, its.uvy, &a3, auvx, auvy);
+        bitmap_vjp<Sink, 1>(sink, sc, b.slot(PSDR_SLOT_ALPHA_V), its.uvx, its.uvy, &a4, auvx, auvy);
+    }
+};
+
+// ---------------------------------------------------------------- per-vertex evaluation
+// Moeller-Trumbore adjoint (include/psdr/utils.h:66-77): given (a_u, a_v, a_t) returns the adjoints
+// of p0, e1, e2 and of the ray origin / direction.
+struct MtAdj { Vec3f p0, e1, e2, o, d; };
+PSDR_HD MtAdj mt_vjp(const Vec3f &p0, const Vec3f &e1, const Vec3f &e2, const RayT<float> &ray, float au, float av, float at) {
+    const Vec3f h = cross(ray.d, e2);
+    const float f = 1.f / dot(e1, h);
+    const Vec3f s = ray.o - p0, q = cross(s, e1);
+    const float a_f = au * dot(s, h) + av * dot(ray.d, q) + at * dot(e2, q);
+    Vec3f as = h * (au * f), ah = s * (au * f);
+    Vec3f ad = q * (av * f), aq = ray.d * (av * f);
+    Vec3f ae2 = q * (at * f);
+    acc(aq, e2 * (at * f));
+    const float a_a = -a_f * f * f;
+    Vec3f ae1 = h * a_a;
+    acc(ah, e1 * a_a);
+    acc(as, cross(e1, aq)); acc(ae1, cross(aq, s));      // q = s x e1
+    acc(ad, cross(e2, ah)); acc(ae2, cross(ah, ray.d));  // h = d x e2
+    MtAdj r; r.p0 = -as; r.e1 = ae1; r.e2 = ae2; r.o = as; r.d = ad;
+    return r;
+}
+
+// camera ray adjoint: o = to_world[:,3] (w = 1), d = R * dcam  (perspective.cpp:130-135)
+template <class Sink> PSDR_HD void camera_ray_vjp(Sink &sink, const SceneView &sc, const Vec3f &dcam, const Vec3f &ao, const Vec3f &ad) {
+    const float o3[3] = {ao.x, ao.y, ao.z}, d3[3] = {ad.x, ad.y, ad.z};
+    {   // o = to_world[:,3] / w
+        const float *c = sc.d.cam + PSDR_CAM_TO_WORLD;
+        const float iw = 1.f / c[15];
+        sink.add_cam(15, -(ao.x * c[3] + ao.y * c[7] + ao.z * c[11]) * iw * iw);
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        sink.add_cam(r * 4 + 3, o3[r] / sc.d.cam[PSDR_CAM_TO_WORLD + 15]);
+        sink.add_cam(r * 4 + 0, d3[r] * dcam.x); sink.add_cam(r * 4 + 1, d3[r] * dcam.y); sink.add_cam(r * 4 + 2, d3[r] * dcam.z);
+    }
+}
+PSDR_HD Vec3f camera_space_dir(const SceneView &sc, float sx, float sy) {
+    const float *m = sc.d.cam + PSDR_CAM_SAMPLE_TO_CAMERA;
+    float v4[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v4[r] = m[r * 4] * sx + m[r * 4 + 1] * sy + m[r * 4 + 3];
+    return normalize(Vec3f{v4[0] / v4[3], v4[1] / v4[3], v4[2] / v4[3]});
+}
+
+// What one vertex hands back to the path loop
+struct VertexOut {
+    Vec3f c;            // sum of the emitter contributions gathered at this vertex (unit throughput)
+    Vec3f f;            // throughput of the first BSDF sample (D form: eval * G * J / pdf0)
+    Its<float> next;    // BSDF-sampled next vertex (path-space form)
+    bool next_valid;
+};
+
+PSDR_HD Its<float> make_path_vertex(const SceneView &sc, const Vec3f &origin, int tri, float hu, float hv, const TriRow<float> &T) {
+    Its<float> n;
+    const int tm = sc.d.tri_mesh[tri];
+    n.valid = true; n.tri = tri; n.mesh = tm & ~PSDR_TRI_FACE_NORMALS; n.hu = hu; n.hv = hv;
+    n.n = T.fn; n.J = 1.f;
+    n.p = bary_point(T.p0, T.e1, T.e2, hu, hv);
+    Vec3f dir = n.p - origin;
+    n.t = norm(dir);
+    dir = dir / n.t;
+    const ShNormal sn = shading_normal(T, (tm & PSDR_TRI_FACE_NORMALS) != 0, hu, hv);
+    n.sh = Frame<float>(sn.n);
+    n.wi = n.sh.to_local(-dir);
+    const float *q = sc.d.tri_uv ? sc.d.tri_uv + (size_t) tri * PSDR_TRIUV_STRIDE : nullptr;
+    n.uvx = q ? (q[2] - q[0]) * hu + ((q[4] - q[0]) * hv + q[0]) : 0.f;
+    n.uvy = q ? (q[3] - q[1]) * hu + ((q[5] - q[1]) * hv + q[1]) : 0.f;
+    return n;
+}
+
+// Evaluates the terms gathered at vertex `its` in their D-mode forms (direct.cpp:64-160) and, when
+// BACKWARD, differentiates them:
+//   a_c : adjoint of every emitter contribution (= a * beta_k)
+//   a_f : adjoint of the continuation throughput f_k (= a * beta_k * T_{k+1}); zero for DirectIntegrator
+// Adjoints of THIS vertex' position / frame / wi / uv accumulate in `va`; everything that belongs to
+// other triangles (next vertex, emitter) is scattered straight into the sink.
+template <bool BACKWARD, class Sink>
+PSDR_HD VertexOut vertex_eval(Sink &sink, const SceneView &sc, TraversalStack &st, Rng &rng, const Its<float> &its, int nB, int nL,
+                              const Vec3f &a_c, const Vec3f &a_f, VertexAdj &va, uint32_t &nrays) {
+    const TangentView<0> tv0{};
+    const BsdfRev<Sink> brev(sc, sc.d.mesh_bsdf[its.mesh]);
+    const Bsdf<float> &bsdf = brev.b;
+    VertexOut out; out.c = Vec3f(0.f); out.f = Vec3f(0.f); out.next_valid = false;
+    for (int i = 0; i < nB; ++i) {
+        const float s[3] = {rng.next(), rng.next(), rng.next()};
+        Vec3f wo_s; float pdf_s;
+        const bool ok = bsdf.sample(sc, tv0, its, s, true, wo_s, pdf_s);
+        if (!ok) continue;
+        const RayT<float> ray1{its.p, its.sh.to_world(wo_s)};
+        nrays++;
+        const Hit h1 = closest_hit(sc, st, ray1.o, ray1.d, INFINITY);
+        if (h1.tri < 0) continue;
+        const int tm = sc.d.tri_mesh[h1.tri], mesh1 = tm & ~PSDR_TRI_FACE_NORMALS;
+        const TriRow<float> T1 = load_tri<float>(sc, tv0, h1.tri);
+        const Vec3f p1 = bary_point(T1.p0, T1.e1, T1.e2, h1.u, h1.v);
+        const Vec3f dvec = p1 - its.p;
+        const float t1 = norm(dvec);
+        const Vec3f wo = dvec / t1;
+        const Vec3f wol = its.sh.to_local(wo);
+        const Vec3f f = bsdf.eval(sc, tv0, its, wol, true);
+        const float cosv = -dot(T1.fn, wo);
+        const float G = fabsf(cosv) / (t1 * t1);
+        const float pdf0 = pdf_s * G;
+        const float cfac = 1.f / pdf_s;                       // G * J / pdf0 with J = 1, pdf0 = pdf_s * G
+        const Vec3f valv = f * cfac;
+        const int e1 = sc.d.mesh_emitter[mesh1];
+        Vec3f Le1(0.f);
+        float w = 1.f / (float) nB, dw_dpdf0 = 0.f;
+        if (e1 >= 0) {
+            const ShNormal sn1 = shading_normal(T1, (tm & PSDR_TRI_FACE_NORMALS) != 0, h1.u, h1.v);
+            if (-dot(wo, sn1.n) > 0.f) { const float *r = sc.d.emitter_f + (size_t) e1 * PSDR_EMITTER_F_STRIDE; Le1 = Vec3f{r[0], r[1], r[2]}; }
+            if (nL > 0) {
+                const float *ef = sc.d.emitter_f + (size_t) e1 * PSDR_EMITTER_F_STRIDE;
+                const float pe = ef[3] * ef[4];
+                const float a2 = pdf0 * pdf0, b2 = pe * pe, den = a2 + b2;
+                w *= a2 / den;
+                dw_dpdf0 = (2.f * pdf0 * b2 / (den * den)) / (float) nB;
+            }
+            out.c = out.c + Le1 * valv * w;
+        }
+        if (i == 0) { out.f = valv; out.next = make_path_vertex(sc, its.p, h1.tri, h1.u, h1.v, T1); out.next_valid = true; }
+        if (!BACKWARD) continue;
+        Vec3f a_val = a_c * Le1 * w;
+        const float a_w = dot(a_c, Le1 * valv);
+        if (i == 0) acc(a_val, a_f);
+        if (e1 >= 0 && (Le1.x != 0.f || Le1.y != 0.f || Le1.z != 0.f)) {
+            const Vec3f gr = a_c * valv * w;
+            sink.add_rad(e1, 0, gr.x); sink.add_rad(e1, 1, gr.y); sink.add_rad(e1, 2, gr.z);
+        }
+        if (a_val.x == 0.f && a_val.y == 0.f && a_val.z == 0.f && a_w == 0.f) continue;
+        float a_pdf0 = a_w * dw_dpdf0;
+        const Vec3f a_fv = a_val * cfac;
+        const float a_cfac = dot(a_val, f);
+        const float a_G = a_cfac / pdf0;                       // cfac = G * J / pdf0
+        const float a_J = a_cfac * cfac;
+        a_pdf0 += -a_cfac * cfac / pdf0;
+        const float a_pdf_s = a_pdf0 * G;                      // pdf0 = pdf_s * detach(G)
+        sink.add_tri(h1.tri, 21, a_J / T1.area);               // J = A / detach(A)
+        const float a_cosv = a_G * (cosv < 0.f ? -1.f : 1.f) / (t1 * t1);
+        float a_t1 = -2.f * a_G * G / t1;
+        scatter_vec(sink, h1.tri, 18, wo * (-a_cosv));         // cosv = -fn . wo
+        Vec3f a_wo = T1.fn * (-a_cosv);
+        Vec3f a_wol(0.f);
+        brev.eval_vjp(sink, tv0, its, wol, a_fv, va.wi, a_wol, va.u, va.v);
+        brev.sampled_pdf_vjp(sink, tv0, its, s, a_pdf_s, va.wi, va.u, va.v);
+        acc(a_wo, its.sh.s * a_wol.x + its.sh.t * a_wol.y + its.sh.n * a_wol.z);   // wol = to_local(wo)
+        acc(va.s, wo * a_wol.x); acc(va.t, wo * a_wol.y); acc(va.n, wo * a_wol.z);
+        Vec3f a_dvec = a_wo / t1;                              // wo = dvec / t1 ; t1 = |dvec|
+        a_t1 += -dot(a_wo, wo) / t1;
+        acc(a_dvec, wo * a_t1);
+        scatter_point(sink, h1.tri, h1.u, h1.v, a_dvec);
+        acc(va.p, -a_dvec);
+    }
+    for (int i = 0; i < nL; ++i) {
+        const float s0 = rng.next(), s1 = rng.next();
+        float r0 = s0, r1 = s1;                                // mirrors sample_emitter_position
+        int e = 0; float epdf = 1.f;
+        if (sc.d.num_emitters > 1) e = sample_reuse(sc.d.emitter_cmf, sc.d.emitter_pmf, sc.d.emitter_sum, sc.d.num_emitters, r1, epdf);
+        const float *ef = sc.d.emitter_f + (size_t) e * PSDR_EMITTER_F_STRIDE;
+        const int32_t *ei = sc.d.emitter_i + (size_t) e * PSDR_EMITTER_I_STRIDE;
+        float fp;
+        const int fidx = sample_reuse(sc.d.face_cmf + ei[3], sc.d.face_pmf + ei[3], ef[5], ei[2], r0, fp);
+        const float tt = sqrtf(fmaxf(1.f - r0, 0.f));
+        const float ba = 1.f - tt, bb = tt * r1;
+        const int etri = ei[1] + fidx;
+        const TriRow<float> Te = load_tri<float>(sc, tv0, etri);
+        const Vec3f psp = bary_point(Te.p0, Te.e1, Te.e2, ba, bb);
+        const float pspdf = ef[4] * epdf;
+        const Vec3f wov = psp - its.p;
+        const float d2 = dot(wov, wov), dist = sqrtf(fmaxf(d2, 0.f));
+        const Vec3f wo = wov / dist;
+        nrays++;
+        const Hit h2 = closest_hit(sc, st, its.p, wo, INFINITY);
+        if (h2.tri < 0) continue;
+        const int tm2 = sc.d.tri_mesh[h2.tri], mesh2 = tm2 & ~PSDR_TRI_FACE_NORMALS;
+        const int e2 = sc.d.mesh_emitter[mesh2];
+        const TriRow<float> T2 = load_tri<float>(sc, tv0, h2.tri);
+        const Vec3f p2 = bary_point(T2.p0, T2.e1, T2.e2, h2.u, h2.v);
+        const float t2 = norm(p2 - its.p);
+        if (!(t2 > dist - kShadowEpsilon && e2 >= 0)) continue;
+        const ShNormal sn2 = shading_normal(T2, (tm2 & PSDR_TRI_FACE_NORMALS) != 0, h2.u, h2.v);
+        if (!(-dot((p2 - its.p) / t2, sn2.n) > 0.f)) continue;         // Le = 0 from behind
+        const float *rr = sc.d.emitter_f + (size_t) e2 * PSDR_EMITTER_F_STRIDE;
+        const Vec3f Le2{rr[0], rr[1], rr[2]};
+        const float cosv = -dot(T2.fn, wo);
+        const float G = fabsf(cosv) / d2;
+        const Vec3f wl = its.sh.to_local(wo);
+        const Vec3f f = bsdf.eval(sc, tv0, its, wl, true);
+        const float cfac = G / pspdf;                                   // G * ps.J / ps.pdf, J = 1
+        const Vec3f valv = f * cfac;
+        const float pdfb = bsdf.pdf(sc, tv0, its, wl, true);
+        const float pdf1 = pdfb * G;
+        float w = 1.f / (float) nL, dw_dpdf1 = 0.f;
+        if (nB > 0) {
+            const float a2 = pspdf * pspdf, b2 = pdf1 * pdf1, den = a2 + b2;
+            w *= a2 / den;
+            dw_dpdf1 = (-2.f * a2 * pdf1 / (den * den)) / (float) nL;
+        }
+        out.c = out.c + Le2 * valv * w;
+        if (!BACKWARD) continue;
+        const Vec3f gr = a_c * valv * w;
+        sink.add_rad(e2, 0, gr.x); sink.add_rad(e2, 1, gr.y); sink.add_rad(e2, 2, gr.z);
+        const Vec3f a_val = a_c * Le2 * w;
+        const float a_w = dot(a_c, Le2 * valv);
+        const float a_pdfb = a_w * dw_dpdf1 * G;                        // pdf1 = pdfb * detach(G)
+        const Vec3f a_fv = a_val * cfac;
+        const float a_cfac = dot(a_val, f);
+        const float a_G = a_cfac / pspdf;
+        sink.add_tri(etri, 21, a_cfac * cfac / Te.area);                // ps.J = A_e / detach(A_e)
+        const float a_cosv = a_G * (cosv < 0.f ? -1.f : 1.f) / d2;
+        float a_d2 = -a_G * G / d2;
+        scatter_vec(sink, h2.tri, 18, wo * (-a_cosv));
+        Vec3f a_wo = T2.fn * (-a_cosv);
+        Vec3f a_wl(0.f);
+        brev.eval_vjp(sink, tv0, its, wl, a_fv, va.wi, a_wl, va.u, va.v);
+        brev.pdf_vjp(sink, tv0, its, wl, a_pdfb, va.wi, a_wl, va.u, va.v);
+        acc(a_wo, its.sh.s * a_wl.x + its.sh.t * a_wl.y + its.sh.n * a_wl.z);
+        acc(va.s, wo * a_wl.x); acc(va.t, wo * a_wl.y); acc(va.n, wo * a_wl.z);
+        Vec3f a_wov = a_wo / dist;
+        const float a_dist = -dot(a_wo, wo) / dist;
+        a_d2 += a_dist / (2.f * dist);
+        acc(a_wov, wov * (2.f * a_d2));
+        scatter_point(sink, etri, ba, bb, a_wov);
+        acc(va.p, -a_wov);
+    }
+    return out;
+}
+
+struct NullSink {
+    PSDR_HD void add_tri(int, int, float) {}
+    PSDR_HD void add_texel(int, float) {}
+    PSDR_HD void add_rad(int, int, float) {}
+    PSDR_HD void add_cam(int, float) {}
+    PSDR_HD void add_sedge(int, int, float) {}
+    PSDR_HD void add_pedge(int, int, float) {}
+};
+
+constexpr int kMaxRevDepth = 8;
+
+// Back-propagates the adjoints of a PATH-SPACE vertex (k >= 1) into its triangle row and returns the
+// adjoint of the previous vertex' position (wi_k = to_local_k(-(p_k - p_{k-1}) / t)).
+template <class Sink> PSDR_HD Vec3f path_vertex_backward(Sink &sink, const SceneView &sc, const Its<float> &v, const Vec3f &prev_p, VertexAdj va) {
+    const TangentView<0> tv0{};
+    const TriRow<float> T = load_tri<float>(sc, tv0, v.tri);
+    const bool face = (sc.d.tri_mesh[v.tri] & PSDR_TRI_FACE_NORMALS) != 0;
+    const ShNormal sn = shading_normal(T, face, v.hu, v.hv);
+    Vec3f dir = v.p - prev_p;
+    const float t = norm(dir);
+    dir = dir / t;
+    const Vec3f a_dir = -(v.sh.s * va.wi.x + v.sh.t * va.wi.y + v.sh.n * va.wi.z);
+    acc(va.s, dir * (-va.wi.x)); acc(va.t, dir * (-va.wi.y)); acc(va.n, dir * (-va.wi.z));
+    const Vec3f a_shn = va.n + frame_vjp(sn.n, va.s, va.t);
+    float abu = 0.f, abv = 0.f;
+    shading_normal_vjp(sink, v.tri, T, sn, v.hu, v.hv, a_shn, abu, abv);      // barycentrics detached: abu/abv dropped
+    const Vec3f a_dvec = (a_dir - dir * dot(dir, a_dir)) / t;
+    scatter_point(sink, v.tri, v.hu, v.hv, va.p + a_dvec);
+    return -a_dvec;
+}
+
+// One camera sample in reverse mode (Integrator::__render<true> + enoki.backward).
+//   adj = dLoss/d(pixel) / spp.   Returns the primal sample value.
+template <class Sink>
+PSDR_HD Vec3f camera_sample_reverse(Sink &sink, const SceneView &sc, TraversalStack &st, const LiParams &lp, const RngJump &jump, int pixel,
+                                    uint64_t slot, const Vec3f &adj, uint32_t &nrays) {
+    const TangentView<0> tv0{};
+    Rng rng; rng.init(slot, jump);
+    const float j0 = rng.next(), j1 = rng.next();
+    const int W = sc.d.width;
+    const float sx = ((float) (pixel % W) + j0) / (float) W, sy = ((float) (pixel / W) + j1) / (float) sc.d.height;
+    const Vec3f dcam = camera_space_dir(sc, sx, sy);
+    const RayT<float> ray = primary_ray<float>(sc, tv0, sx, sy);
+    nrays++;
+    const Hit h0 = closest_hit(sc, st, ray.o, ray.d, INFINITY);
+    if (h0.tri < 0) return Vec3f(0.f);
+    const int tm0 = sc.d.tri_mesh[h0.tri];
+    const bool face0 = (tm0 & PSDR_TRI_FACE_NORMALS) != 0;
+    const TriRow<float> T0 = load_tri<float>(sc, tv0, h0.tri);
+    // solid-angle form (scene.cpp:355-376)
+    float bu, bv, t0;
+    moeller_trumbore(T0.p0, T0.e1, T0.e2, ray, bu, bv, t0);
+    Its<float> its;
+    its.valid = true; its.tri = h0.tri; its.mesh = tm0 & ~PSDR_TRI_FACE_NORMALS; its.hu = h0.u; its.hv = h0.v;
+    its.n = T0.fn; its.J = 1.f; its.t = t0;
+    its.p = ray.o + ray.d * t0;
+    const ShNormal sn0 = shading_normal(T0, face0, bu, bv);
+    its.sh = Frame<float>(sn0.n);
+    its.wi = its.sh.to_local(-ray.d);
+    const float *q = sc.d.tri_uv ? sc.d.tri_uv + (size_t) h0.tri * PSDR_TRIUV_STRIDE : nullptr;
+    its.uvx = q ? (q[2] - q[0]) * bu + ((q[4] - q[0]) * bv + q[0]) : 0.f;
+    its.uvy = q ? (q[3] - q[1]) * bu + ((q[5] - q[1]) * bv + q[1]) : 0.f;
+
+    VertexAdj va0; va0.clear();                 // adjoints of the primary vertex; its solid-angle chain runs last
+    Vec3f result(0.f);
+    if (lp.integrator == PSDR_INTEGRATOR_FIELD) {
+        // FieldExtractionIntegrator (field.cpp:34-54): position / depth / geoNormal carry derivatives
+        float a_t = 0.f;
+        switch (lp.field) {
+            case PSDR_FIELD_SILHOUETTE: result = Vec3f(1.f); break;
+            case PSDR_FIELD_POSITION: result = its.p; va0.p = adj; break;
+            case PSDR_FIELD_DEPTH: result = Vec3f(t0); a_t = adj.x + adj.y + adj.z; break;
+            case PSDR_FIELD_GEONORMAL: result = its.n; scatter_vec(sink, h0.tri, 18, adj); break;
+            case PSDR_FIELD_SHNORMAL: result = its.sh.n; va0.n = adj; break;
+            default: result = Vec3f{its.uvx, its.uvy, 0.f}; va0.u = adj.x; va0.v = adj.y; break;
+        }
+        if (!(isfinite(result.x) && isfinite(result.y) && isfinite(result.z))) return zero_nonfinite(result);
+        // fold a_t into the chain below through p = o + t d  (depth == t)
+        const Vec3f a_shn = va0.n + frame_vjp(sn0.n, va0.s, va0.t);
+        float abu = 0.f, abv = 0.f;
+        shading_normal_vjp(sink, h0.tri, T0, sn0, bu, bv, a_shn, abu, abv);
+        if (q) { abu += va0.u * (q[2] - q[0]) + va0.v * (q[3] - q[1]); abv += va0.u * (q[4] - q[0]) + va0.v * (q[5] - q[1]); }
+        const MtAdj ma = mt_vjp(T0.p0, T0.e1, T0.e2, ray, abu, abv, a_t + dot(va0.p, ray.d));
+        scatter_vec(sink, h0.tri, 0, ma.p0); scatter_vec(sink, h0.tri, 3, ma.e1); scatter_vec(sink, h0.tri, 6, ma.e2);
+        camera_ray_vjp(sink, sc, dcam, va0.p + ma.o, va0.p * t0 + ma.d);
+        return result;
+    }
+
+    const bool direct = lp.integrator == PSDR_INTEGRATOR_DIRECT;
+    const int nB = direct ? lp.bsdf_samples : 1, nL = direct ? lp.light_samples : 1;
+    const int depth = direct ? 1 : (lp.max_depth < kMaxRevDepth ? lp.max_depth : kMaxRevDepth);
+
+    const int e0 = sc.d.mesh_emitter[its.mesh];
+    const bool le0 = !lp.hide_emitters && e0 >= 0 && its.wi.z > 0.f;
+    if (le0) { const float *r = sc.d.emitter_f + (size_t) e0 * PSDR_EMITTER_F_STRIDE; result = Vec3f{r[0], r[1], r[2]}; }
+
+    // ---- sweep 1 (values): record (c_k, f_k), build the suffix radiances T_k
+    Vec3f ck[kMaxRevDepth], fk[kMaxRevDepth];
+    int nv = 0;
+    {
+        NullSink ns; VertexAdj dummy; dummy.clear();
+        Rng r1 = rng;
+        Its<float> cur = its;
+        Vec3f beta(1.f);
+        for (int k = 0; k < depth; ++k) {
+            const VertexOut vo = vertex_eval<false>(ns, sc, st, r1, cur, nB, nL, Vec3f(0.f), Vec3f(0.f), dummy, nrays);
+            ck[k] = vo.c; fk[k] = vo.f; nv = k + 1;
+            result = result + beta * vo.c;
+            if (!vo.next_valid) break;
+            beta = beta * vo.f; cur = vo.next;
+            if (!(beta.x != 0.f || beta.y != 0.f || beta.z != 0.f)) break;
+        }
+    }
+    // masked(value, ~isfinite(value)) = 0 (integrator.cpp:87): a zeroed sample has no gradient either
+    if (!(isfinite(result.x) && isfinite(result.y) && isfinite(result.z))) return zero_nonfinite(result);
+    if (le0) { sink.add_rad(e0, 0, adj.x); sink.add_rad(e0, 1, adj.y); sink.add_rad(e0, 2, adj.z); }
+    Vec3f Tk[kMaxRevDepth + 1];
+    Tk[nv] = Vec3f(0.f);
+    for (int k = nv - 1; k >= 0; --k) Tk[k] = ck[k] + fk[k] * Tk[k + 1];
+
+    // ---- sweep 2: replay the same random numbers, differentiate vertex by vertex
+    {
+        Its<float> cur = its;
+        Vec3f beta(1.f);
+        Its<float> prev = its;       // vertex k-1
+        for (int k = 0; k < nv; ++k) {
+            const Vec3f a_c = adj * beta;
+            const Vec3f a_f = (k + 1 < nv) ? a_c * Tk[k + 1] : Vec3f(0.f);
+            VertexAdj va; va.clear();
+            const VertexOut vo = vertex_eval<true>(sink, sc, st, rng, cur, nB, nL, a_c, a_f, k == 0 ? va0 : va, nrays);
+            if (k >= 1) {
+                const Vec3f a_prev = path_vertex_backward(sink, sc, cur, prev.p, va);
+                if (k == 1) acc(va0.p, a_prev);
+                else scatter_point(sink, prev.tri, prev.hu, prev.hv, a_prev);
+            }
+            if (!vo.next_valid || k + 1 >= nv) break;
+            beta = beta * vo.f; prev = cur; cur = vo.next;
+        }
+    }
+    // ---- primary vertex: wi = to_local(-d), frame(sh_n(bu,bv)), uv(bu,bv), p = o + t d, (bu,bv,t) = MT(tri0, ray)
+    {
+        Vec3f a_d = -(its.sh.s * va0.wi.x + its.sh.t * va0.wi.y + its.sh.n * va0.wi.z);
+        acc(va0.s, ray.d * (-va0.wi.x)); acc(va0.t, ray.d * (-va0.wi.y)); acc(va0.n, ray.d * (-va0.wi.z));
+        const Vec3f a_shn = va0.n + frame_vjp(sn0.n, va0.s, va0.t);
+        float abu = 0.f, abv = 0.f;
+        shading_normal_vjp(sink, h0.tri, T0, sn0, bu, bv, a_shn, abu, abv);
+        if (q) { abu += va0.u * (q[2] - q[0]) + va0.v * (q[3] - q[1]); abv += va0.u * (q[4] - q[0]) + va0.v * (q[5] - q[1]); }
+        const MtAdj ma = mt_vjp(T0.p0, T0.e1, T0.e2, ray, abu, abv, dot(va0.p, ray.d));
+        scatter_vec(sink, h0.tri, 0, ma.p0); scatter_vec(sink, h0.tri, 3, ma.e1); scatter_vec(sink, h0.tri, 6, ma.e2);
+        camera_ray_vjp(sink, sc, dcam, va0.p + ma.o, a_d + va0.p * t0 + ma.d);
+    }
+    return result;
+}
+
+// One primary-edge slot in reverse mode (integrator.cpp:98-119): value = x_dot_n * dL / pdf / sppe with
+// x_dot_n = dot(lerp(p0, p1, u), n) the only differentiable factor -> gradient w.r.t. the edge table.
+template <class Sink>
+PSDR_HD void primary_edge_reverse(Sink &sink, const SceneView &sc, TraversalStack &st, const LiParams &lp, const RngJump &jump, uint64_t slot,
+                                  float inv_sppe, const float *__restrict__ adj_img, uint32_t &nrays) {
+    Rng rng; rng.init(slot, jump);
+    float u = rng.next(), pmf;
+    const int k = sample_reuse(sc.d.prim_cmf, sc.d.prim_pmf, sc.d.prim_sum, sc.d.num_prim_edges, u, pmf);
+    const float *pe = sc.d.prim_edge + (size_t) k * PSDR_PEDGE_STRIDE;
+    const float nx = pe[4], ny = pe[5], pdf = pmf / pe[6];
+    const float px = pe[0] * (1.f - u) + pe[2] * u, py = pe[1] * (1.f - u) + pe[3] * u;
+    const int W = sc.d.width, H = sc.d.height;
+    const int ix = (int) floorf(px * (float) W), iy = (int) floorf(py * (float) H);
+    const bool valid = ix >= 0 && ix < W && iy >= 0 && iy < H;
+    const TangentView<0> tv0{};
+    const RayT<float> ray_p = primary_ray<float>(sc, tv0, px + kEdgeEpsilon * nx, py + kEdgeEpsilon * ny);
+    const RayT<float> ray_n = primary_ray<float>(sc, tv0, px - kEdgeEpsilon * nx, py - kEdgeEpsilon * ny);
+    const Vec3f Ln = Li<float>(sc, tv0, st, lp, rng, ray_n, valid, nrays);
+    const Vec3f Lp = Li<float>(sc, tv0, st, lp, rng, ray_p, valid, nrays);
+    if (!valid) return;
+    const float *a = adj_img + (size_t) (iy * W + ix) * 3;
+    const float xdn = px * nx + py * ny;
+    float g = 0.f;
+    const float dL[3] = {(Ln.x - Lp.x) / pdf, (Ln.y - Lp.y) / pdf, (Ln.z - Lp.z) / pdf};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) if (isfinite(xdn * dL[c])) g += a[c] * dL[c];
+    g *= inv_sppe;
+    if (g == 0.f || !isfinite(g)) return;
+    sink.add_pedge(k, 0, g * (1.f - u) * nx); sink.add_pedge(k, 1, g * (1.f - u) * ny);
+    sink.add_pedge(k, 2, g * u * nx); sink.add_pedge(k, 3, g * u * ny);
+}
+
+// One secondary-edge slot in reverse mode (direct.cpp:225-316): result = value0 * dot(n, u2(theta)).
+template <class Sink>
+PSDR_HD void secondary_edge_reverse(Sink &sink, const SceneView &sc, TraversalStack &st, const float s3[3], float scale,
+                                    const float *__restrict__ adj_img, uint32_t &nrays) {
+    const TangentView<0> tv0{};
+    float s1 = s3[0], pdf0;
+    const int k = sample_reuse(sc.d.sec_cmf, sc.d.sec_pmf, sc.d.sec_sum, sc.d.num_sec_edges, s1, pdf0);
+    const float *se = sc.d.sec_edge + (size_t) k * PSDR_SEDGE_STRIDE;
+    const Vec3f ep0{se[0], se[1], se[2]}, ee1{se[3], se[4], se[5]}, n0{se[6], se[7], se[8]}, n1{se[9], se[10], se[11]}, ep2{se[12], se[13], se[14]};
+    const bool is_boundary = se[15] != 0.f;
+    const Vec3f p0 = ee1 * s1 + ep0;
+    const float e1len = norm(ee1);
+    const Vec3f edge = ee1 / e1len, edge2 = ep2 - ep0;
+    pdf0 /= e1len;
+    const PosSample<float> ps2 = sample_emitter_position<float>(sc, tv0, s3[1], s3[2], false);
+    const Vec3f p2 = ps2.p, bn = ps2.n;
+    Vec3f e = p2 - p0;
+    const float distSqr = dot(e, e);
+    e = e / sqrtf(fmaxf(distSqr, 0.f));
+    const float cosTheta = -dot(bn, e);
+    const float d0n = dot(n0, e), d1n = dot(n1, e);
+    const int sgn0 = d0n > kEdgeEpsilon ? 1 : (d0n < -kEdgeEpsilon ? -1 : 0), sgn1 = d1n > kEdgeEpsilon ? 1 : (d1n < -kEdgeEpsilon ? -1 : 0);
+    bool valid = cosTheta > kEpsilon && (is_boundary ? sgn0 != 0 : sgn0 * sgn1 < 0);
+    const float bpdf = pdf0 * ps2.pdf * (distSqr / cosTheta);
+    const Vec3f dir = normalize(p2 - p0);
+    const Its<float> its2 = intersect<float>(sc, tv0, st, RayT<float>{p0, dir}, valid, kDetached, nrays);
+    valid = valid && its2.valid && norm(its2.p - p2) < kShadowEpsilon;
+    const Its<float> its1c = intersect<float>(sc, tv0, st, RayT<float>{p0, -dir}, valid, kDetached, nrays);
+    if (!(valid && its1c.valid)) return;
+    const Vec3f p1 = its1c.p;
+    int pixel; float qx, qy, sensor_val;
+    if (!sample_direct(sc, p1, pixel, qx, qy, sensor_val)) return;
+    const Vec3f dcam = camera_space_dir(sc, qx, qy);
+    const RayT<float> cam = primary_ray<float>(sc, tv0, qx, qy);
+    nrays++;
+    const Hit hc = closest_hit(sc, st, cam.o, cam.d, INFINITY);
+    if (hc.tri < 0) return;
+    const TriRow<float> Tc = load_tri<float>(sc, tv0, hc.tri);
+    float cu, cv, ct;
+    moeller_trumbore(Tc.p0, Tc.e1, Tc.e2, cam, cu, cv, ct);
+    const Vec3f x1 = cam.o + cam.d * ct;                                  // its1.p (solid-angle form)
+    if (!(norm(x1 - p1) < kShadowEpsilon)) return;
+    const float dist = norm(p2 - p1), cos2 = fabsf(dot(bn, dir));
+    const Vec3f ev = cross(edge, dir);
+    const float sinphi = norm(ev);
+    const Vec3f proj = normalize(cross(ev, bn));
+    const float sinphi2 = norm(cross(dir, proj));
+    if (!(sinphi > kEpsilon && sinphi2 > kEpsilon)) return;
+    const float base_v = (its1c.t / dist) * (sinphi / sinphi2) * cos2;
+    const Vec3f d0 = -cam.d;
+    const Vec3f d0_local = its1c.sh.to_local(d0);
+    const Bsdf<float> bsdf(sc, sc.d.mesh_bsdf[its1c.mesh]);
+    Vec3f bsdf_val = bsdf.eval(sc, tv0, its1c, d0_local, true);
+    bsdf_val = bsdf_val * fabsf((its1c.wi.z * dot(d0, its1c.n)) / (d0_local.z * dot(dir, its1c.n)));
+    Vec3f value0 = bsdf_val * Le<float>(sc, tv0, its2, true) * (base_v * sensor_val / bpdf);
+    const Vec3f n = normalize(cross(bn, proj));
+    value0 = value0 * (copysignf(1.f, dot(ev, edge2)) * copysignf(1.f, dot(ev, n)));
+    const TriRow<float> TA = load_tri<float>(sc, tv0, its2.tri);
+    const Vec3f wv = p0 - x1;
+    const RayT<float> shadow{x1, normalize(wv)};
+    // adjoint seed: a_dn = <adj_pixel, value0> * scale (non-finite components of the value are masked)
+    float su, sv, stt;
+    moeller_trumbore(TA.p0, TA.e1, TA.e2, shadow, su, sv, stt);
+    const Vec3f u2 = bary_point(TA.p0, TA.e1, TA.e2, su, sv);
+    const float dn = dot(n, u2);
+    const float *a = adj_img + (size_t) pixel * 3;
+    float a_dn = 0.f;
+    const float v0[3] = {value0.x, value0.y, value0.z};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) if (isfinite(v0[c] * dn)) a_dn += a[c] * v0[c];
+    a_dn *= scale;
+    if (a_dn == 0.f || !isfinite(a_dn)) return;
+    const Vec3f a_u2 = n * a_dn;
+    const MtAdj ma = mt_vjp(TA.p0, TA.e1, TA.e2, shadow, dot(a_u2, TA.e1), dot(a_u2, TA.e2), 0.f);
+    scatter_vec(sink, its2.tri, 0, ma.p0); scatter_vec(sink, its2.tri, 3, ma.e1); scatter_vec(sink, its2.tri, 6, ma.e2);
+    const Vec3f a_w = normalize_vjp(wv, shadow.d, ma.d);
+    // bp0 = e1 * s1 + p0 (edge table)
+    sink.add_sedge(k, 0, a_w.x); sink.add_sedge(k, 1, a_w.y); sink.add_sedge(k, 2, a_w.z);
+    sink.add_sedge(k, 3, a_w.x * s1); sink.add_sedge(k, 4, a_w.y * s1); sink.add_sedge(k, 5, a_w.z * s1);
+    const Vec3f a_x1 = ma.o - a_w;
+    // x1 = o + t d with (.,.,t) = MT(triangle C, camera ray)
+    const MtAdj mc = mt_vjp(Tc.p0, Tc.e1, Tc.e2, cam, 0.f, 0.f, dot(a_x1, cam.d));
+    scatter_vec(sink, hc.tri, 0, mc.p0); scatter_vec(sink, hc.tri, 3, mc.e1); scatter_vec(sink, hc.tri, 6, mc.e2);
+    camera_ray_vjp(sink, sc, dcam, a_x1 + mc.o, a_x1 * ct + mc.d);
+}
+
+}  // namespace psdr

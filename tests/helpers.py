@@ -81,6 +81,47 @@ def host_render(tb, opts, mode=0, tangents=None, guide=None, nthreads=None):
     return (img.reshape(-1, 3), dimg.reshape(-1, 3)) if mode else img.reshape(-1, 3)
 
 
+def _grad_buffers(tb, want):
+    bufs, g = {}, _abi.Grads()
+    for name in want:
+        t = tb.get(name)
+        if t is None:
+            continue
+        bufs[name] = np.zeros(tuple(t.shape), dtype=np.float32)
+        setattr(g, "g_" + name, bufs[name].ctypes.data)
+    return bufs, g
+
+
+def host_render_rev(tb, opts, adj, want=AD_KEYS, guide=None):
+    """Reverse mode of the product code on the host: returns (img, {table: gradient})."""
+    H = hostcheck_lib()
+    tbc = {k: (v.detach().cpu() if isinstance(v, torch.Tensor) else v) for k, v in tb.items()}
+    if guide is not None:
+        guide = (guide[0], guide[1].cpu(), guide[2].cpu(), guide[3])
+    desc, keep = make_desc(tbc, guide, device="cpu")
+    bufs, g = _grad_buffers(tbc, want)
+    adj = np.ascontiguousarray(adj, dtype=np.float32).reshape(-1)
+    img = np.zeros(adj.shape[0], np.float32)
+    rc = H.hostcheck_render_rev(C.byref(desc), C.byref(opts), C.c_void_p(adj.ctypes.data), C.c_void_p(img.ctypes.data), C.byref(g))
+    assert rc == 0
+    return img.reshape(-1, 3), bufs
+
+
+def random_tangents(tb, names, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    for n in names:
+        t = tb.get(n)
+        if t is not None:
+            out[n] = (torch.rand(t.shape, generator=g) - 0.5).float()
+    return out
+
+
+def dot_tables(grads, tangents):
+    return float(sum((np.asarray(grads[n], dtype=np.float64) * tangents[n].numpy().astype(np.float64)).sum()
+                     for n in tangents if n in grads))
+
+
 # ---------------------------------------------------------------- GPU through the C ABI
 class GpuScene:
     """Thin ctypes driver of libpsdr_hip.so (exactly what a foreign-language binding would do)."""
@@ -132,6 +173,22 @@ class GpuScene:
         _abi.check(self.lib, self.lib.psdr_render_d_fwd(self.h, C.byref(opts), K, tarr, img.data_ptr(), dimg.data_ptr(), None))
         torch.cuda.synchronize()
         return img.cpu().numpy().reshape(-1, 3), dimg.cpu().numpy().reshape(K, -1, 3)
+
+    def render_d_rev(self, opts, adj, want=AD_KEYS, with_image=True):
+        adj_t = torch.as_tensor(np.ascontiguousarray(adj, dtype=np.float32).reshape(-1)).cuda()
+        img = torch.empty(self.n, dtype=torch.float32, device="cuda") if with_image else None
+        g = _abi.Grads()
+        bufs = {}
+        for name in want:
+            t = self.tb.get(name)
+            if t is None:
+                continue
+            bufs[name] = torch.zeros(tuple(t.shape), dtype=torch.float32, device="cuda")
+            setattr(g, "g_" + name, bufs[name].data_ptr())
+        _abi.check(self.lib, self.lib.psdr_render_d_rev(self.h, C.byref(opts), adj_t.data_ptr(), img.data_ptr() if with_image else None,
+                                                        C.byref(g), None))
+        torch.cuda.synchronize()
+        return (img.cpu().numpy().reshape(-1, 3) if with_image else None), {k: v.cpu().numpy() for k, v in bufs.items()}
 
     def trace(self, o, d, tmax=None):
         o = torch.as_tensor(np.ascontiguousarray(o, dtype=np.float32)).cuda()

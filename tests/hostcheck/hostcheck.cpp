@@ -3,6 +3,7 @@
 // oracle where no GPU exists.  It is never imported by the psdr_cuda package and is not a fallback:
 // the render path (libpsdr_hip.so) only ever executes these functions inside HIP kernels.
 #include "../../psdr-cuda_amd/csrc/psdr_bvh_build.h"
+#include "../../psdr-cuda_amd/csrc/psdr_reverse.h"
 
 #include <thread>
 #include <vector>
@@ -150,4 +151,56 @@ int hostcheck_guide(const psdr_scene_desc *d, const int *reso, int nrounds, floa
     for (long long c = 0; c < cells; ++c) mass[c] = (float) m[c];
     return 0;
 }
+}
+
+namespace {
+struct HostSink {
+    psdr_grads g;
+    static void put(float *b, size_t i, float v) { if (b && v != 0.f && std::isfinite(v)) b[i] += v; }
+    void add_tri(int tri, int word, float v) const { put(g.g_tri_info, (size_t) tri * PSDR_TRI_STRIDE + word, v); }
+    void add_texel(int idx, float v) const { put(g.g_texels, idx, v); }
+    void add_rad(int e, int c, float v) const { put(g.g_emitter_rad, (size_t) e * 3 + c, v); }
+    void add_cam(int w, float v) const { put(g.g_cam_to_world, w, v); }
+    void add_sedge(int e, int w, float v) const { put(g.g_sec_edge, (size_t) e * PSDR_SEDGE_STRIDE + w, v); }
+    void add_pedge(int e, int w, float v) const { put(g.g_prim_edge, (size_t) e * PSDR_PEDGE_STRIDE + w, v); }
+};
+}  // namespace
+
+extern "C" int hostcheck_render_rev(const psdr_scene_desc *d, const psdr_render_opts *o, const float *adj, float *img, const psdr_grads *grads) {
+    HostScene hs;
+    if (!setup(hs, d)) return 1;
+    const int W = d->width, H = d->height;
+    const long long WH = (long long) W * H;
+    LiParams lp{o->integrator, o->bsdf_samples, o->light_samples, o->max_depth, o->hide_emitters, o->field};
+    HostSink sink; sink.g = *grads;
+    TraversalStack st; uint32_t nr = 0;
+    std::vector<double> acc((size_t) WH * 3, 0.0);
+    const int nsp = o->spp_end - o->spp_begin;
+    if (o->spp > 0 && nsp > 0) {
+        const RngJump jump = make_rng_jump(o->rng_offset[0]);
+        for (long long j = 0; j < WH * nsp; ++j) {
+            const int pixel = (int) (j / nsp), s = o->spp_begin + (int) (j % nsp);
+            const float inv = 1.f / o->spp;
+            const Vec3f a{adj[pixel * 3] * inv, adj[pixel * 3 + 1] * inv, adj[pixel * 3 + 2] * inv};
+            const Vec3f r = camera_sample_reverse(sink, hs.sc, st, lp, jump, pixel, (uint64_t) pixel * o->spp + s, a, nr);
+            acc[pixel * 3] += r.x * inv; acc[pixel * 3 + 1] += r.y * inv; acc[pixel * 3 + 2] += r.z * inv;
+        }
+    }
+    if (o->sppe > 0 && o->sppe_end > o->sppe_begin && d->num_prim_edges > 0) {
+        const RngJump jump = make_rng_jump(o->rng_offset[1]);
+        for (long long j = WH * o->sppe_begin; j < WH * o->sppe_end; ++j)
+            primary_edge_reverse(sink, hs.sc, st, lp, jump, (uint64_t) j, 1.f / o->sppe, adj, nr);
+    }
+    if (o->sppse > 0 && o->sppse_end > o->sppse_begin && d->num_sec_edges > 0 && o->integrator == PSDR_INTEGRATOR_DIRECT) {
+        const RngJump jump = make_rng_jump(o->rng_offset[2]);
+        const bool guided = d->guide_cmf && d->num_guide_cells > 0;
+        for (long long j = WH * o->sppse_begin; j < WH * o->sppse_end; ++j) {
+            Rng rng; rng.init((uint64_t) j, jump);
+            float s3[3] = {rng.next(), rng.next(), rng.next()};
+            const float pdf0 = guided ? guide_sample_reuse(hs.sc, s3) : 1.f;
+            secondary_edge_reverse(sink, hs.sc, st, s3, (pdf0 > kEpsilon ? 1.f / pdf0 : 1.f) / o->sppse, adj, nr);
+        }
+    }
+    if (img) for (size_t i = 0; i < acc.size(); ++i) img[i] = (float) acc[i];
+    return 0;
 }
