@@ -112,6 +112,12 @@ PSDR_HD Hit closest_hit(const SceneView &sc, TraversalStack &st, const Vec3f &o,
 }
 
 // ------------------------------------------------------------------------ table loads
+// Two scalar types run through the estimators:
+//   G  geometry  (positions, directions, frames, hit records):  float or Dual<K>
+//   M  material / radiance / throughput / result:               float or Dual<K>
+// with G in {float, M}.  <float,float> = renderC; <Dual,Dual> = renderD with geometry tangents;
+// <float,Dual> = renderD when only texels / emitter radiance carry tangents (albedo, roughness):
+// the geometry then stays in plain fp32 registers.
 template <class R> struct Loader;
 template <> struct Loader<float> {
     template <int KK> static PSDR_HD float f(const float *tab, const TangentView<KK> &, const float *const psdr_tangents::*, size_t i) { return tab[i]; }
@@ -125,16 +131,21 @@ template <int K> struct Loader<Dual<K>> {
     }
 };
 template <class R> using TV = TangentView<ad_traits<R>::K>;
-template <class R> PSDR_HD R ldf(const float *tab, const TV<R> &tv, const float *const psdr_tangents::*m, size_t i) {
+template <class R, class TVT> PSDR_HD R ldf(const float *tab, const TVT &tv, const float *const psdr_tangents::*m, size_t i) {
     return Loader<R>::f(tab, tv, m, i);
 }
-template <class R> PSDR_HD Vec3<R> ld3(const float *tab, const TV<R> &tv, const float *const psdr_tangents::*m, size_t i) {
+template <class R, class TVT> PSDR_HD Vec3<R> ld3(const float *tab, const TVT &tv, const float *const psdr_tangents::*m, size_t i) {
     return {ldf<R>(tab, tv, m, i), ldf<R>(tab, tv, m, i + 1), ldf<R>(tab, tv, m, i + 2)};
 }
+// G -> M promotion (identity, or float -> Dual with zero tangents)
+template <class M> PSDR_HD M to_m(float x) { return M(x); }
+template <class M, int K> PSDR_HD M to_m(const Dual<K> &x) { return x; }
+template <class M, class G> PSDR_HD Vec3<M> to_m3(const Vec3<G> &a) { return {to_m<M>(a.x), to_m<M>(a.y), to_m<M>(a.z)}; }
+// Vec3<M> * G-scalar when G = float and M = Dual is covered by the Vec3<Dual<K>> * float overload.
 
 // TriangleInfo_ row (include/psdr/types.h:135-146), gathered by global triangle id (scene.cpp:300)
 template <class R> struct TriRow { Vec3<R> p0, e1, e2, n0, n1, n2, fn; R area; };
-template <class R> PSDR_HD TriRow<R> load_tri(const SceneView &sc, const TV<R> &tv, int id) {
+template <class R, class TVT> PSDR_HD TriRow<R> load_tri(const SceneView &sc, const TVT &tv, int id) {
     const size_t o = (size_t) id * PSDR_TRI_STRIDE;
     const float *a = sc.d.tri_info;
     constexpr auto m = &psdr_tangents::d_tri_info;
@@ -175,8 +186,8 @@ enum HitForm { kDetached = 0, kPathSpace = 1, kSolidAngle = 2 };
 //   kDetached  : C types; barycentrics from the traversal, J = 1
 //   kPathSpace : D types, barycentrics DETACHED (point rides on the moving triangle), J = A/detach(A)
 //   kSolidAngle: D types, differentiable Moeller-Trumbore on the chosen triangle, J = 1
-template <class R> PSDR_HD Its<R> intersect(const SceneView &sc, const TV<R> &tv, TraversalStack &st, const RayT<R> &ray,
-                                            bool active, HitForm form, uint32_t &nrays) {
+template <class R, class TVT> PSDR_HD Its<R> intersect(const SceneView &sc, const TVT &tv, TraversalStack &st, const RayT<R> &ray,
+                                                       bool active, HitForm form, uint32_t &nrays) {
     Its<R> its;
     its.valid = false; its.tri = its.mesh = -1; its.J = R(1.f); its.t = R(INFINITY);
     if (!active) return its;
@@ -218,12 +229,12 @@ template <class R> PSDR_HD Its<R> intersect(const SceneView &sc, const TV<R> &tv
 
 template <class R> PSDR_HD int emitter_of(const SceneView &sc, const Its<R> &its) { return its.valid ? sc.d.mesh_emitter[its.mesh] : -1; }
 
-template <class R> PSDR_HD Vec3<R> radiance(const SceneView &sc, const TV<R> &tv, int e) {
+template <class M, class TVT> PSDR_HD Vec3<M> radiance(const SceneView &sc, const TVT &tv, int e) {
     const float *f = sc.d.emitter_f + (size_t) e * PSDR_EMITTER_F_STRIDE;
-    Vec3<R> r = {R(f[0]), R(f[1]), R(f[2])};
-    if constexpr (is_ad<R>()) {
+    Vec3<M> r = {M(f[0]), M(f[1]), M(f[2])};
+    if constexpr (is_ad<M>()) {
 #pragma unroll
-        for (int k = 0; k < ad_traits<R>::K; ++k) {
+        for (int k = 0; k < ad_traits<M>::K; ++k) {
             const float *p = tv.t[k].d_emitter_rad;
             if (p) { r.x.d[k] = p[e * 3]; r.y.d[k] = p[e * 3 + 1]; r.z.d[k] = p[e * 3 + 2]; }
         }
@@ -231,36 +242,38 @@ template <class R> PSDR_HD Vec3<R> radiance(const SceneView &sc, const TV<R> &tv
     return r;
 }
 // Intersection::Le -> AreaLight::eval (src/emitter/area.cpp:20-29)
-template <class R> PSDR_HD Vec3<R> Le(const SceneView &sc, const TV<R> &tv, const Its<R> &its, bool active) {
+template <class M, class G, class TVT> PSDR_HD Vec3<M> Le(const SceneView &sc, const TVT &tv, const Its<G> &its, bool active) {
     const int e = active ? emitter_of(sc, its) : -1;
-    if (e < 0 || !(val(its.wi.z) > 0.f)) return zero3<R>();
-    return radiance<R>(sc, tv, e);
+    if (e < 0 || !(val(its.wi.z) > 0.f)) return zero3<M>();
+    return radiance<M>(sc, tv, e);
 }
 
 // ------------------------------------------------------------------------------ BSDF
-// Bitmap<c>::eval (src/core/bitmap.cpp:41-89); 3-channel textures are stored interleaved RGB
-template <class R, int C> PSDR_HD void bitmap_eval(const SceneView &sc, const TV<R> &tv, const int32_t *slot, R u, R v, R *out) {
+// Bitmap<c>::eval (src/core/bitmap.cpp:41-89); 3-channel textures are stored interleaved RGB.
+// U = type of the texture coordinates (geometry), M = type of the texels.
+template <class M, int C, class U, class TVT>
+PSDR_HD void bitmap_eval(const SceneView &sc, const TVT &tv, const int32_t *slot, U u, U v, M *out) {
     const int off = slot[0], w = slot[1], h = slot[2];
     const float *tx = sc.d.texels;
     constexpr auto m = &psdr_tangents::d_texels;
     if (w == 1 && h == 1) {
 #pragma unroll
-        for (int c = 0; c < C; ++c) out[c] = ldf<R>(tx, tv, m, off + c);
+        for (int c = 0; c < C; ++c) out[c] = ldf<M>(tx, tv, m, off + c);
         return;
     }
     v = -v;
     u = u - floorf(val(u)); v = v - floorf(val(v));
     u = u * (float) (w - 1); v = v * (float) (h - 1);
     int px = (int) floorf(val(u)), py = (int) floorf(val(v));
-    const R w1x = u - (float) px, w1y = v - (float) py;
-    const R w0x = 1.f - w1x, w0y = 1.f - w1y;
+    const U w1x = u - (float) px, w1y = v - (float) py;
+    const U w0x = 1.f - w1x, w0y = 1.f - w1y;
     px = px < w - 2 ? px : w - 2; py = py < h - 2 ? py : h - 2;
     const size_t idx = (size_t) py * w + px;
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-        const R v00 = ldf<R>(tx, tv, m, off + idx * C + c), v10 = ldf<R>(tx, tv, m, off + (idx + 1) * C + c);
-        const R v01 = ldf<R>(tx, tv, m, off + (idx + w) * C + c), v11 = ldf<R>(tx, tv, m, off + (idx + w + 1) * C + c);
-        out[c] = w0y * (w0x * v00 + w1x * v10) + w1y * (w0x * v01 + w1x * v11);
+        const M v00 = ldf<M>(tx, tv, m, off + idx * C + c), v10 = ldf<M>(tx, tv, m, off + (idx + 1) * C + c);
+        const M v01 = ldf<M>(tx, tv, m, off + (idx + w) * C + c), v11 = ldf<M>(tx, tv, m, off + (idx + w + 1) * C + c);
+        out[c] = (v00 * w0x + v10 * w1x) * w0y + (v01 * w0x + v11 * w1x) * w1y;
     }
 }
 
@@ -317,53 +330,62 @@ template <class R> PSDR_HD R fresnel_conductor(const R &eta, const R &k, const R
     return 0.5f * (rs + rs * (T3 - T4) / (T3 + T4));
 }
 
-template <class R> struct Bsdf {
+// BSDF evaluated at a hit of geometry type G with parameters of type M; all results are M.
+template <class G, class M> struct Bsdf {
     const int32_t *rec;
     PSDR_HD Bsdf(const SceneView &sc, int id) : rec(sc.d.bsdf_rec + (size_t) (id < 0 ? 0 : id) * PSDR_BSDF_STRIDE) {}
     PSDR_HD int type() const { return rec[0]; }
     PSDR_HD const int32_t *slot(int s) const { return rec + 1 + 3 * s; }
-    PSDR_HD Vec3<R> tex3(const SceneView &sc, const TV<R> &tv, int s, const Its<R> &its) const {
-        R o[3]; bitmap_eval<R, 3>(sc, tv, slot(s), its.uvx, its.uvy, o); return {o[0], o[1], o[2]};
+    template <class TVT> PSDR_HD Vec3<M> tex3(const SceneView &sc, const TVT &tv, int s, const Its<G> &its) const {
+        M o[3]; bitmap_eval<M, 3>(sc, tv, slot(s), its.uvx, its.uvy, o); return {o[0], o[1], o[2]};
     }
-    PSDR_HD R tex1(const SceneView &sc, const TV<R> &tv, int s, const Its<R> &its) const {
-        R o[1]; bitmap_eval<R, 1>(sc, tv, slot(s), its.uvx, its.uvy, o); return o[0];
+    template <class TVT> PSDR_HD M tex1(const SceneView &sc, const TVT &tv, int s, const Its<G> &its) const {
+        M o[1]; bitmap_eval<M, 1>(sc, tv, slot(s), its.uvx, its.uvy, o); return o[0];
     }
     // Diffuse::__eval (diffuse.cpp:25-35) / RoughConductor::__eval (roughconductor.cpp:40-58); value = f * cos(theta_o)
-    PSDR_HD Vec3<R> eval(const SceneView &sc, const TV<R> &tv, const Its<R> &its, const Vec3<R> &wo, bool active) const {
-        if (!(active && val(its.wi.z) > 0.f && val(wo.z) > 0.f)) return zero3<R>();
+    template <class TVT> PSDR_HD Vec3<M> eval(const SceneView &sc, const TVT &tv, const Its<G> &its, const Vec3<G> &wo, bool active) const {
+        if (!(active && val(its.wi.z) > 0.f && val(wo.z) > 0.f)) return zero3<M>();
         if (type() == PSDR_BSDF_DIFFUSE) return tex3(sc, tv, PSDR_SLOT_REFLECTANCE, its) * (wo.z * kInvPi);
-        const GGX<R> g{tex1(sc, tv, PSDR_SLOT_ALPHA_U, its), tex1(sc, tv, PSDR_SLOT_ALPHA_V, its)};
-        const Vec3<R> H = normalize(wo + its.wi);
-        const R D = g.eval(H);
-        if (val(D) == 0.f) return zero3<R>();
-        const R res = D * (g.smith_g1(its.wi, H) * g.smith_g1(wo, H)) / (4.f * its.wi.z);
-        const Vec3<R> eta = tex3(sc, tv, PSDR_SLOT_ETA, its), k = tex3(sc, tv, PSDR_SLOT_K, its);
-        const R c = dot(its.wi, H);
-        const Vec3<R> F{fresnel_conductor(eta.x, k.x, c), fresnel_conductor(eta.y, k.y, c), fresnel_conductor(eta.z, k.z, c)};
+        const GGX<M> g{tex1(sc, tv, PSDR_SLOT_ALPHA_U, its), tex1(sc, tv, PSDR_SLOT_ALPHA_V, its)};
+        const Vec3<M> wi_m = to_m3<M>(its.wi), wo_m = to_m3<M>(wo);
+        const Vec3<M> H = normalize(wo_m + wi_m);
+        const M D = g.eval(H);
+        if (val(D) == 0.f) return zero3<M>();
+        const M res = D * (g.smith_g1(wi_m, H) * g.smith_g1(wo_m, H)) / (4.f * wi_m.z);
+        const Vec3<M> eta = tex3(sc, tv, PSDR_SLOT_ETA, its), k = tex3(sc, tv, PSDR_SLOT_K, its);
+        const M c = dot(wi_m, H);
+        const Vec3<M> F{fresnel_conductor(eta.x, k.x, c), fresnel_conductor(eta.y, k.y, c), fresnel_conductor(eta.z, k.z, c)};
         return F * res * tex3(sc, tv, PSDR_SLOT_REFLECTANCE, its);
     }
     // Diffuse::__pdf (diffuse.cpp:70-81: detached) / RoughConductor::__pdf (roughconductor.cpp:61-75: mask not applied)
-    PSDR_HD R pdf(const SceneView &sc, const TV<R> &tv, const Its<R> &its, const Vec3<R> &wo, bool active) const {
+    template <class TVT> PSDR_HD M pdf(const SceneView &sc, const TVT &tv, const Its<G> &its, const Vec3<G> &wo, bool active) const {
         if (type() == PSDR_BSDF_DIFFUSE) {
             const float ci = val(its.wi.z), co = val(wo.z);
-            return R((active && ci > 0.f && co > 0.f) ? kInvPi * co : 0.f);
+            return M((active && ci > 0.f && co > 0.f) ? kInvPi * co : 0.f);
         }
-        const Vec3<R> m = normalize(wo + its.wi);
-        const GGX<R> g{tex1(sc, tv, PSDR_SLOT_ALPHA_U, its), tex1(sc, tv, PSDR_SLOT_ALPHA_V, its)};
-        return g.eval(m) * g.smith_g1(its.wi, m) / (4.f * its.wi.z);
+        const Vec3<M> wi_m = to_m3<M>(its.wi);
+        const Vec3<M> m = normalize(to_m3<M>(wo) + wi_m);
+        const GGX<M> g{tex1(sc, tv, PSDR_SLOT_ALPHA_U, its), tex1(sc, tv, PSDR_SLOT_ALPHA_V, its)};
+        return g.eval(m) * g.smith_g1(wi_m, m) / (4.f * wi_m.z);
     }
-    // Diffuse::__sample (diffuse.cpp:48-57, uses tail<2>) / RoughConductor::__sample (roughconductor.cpp:78-92)
-    PSDR_HD bool sample(const SceneView &sc, const TV<R> &tv, const Its<R> &its, const float s[3], bool active, Vec3<R> &wo, R &pdf_) const {
+    // Diffuse::__sample (diffuse.cpp:48-57, uses tail<2>) / RoughConductor::__sample (roughconductor.cpp:78-92).
+    // Returns the sampled direction as plain floats (it only steers the traced ray; in D mode the
+    // BSDF is re-evaluated from the hit points) and its pdf as M (GGX: carries d/d(alpha, wi)).
+    template <class TVT> PSDR_HD bool sample(const SceneView &sc, const TVT &tv, const Its<G> &its, const float s[3], bool active, Vec3f &wo,
+                                             M &pdf_) const {
         if (type() == PSDR_BSDF_DIFFUSE) {
-            const Vec3f w = cosine_hemisphere(s[1], s[2]);
-            wo = lift<R>(w); pdf_ = R(kInvPi * w.z);
+            wo = cosine_hemisphere(s[1], s[2]);
+            pdf_ = M(kInvPi * wo.z);
             return active && val(its.wi.z) > 0.f;
         }
-        const GGX<R> g{tex1(sc, tv, PSDR_SLOT_ALPHA_U, its), tex1(sc, tv, PSDR_SLOT_ALPHA_V, its)};
-        const Vec3<R> m = g.sample(its.wi, s[0], s[1]);
-        wo = m * (2.f * dot(its.wi, m)) - its.wi;
-        pdf_ = pdf(sc, tv, its, wo, active);
-        return active && val(its.wi.z) > 0.f && val(pdf_) != 0.f && val(wo.z) > 0.f;
+        const GGX<M> g{tex1(sc, tv, PSDR_SLOT_ALPHA_U, its), tex1(sc, tv, PSDR_SLOT_ALPHA_V, its)};
+        const Vec3<M> wi_m = to_m3<M>(its.wi);
+        const Vec3<M> m = g.sample(wi_m, s[0], s[1]);
+        const Vec3<M> wo_m = m * (2.f * dot(wi_m, m)) - wi_m;
+        const Vec3<M> h = normalize(wo_m + wi_m);
+        pdf_ = g.eval(h) * g.smith_g1(wi_m, h) / (4.f * wi_m.z);
+        wo = val(wo_m);
+        return active && val(its.wi.z) > 0.f && val(pdf_) != 0.f && wo.z > 0.f;
     }
 };
 
@@ -372,7 +394,7 @@ template <class R> struct PosSample { Vec3<R> p, n; R J; float pdf; bool valid; 
 
 // Scene::sample_emitter_position (scene.cpp:427-447) -> AreaLight::sample_position (area.cpp:32-46)
 // -> Mesh::__sample_position (mesh.cpp:306-330)
-template <class R> PSDR_HD PosSample<R> sample_emitter_position(const SceneView &sc, const TV<R> &tv, float s0, float s1, bool with_J) {
+template <class R, class TVT> PSDR_HD PosSample<R> sample_emitter_position(const SceneView &sc, const TVT &tv, float s0, float s1, bool with_J) {
     PosSample<R> ps;
     int e = 0; float epdf = 1.f;
     if (sc.d.num_emitters > 1) e = sample_reuse(sc.d.emitter_cmf, sc.d.emitter_pmf, sc.d.emitter_sum, sc.d.num_emitters, s1, epdf);
@@ -400,7 +422,7 @@ template <class R> PSDR_HD float emitter_position_pdf(const SceneView &sc, const
 
 // ---------------------------------------------------------------------------- camera
 // PerspectiveCamera::sample_primary_ray (src/sensor/perspective.cpp:120-136)
-template <class R> PSDR_HD RayT<R> primary_ray(const SceneView &sc, const TV<R> &tv, float sx, float sy) {
+template <class R, class TVT> PSDR_HD RayT<R> primary_ray(const SceneView &sc, const TVT &tv, float sx, float sy) {
     const float *m = sc.d.cam + PSDR_CAM_SAMPLE_TO_CAMERA;
     float v[4];
 #pragma unroll
@@ -446,91 +468,96 @@ struct LiParams {                 // uniform per launch
 
 // The loop bodies of DirectIntegrator::__Li (src/integrator/direct.cpp:64-160) evaluated at `its`.
 // next_* report the FIRST BSDF-sampled vertex so the build-defined PathTracer can
-// continue the path from it.
-template <class R>
-PSDR_HD Vec3<R> direct_step(const SceneView &sc, const TV<R> &tv, TraversalStack &st, Rng &rng, const Its<R> &its, bool active, int nB,
-                            int nL, uint32_t &nrays, Its<R> *next_its, Vec3<R> *next_f, bool *next_valid) {
-    constexpr bool ad = is_ad<R>();
-    Vec3<R> result = zero3<R>();
-    const Bsdf<R> bsdf(sc, active ? sc.d.mesh_bsdf[its.mesh] : 0);
+// continue the path from it.  The D-mode forms (path-space hits, BSDF re-evaluated from the hit
+// points, detached G in the pdfs) are used whenever the result type M carries tangents.
+template <class G, class M, class TVT>
+PSDR_HD Vec3<M> direct_step(const SceneView &sc, const TVT &tv, TraversalStack &st, Rng &rng, const Its<G> &its, bool active, int nB,
+                            int nL, uint32_t &nrays, Its<G> *next_its, Vec3<M> *next_f, bool *next_valid) {
+    constexpr bool ad = is_ad<M>();
+    constexpr HitForm form = is_ad<G>() ? kPathSpace : kDetached;
+    Vec3<M> result = zero3<M>();
+    const Bsdf<G, M> bsdf(sc, active ? sc.d.mesh_bsdf[its.mesh] : 0);
     for (int i = 0; i < nB; ++i) {
         const float s[3] = {rng.next(), rng.next(), rng.next()};
         if (!active) continue;
-        Vec3<R> wo_s; R pdf_s;
+        Vec3f wo_s; M pdf_s;
         bool a1 = bsdf.sample(sc, tv, its, s, active, wo_s, pdf_s);
-        const RayT<R> ray1{its.p, its.sh.to_world(wo_s)};
-        const Its<R> its1 = intersect<R>(sc, tv, st, ray1, a1, ad ? kPathSpace : kDetached, nrays);
+        const Vec3f dir1 = val(its.sh.s) * wo_s.x + val(its.sh.t) * wo_s.y + val(its.sh.n) * wo_s.z;
+        const RayT<G> ray1{its.p, lift<G>(dir1)};
+        const Its<G> its1 = intersect<G>(sc, tv, st, ray1, a1, form, nrays);
         const bool a_hit = a1 && its1.valid;
         a1 = a_hit && emitter_of(sc, its1) >= 0;
-        Vec3<R> bsdf_val = zero3<R>(); R pdf0(0.f);
+        Vec3<M> bsdf_val = zero3<M>(); M pdf0(0.f);
         if (a_hit) {
             if constexpr (ad) {
-                const Vec3<R> wo = (its1.p - its.p) / its1.t;
+                const Vec3<G> wo = (its1.p - its.p) / its1.t;
                 bsdf_val = bsdf.eval(sc, tv, its, its.sh.to_local(wo), true);
-                const R G = abs_(dot(its1.n, -wo)) / sqr(its1.t);
-                pdf0 = pdf_s * detach(G);
-                bsdf_val = bsdf_val * (G * its1.J / pdf0);
+                const G Gv = abs_(dot(its1.n, -wo)) / sqr(its1.t);
+                pdf0 = pdf_s * val(Gv);
+                bsdf_val = bsdf_val * (to_m<M>(Gv * its1.J) / pdf0);
             } else {
-                bsdf_val = bsdf.eval(sc, tv, its, wo_s, true);
-                const R G = abs_(dot(its1.n, -ray1.d)) / sqr(its1.t);
-                pdf0 = pdf_s * G;
+                bsdf_val = bsdf.eval(sc, tv, its, lift<G>(wo_s), true);
+                const G Gv = abs_(dot(its1.n, -ray1.d)) / sqr(its1.t);
+                pdf0 = pdf_s * Gv;
                 bsdf_val = bsdf_val / pdf_s;
             }
         }
         if (a1) {
-            R w(1.f / (float) nB);
-            if (nL > 0) w = w * mis_weight(pdf0, R(emitter_position_pdf(sc, its1)));
-            result = result + Le(sc, tv, its1, true) * bsdf_val * w;
+            M w(1.f / (float) nB);
+            if (nL > 0) w = w * mis_weight(pdf0, M(emitter_position_pdf(sc, its1)));
+            result = result + Le<M>(sc, tv, its1, true) * bsdf_val * w;
         }
         if (next_its && i == 0) { *next_its = its1; *next_f = bsdf_val; *next_valid = a_hit; }
     }
     for (int i = 0; i < nL; ++i) {
         const float s0 = rng.next(), s1 = rng.next();
         if (!active) continue;
-        const PosSample<R> ps = sample_emitter_position<R>(sc, tv, s0, s1, ad);
-        Vec3<R> wo = ps.p - its.p;
-        const R d2 = dot(wo, wo), dist = safe_sqrt(d2);
+        const PosSample<G> ps = sample_emitter_position<G>(sc, tv, s0, s1, is_ad<G>());
+        Vec3<G> wo = ps.p - its.p;
+        const G d2 = dot(wo, wo), dist = safe_sqrt(d2);
         wo = wo / dist;
-        const RayT<R> ray1{its.p, wo};
-        const Its<R> its1 = intersect<R>(sc, tv, st, ray1, ps.valid, ad ? kPathSpace : kDetached, nrays);
+        const RayT<G> ray1{its.p, wo};
+        const Its<G> its1 = intersect<G>(sc, tv, st, ray1, ps.valid, form, nrays);
         if (!(its1.valid && val(its1.t) > val(dist) - kShadowEpsilon && emitter_of(sc, its1) >= 0)) continue;
-        const R G = abs_(dot(its1.n, -wo)) / d2;
-        const Vec3<R> wl = its.sh.to_local(wo);
-        Vec3<R> bsdf_val = bsdf.eval(sc, tv, its, wl, true) * (G * ps.J / ps.pdf);
-        const R pdf1 = bsdf.pdf(sc, tv, its, wl, true) * (ad ? detach(G) : G);
-        R w(1.f / (float) nL);
-        if (nB > 0) w = w * mis_weight(R(ps.pdf), pdf1);
-        result = result + Le(sc, tv, its1, true) * bsdf_val * w;
+        const G Gv = abs_(dot(its1.n, -wo)) / d2;
+        const Vec3<G> wl = its.sh.to_local(wo);
+        const Vec3<M> bsdf_val = bsdf.eval(sc, tv, its, wl, true) * to_m<M>(Gv * ps.J / ps.pdf);
+        M pdf1 = bsdf.pdf(sc, tv, its, wl, true);
+        if constexpr (ad) pdf1 = pdf1 * val(Gv); else pdf1 = pdf1 * Gv;
+        M w(1.f / (float) nL);
+        if (nB > 0) w = w * mis_weight(M(ps.pdf), pdf1);
+        result = result + Le<M>(sc, tv, its1, true) * bsdf_val * w;
     }
     return result;
 }
 
 // DirectIntegrator::__Li (direct.cpp:47-163); FieldExtractionIntegrator::__Li (field.cpp:34-54);
 // PathTracer = iterated direct step (no reference implementation; depth 1 == DirectIntegrator(1,1)).
-template <class R>
-PSDR_HD Vec3<R> Li(const SceneView &sc, const TV<R> &tv, TraversalStack &st, const LiParams &lp, Rng &rng, const RayT<R> &ray, bool active,
+template <class G, class M, class TVT>
+PSDR_HD Vec3<M> Li(const SceneView &sc, const TVT &tv, TraversalStack &st, const LiParams &lp, Rng &rng, const RayT<G> &ray, bool active,
                    uint32_t &nrays) {
-    constexpr bool ad = is_ad<R>();
-    Its<R> its = intersect<R>(sc, tv, st, ray, active, ad ? kSolidAngle : kDetached, nrays);
+    // renderD traces its primary ray in the solid-angle form (scene.cpp:355-376) also when only
+    // material parameters are differentiated: p = o + t d, (u,v,t) from Moeller-Trumbore
+    Its<G> its = intersect<G>(sc, tv, st, ray, active, is_ad<M>() ? kSolidAngle : kDetached, nrays);
     active = active && its.valid;
     if (lp.integrator == PSDR_INTEGRATOR_FIELD) {
-        if (!active) return zero3<R>();
+        if (!active) return zero3<M>();
         switch (lp.field) {
-            case PSDR_FIELD_SILHOUETTE: return Vec3<R>(1.f);
-            case PSDR_FIELD_POSITION: return its.p;
-            case PSDR_FIELD_DEPTH: return Vec3<R>(its.t, its.t, its.t);
-            case PSDR_FIELD_GEONORMAL: return its.n;
-            case PSDR_FIELD_SHNORMAL: return its.sh.n;
-            default: return Vec3<R>(its.uvx, its.uvy, R(0.f));
+            case PSDR_FIELD_SILHOUETTE: return Vec3<M>(1.f);
+            case PSDR_FIELD_POSITION: return to_m3<M>(its.p);
+            case PSDR_FIELD_DEPTH: return Vec3<M>(to_m<M>(its.t), to_m<M>(its.t), to_m<M>(its.t));
+            case PSDR_FIELD_GEONORMAL: return to_m3<M>(its.n);
+            case PSDR_FIELD_SHNORMAL: return to_m3<M>(its.sh.n);
+            default: return Vec3<M>(to_m<M>(its.uvx), to_m<M>(its.uvy), M(0.f));
         }
     }
-    Vec3<R> result = lp.hide_emitters ? zero3<R>() : Le(sc, tv, its, active);
+    Vec3<M> result = lp.hide_emitters ? zero3<M>() : Le<M>(sc, tv, its, active);
     if (lp.integrator == PSDR_INTEGRATOR_DIRECT)
-        return result + direct_step<R>(sc, tv, st, rng, its, active, lp.bsdf_samples, lp.light_samples, nrays, nullptr, nullptr, nullptr);
-    Vec3<R> beta(1.f);
+        return result + direct_step<G, M>(sc, tv, st, rng, its, active, lp.bsdf_samples, lp.light_samples, nrays, nullptr, nullptr, nullptr);
+    Vec3<M> beta(1.f);
     for (int depth = 0; depth < lp.max_depth; ++depth) {
-        Its<R> nits; Vec3<R> nf; bool nvalid = false;
-        const Vec3<R> c = direct_step<R>(sc, tv, st, rng, its, active, 1, 1, nrays, &nits, &nf, &nvalid);
+        Its<G> nits; Vec3<M> nf; bool nvalid = false;
+        const Vec3<M> c = direct_step<G, M>(sc, tv, st, rng, its, active, 1, 1, nrays, &nits, &nf, &nvalid);
         if (active) {
             result = result + beta * c;
             active = nvalid;
@@ -556,16 +583,16 @@ template <int K> PSDR_HD Dual<K> zero_nonfinite(const Dual<K> &x) {
 template <class R> PSDR_HD Vec3<R> zero_nonfinite(const Vec3<R> &v) { return {zero_nonfinite(v.x), zero_nonfinite(v.y), zero_nonfinite(v.z)}; }
 
 // One camera sample slot: Integrator::__render (src/integrator/integrator.cpp:64-95), before the splat
-template <class R>
-PSDR_HD Vec3<R> camera_sample(const SceneView &sc, const TV<R> &tv, TraversalStack &st, const LiParams &lp, const RngJump &jump,
+template <class G, class M, class TVT>
+PSDR_HD Vec3<M> camera_sample(const SceneView &sc, const TVT &tv, TraversalStack &st, const LiParams &lp, const RngJump &jump,
                               int pixel, uint64_t slot, uint32_t &nrays) {
     Rng rng; rng.init(slot, jump);
     const float j0 = rng.next(), j1 = rng.next();
     const int W = sc.d.width;
     const int px = pixel % W, py = pixel / W;
     const float sx = ((float) px + j0) / (float) W, sy = ((float) py + j1) / (float) sc.d.height;
-    const RayT<R> ray = primary_ray<R>(sc, tv, sx, sy);
-    return zero_nonfinite(Li<R>(sc, tv, st, lp, rng, ray, true, nrays));
+    const RayT<G> ray = primary_ray<G>(sc, tv, sx, sy);
+    return zero_nonfinite(Li<G, M>(sc, tv, st, lp, rng, ray, true, nrays));
 }
 
 // One primary-edge slot: Integrator::render_primary_edges (integrator.cpp:98-119) +
@@ -587,8 +614,8 @@ PSDR_HD int primary_edge_sample(const SceneView &sc, const TangentView<K> &tv, T
     const TangentView<0> tv0{};
     const RayT<float> ray_p = primary_ray<float>(sc, tv0, px + kEdgeEpsilon * nx, py + kEdgeEpsilon * ny);
     const RayT<float> ray_n = primary_ray<float>(sc, tv0, px - kEdgeEpsilon * nx, py - kEdgeEpsilon * ny);
-    const Vec3f Ln = Li<float>(sc, tv0, st, lp, rng, ray_n, valid, nrays);
-    const Vec3f Lp = Li<float>(sc, tv0, st, lp, rng, ray_p, valid, nrays);
+    const Vec3f Ln = Li<float, float>(sc, tv0, st, lp, rng, ray_n, valid, nrays);
+    const Vec3f Lp = Li<float, float>(sc, tv0, st, lp, rng, ray_p, valid, nrays);
     if (!valid) return -1;
     const Vec3f dL{(Ln.x - Lp.x) / pdf, (Ln.y - Lp.y) / pdf, (Ln.z - Lp.z) / pdf};
     const float xdn = px * nx + py * ny;
@@ -619,8 +646,8 @@ PSDR_HD float guide_sample_reuse(const SceneView &sc, float s[3]) {
 
 // DirectIntegrator::eval_secondary_edge (direct.cpp:225-316) + Scene::sample_boundary_segment_direct
 // (scene.cpp:456-492).  R = float: returns value0 (guiding, pixel -1); R = Dual<K>: tangent-only value.
-template <class R>
-PSDR_HD int secondary_edge_sample(const SceneView &sc, const TV<R> &tv, TraversalStack &st, const float s3[3], Vec3<R> &out, uint32_t &nrays) {
+template <class R, class TVT>
+PSDR_HD int secondary_edge_sample(const SceneView &sc, const TVT &tv, TraversalStack &st, const float s3[3], Vec3<R> &out, uint32_t &nrays) {
     constexpr bool ad = is_ad<R>();
     out = zero3<R>();
     const TangentView<0> tv0{};
@@ -670,7 +697,7 @@ PSDR_HD int secondary_edge_sample(const SceneView &sc, const TV<R> &tv, Traversa
     if (!(sinphi > kEpsilon && sinphi2 > kEpsilon)) return -1;
     const Vec3f d0 = -val(camera_ray.d);
     const Vec3f d0_local = its1c.sh.to_local(d0);
-    const Bsdf<float> bsdf(sc, sc.d.mesh_bsdf[its1c.mesh]);
+    const Bsdf<float, float> bsdf(sc, sc.d.mesh_bsdf[its1c.mesh]);
     Vec3f bsdf_val = bsdf.eval(sc, tv0, its1c, d0_local, true);
     const float correction = fabsf((its1c.wi.z * dot(d0, its1c.n)) / (d0_local.z * dot(dir, its1c.n)));
     bsdf_val = bsdf_val * correction;

@@ -84,7 +84,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(SceneView sc, int m, const flo
 
 // ------------------------------------------------------------------------------ k_camera
 // n = W*H*nsp slots of this shard, pixel-major: slot j -> pixel j / nsp, sample s_begin + j % nsp.
-template <class R>
+template <class G, class R>
 __global__ __launch_bounds__(kBlock) void k_camera(LaunchCtx cx, TV<R> tv, int spp, int s_begin, int nsp, long long n, float inv_spp,
                                                    float *__restrict__ img, float *__restrict__ dimg, long long plane,
                                                    unsigned long long *counters) {
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(kBlock) void k_camera(LaunchCtx cx, TV<R> tv, int s
         if (in) {
             const int s = s_begin + (int) (j % nsp);
             const uint64_t slot = (uint64_t) pixel * (uint64_t) spp + (uint64_t) s;
-            const Vec3<R> r = camera_sample<R>(cx.sc, tv, st, cx.lp, cx.jump, pixel, slot, nrays);
+            const Vec3<R> r = camera_sample<G, R>(cx.sc, tv, st, cx.lp, cx.jump, pixel, slot, nrays);
             v[0] = val(r.x) * inv_spp; v[1] = val(r.y) * inv_spp; v[2] = val(r.z) * inv_spp;
 #pragma unroll
             for (int k = 0; k < K; ++k) {
@@ -336,7 +336,7 @@ int check_counts(const psdr_scene_s *h, const psdr_render_opts *o) {
     return 0;
 }
 
-template <class R>
+template <class G, class R>
 int run_camera(psdr_scene_s *h, const psdr_render_opts *o, const TV<R> &tv, float *img, float *dimg, hipStream_t s) {
     const long long WH = (long long) h->desc.width * h->desc.height;
     const int nsp = o->spp_end - o->spp_begin;
@@ -345,7 +345,7 @@ int run_camera(psdr_scene_s *h, const psdr_render_opts *o, const TV<R> &tv, floa
     if (int rc = make_ctx(h, o, 0, cx)) return rc;
     const long long n = WH * nsp;
     h->slots[0] += (uint64_t) n;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_camera<R>), dim3(launch_blocks(h, n)), dim3(kBlock), 0, s, cx, tv, o->spp, o->spp_begin, nsp, n,
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_camera<G, R>), dim3(launch_blocks(h, n)), dim3(kBlock), 0, s, cx, tv, o->spp, o->spp_begin, nsp, n,
                        1.f / (float) o->spp, img, dimg, WH * 3, h->d_counters);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -358,7 +358,11 @@ int render_fwd(psdr_scene_s *h, const psdr_render_opts *o, const psdr_tangents *
     for (int k = 0; k < K; ++k) tv.t[k] = tangents[k];
     HIP_TRY(hipMemsetAsync(img, 0, sizeof(float) * WH * 3, s));
     HIP_TRY(hipMemsetAsync(dimg, 0, sizeof(float) * WH * 3 * K, s));
-    if (int rc = run_camera<Dual<K>>(h, o, tv, img, dimg, s)) return rc;
+    // geometry stays in plain fp32 when only material / emitter tables carry tangents
+    bool geo = false;
+    for (int k = 0; k < K; ++k) geo = geo || tangents[k].d_tri_info || tangents[k].d_cam_to_world;
+    if (geo) { if (int rc = run_camera<Dual<K>, Dual<K>>(h, o, tv, img, dimg, s)) return rc; }
+    else { if (int rc = run_camera<float, Dual<K>>(h, o, tv, img, dimg, s)) return rc; }
     if (o->sppe > 0 && o->sppe_end > o->sppe_begin && h->desc.num_prim_edges > 0) {
         LaunchCtx cx;
         if (int rc = make_ctx(h, o, 1, cx)) return rc;
@@ -478,7 +482,7 @@ int psdr_render_c(psdr_scene_t h, const psdr_render_opts *o, float *out_img, voi
     const long long WH = (long long) h->desc.width * h->desc.height;
     HIP_TRY(hipMemsetAsync(out_img, 0, sizeof(float) * WH * 3, s));
     const TangentView<0> tv0{};
-    return run_camera<float>(h, o, tv0, out_img, nullptr, s);
+    return run_camera<float, float>(h, o, tv0, out_img, nullptr, s);
 }
 
 int psdr_render_d_fwd(psdr_scene_t h, const psdr_render_opts *o, int32_t K, const psdr_tangents *tangents, float *out_img,

@@ -127,7 +127,7 @@ struct RcParams { float au, av; Vec3f eta, k, spec; };
 
 template <class Sink> struct BsdfRev {
     const SceneView &sc;
-    Bsdf<float> b;
+    Bsdf<float, float> b;
     PSDR_HD BsdfRev(const SceneView &s, int id) : sc(s), b(s, id) {}
 
     PSDR_HD RcParams rc_params(const TangentView<0> &tv0, const Its<float> &its) const {
@@ -308,7 +308,7 @@ PSDR_HD VertexOut vertex_eval(Sink &sink, const SceneView &sc, TraversalStack &s
                               const Vec3f &a_c, const Vec3f &a_f, VertexAdj &va, uint32_t &nrays) {
     const TangentView<0> tv0{};
     const BsdfRev<Sink> brev(sc, sc.d.mesh_bsdf[its.mesh]);
-    const Bsdf<float> &bsdf = brev.b;
+    const Bsdf<float, float> &bsdf = brev.b;
     VertexOut out; out.c = Vec3f(0.f); out.f = Vec3f(0.f); out.next_valid = false;
     for (int i = 0; i < nB; ++i) {
         const float s[3] = {rng.next(), rng.next(), rng.next()};
@@ -626,8 +626,8 @@ PSDR_HD void primary_edge_reverse(Sink &sink, const SceneView &sc, TraversalStac
     const TangentView<0> tv0{};
     const RayT<float> ray_p = primary_ray<float>(sc, tv0, px + kEdgeEpsilon * nx, py + kEdgeEpsilon * ny);
     const RayT<float> ray_n = primary_ray<float>(sc, tv0, px - kEdgeEpsilon * nx, py - kEdgeEpsilon * ny);
-    const Vec3f Ln = Li<float>(sc, tv0, st, lp, rng, ray_n, valid, nrays);
-    const Vec3f Lp = Li<float>(sc, tv0, st, lp, rng, ray_p, valid, nrays);
+    const Vec3f Ln = Li<float, float>(sc, tv0, st, lp, rng, ray_n, valid, nrays);
+    const Vec3f Lp = Li<float, float>(sc, tv0, st, lp, rng, ray_p, valid, nrays);
     if (!valid) return;
     const float *a = adj_img + (size_t) (iy * W + ix) * 3;
     const float xdn = px * nx + py * ny;
@@ -692,7 +692,7 @@ PSDR_HD void secondary_edge_reverse(Sink &sink, const SceneView &sc, TraversalSt
     const float base_v = (its1c.t / dist) * (sinphi / sinphi2) * cos2;
     const Vec3f d0 = -cam.d;
     const Vec3f d0_local = its1c.sh.to_local(d0);
-    const Bsdf<float> bsdf(sc, sc.d.mesh_bsdf[its1c.mesh]);
+    const Bsdf<float, float> bsdf(sc, sc.d.mesh_bsdf[its1c.mesh]);
     Vec3f bsdf_val = bsdf.eval(sc, tv0, its1c, d0_local, true);
     bsdf_val = bsdf_val * fabsf((its1c.wi.z * dot(d0, its1c.n)) / (d0_local.z * dot(dir, its1c.n)));
     Vec3f value0 = bsdf_val * Le<float>(sc, tv0, its2, true) * (base_v * sensor_val / bpdf);

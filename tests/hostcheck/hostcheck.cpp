@@ -69,10 +69,12 @@ int hostcheck_render(const psdr_scene_desc *d, const psdr_render_opts *o, int mo
                 const int pixel = (int) (j / nsp), s = o->spp_begin + (int) (j % nsp);
                 const uint64_t slot = (uint64_t) pixel * o->spp + s;
                 if (mode == 0) {
-                    Vec3f r = camera_sample<float>(hs.sc, tv0, st, lp, jump, pixel, slot, nr);
+                    Vec3f r = camera_sample<float, float>(hs.sc, tv0, st, lp, jump, pixel, slot, nr);
                     acc[t][pixel * 3] += r.x / o->spp; acc[t][pixel * 3 + 1] += r.y / o->spp; acc[t][pixel * 3 + 2] += r.z / o->spp;
                 } else {
-                    Vec3<Dual<1>> r = camera_sample<Dual<1>>(hs.sc, tv1, st, lp, jump, pixel, slot, nr);
+                    const bool geo = tv1.t[0].d_tri_info || tv1.t[0].d_cam_to_world;
+                    Vec3<Dual<1>> r = geo ? camera_sample<Dual<1>, Dual<1>>(hs.sc, tv1, st, lp, jump, pixel, slot, nr)
+                                          : camera_sample<float, Dual<1>>(hs.sc, tv1, st, lp, jump, pixel, slot, nr);
                     acc[t][pixel * 3] += r.x.v / o->spp; acc[t][pixel * 3 + 1] += r.y.v / o->spp; acc[t][pixel * 3 + 2] += r.z.v / o->spp;
                     dacc[t][pixel * 3] += r.x.d[0] / o->spp; dacc[t][pixel * 3 + 1] += r.y.d[0] / o->spp; dacc[t][pixel * 3 + 2] += r.z.d[0] / o->spp;
                 }
