@@ -84,8 +84,22 @@ __global__ __launch_bounds__(kBlock) void k_trace(SceneView sc, int m, const flo
 
 // ------------------------------------------------------------------------------ k_camera
 // n = W*H*nsp slots of this shard, pixel-major: slot j -> pixel j / nsp, sample s_begin + j % nsp.
+// Occupancy targets (waves per SIMD) of the camera kernel.  The kernel is latency/dependency bound
+// (rocprof r01: 43 % of wave cycles waiting at 2 waves/SIMD), so trading registers for resident
+// waves pays: measured 6.2 -> 4.6 ms (renderC, 4 waves) and 12.5 -> 7.0 ms (renderD K=3 material-only, 2 waves,
+// no spills) on C2; 5 waves (renderC) and 3-4 waves (Dual<3>) spill and lose.
+#ifndef PSDR_WAVES_C
+#define PSDR_WAVES_C 4
+#endif
+#ifndef PSDR_WAVES_DM
+#define PSDR_WAVES_DM 2
+#endif
+#ifndef PSDR_WAVES_DG
+#define PSDR_WAVES_DG 2
+#endif
+template <class G, class R> constexpr int camera_waves() { return !is_ad<R>() ? PSDR_WAVES_C : (is_ad<G>() ? PSDR_WAVES_DG : PSDR_WAVES_DM); }
 template <class G, class R>
-__global__ __launch_bounds__(kBlock) void k_camera(LaunchCtx cx, TV<R> tv, int spp, int s_begin, int nsp, long long n, float inv_spp,
+__global__ __launch_bounds__(kBlock, (camera_waves<G, R>())) void k_camera(LaunchCtx cx, TV<R> tv, int spp, int s_begin, int nsp, long long n, float inv_spp,
                                                    float *__restrict__ img, float *__restrict__ dimg, long long plane,
                                                    unsigned long long *counters) {
     constexpr int K = ad_traits<R>::K;

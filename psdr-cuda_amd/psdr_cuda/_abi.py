@@ -82,7 +82,7 @@ HIP_SYMBOLS = (
     "psdr_guide_build", "psdr_get_counters",
 )
 
-HIP_LIB_PATH = os.path.join(PKG_ROOT, "lib", "libpsdr_hip.so")
+HIP_LIB_PATH = os.environ.get("PSDR_HIP_LIB") or os.path.join(PKG_ROOT, "lib", "libpsdr_hip.so")   # env override: kernel A/B experiments
 ORACLE_LIB_PATH = os.path.join(REPO_ROOT, "oracle", "libpsdr_oracle.so")
 
 _hip = None
