@@ -226,40 +226,125 @@ __global__ __launch_bounds__(kBlock) void k_guide(LaunchCtx cx, int r0, int r1, 
 }
 
 // ------------------------------------------------------------------------ reverse mode
-// Gradient sink of the reverse kernels: the "per-parameter gradient scatter-add".  Every add is a
-// hardware f32 atomic on the gradient table (NULL table = gradient not requested).  Non-finite
-// pieces are dropped (forward mode zeroes non-finite tangents, psdr_device.h zero_nonfinite).
+// Gradient sink of the reverse kernels: the "per-parameter gradient scatter-add".
+//   level 0  camera matrix: per-lane REGISTERS, wave-reduced once at kernel end
+//   level 1  primary-triangle row: summed across the wave (lanes share their pixel) by the kernel
+//   level 2  per-workgroup LDS cache (ds_add_f32) for everything hot: all texels and emitter
+//            radiances (if they fit), and "hot" triangle-row ranges = the whole table when it is
+//            small, otherwise the emitter meshes' rows (every light sample lands on them)
+//   level 3  hardware global_atomic_add_f32 on the gradient table for the incoherent remainder
+// The cache is flushed with one global atomic per non-zero cached word per workgroup.
+// Non-finite pieces are dropped (forward mode zeroes non-finite tangents, zero_nonfinite).
+constexpr int kSinkCacheWords = 6144;        // 24 KB of LDS next to the 40 KB of traversal stacks
+constexpr int kSinkMaxHot = 4;
+struct SinkLayout {
+    int tex_off, tex_n;                      // texel cache (tex_n = 0: not cached)
+    int rad_off, rad_n;
+    int cam_off;                             // 16 words
+    int hot_n, hot_start[kSinkMaxHot], hot_count[kSinkMaxHot], hot_off[kSinkMaxHot];
+    int total;
+};
 struct DeviceSink {
     psdr_grads g;
-    __device__ __forceinline__ void put(float *base, size_t i, float v) const {
-        if (base != nullptr && v != 0.f && isfinite(v)) atomicAdd(base + i, v);
+    SinkLayout L;
+    float *lds;
+    float cam[16];
+    __device__ __forceinline__ static bool ok(float v) { return v != 0.f && isfinite(v); }
+    __device__ __forceinline__ void glob(float *base, size_t i, float v) const { if (base != nullptr && ok(v)) atomicAdd(base + i, v); }
+    __device__ __forceinline__ void add_tri(int tri, int word, float v) const {
+        if (g.g_tri_info == nullptr || !ok(v)) return;
+#pragma unroll
+        for (int r = 0; r < kSinkMaxHot; ++r)
+            if (r < L.hot_n && (unsigned) (tri - L.hot_start[r]) < (unsigned) L.hot_count[r]) {
+                atomicAdd(lds + L.hot_off[r] + (tri - L.hot_start[r]) * PSDR_TRI_STRIDE + word, v);
+                return;
+            }
+        atomicAdd(g.g_tri_info + (size_t) tri * PSDR_TRI_STRIDE + word, v);
     }
-    __device__ __forceinline__ void add_tri(int tri, int word, float v) const { put(g.g_tri_info, (size_t) tri * PSDR_TRI_STRIDE + word, v); }
-    __device__ __forceinline__ void add_texel(int idx, float v) const { put(g.g_texels, (size_t) idx, v); }
-    __device__ __forceinline__ void add_rad(int e, int c, float v) const { put(g.g_emitter_rad, (size_t) e * 3 + c, v); }
-    __device__ __forceinline__ void add_cam(int word, float v) const { put(g.g_cam_to_world, (size_t) word, v); }
-    __device__ __forceinline__ void add_sedge(int e, int word, float v) const { put(g.g_sec_edge, (size_t) e * PSDR_SEDGE_STRIDE + word, v); }
-    __device__ __forceinline__ void add_pedge(int e, int word, float v) const { put(g.g_prim_edge, (size_t) e * PSDR_PEDGE_STRIDE + word, v); }
+    __device__ __forceinline__ void add_texel(int idx, float v) const {
+        if (g.g_texels == nullptr || !ok(v)) return;
+        if (L.tex_n) atomicAdd(lds + L.tex_off + idx, v); else atomicAdd(g.g_texels + idx, v);
+    }
+    __device__ __forceinline__ void add_rad(int e, int c, float v) const {
+        if (g.g_emitter_rad == nullptr || !ok(v)) return;
+        if (L.rad_n) atomicAdd(lds + L.rad_off + e * 3 + c, v); else atomicAdd(g.g_emitter_rad + e * 3 + c, v);
+    }
+    __device__ __forceinline__ void add_cam(int word, float v) { if (ok(v)) cam[word] += v; }
+    __device__ __forceinline__ void add_sedge(int e, int word, float v) const { glob(g.g_sec_edge, (size_t) e * PSDR_SEDGE_STRIDE + word, v); }
+    __device__ __forceinline__ void add_pedge(int e, int word, float v) const { glob(g.g_prim_edge, (size_t) e * PSDR_PEDGE_STRIDE + word, v); }
+
+    __device__ __forceinline__ void begin(float *cache) {
+        lds = cache;
+        for (int i = threadIdx.x; i < L.total; i += kBlock) cache[i] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) cam[i] = 0.f;
+        __syncthreads();
+    }
+    __device__ __forceinline__ void end() {
+        if (g.g_cam_to_world != nullptr) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                float v = cam[i];
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+                if ((threadIdx.x & 63) == 0 && v != 0.f) atomicAdd(lds + L.cam_off + i, v);
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < L.total; i += kBlock) {
+            const float v = lds[i];
+            if (v == 0.f) continue;
+            if (i >= L.cam_off && i < L.cam_off + 16) { atomicAdd(g.g_cam_to_world + (i - L.cam_off), v); continue; }
+            if (L.tex_n && i >= L.tex_off && i < L.tex_off + L.tex_n) { atomicAdd(g.g_texels + (i - L.tex_off), v); continue; }
+            if (L.rad_n && i >= L.rad_off && i < L.rad_off + L.rad_n) { atomicAdd(g.g_emitter_rad + (i - L.rad_off), v); continue; }
+            for (int r = 0; r < L.hot_n; ++r) {
+                const int rel = i - L.hot_off[r];
+                if (rel >= 0 && rel < L.hot_count[r] * PSDR_TRI_STRIDE) { atomicAdd(g.g_tri_info + (size_t) L.hot_start[r] * PSDR_TRI_STRIDE + rel, v); break; }
+            }
+        }
+    }
 };
+
+// Sum of v over runs of ADJACENT lanes holding the same key; the first lane of each run gets the total.
+template <int N> __device__ __forceinline__ bool wave_run_sum(int key, float (&v)[N]) {
+    const int lane = threadIdx.x & 63;
+    const int prev = __shfl_up(key, 1, 64);
+    const bool head = lane == 0 || prev != key;
+    const unsigned long long heads = __ballot(head);
+    const int seg = __popcll(heads & (~0ull >> (63 - lane)));       // run index: non-decreasing
+    wave_segmented_sum<N>(seg, v);
+    return head;
+}
 
 __global__ __launch_bounds__(kBlock) void k_camera_rev(LaunchCtx cx, DeviceSink sink, int spp, int s_begin, int nsp, long long n, float inv_spp,
                                                        const float *__restrict__ adj_img, float *__restrict__ img,
                                                        unsigned long long *counters) {
     __shared__ int32_t lds[kBvhStack * kBlock];
+    __shared__ float cache[kSinkCacheWords];
     TraversalStack st; bind_stack(st, lds);
+    sink.begin(cache);
     uint32_t nrays = 0;
     const long long nceil = (n + kBlock - 1) / kBlock * kBlock;
     for (long long j = (long long) blockIdx.x * kBlock + threadIdx.x; j < nceil; j += (long long) gridDim.x * kBlock) {
         const bool in = j < n;
         const int pixel = in ? (int) (j / nsp) : 0x7fffffff;
         float v[3] = {0.f, 0.f, 0.f};
+        PrimaryGrad pg; pg.clear();
         if (in) {
             const int s = s_begin + (int) (j % nsp);
             const uint64_t slot = (uint64_t) pixel * (uint64_t) spp + (uint64_t) s;
             const float *a = adj_img + (size_t) pixel * 3;
             const Vec3f adj{a[0] * inv_spp, a[1] * inv_spp, a[2] * inv_spp};
-            const Vec3f r = camera_sample_reverse(sink, cx.sc, st, cx.lp, cx.jump, pixel, slot, adj, nrays);
+            const Vec3f r = camera_sample_reverse(sink, pg, cx.sc, st, cx.lp, cx.jump, pixel, slot, adj, nrays);
             v[0] = r.x * inv_spp; v[1] = r.y * inv_spp; v[2] = r.z * inv_spp;
+        }
+        // primary-triangle row: one add per run of lanes that hit the same triangle
+        if (sink.g.g_tri_info != nullptr) {
+            const bool head = wave_run_sum<kPrimaryWords>(pg.tri, pg.w);
+            if (head && pg.tri >= 0) {
+#pragma unroll
+                for (int w = 0; w < kPrimaryWords; ++w) sink.add_tri(pg.tri, w, pg.w[w]);
+            }
         }
         if (img != nullptr) {
             const bool head = wave_segmented_sum<3>(pixel, v);
@@ -271,23 +356,29 @@ __global__ __launch_bounds__(kBlock) void k_camera_rev(LaunchCtx cx, DeviceSink 
             }
         }
     }
+    sink.end();
     count_rays(counters, nrays);
 }
 
 __global__ __launch_bounds__(kBlock) void k_primary_edge_rev(LaunchCtx cx, DeviceSink sink, long long i0, long long n, float inv_sppe,
                                                              const float *__restrict__ adj_img, unsigned long long *counters) {
     __shared__ int32_t lds[kBvhStack * kBlock];
+    __shared__ float cache[kSinkCacheWords];
     TraversalStack st; bind_stack(st, lds);
+    sink.begin(cache);
     uint32_t nrays = 0;
     for (long long j = (long long) blockIdx.x * kBlock + threadIdx.x; j < n; j += (long long) gridDim.x * kBlock)
         primary_edge_reverse(sink, cx.sc, st, cx.lp, cx.jump, (uint64_t) (i0 + j), inv_sppe, adj_img, nrays);
+    sink.end();
     count_rays(counters, nrays);
 }
 
 __global__ __launch_bounds__(kBlock) void k_secondary_edge_rev(LaunchCtx cx, DeviceSink sink, long long i0, long long n, float inv_sppse,
                                                                const float *__restrict__ adj_img, unsigned long long *counters) {
     __shared__ int32_t lds[kBvhStack * kBlock];
+    __shared__ float cache[kSinkCacheWords];
     TraversalStack st; bind_stack(st, lds);
+    sink.begin(cache);
     uint32_t nrays = 0;
     const bool guided = cx.sc.d.guide_cmf != nullptr && cx.sc.d.num_guide_cells > 0;
     for (long long j = (long long) blockIdx.x * kBlock + threadIdx.x; j < n; j += (long long) gridDim.x * kBlock) {
@@ -296,6 +387,7 @@ __global__ __launch_bounds__(kBlock) void k_secondary_edge_rev(LaunchCtx cx, Dev
         const float pdf0 = guided ? guide_sample_reuse(cx.sc, s3) : 1.f;
         secondary_edge_reverse(sink, cx.sc, st, s3, (pdf0 > kEpsilon ? 1.f / pdf0 : 1.f) * inv_sppse, adj_img, nrays);
     }
+    sink.end();
     count_rays(counters, nrays);
 }
 
@@ -318,6 +410,7 @@ struct psdr_scene_s {
     unsigned long long *d_counters = nullptr;
     uint64_t slots[3] = {0, 0, 0};
     int num_cus = 256;
+    std::vector<int32_t> emitter_i;          // host copy of desc.emitter_i (hot-row ranges of the reverse sink)
 };
 
 namespace {
@@ -398,6 +491,31 @@ int render_fwd(psdr_scene_s *h, const psdr_render_opts *o, const psdr_tangents *
     return 0;
 }
 
+SinkLayout make_sink_layout(const psdr_scene_s *h, const psdr_grads *g) {
+    SinkLayout L{};
+    int off = 0;
+    L.cam_off = off; off += 16;
+    const int nt = h->desc.num_texels, nr = h->desc.num_emitters * 3;
+    if (g->g_texels && nt > 0 && nt <= 2048) { L.tex_off = off; L.tex_n = nt; off += nt; }
+    if (g->g_emitter_rad && nr > 0 && nr <= 256) { L.rad_off = off; L.rad_n = nr; off += nr; }
+    if (g->g_tri_info) {
+        const int T = h->desc.num_tris;
+        if (T * PSDR_TRI_STRIDE <= kSinkCacheWords - off) {
+            L.hot_start[0] = 0; L.hot_count[0] = T; L.hot_off[0] = off; L.hot_n = 1; off += T * PSDR_TRI_STRIDE;
+        } else {
+            for (int e = 0; e < h->desc.num_emitters && L.hot_n < kSinkMaxHot; ++e) {
+                const int32_t *ei = h->emitter_i.data() + (size_t) e * PSDR_EMITTER_I_STRIDE;
+                const int cnt = ei[2];
+                if (cnt <= 0 || cnt * PSDR_TRI_STRIDE > kSinkCacheWords - off) continue;
+                const int r = L.hot_n++;
+                L.hot_start[r] = ei[1]; L.hot_count[r] = cnt; L.hot_off[r] = off; off += cnt * PSDR_TRI_STRIDE;
+            }
+        }
+    }
+    L.total = off;
+    return L;
+}
+
 int begin_call(psdr_scene_s *h, hipStream_t s) {
     h->slots[0] = h->slots[1] = h->slots[2] = 0;
     HIP_TRY(hipMemsetAsync(h->d_counters, 0, sizeof(unsigned long long) * 4, s));
@@ -454,6 +572,9 @@ int psdr_bvh_build(psdr_scene_t h, void *stream) {
     std::vector<float> rows((size_t) T * PSDR_TRI_STRIDE);
     HIP_TRY(hipMemcpyAsync(rows.data(), h->desc.tri_info, rows.size() * sizeof(float), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    h->emitter_i.assign((size_t) std::max(h->desc.num_emitters, 0) * PSDR_EMITTER_I_STRIDE, 0);
+    if (h->desc.num_emitters > 0 && h->desc.emitter_i)
+        HIP_TRY(hipMemcpy(h->emitter_i.data(), h->desc.emitter_i, h->emitter_i.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
     Builder b;
     int32_t root = 0;
     if (const char *err = b.run(rows.data(), T, root)) return fail(err);
@@ -523,7 +644,7 @@ int psdr_render_d_rev(psdr_scene_t h, const psdr_render_opts *o, const float *ad
     if (int rc = begin_call(h, s)) return rc;
     const long long WH = (long long) h->desc.width * h->desc.height;
     if (out_img) HIP_TRY(hipMemsetAsync(out_img, 0, sizeof(float) * WH * 3, s));
-    DeviceSink sink; sink.g = *grads;
+    DeviceSink sink{}; sink.g = *grads; sink.L = make_sink_layout(h, grads);
     const int nsp = o->spp_end - o->spp_begin;
     if (o->spp > 0 && nsp > 0) {
         LaunchCtx cx;

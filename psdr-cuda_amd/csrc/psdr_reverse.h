@@ -466,6 +466,32 @@ struct NullSink {
 
 constexpr int kMaxRevDepth = 8;
 
+// Gradient of the PRIMARY triangle row of one camera sample (p0 e1 e2 n0 n1 n2 fn = words 0..20).
+// Lanes of a wave share their pixel, hence almost always their primary triangle: the kernel sums
+// these rows across the wave (segmented by triangle id) before touching memory.
+constexpr int kPrimaryWords = 21;
+struct PrimaryGrad {
+    int tri;
+    float w[kPrimaryWords];
+    PSDR_HD void clear() { tri = -1;
+#pragma unroll
+        for (int i = 0; i < kPrimaryWords; ++i) w[i] = 0.f; }
+};
+// Routes add_tri(primary triangle, word < 21) into registers, everything else to the real sink.
+template <class Sink> struct PrimarySink {
+    Sink &real; PrimaryGrad &pg;
+    PSDR_HD PrimarySink(Sink &r, PrimaryGrad &p) : real(r), pg(p) {}
+    PSDR_HD void add_tri(int tri, int word, float v) {
+        if (tri == pg.tri && word < kPrimaryWords) { if (v != 0.f && isfinite(v)) pg.w[word] += v; }
+        else real.add_tri(tri, word, v);
+    }
+    PSDR_HD void add_texel(int i, float v) { real.add_texel(i, v); }
+    PSDR_HD void add_rad(int e, int c, float v) { real.add_rad(e, c, v); }
+    PSDR_HD void add_cam(int w, float v) { real.add_cam(w, v); }
+    PSDR_HD void add_sedge(int e, int w, float v) { real.add_sedge(e, w, v); }
+    PSDR_HD void add_pedge(int e, int w, float v) { real.add_pedge(e, w, v); }
+};
+
 // Back-propagates the adjoints of a PATH-SPACE vertex (k >= 1) into its triangle row and returns the
 // adjoint of the previous vertex' position (wi_k = to_local_k(-(p_k - p_{k-1}) / t)).
 template <class Sink> PSDR_HD Vec3f path_vertex_backward(Sink &sink, const SceneView &sc, const Its<float> &v, const Vec3f &prev_p, VertexAdj va) {
@@ -488,9 +514,12 @@ template <class Sink> PSDR_HD Vec3f path_vertex_backward(Sink &sink, const Scene
 
 // One camera sample in reverse mode (Integrator::__render<true> + enoki.backward).
 //   adj = dLoss/d(pixel) / spp.   Returns the primal sample value.
-template <class Sink>
-PSDR_HD Vec3f camera_sample_reverse(Sink &sink, const SceneView &sc, TraversalStack &st, const LiParams &lp, const RngJump &jump, int pixel,
-                                    uint64_t slot, const Vec3f &adj, uint32_t &nrays) {
+template <class RealSink>
+PSDR_HD Vec3f camera_sample_reverse(RealSink &real_sink, PrimaryGrad &pg, const SceneView &sc, TraversalStack &st, const LiParams &lp,
+                                    const RngJump &jump, int pixel, uint64_t slot, const Vec3f &adj, uint32_t &nrays) {
+    pg.clear();
+    PrimarySink<RealSink> sink(real_sink, pg);
+    using Sink = PrimarySink<RealSink>;
     const TangentView<0> tv0{};
     Rng rng; rng.init(slot, jump);
     const float j0 = rng.next(), j1 = rng.next();
@@ -501,6 +530,7 @@ PSDR_HD Vec3f camera_sample_reverse(Sink &sink, const SceneView &sc, TraversalSt
     nrays++;
     const Hit h0 = closest_hit(sc, st, ray.o, ray.d, INFINITY);
     if (h0.tri < 0) return Vec3f(0.f);
+    pg.tri = h0.tri;
     const int tm0 = sc.d.tri_mesh[h0.tri];
     const bool face0 = (tm0 & PSDR_TRI_FACE_NORMALS) != 0;
     const TriRow<float> T0 = load_tri<float>(sc, tv0, h0.tri);
@@ -584,7 +614,7 @@ PSDR_HD Vec3f camera_sample_reverse(Sink &sink, const SceneView &sc, TraversalSt
             const Vec3f a_c = adj * beta;
             const Vec3f a_f = (k + 1 < nv) ? a_c * Tk[k + 1] : Vec3f(0.f);
             VertexAdj va; va.clear();
-            const VertexOut vo = vertex_eval<true>(sink, sc, st, rng, cur, nB, nL, a_c, a_f, k == 0 ? va0 : va, nrays);
+            const VertexOut vo = vertex_eval<true, Sink>(sink, sc, st, rng, cur, nB, nL, a_c, a_f, k == 0 ? va0 : va, nrays);
             if (k >= 1) {
                 const Vec3f a_prev = path_vertex_backward(sink, sc, cur, prev.p, va);
                 if (k == 1) acc(va0.p, a_prev);

@@ -1,0 +1,70 @@
+#!/usr/bin/env python
+"""Times the C-ABI entry points on a set of workloads (run on the GPU box).  Not the headline bench:
+a developer tool to see where each kernel stands (ms per call, Msamples/s, rays/slot)."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in ("psdr-cuda_amd", "oracle", "tests"):
+    sys.path.insert(0, os.path.join(ROOT, p))
+import numpy as np
+import torch
+from helpers import GpuScene, load_scene, random_tangents, tangents_wrt
+from psdr_cuda import _abi
+
+
+def timeit(fn, reps=3):
+    fn(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps * 1e3
+
+
+def main():
+    which = sys.argv[1:] or ["c2", "c3"]
+    if "c2" in which:
+        sc, _ = load_scene("cbox", res=512, spp=64)
+        tb = sc.tables(0)
+        g = GpuScene(tb)
+        n = 512 * 512 * 64
+        adj = np.random.default_rng(0).random((512 * 512, 3)).astype(np.float32)
+        for name, kw in (("direct11", dict(bsdf_samples=1, light_samples=1)), ("path3", dict(integrator=_abi.INTEGRATOR_PATH, max_depth=3))):
+            o = _abi.make_opts(spp=64, **kw)
+            ms = timeit(lambda: g.render_c(o)); r = g.counters()[0] / n
+            print("C2 %-9s renderC            %8.2f ms  %7.0f Msamples/s  rays/slot %.2f" % (name, ms, n / ms / 1e3, r))
+            t3 = [{"texels": torch.eye(tb["texels"].numel())[c]} for c in range(3)]
+            ms = timeit(lambda: g.render_d_fwd(o, t3))
+            print("C2 %-9s renderD fwd K=3 mat  %8.2f ms  %7.0f Msamples/s" % (name, ms, n / ms / 1e3))
+            tg = random_tangents(tb, ["tri_info"])
+            ms = timeit(lambda: g.render_d_fwd(o, [tg]))
+            print("C2 %-9s renderD fwd K=1 geo  %8.2f ms  %7.0f Msamples/s" % (name, ms, n / ms / 1e3))
+            ms = timeit(lambda: g.render_d_rev(o, adj, want=["texels"], with_image=False))
+            print("C2 %-9s renderD rev texels   %8.2f ms  %7.0f Msamples/s" % (name, ms, n / ms / 1e3))
+            ms = timeit(lambda: g.render_d_rev(o, adj, want=["texels", "emitter_rad", "tri_info", "cam_to_world"], with_image=False))
+            print("C2 %-9s renderD rev all      %8.2f ms  %7.0f Msamples/s" % (name, ms, n / ms / 1e3))
+    if "c3" in which:
+        res, spp = 512, 16
+        sc, P = load_scene("cbox_bunny", res=res, spp=spp, sppe=spp, sppse=spp, translate=(1, (1.0, 0.0, 0.0)))
+        tb = sc.tables(0)
+        g = GpuScene(tb)
+        n = res * res * spp
+        adj = np.random.default_rng(0).random((res * res, 3)).astype(np.float32)
+        o = _abi.make_opts(spp=spp, sppe=spp, sppse=spp)
+        oc = _abi.make_opts(spp=spp)
+        ms = timeit(lambda: g.render_c(oc)); r = g.counters()[0] / n
+        print("C3 bunny direct11 renderC         %8.2f ms  %7.0f Msamples/s  rays/slot %.2f" % (ms, n / ms / 1e3, r))
+        tan = tangents_wrt(tb, P)
+        ms = timeit(lambda: g.render_d_fwd(o, [tan])); c = g.counters()
+        print("C3 bunny renderD fwd K=1 (3 terms) %8.2f ms  %7.0f Mslots/s (slots %s rays %d)" % (ms, 3 * n / ms / 1e3, c[1:], c[0]))
+        ms = timeit(lambda: g.render_d_rev(o, adj, with_image=False))
+        print("C3 bunny renderD rev (3 terms)     %8.2f ms  %7.0f Mslots/s" % (ms, 3 * n / ms / 1e3))
+        op = _abi.make_opts(integrator=_abi.INTEGRATOR_PATH, max_depth=3, spp=spp)
+        ms = timeit(lambda: g.render_c(op)); r = g.counters()[0] / n
+        print("C3 bunny path3 renderC            %8.2f ms  %7.0f Msamples/s  rays/slot %.2f" % (ms, n / ms / 1e3, r))
+
+
+if __name__ == "__main__":
+    main()
