@@ -118,7 +118,7 @@ def random_tangents(tb, names, seed=0):
 
 
 def dot_tables(grads, tangents):
-    return float(sum((np.asarray(grads[n], dtype=np.float64) * tangents[n].numpy().astype(np.float64)).sum()
+    return float(sum((np.asarray(grads[n], dtype=np.float64) * tangents[n].detach().cpu().numpy().astype(np.float64)).sum()
                      for n in tangents if n in grads))
 
 
