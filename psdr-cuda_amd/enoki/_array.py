@@ -45,7 +45,7 @@ class ArrayBase:
                 if a._kind != k:
                     t = self._coerce(t, a._kind)
             elif isinstance(a, torch.Tensor):
-                t = a.to(self._dtype) if a.dtype != self._dtype else a
+                t = a.to(device=dev, dtype=self._dtype)      # arrays live on the render device
                 t = self._coerce(t, None)
             else:
                 arr = np.asarray(a, dtype=np.float64 if self._dtype.is_floating_point else None)

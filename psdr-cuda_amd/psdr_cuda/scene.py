@@ -825,7 +825,7 @@ class Scene(Object):
             nonlocal off
             t = bm.tensor()
             w, h = bm.resolution
-            pool.append(t.reshape(-1))
+            pool.append(t.reshape(-1).to(d))
             o_ = off
             off += t.numel()
             return [o_, w, h]
