@@ -139,6 +139,28 @@ struct Builder {
         float lo[3], hi[3];
         root = build(0, T, 0, lo, hi);
         if (max_depth > kBvhStack - 2) return "psdr_bvh_build: tree too deep for the traversal stack";
+        // breadth-first relabelling: a prefix of the node array is the top of the tree (the part the
+        // kernels stage in LDS)
+        if (root >= 0) {
+            std::vector<int> order_bfs; order_bfs.reserve(nodes.size());
+            std::vector<int> newid(nodes.size(), -1);
+            order_bfs.push_back(root);
+            for (size_t i = 0; i < order_bfs.size(); ++i) {
+                const BvhNode &n = nodes[order_bfs[i]];
+                if (n.c0 >= 0) order_bfs.push_back(n.c0);
+                if (n.c1 >= 0) order_bfs.push_back(n.c1);
+            }
+            for (size_t i = 0; i < order_bfs.size(); ++i) newid[order_bfs[i]] = (int) i;
+            std::vector<BvhNode> out(order_bfs.size());
+            for (size_t i = 0; i < order_bfs.size(); ++i) {
+                BvhNode n = nodes[order_bfs[i]];
+                if (n.c0 >= 0) n.c0 = newid[n.c0];
+                if (n.c1 >= 0) n.c1 = newid[n.c1];
+                out[i] = n;
+            }
+            nodes.swap(out);
+            root = 0;
+        }
         return nullptr;
     }
 };

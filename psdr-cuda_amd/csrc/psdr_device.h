@@ -30,7 +30,16 @@ struct SceneView {
     const BvhNode *nodes;
     const float4 *btris;
     int32_t root;          // encoded like a child (negative = single leaf)
+    // LDS-staged prefix of the scene (device only; offsets in bytes into the dynamic LDS block):
+    // the first n_lnodes BVH nodes (breadth-first order = the top of the tree), the first
+    // n_lbtris leaf triangles and the first n_ltri TriangleInfo rows.
+    int32_t n_lnodes, n_lbtris, n_ltri;
+    int32_t off_lnodes, off_lbtris, off_ltri;
 };
+
+#if defined(__HIP_DEVICE_COMPILE__)
+extern __shared__ __attribute__((aligned(16))) unsigned char psdr_dyn_lds[];
+#endif
 
 // K sets of forward-mode tangent tables (struct of K pointer groups)
 template <int K> struct TangentView { psdr_tangents t[K > 0 ? K : 1]; };
@@ -73,8 +82,17 @@ PSDR_HD Hit closest_hit(const SceneView &sc, TraversalStack &st, const Vec3f &o,
     for (;;) {
         if (cur < 0) {
             const int enc = ~cur, first = enc >> 3, cnt = (enc & 7) + 1;
+#if defined(__HIP_DEVICE_COMPILE__)
+            const bool staged = first + cnt <= sc.n_lbtris;
+            const float4 *lt = reinterpret_cast<const float4 *>(psdr_dyn_lds + sc.off_lbtris);
+#endif
             for (int i = 0; i < cnt; ++i) {
-                const float4 a = sc.btris[(first + i) * 3 + 0], b = sc.btris[(first + i) * 3 + 1], c = sc.btris[(first + i) * 3 + 2];
+                float4 a, b, c;
+#if defined(__HIP_DEVICE_COMPILE__)
+                if (staged) { a = lt[(first + i) * 3]; b = lt[(first + i) * 3 + 1]; c = lt[(first + i) * 3 + 2]; }
+                else
+#endif
+                { a = sc.btris[(first + i) * 3]; b = sc.btris[(first + i) * 3 + 1]; c = sc.btris[(first + i) * 3 + 2]; }
                 // Moeller-Trumbore (the OptiX built-in triangle test is closed source)
                 const Vec3f e1{b.x, b.y, b.z}, e2{c.x, c.y, c.z};
                 const Vec3f h = cross(d, e2);
@@ -94,7 +112,12 @@ PSDR_HD Hit closest_hit(const SceneView &sc, TraversalStack &st, const Vec3f &o,
             cur = st.get(--sp);
             continue;
         }
-        const BvhNode &n = sc.nodes[cur];
+        BvhNode n;
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (cur < sc.n_lnodes) n = reinterpret_cast<const BvhNode *>(psdr_dyn_lds + sc.off_lnodes)[cur];
+        else
+#endif
+            n = sc.nodes[cur];
         const float t0 = slab(n.lo0, n.hi0, o, inv, best.t), t1 = slab(n.lo1, n.hi1, o, inv, best.t);
         const bool h0 = t0 < INFINITY, h1 = t1 < INFINITY;
         if (h0 && h1) {
@@ -145,7 +168,28 @@ template <class M, class G> PSDR_HD Vec3<M> to_m3(const Vec3<G> &a) { return {to
 
 // TriangleInfo_ row (include/psdr/types.h:135-146), gathered by global triangle id (scene.cpp:300)
 template <class R> struct TriRow { Vec3<R> p0, e1, e2, n0, n1, n2, fn; R area; };
+template <class TVT> PSDR_HD TriRow<float> load_tri_f(const SceneView &sc, const TVT &, int id) {
+    TriRow<float> t;
+    float4 r[6];
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (id < sc.n_ltri) {
+        const float4 *q = reinterpret_cast<const float4 *>(psdr_dyn_lds + sc.off_ltri) + (size_t) id * 6;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) r[i] = q[i];
+    } else
+#endif
+    {
+        const float4 *q = reinterpret_cast<const float4 *>(sc.d.tri_info) + (size_t) id * 6;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) r[i] = q[i];
+    }
+    t.p0 = {r[0].x, r[0].y, r[0].z}; t.e1 = {r[0].w, r[1].x, r[1].y}; t.e2 = {r[1].z, r[1].w, r[2].x};
+    t.n0 = {r[2].y, r[2].z, r[2].w}; t.n1 = {r[3].x, r[3].y, r[3].z}; t.n2 = {r[3].w, r[4].x, r[4].y};
+    t.fn = {r[4].z, r[4].w, r[5].x}; t.area = r[5].y;
+    return t;
+}
 template <class R, class TVT> PSDR_HD TriRow<R> load_tri(const SceneView &sc, const TVT &tv, int id) {
+    if constexpr (!is_ad<R>()) return load_tri_f(sc, tv, id);
     const size_t o = (size_t) id * PSDR_TRI_STRIDE;
     const float *a = sc.d.tri_info;
     constexpr auto m = &psdr_tangents::d_tri_info;

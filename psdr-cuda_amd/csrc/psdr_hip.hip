@@ -52,28 +52,41 @@ __device__ __forceinline__ void count_rays(unsigned long long *counters, uint32_
     if ((threadIdx.x & 63) == 0 && s) atomicAdd(counters, (unsigned long long) s);
 }
 
-__device__ __forceinline__ void bind_stack(TraversalStack &st, int32_t *lds) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    st.base = lds + threadIdx.x;
-#else
-    (void) st; (void) lds;
-#endif
-}
-
 struct LaunchCtx {
     SceneView sc;
     LiParams lp;
     RngJump jump;
+    int32_t off_stack;          // byte offset of the traversal stacks inside the dynamic LDS block
 };
 
+// Dynamic LDS block of every kernel:  [ staged BVH nodes | staged leaf triangles | staged
+// TriangleInfo rows | traversal stacks (stack_entries x 256 lanes) ].  The stacks are sized from the
+// depth of THIS scene's tree, so a 12-triangle scene uses 5 KB instead of 40 KB and the freed LDS
+// holds the scene itself (LDS latency ~64 clk vs ~200 for an L2 hit).
+__device__ __forceinline__ void setup_lds(const LaunchCtx &cx, TraversalStack &st) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const SceneView &sc = cx.sc;
+    float4 *dst = reinterpret_cast<float4 *>(psdr_dyn_lds);
+    const float4 *src = reinterpret_cast<const float4 *>(sc.nodes);
+    for (int i = threadIdx.x; i < sc.n_lnodes * 4; i += kBlock) dst[sc.off_lnodes / 16 + i] = src[i];
+    for (int i = threadIdx.x; i < sc.n_lbtris * 3; i += kBlock) dst[sc.off_lbtris / 16 + i] = sc.btris[i];
+    src = reinterpret_cast<const float4 *>(sc.d.tri_info);
+    for (int i = threadIdx.x; i < sc.n_ltri * 6; i += kBlock) dst[sc.off_ltri / 16 + i] = src[i];
+    st.base = reinterpret_cast<int32_t *>(psdr_dyn_lds + cx.off_stack) + threadIdx.x;
+    __syncthreads();
+#else
+    (void) cx; (void) st;
+#endif
+}
+
 // ------------------------------------------------------------------------------- k_trace
-__global__ __launch_bounds__(kBlock) void k_trace(SceneView sc, int m, const float *__restrict__ ox, const float *__restrict__ oy,
+__global__ __launch_bounds__(kBlock) void k_trace(LaunchCtx cx, int m, const float *__restrict__ ox, const float *__restrict__ oy,
                                                   const float *__restrict__ oz, const float *__restrict__ dx,
                                                   const float *__restrict__ dy, const float *__restrict__ dz,
                                                   const float *__restrict__ tmax, int32_t *__restrict__ out_shape,
                                                   int32_t *__restrict__ out_tri, float *__restrict__ out_u, float *__restrict__ out_v) {
-    __shared__ int32_t lds[kBvhStack * kBlock];
-    TraversalStack st; bind_stack(st, lds);
+    TraversalStack st; setup_lds(cx, st);
+    const SceneView &sc = cx.sc;
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < m; i += gridDim.x * kBlock) {
         const Hit h = closest_hit(sc, st, Vec3f{ox[i], oy[i], oz[i]}, Vec3f{dx[i], dy[i], dz[i]}, tmax[i]);
         out_tri[i] = h.tri;
@@ -104,8 +117,7 @@ __global__ __launch_bounds__(kBlock, (camera_waves<G, R>())) void k_camera(Launc
                                                    unsigned long long *counters) {
     constexpr int K = ad_traits<R>::K;
     constexpr int NV = 3 * (1 + K);
-    __shared__ int32_t lds[kBvhStack * kBlock];
-    TraversalStack st; bind_stack(st, lds);
+    TraversalStack st; setup_lds(cx, st);
     uint32_t nrays = 0;
     const long long nceil = (n + kBlock - 1) / kBlock * kBlock;
     for (long long j = (long long) blockIdx.x * kBlock + threadIdx.x; j < nceil; j += (long long) gridDim.x * kBlock) {
@@ -146,8 +158,7 @@ __global__ __launch_bounds__(kBlock, (camera_waves<G, R>())) void k_camera(Launc
 template <int K>
 __global__ __launch_bounds__(kBlock) void k_primary_edge(LaunchCtx cx, TangentView<K> tv, long long i0, long long n, float inv_sppe,
                                                          float *__restrict__ dimg, long long plane, unsigned long long *counters) {
-    __shared__ int32_t lds[kBvhStack * kBlock];
-    TraversalStack st; bind_stack(st, lds);
+    TraversalStack st; setup_lds(cx, st);
     uint32_t nrays = 0;
     for (long long j = (long long) blockIdx.x * kBlock + threadIdx.x; j < n; j += (long long) gridDim.x * kBlock) {
         float tan[K][3];
@@ -168,8 +179,7 @@ template <int K>
 __global__ __launch_bounds__(kBlock) void k_secondary_edge(LaunchCtx cx, TangentView<K> tv, long long i0, long long n, float inv_sppse,
                                                            float *__restrict__ dimg, long long plane, unsigned long long *counters) {
     using R = Dual<K>;
-    __shared__ int32_t lds[kBvhStack * kBlock];
-    TraversalStack st; bind_stack(st, lds);
+    TraversalStack st; setup_lds(cx, st);
     uint32_t nrays = 0;
     const bool guided = cx.sc.d.guide_cmf != nullptr && cx.sc.d.num_guide_cells > 0;
     for (long long j = (long long) blockIdx.x * kBlock + threadIdx.x; j < n; j += (long long) gridDim.x * kBlock) {
@@ -198,8 +208,7 @@ __global__ __launch_bounds__(kBlock) void k_secondary_edge(LaunchCtx cx, Tangent
 // stream; nrounds evaluations each; mass[cell] += hmax(value0 / reso3) / nrounds.
 __global__ __launch_bounds__(kBlock) void k_guide(LaunchCtx cx, int r0, int r1, int r2, int per, int nrounds, long long n,
                                                   float *__restrict__ mass, unsigned long long *counters) {
-    __shared__ int32_t lds[kBvhStack * kBlock];
-    TraversalStack st; bind_stack(st, lds);
+    TraversalStack st; setup_lds(cx, st);
     uint32_t nrays = 0;
     const TangentView<0> tv0{};
     const RngJump nojump{1ull, 0ull};
@@ -319,9 +328,8 @@ template <int N> __device__ __forceinline__ bool wave_run_sum(int key, float (&v
 __global__ __launch_bounds__(kBlock) void k_camera_rev(LaunchCtx cx, DeviceSink sink, int spp, int s_begin, int nsp, long long n, float inv_spp,
                                                        const float *__restrict__ adj_img, float *__restrict__ img,
                                                        unsigned long long *counters) {
-    __shared__ int32_t lds[kBvhStack * kBlock];
     __shared__ float cache[kSinkCacheWords];
-    TraversalStack st; bind_stack(st, lds);
+    TraversalStack st; setup_lds(cx, st);
     sink.begin(cache);
     uint32_t nrays = 0;
     const long long nceil = (n + kBlock - 1) / kBlock * kBlock;
@@ -362,9 +370,8 @@ __global__ __launch_bounds__(kBlock) void k_camera_rev(LaunchCtx cx, DeviceSink 
 
 __global__ __launch_bounds__(kBlock) void k_primary_edge_rev(LaunchCtx cx, DeviceSink sink, long long i0, long long n, float inv_sppe,
                                                              const float *__restrict__ adj_img, unsigned long long *counters) {
-    __shared__ int32_t lds[kBvhStack * kBlock];
     __shared__ float cache[kSinkCacheWords];
-    TraversalStack st; bind_stack(st, lds);
+    TraversalStack st; setup_lds(cx, st);
     sink.begin(cache);
     uint32_t nrays = 0;
     for (long long j = (long long) blockIdx.x * kBlock + threadIdx.x; j < n; j += (long long) gridDim.x * kBlock)
@@ -375,9 +382,8 @@ __global__ __launch_bounds__(kBlock) void k_primary_edge_rev(LaunchCtx cx, Devic
 
 __global__ __launch_bounds__(kBlock) void k_secondary_edge_rev(LaunchCtx cx, DeviceSink sink, long long i0, long long n, float inv_sppse,
                                                                const float *__restrict__ adj_img, unsigned long long *counters) {
-    __shared__ int32_t lds[kBvhStack * kBlock];
     __shared__ float cache[kSinkCacheWords];
-    TraversalStack st; bind_stack(st, lds);
+    TraversalStack st; setup_lds(cx, st);
     sink.begin(cache);
     uint32_t nrays = 0;
     const bool guided = cx.sc.d.guide_cmf != nullptr && cx.sc.d.num_guide_cells > 0;
@@ -410,7 +416,8 @@ struct psdr_scene_s {
     unsigned long long *d_counters = nullptr;
     uint64_t slots[3] = {0, 0, 0};
     int num_cus = 256;
-    std::vector<int32_t> emitter_i;          // host copy of desc.emitter_i (hot-row ranges of the reverse sink)
+    std::vector<int32_t> emitter_i;
+    int bvh_depth = 0, num_nodes = 0, num_btris = 0;          // host copy of desc.emitter_i (hot-row ranges of the reverse sink)
 };
 
 namespace {
@@ -421,6 +428,25 @@ int launch_blocks(const psdr_scene_s *h, long long n) {
     return (int) std::max(1LL, std::min(need, cap));
 }
 
+// LDS plan of one launch: stacks sized by the tree depth, the rest of a 40 KB budget (4 workgroups
+// per CU) filled with the top of the BVH, then the leaf triangles, then the TriangleInfo rows.
+constexpr int kLdsBudget = 40 * 1024;
+int plan_lds(const psdr_scene_s *h, LaunchCtx &cx, int reserved = 0) {
+    const int stack_entries = std::min(kBvhStack, h->bvh_depth + 2);
+    const int stack_bytes = stack_entries * kBlock * 4;
+    int room = std::max(0, kLdsBudget - reserved - stack_bytes);
+    SceneView &sc = cx.sc;
+    int off = 0;
+    sc.n_lnodes = std::min(h->num_nodes, room / 64); sc.off_lnodes = off; off += sc.n_lnodes * 64; room -= sc.n_lnodes * 64;
+    sc.n_lbtris = (sc.n_lnodes == h->num_nodes) ? std::min(h->num_btris, room / 48) : 0;
+    sc.off_lbtris = off; off += sc.n_lbtris * 48; room -= sc.n_lbtris * 48;
+    sc.n_ltri = (sc.n_lbtris == h->num_btris) ? std::min(h->desc.num_tris, room / 96) : 0;
+    sc.off_ltri = off; off += sc.n_ltri * 96;
+    cx.off_stack = off;
+    return off + stack_bytes;
+}
+int lds_bytes(const LaunchCtx &cx, const psdr_scene_s *h) { return cx.off_stack + std::min(kBvhStack, h->bvh_depth + 2) * kBlock * 4; }
+
 int make_ctx(psdr_scene_s *h, const psdr_render_opts *o, int sampler, LaunchCtx &cx) {
     if (!h->have_tables) return fail("Scene not loaded yet!");
     if (!h->have_bvh) return fail("Input scene must be configured!");
@@ -428,6 +454,7 @@ int make_ctx(psdr_scene_s *h, const psdr_render_opts *o, int sampler, LaunchCtx 
     if (o->integrator == PSDR_INTEGRATOR_DIRECT && !(o->bsdf_samples >= 0 && o->light_samples >= 0 && o->bsdf_samples + o->light_samples > 0))
         return fail("DirectIntegrator: bsdf_samples + light_samples must be positive");
     cx.sc.d = h->desc; cx.sc.nodes = h->d_nodes; cx.sc.btris = h->d_btris; cx.sc.root = h->root;
+    plan_lds(h, cx);
     cx.lp = LiParams{o->integrator, o->bsdf_samples, o->light_samples, o->max_depth, o->hide_emitters, o->field};
     cx.jump = make_rng_jump(o->rng_offset[sampler]);
     return 0;
@@ -452,7 +479,7 @@ int run_camera(psdr_scene_s *h, const psdr_render_opts *o, const TV<R> &tv, floa
     if (int rc = make_ctx(h, o, 0, cx)) return rc;
     const long long n = WH * nsp;
     h->slots[0] += (uint64_t) n;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_camera<G, R>), dim3(launch_blocks(h, n)), dim3(kBlock), 0, s, cx, tv, o->spp, o->spp_begin, nsp, n,
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_camera<G, R>), dim3(launch_blocks(h, n)), dim3(kBlock), lds_bytes(cx, h), s, cx, tv, o->spp, o->spp_begin, nsp, n,
                        1.f / (float) o->spp, img, dimg, WH * 3, h->d_counters);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -475,7 +502,7 @@ int render_fwd(psdr_scene_s *h, const psdr_render_opts *o, const psdr_tangents *
         if (int rc = make_ctx(h, o, 1, cx)) return rc;
         const long long i0 = WH * o->sppe_begin, n = WH * (o->sppe_end - o->sppe_begin);
         h->slots[1] += (uint64_t) n;
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_primary_edge<K>), dim3(launch_blocks(h, n)), dim3(kBlock), 0, s, cx, tv, i0, n,
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_primary_edge<K>), dim3(launch_blocks(h, n)), dim3(kBlock), lds_bytes(cx, h), s, cx, tv, i0, n,
                            1.f / (float) o->sppe, dimg, WH * 3, h->d_counters);
         HIP_TRY(hipGetLastError());
     }
@@ -484,7 +511,7 @@ int render_fwd(psdr_scene_s *h, const psdr_render_opts *o, const psdr_tangents *
         if (int rc = make_ctx(h, o, 2, cx)) return rc;
         const long long i0 = WH * o->sppse_begin, n = WH * (o->sppse_end - o->sppse_begin);
         h->slots[2] += (uint64_t) n;
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_secondary_edge<K>), dim3(launch_blocks(h, n)), dim3(kBlock), 0, s, cx, tv, i0, n,
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_secondary_edge<K>), dim3(launch_blocks(h, n)), dim3(kBlock), lds_bytes(cx, h), s, cx, tv, i0, n,
                            1.f / (float) o->sppse, dimg, WH * 3, h->d_counters);
         HIP_TRY(hipGetLastError());
     }
@@ -592,6 +619,7 @@ int psdr_bvh_build(psdr_scene_t h, void *stream) {
     HIP_TRY(hipMemcpyAsync(h->d_btris, b.btris.data(), b.btris.size() * sizeof(float4), hipMemcpyHostToDevice, s));
     HIP_TRY(hipStreamSynchronize(s));     // host vectors die at return
     h->root = root;
+    h->bvh_depth = b.max_depth; h->num_nodes = (int) b.nodes.size(); h->num_btris = (int) b.btris.size() / 3;
     h->have_bvh = true;
     return 0;
 }
@@ -601,8 +629,10 @@ int psdr_trace(psdr_scene_t h, int32_t m, const float *ox, const float *oy, cons
     if (!h || !h->have_tables) return fail("Scene not loaded yet!");
     if (!h->have_bvh) return fail("Input scene must be configured!");
     if (m <= 0) return 0;
-    SceneView sc; sc.d = h->desc; sc.nodes = h->d_nodes; sc.btris = h->d_btris; sc.root = h->root;
-    hipLaunchKernelGGL(k_trace, dim3(launch_blocks(h, m)), dim3(kBlock), 0, (hipStream_t) stream, sc, m, ox, oy, oz, dx, dy, dz, tmax,
+    LaunchCtx cx{};
+    cx.sc.d = h->desc; cx.sc.nodes = h->d_nodes; cx.sc.btris = h->d_btris; cx.sc.root = h->root;
+    plan_lds(h, cx);
+    hipLaunchKernelGGL(k_trace, dim3(launch_blocks(h, m)), dim3(kBlock), lds_bytes(cx, h), (hipStream_t) stream, cx, m, ox, oy, oz, dx, dy, dz, tmax,
                        out_shape, out_tri, out_u, out_v);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -651,7 +681,7 @@ int psdr_render_d_rev(psdr_scene_t h, const psdr_render_opts *o, const float *ad
         if (int rc = make_ctx(h, o, 0, cx)) return rc;
         const long long n = WH * nsp;
         h->slots[0] += (uint64_t) n;
-        hipLaunchKernelGGL(k_camera_rev, dim3(launch_blocks(h, n)), dim3(kBlock), 0, s, cx, sink, o->spp, o->spp_begin, nsp, n,
+        hipLaunchKernelGGL(k_camera_rev, dim3(launch_blocks(h, n)), dim3(kBlock), lds_bytes(cx, h), s, cx, sink, o->spp, o->spp_begin, nsp, n,
                            1.f / (float) o->spp, adj_img, out_img, h->d_counters);
         HIP_TRY(hipGetLastError());
     }
@@ -660,7 +690,7 @@ int psdr_render_d_rev(psdr_scene_t h, const psdr_render_opts *o, const float *ad
         if (int rc = make_ctx(h, o, 1, cx)) return rc;
         const long long i0 = WH * o->sppe_begin, n = WH * (o->sppe_end - o->sppe_begin);
         h->slots[1] += (uint64_t) n;
-        hipLaunchKernelGGL(k_primary_edge_rev, dim3(launch_blocks(h, n)), dim3(kBlock), 0, s, cx, sink, i0, n, 1.f / (float) o->sppe, adj_img,
+        hipLaunchKernelGGL(k_primary_edge_rev, dim3(launch_blocks(h, n)), dim3(kBlock), lds_bytes(cx, h), s, cx, sink, i0, n, 1.f / (float) o->sppe, adj_img,
                            h->d_counters);
         HIP_TRY(hipGetLastError());
     }
@@ -669,7 +699,7 @@ int psdr_render_d_rev(psdr_scene_t h, const psdr_render_opts *o, const float *ad
         if (int rc = make_ctx(h, o, 2, cx)) return rc;
         const long long i0 = WH * o->sppse_begin, n = WH * (o->sppse_end - o->sppse_begin);
         h->slots[2] += (uint64_t) n;
-        hipLaunchKernelGGL(k_secondary_edge_rev, dim3(launch_blocks(h, n)), dim3(kBlock), 0, s, cx, sink, i0, n, 1.f / (float) o->sppse,
+        hipLaunchKernelGGL(k_secondary_edge_rev, dim3(launch_blocks(h, n)), dim3(kBlock), lds_bytes(cx, h), s, cx, sink, i0, n, 1.f / (float) o->sppse,
                            adj_img, h->d_counters);
         HIP_TRY(hipGetLastError());
     }
@@ -689,7 +719,7 @@ int psdr_guide_build(psdr_scene_t h, const psdr_render_opts *o, const int32_t re
     const long long n = cells * reso[3];
     if (n <= 0 || n > 0x7fffffffLL) return fail("psdr_guide_build: invalid resolution");
     HIP_TRY(hipMemsetAsync(out_mass, 0, sizeof(float) * cells, s));
-    hipLaunchKernelGGL(k_guide, dim3(launch_blocks(h, n)), dim3(kBlock), 0, s, cx, reso[0], reso[1], reso[2], reso[3], nrounds, n, out_mass,
+    hipLaunchKernelGGL(k_guide, dim3(launch_blocks(h, n)), dim3(kBlock), lds_bytes(cx, h), s, cx, reso[0], reso[1], reso[2], reso[3], nrounds, n, out_mass,
                        h->d_counters);
     HIP_TRY(hipGetLastError());
     return 0;
