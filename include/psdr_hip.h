@@ -114,6 +114,13 @@ typedef struct psdr_scene_desc {
     float          guide_sum;
 } psdr_scene_desc;
 
+/* psdr_render_opts.flags: execution strategy of the PathTracer interior term.
+   default: the library chooses.  FUSED = one lane carries a whole path in registers.
+   WAVEFRONT = one kernel per bounce over SoA path-state streams in HBM with wave-ballot stream
+   compaction of the live paths between bounces (renderC and material-only renderD). */
+#define PSDR_FLAG_FUSED     1
+#define PSDR_FLAG_WAVEFRONT 2
+
 /* One render call = Integrator::renderC / renderD on one shard of the sample
    slots (src/integrator/integrator.cpp:13-119, src/integrator/direct.cpp). */
 typedef struct psdr_render_opts {
@@ -126,7 +133,7 @@ typedef struct psdr_render_opts {
     int32_t spp_begin, spp_end;          /* this call evaluates s in [begin,end) of every pixel */
     int32_t sppe_begin, sppe_end;        /* slots [W*H*begin, W*H*end) of sampler 1 */
     int32_t sppse_begin, sppse_end;      /* slots [W*H*begin, W*H*end) of sampler 2 */
-    int32_t reserved;
+    int32_t flags;                       /* PSDR_FLAG_* (0 = library chooses) */
     uint64_t rng_offset[3];              /* draws already consumed per stream of sampler 0/1/2:
                                             the reference keeps the PCG32 states alive across
                                             render calls (scene.cpp:65-79) */

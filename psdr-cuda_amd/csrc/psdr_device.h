@@ -271,6 +271,27 @@ template <class R, class TVT> PSDR_HD Its<R> intersect(const SceneView &sc, cons
     return its;
 }
 
+// Path vertex rebuilt from its stream record (wavefront mode): triangle id, detached barycentrics and
+// the unit direction of arrival.  Same arithmetic as the path-space branch of intersect().
+template <class TVT> PSDR_HD Its<float> path_vertex_from_record(const SceneView &sc, const TVT &tv, int tri, float hu, float hv, const Vec3f &dir) {
+    Its<float> its;
+    its.valid = true; its.tri = tri; its.hu = hu; its.hv = hv; its.J = 1.f; its.t = 0.f;
+    const int tm = sc.d.tri_mesh[tri];
+    its.mesh = tm & ~PSDR_TRI_FACE_NORMALS;
+    const TriRow<float> T = load_tri_f(sc, tv, tri);
+    its.n = T.fn;
+    its.p = bary_point(T.p0, T.e1, T.e2, hu, hv);
+    const Vec3f sh_n = (tm & PSDR_TRI_FACE_NORMALS) ? its.n : normalize(bary_point(T.n0, T.n1 - T.n0, T.n2 - T.n0, hu, hv));
+    its.sh = Frame<float>(sh_n);
+    its.wi = its.sh.to_local(-dir);
+    if (sc.d.tri_uv) {
+        const float *q = sc.d.tri_uv + (size_t) tri * PSDR_TRIUV_STRIDE;
+        its.uvx = (q[2] - q[0]) * hu + ((q[4] - q[0]) * hv + q[0]);
+        its.uvy = (q[3] - q[1]) * hu + ((q[5] - q[1]) * hv + q[1]);
+    } else { its.uvx = 0.f; its.uvy = 0.f; }
+    return its;
+}
+
 template <class R> PSDR_HD int emitter_of(const SceneView &sc, const Its<R> &its) { return its.valid ? sc.d.mesh_emitter[its.mesh] : -1; }
 
 template <class M, class TVT> PSDR_HD Vec3<M> radiance(const SceneView &sc, const TVT &tv, int e) {
@@ -625,6 +646,37 @@ template <int K> PSDR_HD Dual<K> zero_nonfinite(const Dual<K> &x) {
     return r;
 }
 template <class R> PSDR_HD Vec3<R> zero_nonfinite(const Vec3<R> &v) { return {zero_nonfinite(v.x), zero_nonfinite(v.y), zero_nonfinite(v.z)}; }
+
+// Wavefront mode, stage 0: camera ray, primary hit, Le and the direct step at the primary vertex;
+// reports the BSDF-sampled continuation (next vertex record + throughput).
+template <class M, class TVT>
+PSDR_HD Vec3<M> wavefront_camera_vertex(const SceneView &sc, const TVT &tv, TraversalStack &st, const LiParams &lp, const RngJump &jump,
+                                        int pixel, uint64_t slot, uint32_t &nrays, Its<float> &next, Vec3<M> &beta, Vec3f &origin, bool &alive) {
+    Rng rng; rng.init(slot, jump);
+    const float j0 = rng.next(), j1 = rng.next();
+    const int W = sc.d.width;
+    const float sx = ((float) (pixel % W) + j0) / (float) W, sy = ((float) (pixel / W) + j1) / (float) sc.d.height;
+    const RayT<float> ray = primary_ray<float>(sc, tv, sx, sy);
+    const Its<float> its = intersect<float>(sc, tv, st, ray, true, is_ad<M>() ? kSolidAngle : kDetached, nrays);
+    alive = false;
+    if (!its.valid) return zero3<M>();
+    Vec3<M> result = lp.hide_emitters ? zero3<M>() : Le<M>(sc, tv, its, true);
+    bool nvalid = false;
+    result = result + direct_step<float, M>(sc, tv, st, rng, its, true, 1, 1, nrays, &next, &beta, &nvalid);
+    origin = its.p;
+    if (nvalid) { const Vec3f b = val(beta); alive = b.x != 0.f || b.y != 0.f || b.z != 0.f; }
+    return result;
+}
+// Wavefront mode, stage k >= 1: the direct step at a path vertex read back from the stream.
+template <class M, class TVT>
+PSDR_HD Vec3<M> wavefront_bounce_vertex(const SceneView &sc, const TVT &tv, TraversalStack &st, const RngJump &jump_k, uint64_t slot,
+                                        const Its<float> &its, uint32_t &nrays, Its<float> &next, Vec3<M> &f, bool &alive) {
+    Rng rng; rng.init(slot, jump_k);
+    bool nvalid = false;
+    const Vec3<M> c = direct_step<float, M>(sc, tv, st, rng, its, true, 1, 1, nrays, &next, &f, &nvalid);
+    alive = nvalid;
+    return c;
+}
 
 // One camera sample slot: Integrator::__render (src/integrator/integrator.cpp:64-95), before the splat
 template <class G, class M, class TVT>

@@ -45,6 +45,18 @@ template <int N> __device__ __forceinline__ bool wave_segmented_sum(int key, flo
     return lane == 0 || pkey != key;
 }
 
+// Sum of v over runs of ADJACENT lanes holding the same key (keys in any order); the first lane of
+// each run gets the total.
+template <int N> __device__ __forceinline__ bool wave_run_sum(int key, float (&v)[N]) {
+    const int lane = threadIdx.x & 63;
+    const int prev = __shfl_up(key, 1, 64);
+    const bool head = lane == 0 || prev != key;
+    const unsigned long long heads = __ballot(head);
+    const int seg = __popcll(heads & (~0ull >> (63 - lane)));       // run index: non-decreasing
+    wave_segmented_sum<N>(seg, v);
+    return head;
+}
+
 __device__ __forceinline__ void count_rays(unsigned long long *counters, uint32_t nrays) {
     uint32_t s = nrays;
 #pragma unroll
@@ -150,6 +162,136 @@ __global__ __launch_bounds__(kBlock, (camera_waves<G, R>())) void k_camera(Launc
                 if (v[5 + 3 * k] != 0.f) atomicAdd(q + 2, v[5 + 3 * k]);
             }
         }
+    }
+    count_rays(counters, nrays);
+}
+
+// ----------------------------------------------------------------------- wavefront mode
+// PathTracer as a wavefront: stage 0 (camera ray, primary vertex) then one kernel per bounce over SoA
+// path-state streams in HBM.  Live paths are compacted between stages with a wave ballot + prefix
+// popcount and ONE atomic per wave on the stream counter, so every bounce kernel runs on dense
+// waves.  Record = pixel, slot, triangle, (u,v), arrival direction, throughput (+K tangents):
+// 44 + 12 K bytes, all streams coalesced.
+struct PathStream {
+    int32_t *pixel; uint32_t *slot; int32_t *tri; float *hu, *hv; float *dir; float *beta;   // dir: [3][cap], beta: [3(1+K)][cap]
+    long long cap;
+};
+
+template <class M>
+__device__ __forceinline__ void stream_push(const PathStream &out, int *counter, bool alive, int pixel, uint32_t slot, const Its<float> &next,
+                                            const Vec3f &dir, const Vec3<M> &beta) {
+    constexpr int K = ad_traits<M>::K;
+    const unsigned long long mask = __ballot(alive);
+    if (mask == 0ull) return;
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == __ffsll((long long) mask) - 1) base = atomicAdd(counter, (int) __popcll(mask));
+    base = __shfl(base, __ffsll((long long) mask) - 1, 64);
+    if (!alive) return;
+    const long long i = base + __popcll(mask & ((1ull << lane) - 1ull));
+    out.pixel[i] = pixel; out.slot[i] = slot; out.tri[i] = next.tri; out.hu[i] = next.hu; out.hv[i] = next.hv;
+    out.dir[i] = dir.x; out.dir[out.cap + i] = dir.y; out.dir[2 * out.cap + i] = dir.z;
+    out.beta[i] = val(beta.x); out.beta[out.cap + i] = val(beta.y); out.beta[2 * out.cap + i] = val(beta.z);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        out.beta[(3 + 3 * k) * out.cap + i] = tangent(beta.x, k); out.beta[(4 + 3 * k) * out.cap + i] = tangent(beta.y, k);
+        out.beta[(5 + 3 * k) * out.cap + i] = tangent(beta.z, k);
+    }
+}
+
+template <class M>
+__device__ __forceinline__ void splat_runs(int pixel, bool valid, const Vec3<M> &r, float scale, float *img, float *dimg, long long plane) {
+    constexpr int K = ad_traits<M>::K;
+    constexpr int NV = 3 * (1 + K);
+    float v[NV];
+    v[0] = val(r.x) * scale; v[1] = val(r.y) * scale; v[2] = val(r.z) * scale;
+#pragma unroll
+    for (int k = 0; k < K; ++k) { v[3 + 3 * k] = tangent(r.x, k) * scale; v[4 + 3 * k] = tangent(r.y, k) * scale; v[5 + 3 * k] = tangent(r.z, k) * scale; }
+    if (!valid) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = 0.f;
+    }
+    const bool head = wave_run_sum<NV>(valid ? pixel : -1, v);
+    if (head && valid) {
+        float *p = img + (size_t) pixel * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) if (v[c] != 0.f) atomicAdd(p + c, v[c]);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            float *q = dimg + (size_t) k * plane + (size_t) pixel * 3;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) if (v[3 + 3 * k + c] != 0.f) atomicAdd(q + c, v[3 + 3 * k + c]);
+        }
+    }
+}
+
+template <class M>
+__global__ __launch_bounds__(kBlock, (is_ad<M>() ? 2 : 4)) void k_wf_camera(LaunchCtx cx, TV<M> tv, int spp, int s_begin, int nsp, long long j0, long long n,
+                                                        float inv_spp, float *__restrict__ img, float *__restrict__ dimg, long long plane,
+                                                        PathStream out, int *out_count, int want_next, unsigned long long *counters) {
+    TraversalStack st; setup_lds(cx, st);
+    uint32_t nrays = 0;
+    const long long nceil = (n + kBlock - 1) / kBlock * kBlock;
+    for (long long jj = (long long) blockIdx.x * kBlock + threadIdx.x; jj < nceil; jj += (long long) gridDim.x * kBlock) {
+        const bool in = jj < n;
+        const long long j = j0 + jj;
+        const int pixel = in ? (int) (j / nsp) : 0;
+        Vec3<M> r = zero3<M>(), beta = zero3<M>();
+        Its<float> next; next.tri = -1; next.hu = next.hv = 0.f;
+        Vec3f origin(0.f), dir(0.f);
+        bool alive = false;
+        uint32_t slot = 0;
+        if (in) {
+            slot = (uint32_t) ((uint64_t) pixel * (uint64_t) spp + (uint64_t) (s_begin + (int) (j % nsp)));
+            r = zero_nonfinite(wavefront_camera_vertex<M>(cx.sc, tv, st, cx.lp, cx.jump, pixel, slot, nrays, next, beta, origin, alive));
+            if (alive) { Vec3f d = next.p - origin; const float t = norm(d); dir = d / t; }
+        }
+        splat_runs<M>(pixel, in, r, inv_spp, img, dimg, plane);
+        stream_push<M>(out, out_count, alive && want_next, pixel, slot, next, dir, beta);
+    }
+    count_rays(counters, nrays);
+}
+
+template <class M>
+__global__ __launch_bounds__(kBlock, (is_ad<M>() ? 2 : 4)) void k_wf_bounce(LaunchCtx cx, TV<M> tv, float inv_spp, float *__restrict__ img,
+                                                        float *__restrict__ dimg, long long plane, PathStream in, const int *in_count,
+                                                        PathStream out, int *out_count, int want_next, unsigned long long *counters) {
+    constexpr int K = ad_traits<M>::K;
+    TraversalStack st; setup_lds(cx, st);
+    uint32_t nrays = 0;
+    const long long n = *in_count;
+    const long long nceil = (n + kBlock - 1) / kBlock * kBlock;
+    for (long long j = (long long) blockIdx.x * kBlock + threadIdx.x; j < nceil; j += (long long) gridDim.x * kBlock) {
+        const bool live = j < n;
+        int pixel = -1; uint32_t slot = 0;
+        Vec3<M> r = zero3<M>(), beta = zero3<M>();
+        Its<float> next; next.tri = -1; next.hu = next.hv = 0.f;
+        Vec3f dir(0.f);
+        bool alive = false;
+        if (live) {
+            pixel = in.pixel[j]; slot = in.slot[j];
+            const Vec3f din{in.dir[j], in.dir[in.cap + j], in.dir[2 * in.cap + j]};
+            beta.x = M(in.beta[j]); beta.y = M(in.beta[in.cap + j]); beta.z = M(in.beta[2 * in.cap + j]);
+            if constexpr (K > 0) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    beta.x.d[k] = in.beta[(3 + 3 * k) * in.cap + j]; beta.y.d[k] = in.beta[(4 + 3 * k) * in.cap + j];
+                    beta.z.d[k] = in.beta[(5 + 3 * k) * in.cap + j];
+                }
+            }
+            const Its<float> its = path_vertex_from_record(cx.sc, tv, in.tri[j], in.hu[j], in.hv[j], din);
+            Vec3<M> f;
+            const Vec3<M> c = wavefront_bounce_vertex<M>(cx.sc, tv, st, cx.jump, (uint64_t) slot, its, nrays, next, f, alive);
+            r = zero_nonfinite(beta * c);
+            if (alive) {
+                beta = beta * f;
+                const Vec3f b = val(beta);
+                alive = b.x != 0.f || b.y != 0.f || b.z != 0.f;
+                Vec3f d = next.p - its.p; const float t = norm(d); dir = d / t;
+            }
+        }
+        splat_runs<M>(pixel, live, r, inv_spp, img, dimg, plane);
+        stream_push<M>(out, out_count, alive && want_next, pixel, slot, next, dir, beta);
     }
     count_rays(counters, nrays);
 }
@@ -314,17 +456,6 @@ struct DeviceSink {
     }
 };
 
-// Sum of v over runs of ADJACENT lanes holding the same key; the first lane of each run gets the total.
-template <int N> __device__ __forceinline__ bool wave_run_sum(int key, float (&v)[N]) {
-    const int lane = threadIdx.x & 63;
-    const int prev = __shfl_up(key, 1, 64);
-    const bool head = lane == 0 || prev != key;
-    const unsigned long long heads = __ballot(head);
-    const int seg = __popcll(heads & (~0ull >> (63 - lane)));       // run index: non-decreasing
-    wave_segmented_sum<N>(seg, v);
-    return head;
-}
-
 __global__ __launch_bounds__(kBlock) void k_camera_rev(LaunchCtx cx, DeviceSink sink, int spp, int s_begin, int nsp, long long n, float inv_spp,
                                                        const float *__restrict__ adj_img, float *__restrict__ img,
                                                        unsigned long long *counters) {
@@ -417,7 +548,9 @@ struct psdr_scene_s {
     uint64_t slots[3] = {0, 0, 0};
     int num_cus = 256;
     std::vector<int32_t> emitter_i;
-    int bvh_depth = 0, num_nodes = 0, num_btris = 0;          // host copy of desc.emitter_i (hot-row ranges of the reverse sink)
+    int bvh_depth = 0, num_nodes = 0, num_btris = 0;
+    void *d_ws = nullptr; size_t ws_bytes = 0;
+    int last_path_depth = 0; float path_survival = -1.f;   // rays traced / rays of fully surviving paths (last PathTracer call)          // wavefront path-state streams + counters          // host copy of desc.emitter_i (hot-row ranges of the reverse sink)
 };
 
 namespace {
@@ -485,6 +618,66 @@ int run_camera(psdr_scene_s *h, const psdr_render_opts *o, const TV<R> &tv, floa
     return 0;
 }
 
+// PathTracer interior term as a wavefront (see k_wf_camera / k_wf_bounce).  M = float or Dual<K>
+// with plain-fp32 geometry.
+constexpr long long kWfChunk = 1ll << 25;
+template <class M>
+int run_camera_wavefront(psdr_scene_s *h, const psdr_render_opts *o, const TV<M> &tv, float *img, float *dimg, hipStream_t s) {
+    constexpr int K = ad_traits<M>::K;
+    const long long WH = (long long) h->desc.width * h->desc.height;
+    const int nsp = o->spp_end - o->spp_begin;
+    if (o->spp <= 0 || nsp <= 0) return 0;
+    const long long n = WH * nsp;
+    const long long cap = std::min(n, kWfChunk);
+    const int depth = o->max_depth;
+    const size_t words = 8 + 3 * (1 + K);
+    const size_t need = 2 * words * 4 * (size_t) cap + 256 * sizeof(int);
+    if (need > h->ws_bytes) {
+        if (h->d_ws) (void) hipFree(h->d_ws);
+        h->d_ws = nullptr; h->ws_bytes = 0;
+        HIP_TRY(hipMalloc(&h->d_ws, need));
+        h->ws_bytes = need;
+    }
+    int *cnt = reinterpret_cast<int *>(h->d_ws);
+    PathStream st[2];
+    for (int i = 0; i < 2; ++i) {
+        float *b = reinterpret_cast<float *>(reinterpret_cast<char *>(h->d_ws) + 256 * sizeof(int)) + (size_t) i * words * cap;
+        st[i].cap = cap;
+        st[i].pixel = reinterpret_cast<int32_t *>(b); st[i].slot = reinterpret_cast<uint32_t *>(b + cap); st[i].tri = reinterpret_cast<int32_t *>(b + 2 * cap);
+        st[i].hu = b + 3 * cap; st[i].hv = b + 4 * cap; st[i].dir = b + 5 * cap; st[i].beta = b + 8 * cap;
+    }
+    h->slots[0] += (uint64_t) n;
+    const float inv_spp = 1.f / (float) o->spp;
+    for (long long j0 = 0; j0 < n; j0 += cap) {
+        const long long cn = std::min(cap, n - j0);
+        HIP_TRY(hipMemsetAsync(cnt, 0, 256 * sizeof(int), s));
+        LaunchCtx cx;
+        if (int rc = make_ctx(h, o, 0, cx)) return rc;
+        const int blocks = launch_blocks(h, cn);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wf_camera<M>), dim3(blocks), dim3(kBlock), lds_bytes(cx, h), s, cx, tv, o->spp, o->spp_begin, nsp, j0, cn,
+                           inv_spp, img, dimg, WH * 3, st[0], cnt + 1, depth > 1 ? 1 : 0, h->d_counters);
+        HIP_TRY(hipGetLastError());
+        for (int k = 1; k < depth; ++k) {
+            cx.jump = make_rng_jump(o->rng_offset[0] + 2 + 5 * (uint64_t) k);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wf_bounce<M>), dim3(blocks), dim3(kBlock), lds_bytes(cx, h), s, cx, tv, inv_spp, img, dimg, WH * 3,
+                               st[(k - 1) & 1], cnt + k, st[k & 1], cnt + k + 1, k + 1 < depth ? 1 : 0, h->d_counters);
+            HIP_TRY(hipGetLastError());
+        }
+    }
+    return 0;
+}
+
+// Strategy choice.  Measured on MI355X (tools/perf_cases.py): in a closed box almost every path
+// survives, compaction buys nothing and the fused kernel is 1.1-1.9x faster; in an open scene
+// (bunny_light: 2.5 of 7 possible rays per path) the wavefront is 1.35x faster.  The library keeps
+// the survival ratio of the previous PathTracer call on this handle and switches on it.
+bool use_wavefront(const psdr_scene_s *h, const psdr_render_opts *o) {
+    if (o->integrator != PSDR_INTEGRATOR_PATH || o->max_depth > 250) return false;
+    if (o->flags & PSDR_FLAG_FUSED) return false;
+    if (o->flags & PSDR_FLAG_WAVEFRONT) return true;
+    return o->max_depth >= 2 && h->path_survival >= 0.f && h->path_survival < 0.55f;
+}
+
 template <int K>
 int render_fwd(psdr_scene_s *h, const psdr_render_opts *o, const psdr_tangents *tangents, float *img, float *dimg, hipStream_t s) {
     const long long WH = (long long) h->desc.width * h->desc.height;
@@ -496,6 +689,7 @@ int render_fwd(psdr_scene_s *h, const psdr_render_opts *o, const psdr_tangents *
     bool geo = false;
     for (int k = 0; k < K; ++k) geo = geo || tangents[k].d_tri_info || tangents[k].d_cam_to_world;
     if (geo) { if (int rc = run_camera<Dual<K>, Dual<K>>(h, o, tv, img, dimg, s)) return rc; }
+    else if (use_wavefront(h, o)) { if (int rc = run_camera_wavefront<Dual<K>>(h, o, tv, img, dimg, s)) return rc; }
     else { if (int rc = run_camera<float, Dual<K>>(h, o, tv, img, dimg, s)) return rc; }
     if (o->sppe > 0 && o->sppe_end > o->sppe_begin && h->desc.num_prim_edges > 0) {
         LaunchCtx cx;
@@ -544,7 +738,7 @@ SinkLayout make_sink_layout(const psdr_scene_s *h, const psdr_grads *g) {
 }
 
 int begin_call(psdr_scene_s *h, hipStream_t s) {
-    h->slots[0] = h->slots[1] = h->slots[2] = 0;
+    h->slots[0] = h->slots[1] = h->slots[2] = 0; h->last_path_depth = 0;
     HIP_TRY(hipMemsetAsync(h->d_counters, 0, sizeof(unsigned long long) * 4, s));
     return 0;
 }
@@ -578,6 +772,7 @@ int psdr_scene_destroy(psdr_scene_t h) {
     if (h->d_nodes) (void) hipFree(h->d_nodes);
     if (h->d_btris) (void) hipFree(h->d_btris);
     if (h->d_counters) (void) hipFree(h->d_counters);
+    if (h->d_ws) (void) hipFree(h->d_ws);
     delete h;
     return 0;
 }
@@ -644,9 +839,11 @@ int psdr_render_c(psdr_scene_t h, const psdr_render_opts *o, float *out_img, voi
     if (int rc = check_counts(h, o)) return rc;
     hipStream_t s = (hipStream_t) stream;
     if (int rc = begin_call(h, s)) return rc;
+    if (o->integrator == PSDR_INTEGRATOR_PATH) h->last_path_depth = o->max_depth;
     const long long WH = (long long) h->desc.width * h->desc.height;
     HIP_TRY(hipMemsetAsync(out_img, 0, sizeof(float) * WH * 3, s));
     const TangentView<0> tv0{};
+    if (use_wavefront(h, o)) return run_camera_wavefront<float>(h, o, tv0, out_img, nullptr, s);
     return run_camera<float, float>(h, o, tv0, out_img, nullptr, s);
 }
 
@@ -730,6 +927,8 @@ int psdr_get_counters(psdr_scene_t h, uint64_t out[4]) {
     unsigned long long c[4] = {0, 0, 0, 0};
     HIP_TRY(hipMemcpy(c, h->d_counters, sizeof(c), hipMemcpyDeviceToHost));
     out[0] = c[0]; out[1] = h->slots[0]; out[2] = h->slots[1]; out[3] = h->slots[2];
+    if (h->last_path_depth > 0 && h->slots[0] > 0 && h->slots[1] == 0 && h->slots[2] == 0)
+        h->path_survival = (float) ((double) c[0] / ((double) h->slots[0] * (1.0 + 2.0 * h->last_path_depth)));
     return 0;
 }
 

@@ -27,6 +27,7 @@ BSDF_DIFFUSE, BSDF_ROUGHCONDUCTOR = 0, 1
 SLOT_REFLECTANCE, SLOT_ALPHA_U, SLOT_ALPHA_V, SLOT_ETA, SLOT_K = range(5)
 CAM_SAMPLE_TO_CAMERA, CAM_TO_WORLD, CAM_WORLD_TO_SAMPLE, CAM_POS, CAM_DIR, CAM_INV_AREA = 0, 16, 32, 48, 51, 54
 INTEGRATOR_DIRECT, INTEGRATOR_PATH, INTEGRATOR_FIELD = 0, 1, 2
+FLAG_FUSED, FLAG_WAVEFRONT = 1, 2
 FIELDS = {"silhouette": 0, "position": 1, "depth": 2, "geoNormal": 3, "shNormal": 4, "uv": 5}
 
 _fp = C.c_void_p  # all table pointers travel as raw addresses
@@ -58,7 +59,7 @@ class RenderOpts(C.Structure):
         ("spp_begin", C.c_int32), ("spp_end", C.c_int32),
         ("sppe_begin", C.c_int32), ("sppe_end", C.c_int32),
         ("sppse_begin", C.c_int32), ("sppse_end", C.c_int32),
-        ("reserved", C.c_int32),
+        ("flags", C.c_int32),
         ("rng_offset", C.c_uint64 * 3),
     ]
 
@@ -155,8 +156,9 @@ def load_oracle():
 
 def make_opts(integrator=INTEGRATOR_DIRECT, bsdf_samples=1, light_samples=1, max_depth=1, hide_emitters=False,
               field=0, spp=1, sppe=0, sppse=0, spp_range=None, sppe_range=None, sppse_range=None,
-              rng_offset=(0, 0, 0)):
+              rng_offset=(0, 0, 0), flags=0):
     o = RenderOpts()
+    o.flags = flags
     o.integrator, o.bsdf_samples, o.light_samples = integrator, bsdf_samples, light_samples
     o.max_depth, o.hide_emitters, o.field = max_depth, int(bool(hide_emitters)), field
     o.spp, o.sppe, o.sppse = spp, sppe, sppse

@@ -35,6 +35,17 @@ def main():
             o = _abi.make_opts(spp=64, **kw)
             ms = timeit(lambda: g.render_c(o)); r = g.counters()[0] / n
             print("C2 %-9s renderC            %8.2f ms  %7.0f Msamples/s  rays/slot %.2f" % (name, ms, n / ms / 1e3, r))
+            if name.startswith("path"):
+                for depth in (3, 6):
+                    for fl, fn in ((_abi.FLAG_FUSED, "fused"), (_abi.FLAG_WAVEFRONT, "wavefront")):
+                        ow = _abi.make_opts(spp=64, integrator=_abi.INTEGRATOR_PATH, max_depth=depth, flags=fl)
+                        ms = timeit(lambda: g.render_c(ow)); r = g.counters()[0] / n
+                        print("C2 path%d %-9s renderC        %8.2f ms  %7.0f Msamples/s  rays/slot %.2f" % (depth, fn, ms, n / ms / 1e3, r))
+                t3w = [{"texels": torch.eye(tb["texels"].numel())[c]} for c in range(3)]
+                for fl, fn in ((_abi.FLAG_FUSED, "fused"), (_abi.FLAG_WAVEFRONT, "wavefront")):
+                    ow = _abi.make_opts(spp=64, integrator=_abi.INTEGRATOR_PATH, max_depth=3, flags=fl)
+                    ms = timeit(lambda: g.render_d_fwd(ow, t3w))
+                    print("C2 path3 %-9s renderD K=3 mat %8.2f ms  %7.0f Msamples/s" % (fn, ms, n / ms / 1e3))
             t3 = [{"texels": torch.eye(tb["texels"].numel())[c]} for c in range(3)]
             ms = timeit(lambda: g.render_d_fwd(o, t3))
             print("C2 %-9s renderD fwd K=3 mat  %8.2f ms  %7.0f Msamples/s" % (name, ms, n / ms / 1e3))
@@ -61,9 +72,20 @@ def main():
         print("C3 bunny renderD fwd K=1 (3 terms) %8.2f ms  %7.0f Mslots/s (slots %s rays %d)" % (ms, 3 * n / ms / 1e3, c[1:], c[0]))
         ms = timeit(lambda: g.render_d_rev(o, adj, with_image=False))
         print("C3 bunny renderD rev (3 terms)     %8.2f ms  %7.0f Mslots/s" % (ms, 3 * n / ms / 1e3))
-        op = _abi.make_opts(integrator=_abi.INTEGRATOR_PATH, max_depth=3, spp=spp)
-        ms = timeit(lambda: g.render_c(op)); r = g.counters()[0] / n
-        print("C3 bunny path3 renderC            %8.2f ms  %7.0f Msamples/s  rays/slot %.2f" % (ms, n / ms / 1e3, r))
+        for depth in (3, 6):
+            for fl, fn in ((_abi.FLAG_FUSED, "fused"), (_abi.FLAG_WAVEFRONT, "wavefront")):
+                op = _abi.make_opts(integrator=_abi.INTEGRATOR_PATH, max_depth=depth, spp=spp, flags=fl)
+                ms = timeit(lambda: g.render_c(op)); r = g.counters()[0] / n
+                print("C3 bunny path%d %-9s renderC     %8.2f ms  %7.0f Msamples/s  rays/slot %.2f" % (depth, fn, ms, n / ms / 1e3, r))
+    if "open" in which:
+        res, spp = 512, 32
+        sc, _ = load_scene("bunny_light", res=res, spp=spp)
+        tb = sc.tables(0); g = GpuScene(tb); n = res * res * spp
+        for depth in (3, 6):
+            for fl, fn in ((_abi.FLAG_FUSED, "fused"), (_abi.FLAG_WAVEFRONT, "wavefront")):
+                op = _abi.make_opts(integrator=_abi.INTEGRATOR_PATH, max_depth=depth, spp=spp, flags=fl)
+                ms = timeit(lambda: g.render_c(op)); r = g.counters()[0] / n
+                print("open bunny_light path%d %-9s renderC %8.2f ms  %7.0f Msamples/s  rays/slot %.2f" % (depth, fn, ms, n / ms / 1e3, r))
 
 
 if __name__ == "__main__":
