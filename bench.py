@@ -49,6 +49,23 @@ def algorithmic_bytes(slots, rays, derivative):
     return b
 
 
+def measured_traffic(kernel_key):
+    """HBM bytes per launch of the dominant kernel from the newest committed PMC summary
+    (profiles/*_traffic.json, written by tools/summarize_prof.py from separate rocprofv3 --pmc passes);
+    bench.py itself cannot read PMC counters."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), key=os.path.getmtime)
+    for f in reversed(files):
+        try:
+            d = json.load(open(f))
+            for name, v in d["kernels"].items():
+                if "k_camera" in name and kernel_key in name and "rev" not in name:
+                    return v["hbm_bytes_per_launch"], os.path.relpath(f, ROOT)
+        except Exception:
+            continue
+    return None, None
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -132,8 +149,9 @@ def main():
     dom_rays = rays["d"][0] if ms_d >= ms_c else rays["c"][0]
     abytes = algorithmic_bytes(local_slots, dom_rays, ms_d >= ms_c)
     achieved = abytes / (dom_ms * 1e-3) / 1e9
+    traffic, traffic_src = measured_traffic("Dual<3>" if ms_d >= ms_c else "float, float")
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
-                "frac": round(achieved / 8000.0, 5), "traffic": None, "kernel": dom,
+                "frac": round(achieved / 8000.0, 5), "traffic": traffic, "traffic_source": traffic_src, "kernel": dom,
                 "kernel_ms": round(dom_ms, 4), "rays_per_slot": round(dom_rays / local_slots, 4),
                 "algorithmic_bytes_per_launch": abytes,
                 "render_c_ms": round(ms_c, 4), "render_d_ms": round(ms_d, 4)}
