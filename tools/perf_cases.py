@@ -88,5 +88,33 @@ def main():
                 print("open bunny_light path%d %-9s renderC %8.2f ms  %7.0f Msamples/s  rays/slot %.2f" % (depth, fn, ms, n / ms / 1e3, r))
 
 
+def extra(which):
+    if "c4" in which:
+        # one GPU's shard of C4: cbox_bunny 1024x1024, 64 of the 512 spp
+        sc, P = load_scene("cbox_bunny", res=1024, spp=512, sppe=0, sppse=0)
+        tb = sc.tables(0); g = GpuScene(tb); n = 1024 * 1024 * 64
+        for name, kw in (("direct11", dict(bsdf_samples=1, light_samples=1)), ("path3", dict(integrator=_abi.INTEGRATOR_PATH, max_depth=3))):
+            o = _abi.make_opts(spp=512, spp_range=(0, 64), **kw)
+            ms = timeit(lambda: g.render_c(o), reps=2); r = g.counters()[0] / n
+            print("C4 shard %-9s renderC (67M slots) %8.2f ms  %7.0f Msamples/s  rays/slot %.2f" % (name, ms, n / ms / 1e3, r))
+    if "c5" in which:
+        from psdr_cuda.fixtures import make_interior_scene
+        res, spp = 512, 16
+        sc = make_interior_scene(seed=0, n_objects=10, res=res, spp=spp)
+        sc.configure()
+        tb = sc.tables(0); g = GpuScene(tb); n = res * res * spp
+        adj = np.random.default_rng(0).random((res * res, 3)).astype(np.float32)
+        for name, kw in (("direct11", dict(bsdf_samples=1, light_samples=1)), ("path3", dict(integrator=_abi.INTEGRATOR_PATH, max_depth=3))):
+            o = _abi.make_opts(spp=spp, **kw)
+            ms = timeit(lambda: g.render_c(o)); r = g.counters()[0] / n
+            print("C5 %-9s renderC              %8.2f ms  %7.0f Msamples/s  rays/slot %.2f (T=%d)" % (name, ms, n / ms / 1e3, r, tb["num_tris"]))
+            tg = random_tangents(tb, ["tri_info", "texels"])
+            ms = timeit(lambda: g.render_d_fwd(o, [tg]))
+            print("C5 %-9s renderD fwd K=1 geo+mat %8.2f ms  %7.0f Msamples/s" % (name, ms, n / ms / 1e3))
+            ms = timeit(lambda: g.render_d_rev(o, adj, want=["tri_info", "texels"], with_image=False))
+            print("C5 %-9s renderD rev tri+texels  %8.2f ms  %7.0f Msamples/s" % (name, ms, n / ms / 1e3))
+
+
 if __name__ == "__main__":
+    extra(sys.argv[1:])
     main()
