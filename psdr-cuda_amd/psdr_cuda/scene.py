@@ -258,6 +258,16 @@ class PerspectiveCamera(Sensor):
         return out
 
 
+class PositionSample:
+    """PositionSample_ (include/psdr/core/records.h:20-32): pdf, is_valid, p, n, J."""
+    pdf = is_valid = p = n = J = None
+
+
+class BoundarySegSampleDirect:
+    """records.h:35-44: pdf, is_valid, p0 (differentiable), edge, edge2, p2, n."""
+    pdf = is_valid = p0 = edge = edge2 = p2 = n = None
+
+
 # ------------------------------------------------------------------------------- mesh
 def load_obj(fname):
     """Minimal OBJ reader standing in for tinyobj::LoadObj(triangulate=true)
@@ -498,6 +508,34 @@ class Mesh(Object):
             info = torch.cat([p0, e1, n0, n1, p2, is_b.to(torch.float32).unsqueeze(-1)], dim=-1)
             self._sec_edge_info = info[keep]
         self.m_ready = True
+
+    def sample_position(self, sample2, active=True):
+        """Mesh::__sample_position (mesh.cpp:306-330), host/torch mirror for API parity: face by the
+        area pmf with sample reuse, uniform point on the triangle.  Returns a PositionSample."""
+        psdr_assert(self.m_ready and self._triangle_info is not None)
+        ad = isinstance(sample2, ek.ArrayBase) and sample2._ad
+        s = (sample2.t if isinstance(sample2, ek.ArrayBase) else torch.as_tensor(sample2, device=_dev())).to(torch.float32)
+        d = self._face_distrb
+        u = s[:, 0].detach().clone()
+        if d.m_size > 1:
+            x = u * d.m_sum
+            idx = torch.searchsorted(d.m_cmf, x.contiguous(), right=False).clamp(max=d.m_size - 1)
+            prev = torch.where(idx > 0, d.m_cmf[(idx - 1).clamp(min=0)], torch.zeros_like(x))
+            p = d.m_pmf[idx]
+            u = torch.where(p > 0, (x - prev) / p, x - prev).clamp(0.0, 1.0)
+        else:
+            idx = torch.zeros_like(u, dtype=torch.long)
+        t = torch.sqrt(torch.clamp(1.0 - u, min=0.0))
+        a, b = 1.0 - t, t * s[:, 1].detach()
+        ti = self._triangle_info if ad else self._triangle_info.detach()
+        row = ti[idx]
+        ps = PositionSample()
+        ps.p = (Vector3fD if ad else Vector3fC)._wrap(row[:, 0:3] + a.unsqueeze(-1) * row[:, 3:6] + b.unsqueeze(-1) * row[:, 6:9])
+        ps.n = (Vector3fD if ad else Vector3fC)._wrap(row[:, 18:21])
+        ps.J = (FloatD if ad else FloatC)._wrap(row[:, 21] / row[:, 21].detach() if ad else torch.ones_like(u))
+        ps.pdf = FloatC._wrap(torch.full_like(u, self.m_inv_total_area))
+        ps.is_valid = torch.ones_like(u, dtype=torch.bool)
+        return ps
 
     def dump(self, fname):
         """OBJ writer, reference mesh.cpp:354-418 (raw vertices, 1-based faces)."""
@@ -899,6 +937,43 @@ class Scene(Object):
 
     def is_ready(self):
         return self._configured and all(m.m_ready for m in self.m_meshes)
+
+    def sample_boundary_segment_direct(self, sample3, active=True):
+        """Scene::sample_boundary_segment_direct (scene.cpp:456-492), host/torch mirror for API parity
+        (the kernels run their own copy per sample, csrc/psdr_device.h secondary_edge_sample)."""
+        tb = self._tables
+        psdr_assert(tb is not None and tb["num_sec_edges"] > 0, "Scene has no secondary edges")
+        psdr_assert(len(self.m_emitters) == 1, "host mirror supports a single emitter")
+        s = (sample3.t if isinstance(sample3, ek.ArrayBase) else torch.as_tensor(sample3, device=_dev())).to(torch.float32).detach()
+        x = s[:, 0] * tb["sec_sum"]
+        E = tb["num_sec_edges"]
+        idx = torch.searchsorted(tb["sec_cmf"], x.contiguous(), right=False).clamp(max=E - 1)
+        prev = torch.where(idx > 0, tb["sec_cmf"][(idx - 1).clamp(min=0)], torch.zeros_like(x))
+        pm = tb["sec_pmf"][idx]
+        s1 = torch.where(pm > 0, (x - prev) / pm, x - prev).clamp(0.0, 1.0) if E > 1 else s[:, 0]
+        pdf0 = (pm / tb["sec_sum"]) if E > 1 else torch.ones_like(x)
+        row = tb["sec_edge"][idx]
+        r = BoundarySegSampleDirect()
+        p0 = row[:, 3:6] * s1.unsqueeze(-1) + row[:, 0:3]
+        r.p0 = Vector3fD._wrap(p0)
+        e1 = row[:, 3:6].detach()
+        e1len = torch.sqrt((e1 * e1).sum(-1))
+        r.edge = Vector3fC._wrap(e1 / e1len.unsqueeze(-1))
+        r.edge2 = Vector3fC._wrap(row[:, 12:15].detach() - row[:, 0:3].detach())
+        pdf0 = pdf0 / e1len
+        ps = self.m_emitters[0].m_mesh.sample_position(ek.cuda.Vector2f._wrap(s[:, 1:3]))
+        r.p2, r.n = ps.p, ps.n
+        e = r.p2.t - p0.detach()
+        d2 = (e * e).sum(-1)
+        e = e / torch.sqrt(d2).unsqueeze(-1)
+        cos_t = -(r.n.t * e).sum(-1)
+        d0, d1 = (row[:, 6:9].detach() * e).sum(-1), (row[:, 9:12].detach() * e).sum(-1)
+        sg = lambda v: (v > EdgeEpsilon).to(torch.int32) - (v < -EdgeEpsilon).to(torch.int32)
+        is_b = row[:, 15].detach() != 0
+        valid = (cos_t > Epsilon) & torch.where(is_b, sg(d0) != 0, sg(d0) * sg(d1) < 0)
+        r.is_valid = valid
+        r.pdf = FloatC._wrap(torch.where(valid, pdf0 * ps.pdf.t * d2 / cos_t, torch.zeros_like(d2)))
+        return r
 
     def to_string(self):
         return "Scene[\n  # Sensors\n%s\n  # BSDFs\n%s\n  # Meshes\n%s\n]" % tuple(

@@ -167,3 +167,23 @@ def test_bitmap_eval_follows_the_reference():
     assert np.allclose(out, [0.25 * 1 + 0.25 * 2], atol=1e-6)
     c = psdr_cuda.Bitmap3fD([0.1, 0.2, 0.3])
     assert np.allclose(c.eval(Vector2fD([0.3], [0.9])).numpy(), [[0.1, 0.2, 0.3]])
+
+
+def test_mesh_sample_position_and_boundary_segment_mirror():
+    from enoki.cuda import Vector2f as Vector2fC, Vector3f as Vector3fC
+    sc, _ = load_scene("cbox_occluder", res=8, spp=1, sppe=1, sppse=1)
+    em = sc.param_map["Mesh[0]"]
+    g = torch.Generator().manual_seed(0)
+    s2 = torch.rand(4096, 2, generator=g)
+    ps = em.sample_position(Vector2fC._wrap(s2))
+    p = ps.p.numpy()
+    assert np.allclose(p[:, 1], 190.0, atol=1e-3) and p[:, 0].min() >= 10 - 1e-3 and p[:, 0].max() <= 90 + 1e-3
+    assert abs(p[:, 0].mean() - 50) < 1.5 and abs(p[:, 2].mean()) < 1.5          # uniform over the quad
+    assert np.allclose(ps.pdf.numpy(), 1 / 6400.0)
+    s3 = torch.rand(2048, 3, generator=g)
+    bs = sc.sample_boundary_segment_direct(Vector3fC._wrap(s3))
+    valid = bs.is_valid.cpu().numpy()
+    assert 0.05 < valid.mean() < 0.95 and np.all(bs.pdf.numpy()[valid] > 0) and np.all(bs.pdf.numpy()[~valid] == 0)
+    # the sampled point lies on its edge
+    tb = sc.tables(0)
+    assert bs.p0.numpy().shape == (2048, 3)
