@@ -69,6 +69,7 @@ struct LaunchCtx {
     LiParams lp;
     RngJump jump;
     int32_t off_stack;          // byte offset of the traversal stacks inside the dynamic LDS block
+    int32_t off_pathrec;        // reverse mode: per-lane (c_k, f_k) path records behind the stacks
 };
 
 // Dynamic LDS block of every kernel:  [ staged BVH nodes | staged leaf triangles | staged
@@ -381,18 +382,19 @@ __global__ __launch_bounds__(kBlock) void k_guide(LaunchCtx cx, int r0, int r1, 
 //   level 0  camera matrix: per-lane REGISTERS, wave-reduced once at kernel end
 //   level 1  primary-triangle row: summed across the wave (lanes share their pixel) by the kernel
 //   level 2  per-workgroup LDS cache (ds_add_f32) for everything hot: all texels and emitter
-//            radiances (if they fit), and "hot" triangle-row ranges = the whole table when it is
-//            small, otherwise the emitter meshes' rows (every light sample lands on them)
+//            radiances (if they fit), and the "hot" triangle rows = the whole table when it is small,
+//            otherwise the emitter meshes' rows (every light sample lands on them) plus the
+//            largest-area triangles (walls, floors: the rows most path vertices land on)
 //   level 3  hardware global_atomic_add_f32 on the gradient table for the incoherent remainder
 // The cache is flushed with one global atomic per non-zero cached word per workgroup.
 // Non-finite pieces are dropped (forward mode zeroes non-finite tangents, zero_nonfinite).
 constexpr int kSinkCacheWords = 6144;        // 24 KB of LDS next to the 40 KB of traversal stacks
-constexpr int kSinkMaxHot = 4;
 struct SinkLayout {
     int tex_off, tex_n;                      // texel cache (tex_n = 0: not cached)
     int rad_off, rad_n;
     int cam_off;                             // 16 words
-    int hot_n, hot_start[kSinkMaxHot], hot_count[kSinkMaxHot], hot_off[kSinkMaxHot];
+    int hot_off, hot_rows;                   // cached triangle rows: slot = hot_map[tri] (-1 = not cached)
+    const int32_t *hot_map, *hot_tris;       // [T] tri -> slot, [hot_rows] slot -> tri
     int total;
 };
 struct DeviceSink {
@@ -404,13 +406,9 @@ struct DeviceSink {
     __device__ __forceinline__ void glob(float *base, size_t i, float v) const { if (base != nullptr && ok(v)) atomicAdd(base + i, v); }
     __device__ __forceinline__ void add_tri(int tri, int word, float v) const {
         if (g.g_tri_info == nullptr || !ok(v)) return;
-#pragma unroll
-        for (int r = 0; r < kSinkMaxHot; ++r)
-            if (r < L.hot_n && (unsigned) (tri - L.hot_start[r]) < (unsigned) L.hot_count[r]) {
-                atomicAdd(lds + L.hot_off[r] + (tri - L.hot_start[r]) * PSDR_TRI_STRIDE + word, v);
-                return;
-            }
-        atomicAdd(g.g_tri_info + (size_t) tri * PSDR_TRI_STRIDE + word, v);
+        const int slot = L.hot_rows ? L.hot_map[tri] : -1;
+        if (slot >= 0 && slot < L.hot_rows) atomicAdd(lds + L.hot_off + slot * PSDR_TRI_STRIDE + word, v);
+        else atomicAdd(g.g_tri_info + (size_t) tri * PSDR_TRI_STRIDE + word, v);
     }
     __device__ __forceinline__ void add_texel(int idx, float v) const {
         if (g.g_texels == nullptr || !ok(v)) return;
@@ -448,15 +446,14 @@ struct DeviceSink {
             if (i >= L.cam_off && i < L.cam_off + 16) { atomicAdd(g.g_cam_to_world + (i - L.cam_off), v); continue; }
             if (L.tex_n && i >= L.tex_off && i < L.tex_off + L.tex_n) { atomicAdd(g.g_texels + (i - L.tex_off), v); continue; }
             if (L.rad_n && i >= L.rad_off && i < L.rad_off + L.rad_n) { atomicAdd(g.g_emitter_rad + (i - L.rad_off), v); continue; }
-            for (int r = 0; r < L.hot_n; ++r) {
-                const int rel = i - L.hot_off[r];
-                if (rel >= 0 && rel < L.hot_count[r] * PSDR_TRI_STRIDE) { atomicAdd(g.g_tri_info + (size_t) L.hot_start[r] * PSDR_TRI_STRIDE + rel, v); break; }
-            }
+            const int rel = i - L.hot_off;
+            if (rel >= 0 && rel < L.hot_rows * PSDR_TRI_STRIDE)
+                atomicAdd(g.g_tri_info + (size_t) L.hot_tris[rel / PSDR_TRI_STRIDE] * PSDR_TRI_STRIDE + rel % PSDR_TRI_STRIDE, v);
         }
     }
 };
 
-__global__ __launch_bounds__(kBlock) void k_camera_rev(LaunchCtx cx, DeviceSink sink, int spp, int s_begin, int nsp, long long n, float inv_spp,
+__global__ __launch_bounds__(kBlock, 2) void k_camera_rev(LaunchCtx cx, DeviceSink sink, int spp, int s_begin, int nsp, long long n, float inv_spp,
                                                        const float *__restrict__ adj_img, float *__restrict__ img,
                                                        unsigned long long *counters) {
     __shared__ float cache[kSinkCacheWords];
@@ -469,12 +466,16 @@ __global__ __launch_bounds__(kBlock) void k_camera_rev(LaunchCtx cx, DeviceSink 
         const int pixel = in ? (int) (j / nsp) : 0x7fffffff;
         float v[3] = {0.f, 0.f, 0.f};
         PrimaryGrad pg; pg.clear();
+        PathRec rec;
+#if defined(__HIP_DEVICE_COMPILE__)
+        rec.base = reinterpret_cast<float *>(psdr_dyn_lds + cx.off_pathrec) + threadIdx.x;
+#endif
         if (in) {
             const int s = s_begin + (int) (j % nsp);
             const uint64_t slot = (uint64_t) pixel * (uint64_t) spp + (uint64_t) s;
             const float *a = adj_img + (size_t) pixel * 3;
             const Vec3f adj{a[0] * inv_spp, a[1] * inv_spp, a[2] * inv_spp};
-            const Vec3f r = camera_sample_reverse(sink, pg, cx.sc, st, cx.lp, cx.jump, pixel, slot, adj, nrays);
+            const Vec3f r = camera_sample_reverse(sink, pg, rec, cx.sc, st, cx.lp, cx.jump, pixel, slot, adj, nrays);
             v[0] = r.x * inv_spp; v[1] = r.y * inv_spp; v[2] = r.z * inv_spp;
         }
         // primary-triangle row: one add per run of lanes that hit the same triangle
@@ -549,6 +550,7 @@ struct psdr_scene_s {
     int num_cus = 256;
     std::vector<int32_t> emitter_i;
     int bvh_depth = 0, num_nodes = 0, num_btris = 0;
+    int32_t *d_hot_map = nullptr, *d_hot_tris = nullptr; int hot_rows = 0; size_t hot_cap = 0;   // reverse sink: LDS-cached triangle rows
     void *d_ws = nullptr; size_t ws_bytes = 0;
     int last_path_depth = 0; float path_survival = -1.f;   // rays traced / rays of fully surviving paths (last PathTracer call)          // wavefront path-state streams + counters          // host copy of desc.emitter_i (hot-row ranges of the reverse sink)
 };
@@ -634,6 +636,8 @@ int run_camera_wavefront(psdr_scene_s *h, const psdr_render_opts *o, const TV<M>
     const size_t need = 2 * words * 4 * (size_t) cap + 256 * sizeof(int);
     if (need > h->ws_bytes) {
         if (h->d_ws) (void) hipFree(h->d_ws);
+    if (h->d_hot_map) (void) hipFree(h->d_hot_map);
+    if (h->d_hot_tris) (void) hipFree(h->d_hot_tris);
         h->d_ws = nullptr; h->ws_bytes = 0;
         HIP_TRY(hipMalloc(&h->d_ws, need));
         h->ws_bytes = need;
@@ -719,19 +723,10 @@ SinkLayout make_sink_layout(const psdr_scene_s *h, const psdr_grads *g) {
     const int nt = h->desc.num_texels, nr = h->desc.num_emitters * 3;
     if (g->g_texels && nt > 0 && nt <= 2048) { L.tex_off = off; L.tex_n = nt; off += nt; }
     if (g->g_emitter_rad && nr > 0 && nr <= 256) { L.rad_off = off; L.rad_n = nr; off += nr; }
-    if (g->g_tri_info) {
-        const int T = h->desc.num_tris;
-        if (T * PSDR_TRI_STRIDE <= kSinkCacheWords - off) {
-            L.hot_start[0] = 0; L.hot_count[0] = T; L.hot_off[0] = off; L.hot_n = 1; off += T * PSDR_TRI_STRIDE;
-        } else {
-            for (int e = 0; e < h->desc.num_emitters && L.hot_n < kSinkMaxHot; ++e) {
-                const int32_t *ei = h->emitter_i.data() + (size_t) e * PSDR_EMITTER_I_STRIDE;
-                const int cnt = ei[2];
-                if (cnt <= 0 || cnt * PSDR_TRI_STRIDE > kSinkCacheWords - off) continue;
-                const int r = L.hot_n++;
-                L.hot_start[r] = ei[1]; L.hot_count[r] = cnt; L.hot_off[r] = off; off += cnt * PSDR_TRI_STRIDE;
-            }
-        }
+    if (g->g_tri_info && h->hot_rows > 0) {
+        const int rows = std::min(h->hot_rows, (kSinkCacheWords - off) / PSDR_TRI_STRIDE);
+        // slots >= rows (cache too small for all of them) fall back to global atomics in add_tri
+        if (rows > 0) { L.hot_off = off; L.hot_rows = rows; L.hot_map = h->d_hot_map; L.hot_tris = h->d_hot_tris; off += rows * PSDR_TRI_STRIDE; }
     }
     L.total = off;
     return L;
@@ -773,6 +768,8 @@ int psdr_scene_destroy(psdr_scene_t h) {
     if (h->d_btris) (void) hipFree(h->d_btris);
     if (h->d_counters) (void) hipFree(h->d_counters);
     if (h->d_ws) (void) hipFree(h->d_ws);
+    if (h->d_hot_map) (void) hipFree(h->d_hot_map);
+    if (h->d_hot_tris) (void) hipFree(h->d_hot_tris);
     delete h;
     return 0;
 }
@@ -813,6 +810,31 @@ int psdr_bvh_build(psdr_scene_t h, void *stream) {
     if (!b.nodes.empty()) HIP_TRY(hipMemcpyAsync(h->d_nodes, b.nodes.data(), b.nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(h->d_btris, b.btris.data(), b.btris.size() * sizeof(float4), hipMemcpyHostToDevice, s));
     HIP_TRY(hipStreamSynchronize(s));     // host vectors die at return
+    {   // hot rows of the reverse-mode gradient cache: emitter triangles first, then by decreasing area
+        constexpr int kMaxHotRows = 200;
+        std::vector<int32_t> map((size_t) T, -1), tris;
+        auto add = [&](int t) { if (t >= 0 && t < T && map[t] < 0 && (int) tris.size() < kMaxHotRows) { map[t] = (int32_t) tris.size(); tris.push_back(t); } };
+        for (int e = 0; e < h->desc.num_emitters; ++e) {
+            const int32_t *ei = h->emitter_i.data() + (size_t) e * PSDR_EMITTER_I_STRIDE;
+            for (int f = 0; f < ei[2] && f < 64; ++f) add(ei[1] + f);
+        }
+        std::vector<int> by_area((size_t) T);
+        for (int i = 0; i < T; ++i) by_area[i] = i;
+        const int top = std::min(T, kMaxHotRows);
+        std::partial_sort(by_area.begin(), by_area.begin() + top, by_area.end(),
+                          [&](int a, int c) { return rows[(size_t) a * PSDR_TRI_STRIDE + 21] > rows[(size_t) c * PSDR_TRI_STRIDE + 21]; });
+        for (int i = 0; i < top; ++i) add(by_area[i]);
+        if ((size_t) T > h->hot_cap) {
+            if (h->d_hot_map) (void) hipFree(h->d_hot_map);
+            if (h->d_hot_tris) (void) hipFree(h->d_hot_tris);
+            h->hot_cap = (size_t) T;
+            HIP_TRY(hipMalloc(&h->d_hot_map, h->hot_cap * sizeof(int32_t)));
+            HIP_TRY(hipMalloc(&h->d_hot_tris, kMaxHotRows * sizeof(int32_t)));
+        }
+        HIP_TRY(hipMemcpy(h->d_hot_map, map.data(), map.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(h->d_hot_tris, tris.data(), tris.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        h->hot_rows = (int) tris.size();
+    }
     h->root = root;
     h->bvh_depth = b.max_depth; h->num_nodes = (int) b.nodes.size(); h->num_btris = (int) b.btris.size() / 3;
     h->have_bvh = true;
@@ -878,7 +900,11 @@ int psdr_render_d_rev(psdr_scene_t h, const psdr_render_opts *o, const float *ad
         if (int rc = make_ctx(h, o, 0, cx)) return rc;
         const long long n = WH * nsp;
         h->slots[0] += (uint64_t) n;
-        hipLaunchKernelGGL(k_camera_rev, dim3(launch_blocks(h, n)), dim3(kBlock), lds_bytes(cx, h), s, cx, sink, o->spp, o->spp_begin, nsp, n,
+        const int depth = o->integrator == PSDR_INTEGRATOR_PATH ? std::min(o->max_depth, kMaxRevDepth) : 1;
+        const int rec_bytes = depth * 6 * kBlock * 4;
+        plan_lds(h, cx, rec_bytes + kSinkCacheWords * 4);          // stage less of the scene: the record + cache live in LDS too
+        cx.off_pathrec = lds_bytes(cx, h);
+        hipLaunchKernelGGL(k_camera_rev, dim3(launch_blocks(h, n)), dim3(kBlock), lds_bytes(cx, h) + rec_bytes, s, cx, sink, o->spp, o->spp_begin, nsp, n,
                            1.f / (float) o->spp, adj_img, out_img, h->d_counters);
         HIP_TRY(hipGetLastError());
     }

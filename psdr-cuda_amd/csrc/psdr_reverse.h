@@ -466,6 +466,24 @@ struct NullSink {
 
 constexpr int kMaxRevDepth = 8;
 
+// Per-lane record of (c_k, f_k) along the path (6 floats per vertex).  On the device it lives in LDS
+// (one column per lane) -- a register array indexed by the run-time vertex number would be demoted to
+// scratch, and the scratch of all resident waves (hundreds of MB) thrashes the caches.
+struct PathRec {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float *base;   // &lds[threadIdx.x], stride kBlock
+    __device__ __forceinline__ void put(int k, int c, float v) { base[(k * 6 + c) * kBlock] = v; }
+    __device__ __forceinline__ float get(int k, int c) const { return base[(k * 6 + c) * kBlock]; }
+#else
+    float a[kMaxRevDepth * 6];
+    void put(int k, int c, float v) { a[k * 6 + c] = v; }
+    float get(int k, int c) const { return a[k * 6 + c]; }
+#endif
+    PSDR_HD void put_cf(int k, const Vec3f &c, const Vec3f &f) { put(k, 0, c.x); put(k, 1, c.y); put(k, 2, c.z); put(k, 3, f.x); put(k, 4, f.y); put(k, 5, f.z); }
+    PSDR_HD Vec3f c(int k) const { return {get(k, 0), get(k, 1), get(k, 2)}; }
+    PSDR_HD Vec3f f(int k) const { return {get(k, 3), get(k, 4), get(k, 5)}; }
+};
+
 // Gradient of the PRIMARY triangle row of one camera sample (p0 e1 e2 n0 n1 n2 fn = words 0..20).
 // Lanes of a wave share their pixel, hence almost always their primary triangle: the kernel sums
 // these rows across the wave (segmented by triangle id) before touching memory.
@@ -515,7 +533,7 @@ template <class Sink> PSDR_HD Vec3f path_vertex_backward(Sink &sink, const Scene
 // One camera sample in reverse mode (Integrator::__render<true> + enoki.backward).
 //   adj = dLoss/d(pixel) / spp.   Returns the primal sample value.
 template <class RealSink>
-PSDR_HD Vec3f camera_sample_reverse(RealSink &real_sink, PrimaryGrad &pg, const SceneView &sc, TraversalStack &st, const LiParams &lp,
+PSDR_HD Vec3f camera_sample_reverse(RealSink &real_sink, PrimaryGrad &pg, PathRec &rec, const SceneView &sc, TraversalStack &st, const LiParams &lp,
                                     const RngJump &jump, int pixel, uint64_t slot, const Vec3f &adj, uint32_t &nrays) {
     pg.clear();
     PrimarySink<RealSink> sink(real_sink, pg);
@@ -582,7 +600,6 @@ PSDR_HD Vec3f camera_sample_reverse(RealSink &real_sink, PrimaryGrad &pg, const 
     if (le0) { const float *r = sc.d.emitter_f + (size_t) e0 * PSDR_EMITTER_F_STRIDE; result = Vec3f{r[0], r[1], r[2]}; }
 
     // ---- sweep 1 (values): record (c_k, f_k), build the suffix radiances T_k
-    Vec3f ck[kMaxRevDepth], fk[kMaxRevDepth];
     int nv = 0;
     {
         NullSink ns; VertexAdj dummy; dummy.clear();
@@ -591,7 +608,7 @@ PSDR_HD Vec3f camera_sample_reverse(RealSink &real_sink, PrimaryGrad &pg, const 
         Vec3f beta(1.f);
         for (int k = 0; k < depth; ++k) {
             const VertexOut vo = vertex_eval<false>(ns, sc, st, r1, cur, nB, nL, Vec3f(0.f), Vec3f(0.f), dummy, nrays);
-            ck[k] = vo.c; fk[k] = vo.f; nv = k + 1;
+            rec.put_cf(k, vo.c, vo.f); nv = k + 1;
             result = result + beta * vo.c;
             if (!vo.next_valid) break;
             beta = beta * vo.f; cur = vo.next;
@@ -601,9 +618,11 @@ PSDR_HD Vec3f camera_sample_reverse(RealSink &real_sink, PrimaryGrad &pg, const 
     // masked(value, ~isfinite(value)) = 0 (integrator.cpp:87): a zeroed sample has no gradient either
     if (!(isfinite(result.x) && isfinite(result.y) && isfinite(result.z))) return zero_nonfinite(result);
     if (le0) { sink.add_rad(e0, 0, adj.x); sink.add_rad(e0, 1, adj.y); sink.add_rad(e0, 2, adj.z); }
-    Vec3f Tk[kMaxRevDepth + 1];
-    Tk[nv] = Vec3f(0.f);
-    for (int k = nv - 1; k >= 0; --k) Tk[k] = ck[k] + fk[k] * Tk[k + 1];
+    // suffix radiances T_{k+1} overwrite c_k in place (T_nv = 0): afterwards rec.c(k) == T_{k+1}
+    {
+        Vec3f T(0.f);
+        for (int k = nv - 1; k >= 0; --k) { const Vec3f Tk = rec.c(k) + rec.f(k) * T; rec.put(k, 0, T.x); rec.put(k, 1, T.y); rec.put(k, 2, T.z); T = Tk; }
+    }
 
     // ---- sweep 2: replay the same random numbers, differentiate vertex by vertex
     {
@@ -612,7 +631,7 @@ PSDR_HD Vec3f camera_sample_reverse(RealSink &real_sink, PrimaryGrad &pg, const 
         Its<float> prev = its;       // vertex k-1
         for (int k = 0; k < nv; ++k) {
             const Vec3f a_c = adj * beta;
-            const Vec3f a_f = (k + 1 < nv) ? a_c * Tk[k + 1] : Vec3f(0.f);
+            const Vec3f a_f = (k + 1 < nv) ? a_c * rec.c(k) : Vec3f(0.f);
             VertexAdj va; va.clear();
             const VertexOut vo = vertex_eval<true, Sink>(sink, sc, st, rng, cur, nB, nL, a_c, a_f, k == 0 ? va0 : va, nrays);
             if (k >= 1) {

@@ -184,8 +184,8 @@ extern "C" int hostcheck_render_rev(const psdr_scene_desc *d, const psdr_render_
             const int pixel = (int) (j / nsp), s = o->spp_begin + (int) (j % nsp);
             const float inv = 1.f / o->spp;
             const Vec3f a{adj[pixel * 3] * inv, adj[pixel * 3 + 1] * inv, adj[pixel * 3 + 2] * inv};
-            PrimaryGrad pg;
-            const Vec3f r = camera_sample_reverse(sink, pg, hs.sc, st, lp, jump, pixel, (uint64_t) pixel * o->spp + s, a, nr);
+            PrimaryGrad pg; PathRec rec;
+            const Vec3f r = camera_sample_reverse(sink, pg, rec, hs.sc, st, lp, jump, pixel, (uint64_t) pixel * o->spp + s, a, nr);
             if (pg.tri >= 0) for (int w = 0; w < kPrimaryWords; ++w) sink.add_tri(pg.tri, w, pg.w[w]);
             acc[pixel * 3] += r.x * inv; acc[pixel * 3 + 1] += r.y * inv; acc[pixel * 3 + 2] += r.z * inv;
         }
