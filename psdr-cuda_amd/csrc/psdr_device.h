@@ -598,14 +598,17 @@ PSDR_HD Vec3<M> direct_step(const SceneView &sc, const TVT &tv, TraversalStack &
 
 // DirectIntegrator::__Li (direct.cpp:47-163); FieldExtractionIntegrator::__Li (field.cpp:34-54);
 // PathTracer = iterated direct step (no reference implementation; depth 1 == DirectIntegrator(1,1)).
-template <class G, class M, class TVT>
+template <class G, class M, int INTEG = -1, class TVT>
 PSDR_HD Vec3<M> Li(const SceneView &sc, const TVT &tv, TraversalStack &st, const LiParams &lp, Rng &rng, const RayT<G> &ray, bool active,
                    uint32_t &nrays) {
+    // INTEG >= 0: integrator fixed at compile time (the camera kernels are specialised per integrator so
+    // the other integrators' code does not occupy registers / instruction cache); -1: run-time switch
+    const int integ = INTEG >= 0 ? INTEG : lp.integrator;
     // renderD traces its primary ray in the solid-angle form (scene.cpp:355-376) also when only
     // material parameters are differentiated: p = o + t d, (u,v,t) from Moeller-Trumbore
     Its<G> its = intersect<G>(sc, tv, st, ray, active, is_ad<M>() ? kSolidAngle : kDetached, nrays);
     active = active && its.valid;
-    if (lp.integrator == PSDR_INTEGRATOR_FIELD) {
+    if (integ == PSDR_INTEGRATOR_FIELD) {
         if (!active) return zero3<M>();
         switch (lp.field) {
             case PSDR_FIELD_SILHOUETTE: return Vec3<M>(1.f);
@@ -617,7 +620,7 @@ PSDR_HD Vec3<M> Li(const SceneView &sc, const TVT &tv, TraversalStack &st, const
         }
     }
     Vec3<M> result = lp.hide_emitters ? zero3<M>() : Le<M>(sc, tv, its, active);
-    if (lp.integrator == PSDR_INTEGRATOR_DIRECT)
+    if (integ == PSDR_INTEGRATOR_DIRECT)
         return result + direct_step<G, M>(sc, tv, st, rng, its, active, lp.bsdf_samples, lp.light_samples, nrays, nullptr, nullptr, nullptr);
     Vec3<M> beta(1.f);
     for (int depth = 0; depth < lp.max_depth; ++depth) {
@@ -679,7 +682,7 @@ PSDR_HD Vec3<M> wavefront_bounce_vertex(const SceneView &sc, const TVT &tv, Trav
 }
 
 // One camera sample slot: Integrator::__render (src/integrator/integrator.cpp:64-95), before the splat
-template <class G, class M, class TVT>
+template <class G, class M, int INTEG = -1, class TVT>
 PSDR_HD Vec3<M> camera_sample(const SceneView &sc, const TVT &tv, TraversalStack &st, const LiParams &lp, const RngJump &jump,
                               int pixel, uint64_t slot, uint32_t &nrays) {
     Rng rng; rng.init(slot, jump);
@@ -688,7 +691,7 @@ PSDR_HD Vec3<M> camera_sample(const SceneView &sc, const TVT &tv, TraversalStack
     const int px = pixel % W, py = pixel / W;
     const float sx = ((float) px + j0) / (float) W, sy = ((float) py + j1) / (float) sc.d.height;
     const RayT<G> ray = primary_ray<G>(sc, tv, sx, sy);
-    return zero_nonfinite(Li<G, M>(sc, tv, st, lp, rng, ray, true, nrays));
+    return zero_nonfinite(Li<G, M, INTEG>(sc, tv, st, lp, rng, ray, true, nrays));
 }
 
 // One primary-edge slot: Integrator::render_primary_edges (integrator.cpp:98-119) +

@@ -118,13 +118,13 @@ __global__ __launch_bounds__(kBlock) void k_trace(LaunchCtx cx, int m, const flo
 #define PSDR_WAVES_C 4
 #endif
 #ifndef PSDR_WAVES_DM
-#define PSDR_WAVES_DM 2
+#define PSDR_WAVES_DM 3
 #endif
 #ifndef PSDR_WAVES_DG
 #define PSDR_WAVES_DG 2
 #endif
 template <class G, class R> constexpr int camera_waves() { return !is_ad<R>() ? PSDR_WAVES_C : (is_ad<G>() ? PSDR_WAVES_DG : PSDR_WAVES_DM); }
-template <class G, class R>
+template <class G, class R, int INTEG>
 __global__ __launch_bounds__(kBlock, (camera_waves<G, R>())) void k_camera(LaunchCtx cx, TV<R> tv, int spp, int s_begin, int nsp, long long n, float inv_spp,
                                                    float *__restrict__ img, float *__restrict__ dimg, long long plane,
                                                    unsigned long long *counters) {
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(kBlock, (camera_waves<G, R>())) void k_camera(Launc
         if (in) {
             const int s = s_begin + (int) (j % nsp);
             const uint64_t slot = (uint64_t) pixel * (uint64_t) spp + (uint64_t) s;
-            const Vec3<R> r = camera_sample<G, R>(cx.sc, tv, st, cx.lp, cx.jump, pixel, slot, nrays);
+            const Vec3<R> r = camera_sample<G, R, INTEG>(cx.sc, tv, st, cx.lp, cx.jump, pixel, slot, nrays);
             v[0] = val(r.x) * inv_spp; v[1] = val(r.y) * inv_spp; v[2] = val(r.z) * inv_spp;
 #pragma unroll
             for (int k = 0; k < K; ++k) {
@@ -614,8 +614,16 @@ int run_camera(psdr_scene_s *h, const psdr_render_opts *o, const TV<R> &tv, floa
     if (int rc = make_ctx(h, o, 0, cx)) return rc;
     const long long n = WH * nsp;
     h->slots[0] += (uint64_t) n;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_camera<G, R>), dim3(launch_blocks(h, n)), dim3(kBlock), lds_bytes(cx, h), s, cx, tv, o->spp, o->spp_begin, nsp, n,
-                       1.f / (float) o->spp, img, dimg, WH * 3, h->d_counters);
+#define PSDR_LAUNCH_CAMERA(INTEG)                                                                                                  \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_camera<G, R, INTEG>), dim3(launch_blocks(h, n)), dim3(kBlock), lds_bytes(cx, h), s, cx, tv, o->spp, \
+                       o->spp_begin, nsp, n, 1.f / (float) o->spp, img, dimg, WH * 3, h->d_counters)
+    switch (o->integrator) {
+        case PSDR_INTEGRATOR_DIRECT: PSDR_LAUNCH_CAMERA(PSDR_INTEGRATOR_DIRECT); break;
+        case PSDR_INTEGRATOR_PATH: PSDR_LAUNCH_CAMERA(PSDR_INTEGRATOR_PATH); break;
+        case PSDR_INTEGRATOR_FIELD: PSDR_LAUNCH_CAMERA(PSDR_INTEGRATOR_FIELD); break;
+        default: return fail("Unknown integrator");
+    }
+#undef PSDR_LAUNCH_CAMERA
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -636,8 +644,6 @@ int run_camera_wavefront(psdr_scene_s *h, const psdr_render_opts *o, const TV<M>
     const size_t need = 2 * words * 4 * (size_t) cap + 256 * sizeof(int);
     if (need > h->ws_bytes) {
         if (h->d_ws) (void) hipFree(h->d_ws);
-    if (h->d_hot_map) (void) hipFree(h->d_hot_map);
-    if (h->d_hot_tris) (void) hipFree(h->d_hot_tris);
         h->d_ws = nullptr; h->ws_bytes = 0;
         HIP_TRY(hipMalloc(&h->d_ws, need));
         h->ws_bytes = need;
