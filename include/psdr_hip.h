@@ -48,6 +48,8 @@ extern "C" {
                                    (src/emitter/area.cpp:10-62, src/shape/mesh.cpp:239-249) */
 #define PSDR_EMITTER_I_STRIDE 4 /* mesh id, first global tri id, num faces, offset into face_cmf/pmf */
 #define PSDR_CAM_WORDS    64 /* see below */
+#define PSDR_ENV_WORDS    32 /* EnvironmentMap record (src/emitter/envmap.cpp:10-143,
+                                include/psdr/emitter/envmap.h:38-46), see PSDR_ENV_* below */
 
 /* tri_mesh[t] = mesh id | PSDR_TRI_FACE_NORMALS if the mesh uses face normals
    (scene.cpp:205-216 m_triangle_face_normals) */
@@ -71,6 +73,15 @@ extern "C" {
 #define PSDR_CAM_DIR              51
 #define PSDR_CAM_INV_AREA         54
 
+/* env_f[] layout (EnvironmentMap): m_from_world and m_to_world as row-major 3x3 blocks (only
+   transform_dir is ever applied, include/psdr/core/transform.h:91-94), m_scale, and the
+   scene AABB the sampled directions are projected on (m_lower / m_upper, scene.cpp:135-141) */
+#define PSDR_ENV_FROM_WORLD  0
+#define PSDR_ENV_TO_WORLD    9
+#define PSDR_ENV_SCALE      18
+#define PSDR_ENV_LOWER      19
+#define PSDR_ENV_UPPER      22
+
 /* integrators (src/psdr.cpp:282-294; PathTracer is build-defined) */
 #define PSDR_INTEGRATOR_DIRECT 0
 #define PSDR_INTEGRATOR_PATH   1
@@ -93,7 +104,8 @@ typedef struct psdr_scene_desc {
     const float   *tri_info;             /* [T][PSDR_TRI_STRIDE]   scene.cpp:205-216 */
     const float   *tri_uv;               /* [T][PSDR_TRIUV_STRIDE] or NULL (all zero) */
     const int32_t *tri_mesh;             /* [T] */
-    const int32_t *mesh_bsdf;            /* [M] bsdf id (Mesh::m_bsdf) */
+    const int32_t *mesh_bsdf;            /* [M] bsdf id (Mesh::m_bsdf); -1 = the bounding mesh of the
+                                            environment map (scene.cpp:135-172, bsdf == nullptr) */
     const int32_t *mesh_emitter;         /* [M] emitter id or -1 (Mesh::m_emitter) */
     const int32_t *bsdf_rec;             /* [Nb][PSDR_BSDF_STRIDE] */
     const float   *texels;               /* pool of Bitmap data; 3-ch textures interleaved RGB */
@@ -112,6 +124,15 @@ typedef struct psdr_scene_desc {
     int32_t        guide_reso[3];        /* HyperCubeDistribution3f, src/core/cube_distrb.cpp */
     const float   *guide_cmf, *guide_pmf;/* [num_guide_cells] or NULL (no guiding) */
     float          guide_sum;
+    /* EnvironmentMap (at most one, scene_loader.cpp:294-311): env_emitter = its index in the emitter
+       tables or -1; its emitter_i row names the bounding mesh (scene.cpp:135-172).  The lat-long
+       radiance bitmap lives in the texel pool (so d_texels / g_texels cover it). */
+    int32_t        env_emitter;
+    int32_t        env_tex[3];           /* texel offset, width, height of m_radiance */
+    int32_t        env_reso[2];          /* m_cell_distrb resolution ((w-1)*2, (h-1)*2), envmap.cpp:14-15 */
+    const float   *env_f;                /* [PSDR_ENV_WORDS] */
+    const float   *env_cmf, *env_pmf;    /* [env_reso[0]*env_reso[1]] luminance*sin(theta), envmap.cpp:17-21 */
+    float          env_sum;
 } psdr_scene_desc;
 
 /* psdr_render_opts.flags: execution strategy of the PathTracer interior term.
@@ -147,6 +168,7 @@ typedef struct psdr_tangents {
     const float *d_cam_to_world;         /* [16] row-major */
     const float *d_sec_edge;             /* [E][PSDR_SEDGE_STRIDE] (p0, e1 used... all 15) */
     const float *d_prim_edge;            /* [Ep][PSDR_PEDGE_STRIDE] (p0, p1 used) */
+    const float *d_env_f;                /* [PSDR_ENV_WORDS] (from_world and scale used) */
 } psdr_tangents;
 
 /* Reverse-mode gradient tables (accumulated with +=); NULL = not wanted. */
@@ -157,6 +179,7 @@ typedef struct psdr_grads {
     float *g_cam_to_world;
     float *g_sec_edge;
     float *g_prim_edge;
+    float *g_env_f;
 } psdr_grads;
 
 typedef struct psdr_scene_s *psdr_scene_t;

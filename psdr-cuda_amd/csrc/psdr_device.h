@@ -41,8 +41,14 @@ struct SceneView {
 extern __shared__ __attribute__((aligned(16))) unsigned char psdr_dyn_lds[];
 #endif
 
-// K sets of forward-mode tangent tables (struct of K pointer groups)
-template <int K> struct TangentView { psdr_tangents t[K > 0 ? K : 1]; };
+// K sets of forward-mode tangent tables (struct of K pointer groups).  ENV: the scene has an
+// EnvironmentMap -- a compile-time property of the kernel instance, carried by the type every estimator
+// already receives, so that scenes without one (the common case) do not pay registers for the
+// lat-long lookup / cell sampling code (C2 renderD K=3: 5.3 ms without, 7.1 ms with a run-time branch).
+template <int K, bool ENV = false> struct TangentView {
+    static constexpr bool has_env = ENV;
+    psdr_tangents t[K > 0 ? K : 1];
+};
 
 struct Hit { int tri; float u, v, t; };
 
@@ -143,17 +149,17 @@ PSDR_HD Hit closest_hit(const SceneView &sc, TraversalStack &st, const Vec3f &o,
 // the geometry then stays in plain fp32 registers.
 template <class R> struct Loader;
 template <> struct Loader<float> {
-    template <int KK> static PSDR_HD float f(const float *tab, const TangentView<KK> &, const float *const psdr_tangents::*, size_t i) { return tab[i]; }
+    template <int KK, bool E> static PSDR_HD float f(const float *tab, const TangentView<KK, E> &, const float *const psdr_tangents::*, size_t i) { return tab[i]; }
 };
 template <int K> struct Loader<Dual<K>> {
-    static PSDR_HD Dual<K> f(const float *tab, const TangentView<K> &tv, const float *const psdr_tangents::*m, size_t i) {
+    template <bool E> static PSDR_HD Dual<K> f(const float *tab, const TangentView<K, E> &tv, const float *const psdr_tangents::*m, size_t i) {
         Dual<K> r; r.v = tab[i];
 #pragma unroll
         for (int k = 0; k < K; ++k) { const float *p = tv.t[k].*m; r.d[k] = p ? p[i] : 0.f; }
         return r;
     }
 };
-template <class R> using TV = TangentView<ad_traits<R>::K>;
+template <class R, bool ENV = false> using TV = TangentView<ad_traits<R>::K, ENV>;
 template <class R, class TVT> PSDR_HD R ldf(const float *tab, const TVT &tv, const float *const psdr_tangents::*m, size_t i) {
     return Loader<R>::f(tab, tv, m, i);
 }
@@ -306,18 +312,11 @@ template <class M, class TVT> PSDR_HD Vec3<M> radiance(const SceneView &sc, cons
     }
     return r;
 }
-// Intersection::Le -> AreaLight::eval (src/emitter/area.cpp:20-29)
-template <class M, class G, class TVT> PSDR_HD Vec3<M> Le(const SceneView &sc, const TVT &tv, const Its<G> &its, bool active) {
-    const int e = active ? emitter_of(sc, its) : -1;
-    if (e < 0 || !(val(its.wi.z) > 0.f)) return zero3<M>();
-    return radiance<M>(sc, tv, e);
-}
-
 // ------------------------------------------------------------------------------ BSDF
 // Bitmap<c>::eval (src/core/bitmap.cpp:41-89); 3-channel textures are stored interleaved RGB.
 // U = type of the texture coordinates (geometry), M = type of the texels.
 template <class M, int C, class U, class TVT>
-PSDR_HD void bitmap_eval(const SceneView &sc, const TVT &tv, const int32_t *slot, U u, U v, M *out) {
+PSDR_HD void bitmap_eval(const SceneView &sc, const TVT &tv, const int32_t *slot, U u, U v, M *out, bool flip_v = true) {
     const int off = slot[0], w = slot[1], h = slot[2];
     const float *tx = sc.d.texels;
     constexpr auto m = &psdr_tangents::d_texels;
@@ -326,7 +325,7 @@ PSDR_HD void bitmap_eval(const SceneView &sc, const TVT &tv, const int32_t *slot
         for (int c = 0; c < C; ++c) out[c] = ldf<M>(tx, tv, m, off + c);
         return;
     }
-    v = -v;
+    if (flip_v) v = -v;
     u = u - floorf(val(u)); v = v - floorf(val(v));
     u = u * (float) (w - 1); v = v * (float) (h - 1);
     int px = (int) floorf(val(u)), py = (int) floorf(val(v));
@@ -341,6 +340,36 @@ PSDR_HD void bitmap_eval(const SceneView &sc, const TVT &tv, const int32_t *slot
         out[c] = (v00 * w0x + v10 * w1x) * w0y + (v01 * w0x + v11 * w1x) * w1y;
     }
 }
+
+// ------------------------------------------------------------------- environment map
+constexpr float kInvTwoPi = 0.15915494309189533577f;
+// EnvironmentMap::eval_direction (src/emitter/envmap.cpp:41-59): lat-long lookup along the world
+// direction w.  Tangents: the direction (geometry), m_from_world / m_scale (d_env_f), the texels.
+template <class M, class G, class TVT> PSDR_HD Vec3<M> env_eval_direction(const SceneView &sc, const TVT &tv, const Vec3<G> &w) {
+    const float *f = sc.d.env_f;
+    constexpr auto m = &psdr_tangents::d_env_f;
+    const Vec3<M> wm = to_m3<M>(w);
+    auto row = [&](int r) {
+        return ldf<M>(f, tv, m, PSDR_ENV_FROM_WORLD + r * 3) * wm.x + ldf<M>(f, tv, m, PSDR_ENV_FROM_WORLD + r * 3 + 1) * wm.y +
+               ldf<M>(f, tv, m, PSDR_ENV_FROM_WORLD + r * 3 + 2) * wm.z;
+    };
+    const M vx = row(0), vy = row(1), vz = row(2);
+    M u = atan2_(vx, -vz) * kInvTwoPi, v = safe_acos_(vy) * kInvPi;
+    u = u - floorf(val(u)); v = v - floorf(val(v));
+    M rgb[3];
+    bitmap_eval<M, 3>(sc, tv, sc.d.env_tex, u, v, rgb, false);
+    const M scale = ldf<M>(f, tv, m, PSDR_ENV_SCALE);
+    return {rgb[0] * scale, rgb[1] * scale, rgb[2] * scale};
+}
+// Intersection::Le -> AreaLight::eval (src/emitter/area.cpp:20-29) / EnvironmentMap::eval (envmap.cpp:29-38)
+template <class M, class G, class TVT> PSDR_HD Vec3<M> Le(const SceneView &sc, const TVT &tv, const Its<G> &its, bool active) {
+    const int e = active ? emitter_of(sc, its) : -1;
+    if (e < 0) return zero3<M>();
+    if (TVT::has_env && e == sc.d.env_emitter) return env_eval_direction<M>(sc, tv, -its.sh.to_world(its.wi));
+    if (!(val(its.wi.z) > 0.f)) return zero3<M>();
+    return radiance<M>(sc, tv, e);
+}
+
 
 // GGXDistribution (src/bsdf/ggx.cpp:9-106)
 template <class R> struct GGX {
@@ -457,12 +486,84 @@ template <class G, class M> struct Bsdf {
 // -------------------------------------------------------------------------- emitters
 template <class R> struct PosSample { Vec3<R> p, n; R J; float pdf; bool valid; };
 
+// HyperCubeDistribution<2>::sample_reuse / pdf (src/core/cube_distrb.cpp:42-62) of the env-map cells;
+// cell (x, y) has index x * reso[1] + y (cube_distrb.cpp:19-26)
+PSDR_HD float env_cells_sample_reuse(const SceneView &sc, float &u0, float &u1) {
+    const int r0 = sc.d.env_reso[0], r1 = sc.d.env_reso[1], n = r0 * r1;
+    float pmf;
+    const int idx = sample_reuse(sc.d.env_cmf, sc.d.env_pmf, sc.d.env_sum, n, u1, pmf);
+    const int c0 = idx / r1, c1 = idx - c0 * r1;
+    u0 = (u0 + (float) c0) * (1.f / (float) r0);
+    u1 = (u1 + (float) c1) * (1.f / (float) r1);
+    return pmf * (float) n;
+}
+PSDR_HD float env_cells_pdf(const SceneView &sc, float u0, float u1) {
+    const int r0 = sc.d.env_reso[0], r1 = sc.d.env_reso[1];
+    const int i0 = (int) floorf(u0 * (float) r0), i1 = (int) floorf(u1 * (float) r1);
+    if (!(i0 >= 0 && i0 < r0 && i1 >= 0 && i1 < r1)) return 0.f;
+    return sc.d.env_pmf[i0 * r1 + i1] / sc.d.env_sum * (float) (r0 * r1);
+}
+PSDR_HD Vec3f env_mul3(const float *m, const Vec3f &v) {      // transform_dir, transform.h:91-94
+    return {m[0] * v.x + m[1] * v.y + m[2] * v.z, m[3] * v.x + m[4] * v.y + m[5] * v.z, m[6] * v.x + m[7] * v.y + m[8] * v.z};
+}
+// EnvironmentMap::__sample_position (envmap.cpp:72-95): direction from the luminance cells
+// (sample_direction, :98-111), projected on the scene AABB (ray_intersect_scene_aabb, utils.h:128-145).
+// Everything is detached in the reference, J = 1.
+template <class R> PSDR_HD PosSample<R> env_sample_position(const SceneView &sc, const Vec3f &ref_p, float s0, float s1) {
+    const float *f = sc.d.env_f;
+    float pdf = env_cells_sample_reuse(sc, s0, s1);
+    const float theta = s1 * kPi, phi = s0 * (2.f * kPi);
+    float st, ct, sp, cp;
+    sincosf(theta, &st, &ct); sincosf(phi, &sp, &cp);
+    Vec3f d{sp * st, ct, -cp * st};                          // sphdir(theta, phi) -> (y, z, -x)
+    const float inv_sin_theta = 1.f / sqrtf(fmaxf(d.x * d.x + d.z * d.z, kEpsilon * kEpsilon));
+    if (pdf > kEpsilon) pdf *= inv_sin_theta * (.5f / (kPi * kPi));
+    d = env_mul3(f + PSDR_ENV_TO_WORLD, d);
+    const float o[3] = {ref_p.x, ref_p.y, ref_p.z}, dd[3] = {d.x, d.y, d.z};
+    float t = 0.f; int ax = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float t1 = (f[PSDR_ENV_LOWER + i] - o[i]) / dd[i], t2 = (f[PSDR_ENV_UPPER + i] - o[i]) / dd[i];
+        const float tp = fmaxf(t1, t2);
+        if (i == 0 || tp < t) { t = tp; ax = i; }
+    }
+    float n[3] = {0.f, 0.f, 0.f};
+    n[ax] = -copysignf(1.f, dd[ax]);
+    const float Gv = -(n[0] * d.x + n[1] * d.y + n[2] * d.z) / (t * t);
+    PosSample<R> ps;
+    ps.p = lift<R>(Vec3f{d.x * t + ref_p.x, d.y * t + ref_p.y, d.z * t + ref_p.z});
+    ps.n = lift<R>(Vec3f{n[0], n[1], n[2]});
+    ps.J = R(1.f);
+    ps.pdf = pdf * Gv;
+    ps.valid = true;
+    return ps;
+}
+// EnvironmentMap::__sample_position_pdf (envmap.cpp:124-143), detached
+PSDR_HD float env_position_pdf(const SceneView &sc, const Vec3f &ref_p, const Vec3f &p, const Vec3f &n) {
+    const float *f = sc.d.env_f;
+    Vec3f d = p - ref_p;
+    const float dist2 = dot(d, d);
+    d = d / sqrtf(fmaxf(dist2, 0.f));
+    const float Gv = fabsf(dot(d, n)) / dist2;
+    d = env_mul3(f + PSDR_ENV_FROM_WORLD, d);
+    const float factor = Gv * (1.f / sqrtf(fmaxf(d.x * d.x + d.z * d.z, kEpsilon * kEpsilon))) * (.5f / (kPi * kPi));
+    float u = atan2f(d.x, -d.z) * kInvTwoPi, v = safe_acos_(d.y) * kInvPi;
+    u -= floorf(u); v -= floorf(v);
+    return env_cells_pdf(sc, u, v) * factor;
+}
+
 // Scene::sample_emitter_position (scene.cpp:427-447) -> AreaLight::sample_position (area.cpp:32-46)
-// -> Mesh::__sample_position (mesh.cpp:306-330)
-template <class R, class TVT> PSDR_HD PosSample<R> sample_emitter_position(const SceneView &sc, const TVT &tv, float s0, float s1, bool with_J) {
+// -> Mesh::__sample_position (mesh.cpp:306-330), or EnvironmentMap::sample_position
+template <class R, class TVT>
+PSDR_HD PosSample<R> sample_emitter_position(const SceneView &sc, const TVT &tv, const Vec3f &ref_p, float s0, float s1, bool with_J) {
     PosSample<R> ps;
     int e = 0; float epdf = 1.f;
     if (sc.d.num_emitters > 1) e = sample_reuse(sc.d.emitter_cmf, sc.d.emitter_pmf, sc.d.emitter_sum, sc.d.num_emitters, s1, epdf);
+    if (TVT::has_env && e == sc.d.env_emitter) {
+        ps = env_sample_position<R>(sc, ref_p, s0, s1);
+        ps.pdf *= epdf;
+        return ps;
+    }
     const float *ef = sc.d.emitter_f + (size_t) e * PSDR_EMITTER_F_STRIDE;
     const int32_t *ei = sc.d.emitter_i + (size_t) e * PSDR_EMITTER_I_STRIDE;
     float fp;
@@ -477,10 +578,11 @@ template <class R, class TVT> PSDR_HD PosSample<R> sample_emitter_position(const
     ps.valid = true;
     return ps;
 }
-// Scene::emitter_position_pdf (scene.cpp:451-453) -> area.cpp:60-62 -> mesh.cpp:333-342
-template <class R> PSDR_HD float emitter_position_pdf(const SceneView &sc, const Its<R> &its) {
+// Scene::emitter_position_pdf (scene.cpp:451-453) -> area.cpp:60-62 -> mesh.cpp:333-342, or envmap.cpp:124-143
+template <class R, class TVT> PSDR_HD float emitter_position_pdf(const SceneView &sc, const TVT &, const Vec3f &ref_p, const Its<R> &its) {
     const int e = emitter_of(sc, its);
     if (e < 0) return 0.f;
+    if (TVT::has_env && e == sc.d.env_emitter) return env_position_pdf(sc, ref_p, val(its.p), val(its.n));
     const float *ef = sc.d.emitter_f + (size_t) e * PSDR_EMITTER_F_STRIDE;
     return ef[3] * ef[4];
 }
@@ -541,7 +643,9 @@ PSDR_HD Vec3<M> direct_step(const SceneView &sc, const TVT &tv, TraversalStack &
     constexpr bool ad = is_ad<M>();
     constexpr HitForm form = is_ad<G>() ? kPathSpace : kDetached;
     Vec3<M> result = zero3<M>();
-    const Bsdf<G, M> bsdf(sc, active ? sc.d.mesh_bsdf[its.mesh] : 0);
+    int bsdf_id = active ? sc.d.mesh_bsdf[its.mesh] : 0;
+    if (bsdf_id < 0) { active = false; bsdf_id = 0; }      // bounding mesh of the environment map, direct.cpp:54-57
+    const Bsdf<G, M> bsdf(sc, bsdf_id);
     for (int i = 0; i < nB; ++i) {
         const float s[3] = {rng.next(), rng.next(), rng.next()};
         if (!active) continue;
@@ -569,7 +673,7 @@ PSDR_HD Vec3<M> direct_step(const SceneView &sc, const TVT &tv, TraversalStack &
         }
         if (a1) {
             M w(1.f / (float) nB);
-            if (nL > 0) w = w * mis_weight(pdf0, M(emitter_position_pdf(sc, its1)));
+            if (nL > 0) w = w * mis_weight(pdf0, M(emitter_position_pdf(sc, tv, val(its.p), its1)));
             result = result + Le<M>(sc, tv, its1, true) * bsdf_val * w;
         }
         if (next_its && i == 0) { *next_its = its1; *next_f = bsdf_val; *next_valid = a_hit; }
@@ -577,7 +681,7 @@ PSDR_HD Vec3<M> direct_step(const SceneView &sc, const TVT &tv, TraversalStack &
     for (int i = 0; i < nL; ++i) {
         const float s0 = rng.next(), s1 = rng.next();
         if (!active) continue;
-        const PosSample<G> ps = sample_emitter_position<G>(sc, tv, s0, s1, is_ad<G>());
+        const PosSample<G> ps = sample_emitter_position<G>(sc, tv, val(its.p), s0, s1, is_ad<G>());
         Vec3<G> wo = ps.p - its.p;
         const G d2 = dot(wo, wo), dist = safe_sqrt(d2);
         wo = wo / dist;
@@ -697,8 +801,8 @@ PSDR_HD Vec3<M> camera_sample(const SceneView &sc, const TVT &tv, TraversalStack
 // One primary-edge slot: Integrator::render_primary_edges (integrator.cpp:98-119) +
 // PerspectiveCamera::sample_primary_edge (perspective.cpp:158-200).  Returns the pixel (or -1);
 // tan[k][c] = d value / d P_k (the primal part is exactly zero: value -= detach(value)).
-template <int K>
-PSDR_HD int primary_edge_sample(const SceneView &sc, const TangentView<K> &tv, TraversalStack &st, const LiParams &lp, const RngJump &jump,
+template <int K, bool ENV>
+PSDR_HD int primary_edge_sample(const SceneView &sc, const TangentView<K, ENV> &tv, TraversalStack &st, const LiParams &lp, const RngJump &jump,
                                 uint64_t slot, float inv_sppe, float tan[K][3], uint32_t &nrays) {
     Rng rng; rng.init(slot, jump);
     float u = rng.next(), pmf;
@@ -710,7 +814,7 @@ PSDR_HD int primary_edge_sample(const SceneView &sc, const TangentView<K> &tv, T
     const int W = sc.d.width, H = sc.d.height;
     const int ix = (int) floorf(px * (float) W), iy = (int) floorf(py * (float) H);
     const bool valid = ix >= 0 && ix < W && iy >= 0 && iy < H;
-    const TangentView<0> tv0{};
+    const TangentView<0, ENV> tv0{};
     const RayT<float> ray_p = primary_ray<float>(sc, tv0, px + kEdgeEpsilon * nx, py + kEdgeEpsilon * ny);
     const RayT<float> ray_n = primary_ray<float>(sc, tv0, px - kEdgeEpsilon * nx, py - kEdgeEpsilon * ny);
     const Vec3f Ln = Li<float, float>(sc, tv0, st, lp, rng, ray_n, valid, nrays);
@@ -749,7 +853,7 @@ template <class R, class TVT>
 PSDR_HD int secondary_edge_sample(const SceneView &sc, const TVT &tv, TraversalStack &st, const float s3[3], Vec3<R> &out, uint32_t &nrays) {
     constexpr bool ad = is_ad<R>();
     out = zero3<R>();
-    const TangentView<0> tv0{};
+    const TangentView<0, TVT::has_env> tv0{};
     // -- sample_boundary_segment_direct
     float s1 = s3[0], pdf0;
     const int k = sample_reuse(sc.d.sec_cmf, sc.d.sec_pmf, sc.d.sec_sum, sc.d.num_sec_edges, s1, pdf0);
@@ -764,7 +868,7 @@ PSDR_HD int secondary_edge_sample(const SceneView &sc, const TVT &tv, TraversalS
     const float e1len = norm(e1v);
     const Vec3f edge = e1v / e1len, edge2 = ep2 - val(ep0), p0 = val(bp0);
     pdf0 /= e1len;
-    const PosSample<float> ps2 = sample_emitter_position<float>(sc, tv0, s3[1], s3[2], false);
+    const PosSample<float> ps2 = sample_emitter_position<float>(sc, tv0, p0, s3[1], s3[2], false);
     const Vec3f p2 = ps2.p, bn = ps2.n;
     Vec3f e = p2 - p0;
     const float distSqr = dot(e, e);
@@ -796,6 +900,7 @@ PSDR_HD int secondary_edge_sample(const SceneView &sc, const TVT &tv, TraversalS
     if (!(sinphi > kEpsilon && sinphi2 > kEpsilon)) return -1;
     const Vec3f d0 = -val(camera_ray.d);
     const Vec3f d0_local = its1c.sh.to_local(d0);
+    if (sc.d.mesh_bsdf[its1c.mesh] < 0) return -1;          // bounding mesh: null BSDF evaluates to zero
     const Bsdf<float, float> bsdf(sc, sc.d.mesh_bsdf[its1c.mesh]);
     Vec3f bsdf_val = bsdf.eval(sc, tv0, its1c, d0_local, true);
     const float correction = fabsf((its1c.wi.z * dot(d0, its1c.n)) / (d0_local.z * dot(dir, its1c.n)));

@@ -124,8 +124,8 @@ __global__ __launch_bounds__(kBlock) void k_trace(LaunchCtx cx, int m, const flo
 #define PSDR_WAVES_DG 2
 #endif
 template <class G, class R> constexpr int camera_waves() { return !is_ad<R>() ? PSDR_WAVES_C : (is_ad<G>() ? PSDR_WAVES_DG : PSDR_WAVES_DM); }
-template <class G, class R, int INTEG>
-__global__ __launch_bounds__(kBlock, (camera_waves<G, R>())) void k_camera(LaunchCtx cx, TV<R> tv, int spp, int s_begin, int nsp, long long n, float inv_spp,
+template <class G, class R, int INTEG, bool ENV>
+__global__ __launch_bounds__(kBlock, (camera_waves<G, R>())) void k_camera(LaunchCtx cx, TV<R, ENV> tv, int spp, int s_begin, int nsp, long long n, float inv_spp,
                                                    float *__restrict__ img, float *__restrict__ dimg, long long plane,
                                                    unsigned long long *counters) {
     constexpr int K = ad_traits<R>::K;
@@ -226,8 +226,8 @@ __device__ __forceinline__ void splat_runs(int pixel, bool valid, const Vec3<M> 
     }
 }
 
-template <class M>
-__global__ __launch_bounds__(kBlock, (is_ad<M>() ? 2 : 4)) void k_wf_camera(LaunchCtx cx, TV<M> tv, int spp, int s_begin, int nsp, long long j0, long long n,
+template <class M, bool ENV>
+__global__ __launch_bounds__(kBlock, (is_ad<M>() ? 2 : 4)) void k_wf_camera(LaunchCtx cx, TV<M, ENV> tv, int spp, int s_begin, int nsp, long long j0, long long n,
                                                         float inv_spp, float *__restrict__ img, float *__restrict__ dimg, long long plane,
                                                         PathStream out, int *out_count, int want_next, unsigned long long *counters) {
     TraversalStack st; setup_lds(cx, st);
@@ -253,8 +253,8 @@ __global__ __launch_bounds__(kBlock, (is_ad<M>() ? 2 : 4)) void k_wf_camera(Laun
     count_rays(counters, nrays);
 }
 
-template <class M>
-__global__ __launch_bounds__(kBlock, (is_ad<M>() ? 2 : 4)) void k_wf_bounce(LaunchCtx cx, TV<M> tv, float inv_spp, float *__restrict__ img,
+template <class M, bool ENV>
+__global__ __launch_bounds__(kBlock, (is_ad<M>() ? 2 : 4)) void k_wf_bounce(LaunchCtx cx, TV<M, ENV> tv, float inv_spp, float *__restrict__ img,
                                                         float *__restrict__ dimg, long long plane, PathStream in, const int *in_count,
                                                         PathStream out, int *out_count, int want_next, unsigned long long *counters) {
     constexpr int K = ad_traits<M>::K;
@@ -298,8 +298,8 @@ __global__ __launch_bounds__(kBlock, (is_ad<M>() ? 2 : 4)) void k_wf_bounce(Laun
 }
 
 // ------------------------------------------------------------------------ k_primary_edge
-template <int K>
-__global__ __launch_bounds__(kBlock) void k_primary_edge(LaunchCtx cx, TangentView<K> tv, long long i0, long long n, float inv_sppe,
+template <int K, bool ENV>
+__global__ __launch_bounds__(kBlock) void k_primary_edge(LaunchCtx cx, TangentView<K, ENV> tv, long long i0, long long n, float inv_sppe,
                                                          float *__restrict__ dimg, long long plane, unsigned long long *counters) {
     TraversalStack st; setup_lds(cx, st);
     uint32_t nrays = 0;
@@ -318,8 +318,8 @@ __global__ __launch_bounds__(kBlock) void k_primary_edge(LaunchCtx cx, TangentVi
 }
 
 // ---------------------------------------------------------------------- k_secondary_edge
-template <int K>
-__global__ __launch_bounds__(kBlock) void k_secondary_edge(LaunchCtx cx, TangentView<K> tv, long long i0, long long n, float inv_sppse,
+template <int K, bool ENV>
+__global__ __launch_bounds__(kBlock) void k_secondary_edge(LaunchCtx cx, TangentView<K, ENV> tv, long long i0, long long n, float inv_sppse,
                                                            float *__restrict__ dimg, long long plane, unsigned long long *counters) {
     using R = Dual<K>;
     TraversalStack st; setup_lds(cx, st);
@@ -349,11 +349,12 @@ __global__ __launch_bounds__(kBlock) void k_secondary_edge(LaunchCtx cx, Tangent
 // ------------------------------------------------------------------------------- k_guide
 // DirectIntegrator::preprocess_secondary_edges (direct.cpp:166-204): one lane = one (cell, j) sample
 // stream; nrounds evaluations each; mass[cell] += hmax(value0 / reso3) / nrounds.
+template <bool ENV>
 __global__ __launch_bounds__(kBlock) void k_guide(LaunchCtx cx, int r0, int r1, int r2, int per, int nrounds, long long n,
                                                   float *__restrict__ mass, unsigned long long *counters) {
     TraversalStack st; setup_lds(cx, st);
     uint32_t nrays = 0;
-    const TangentView<0> tv0{};
+    const TangentView<0, ENV> tv0{};
     const RngJump nojump{1ull, 0ull};
     for (long long j = (long long) blockIdx.x * kBlock + threadIdx.x; j < n; j += (long long) gridDim.x * kBlock) {
         const int cell = (int) (j / per);
@@ -605,8 +606,8 @@ int check_counts(const psdr_scene_s *h, const psdr_render_opts *o) {
     return 0;
 }
 
-template <class G, class R>
-int run_camera(psdr_scene_s *h, const psdr_render_opts *o, const TV<R> &tv, float *img, float *dimg, hipStream_t s) {
+template <class G, class R, bool ENV>
+int run_camera(psdr_scene_s *h, const psdr_render_opts *o, const TV<R, ENV> &tv, float *img, float *dimg, hipStream_t s) {
     const long long WH = (long long) h->desc.width * h->desc.height;
     const int nsp = o->spp_end - o->spp_begin;
     if (o->spp <= 0 || nsp <= 0) return 0;
@@ -615,7 +616,7 @@ int run_camera(psdr_scene_s *h, const psdr_render_opts *o, const TV<R> &tv, floa
     const long long n = WH * nsp;
     h->slots[0] += (uint64_t) n;
 #define PSDR_LAUNCH_CAMERA(INTEG)                                                                                                  \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_camera<G, R, INTEG>), dim3(launch_blocks(h, n)), dim3(kBlock), lds_bytes(cx, h), s, cx, tv, o->spp, \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_camera<G, R, INTEG, ENV>), dim3(launch_blocks(h, n)), dim3(kBlock), lds_bytes(cx, h), s, cx, tv, o->spp, \
                        o->spp_begin, nsp, n, 1.f / (float) o->spp, img, dimg, WH * 3, h->d_counters)
     switch (o->integrator) {
         case PSDR_INTEGRATOR_DIRECT: PSDR_LAUNCH_CAMERA(PSDR_INTEGRATOR_DIRECT); break;
@@ -631,8 +632,8 @@ int run_camera(psdr_scene_s *h, const psdr_render_opts *o, const TV<R> &tv, floa
 // PathTracer interior term as a wavefront (see k_wf_camera / k_wf_bounce).  M = float or Dual<K>
 // with plain-fp32 geometry.
 constexpr long long kWfChunk = 1ll << 25;
-template <class M>
-int run_camera_wavefront(psdr_scene_s *h, const psdr_render_opts *o, const TV<M> &tv, float *img, float *dimg, hipStream_t s) {
+template <class M, bool ENV>
+int run_camera_wavefront(psdr_scene_s *h, const psdr_render_opts *o, const TV<M, ENV> &tv, float *img, float *dimg, hipStream_t s) {
     constexpr int K = ad_traits<M>::K;
     const long long WH = (long long) h->desc.width * h->desc.height;
     const int nsp = o->spp_end - o->spp_begin;
@@ -664,12 +665,12 @@ int run_camera_wavefront(psdr_scene_s *h, const psdr_render_opts *o, const TV<M>
         LaunchCtx cx;
         if (int rc = make_ctx(h, o, 0, cx)) return rc;
         const int blocks = launch_blocks(h, cn);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wf_camera<M>), dim3(blocks), dim3(kBlock), lds_bytes(cx, h), s, cx, tv, o->spp, o->spp_begin, nsp, j0, cn,
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wf_camera<M, ENV>), dim3(blocks), dim3(kBlock), lds_bytes(cx, h), s, cx, tv, o->spp, o->spp_begin, nsp, j0, cn,
                            inv_spp, img, dimg, WH * 3, st[0], cnt + 1, depth > 1 ? 1 : 0, h->d_counters);
         HIP_TRY(hipGetLastError());
         for (int k = 1; k < depth; ++k) {
             cx.jump = make_rng_jump(o->rng_offset[0] + 2 + 5 * (uint64_t) k);
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wf_bounce<M>), dim3(blocks), dim3(kBlock), lds_bytes(cx, h), s, cx, tv, inv_spp, img, dimg, WH * 3,
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wf_bounce<M, ENV>), dim3(blocks), dim3(kBlock), lds_bytes(cx, h), s, cx, tv, inv_spp, img, dimg, WH * 3,
                                st[(k - 1) & 1], cnt + k, st[k & 1], cnt + k + 1, k + 1 < depth ? 1 : 0, h->d_counters);
             HIP_TRY(hipGetLastError());
         }
@@ -688,25 +689,25 @@ bool use_wavefront(const psdr_scene_s *h, const psdr_render_opts *o) {
     return o->max_depth >= 2 && h->path_survival >= 0.f && h->path_survival < 0.55f;
 }
 
-template <int K>
+template <int K, bool ENV>
 int render_fwd(psdr_scene_s *h, const psdr_render_opts *o, const psdr_tangents *tangents, float *img, float *dimg, hipStream_t s) {
     const long long WH = (long long) h->desc.width * h->desc.height;
-    TangentView<K> tv;
+    TangentView<K, ENV> tv;
     for (int k = 0; k < K; ++k) tv.t[k] = tangents[k];
     HIP_TRY(hipMemsetAsync(img, 0, sizeof(float) * WH * 3, s));
     HIP_TRY(hipMemsetAsync(dimg, 0, sizeof(float) * WH * 3 * K, s));
     // geometry stays in plain fp32 when only material / emitter tables carry tangents
     bool geo = false;
     for (int k = 0; k < K; ++k) geo = geo || tangents[k].d_tri_info || tangents[k].d_cam_to_world;
-    if (geo) { if (int rc = run_camera<Dual<K>, Dual<K>>(h, o, tv, img, dimg, s)) return rc; }
-    else if (use_wavefront(h, o)) { if (int rc = run_camera_wavefront<Dual<K>>(h, o, tv, img, dimg, s)) return rc; }
-    else { if (int rc = run_camera<float, Dual<K>>(h, o, tv, img, dimg, s)) return rc; }
+    if (geo) { if (int rc = run_camera<Dual<K>, Dual<K>, ENV>(h, o, tv, img, dimg, s)) return rc; }
+    else if (use_wavefront(h, o)) { if (int rc = run_camera_wavefront<Dual<K>, ENV>(h, o, tv, img, dimg, s)) return rc; }
+    else { if (int rc = run_camera<float, Dual<K>, ENV>(h, o, tv, img, dimg, s)) return rc; }
     if (o->sppe > 0 && o->sppe_end > o->sppe_begin && h->desc.num_prim_edges > 0) {
         LaunchCtx cx;
         if (int rc = make_ctx(h, o, 1, cx)) return rc;
         const long long i0 = WH * o->sppe_begin, n = WH * (o->sppe_end - o->sppe_begin);
         h->slots[1] += (uint64_t) n;
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_primary_edge<K>), dim3(launch_blocks(h, n)), dim3(kBlock), lds_bytes(cx, h), s, cx, tv, i0, n,
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_primary_edge<K, ENV>), dim3(launch_blocks(h, n)), dim3(kBlock), lds_bytes(cx, h), s, cx, tv, i0, n,
                            1.f / (float) o->sppe, dimg, WH * 3, h->d_counters);
         HIP_TRY(hipGetLastError());
     }
@@ -715,7 +716,7 @@ int render_fwd(psdr_scene_s *h, const psdr_render_opts *o, const psdr_tangents *
         if (int rc = make_ctx(h, o, 2, cx)) return rc;
         const long long i0 = WH * o->sppse_begin, n = WH * (o->sppse_end - o->sppse_begin);
         h->slots[2] += (uint64_t) n;
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_secondary_edge<K>), dim3(launch_blocks(h, n)), dim3(kBlock), lds_bytes(cx, h), s, cx, tv, i0, n,
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_secondary_edge<K, ENV>), dim3(launch_blocks(h, n)), dim3(kBlock), lds_bytes(cx, h), s, cx, tv, i0, n,
                            1.f / (float) o->sppse, dimg, WH * 3, h->d_counters);
         HIP_TRY(hipGetLastError());
     }
@@ -786,6 +787,13 @@ int psdr_scene_set_tables(psdr_scene_t h, const psdr_scene_desc *desc) {
     if (!desc->cam) return fail("Missing sensor!");
     if (h->have_tables && (desc->tri_info != h->desc.tri_info || desc->num_tris != h->desc.num_tris)) h->have_bvh = false;
     h->desc = *desc;
+    // no environment map unless its record is given (a zero-initialised desc means "none")
+    if (!h->desc.env_f) h->desc.env_emitter = -1;
+    if (h->desc.env_emitter >= 0) {
+        if (h->desc.env_emitter >= h->desc.num_emitters || !h->desc.env_cmf || !h->desc.env_pmf || h->desc.env_reso[0] <= 0 ||
+            h->desc.env_reso[1] <= 0 || h->desc.env_tex[1] < 2 || h->desc.env_tex[2] < 2)
+            return fail("psdr_scene_set_tables: inconsistent environment-map record");
+    }
     h->have_tables = true;
     return 0;
 }
@@ -870,9 +878,14 @@ int psdr_render_c(psdr_scene_t h, const psdr_render_opts *o, float *out_img, voi
     if (o->integrator == PSDR_INTEGRATOR_PATH) h->last_path_depth = o->max_depth;
     const long long WH = (long long) h->desc.width * h->desc.height;
     HIP_TRY(hipMemsetAsync(out_img, 0, sizeof(float) * WH * 3, s));
-    const TangentView<0> tv0{};
-    if (use_wavefront(h, o)) return run_camera_wavefront<float>(h, o, tv0, out_img, nullptr, s);
-    return run_camera<float, float>(h, o, tv0, out_img, nullptr, s);
+    if (h->desc.env_emitter >= 0) {
+        const TangentView<0, true> tv0{};
+        if (use_wavefront(h, o)) return run_camera_wavefront<float, true>(h, o, tv0, out_img, nullptr, s);
+        return run_camera<float, float, true>(h, o, tv0, out_img, nullptr, s);
+    }
+    const TangentView<0, false> tv0{};
+    if (use_wavefront(h, o)) return run_camera_wavefront<float, false>(h, o, tv0, out_img, nullptr, s);
+    return run_camera<float, float, false>(h, o, tv0, out_img, nullptr, s);
 }
 
 int psdr_render_d_fwd(psdr_scene_t h, const psdr_render_opts *o, int32_t K, const psdr_tangents *tangents, float *out_img,
@@ -882,9 +895,10 @@ int psdr_render_d_fwd(psdr_scene_t h, const psdr_render_opts *o, int32_t K, cons
     if (int rc = check_counts(h, o)) return rc;
     hipStream_t s = (hipStream_t) stream;
     if (int rc = begin_call(h, s)) return rc;
+    const bool env = h->desc.env_emitter >= 0;
     switch (K) {
-        case 1: return render_fwd<1>(h, o, tangents, out_img, out_dimg, s);
-        case 3: return render_fwd<3>(h, o, tangents, out_img, out_dimg, s);
+        case 1: return env ? render_fwd<1, true>(h, o, tangents, out_img, out_dimg, s) : render_fwd<1, false>(h, o, tangents, out_img, out_dimg, s);
+        case 3: return env ? render_fwd<3, true>(h, o, tangents, out_img, out_dimg, s) : render_fwd<3, false>(h, o, tangents, out_img, out_dimg, s);
         default: return fail("psdr_render_d_fwd: K must be 1 or 3");
     }
 }
@@ -895,6 +909,7 @@ int psdr_render_d_rev(psdr_scene_t h, const psdr_render_opts *o, const float *ad
     if (!h->have_tables) return fail("Scene not loaded yet!");
     if (int rc = check_counts(h, o)) return rc;
     if (o->integrator == PSDR_INTEGRATOR_PATH && o->max_depth > kMaxRevDepth) return fail("psdr_render_d_rev: max_depth > 8 is not supported");
+    if (h->desc.env_emitter >= 0) return fail("psdr_render_d_rev: environment maps are differentiated in forward mode only");
     hipStream_t s = (hipStream_t) stream;
     if (int rc = begin_call(h, s)) return rc;
     const long long WH = (long long) h->desc.width * h->desc.height;
@@ -948,8 +963,12 @@ int psdr_guide_build(psdr_scene_t h, const psdr_render_opts *o, const int32_t re
     const long long n = cells * reso[3];
     if (n <= 0 || n > 0x7fffffffLL) return fail("psdr_guide_build: invalid resolution");
     HIP_TRY(hipMemsetAsync(out_mass, 0, sizeof(float) * cells, s));
-    hipLaunchKernelGGL(k_guide, dim3(launch_blocks(h, n)), dim3(kBlock), lds_bytes(cx, h), s, cx, reso[0], reso[1], reso[2], reso[3], nrounds, n, out_mass,
-                       h->d_counters);
+    if (h->desc.env_emitter >= 0)
+        hipLaunchKernelGGL(k_guide<true>, dim3(launch_blocks(h, n)), dim3(kBlock), lds_bytes(cx, h), s, cx, reso[0], reso[1], reso[2], reso[3], nrounds, n,
+                           out_mass, h->d_counters);
+    else
+        hipLaunchKernelGGL(k_guide<false>, dim3(launch_blocks(h, n)), dim3(kBlock), lds_bytes(cx, h), s, cx, reso[0], reso[1], reso[2], reso[3], nrounds, n,
+                           out_mass, h->d_counters);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -102,6 +102,25 @@ template <class R> PSDR_HD R max_(const R &a, float b) { return val(a) > b ? a :
 template <class R> PSDR_HD R min_(const R &a, float b) { return val(a) < b ? a : R(b); }
 template <class R> PSDR_HD R safe_sqrt(const R &a) { return sqrt_(max_(a, 0.f)); }
 template <class R> PSDR_HD R clamp_(const R &a, float lo, float hi) { return max_(min_(a, hi), lo); }
+// atan2 / safe_acos with their derivatives (EnvironmentMap::eval_direction, src/emitter/envmap.cpp:52)
+PSDR_HD float atan2_(float y, float x) { return atan2f(y, x); }
+template <int K> PSDR_HD Dual<K> atan2_(const Dual<K> &y, const Dual<K> &x) {
+    Dual<K> r; r.v = atan2f(y.v, x.v);
+    const float inv = 1.f / (x.v * x.v + y.v * y.v);
+#pragma unroll
+    for (int k = 0; k < K; ++k) r.d[k] = (x.v * y.d[k] - y.v * x.d[k]) * inv;
+    return r;
+}
+PSDR_HD float safe_acos_(float x) { return acosf(fminf(fmaxf(x, -1.f), 1.f)); }
+template <int K> PSDR_HD Dual<K> safe_acos_(const Dual<K> &x) {
+    const float c = fminf(fmaxf(x.v, -1.f), 1.f);
+    Dual<K> r; r.v = acosf(c);
+    const bool inside = x.v > -1.f && x.v < 1.f;          // the clamp has zero derivative
+    const float g = inside ? -1.f / sqrtf(1.f - c * c) : 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) r.d[k] = g * x.d[k];
+    return r;
+}
 PSDR_HD bool finite_(float x) { return isfinite(x); }
 
 // ------------------------------------------------------------------------------ vectors

@@ -704,7 +704,7 @@ PSDR_HD void secondary_edge_reverse(Sink &sink, const SceneView &sc, TraversalSt
     const float e1len = norm(ee1);
     const Vec3f edge = ee1 / e1len, edge2 = ep2 - ep0;
     pdf0 /= e1len;
-    const PosSample<float> ps2 = sample_emitter_position<float>(sc, tv0, s3[1], s3[2], false);
+    const PosSample<float> ps2 = sample_emitter_position<float>(sc, tv0, p0, s3[1], s3[2], false);
     const Vec3f p2 = ps2.p, bn = ps2.n;
     Vec3f e = p2 - p0;
     const float distSqr = dot(e, e);

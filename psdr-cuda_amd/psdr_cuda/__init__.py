@@ -7,7 +7,7 @@ import enoki.cuda_autodiff  # noqa: F401
 
 from .core import (Object, RenderOption, Bitmap1fD, Bitmap3fD, DiscreteDistribution,  # noqa: F401
                    HyperCubeDistribution2f, HyperCubeDistribution3f)
-from .scene import (BSDF, Diffuse, DiffuseBSDF, RoughConductor, RoughConductorBSDF, Emitter, AreaLight,  # noqa: F401
+from .scene import (BSDF, Diffuse, DiffuseBSDF, RoughConductor, RoughConductorBSDF, Emitter, AreaLight, EnvironmentMap,  # noqa: F401
                     Sensor, PerspectiveCamera, Mesh, Scene, PositionSample, BoundarySegSampleDirect)
 from .integrator import Integrator, FieldExtractionIntegrator, DirectIntegrator, PathTracer  # noqa: F401
 

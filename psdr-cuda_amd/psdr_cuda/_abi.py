@@ -21,6 +21,7 @@ BSDF_STRIDE = 16
 EMITTER_F_STRIDE = 8
 EMITTER_I_STRIDE = 4
 CAM_WORDS = 64
+ENV_WORDS = 32
 TRI_FACE_NORMALS = 0x40000000
 
 BSDF_DIFFUSE, BSDF_ROUGHCONDUCTOR = 0, 1
@@ -48,6 +49,8 @@ class SceneDesc(C.Structure):
         ("prim_edge", _fp), ("prim_cmf", _fp), ("prim_pmf", _fp), ("prim_sum", C.c_float),
         ("guide_reso", C.c_int32 * 3),
         ("guide_cmf", _fp), ("guide_pmf", _fp), ("guide_sum", C.c_float),
+        ("env_emitter", C.c_int32), ("env_tex", C.c_int32 * 3), ("env_reso", C.c_int32 * 2),
+        ("env_f", _fp), ("env_cmf", _fp), ("env_pmf", _fp), ("env_sum", C.c_float),
     ]
 
 
@@ -66,15 +69,15 @@ class RenderOpts(C.Structure):
 
 class Tangents(C.Structure):
     _fields_ = [("d_tri_info", _fp), ("d_texels", _fp), ("d_emitter_rad", _fp), ("d_cam_to_world", _fp),
-                ("d_sec_edge", _fp), ("d_prim_edge", _fp)]
+                ("d_sec_edge", _fp), ("d_prim_edge", _fp), ("d_env_f", _fp)]
 
 
 class Grads(C.Structure):
     _fields_ = [("g_tri_info", _fp), ("g_texels", _fp), ("g_emitter_rad", _fp), ("g_cam_to_world", _fp),
-                ("g_sec_edge", _fp), ("g_prim_edge", _fp)]
+                ("g_sec_edge", _fp), ("g_prim_edge", _fp), ("g_env_f", _fp)]
 
 
-TANGENT_FIELDS = ("tri_info", "texels", "emitter_rad", "cam_to_world", "sec_edge", "prim_edge")
+TANGENT_FIELDS = ("tri_info", "texels", "emitter_rad", "cam_to_world", "sec_edge", "prim_edge", "env_f")
 
 # every symbol include/psdr_hip.h declares (checked by tests/test_abi.py)
 HIP_SYMBOLS = (

@@ -19,7 +19,7 @@ from . import _abi
 from .core import Object, psdr_assert, Vector3fC, Vector3fD, HyperCubeDistribution3f
 from .scene import make_desc
 
-_AD_KEYS = ("tri_info", "texels", "emitter_rad", "cam_to_world", "sec_edge", "prim_edge")
+_AD_KEYS = _abi.TANGENT_FIELDS
 
 
 def _dist():

@@ -131,6 +131,65 @@ class AreaLight(Emitter):
         return "AreaLight[radiance = %s, sampling_weight = %g]" % (self.radiance.numpy().tolist(), self.m_sampling_weight)
 
 
+class EnvironmentMap(Emitter):
+    """reference include/psdr/emitter/envmap.h:11-58, src/emitter/envmap.cpp:10-27 (configure).
+    eval / sample_position / sample_position_pdf run per sample inside the kernels
+    (csrc/psdr_device.h env_*); this class owns the parameters and builds the tables."""
+    _type_name = "EnvironmentMap"
+
+    def __init__(self, file_name=None):
+        super().__init__()
+        self.radiance = Bitmap3fD()
+        if file_name is not None:
+            self.radiance.load_openexr(file_name)
+        self.scale = FloatD(1.0)
+        d = _dev()
+        self._to_world_raw = torch.eye(4, device=d)
+        self._to_world_left = torch.eye(4, device=d)
+        self.m_sampling_weight = 1.0          # never reset by configure (emitter.h:27, envmap.cpp:10-27)
+        self.m_lower = self.m_upper = None    # scene AABB + margin, set once by Scene.configure
+        self.m_mesh = None                    # the bounding mesh
+        self.m_ready = False
+
+    @property
+    def to_world(self):
+        return Matrix4fD._wrap(self._to_world_raw)
+
+    def set_transform(self, mat):
+        self._to_world_left = _mat(mat)
+        self.m_ready = False
+
+    def configure(self):
+        w, h = self.radiance.resolution
+        psdr_assert(w > 1 and h > 1)
+        width, height = (w - 1) << 1, (h - 1) << 1
+        d = _dev()
+        idx = torch.arange(width * height, device=d)
+        cx, cy = idx // height, idx % height          # HyperCubeDistribution<2> cell order, cube_distrb.cpp:19-26
+        uv = torch.stack([(cx.to(torch.float32) + .5) * np.float32(1.0 / width),
+                          (cy.to(torch.float32) + .5) * np.float32(1.0 / height)], dim=-1)
+        with torch.no_grad():
+            val = self.radiance.eval(uv, False).t.detach()
+        theta = (cy.to(torch.float32) + .5) * np.float32(np.pi / height)
+        lum = val[:, 0] * .2126 + val[:, 1] * .7152 + val[:, 2] * .0722
+        self._cell_reso = (width, height)
+        self._cell_distrb = DiscreteDistribution()
+        self._cell_distrb.init((lum * torch.sin(theta)).to(torch.float32))
+        self._to_world = self._to_world_left @ self._to_world_raw
+        self._from_world = torch.linalg.inv(self._to_world)
+        self.m_ready = True
+
+    def record(self):
+        """env_f (include/psdr_hip.h PSDR_ENV_*), differentiable w.r.t. the transform and the scale."""
+        sc = self.scale.t.reshape(-1)[:1].to(torch.float32)
+        return torch.cat([self._from_world[:3, :3].reshape(-1), self._to_world[:3, :3].detach().reshape(-1), sc,
+                          self.m_lower.reshape(3), self.m_upper.reshape(3),
+                          torch.zeros(_abi.ENV_WORDS - 25, device=sc.device)]).contiguous()
+
+    def to_string(self):
+        return "EnvironmentMap[sampling_weight = %g]" % self.m_sampling_weight
+
+
 # ----------------------------------------------------------------------------- sensors
 class Sensor(Object):
     _type_name = "Sensor"
@@ -658,6 +717,8 @@ class Scene(Object):
         self.opts = RenderOption(0, 0, 0, 0, 0)
         self.m_loaded = False
         self.m_sensors, self.m_emitters, self.m_bsdfs, self.m_meshes = [], [], [], []
+        self.m_emitter_env = None
+        self.m_has_bound_mesh = False
         self.param_map = {}
         self.num_sensors = 0
         self.num_meshes = 0
@@ -704,7 +765,7 @@ class Scene(Object):
         for node in root.findall("bsdf"):
             self._load_bsdf(node, base_dir)
         for node in root.findall("emitter"):
-            raise RuntimeError("Unsupported emitter: " + str(node.get("type")))   # envmap: SURVEY 8(f) N2
+            self._load_emitter(node, base_dir)
         for node in root.findall("shape"):
             self._load_shape(node, base_dir)
         self._build_param_map()
@@ -745,6 +806,26 @@ class Scene(Object):
                               float(ff.get("value", 1e4)) if ff is not None else 1e4)
         s.to_world = to_world
         self.m_sensors.append(s)
+
+    def _load_emitter(self, node, base_dir):
+        """SceneLoader::load_emitter, scene_loader.cpp:291-315 (top-level emitters: envmap only)."""
+        if node.get("type") != "envmap":
+            raise RuntimeError("Unsupported emitter: " + str(node.get("type")))
+        psdr_assert(self.m_emitter_env is None, "A scene is only allowed to have one envmap!")
+        fn = node.find("string")
+        psdr_assert(fn is not None and fn.get("name") == "filename" and fn.get("value"), "Failed to retrieve bitmap filename")
+        sc = _find_child(node, {"scale"}, True)
+        e = EnvironmentMap(_resolve(fn.get("value"), base_dir))
+        e.scale = FloatD(float(sc.get("value", 1.0)) if sc is not None else 1.0)
+        e._to_world_raw = torch.as_tensor(_load_transform(node.find("transform")), dtype=torch.float32, device=_dev())
+        self.m_emitters.append(e)
+        self.m_emitter_env = e
+
+    def add_environment_map(self, env):
+        """programmatic construction (fixtures / tests)"""
+        psdr_assert(self.m_emitter_env is None, "A scene is only allowed to have one envmap!")
+        self.m_emitters.append(env)
+        self.m_emitter_env = env
 
     def _load_bsdf(self, node, base_dir):
         bid = node.get("id")
@@ -831,7 +912,8 @@ class Scene(Object):
         tri_rows, uv_rows, tri_mesh, sec_rows = [], [], [], []
         has_uv = any(m.m_has_uv for m in self.m_meshes)
         face_offset = [0]
-        for i, mesh in enumerate(self.m_meshes):
+
+        def add_mesh_rows(i, mesh):
             mesh.configure()
             tri_rows.append(mesh._triangle_info)
             flag = _abi.TRI_FACE_NORMALS if mesh.use_face_normals else 0
@@ -842,18 +924,49 @@ class Scene(Object):
             if o.sppse > 0 and mesh.enable_edges and mesh._sec_edge_info is not None:
                 sec_rows.append(mesh._sec_edge_info)
             face_offset.append(face_offset[-1] + mesh.num_faces)
+        for i, mesh in enumerate(self.m_meshes):
+            add_mesh_rows(i, mesh)
+        # AABB over the meshes, scene.cpp:88-101 (m_upper starts at numeric_limits<float>::min(), the
+        # smallest POSITIVE float: kept as is)
+        allv = torch.cat([m._vertex_positions.detach() for m in self.m_meshes], dim=0)
+        self.m_lower = allv.min(dim=0)[0]
+        self.m_upper = torch.clamp(allv.max(dim=0)[0], min=float(np.finfo(np.float32).tiny))
+
+        # sensors (+ camera positions into the AABB, scene.cpp:104-119)
+        self._sensor_tables = [s.configure(self) for s in self.m_sensors]
+        for st in self._sensor_tables:
+            cp = st["cam"][_abi.CAM_POS:_abi.CAM_POS + 3].detach()
+            self.m_lower, self.m_upper = torch.minimum(self.m_lower, cp), torch.maximum(self.m_upper, cp)
+
+        # environment lighting: bounding mesh added once, scene.cpp:135-180
+        if self.m_emitter_env is not None and not self.m_has_bound_mesh:
+            margin = ((self.m_upper - self.m_lower) * np.float32(0.05)).min()
+            self.m_lower, self.m_upper = self.m_lower - margin, self.m_upper + margin
+            env = self.m_emitter_env
+            env.m_lower, env.m_upper = self.m_lower.clone(), self.m_upper.clone()
+            lo, hi = self.m_lower.cpu().numpy(), self.m_upper.cpu().numpy()
+            verts = np.array([[hi[j] if (i >> j) & 1 else lo[j] for j in range(3)] for i in range(8)], dtype=np.float32)
+            faces = np.array([[0, 1, 3], [0, 3, 2], [1, 5, 7], [1, 7, 3], [2, 3, 7], [2, 7, 6],
+                              [0, 5, 1], [0, 4, 5], [0, 2, 6], [0, 6, 4], [4, 7, 5], [4, 6, 7]], dtype=np.int32)
+            bound = Mesh()
+            bound.enable_edges = False
+            bound.use_face_normals = True
+            bound.set_geometry(verts, faces, fname="<envmap bounding mesh>")
+            bound.bsdf, bound.m_emitter = None, env
+            env.m_mesh = bound
+            self.m_meshes.append(bound)
+            self.num_meshes = len(self.m_meshes)
+            self.m_has_bound_mesh = True
+            add_mesh_rows(len(self.m_meshes) - 1, bound)
+            if o.log_level > 0:
+                self.log("Bounding mesh added for environmental lighting.")
+
         T = face_offset[-1]
         tri_info = torch.cat([torch.cat(tri_rows, dim=0), torch.zeros(T, 2, device=d)], dim=-1).contiguous()
         tb = {"tri_info": tri_info, "tri_mesh": torch.cat(tri_mesh).contiguous(), "num_tris": T,
               "tri_uv": None, "face_offset": face_offset}
         if has_uv:
             tb["tri_uv"] = torch.cat([torch.cat(uv_rows, dim=0).detach(), torch.zeros(T, 2, device=d)], dim=-1).contiguous()
-        # AABB (log only)
-        allv = torch.cat([m._vertex_positions.detach() for m in self.m_meshes], dim=0)
-        self.m_lower, self.m_upper = allv.min(dim=0)[0], allv.max(dim=0)[0]
-
-        # sensors
-        self._sensor_tables = [s.configure(self) for s in self.m_sensors]
 
         # BSDF records + texel pool
         bsdf_ids = {id(b): i for i, b in enumerate(self.m_bsdfs)}
@@ -877,6 +990,7 @@ class Scene(Object):
                 raise RuntimeError("Unsupported BSDF: " + b.type_name())
             rec.append(r)
         tb["bsdf_rec"] = torch.tensor(rec if rec else [[0] * 16], dtype=torch.int32, device=d).contiguous()
+        env_tex = put(self.m_emitter_env.radiance) if self.m_emitter_env is not None else [0, 0, 0]
         tb["texels"] = (torch.cat(pool) if pool else torch.zeros(1, device=d)).to(torch.float32).contiguous()
         tb["mesh_bsdf"] = torch.tensor([bsdf_ids.get(id(m.bsdf), -1) for m in self.m_meshes], dtype=torch.int32, device=d)
 
@@ -899,6 +1013,11 @@ class Scene(Object):
             for i, e in enumerate(self.m_emitters):
                 e.m_sampling_weight = float(np.float32(e.m_sampling_weight) * inv_total)
                 mi = self.m_meshes.index(e.m_mesh)
+                if isinstance(e, EnvironmentMap):
+                    ef[i, 3] = e.m_sampling_weight
+                    ei[i] = torch.tensor([mi, face_offset[mi], e.m_mesh.num_faces, 0], dtype=torch.int32)
+                    rads.append(torch.zeros(3, device=d))
+                    continue
                 fd = e.m_mesh._face_distrb
                 ef[i, 3], ef[i, 4], ef[i, 5] = e.m_sampling_weight, e.m_mesh.m_inv_total_area, fd.m_sum
                 ei[i] = torch.tensor([mi, face_offset[mi], e.m_mesh.num_faces, coff], dtype=torch.int32)
@@ -914,6 +1033,13 @@ class Scene(Object):
         tb["face_cmf"] = torch.cat(cmfs).contiguous() if cmfs else torch.zeros(1, device=d)
         tb["face_pmf"] = torch.cat(pmfs).contiguous() if pmfs else torch.zeros(1, device=d)
         tb["num_emitters"] = Ne
+        if self.m_emitter_env is not None:
+            env = self.m_emitter_env
+            cd = env._cell_distrb
+            tb.update(env_emitter=self.m_emitters.index(env), env_tex=env_tex, env_reso=list(env._cell_reso),
+                      env_f=env.record(), env_cmf=cd.m_cmf, env_pmf=cd.m_pmf, env_sum=cd.m_sum)
+        else:
+            tb.update(env_emitter=-1, env_tex=[0, 0, 0], env_reso=[0, 0], env_f=None, env_cmf=None, env_pmf=None, env_sum=0.0)
 
         # secondary edges, scene.cpp:219-244
         if o.sppse > 0 and sec_rows:
@@ -1020,6 +1146,12 @@ def make_desc(tb, guide=None, device=None):
     d.cam = p(tb["cam"])
     d.sec_edge, d.sec_cmf, d.sec_pmf, d.sec_sum = p(tb["sec_edge"]), p(tb["sec_cmf"]), p(tb["sec_pmf"]), tb["sec_sum"]
     d.prim_edge, d.prim_cmf, d.prim_pmf, d.prim_sum = p(tb["prim_edge"]), p(tb["prim_cmf"]), p(tb["prim_pmf"]), tb["prim_sum"]
+    d.env_emitter = int(tb.get("env_emitter", -1))
+    if d.env_emitter >= 0:
+        for i in range(3):
+            d.env_tex[i] = int(tb["env_tex"][i])
+        d.env_reso[0], d.env_reso[1] = int(tb["env_reso"][0]), int(tb["env_reso"][1])
+        d.env_f, d.env_cmf, d.env_pmf, d.env_sum = p(tb["env_f"]), p(tb["env_cmf"]), p(tb["env_pmf"]), float(tb["env_sum"])
     if guide is not None:
         reso, cmf, pmf, s = guide
         d.guide_reso[0], d.guide_reso[1], d.guide_reso[2] = int(reso[0]), int(reso[1]), int(reso[2])

@@ -17,6 +17,7 @@ struct HostScene {
 };
 bool setup(HostScene &hs, const psdr_scene_desc *d) {
     hs.sc.d = *d;
+    if (!hs.sc.d.env_f) hs.sc.d.env_emitter = -1;
     int32_t root = 0;
     if (hs.b.run(d->tri_info, d->num_tris, root)) return false;
     hs.sc.nodes = hs.b.nodes.data(); hs.sc.btris = hs.b.btris.data(); hs.sc.root = root;
@@ -58,8 +59,8 @@ int hostcheck_render(const psdr_scene_desc *d, const psdr_render_opts *o, int mo
     nthreads = std::max(1, nthreads);
     std::vector<std::vector<double>> acc(nthreads, std::vector<double>(n3, 0.0)), dacc(nthreads, std::vector<double>(mode ? n3 : 0, 0.0));
     LiParams lp{o->integrator, o->bsdf_samples, o->light_samples, o->max_depth, o->hide_emitters, o->field};
-    TangentView<1> tv1; tv1.t[0] = tan ? *tan : psdr_tangents{};
-    const TangentView<0> tv0{};
+    TangentView<1, true> tv1; tv1.t[0] = tan ? *tan : psdr_tangents{};
+    const TangentView<0, true> tv0{};   // ENV = true: the host check always carries the env-map code
     const int nsp = o->spp_end - o->spp_begin;
     if (o->spp > 0 && nsp > 0) {
         const RngJump jump = make_rng_jump(o->rng_offset[0]);
@@ -128,7 +129,7 @@ int hostcheck_guide(const psdr_scene_desc *d, const int *reso, int nrounds, floa
     hs.sc.d.guide_cmf = nullptr; hs.sc.d.num_guide_cells = 0;
     const long long cells = (long long) reso[0] * reso[1] * reso[2], n = cells * reso[3];
     std::vector<double> m(cells, 0.0);
-    const TangentView<0> tv0{};
+    const TangentView<0, true> tv0{};   // ENV = true: the host check always carries the env-map code
     const RngJump nojump{1ull, 0ull};
     pfor(cells, std::max(1, nthreads), [&](long long a, long long b, int) {
         TraversalStack st; uint32_t nr = 0;
