@@ -394,11 +394,13 @@ struct SinkLayout {
     int tex_off, tex_n;                      // texel cache (tex_n = 0: not cached)
     int rad_off, rad_n;
     int cam_off;                             // 16 words
+    int env_off, env_n;                      // environment-map record (PSDR_ENV_WORDS) if wanted
     int hot_off, hot_rows;                   // cached triangle rows: slot = hot_map[tri] (-1 = not cached)
     const int32_t *hot_map, *hot_tris;       // [T] tri -> slot, [hot_rows] slot -> tri
     int total;
 };
-struct DeviceSink {
+template <bool ENV> struct DeviceSink {
+    static constexpr bool has_env = ENV;
     psdr_grads g;
     SinkLayout L;
     float *lds;
@@ -420,6 +422,7 @@ struct DeviceSink {
         if (L.rad_n) atomicAdd(lds + L.rad_off + e * 3 + c, v); else atomicAdd(g.g_emitter_rad + e * 3 + c, v);
     }
     __device__ __forceinline__ void add_cam(int word, float v) { if (ok(v)) cam[word] += v; }
+    __device__ __forceinline__ void add_env(int word, float v) const { if (L.env_n && ok(v)) atomicAdd(lds + L.env_off + word, v); }
     __device__ __forceinline__ void add_sedge(int e, int word, float v) const { glob(g.g_sec_edge, (size_t) e * PSDR_SEDGE_STRIDE + word, v); }
     __device__ __forceinline__ void add_pedge(int e, int word, float v) const { glob(g.g_prim_edge, (size_t) e * PSDR_PEDGE_STRIDE + word, v); }
 
@@ -447,6 +450,7 @@ struct DeviceSink {
             if (i >= L.cam_off && i < L.cam_off + 16) { atomicAdd(g.g_cam_to_world + (i - L.cam_off), v); continue; }
             if (L.tex_n && i >= L.tex_off && i < L.tex_off + L.tex_n) { atomicAdd(g.g_texels + (i - L.tex_off), v); continue; }
             if (L.rad_n && i >= L.rad_off && i < L.rad_off + L.rad_n) { atomicAdd(g.g_emitter_rad + (i - L.rad_off), v); continue; }
+            if (L.env_n && i >= L.env_off && i < L.env_off + L.env_n) { atomicAdd(g.g_env_f + (i - L.env_off), v); continue; }
             const int rel = i - L.hot_off;
             if (rel >= 0 && rel < L.hot_rows * PSDR_TRI_STRIDE)
                 atomicAdd(g.g_tri_info + (size_t) L.hot_tris[rel / PSDR_TRI_STRIDE] * PSDR_TRI_STRIDE + rel % PSDR_TRI_STRIDE, v);
@@ -454,7 +458,8 @@ struct DeviceSink {
     }
 };
 
-__global__ __launch_bounds__(kBlock, 2) void k_camera_rev(LaunchCtx cx, DeviceSink sink, int spp, int s_begin, int nsp, long long n, float inv_spp,
+template <bool ENV>
+__global__ __launch_bounds__(kBlock, 2) void k_camera_rev(LaunchCtx cx, DeviceSink<ENV> sink, int spp, int s_begin, int nsp, long long n, float inv_spp,
                                                        const float *__restrict__ adj_img, float *__restrict__ img,
                                                        unsigned long long *counters) {
     __shared__ float cache[kSinkCacheWords];
@@ -501,7 +506,8 @@ __global__ __launch_bounds__(kBlock, 2) void k_camera_rev(LaunchCtx cx, DeviceSi
     count_rays(counters, nrays);
 }
 
-__global__ __launch_bounds__(kBlock) void k_primary_edge_rev(LaunchCtx cx, DeviceSink sink, long long i0, long long n, float inv_sppe,
+template <bool ENV>
+__global__ __launch_bounds__(kBlock) void k_primary_edge_rev(LaunchCtx cx, DeviceSink<ENV> sink, long long i0, long long n, float inv_sppe,
                                                              const float *__restrict__ adj_img, unsigned long long *counters) {
     __shared__ float cache[kSinkCacheWords];
     TraversalStack st; setup_lds(cx, st);
@@ -513,7 +519,8 @@ __global__ __launch_bounds__(kBlock) void k_primary_edge_rev(LaunchCtx cx, Devic
     count_rays(counters, nrays);
 }
 
-__global__ __launch_bounds__(kBlock) void k_secondary_edge_rev(LaunchCtx cx, DeviceSink sink, long long i0, long long n, float inv_sppse,
+template <bool ENV>
+__global__ __launch_bounds__(kBlock) void k_secondary_edge_rev(LaunchCtx cx, DeviceSink<ENV> sink, long long i0, long long n, float inv_sppse,
                                                                const float *__restrict__ adj_img, unsigned long long *counters) {
     __shared__ float cache[kSinkCacheWords];
     TraversalStack st; setup_lds(cx, st);
@@ -727,6 +734,7 @@ SinkLayout make_sink_layout(const psdr_scene_s *h, const psdr_grads *g) {
     SinkLayout L{};
     int off = 0;
     L.cam_off = off; off += 16;
+    if (g->g_env_f && h->desc.env_emitter >= 0) { L.env_off = off; L.env_n = PSDR_ENV_WORDS; off += PSDR_ENV_WORDS; }
     const int nt = h->desc.num_texels, nr = h->desc.num_emitters * 3;
     if (g->g_texels && nt > 0 && nt <= 2048) { L.tex_off = off; L.tex_n = nt; off += nt; }
     if (g->g_emitter_rad && nr > 0 && nr <= 256) { L.rad_off = off; L.rad_n = nr; off += nr; }
@@ -748,6 +756,48 @@ int begin_call(psdr_scene_s *h, hipStream_t s) {
 }  // namespace
 
 // ================================================================================= C ABI
+namespace {
+template <bool ENV>
+int render_rev(psdr_scene_s *h, const psdr_render_opts *o, const float *adj_img, float *out_img, const psdr_grads *grads, hipStream_t s) {
+    const long long WH = (long long) h->desc.width * h->desc.height;
+    if (out_img) HIP_TRY(hipMemsetAsync(out_img, 0, sizeof(float) * WH * 3, s));
+    DeviceSink<ENV> sink{}; sink.g = *grads; sink.L = make_sink_layout(h, grads);
+    const int nsp = o->spp_end - o->spp_begin;
+    if (o->spp > 0 && nsp > 0) {
+        LaunchCtx cx;
+        if (int rc = make_ctx(h, o, 0, cx)) return rc;
+        const long long n = WH * nsp;
+        h->slots[0] += (uint64_t) n;
+        const int depth = o->integrator == PSDR_INTEGRATOR_PATH ? std::min(o->max_depth, kMaxRevDepth) : 1;
+        const int rec_bytes = depth * 6 * kBlock * 4;
+        plan_lds(h, cx, rec_bytes + kSinkCacheWords * 4);          // stage less of the scene: the record + cache live in LDS too
+        cx.off_pathrec = lds_bytes(cx, h);
+        hipLaunchKernelGGL(k_camera_rev<ENV>, dim3(launch_blocks(h, n)), dim3(kBlock), lds_bytes(cx, h) + rec_bytes, s, cx, sink, o->spp, o->spp_begin, nsp, n,
+                           1.f / (float) o->spp, adj_img, out_img, h->d_counters);
+        HIP_TRY(hipGetLastError());
+    }
+    if (o->sppe > 0 && o->sppe_end > o->sppe_begin && h->desc.num_prim_edges > 0 && grads->g_prim_edge) {
+        LaunchCtx cx;
+        if (int rc = make_ctx(h, o, 1, cx)) return rc;
+        const long long i0 = WH * o->sppe_begin, n = WH * (o->sppe_end - o->sppe_begin);
+        h->slots[1] += (uint64_t) n;
+        hipLaunchKernelGGL(k_primary_edge_rev<ENV>, dim3(launch_blocks(h, n)), dim3(kBlock), lds_bytes(cx, h), s, cx, sink, i0, n, 1.f / (float) o->sppe, adj_img,
+                           h->d_counters);
+        HIP_TRY(hipGetLastError());
+    }
+    if (o->sppse > 0 && o->sppse_end > o->sppse_begin && h->desc.num_sec_edges > 0 && o->integrator == PSDR_INTEGRATOR_DIRECT) {
+        LaunchCtx cx;
+        if (int rc = make_ctx(h, o, 2, cx)) return rc;
+        const long long i0 = WH * o->sppse_begin, n = WH * (o->sppse_end - o->sppse_begin);
+        h->slots[2] += (uint64_t) n;
+        hipLaunchKernelGGL(k_secondary_edge_rev<ENV>, dim3(launch_blocks(h, n)), dim3(kBlock), lds_bytes(cx, h), s, cx, sink, i0, n, 1.f / (float) o->sppse,
+                           adj_img, h->d_counters);
+        HIP_TRY(hipGetLastError());
+    }
+    return 0;
+}
+}  // namespace
+
 extern "C" {
 
 const char *psdr_last_error(void) { return g_err.c_str(); }
@@ -909,45 +959,9 @@ int psdr_render_d_rev(psdr_scene_t h, const psdr_render_opts *o, const float *ad
     if (!h->have_tables) return fail("Scene not loaded yet!");
     if (int rc = check_counts(h, o)) return rc;
     if (o->integrator == PSDR_INTEGRATOR_PATH && o->max_depth > kMaxRevDepth) return fail("psdr_render_d_rev: max_depth > 8 is not supported");
-    if (h->desc.env_emitter >= 0) return fail("psdr_render_d_rev: environment maps are differentiated in forward mode only");
     hipStream_t s = (hipStream_t) stream;
     if (int rc = begin_call(h, s)) return rc;
-    const long long WH = (long long) h->desc.width * h->desc.height;
-    if (out_img) HIP_TRY(hipMemsetAsync(out_img, 0, sizeof(float) * WH * 3, s));
-    DeviceSink sink{}; sink.g = *grads; sink.L = make_sink_layout(h, grads);
-    const int nsp = o->spp_end - o->spp_begin;
-    if (o->spp > 0 && nsp > 0) {
-        LaunchCtx cx;
-        if (int rc = make_ctx(h, o, 0, cx)) return rc;
-        const long long n = WH * nsp;
-        h->slots[0] += (uint64_t) n;
-        const int depth = o->integrator == PSDR_INTEGRATOR_PATH ? std::min(o->max_depth, kMaxRevDepth) : 1;
-        const int rec_bytes = depth * 6 * kBlock * 4;
-        plan_lds(h, cx, rec_bytes + kSinkCacheWords * 4);          // stage less of the scene: the record + cache live in LDS too
-        cx.off_pathrec = lds_bytes(cx, h);
-        hipLaunchKernelGGL(k_camera_rev, dim3(launch_blocks(h, n)), dim3(kBlock), lds_bytes(cx, h) + rec_bytes, s, cx, sink, o->spp, o->spp_begin, nsp, n,
-                           1.f / (float) o->spp, adj_img, out_img, h->d_counters);
-        HIP_TRY(hipGetLastError());
-    }
-    if (o->sppe > 0 && o->sppe_end > o->sppe_begin && h->desc.num_prim_edges > 0 && grads->g_prim_edge) {
-        LaunchCtx cx;
-        if (int rc = make_ctx(h, o, 1, cx)) return rc;
-        const long long i0 = WH * o->sppe_begin, n = WH * (o->sppe_end - o->sppe_begin);
-        h->slots[1] += (uint64_t) n;
-        hipLaunchKernelGGL(k_primary_edge_rev, dim3(launch_blocks(h, n)), dim3(kBlock), lds_bytes(cx, h), s, cx, sink, i0, n, 1.f / (float) o->sppe, adj_img,
-                           h->d_counters);
-        HIP_TRY(hipGetLastError());
-    }
-    if (o->sppse > 0 && o->sppse_end > o->sppse_begin && h->desc.num_sec_edges > 0 && o->integrator == PSDR_INTEGRATOR_DIRECT) {
-        LaunchCtx cx;
-        if (int rc = make_ctx(h, o, 2, cx)) return rc;
-        const long long i0 = WH * o->sppse_begin, n = WH * (o->sppse_end - o->sppse_begin);
-        h->slots[2] += (uint64_t) n;
-        hipLaunchKernelGGL(k_secondary_edge_rev, dim3(launch_blocks(h, n)), dim3(kBlock), lds_bytes(cx, h), s, cx, sink, i0, n, 1.f / (float) o->sppse,
-                           adj_img, h->d_counters);
-        HIP_TRY(hipGetLastError());
-    }
-    return 0;
+    return h->desc.env_emitter >= 0 ? render_rev<true>(h, o, adj_img, out_img, grads, s) : render_rev<false>(h, o, adj_img, out_img, grads, s);
 }
 
 int psdr_guide_build(psdr_scene_t h, const psdr_render_opts *o, const int32_t reso[4], int32_t nrounds, float *out_mass, void *stream) {

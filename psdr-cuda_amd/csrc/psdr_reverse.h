@@ -88,7 +88,8 @@ PSDR_HD void shading_normal_vjp(Sink &sink, int tri, const TriRow<float> &T, con
 // ------------------------------------------------------------------ BSDF with adjoints
 // Texture lookup adjoint: scatter a_out (C channels) to the texels, return d/d(u,v).
 template <class Sink, int C>
-PSDR_HD void bitmap_vjp(Sink &sink, const SceneView &sc, const int32_t *slot, float u, float v, const float *a_out, float &au, float &av) {
+PSDR_HD void bitmap_vjp(Sink &sink, const SceneView &sc, const int32_t *slot, float u, float v, const float *a_out, float &au, float &av,
+                        bool flip_v = true) {
     const int off = slot[0], w = slot[1], h = slot[2];
     if (w == 1 && h == 1) {
 #pragma unroll
@@ -96,7 +97,7 @@ PSDR_HD void bitmap_vjp(Sink &sink, const SceneView &sc, const int32_t *slot, fl
         return;
     }
     const float *tx = sc.d.texels;
-    float vv = -v;
+    float vv = flip_v ? -v : v;
     u = u - floorf(u); vv = vv - floorf(vv);
     u = u * (float) (w - 1); vv = vv * (float) (h - 1);
     int px = (int) floorf(u), py = (int) floorf(vv);
@@ -115,7 +116,36 @@ PSDR_HD void bitmap_vjp(Sink &sink, const SceneView &sc, const int32_t *slot, fl
         dv += a * ((w0x * v01 + w1x * v11) - (w0x * v00 + w1x * v10));
     }
     au += du * (float) (w - 1);
-    av += -dv * (float) (h - 1);        // v was negated (flip_v)
+    av += (flip_v ? -dv : dv) * (float) (h - 1);        // v was negated (flip_v)
+}
+
+// EnvironmentMap::eval_direction adjoint (envmap.cpp:41-59): scatters a_out (adjoint of the returned
+// radiance) to the map's texels, m_scale and m_from_world, returns the adjoint of the direction w.
+template <class Sink> PSDR_HD Vec3f env_eval_vjp(Sink &sink, const SceneView &sc, const Vec3f &w, const Vec3f &a_out) {
+    const float *f = sc.d.env_f;
+    const Vec3f v = env_mul3(f + PSDR_ENV_FROM_WORLD, w);
+    float tu = atan2f(v.x, -v.z) * kInvTwoPi, tv = safe_acos_(v.y) * kInvPi;
+    tu -= floorf(tu); tv -= floorf(tv);
+    const TangentView<0, true> tv0{};
+    float rgb[3];
+    bitmap_eval<float, 3>(sc, tv0, sc.d.env_tex, tu, tv, rgb, false);
+    const float scale = f[PSDR_ENV_SCALE];
+    sink.add_env(PSDR_ENV_SCALE, a_out.x * rgb[0] + a_out.y * rgb[1] + a_out.z * rgb[2]);
+    const float a_rgb[3] = {a_out.x * scale, a_out.y * scale, a_out.z * scale};
+    float a_tu = 0.f, a_tv = 0.f;
+    bitmap_vjp<Sink, 3>(sink, sc, sc.d.env_tex, tu, tv, a_rgb, a_tu, a_tv, false);
+    // tu = atan2(v.x, -v.z) / 2pi ; tv = acos(clamp(v.y)) / pi
+    const float r2 = v.x * v.x + v.z * v.z;
+    const float au = a_tu * kInvTwoPi / r2;
+    Vec3f a_v{au * (-v.z), 0.f, au * v.x};
+    if (v.y > -1.f && v.y < 1.f) a_v.y = -a_tv * kInvPi / sqrtf(1.f - v.y * v.y);
+    const float av3[3] = {a_v.x, a_v.y, a_v.z}, w3[3] = {w.x, w.y, w.z};
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) sink.add_env(PSDR_ENV_FROM_WORLD + r * 3 + c, av3[r] * w3[c]);
+    const float *m = f + PSDR_ENV_FROM_WORLD;
+    return {m[0] * a_v.x + m[3] * a_v.y + m[6] * a_v.z, m[1] * a_v.x + m[4] * a_v.y + m[7] * a_v.z, m[2] * a_v.x + m[5] * a_v.y + m[8] * a_v.z};
 }
 
 // value and partials of one RoughConductor quantity w.r.t. the packed inputs
@@ -130,7 +160,7 @@ template <class Sink> struct BsdfRev {
     Bsdf<float, float> b;
     PSDR_HD BsdfRev(const SceneView &s, int id) : sc(s), b(s, id) {}
 
-    PSDR_HD RcParams rc_params(const TangentView<0> &tv0, const Its<float> &its) const {
+    template <class TVT> PSDR_HD RcParams rc_params(const TVT &tv0, const Its<float> &its) const {
         RcParams p;
         p.au = b.tex1(sc, tv0, PSDR_SLOT_ALPHA_U, its); p.av = b.tex1(sc, tv0, PSDR_SLOT_ALPHA_V, its);
         p.eta = b.tex3(sc, tv0, PSDR_SLOT_ETA, its); p.k = b.tex3(sc, tv0, PSDR_SLOT_K, its);
@@ -139,7 +169,7 @@ template <class Sink> struct BsdfRev {
     }
 
     // adjoint of value = eval(its, wo): a_f (RGB) -> a_wi, a_wo, texels, a_uv
-    PSDR_HD void eval_vjp(Sink &sink, const TangentView<0> &tv0, const Its<float> &its, const Vec3f &wo, const Vec3f &af, Vec3f &awi,
+    template <class TVT> PSDR_HD void eval_vjp(Sink &sink, const TVT &tv0, const Its<float> &its, const Vec3f &wo, const Vec3f &af, Vec3f &awi,
                           Vec3f &awo, float &auvx, float &auvy) const {
         if (!(its.wi.z > 0.f && wo.z > 0.f)) return;
         if (b.type() == PSDR_BSDF_DIFFUSE) {
@@ -190,7 +220,7 @@ template <class Sink> struct BsdfRev {
     }
 
     // adjoint of pdf(its, wo) (only RoughConductor carries derivatives; Diffuse::__pdf is detached)
-    PSDR_HD void pdf_vjp(Sink &sink, const TangentView<0> &tv0, const Its<float> &its, const Vec3f &wo, float apdf, Vec3f &awi, Vec3f &awo,
+    template <class TVT> PSDR_HD void pdf_vjp(Sink &sink, const TVT &tv0, const Its<float> &its, const Vec3f &wo, float apdf, Vec3f &awi, Vec3f &awo,
                          float &auvx, float &auvy) const {
         if (b.type() == PSDR_BSDF_DIFFUSE || apdf == 0.f) return;
         const RcParams p = rc_params(tv0, its);
@@ -208,7 +238,7 @@ template <class Sink> struct BsdfRev {
 
     // adjoint of the SAMPLED pdf: pdf_s = pdf(its, wo_s(wi, alpha; xi))  (roughconductor.cpp:79-92 keeps this
     // dependency alive; Diffuse: constant)
-    PSDR_HD void sampled_pdf_vjp(Sink &sink, const TangentView<0> &tv0, const Its<float> &its, const float s[3], float apdf, Vec3f &awi,
+    template <class TVT> PSDR_HD void sampled_pdf_vjp(Sink &sink, const TVT &tv0, const Its<float> &its, const float s[3], float apdf, Vec3f &awi,
                                  float &auvx, float &auvy) const {
         if (b.type() == PSDR_BSDF_DIFFUSE || apdf == 0.f) return;
         using D5 = Dual<5>;
@@ -306,10 +336,14 @@ PSDR_HD Its<float> make_path_vertex(const SceneView &sc, const Vec3f &origin, in
 template <bool BACKWARD, class Sink>
 PSDR_HD VertexOut vertex_eval(Sink &sink, const SceneView &sc, TraversalStack &st, Rng &rng, const Its<float> &its, int nB, int nL,
                               const Vec3f &a_c, const Vec3f &a_f, VertexAdj &va, uint32_t &nrays) {
-    const TangentView<0> tv0{};
+    const TangentView<0, Sink::has_env> tv0{};
+    VertexOut out; out.c = Vec3f(0.f); out.f = Vec3f(0.f); out.next_valid = false;
+    // the bounding mesh of the environment map has no BSDF (direct.cpp:54-57): nothing is gathered there and
+    // the path ends (the caller stops on !next_valid, so the skipped random numbers are never missed)
+    if (sc.d.mesh_bsdf[its.mesh] < 0) return out;
+    constexpr bool kEnv = Sink::has_env;
     const BsdfRev<Sink> brev(sc, sc.d.mesh_bsdf[its.mesh]);
     const Bsdf<float, float> &bsdf = brev.b;
-    VertexOut out; out.c = Vec3f(0.f); out.f = Vec3f(0.f); out.next_valid = false;
     for (int i = 0; i < nB; ++i) {
         const float s[3] = {rng.next(), rng.next(), rng.next()};
         Vec3f wo_s; float pdf_s;
@@ -335,12 +369,16 @@ PSDR_HD VertexOut vertex_eval(Sink &sink, const SceneView &sc, TraversalStack &s
         const int e1 = sc.d.mesh_emitter[mesh1];
         Vec3f Le1(0.f);
         float w = 1.f / (float) nB, dw_dpdf0 = 0.f;
+        const bool env1 = kEnv && e1 >= 0 && e1 == sc.d.env_emitter;
         if (e1 >= 0) {
-            const ShNormal sn1 = shading_normal(T1, (tm & PSDR_TRI_FACE_NORMALS) != 0, h1.u, h1.v);
-            if (-dot(wo, sn1.n) > 0.f) { const float *r = sc.d.emitter_f + (size_t) e1 * PSDR_EMITTER_F_STRIDE; Le1 = Vec3f{r[0], r[1], r[2]}; }
+            if (env1) Le1 = env_eval_direction<float>(sc, tv0, wo);
+            else {
+                const ShNormal sn1 = shading_normal(T1, (tm & PSDR_TRI_FACE_NORMALS) != 0, h1.u, h1.v);
+                if (-dot(wo, sn1.n) > 0.f) { const float *r = sc.d.emitter_f + (size_t) e1 * PSDR_EMITTER_F_STRIDE; Le1 = Vec3f{r[0], r[1], r[2]}; }
+            }
             if (nL > 0) {
                 const float *ef = sc.d.emitter_f + (size_t) e1 * PSDR_EMITTER_F_STRIDE;
-                const float pe = ef[3] * ef[4];
+                const float pe = env1 ? env_position_pdf(sc, its.p, p1, T1.fn) : ef[3] * ef[4];
                 const float a2 = pdf0 * pdf0, b2 = pe * pe, den = a2 + b2;
                 w *= a2 / den;
                 dw_dpdf0 = (2.f * pdf0 * b2 / (den * den)) / (float) nB;
@@ -352,11 +390,15 @@ PSDR_HD VertexOut vertex_eval(Sink &sink, const SceneView &sc, TraversalStack &s
         Vec3f a_val = a_c * Le1 * w;
         const float a_w = dot(a_c, Le1 * valv);
         if (i == 0) acc(a_val, a_f);
-        if (e1 >= 0 && (Le1.x != 0.f || Le1.y != 0.f || Le1.z != 0.f)) {
+        Vec3f a_wo(0.f);
+        bool le_dir = false;
+        if (env1) {
+            if constexpr (kEnv) { a_wo = env_eval_vjp(sink, sc, wo, a_c * valv * w); le_dir = true; }
+        } else if (e1 >= 0 && (Le1.x != 0.f || Le1.y != 0.f || Le1.z != 0.f)) {
             const Vec3f gr = a_c * valv * w;
             sink.add_rad(e1, 0, gr.x); sink.add_rad(e1, 1, gr.y); sink.add_rad(e1, 2, gr.z);
         }
-        if (a_val.x == 0.f && a_val.y == 0.f && a_val.z == 0.f && a_w == 0.f) continue;
+        if (a_val.x == 0.f && a_val.y == 0.f && a_val.z == 0.f && a_w == 0.f && !le_dir) continue;
         float a_pdf0 = a_w * dw_dpdf0;
         const Vec3f a_fv = a_val * cfac;
         const float a_cfac = dot(a_val, f);
@@ -368,7 +410,7 @@ PSDR_HD VertexOut vertex_eval(Sink &sink, const SceneView &sc, TraversalStack &s
         const float a_cosv = a_G * (cosv < 0.f ? -1.f : 1.f) / (t1 * t1);
         float a_t1 = -2.f * a_G * G / t1;
         scatter_vec(sink, h1.tri, 18, wo * (-a_cosv));         // cosv = -fn . wo
-        Vec3f a_wo = T1.fn * (-a_cosv);
+        acc(a_wo, T1.fn * (-a_cosv));
         Vec3f a_wol(0.f);
         brev.eval_vjp(sink, tv0, its, wol, a_fv, va.wi, a_wol, va.u, va.v);
         brev.sampled_pdf_vjp(sink, tv0, its, s, a_pdf_s, va.wi, va.u, va.v);
@@ -385,16 +427,24 @@ PSDR_HD VertexOut vertex_eval(Sink &sink, const SceneView &sc, TraversalStack &s
         float r0 = s0, r1 = s1;                                // mirrors sample_emitter_position
         int e = 0; float epdf = 1.f;
         if (sc.d.num_emitters > 1) e = sample_reuse(sc.d.emitter_cmf, sc.d.emitter_pmf, sc.d.emitter_sum, sc.d.num_emitters, r1, epdf);
-        const float *ef = sc.d.emitter_f + (size_t) e * PSDR_EMITTER_F_STRIDE;
-        const int32_t *ei = sc.d.emitter_i + (size_t) e * PSDR_EMITTER_I_STRIDE;
-        float fp;
-        const int fidx = sample_reuse(sc.d.face_cmf + ei[3], sc.d.face_pmf + ei[3], ef[5], ei[2], r0, fp);
-        const float tt = sqrtf(fmaxf(1.f - r0, 0.f));
-        const float ba = 1.f - tt, bb = tt * r1;
-        const int etri = ei[1] + fidx;
-        const TriRow<float> Te = load_tri<float>(sc, tv0, etri);
-        const Vec3f psp = bary_point(Te.p0, Te.e1, Te.e2, ba, bb);
-        const float pspdf = ef[4] * epdf;
+        const bool env_s = kEnv && e == sc.d.env_emitter;       // sampled from the environment map: detached, J = 1
+        Vec3f psp; float pspdf, ba = 0.f, bb = 0.f, e_area = 1.f; int etri = -1;
+        if (env_s) {
+            const PosSample<float> pse = env_sample_position<float>(sc, its.p, r0, r1);
+            psp = pse.p; pspdf = pse.pdf * epdf;
+        } else {
+            const float *ef = sc.d.emitter_f + (size_t) e * PSDR_EMITTER_F_STRIDE;
+            const int32_t *ei = sc.d.emitter_i + (size_t) e * PSDR_EMITTER_I_STRIDE;
+            float fp;
+            const int fidx = sample_reuse(sc.d.face_cmf + ei[3], sc.d.face_pmf + ei[3], ef[5], ei[2], r0, fp);
+            const float tt = sqrtf(fmaxf(1.f - r0, 0.f));
+            ba = 1.f - tt; bb = tt * r1;
+            etri = ei[1] + fidx;
+            const TriRow<float> Te = load_tri<float>(sc, tv0, etri);
+            psp = bary_point(Te.p0, Te.e1, Te.e2, ba, bb);
+            pspdf = ef[4] * epdf;
+            e_area = Te.area;
+        }
         const Vec3f wov = psp - its.p;
         const float d2 = dot(wov, wov), dist = sqrtf(fmaxf(d2, 0.f));
         const Vec3f wo = wov / dist;
@@ -407,10 +457,17 @@ PSDR_HD VertexOut vertex_eval(Sink &sink, const SceneView &sc, TraversalStack &s
         const Vec3f p2 = bary_point(T2.p0, T2.e1, T2.e2, h2.u, h2.v);
         const float t2 = norm(p2 - its.p);
         if (!(t2 > dist - kShadowEpsilon && e2 >= 0)) continue;
-        const ShNormal sn2 = shading_normal(T2, (tm2 & PSDR_TRI_FACE_NORMALS) != 0, h2.u, h2.v);
-        if (!(-dot((p2 - its.p) / t2, sn2.n) > 0.f)) continue;         // Le = 0 from behind
-        const float *rr = sc.d.emitter_f + (size_t) e2 * PSDR_EMITTER_F_STRIDE;
-        const Vec3f Le2{rr[0], rr[1], rr[2]};
+        const bool env2 = kEnv && e2 == sc.d.env_emitter;
+        Vec3f Le2;
+        // the forward pass looks the map up along the path-space direction to the HIT point p2 (its1.wi)
+        const Vec3f dir2 = (p2 - its.p) / t2;
+        if (env2) Le2 = env_eval_direction<float>(sc, tv0, dir2);
+        else {
+            const ShNormal sn2 = shading_normal(T2, (tm2 & PSDR_TRI_FACE_NORMALS) != 0, h2.u, h2.v);
+            if (!(-dot((p2 - its.p) / t2, sn2.n) > 0.f)) continue;         // Le = 0 from behind
+            const float *rr = sc.d.emitter_f + (size_t) e2 * PSDR_EMITTER_F_STRIDE;
+            Le2 = Vec3f{rr[0], rr[1], rr[2]};
+        }
         const float cosv = -dot(T2.fn, wo);
         const float G = fabsf(cosv) / d2;
         const Vec3f wl = its.sh.to_local(wo);
@@ -428,18 +485,26 @@ PSDR_HD VertexOut vertex_eval(Sink &sink, const SceneView &sc, TraversalStack &s
         out.c = out.c + Le2 * valv * w;
         if (!BACKWARD) continue;
         const Vec3f gr = a_c * valv * w;
-        sink.add_rad(e2, 0, gr.x); sink.add_rad(e2, 1, gr.y); sink.add_rad(e2, 2, gr.z);
+        Vec3f a_wo(0.f);
+        if (env2) {
+            if constexpr (kEnv) {
+                const Vec3f a_dir2 = env_eval_vjp(sink, sc, dir2, gr);
+                const Vec3f a_p2 = (a_dir2 - dir2 * dot(dir2, a_dir2)) / t2;      // dir2 = (p2 - p) / |p2 - p|
+                scatter_point(sink, h2.tri, h2.u, h2.v, a_p2);
+                acc(va.p, -a_p2);
+            }
+        } else { sink.add_rad(e2, 0, gr.x); sink.add_rad(e2, 1, gr.y); sink.add_rad(e2, 2, gr.z); }
         const Vec3f a_val = a_c * Le2 * w;
         const float a_w = dot(a_c, Le2 * valv);
         const float a_pdfb = a_w * dw_dpdf1 * G;                        // pdf1 = pdfb * detach(G)
         const Vec3f a_fv = a_val * cfac;
         const float a_cfac = dot(a_val, f);
         const float a_G = a_cfac / pspdf;
-        sink.add_tri(etri, 21, a_cfac * cfac / Te.area);                // ps.J = A_e / detach(A_e)
+        if (!env_s) sink.add_tri(etri, 21, a_cfac * cfac / e_area);     // ps.J = A_e / detach(A_e)
         const float a_cosv = a_G * (cosv < 0.f ? -1.f : 1.f) / d2;
         float a_d2 = -a_G * G / d2;
         scatter_vec(sink, h2.tri, 18, wo * (-a_cosv));
-        Vec3f a_wo = T2.fn * (-a_cosv);
+        acc(a_wo, T2.fn * (-a_cosv));
         Vec3f a_wl(0.f);
         brev.eval_vjp(sink, tv0, its, wl, a_fv, va.wi, a_wl, va.u, va.v);
         brev.pdf_vjp(sink, tv0, its, wl, a_pdfb, va.wi, a_wl, va.u, va.v);
@@ -449,13 +514,15 @@ PSDR_HD VertexOut vertex_eval(Sink &sink, const SceneView &sc, TraversalStack &s
         const float a_dist = -dot(a_wo, wo) / dist;
         a_d2 += a_dist / (2.f * dist);
         acc(a_wov, wov * (2.f * a_d2));
-        scatter_point(sink, etri, ba, bb, a_wov);
+        if (!env_s) scatter_point(sink, etri, ba, bb, a_wov);
         acc(va.p, -a_wov);
     }
     return out;
 }
 
-struct NullSink {
+template <bool ENV = false> struct NullSink {
+    static constexpr bool has_env = ENV;
+    PSDR_HD void add_env(int, float) {}
     PSDR_HD void add_tri(int, int, float) {}
     PSDR_HD void add_texel(int, float) {}
     PSDR_HD void add_rad(int, int, float) {}
@@ -497,7 +564,9 @@ struct PrimaryGrad {
 };
 // Routes add_tri(primary triangle, word < 21) into registers, everything else to the real sink.
 template <class Sink> struct PrimarySink {
+    static constexpr bool has_env = Sink::has_env;
     Sink &real; PrimaryGrad &pg;
+    PSDR_HD void add_env(int w, float v) { real.add_env(w, v); }
     PSDR_HD PrimarySink(Sink &r, PrimaryGrad &p) : real(r), pg(p) {}
     PSDR_HD void add_tri(int tri, int word, float v) {
         if (tri == pg.tri && word < kPrimaryWords) { if (v != 0.f && isfinite(v)) pg.w[word] += v; }
@@ -513,7 +582,7 @@ template <class Sink> struct PrimarySink {
 // Back-propagates the adjoints of a PATH-SPACE vertex (k >= 1) into its triangle row and returns the
 // adjoint of the previous vertex' position (wi_k = to_local_k(-(p_k - p_{k-1}) / t)).
 template <class Sink> PSDR_HD Vec3f path_vertex_backward(Sink &sink, const SceneView &sc, const Its<float> &v, const Vec3f &prev_p, VertexAdj va) {
-    const TangentView<0> tv0{};
+    const TangentView<0, Sink::has_env> tv0{};
     const TriRow<float> T = load_tri<float>(sc, tv0, v.tri);
     const bool face = (sc.d.tri_mesh[v.tri] & PSDR_TRI_FACE_NORMALS) != 0;
     const ShNormal sn = shading_normal(T, face, v.hu, v.hv);
@@ -538,7 +607,7 @@ PSDR_HD Vec3f camera_sample_reverse(RealSink &real_sink, PrimaryGrad &pg, PathRe
     pg.clear();
     PrimarySink<RealSink> sink(real_sink, pg);
     using Sink = PrimarySink<RealSink>;
-    const TangentView<0> tv0{};
+    const TangentView<0, Sink::has_env> tv0{};
     Rng rng; rng.init(slot, jump);
     const float j0 = rng.next(), j1 = rng.next();
     const int W = sc.d.width;
@@ -596,18 +665,20 @@ PSDR_HD Vec3f camera_sample_reverse(RealSink &real_sink, PrimaryGrad &pg, PathRe
     const int depth = direct ? 1 : (lp.max_depth < kMaxRevDepth ? lp.max_depth : kMaxRevDepth);
 
     const int e0 = sc.d.mesh_emitter[its.mesh];
-    const bool le0 = !lp.hide_emitters && e0 >= 0 && its.wi.z > 0.f;
+    const bool env0 = Sink::has_env && !lp.hide_emitters && e0 >= 0 && e0 == sc.d.env_emitter;
+    const bool le0 = !lp.hide_emitters && e0 >= 0 && !env0 && its.wi.z > 0.f;
     if (le0) { const float *r = sc.d.emitter_f + (size_t) e0 * PSDR_EMITTER_F_STRIDE; result = Vec3f{r[0], r[1], r[2]}; }
+    if (env0) result = env_eval_direction<float>(sc, tv0, ray.d);
 
     // ---- sweep 1 (values): record (c_k, f_k), build the suffix radiances T_k
     int nv = 0;
     {
-        NullSink ns; VertexAdj dummy; dummy.clear();
+        NullSink<Sink::has_env> ns; VertexAdj dummy; dummy.clear();
         Rng r1 = rng;
         Its<float> cur = its;
         Vec3f beta(1.f);
         for (int k = 0; k < depth; ++k) {
-            const VertexOut vo = vertex_eval<false>(ns, sc, st, r1, cur, nB, nL, Vec3f(0.f), Vec3f(0.f), dummy, nrays);
+            const VertexOut vo = vertex_eval<false, NullSink<Sink::has_env>>(ns, sc, st, r1, cur, nB, nL, Vec3f(0.f), Vec3f(0.f), dummy, nrays);
             rec.put_cf(k, vo.c, vo.f); nv = k + 1;
             result = result + beta * vo.c;
             if (!vo.next_valid) break;
@@ -618,6 +689,8 @@ PSDR_HD Vec3f camera_sample_reverse(RealSink &real_sink, PrimaryGrad &pg, PathRe
     // masked(value, ~isfinite(value)) = 0 (integrator.cpp:87): a zeroed sample has no gradient either
     if (!(isfinite(result.x) && isfinite(result.y) && isfinite(result.z))) return zero_nonfinite(result);
     if (le0) { sink.add_rad(e0, 0, adj.x); sink.add_rad(e0, 1, adj.y); sink.add_rad(e0, 2, adj.z); }
+    Vec3f a_d_le0(0.f);                         // d Le(primary) / d ray direction (environment map seen directly)
+    if (env0) { if constexpr (Sink::has_env) a_d_le0 = env_eval_vjp(sink, sc, ray.d, adj); }
     // suffix radiances T_{k+1} overwrite c_k in place (T_nv = 0): afterwards rec.c(k) == T_{k+1}
     {
         Vec3f T(0.f);
@@ -645,7 +718,7 @@ PSDR_HD Vec3f camera_sample_reverse(RealSink &real_sink, PrimaryGrad &pg, PathRe
     }
     // ---- primary vertex: wi = to_local(-d), frame(sh_n(bu,bv)), uv(bu,bv), p = o + t d, (bu,bv,t) = MT(tri0, ray)
     {
-        Vec3f a_d = -(its.sh.s * va0.wi.x + its.sh.t * va0.wi.y + its.sh.n * va0.wi.z);
+        Vec3f a_d = a_d_le0 - (its.sh.s * va0.wi.x + its.sh.t * va0.wi.y + its.sh.n * va0.wi.z);
         acc(va0.s, ray.d * (-va0.wi.x)); acc(va0.t, ray.d * (-va0.wi.y)); acc(va0.n, ray.d * (-va0.wi.z));
         const Vec3f a_shn = va0.n + frame_vjp(sn0.n, va0.s, va0.t);
         float abu = 0.f, abv = 0.f;
@@ -672,7 +745,7 @@ PSDR_HD void primary_edge_reverse(Sink &sink, const SceneView &sc, TraversalStac
     const int W = sc.d.width, H = sc.d.height;
     const int ix = (int) floorf(px * (float) W), iy = (int) floorf(py * (float) H);
     const bool valid = ix >= 0 && ix < W && iy >= 0 && iy < H;
-    const TangentView<0> tv0{};
+    const TangentView<0, Sink::has_env> tv0{};
     const RayT<float> ray_p = primary_ray<float>(sc, tv0, px + kEdgeEpsilon * nx, py + kEdgeEpsilon * ny);
     const RayT<float> ray_n = primary_ray<float>(sc, tv0, px - kEdgeEpsilon * nx, py - kEdgeEpsilon * ny);
     const Vec3f Ln = Li<float, float>(sc, tv0, st, lp, rng, ray_n, valid, nrays);
@@ -694,7 +767,7 @@ PSDR_HD void primary_edge_reverse(Sink &sink, const SceneView &sc, TraversalStac
 template <class Sink>
 PSDR_HD void secondary_edge_reverse(Sink &sink, const SceneView &sc, TraversalStack &st, const float s3[3], float scale,
                                     const float *__restrict__ adj_img, uint32_t &nrays) {
-    const TangentView<0> tv0{};
+    const TangentView<0, Sink::has_env> tv0{};
     float s1 = s3[0], pdf0;
     const int k = sample_reuse(sc.d.sec_cmf, sc.d.sec_pmf, sc.d.sec_sum, sc.d.num_sec_edges, s1, pdf0);
     const float *se = sc.d.sec_edge + (size_t) k * PSDR_SEDGE_STRIDE;
@@ -741,6 +814,7 @@ PSDR_HD void secondary_edge_reverse(Sink &sink, const SceneView &sc, TraversalSt
     const float base_v = (its1c.t / dist) * (sinphi / sinphi2) * cos2;
     const Vec3f d0 = -cam.d;
     const Vec3f d0_local = its1c.sh.to_local(d0);
+    if (sc.d.mesh_bsdf[its1c.mesh] < 0) return;
     const Bsdf<float, float> bsdf(sc, sc.d.mesh_bsdf[its1c.mesh]);
     Vec3f bsdf_val = bsdf.eval(sc, tv0, its1c, d0_local, true);
     bsdf_val = bsdf_val * fabsf((its1c.wi.z * dot(d0, its1c.n)) / (d0_local.z * dot(dir, its1c.n)));

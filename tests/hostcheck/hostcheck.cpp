@@ -158,7 +158,9 @@ int hostcheck_guide(const psdr_scene_desc *d, const int *reso, int nrounds, floa
 
 namespace {
 struct HostSink {
+    static constexpr bool has_env = true;
     psdr_grads g;
+    void add_env(int w, float v) const { put(g.g_env_f, w, v); }
     static void put(float *b, size_t i, float v) { if (b && v != 0.f && std::isfinite(v)) b[i] += v; }
     void add_tri(int tri, int word, float v) const { put(g.g_tri_info, (size_t) tri * PSDR_TRI_STRIDE + word, v); }
     void add_texel(int idx, float v) const { put(g.g_texels, idx, v); }

@@ -18,7 +18,23 @@ CASES = [
     ("cbox_occluder", dict(bsdf_samples=1, light_samples=1), ["tri_info", "sec_edge", "prim_edge", "cam_to_world"], 4, 4),
     ("cbox", dict(integrator=_abi.INTEGRATOR_FIELD, field=_abi.FIELDS["position"]), ["tri_info", "cam_to_world"], 0, 0),
     ("cbox_bunny", dict(integrator=_abi.INTEGRATOR_FIELD, field=_abi.FIELDS["shNormal"]), ["tri_info"], 0, 0),
+    # environment map: lat-long texels, scale / rotation record, directions through the geometry and the camera
+    ("bunny_env", dict(bsdf_samples=1, light_samples=1), ["texels", "env_f", "tri_info", "cam_to_world"], 0, 0),
+    ("bunny_env", dict(integrator=_abi.INTEGRATOR_PATH, max_depth=3), ["texels", "env_f", "tri_info"], 0, 0),
+    ("cbox_env", dict(bsdf_samples=2, light_samples=2), ["texels", "env_f", "emitter_rad", "tri_info"], 0, 0),
+    ("cbox_env", dict(bsdf_samples=1, light_samples=1), ["tri_info", "sec_edge", "prim_edge"], 4, 4),
 ]
+
+
+def _tangents(tb, n):
+    """random tangent table; rows of the env-map bounding mesh stay zero: its vertices are constants in the
+    reference (scene.cpp:143-172) and the hand-written adjoints use identities (orthonormal frames) that
+    hold for tangents produced by the table chain, not for arbitrary ones on those rows"""
+    tan = random_tangents(tb, [n], seed=1)
+    if n == "tri_info" and tb.get("env_emitter", -1) >= 0:
+        mesh = (tb["tri_mesh"] & 0x3fffffff).long()
+        tan[n][tb["mesh_bsdf"][mesh] < 0] = 0.0
+    return tan
 
 
 def _setup(scene, kw, sppe, sppse, res=16, spp=4):
@@ -33,7 +49,7 @@ def _setup(scene, kw, sppe, sppse, res=16, spp=4):
 def test_dot_product_identity_host(scene, kw, names, sppe, sppse):
     tb, o, adj = _setup(scene, kw, sppe, sppse)
     for n in names:
-        tan = random_tangents(tb, [n], seed=1)
+        tan = _tangents(tb, n)
         img_f, dimg = host_render(tb, o, mode=1, tangents=tan)
         img_r, grads = host_render_rev(tb, o, adj, want=[n])
         lhs, rhs = float((adj.astype(np.float64) * dimg).sum()), dot_tables(grads, tan)
@@ -61,7 +77,7 @@ def test_dot_product_identity_gpu(scene, kw, names, sppe, sppse):
     g = GpuScene(tb)
     img_r, grads = g.render_d_rev(o, adj, want=names)
     for n in names:
-        tan = random_tangents(tb, [n], seed=1)
+        tan = _tangents(tb, n)
         img_f, dimg = g.render_d_fwd(o, [tan])
         lhs, rhs = float((adj.astype(np.float64) * dimg[0]).sum()), dot_tables(grads, tan)
         scale = float(np.abs(adj.astype(np.float64) * dimg[0]).sum())
