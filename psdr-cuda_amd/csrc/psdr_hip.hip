@@ -458,8 +458,11 @@ template <bool ENV> struct DeviceSink {
     }
 };
 
+#ifndef PSDR_WAVES_REV
+#define PSDR_WAVES_REV 2
+#endif
 template <bool ENV>
-__global__ __launch_bounds__(kBlock, 2) void k_camera_rev(LaunchCtx cx, DeviceSink<ENV> sink, int spp, int s_begin, int nsp, long long n, float inv_spp,
+__global__ __launch_bounds__(kBlock, PSDR_WAVES_REV) void k_camera_rev(LaunchCtx cx, DeviceSink<ENV> sink, int spp, int s_begin, int nsp, long long n, float inv_spp,
                                                        const float *__restrict__ adj_img, float *__restrict__ img,
                                                        unsigned long long *counters) {
     __shared__ float cache[kSinkCacheWords];

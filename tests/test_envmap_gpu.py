@@ -133,3 +133,18 @@ def test_python_surface_backward_env_radiance_scale_and_rotation():
     # image = scale * (linear in texels): <g_tex, texels> == <w, image>
     lhs = float((g_tex.astype(np.float64) * env.radiance.data.numpy()).sum())
     assert abs(lhs / float((wn * img.numpy()).sum()) - 1) < 1e-3
+
+
+def test_reference_ballroom_map_full_size_cells():
+    """the reference's 1024x512 PIZ panorama: 2046 x 1022 luminance cells (21-step binary search per light
+    sample), rough conductor alpha = 0.05"""
+    sc, _ = load_scene("bunny_env_ballroom", res=48, spp=8)
+    tb = sc.tables(0)
+    assert tb["env_cmf"].numel() == 2046 * 1022
+    g = GpuScene(tb)
+    for kind in ("direct11", "direct02", "path3"):
+        o = _abi.make_opts(spp=8, rng_offset=(1, 0, 0), **KINDS[kind])
+        ref = oracle.render(tb, o)
+        img = g.render_c(o)
+        bad = (np.abs(img - ref).max(1) > 1e-3 * (1 + np.abs(ref).max(1))).mean()
+        assert np.isfinite(img).all() and bad < 0.01 and rel_l2(img, ref) < 2e-2, kind
