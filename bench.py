@@ -97,7 +97,7 @@ def main():
     for c in range(3):
         t = torch.zeros_like(tb["texels"])
         t[c] = 1.0
-        tangent_sets.append([None, t, None, None, None, None])
+        tangent_sets.append([None, t, None, None, None, None, None])
 
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
     kern_ms = {"render_c": [], "render_d": []}
@@ -178,6 +178,33 @@ def main():
                "sample": "%d x (renderC + renderD fwd K=1) of the same scene at %dx%d spp=%d, oracle fp32, %d threads"
                          % (reps, args.res, args.res, cspp, cores)}
 
+    # the metric's parity half: gradient rel-L2 of the HIP path against the CPU oracle, same RNG streams,
+    # at a size the oracle finishes in a second (tests/ hold the full parity suite)
+    grad = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import oracle
+        gres, gspp = 64, 8
+        sc2 = psdr_cuda.Scene()
+        sc2.load_file(scene_path(args.scene), False)
+        sc2.opts.width = sc2.opts.height = gres
+        sc2.opts.spp, sc2.opts.sppe, sc2.opts.sppse, sc2.opts.log_level = gspp, 0, 0, 0
+        sc2.configure()
+        tb2 = sc2.tables(0)
+        o2 = integ._opts(sc2, with_edges=False)
+        ts2 = []
+        for c in range(3):
+            t = torch.zeros_like(tb2["texels"]); t[c] = 1.0
+            ts2.append([None, t, None, None, None, None, None])
+        _, dimgs = integ._render_fwd(sc2, tb2, o2, None, ts2)
+        worst = 0.0
+        for c in range(3):
+            ref = oracle.render(tb2, o2, mode=1, tangents={"texels": ts2[c][1]})[1].reshape(-1)
+            got = dimgs[c].cpu().numpy().astype(np.float64)
+            worst = max(worst, float(np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-30)))
+        grad = {"rel_l2": round(worst, 8), "bound": 1e-3,
+                "check": "d image / d albedo(r,g,b), %s %dx%d spp=%d PathTracer(max_depth=%d), HIP vs CPU oracle on the same sample streams"
+                         % (args.scene, gres, gres, gspp, args.max_depth)}
+
     if rank == 0:
         out = {
             "metric": "Mpath-samples/s renderC+renderD, cbox 512x512 spp=64; grad rel-L2 vs ref",
@@ -188,7 +215,7 @@ def main():
                                    % (args.scene, args.res, args.res, args.spp, args.max_depth),
                        "triangles": int(tb["num_tris"]), "global_spp": args.spp * world,
                        "parallelism": "spp-shard x%d, one all-reduce per render call" % world},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "grad_rel_l2": grad,
         }
         print(json.dumps(out))
     if dist:

@@ -708,9 +708,12 @@ PSDR_HD Vec3<M> Li(const SceneView &sc, const TVT &tv, TraversalStack &st, const
     // INTEG >= 0: integrator fixed at compile time (the camera kernels are specialised per integrator so
     // the other integrators' code does not occupy registers / instruction cache); -1: run-time switch
     const int integ = INTEG >= 0 ? INTEG : lp.integrator;
-    // renderD traces its primary ray in the solid-angle form (scene.cpp:355-376) also when only
-    // material parameters are differentiated: p = o + t d, (u,v,t) from Moeller-Trumbore
-    Its<G> its = intersect<G>(sc, tv, st, ray, active, is_ad<M>() ? kSolidAngle : kDetached, nrays);
+    // renderD traces its primary ray in the solid-angle form (scene.cpp:355-376: p = o + t d, (u,v,t) from a
+    // differentiable Moeller-Trumbore) when GEOMETRY carries tangents.  With material-only tangents the
+    // two forms have the same value and derivative, and the on-surface form p = p0 + u e1 + v e2 is used:
+    // o + t d sits up to ~1e-4 off the wall (fp32 t at distance ~1000), which lets ~1e-3 of the grazing
+    // continuation rays re-hit their own wall -- isolated O(1) sample flips between any two fp32 builds
+    Its<G> its = intersect<G>(sc, tv, st, ray, active, is_ad<G>() ? kSolidAngle : kDetached, nrays);
     active = active && its.valid;
     if (integ == PSDR_INTEGRATOR_FIELD) {
         if (!active) return zero3<M>();
@@ -764,7 +767,7 @@ PSDR_HD Vec3<M> wavefront_camera_vertex(const SceneView &sc, const TVT &tv, Trav
     const int W = sc.d.width;
     const float sx = ((float) (pixel % W) + j0) / (float) W, sy = ((float) (pixel / W) + j1) / (float) sc.d.height;
     const RayT<float> ray = primary_ray<float>(sc, tv, sx, sy);
-    const Its<float> its = intersect<float>(sc, tv, st, ray, true, is_ad<M>() ? kSolidAngle : kDetached, nrays);
+    const Its<float> its = intersect<float>(sc, tv, st, ray, true, kDetached, nrays);     // geometry is plain fp32 here, see Li
     alive = false;
     if (!its.valid) return zero3<M>();
     Vec3<M> result = lp.hide_emitters ? zero3<M>() : Le<M>(sc, tv, its, true);

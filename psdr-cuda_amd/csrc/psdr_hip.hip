@@ -469,6 +469,7 @@ __global__ __launch_bounds__(kBlock, PSDR_WAVES_REV) void k_camera_rev(LaunchCtx
     TraversalStack st; setup_lds(cx, st);
     sink.begin(cache);
     uint32_t nrays = 0;
+    const bool geo = sink.g.g_tri_info != nullptr || sink.g.g_cam_to_world != nullptr;
     const long long nceil = (n + kBlock - 1) / kBlock * kBlock;
     for (long long j = (long long) blockIdx.x * kBlock + threadIdx.x; j < nceil; j += (long long) gridDim.x * kBlock) {
         const bool in = j < n;
@@ -484,7 +485,7 @@ __global__ __launch_bounds__(kBlock, PSDR_WAVES_REV) void k_camera_rev(LaunchCtx
             const uint64_t slot = (uint64_t) pixel * (uint64_t) spp + (uint64_t) s;
             const float *a = adj_img + (size_t) pixel * 3;
             const Vec3f adj{a[0] * inv_spp, a[1] * inv_spp, a[2] * inv_spp};
-            const Vec3f r = camera_sample_reverse(sink, pg, rec, cx.sc, st, cx.lp, cx.jump, pixel, slot, adj, nrays);
+            const Vec3f r = camera_sample_reverse(sink, pg, rec, cx.sc, st, cx.lp, cx.jump, pixel, slot, adj, nrays, geo);
             v[0] = r.x * inv_spp; v[1] = r.y * inv_spp; v[2] = r.z * inv_spp;
         }
         // primary-triangle row: one add per run of lanes that hit the same triangle

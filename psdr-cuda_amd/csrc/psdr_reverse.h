@@ -601,9 +601,11 @@ template <class Sink> PSDR_HD Vec3f path_vertex_backward(Sink &sink, const Scene
 
 // One camera sample in reverse mode (Integrator::__render<true> + enoki.backward).
 //   adj = dLoss/d(pixel) / spp.   Returns the primal sample value.
+//   geo: a geometry gradient (triangle table / camera) is wanted -> solid-angle form of the primary hit and
+//        its adjoint chain; otherwise the on-surface form, exactly like forward mode (psdr_device.h Li)
 template <class RealSink>
 PSDR_HD Vec3f camera_sample_reverse(RealSink &real_sink, PrimaryGrad &pg, PathRec &rec, const SceneView &sc, TraversalStack &st, const LiParams &lp,
-                                    const RngJump &jump, int pixel, uint64_t slot, const Vec3f &adj, uint32_t &nrays) {
+                                    const RngJump &jump, int pixel, uint64_t slot, const Vec3f &adj, uint32_t &nrays, bool geo = true) {
     pg.clear();
     PrimarySink<RealSink> sink(real_sink, pg);
     using Sink = PrimarySink<RealSink>;
@@ -623,11 +625,17 @@ PSDR_HD Vec3f camera_sample_reverse(RealSink &real_sink, PrimaryGrad &pg, PathRe
     const TriRow<float> T0 = load_tri<float>(sc, tv0, h0.tri);
     // solid-angle form (scene.cpp:355-376)
     float bu, bv, t0;
-    moeller_trumbore(T0.p0, T0.e1, T0.e2, ray, bu, bv, t0);
     Its<float> its;
+    if (geo) {
+        moeller_trumbore(T0.p0, T0.e1, T0.e2, ray, bu, bv, t0);
+        its.p = ray.o + ray.d * t0;
+    } else {
+        bu = h0.u; bv = h0.v;
+        its.p = bary_point(T0.p0, T0.e1, T0.e2, bu, bv);
+        t0 = norm(its.p - ray.o);
+    }
     its.valid = true; its.tri = h0.tri; its.mesh = tm0 & ~PSDR_TRI_FACE_NORMALS; its.hu = h0.u; its.hv = h0.v;
     its.n = T0.fn; its.J = 1.f; its.t = t0;
-    its.p = ray.o + ray.d * t0;
     const ShNormal sn0 = shading_normal(T0, face0, bu, bv);
     its.sh = Frame<float>(sn0.n);
     its.wi = its.sh.to_local(-ray.d);
@@ -649,6 +657,7 @@ PSDR_HD Vec3f camera_sample_reverse(RealSink &real_sink, PrimaryGrad &pg, PathRe
             default: result = Vec3f{its.uvx, its.uvy, 0.f}; va0.u = adj.x; va0.v = adj.y; break;
         }
         if (!(isfinite(result.x) && isfinite(result.y) && isfinite(result.z))) return zero_nonfinite(result);
+        if (!geo) return result;
         // fold a_t into the chain below through p = o + t d  (depth == t)
         const Vec3f a_shn = va0.n + frame_vjp(sn0.n, va0.s, va0.t);
         float abu = 0.f, abv = 0.f;
@@ -717,7 +726,7 @@ PSDR_HD Vec3f camera_sample_reverse(RealSink &real_sink, PrimaryGrad &pg, PathRe
         }
     }
     // ---- primary vertex: wi = to_local(-d), frame(sh_n(bu,bv)), uv(bu,bv), p = o + t d, (bu,bv,t) = MT(tri0, ray)
-    {
+    if (geo) {
         Vec3f a_d = a_d_le0 - (its.sh.s * va0.wi.x + its.sh.t * va0.wi.y + its.sh.n * va0.wi.z);
         acc(va0.s, ray.d * (-va0.wi.x)); acc(va0.t, ray.d * (-va0.wi.y)); acc(va0.n, ray.d * (-va0.wi.z));
         const Vec3f a_shn = va0.n + frame_vjp(sn0.n, va0.s, va0.t);

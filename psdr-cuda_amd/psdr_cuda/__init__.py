@@ -6,7 +6,8 @@ import enoki.cuda  # noqa: F401
 import enoki.cuda_autodiff  # noqa: F401
 
 from .core import (Object, RenderOption, Bitmap1fD, Bitmap3fD, DiscreteDistribution,  # noqa: F401
-                   HyperCubeDistribution2f, HyperCubeDistribution3f)
+                   HyperCubeDistribution2f, HyperCubeDistribution3f, RayC, RayD, FrameC, FrameD,
+                   SampleRecordC, SampleRecordD, PositionSampleC, PositionSampleD)
 from .scene import (BSDF, Diffuse, DiffuseBSDF, RoughConductor, RoughConductorBSDF, Emitter, AreaLight, EnvironmentMap,  # noqa: F401
                     Sensor, PerspectiveCamera, Mesh, Scene, PositionSample, BoundarySegSampleDirect)
 from .integrator import Integrator, FieldExtractionIntegrator, DirectIntegrator, PathTracer  # noqa: F401

@@ -61,6 +61,74 @@ def _to_tensor(x, cols=None):
     return t
 
 
+# ------------------------------------------------------------------ rays, frames, records
+def _make_ray(name, V3, F):
+    class _Ray:
+        """Ray<ad> (reference include/psdr/core/ray.h:8-29; src/psdr.cpp:76-86): o, d, tmax, reversed()."""
+
+        def __init__(self, o=None, d=None, tmax=None):
+            self.o, self.d = o, d
+            if tmax is None and o is not None:
+                tmax = F._wrap(torch.full((ek.slices(o),), float("inf"), device=o.t.device))
+            self.tmax = tmax
+
+        def __call__(self, t):
+            return V3._wrap(self.d.t * (t.t if isinstance(t, ek.ArrayBase) else t).reshape(-1, 1) + self.o.t)
+
+        def reversed(self):
+            return type(self)(self.o, V3._wrap(-self.d.t), self.tmax)
+    _Ray.__name__ = _Ray.__qualname__ = name
+    return _Ray
+
+
+def _make_frame(name, V3):
+    class _Frame:
+        """Frame_ (reference include/psdr/core/frame.h:9-60; src/psdr.cpp:88-100): orthonormal basis around n
+        by Duff et al. (coordinate_system), to_local / to_world."""
+
+        def __init__(self, v=None):
+            self.s = self.t = self.n = None
+            if v is not None:
+                n = v.t if isinstance(v, ek.ArrayBase) else torch.as_tensor(v, dtype=torch.float32).reshape(-1, 3)
+                nx, ny, nz = n[:, 0], n[:, 1], n[:, 2]
+                sign = torch.where(nz >= 0, torch.ones_like(nz), -torch.ones_like(nz))
+                a = -1.0 / (sign + nz)
+                b = nx * ny * a
+                self.s = V3._wrap(torch.stack([sign * nx * nx * a + 1.0, sign * b, -sign * nx], dim=-1))
+                self.t = V3._wrap(torch.stack([b, sign + ny * ny * a, -ny], dim=-1))
+                self.n = V3._wrap(n)
+
+        def to_local(self, v):
+            return V3._wrap(torch.stack([(v.t * self.s.t).sum(-1), (v.t * self.t.t).sum(-1), (v.t * self.n.t).sum(-1)], dim=-1))
+
+        def to_world(self, v):
+            return V3._wrap(self.s.t * v.t[:, 0:1] + self.t.t * v.t[:, 1:2] + self.n.t * v.t[:, 2:3])
+    _Frame.__name__ = _Frame.__qualname__ = name
+    return _Frame
+
+
+RayC, RayD = _make_ray("RayC", Vector3fC, FloatC), _make_ray("RayD", Vector3fD, FloatD)
+FrameC, FrameD = _make_frame("FrameC", Vector3fC), _make_frame("FrameD", Vector3fD)
+
+
+class SampleRecordC:
+    """SampleRecord_ (reference include/psdr/core/records.h:10-17): pdf, is_valid"""
+    pdf = is_valid = None
+
+
+class SampleRecordD(SampleRecordC):
+    pass
+
+
+class PositionSampleC(SampleRecordC):
+    """PositionSample_ (records.h:20-32): pdf, is_valid, p, n, J"""
+    p = n = J = None
+
+
+class PositionSampleD(SampleRecordD):
+    p = n = J = None
+
+
 class _Bitmap(Object):
     """Bitmap<channels> (reference include/psdr/core/bitmap.h:10-37, src/core/bitmap.cpp:9-89).
     `data` is an enoki-shim array: Float32 (1 channel) or Vector3f (3 channels) with w*h slices."""

@@ -16,7 +16,7 @@ import torch
 
 import enoki as ek
 from . import _abi
-from .core import (Object, RenderOption, Bitmap1fD, Bitmap3fD, DiscreteDistribution, psdr_assert,
+from .core import (Object, RenderOption, Bitmap1fD, Bitmap3fD, DiscreteDistribution, psdr_assert, PositionSampleC, PositionSampleD,
                    FloatC, FloatD, Vector2fD, Vector3fC, Vector3fD, Matrix4fD, IntC)
 
 Epsilon = 1e-5
@@ -317,9 +317,7 @@ class PerspectiveCamera(Sensor):
         return out
 
 
-class PositionSample:
-    """PositionSample_ (include/psdr/core/records.h:20-32): pdf, is_valid, p, n, J."""
-    pdf = is_valid = p = n = J = None
+PositionSample = PositionSampleD      # kept as an alias (older name of this build)
 
 
 class BoundarySegSampleDirect:
@@ -588,7 +586,7 @@ class Mesh(Object):
         a, b = 1.0 - t, t * s[:, 1].detach()
         ti = self._triangle_info if ad else self._triangle_info.detach()
         row = ti[idx]
-        ps = PositionSample()
+        ps = PositionSampleD() if ad else PositionSampleC()
         ps.p = (Vector3fD if ad else Vector3fC)._wrap(row[:, 0:3] + a.unsqueeze(-1) * row[:, 3:6] + b.unsqueeze(-1) * row[:, 6:9])
         ps.n = (Vector3fD if ad else Vector3fC)._wrap(row[:, 18:21])
         ps.J = (FloatD if ad else FloatC)._wrap(row[:, 21] / row[:, 21].detach() if ad else torch.ones_like(u))

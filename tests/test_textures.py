@@ -44,12 +44,14 @@ def test_textured_render_host_vs_oracle(kw):
     tan = random_tangents(tb, ["texels"], seed=3)
     ref_img, ref_d = oracle.render(tb, o, mode=1, tangents=tan)
     img, dimg = host_render(tb, o, mode=1, tangents=tan)
-    tol = 3e-2 if kw.get("integrator") == _abi.INTEGRATOR_PATH else 1e-3   # PathTracer D mode: off-surface primary vertex
-    assert rel_l2(dimg, ref_d) < tol and np.abs(ref_d).max() > 0
+    assert rel_l2(dimg, ref_d) < 1e-3 and np.abs(ref_d).max() > 0
     adj = np.random.default_rng(1).random((24 * 24, 3)).astype(np.float32)
-    _, grads = host_render_rev(tb, o, adj, want=["texels", "tri_info"])
+    # (the primary hit is evaluated on-surface when only material tables are differentiated and in the solid-angle
+    # form when a geometry table is: forward and reverse follow the same rule, so compare like with like)
+    _, grads = host_render_rev(tb, o, adj, want=["texels"])
     lhs, rhs = float((adj.astype(np.float64) * dimg).sum()), dot_tables(grads, tan)
     assert abs(lhs - rhs) < 1e-4 * np.abs(adj * dimg).sum()
+    _, grads = host_render_rev(tb, o, adj, want=["texels", "tri_info"])
     # uv adjoint path: a geometry tangent moves the texture lookup of the primary hit
     tg = random_tangents(tb, ["tri_info"], seed=4)
     ref_img, ref_dg = oracle.render(tb, o, mode=1, tangents=tg)
