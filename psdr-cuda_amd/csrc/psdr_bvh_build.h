@@ -22,6 +22,8 @@ struct Builder {
     std::vector<float4> btris;
     int max_depth = 0;
     float pad = 0.f;
+    static constexpr int kMaxLeaf = 4;              // leaf encoding holds 1..8
+    static constexpr float kTraversalCost = 1.0f;   // node visit / triangle test (both ~40-50 VALU ops)
 
     static float area(const float *lo, const float *hi) {
         const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
@@ -55,11 +57,12 @@ struct Builder {
         float clo[3], chi[3];
         bounds(first, count, lo, hi, clo, chi);
         max_depth = std::max(max_depth, depth);
-        if (count <= 4) {
+        auto leaf_here = [&]() {
             const int32_t leaf = make_leaf(first, count);
             for (int k = 0; k < 3; ++k) { lo[k] -= pad; hi[k] += pad; }
             return leaf;
-        }
+        };
+        if (count == 1) return leaf_here();
         int mid = -1;
         int ax = 0;
         for (int k = 1; k < 3; ++k) if (chi[k] - clo[k] > chi[ax] - clo[ax]) ax = k;
@@ -93,6 +96,14 @@ struct Builder {
                     if (cost < best) { best = cost; best_ax = a; best_b = b; }
                 }
             }
+            // SAH termination for small groups: a leaf of n triangles costs n tests; splitting costs one node
+            // visit (two slab tests, an LDS stack push) plus the area-weighted tests of the children.  Large flat
+            // primitives (walls) end up one quad per leaf instead of sharing a room-sized box with their neighbours.
+            if (count <= kMaxLeaf) {
+                const float parent = area(lo, hi);
+                const float split_cost = best_ax >= 0 && parent > 0.f ? kTraversalCost + best / parent : INFINITY;
+                if (!(split_cost < (float) count)) return leaf_here();
+            }
             if (best_ax >= 0) {
                 const float scale = NB / (chi[best_ax] - clo[best_ax]);
                 auto it = std::partition(order.begin() + first, order.begin() + first + count, [&](int id) {
@@ -103,6 +114,7 @@ struct Builder {
                 if (mid == first || mid == first + count) mid = -1;
             }
         }
+        if (mid < 0 && count <= kMaxLeaf) return leaf_here();
         if (mid < 0) {   // median split keeps the depth bounded
             mid = first + count / 2;
             std::nth_element(order.begin() + first, order.begin() + mid, order.begin() + first + count,
@@ -135,6 +147,7 @@ struct Builder {
         }
         const float ext = std::max(shi[0] - slo[0], std::max(shi[1] - slo[1], shi[2] - slo[2]));
         pad = std::max(1e-6f, 1e-5f * ext);       // keeps flat (axis-aligned) triangles inside a non-degenerate slab
+        nodes.clear(); btris.clear();
         nodes.reserve(T); btris.reserve((size_t) T * 3);
         float lo[3], hi[3];
         root = build(0, T, 0, lo, hi);

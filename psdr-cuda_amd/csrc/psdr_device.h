@@ -70,6 +70,8 @@ PSDR_HD int __float_as_int_hd(float f) { union { float f; int i; } c; c.f = f; r
 
 PSDR_HD float slab(const float *lo, const float *hi, const Vec3f &o, const Vec3f &inv, float tmax) {
     // returns entry distance or +inf if the box is missed.  NaNs (0*inf) drop out of fmin/fmax.
+    // (lo - o) * inv is kept as two operations: folding it into fma(lo, inv, -o * inv) loses the exact
+    // difference near the origin of the ray and was measured 2.5x SLOWER on cbox_bunny paths.
     const float ax = (lo[0] - o.x) * inv.x, bx = (hi[0] - o.x) * inv.x;
     const float ay = (lo[1] - o.y) * inv.y, by = (hi[1] - o.y) * inv.y;
     const float az = (lo[2] - o.z) * inv.z, bz = (hi[2] - o.z) * inv.z;
@@ -85,8 +87,32 @@ PSDR_HD Hit closest_hit(const SceneView &sc, TraversalStack &st, const Vec3f &o,
     const Vec3f inv{1.f / d.x, 1.f / d.y, 1.f / d.z};
     int sp = 0;
     int32_t cur = sc.root;
-    for (;;) {
-        if (cur < 0) {
+    constexpr int32_t kDone = 0x7fffffff;        // never a node index (node count < 2^28)
+    // "while-while" traversal: every lane first walks inner nodes until it holds a leaf (or is done), THEN
+    // the wave tests leaf triangles together -- the two phases have very different lengths, and in one
+    // merged loop lanes sitting at a leaf would idle through the others' node steps and vice versa.
+    while (cur != kDone) {
+        while (cur >= 0 && cur != kDone) {
+            BvhNode n;
+#if defined(__HIP_DEVICE_COMPILE__)
+            if (cur < sc.n_lnodes) n = reinterpret_cast<const BvhNode *>(psdr_dyn_lds + sc.off_lnodes)[cur];
+            else
+#endif
+                n = sc.nodes[cur];
+            const float t0 = slab(n.lo0, n.hi0, o, inv, best.t), t1 = slab(n.lo1, n.hi1, o, inv, best.t);
+            const bool h0 = t0 < INFINITY, h1 = t1 < INFINITY;
+            if (h0 && h1) {
+                const bool first0 = t0 <= t1;
+                st.put(sp++, first0 ? n.c1 : n.c0);
+                cur = first0 ? n.c0 : n.c1;
+            } else if (h0 || h1) {
+                cur = h0 ? n.c0 : n.c1;
+            } else {
+                cur = sp > 0 ? st.get(--sp) : kDone;
+            }
+        }
+        if (cur == kDone) break;
+        {
             const int enc = ~cur, first = enc >> 3, cnt = (enc & 7) + 1;
 #if defined(__HIP_DEVICE_COMPILE__)
             const bool staged = first + cnt <= sc.n_lbtris;
@@ -99,7 +125,8 @@ PSDR_HD Hit closest_hit(const SceneView &sc, TraversalStack &st, const Vec3f &o,
                 else
 #endif
                 { a = sc.btris[(first + i) * 3]; b = sc.btris[(first + i) * 3 + 1]; c = sc.btris[(first + i) * 3 + 2]; }
-                // Moeller-Trumbore (the OptiX built-in triangle test is closed source)
+                // Moeller-Trumbore (the OptiX built-in triangle test is closed source).  A precomputed plane form
+                // (18 FMAs) was measured: no faster here (the loop is latency-, not ALU-bound) and less accurate.
                 const Vec3f e1{b.x, b.y, b.z}, e2{c.x, c.y, c.z};
                 const Vec3f h = cross(d, e2);
                 const float det = dot(e1, h);
@@ -114,27 +141,7 @@ PSDR_HD Hit closest_hit(const SceneView &sc, TraversalStack &st, const Vec3f &o,
                     best.t = t; best.u = u; best.v = v; best.tri = __float_as_int_hd(a.w);
                 }
             }
-            if (sp == 0) break;
-            cur = st.get(--sp);
-            continue;
-        }
-        BvhNode n;
-#if defined(__HIP_DEVICE_COMPILE__)
-        if (cur < sc.n_lnodes) n = reinterpret_cast<const BvhNode *>(psdr_dyn_lds + sc.off_lnodes)[cur];
-        else
-#endif
-            n = sc.nodes[cur];
-        const float t0 = slab(n.lo0, n.hi0, o, inv, best.t), t1 = slab(n.lo1, n.hi1, o, inv, best.t);
-        const bool h0 = t0 < INFINITY, h1 = t1 < INFINITY;
-        if (h0 && h1) {
-            const bool first0 = t0 <= t1;
-            st.put(sp++, first0 ? n.c1 : n.c0);
-            cur = first0 ? n.c0 : n.c1;
-        } else if (h0 || h1) {
-            cur = h0 ? n.c0 : n.c1;
-        } else {
-            if (sp == 0) break;
-            cur = st.get(--sp);
+            cur = sp > 0 ? st.get(--sp) : kDone;
         }
     }
     return best;
