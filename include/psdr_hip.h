@@ -133,6 +133,11 @@ typedef struct psdr_scene_desc {
     const float   *env_f;                /* [PSDR_ENV_WORDS] */
     const float   *env_cmf, *env_pmf;    /* [env_reso[0]*env_reso[1]] luminance*sin(theta), envmap.cpp:17-21 */
     float          env_sum;
+    /* Bit t set = a BSDF of type t (PSDR_BSDF_*) occurs in bsdf_rec; 0 = unknown (the library then keeps
+       the code of every BSDF type in its kernels).  A host that knows its materials sets it so that, e.g.,
+       an all-diffuse scene runs the kernel variant compiled without the GGX / conductor-Fresnel code.
+       Bits that are clear MUST be right: a cleared type is evaluated as diffuse. */
+    uint32_t       material_mask;
 } psdr_scene_desc;
 
 /* psdr_render_opts.flags: execution strategy of the PathTracer interior term.

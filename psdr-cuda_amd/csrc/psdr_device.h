@@ -41,12 +41,17 @@ struct SceneView {
 extern __shared__ __attribute__((aligned(16))) unsigned char psdr_dyn_lds[];
 #endif
 
-// K sets of forward-mode tangent tables (struct of K pointer groups).  ENV: the scene has an
-// EnvironmentMap -- a compile-time property of the kernel instance, carried by the type every estimator
-// already receives, so that scenes without one (the common case) do not pay registers for the
-// lat-long lookup / cell sampling code (C2 renderD K=3: 5.3 ms without, 7.1 ms with a run-time branch).
-template <int K, bool ENV = false> struct TangentView {
-    static constexpr bool has_env = ENV;
+// K sets of forward-mode tangent tables (struct of K pointer groups).  FLAGS: compile-time properties of
+// the SCENE the kernel instance serves, carried by the type every estimator already receives, so that
+// scenes without the feature do not pay registers / instruction cache for its code:
+//   kSceneEnv    an EnvironmentMap exists (lat-long lookup, cell sampling; C2 renderD K=3: 5.3 ms without
+//                the code, 7.1 ms with a run-time branch)
+//   kSceneRough  a RoughConductor BSDF exists (GGX + conductor Fresnel, and in reverse mode their Dual<8>
+//                adjoints: diffuse-only scenes run renderD K=3 15 % and reverse mode 40 % faster without)
+constexpr int kSceneEnv = 1, kSceneRough = 2, kSceneAll = 3;
+template <int K, int FLAGS = kSceneRough> struct TangentView {
+    static constexpr int flags = FLAGS;
+    static constexpr bool has_env = (FLAGS & kSceneEnv) != 0, has_rough = (FLAGS & kSceneRough) != 0;
     psdr_tangents t[K > 0 ? K : 1];
 };
 
@@ -156,17 +161,17 @@ PSDR_HD Hit closest_hit(const SceneView &sc, TraversalStack &st, const Vec3f &o,
 // the geometry then stays in plain fp32 registers.
 template <class R> struct Loader;
 template <> struct Loader<float> {
-    template <int KK, bool E> static PSDR_HD float f(const float *tab, const TangentView<KK, E> &, const float *const psdr_tangents::*, size_t i) { return tab[i]; }
+    template <int KK, int E> static PSDR_HD float f(const float *tab, const TangentView<KK, E> &, const float *const psdr_tangents::*, size_t i) { return tab[i]; }
 };
 template <int K> struct Loader<Dual<K>> {
-    template <bool E> static PSDR_HD Dual<K> f(const float *tab, const TangentView<K, E> &tv, const float *const psdr_tangents::*m, size_t i) {
+    template <int E> static PSDR_HD Dual<K> f(const float *tab, const TangentView<K, E> &tv, const float *const psdr_tangents::*m, size_t i) {
         Dual<K> r; r.v = tab[i];
 #pragma unroll
         for (int k = 0; k < K; ++k) { const float *p = tv.t[k].*m; r.d[k] = p ? p[i] : 0.f; }
         return r;
     }
 };
-template <class R, bool ENV = false> using TV = TangentView<ad_traits<R>::K, ENV>;
+template <class R, int FLAGS = kSceneRough> using TV = TangentView<ad_traits<R>::K, FLAGS>;
 template <class R, class TVT> PSDR_HD R ldf(const float *tab, const TVT &tv, const float *const psdr_tangents::*m, size_t i) {
     return Loader<R>::f(tab, tv, m, i);
 }
@@ -436,6 +441,8 @@ template <class G, class M> struct Bsdf {
     const int32_t *rec;
     PSDR_HD Bsdf(const SceneView &sc, int id) : rec(sc.d.bsdf_rec + (size_t) (id < 0 ? 0 : id) * PSDR_BSDF_STRIDE) {}
     PSDR_HD int type() const { return rec[0]; }
+    // diffuse unless the kernel instance carries the rough-conductor code (TangentView FLAGS)
+    template <class TVT> PSDR_HD bool is_diffuse(const TVT &) const { return !TVT::has_rough || rec[0] == PSDR_BSDF_DIFFUSE; }
     PSDR_HD const int32_t *slot(int s) const { return rec + 1 + 3 * s; }
     template <class TVT> PSDR_HD Vec3<M> tex3(const SceneView &sc, const TVT &tv, int s, const Its<G> &its) const {
         M o[3]; bitmap_eval<M, 3>(sc, tv, slot(s), its.uvx, its.uvy, o); return {o[0], o[1], o[2]};
@@ -446,7 +453,7 @@ template <class G, class M> struct Bsdf {
     // Diffuse::__eval (diffuse.cpp:25-35) / RoughConductor::__eval (roughconductor.cpp:40-58); value = f * cos(theta_o)
     template <class TVT> PSDR_HD Vec3<M> eval(const SceneView &sc, const TVT &tv, const Its<G> &its, const Vec3<G> &wo, bool active) const {
         if (!(active && val(its.wi.z) > 0.f && val(wo.z) > 0.f)) return zero3<M>();
-        if (type() == PSDR_BSDF_DIFFUSE) return tex3(sc, tv, PSDR_SLOT_REFLECTANCE, its) * (wo.z * kInvPi);
+        if (is_diffuse(tv)) return tex3(sc, tv, PSDR_SLOT_REFLECTANCE, its) * (wo.z * kInvPi);
         const GGX<M> g{tex1(sc, tv, PSDR_SLOT_ALPHA_U, its), tex1(sc, tv, PSDR_SLOT_ALPHA_V, its)};
         const Vec3<M> wi_m = to_m3<M>(its.wi), wo_m = to_m3<M>(wo);
         const Vec3<M> H = normalize(wo_m + wi_m);
@@ -460,7 +467,7 @@ template <class G, class M> struct Bsdf {
     }
     // Diffuse::__pdf (diffuse.cpp:70-81: detached) / RoughConductor::__pdf (roughconductor.cpp:61-75: mask not applied)
     template <class TVT> PSDR_HD M pdf(const SceneView &sc, const TVT &tv, const Its<G> &its, const Vec3<G> &wo, bool active) const {
-        if (type() == PSDR_BSDF_DIFFUSE) {
+        if (is_diffuse(tv)) {
             const float ci = val(its.wi.z), co = val(wo.z);
             return M((active && ci > 0.f && co > 0.f) ? kInvPi * co : 0.f);
         }
@@ -474,7 +481,7 @@ template <class G, class M> struct Bsdf {
     // BSDF is re-evaluated from the hit points) and its pdf as M (GGX: carries d/d(alpha, wi)).
     template <class TVT> PSDR_HD bool sample(const SceneView &sc, const TVT &tv, const Its<G> &its, const float s[3], bool active, Vec3f &wo,
                                              M &pdf_) const {
-        if (type() == PSDR_BSDF_DIFFUSE) {
+        if (is_diffuse(tv)) {
             wo = cosine_hemisphere(s[1], s[2]);
             pdf_ = M(kInvPi * wo.z);
             return active && val(its.wi.z) > 0.f;
@@ -811,8 +818,8 @@ PSDR_HD Vec3<M> camera_sample(const SceneView &sc, const TVT &tv, TraversalStack
 // One primary-edge slot: Integrator::render_primary_edges (integrator.cpp:98-119) +
 // PerspectiveCamera::sample_primary_edge (perspective.cpp:158-200).  Returns the pixel (or -1);
 // tan[k][c] = d value / d P_k (the primal part is exactly zero: value -= detach(value)).
-template <int K, bool ENV>
-PSDR_HD int primary_edge_sample(const SceneView &sc, const TangentView<K, ENV> &tv, TraversalStack &st, const LiParams &lp, const RngJump &jump,
+template <int K, int FL>
+PSDR_HD int primary_edge_sample(const SceneView &sc, const TangentView<K, FL> &tv, TraversalStack &st, const LiParams &lp, const RngJump &jump,
                                 uint64_t slot, float inv_sppe, float tan[K][3], uint32_t &nrays) {
     Rng rng; rng.init(slot, jump);
     float u = rng.next(), pmf;
@@ -824,7 +831,7 @@ PSDR_HD int primary_edge_sample(const SceneView &sc, const TangentView<K, ENV> &
     const int W = sc.d.width, H = sc.d.height;
     const int ix = (int) floorf(px * (float) W), iy = (int) floorf(py * (float) H);
     const bool valid = ix >= 0 && ix < W && iy >= 0 && iy < H;
-    const TangentView<0, ENV> tv0{};
+    const TangentView<0, FL> tv0{};
     const RayT<float> ray_p = primary_ray<float>(sc, tv0, px + kEdgeEpsilon * nx, py + kEdgeEpsilon * ny);
     const RayT<float> ray_n = primary_ray<float>(sc, tv0, px - kEdgeEpsilon * nx, py - kEdgeEpsilon * ny);
     const Vec3f Ln = Li<float, float>(sc, tv0, st, lp, rng, ray_n, valid, nrays);
@@ -863,7 +870,7 @@ template <class R, class TVT>
 PSDR_HD int secondary_edge_sample(const SceneView &sc, const TVT &tv, TraversalStack &st, const float s3[3], Vec3<R> &out, uint32_t &nrays) {
     constexpr bool ad = is_ad<R>();
     out = zero3<R>();
-    const TangentView<0, TVT::has_env> tv0{};
+    const TangentView<0, TVT::flags> tv0{};
     // -- sample_boundary_segment_direct
     float s1 = s3[0], pdf0;
     const int k = sample_reuse(sc.d.sec_cmf, sc.d.sec_pmf, sc.d.sec_sum, sc.d.num_sec_edges, s1, pdf0);

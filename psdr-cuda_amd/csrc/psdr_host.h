@@ -1,0 +1,115 @@
+// psdr_host.h -- what the translation units of libpsdr_hip.so share: the launch context, the scene
+// handle, the host-side launch helpers (defined in psdr_hip.hip) and the table of kernel variants.
+//
+// The kernels are compiled once per SCENE FLAG SET (TangentView FLAGS in psdr_device.h: environment map
+// present, rough conductor present) in separate translation units (psdr_variant.hip with
+// -DPSDR_VARIANT_FLAGS=n), built in parallel; the C ABI in psdr_hip.hip picks the variant of the scene.
+#pragma once
+#include "psdr_device.h"
+#include "psdr_reverse.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace psdr;
+
+struct LaunchCtx {
+    SceneView sc;
+    LiParams lp;
+    RngJump jump;
+    int32_t off_stack;          // byte offset of the traversal stacks inside the dynamic LDS block
+    int32_t off_pathrec;        // reverse mode: per-lane (c_k, f_k) path records behind the stacks
+};
+
+// Dynamic LDS block of every kernel:  [ staged BVH nodes | staged leaf triangles | staged
+// TriangleInfo rows | traversal stacks (stack_entries x 256 lanes) ].  The stacks are sized from the
+// depth of THIS scene's tree, so a 12-triangle scene uses 5 KB instead of 40 KB and the freed LDS
+// holds the scene itself (LDS latency ~64 clk vs ~200 for an L2 hit).
+__device__ __forceinline__ void setup_lds(const LaunchCtx &cx, TraversalStack &st) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const SceneView &sc = cx.sc;
+    float4 *dst = reinterpret_cast<float4 *>(psdr_dyn_lds);
+    const float4 *src = reinterpret_cast<const float4 *>(sc.nodes);
+    for (int i = threadIdx.x; i < sc.n_lnodes * 4; i += kBlock) dst[sc.off_lnodes / 16 + i] = src[i];
+    for (int i = threadIdx.x; i < sc.n_lbtris * 3; i += kBlock) dst[sc.off_lbtris / 16 + i] = sc.btris[i];
+    src = reinterpret_cast<const float4 *>(sc.d.tri_info);
+    for (int i = threadIdx.x; i < sc.n_ltri * 6; i += kBlock) dst[sc.off_ltri / 16 + i] = src[i];
+    st.base = reinterpret_cast<int32_t *>(psdr_dyn_lds + cx.off_stack) + threadIdx.x;
+    __syncthreads();
+#else
+    (void) cx; (void) st;
+#endif
+}
+
+// ------------------------------------------------------------------------ reverse mode
+// Gradient sink of the reverse kernels: the "per-parameter gradient scatter-add".
+//   level 0  camera matrix: per-lane REGISTERS, wave-reduced once at kernel end
+//   level 1  primary-triangle row: summed across the wave (lanes share their pixel) by the kernel
+//   level 2  per-workgroup LDS cache (ds_add_f32) for everything hot: all texels and emitter
+//            radiances (if they fit), and the "hot" triangle rows = the whole table when it is small,
+//            otherwise the emitter meshes' rows (every light sample lands on them) plus the
+//            largest-area triangles (walls, floors: the rows most path vertices land on)
+//   level 3  hardware global_atomic_add_f32 on the gradient table for the incoherent remainder
+// The cache is flushed with one global atomic per non-zero cached word per workgroup.
+// Non-finite pieces are dropped (forward mode zeroes non-finite tangents, zero_nonfinite).
+constexpr int kSinkCacheWords = 6144;        // 24 KB of LDS next to the 40 KB of traversal stacks
+struct SinkLayout {
+    int tex_off, tex_n;                      // texel cache (tex_n = 0: not cached)
+    int rad_off, rad_n;
+    int cam_off;                             // 16 words
+    int env_off, env_n;                      // environment-map record (PSDR_ENV_WORDS) if wanted
+    int hot_off, hot_rows;                   // cached triangle rows: slot = hot_map[tri] (-1 = not cached)
+    const int32_t *hot_map, *hot_tris;       // [T] tri -> slot, [hot_rows] slot -> tri
+    int total;
+};
+
+struct psdr_scene_s {
+    psdr_scene_desc desc{};
+    bool have_tables = false;
+    bool has_rough = true;                 // a RoughConductor may be present (desc.material_mask)
+    BvhNode *d_nodes = nullptr;
+    float4 *d_btris = nullptr;
+    size_t cap_nodes = 0, cap_btris = 0;
+    int32_t root = 0;
+    bool have_bvh = false;
+    unsigned long long *d_counters = nullptr;
+    uint64_t slots[3] = {0, 0, 0};
+    int num_cus = 256;
+    std::vector<int32_t> emitter_i;
+    int bvh_depth = 0, num_nodes = 0, num_btris = 0;
+    int32_t *d_hot_map = nullptr, *d_hot_tris = nullptr; int hot_rows = 0; size_t hot_cap = 0;   // reverse sink: LDS-cached triangle rows
+    void *d_ws = nullptr; size_t ws_bytes = 0;
+    int last_path_depth = 0; float path_survival = -1.f;   // rays traced / rays of fully surviving paths (last PathTracer call)          // wavefront path-state streams + counters          // host copy of desc.emitter_i (hot-row ranges of the reverse sink)
+};
+
+
+namespace psdr_host {
+int fail(const std::string &m);
+int launch_blocks(const psdr_scene_s *h, long long n);
+int plan_lds(const psdr_scene_s *h, LaunchCtx &cx, int reserved = 0);
+int lds_bytes(const LaunchCtx &cx, const psdr_scene_s *h);
+int make_ctx(psdr_scene_s *h, const psdr_render_opts *o, int sampler, LaunchCtx &cx);
+bool use_wavefront(const psdr_scene_s *h, const psdr_render_opts *o);
+SinkLayout make_sink_layout(const psdr_scene_s *h, const psdr_grads *g);
+int check_counts(const psdr_scene_s *h, const psdr_render_opts *o);
+int begin_call(psdr_scene_s *h, hipStream_t s);
+
+// entry points of one kernel variant (one scene flag set)
+struct VariantOps {
+    int (*render_c)(psdr_scene_s *h, const psdr_render_opts *o, float *img, hipStream_t s);
+    int (*render_fwd)(psdr_scene_s *h, const psdr_render_opts *o, int K, const psdr_tangents *tangents, float *img, float *dimg, hipStream_t s);
+    int (*render_rev)(psdr_scene_s *h, const psdr_render_opts *o, const float *adj_img, float *out_img, const psdr_grads *grads, hipStream_t s);
+    int (*guide)(psdr_scene_s *h, LaunchCtx &cx, const int32_t reso[4], int nrounds, long long n, float *out_mass, hipStream_t s);
+};
+const VariantOps *variant_ops_0();
+const VariantOps *variant_ops_1();
+const VariantOps *variant_ops_2();
+const VariantOps *variant_ops_3();
+}  // namespace psdr_host
+
+#define HIP_TRY(expr)                                                                              \
+    do { hipError_t e_ = (expr); if (e_ != hipSuccess) return psdr_host::fail(std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)

@@ -1,0 +1,643 @@
+// psdr_kernels.h -- the gfx950 kernels (all hand-written HIP for CDNA4, wave64) and their launch drivers,
+// templated on the scene flag set FL (psdr_device.h TangentView).  Included by psdr_variant.hip once per
+// flag set.
+//   k_camera<G,M,INTEG,FL>  one lane = one camera sample slot: raygen + Li + segmented wave splat
+//   k_wf_camera / k_wf_bounce  the same PathTracer as a wavefront over SoA path-state streams
+//   k_primary_edge<K,FL>    one lane = one primary-edge slot (two detached Li evaluations)
+//   k_secondary_edge<K,FL>  one lane = one secondary-edge slot (3 rays + boundary integrand)
+//   k_guide<FL>             guiding-grid mass accumulation
+//   k_camera_rev / k_primary_edge_rev / k_secondary_edge_rev   reverse mode (gradient scatter-add)
+// Traversal stacks live in LDS (one column per lane); image accumulation uses a segmented
+// wave reduction followed by one hardware f32 atomic per (pixel run, channel).
+#pragma once
+#include "psdr_host.h"
+
+namespace {
+using namespace psdr_host;
+
+__device__ __forceinline__ float wave_shfl_down(float v, int off) { return __shfl_down(v, off, 64); }
+
+// Segmented sum over a wave for NON-DECREASING integer keys (camera slots are pixel-major, so a
+// wave covers a few consecutive pixels).  After the loop the first lane of every key run holds
+// the run total.  All 64 lanes must call this.
+template <int N> __device__ __forceinline__ bool wave_segmented_sum(int key, float (&v)[N]) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int okey = __shfl_down(key, off, 64);
+        const bool take = (lane + off < 64) && (okey == key);
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const float o = wave_shfl_down(v[i], off);
+            if (take) v[i] += o;
+        }
+    }
+    const int pkey = __shfl_up(key, 1, 64);
+    return lane == 0 || pkey != key;
+}
+
+// Sum of v over runs of ADJACENT lanes holding the same key (keys in any order); the first lane of
+// each run gets the total.
+template <int N> __device__ __forceinline__ bool wave_run_sum(int key, float (&v)[N]) {
+    const int lane = threadIdx.x & 63;
+    const int prev = __shfl_up(key, 1, 64);
+    const bool head = lane == 0 || prev != key;
+    const unsigned long long heads = __ballot(head);
+    const int seg = __popcll(heads & (~0ull >> (63 - lane)));       // run index: non-decreasing
+    wave_segmented_sum<N>(seg, v);
+    return head;
+}
+
+__device__ __forceinline__ void count_rays(unsigned long long *counters, uint32_t nrays) {
+    uint32_t s = nrays;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0 && s) atomicAdd(counters, (unsigned long long) s);
+}
+
+// ------------------------------------------------------------------------------ k_camera
+// n = W*H*nsp slots of this shard, pixel-major: slot j -> pixel j / nsp, sample s_begin + j % nsp.
+// Occupancy targets (waves per SIMD) of the camera kernel.  The kernel is latency/dependency bound
+// (rocprof r01: 43 % of wave cycles waiting at 2 waves/SIMD), so trading registers for resident
+// waves pays: measured 6.2 -> 4.6 ms (renderC, 4 waves) and 12.5 -> 7.0 ms (renderD K=3 material-only, 2 waves,
+// no spills) on C2; 5 waves (renderC) and 3-4 waves (Dual<3>) spill and lose.
+#ifndef PSDR_WAVES_C
+#define PSDR_WAVES_C 4
+#endif
+#ifndef PSDR_WAVES_DM
+#define PSDR_WAVES_DM 3
+#endif
+#ifndef PSDR_WAVES_DG
+#define PSDR_WAVES_DG 2
+#endif
+template <class G, class R> constexpr int camera_waves() { return !is_ad<R>() ? PSDR_WAVES_C : (is_ad<G>() ? PSDR_WAVES_DG : PSDR_WAVES_DM); }
+template <class G, class R, int INTEG, int FL>
+__global__ __launch_bounds__(kBlock, (camera_waves<G, R>())) void k_camera(LaunchCtx cx, TV<R, FL> tv, int spp, int s_begin, int nsp, long long n, float inv_spp,
+                                                   float *__restrict__ img, float *__restrict__ dimg, long long plane,
+                                                   unsigned long long *counters) {
+    constexpr int K = ad_traits<R>::K;
+    constexpr int NV = 3 * (1 + K);
+    TraversalStack st; setup_lds(cx, st);
+    uint32_t nrays = 0;
+    const long long nceil = (n + kBlock - 1) / kBlock * kBlock;
+    for (long long j = (long long) blockIdx.x * kBlock + threadIdx.x; j < nceil; j += (long long) gridDim.x * kBlock) {
+        const bool in = j < n;
+        const int pixel = in ? (int) (j / nsp) : 0x7fffffff;
+        float v[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = 0.f;
+        if (in) {
+            const int s = s_begin + (int) (j % nsp);
+            const uint64_t slot = (uint64_t) pixel * (uint64_t) spp + (uint64_t) s;
+            const Vec3<R> r = camera_sample<G, R, INTEG>(cx.sc, tv, st, cx.lp, cx.jump, pixel, slot, nrays);
+            v[0] = val(r.x) * inv_spp; v[1] = val(r.y) * inv_spp; v[2] = val(r.z) * inv_spp;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                v[3 + 3 * k] = tangent(r.x, k) * inv_spp; v[4 + 3 * k] = tangent(r.y, k) * inv_spp; v[5 + 3 * k] = tangent(r.z, k) * inv_spp;
+            }
+        }
+        const bool head = wave_segmented_sum<NV>(pixel, v);
+        if (head && in) {
+            float *p = img + (size_t) pixel * 3;
+            if (v[0] != 0.f) atomicAdd(p, v[0]);
+            if (v[1] != 0.f) atomicAdd(p + 1, v[1]);
+            if (v[2] != 0.f) atomicAdd(p + 2, v[2]);
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                float *q = dimg + (size_t) k * plane + (size_t) pixel * 3;
+                if (v[3 + 3 * k] != 0.f) atomicAdd(q, v[3 + 3 * k]);
+                if (v[4 + 3 * k] != 0.f) atomicAdd(q + 1, v[4 + 3 * k]);
+                if (v[5 + 3 * k] != 0.f) atomicAdd(q + 2, v[5 + 3 * k]);
+            }
+        }
+    }
+    count_rays(counters, nrays);
+}
+
+// ----------------------------------------------------------------------- wavefront mode
+// PathTracer as a wavefront: stage 0 (camera ray, primary vertex) then one kernel per bounce over SoA
+// path-state streams in HBM.  Live paths are compacted between stages with a wave ballot + prefix
+// popcount and ONE atomic per wave on the stream counter, so every bounce kernel runs on dense
+// waves.  Record = pixel, slot, triangle, (u,v), arrival direction, throughput (+K tangents):
+// 44 + 12 K bytes, all streams coalesced.
+struct PathStream {
+    int32_t *pixel; uint32_t *slot; int32_t *tri; float *hu, *hv; float *dir; float *beta;   // dir: [3][cap], beta: [3(1+K)][cap]
+    long long cap;
+};
+
+template <class M>
+__device__ __forceinline__ void stream_push(const PathStream &out, int *counter, bool alive, int pixel, uint32_t slot, const Its<float> &next,
+                                            const Vec3f &dir, const Vec3<M> &beta) {
+    constexpr int K = ad_traits<M>::K;
+    const unsigned long long mask = __ballot(alive);
+    if (mask == 0ull) return;
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == __ffsll((long long) mask) - 1) base = atomicAdd(counter, (int) __popcll(mask));
+    base = __shfl(base, __ffsll((long long) mask) - 1, 64);
+    if (!alive) return;
+    const long long i = base + __popcll(mask & ((1ull << lane) - 1ull));
+    out.pixel[i] = pixel; out.slot[i] = slot; out.tri[i] = next.tri; out.hu[i] = next.hu; out.hv[i] = next.hv;
+    out.dir[i] = dir.x; out.dir[out.cap + i] = dir.y; out.dir[2 * out.cap + i] = dir.z;
+    out.beta[i] = val(beta.x); out.beta[out.cap + i] = val(beta.y); out.beta[2 * out.cap + i] = val(beta.z);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        out.beta[(3 + 3 * k) * out.cap + i] = tangent(beta.x, k); out.beta[(4 + 3 * k) * out.cap + i] = tangent(beta.y, k);
+        out.beta[(5 + 3 * k) * out.cap + i] = tangent(beta.z, k);
+    }
+}
+
+template <class M>
+__device__ __forceinline__ void splat_runs(int pixel, bool valid, const Vec3<M> &r, float scale, float *img, float *dimg, long long plane) {
+    constexpr int K = ad_traits<M>::K;
+    constexpr int NV = 3 * (1 + K);
+    float v[NV];
+    v[0] = val(r.x) * scale; v[1] = val(r.y) * scale; v[2] = val(r.z) * scale;
+#pragma unroll
+    for (int k = 0; k < K; ++k) { v[3 + 3 * k] = tangent(r.x, k) * scale; v[4 + 3 * k] = tangent(r.y, k) * scale; v[5 + 3 * k] = tangent(r.z, k) * scale; }
+    if (!valid) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = 0.f;
+    }
+    const bool head = wave_run_sum<NV>(valid ? pixel : -1, v);
+    if (head && valid) {
+        float *p = img + (size_t) pixel * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) if (v[c] != 0.f) atomicAdd(p + c, v[c]);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            float *q = dimg + (size_t) k * plane + (size_t) pixel * 3;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) if (v[3 + 3 * k + c] != 0.f) atomicAdd(q + c, v[3 + 3 * k + c]);
+        }
+    }
+}
+
+template <class M, int FL>
+__global__ __launch_bounds__(kBlock, (is_ad<M>() ? 2 : 4)) void k_wf_camera(LaunchCtx cx, TV<M, FL> tv, int spp, int s_begin, int nsp, long long j0, long long n,
+                                                        float inv_spp, float *__restrict__ img, float *__restrict__ dimg, long long plane,
+                                                        PathStream out, int *out_count, int want_next, unsigned long long *counters) {
+    TraversalStack st; setup_lds(cx, st);
+    uint32_t nrays = 0;
+    const long long nceil = (n + kBlock - 1) / kBlock * kBlock;
+    for (long long jj = (long long) blockIdx.x * kBlock + threadIdx.x; jj < nceil; jj += (long long) gridDim.x * kBlock) {
+        const bool in = jj < n;
+        const long long j = j0 + jj;
+        const int pixel = in ? (int) (j / nsp) : 0;
+        Vec3<M> r = zero3<M>(), beta = zero3<M>();
+        Its<float> next; next.tri = -1; next.hu = next.hv = 0.f;
+        Vec3f origin(0.f), dir(0.f);
+        bool alive = false;
+        uint32_t slot = 0;
+        if (in) {
+            slot = (uint32_t) ((uint64_t) pixel * (uint64_t) spp + (uint64_t) (s_begin + (int) (j % nsp)));
+            r = zero_nonfinite(wavefront_camera_vertex<M>(cx.sc, tv, st, cx.lp, cx.jump, pixel, slot, nrays, next, beta, origin, alive));
+            if (alive) { Vec3f d = next.p - origin; const float t = norm(d); dir = d / t; }
+        }
+        splat_runs<M>(pixel, in, r, inv_spp, img, dimg, plane);
+        stream_push<M>(out, out_count, alive && want_next, pixel, slot, next, dir, beta);
+    }
+    count_rays(counters, nrays);
+}
+
+template <class M, int FL>
+__global__ __launch_bounds__(kBlock, (is_ad<M>() ? 2 : 4)) void k_wf_bounce(LaunchCtx cx, TV<M, FL> tv, float inv_spp, float *__restrict__ img,
+                                                        float *__restrict__ dimg, long long plane, PathStream in, const int *in_count,
+                                                        PathStream out, int *out_count, int want_next, unsigned long long *counters) {
+    constexpr int K = ad_traits<M>::K;
+    TraversalStack st; setup_lds(cx, st);
+    uint32_t nrays = 0;
+    const long long n = *in_count;
+    const long long nceil = (n + kBlock - 1) / kBlock * kBlock;
+    for (long long j = (long long) blockIdx.x * kBlock + threadIdx.x; j < nceil; j += (long long) gridDim.x * kBlock) {
+        const bool live = j < n;
+        int pixel = -1; uint32_t slot = 0;
+        Vec3<M> r = zero3<M>(), beta = zero3<M>();
+        Its<float> next; next.tri = -1; next.hu = next.hv = 0.f;
+        Vec3f dir(0.f);
+        bool alive = false;
+        if (live) {
+            pixel = in.pixel[j]; slot = in.slot[j];
+            const Vec3f din{in.dir[j], in.dir[in.cap + j], in.dir[2 * in.cap + j]};
+            beta.x = M(in.beta[j]); beta.y = M(in.beta[in.cap + j]); beta.z = M(in.beta[2 * in.cap + j]);
+            if constexpr (K > 0) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    beta.x.d[k] = in.beta[(3 + 3 * k) * in.cap + j]; beta.y.d[k] = in.beta[(4 + 3 * k) * in.cap + j];
+                    beta.z.d[k] = in.beta[(5 + 3 * k) * in.cap + j];
+                }
+            }
+            const Its<float> its = path_vertex_from_record(cx.sc, tv, in.tri[j], in.hu[j], in.hv[j], din);
+            Vec3<M> f;
+            const Vec3<M> c = wavefront_bounce_vertex<M>(cx.sc, tv, st, cx.jump, (uint64_t) slot, its, nrays, next, f, alive);
+            r = zero_nonfinite(beta * c);
+            if (alive) {
+                beta = beta * f;
+                const Vec3f b = val(beta);
+                alive = b.x != 0.f || b.y != 0.f || b.z != 0.f;
+                Vec3f d = next.p - its.p; const float t = norm(d); dir = d / t;
+            }
+        }
+        splat_runs<M>(pixel, live, r, inv_spp, img, dimg, plane);
+        stream_push<M>(out, out_count, alive && want_next, pixel, slot, next, dir, beta);
+    }
+    count_rays(counters, nrays);
+}
+
+// ------------------------------------------------------------------------ k_primary_edge
+template <int K, int FL>
+__global__ __launch_bounds__(kBlock) void k_primary_edge(LaunchCtx cx, TangentView<K, FL> tv, long long i0, long long n, float inv_sppe,
+                                                         float *__restrict__ dimg, long long plane, unsigned long long *counters) {
+    TraversalStack st; setup_lds(cx, st);
+    uint32_t nrays = 0;
+    for (long long j = (long long) blockIdx.x * kBlock + threadIdx.x; j < n; j += (long long) gridDim.x * kBlock) {
+        float tan[K][3];
+        const int pixel = primary_edge_sample<K>(cx.sc, tv, st, cx.lp, cx.jump, (uint64_t) (i0 + j), inv_sppe, tan, nrays);
+        if (pixel >= 0) {
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    if (tan[k][c] != 0.f) atomicAdd(dimg + (size_t) k * plane + (size_t) pixel * 3 + c, tan[k][c]);
+        }
+    }
+    count_rays(counters, nrays);
+}
+
+// ---------------------------------------------------------------------- k_secondary_edge
+template <int K, int FL>
+__global__ __launch_bounds__(kBlock) void k_secondary_edge(LaunchCtx cx, TangentView<K, FL> tv, long long i0, long long n, float inv_sppse,
+                                                           float *__restrict__ dimg, long long plane, unsigned long long *counters) {
+    using R = Dual<K>;
+    TraversalStack st; setup_lds(cx, st);
+    uint32_t nrays = 0;
+    const bool guided = cx.sc.d.guide_cmf != nullptr && cx.sc.d.num_guide_cells > 0;
+    for (long long j = (long long) blockIdx.x * kBlock + threadIdx.x; j < n; j += (long long) gridDim.x * kBlock) {
+        Rng rng; rng.init((uint64_t) (i0 + j), cx.jump);
+        float s3[3] = {rng.next(), rng.next(), rng.next()};
+        const float pdf0 = guided ? guide_sample_reuse(cx.sc, s3) : 1.f;
+        Vec3<R> value;
+        const int pixel = secondary_edge_sample<R>(cx.sc, tv, st, s3, value, nrays);
+        if (pixel >= 0) {
+            value = zero_nonfinite(value);
+            const float scale = (pdf0 > kEpsilon ? 1.f / pdf0 : 1.f) * inv_sppse;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const float g[3] = {value.x.d[k] * scale, value.y.d[k] * scale, value.z.d[k] * scale};
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    if (g[c] != 0.f) atomicAdd(dimg + (size_t) k * plane + (size_t) pixel * 3 + c, g[c]);
+            }
+        }
+    }
+    count_rays(counters, nrays);
+}
+
+// ------------------------------------------------------------------------------- k_guide
+// DirectIntegrator::preprocess_secondary_edges (direct.cpp:166-204): one lane = one (cell, j) sample
+// stream; nrounds evaluations each; mass[cell] += hmax(value0 / reso3) / nrounds.
+template <int FL>
+__global__ __launch_bounds__(kBlock) void k_guide(LaunchCtx cx, int r0, int r1, int r2, int per, int nrounds, long long n,
+                                                  float *__restrict__ mass, unsigned long long *counters) {
+    TraversalStack st; setup_lds(cx, st);
+    uint32_t nrays = 0;
+    const TangentView<0, FL> tv0{};
+    const RngJump nojump{1ull, 0ull};
+    for (long long j = (long long) blockIdx.x * kBlock + threadIdx.x; j < n; j += (long long) gridDim.x * kBlock) {
+        const int cell = (int) (j / per);
+        const int c0 = cell / (r1 * r2), rem = cell - c0 * r1 * r2, c1 = rem / r2, c2 = rem - c1 * r2;
+        Rng rng; rng.init((uint64_t) j, nojump);
+        float acc = 0.f;
+        for (int r = 0; r < nrounds; ++r) {
+            float s3[3] = {rng.next(), rng.next(), rng.next()};
+            s3[0] = (s3[0] + (float) c0) * (1.f / (float) r0);
+            s3[1] = (s3[1] + (float) c1) * (1.f / (float) r1);
+            s3[2] = (s3[2] + (float) c2) * (1.f / (float) r2);
+            Vec3f v;
+            secondary_edge_sample<float>(cx.sc, tv0, st, s3, v, nrays);
+            v = zero_nonfinite(v);
+            if (per > 1) v = v / (float) per;
+            acc += fmaxf(v.x, fmaxf(v.y, v.z));
+        }
+        if (nrounds > 1) acc /= (float) nrounds;
+        if (acc != 0.f) atomicAdd(mass + cell, acc);
+    }
+    count_rays(counters, nrays);
+}
+
+template <int FL> struct DeviceSink {
+    static constexpr int flags = FL;
+    static constexpr bool has_env = (FL & kSceneEnv) != 0;
+    psdr_grads g;
+    SinkLayout L;
+    float *lds;
+    float cam[16];
+    __device__ __forceinline__ static bool ok(float v) { return v != 0.f && isfinite(v); }
+    __device__ __forceinline__ void glob(float *base, size_t i, float v) const { if (base != nullptr && ok(v)) atomicAdd(base + i, v); }
+    __device__ __forceinline__ void add_tri(int tri, int word, float v) const {
+        if (g.g_tri_info == nullptr || !ok(v)) return;
+        const int slot = L.hot_rows ? L.hot_map[tri] : -1;
+        if (slot >= 0 && slot < L.hot_rows) atomicAdd(lds + L.hot_off + slot * PSDR_TRI_STRIDE + word, v);
+        else atomicAdd(g.g_tri_info + (size_t) tri * PSDR_TRI_STRIDE + word, v);
+    }
+    __device__ __forceinline__ void add_texel(int idx, float v) const {
+        if (g.g_texels == nullptr || !ok(v)) return;
+        if (L.tex_n) atomicAdd(lds + L.tex_off + idx, v); else atomicAdd(g.g_texels + idx, v);
+    }
+    __device__ __forceinline__ void add_rad(int e, int c, float v) const {
+        if (g.g_emitter_rad == nullptr || !ok(v)) return;
+        if (L.rad_n) atomicAdd(lds + L.rad_off + e * 3 + c, v); else atomicAdd(g.g_emitter_rad + e * 3 + c, v);
+    }
+    __device__ __forceinline__ void add_cam(int word, float v) { if (ok(v)) cam[word] += v; }
+    __device__ __forceinline__ void add_env(int word, float v) const { if (L.env_n && ok(v)) atomicAdd(lds + L.env_off + word, v); }
+    __device__ __forceinline__ void add_sedge(int e, int word, float v) const { glob(g.g_sec_edge, (size_t) e * PSDR_SEDGE_STRIDE + word, v); }
+    __device__ __forceinline__ void add_pedge(int e, int word, float v) const { glob(g.g_prim_edge, (size_t) e * PSDR_PEDGE_STRIDE + word, v); }
+
+    __device__ __forceinline__ void begin(float *cache) {
+        lds = cache;
+        for (int i = threadIdx.x; i < L.total; i += kBlock) cache[i] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) cam[i] = 0.f;
+        __syncthreads();
+    }
+    __device__ __forceinline__ void end() {
+        if (g.g_cam_to_world != nullptr) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                float v = cam[i];
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+                if ((threadIdx.x & 63) == 0 && v != 0.f) atomicAdd(lds + L.cam_off + i, v);
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < L.total; i += kBlock) {
+            const float v = lds[i];
+            if (v == 0.f) continue;
+            if (i >= L.cam_off && i < L.cam_off + 16) { atomicAdd(g.g_cam_to_world + (i - L.cam_off), v); continue; }
+            if (L.tex_n && i >= L.tex_off && i < L.tex_off + L.tex_n) { atomicAdd(g.g_texels + (i - L.tex_off), v); continue; }
+            if (L.rad_n && i >= L.rad_off && i < L.rad_off + L.rad_n) { atomicAdd(g.g_emitter_rad + (i - L.rad_off), v); continue; }
+            if (L.env_n && i >= L.env_off && i < L.env_off + L.env_n) { atomicAdd(g.g_env_f + (i - L.env_off), v); continue; }
+            const int rel = i - L.hot_off;
+            if (rel >= 0 && rel < L.hot_rows * PSDR_TRI_STRIDE)
+                atomicAdd(g.g_tri_info + (size_t) L.hot_tris[rel / PSDR_TRI_STRIDE] * PSDR_TRI_STRIDE + rel % PSDR_TRI_STRIDE, v);
+        }
+    }
+};
+
+#ifndef PSDR_WAVES_REV
+#define PSDR_WAVES_REV 2
+#endif
+template <int FL>
+__global__ __launch_bounds__(kBlock, PSDR_WAVES_REV) void k_camera_rev(LaunchCtx cx, DeviceSink<FL> sink, int spp, int s_begin, int nsp, long long n, float inv_spp,
+                                                       const float *__restrict__ adj_img, float *__restrict__ img,
+                                                       unsigned long long *counters) {
+    __shared__ float cache[kSinkCacheWords];
+    TraversalStack st; setup_lds(cx, st);
+    sink.begin(cache);
+    uint32_t nrays = 0;
+    const bool geo = sink.g.g_tri_info != nullptr || sink.g.g_cam_to_world != nullptr;
+    const long long nceil = (n + kBlock - 1) / kBlock * kBlock;
+    for (long long j = (long long) blockIdx.x * kBlock + threadIdx.x; j < nceil; j += (long long) gridDim.x * kBlock) {
+        const bool in = j < n;
+        const int pixel = in ? (int) (j / nsp) : 0x7fffffff;
+        float v[3] = {0.f, 0.f, 0.f};
+        PrimaryGrad pg; pg.clear();
+        PathRec rec;
+#if defined(__HIP_DEVICE_COMPILE__)
+        rec.base = reinterpret_cast<float *>(psdr_dyn_lds + cx.off_pathrec) + threadIdx.x;
+#endif
+        if (in) {
+            const int s = s_begin + (int) (j % nsp);
+            const uint64_t slot = (uint64_t) pixel * (uint64_t) spp + (uint64_t) s;
+            const float *a = adj_img + (size_t) pixel * 3;
+            const Vec3f adj{a[0] * inv_spp, a[1] * inv_spp, a[2] * inv_spp};
+            const Vec3f r = camera_sample_reverse(sink, pg, rec, cx.sc, st, cx.lp, cx.jump, pixel, slot, adj, nrays, geo);
+            v[0] = r.x * inv_spp; v[1] = r.y * inv_spp; v[2] = r.z * inv_spp;
+        }
+        // primary-triangle row: one add per run of lanes that hit the same triangle
+        if (sink.g.g_tri_info != nullptr) {
+            const bool head = wave_run_sum<kPrimaryWords>(pg.tri, pg.w);
+            if (head && pg.tri >= 0) {
+#pragma unroll
+                for (int w = 0; w < kPrimaryWords; ++w) sink.add_tri(pg.tri, w, pg.w[w]);
+            }
+        }
+        if (img != nullptr) {
+            const bool head = wave_segmented_sum<3>(pixel, v);
+            if (head && in) {
+                float *p = img + (size_t) pixel * 3;
+                if (v[0] != 0.f) atomicAdd(p, v[0]);
+                if (v[1] != 0.f) atomicAdd(p + 1, v[1]);
+                if (v[2] != 0.f) atomicAdd(p + 2, v[2]);
+            }
+        }
+    }
+    sink.end();
+    count_rays(counters, nrays);
+}
+
+template <int FL>
+__global__ __launch_bounds__(kBlock) void k_primary_edge_rev(LaunchCtx cx, DeviceSink<FL> sink, long long i0, long long n, float inv_sppe,
+                                                             const float *__restrict__ adj_img, unsigned long long *counters) {
+    __shared__ float cache[kSinkCacheWords];
+    TraversalStack st; setup_lds(cx, st);
+    sink.begin(cache);
+    uint32_t nrays = 0;
+    for (long long j = (long long) blockIdx.x * kBlock + threadIdx.x; j < n; j += (long long) gridDim.x * kBlock)
+        primary_edge_reverse(sink, cx.sc, st, cx.lp, cx.jump, (uint64_t) (i0 + j), inv_sppe, adj_img, nrays);
+    sink.end();
+    count_rays(counters, nrays);
+}
+
+template <int FL>
+__global__ __launch_bounds__(kBlock) void k_secondary_edge_rev(LaunchCtx cx, DeviceSink<FL> sink, long long i0, long long n, float inv_sppse,
+                                                               const float *__restrict__ adj_img, unsigned long long *counters) {
+    __shared__ float cache[kSinkCacheWords];
+    TraversalStack st; setup_lds(cx, st);
+    sink.begin(cache);
+    uint32_t nrays = 0;
+    const bool guided = cx.sc.d.guide_cmf != nullptr && cx.sc.d.num_guide_cells > 0;
+    for (long long j = (long long) blockIdx.x * kBlock + threadIdx.x; j < n; j += (long long) gridDim.x * kBlock) {
+        Rng rng; rng.init((uint64_t) (i0 + j), cx.jump);
+        float s3[3] = {rng.next(), rng.next(), rng.next()};
+        const float pdf0 = guided ? guide_sample_reuse(cx.sc, s3) : 1.f;
+        secondary_edge_reverse(sink, cx.sc, st, s3, (pdf0 > kEpsilon ? 1.f / pdf0 : 1.f) * inv_sppse, adj_img, nrays);
+    }
+    sink.end();
+    count_rays(counters, nrays);
+}
+
+
+// ============================================================================ launch drivers
+template <class G, class R, int FL>
+int run_camera(psdr_scene_s *h, const psdr_render_opts *o, const TV<R, FL> &tv, float *img, float *dimg, hipStream_t s) {
+    const long long WH = (long long) h->desc.width * h->desc.height;
+    const int nsp = o->spp_end - o->spp_begin;
+    if (o->spp <= 0 || nsp <= 0) return 0;
+    LaunchCtx cx;
+    if (int rc = make_ctx(h, o, 0, cx)) return rc;
+    const long long n = WH * nsp;
+    h->slots[0] += (uint64_t) n;
+#define PSDR_LAUNCH_CAMERA(INTEG)                                                                                                  \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_camera<G, R, INTEG, FL>), dim3(launch_blocks(h, n)), dim3(kBlock), lds_bytes(cx, h), s, cx, tv, o->spp, \
+                       o->spp_begin, nsp, n, 1.f / (float) o->spp, img, dimg, WH * 3, h->d_counters)
+    switch (o->integrator) {
+        case PSDR_INTEGRATOR_DIRECT: PSDR_LAUNCH_CAMERA(PSDR_INTEGRATOR_DIRECT); break;
+        case PSDR_INTEGRATOR_PATH: PSDR_LAUNCH_CAMERA(PSDR_INTEGRATOR_PATH); break;
+        case PSDR_INTEGRATOR_FIELD: PSDR_LAUNCH_CAMERA(PSDR_INTEGRATOR_FIELD); break;
+        default: return fail("Unknown integrator");
+    }
+#undef PSDR_LAUNCH_CAMERA
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// PathTracer interior term as a wavefront (see k_wf_camera / k_wf_bounce).  M = float or Dual<K>
+// with plain-fp32 geometry.
+constexpr long long kWfChunk = 1ll << 25;
+template <class M, int FL>
+int run_camera_wavefront(psdr_scene_s *h, const psdr_render_opts *o, const TV<M, FL> &tv, float *img, float *dimg, hipStream_t s) {
+    constexpr int K = ad_traits<M>::K;
+    const long long WH = (long long) h->desc.width * h->desc.height;
+    const int nsp = o->spp_end - o->spp_begin;
+    if (o->spp <= 0 || nsp <= 0) return 0;
+    const long long n = WH * nsp;
+    const long long cap = std::min(n, kWfChunk);
+    const int depth = o->max_depth;
+    const size_t words = 8 + 3 * (1 + K);
+    const size_t need = 2 * words * 4 * (size_t) cap + 256 * sizeof(int);
+    if (need > h->ws_bytes) {
+        if (h->d_ws) (void) hipFree(h->d_ws);
+        h->d_ws = nullptr; h->ws_bytes = 0;
+        HIP_TRY(hipMalloc(&h->d_ws, need));
+        h->ws_bytes = need;
+    }
+    int *cnt = reinterpret_cast<int *>(h->d_ws);
+    PathStream st[2];
+    for (int i = 0; i < 2; ++i) {
+        float *b = reinterpret_cast<float *>(reinterpret_cast<char *>(h->d_ws) + 256 * sizeof(int)) + (size_t) i * words * cap;
+        st[i].cap = cap;
+        st[i].pixel = reinterpret_cast<int32_t *>(b); st[i].slot = reinterpret_cast<uint32_t *>(b + cap); st[i].tri = reinterpret_cast<int32_t *>(b + 2 * cap);
+        st[i].hu = b + 3 * cap; st[i].hv = b + 4 * cap; st[i].dir = b + 5 * cap; st[i].beta = b + 8 * cap;
+    }
+    h->slots[0] += (uint64_t) n;
+    const float inv_spp = 1.f / (float) o->spp;
+    for (long long j0 = 0; j0 < n; j0 += cap) {
+        const long long cn = std::min(cap, n - j0);
+        HIP_TRY(hipMemsetAsync(cnt, 0, 256 * sizeof(int), s));
+        LaunchCtx cx;
+        if (int rc = make_ctx(h, o, 0, cx)) return rc;
+        const int blocks = launch_blocks(h, cn);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wf_camera<M, FL>), dim3(blocks), dim3(kBlock), lds_bytes(cx, h), s, cx, tv, o->spp, o->spp_begin, nsp, j0, cn,
+                           inv_spp, img, dimg, WH * 3, st[0], cnt + 1, depth > 1 ? 1 : 0, h->d_counters);
+        HIP_TRY(hipGetLastError());
+        for (int k = 1; k < depth; ++k) {
+            cx.jump = make_rng_jump(o->rng_offset[0] + 2 + 5 * (uint64_t) k);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wf_bounce<M, FL>), dim3(blocks), dim3(kBlock), lds_bytes(cx, h), s, cx, tv, inv_spp, img, dimg, WH * 3,
+                               st[(k - 1) & 1], cnt + k, st[k & 1], cnt + k + 1, k + 1 < depth ? 1 : 0, h->d_counters);
+            HIP_TRY(hipGetLastError());
+        }
+    }
+    return 0;
+}
+
+template <int K, int FL>
+int render_fwd(psdr_scene_s *h, const psdr_render_opts *o, const psdr_tangents *tangents, float *img, float *dimg, hipStream_t s) {
+    const long long WH = (long long) h->desc.width * h->desc.height;
+    TangentView<K, FL> tv;
+    for (int k = 0; k < K; ++k) tv.t[k] = tangents[k];
+    HIP_TRY(hipMemsetAsync(img, 0, sizeof(float) * WH * 3, s));
+    HIP_TRY(hipMemsetAsync(dimg, 0, sizeof(float) * WH * 3 * K, s));
+    // geometry stays in plain fp32 when only material / emitter tables carry tangents
+    bool geo = false;
+    for (int k = 0; k < K; ++k) geo = geo || tangents[k].d_tri_info || tangents[k].d_cam_to_world;
+    if (geo) { if (int rc = run_camera<Dual<K>, Dual<K>, FL>(h, o, tv, img, dimg, s)) return rc; }
+    else if (use_wavefront(h, o)) { if (int rc = run_camera_wavefront<Dual<K>, FL>(h, o, tv, img, dimg, s)) return rc; }
+    else { if (int rc = run_camera<float, Dual<K>, FL>(h, o, tv, img, dimg, s)) return rc; }
+    if (o->sppe > 0 && o->sppe_end > o->sppe_begin && h->desc.num_prim_edges > 0) {
+        LaunchCtx cx;
+        if (int rc = make_ctx(h, o, 1, cx)) return rc;
+        const long long i0 = WH * o->sppe_begin, n = WH * (o->sppe_end - o->sppe_begin);
+        h->slots[1] += (uint64_t) n;
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_primary_edge<K, FL>), dim3(launch_blocks(h, n)), dim3(kBlock), lds_bytes(cx, h), s, cx, tv, i0, n,
+                           1.f / (float) o->sppe, dimg, WH * 3, h->d_counters);
+        HIP_TRY(hipGetLastError());
+    }
+    if (o->sppse > 0 && o->sppse_end > o->sppse_begin && h->desc.num_sec_edges > 0 && o->integrator == PSDR_INTEGRATOR_DIRECT) {
+        LaunchCtx cx;
+        if (int rc = make_ctx(h, o, 2, cx)) return rc;
+        const long long i0 = WH * o->sppse_begin, n = WH * (o->sppse_end - o->sppse_begin);
+        h->slots[2] += (uint64_t) n;
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_secondary_edge<K, FL>), dim3(launch_blocks(h, n)), dim3(kBlock), lds_bytes(cx, h), s, cx, tv, i0, n,
+                           1.f / (float) o->sppse, dimg, WH * 3, h->d_counters);
+        HIP_TRY(hipGetLastError());
+    }
+    return 0;
+}
+
+template <int FL>
+int render_rev(psdr_scene_s *h, const psdr_render_opts *o, const float *adj_img, float *out_img, const psdr_grads *grads, hipStream_t s) {
+    const long long WH = (long long) h->desc.width * h->desc.height;
+    if (out_img) HIP_TRY(hipMemsetAsync(out_img, 0, sizeof(float) * WH * 3, s));
+    DeviceSink<FL> sink{}; sink.g = *grads; sink.L = make_sink_layout(h, grads);
+    const int nsp = o->spp_end - o->spp_begin;
+    if (o->spp > 0 && nsp > 0) {
+        LaunchCtx cx;
+        if (int rc = make_ctx(h, o, 0, cx)) return rc;
+        const long long n = WH * nsp;
+        h->slots[0] += (uint64_t) n;
+        const int depth = o->integrator == PSDR_INTEGRATOR_PATH ? std::min(o->max_depth, kMaxRevDepth) : 1;
+        const int rec_bytes = depth * 6 * kBlock * 4;
+        plan_lds(h, cx, rec_bytes + kSinkCacheWords * 4);          // stage less of the scene: the record + cache live in LDS too
+        cx.off_pathrec = lds_bytes(cx, h);
+        hipLaunchKernelGGL(k_camera_rev<FL>, dim3(launch_blocks(h, n)), dim3(kBlock), lds_bytes(cx, h) + rec_bytes, s, cx, sink, o->spp, o->spp_begin, nsp, n,
+                           1.f / (float) o->spp, adj_img, out_img, h->d_counters);
+        HIP_TRY(hipGetLastError());
+    }
+    if (o->sppe > 0 && o->sppe_end > o->sppe_begin && h->desc.num_prim_edges > 0 && grads->g_prim_edge) {
+        LaunchCtx cx;
+        if (int rc = make_ctx(h, o, 1, cx)) return rc;
+        const long long i0 = WH * o->sppe_begin, n = WH * (o->sppe_end - o->sppe_begin);
+        h->slots[1] += (uint64_t) n;
+        hipLaunchKernelGGL(k_primary_edge_rev<FL>, dim3(launch_blocks(h, n)), dim3(kBlock), lds_bytes(cx, h), s, cx, sink, i0, n, 1.f / (float) o->sppe, adj_img,
+                           h->d_counters);
+        HIP_TRY(hipGetLastError());
+    }
+    if (o->sppse > 0 && o->sppse_end > o->sppse_begin && h->desc.num_sec_edges > 0 && o->integrator == PSDR_INTEGRATOR_DIRECT) {
+        LaunchCtx cx;
+        if (int rc = make_ctx(h, o, 2, cx)) return rc;
+        const long long i0 = WH * o->sppse_begin, n = WH * (o->sppse_end - o->sppse_begin);
+        h->slots[2] += (uint64_t) n;
+        hipLaunchKernelGGL(k_secondary_edge_rev<FL>, dim3(launch_blocks(h, n)), dim3(kBlock), lds_bytes(cx, h), s, cx, sink, i0, n, 1.f / (float) o->sppse,
+                           adj_img, h->d_counters);
+        HIP_TRY(hipGetLastError());
+    }
+    return 0;
+}
+
+template <int FL>
+int guide_launch(psdr_scene_s *h, LaunchCtx &cx, const int32_t reso[4], int nrounds, long long n, float *out_mass, hipStream_t s) {
+    hipLaunchKernelGGL(k_guide<FL>, dim3(launch_blocks(h, n)), dim3(kBlock), lds_bytes(cx, h), s, cx, reso[0], reso[1], reso[2], reso[3], nrounds, n,
+                       out_mass, h->d_counters);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+template <int FL>
+int render_c_launch(psdr_scene_s *h, const psdr_render_opts *o, float *out_img, hipStream_t s) {
+    const TangentView<0, FL> tv0{};
+    if (use_wavefront(h, o)) return run_camera_wavefront<float, FL>(h, o, tv0, out_img, nullptr, s);
+    return run_camera<float, float, FL>(h, o, tv0, out_img, nullptr, s);
+}
+
+template <int FL>
+int render_fwd_launch(psdr_scene_s *h, const psdr_render_opts *o, int K, const psdr_tangents *tangents, float *img, float *dimg, hipStream_t s) {
+    switch (K) {
+        case 1: return render_fwd<1, FL>(h, o, tangents, img, dimg, s);
+        case 3: return render_fwd<3, FL>(h, o, tangents, img, dimg, s);
+        default: return fail("psdr_render_d_fwd: K must be 1 or 3");
+    }
+}
+
+}  // namespace

@@ -126,7 +126,7 @@ template <class Sink> PSDR_HD Vec3f env_eval_vjp(Sink &sink, const SceneView &sc
     const Vec3f v = env_mul3(f + PSDR_ENV_FROM_WORLD, w);
     float tu = atan2f(v.x, -v.z) * kInvTwoPi, tv = safe_acos_(v.y) * kInvPi;
     tu -= floorf(tu); tv -= floorf(tv);
-    const TangentView<0, true> tv0{};
+    const TangentView<0, kSceneEnv> tv0{};
     float rgb[3];
     bitmap_eval<float, 3>(sc, tv0, sc.d.env_tex, tu, tv, rgb, false);
     const float scale = f[PSDR_ENV_SCALE];
@@ -172,7 +172,7 @@ template <class Sink> struct BsdfRev {
     template <class TVT> PSDR_HD void eval_vjp(Sink &sink, const TVT &tv0, const Its<float> &its, const Vec3f &wo, const Vec3f &af, Vec3f &awi,
                           Vec3f &awo, float &auvx, float &auvy) const {
         if (!(its.wi.z > 0.f && wo.z > 0.f)) return;
-        if (b.type() == PSDR_BSDF_DIFFUSE) {
+        if (b.is_diffuse(tv0)) {
             const Vec3f rho = b.tex3(sc, tv0, PSDR_SLOT_REFLECTANCE, its);
             const float c = wo.z * kInvPi;
             const float ar[3] = {af.x * c, af.y * c, af.z * c};
@@ -222,7 +222,7 @@ template <class Sink> struct BsdfRev {
     // adjoint of pdf(its, wo) (only RoughConductor carries derivatives; Diffuse::__pdf is detached)
     template <class TVT> PSDR_HD void pdf_vjp(Sink &sink, const TVT &tv0, const Its<float> &its, const Vec3f &wo, float apdf, Vec3f &awi, Vec3f &awo,
                          float &auvx, float &auvy) const {
-        if (b.type() == PSDR_BSDF_DIFFUSE || apdf == 0.f) return;
+        if (b.is_diffuse(tv0) || apdf == 0.f) return;
         const RcParams p = rc_params(tv0, its);
         const Vec3<D8> dwi{seed8(its.wi.x, 0), seed8(its.wi.y, 1), seed8(its.wi.z, 2)};
         const Vec3<D8> dwo{seed8(wo.x, 3), seed8(wo.y, 4), seed8(wo.z, 5)};
@@ -240,7 +240,7 @@ template <class Sink> struct BsdfRev {
     // dependency alive; Diffuse: constant)
     template <class TVT> PSDR_HD void sampled_pdf_vjp(Sink &sink, const TVT &tv0, const Its<float> &its, const float s[3], float apdf, Vec3f &awi,
                                  float &auvx, float &auvy) const {
-        if (b.type() == PSDR_BSDF_DIFFUSE || apdf == 0.f) return;
+        if (b.is_diffuse(tv0) || apdf == 0.f) return;
         using D5 = Dual<5>;
         const RcParams p = rc_params(tv0, its);
         auto sd = [](float v, int i) { D5 r(v); r.d[i] = 1.f; return r; };
@@ -336,7 +336,7 @@ PSDR_HD Its<float> make_path_vertex(const SceneView &sc, const Vec3f &origin, in
 template <bool BACKWARD, class Sink>
 PSDR_HD VertexOut vertex_eval(Sink &sink, const SceneView &sc, TraversalStack &st, Rng &rng, const Its<float> &its, int nB, int nL,
                               const Vec3f &a_c, const Vec3f &a_f, VertexAdj &va, uint32_t &nrays) {
-    const TangentView<0, Sink::has_env> tv0{};
+    const TangentView<0, Sink::flags> tv0{};
     VertexOut out; out.c = Vec3f(0.f); out.f = Vec3f(0.f); out.next_valid = false;
     // the bounding mesh of the environment map has no BSDF (direct.cpp:54-57): nothing is gathered there and
     // the path ends (the caller stops on !next_valid, so the skipped random numbers are never missed)
@@ -520,8 +520,9 @@ PSDR_HD VertexOut vertex_eval(Sink &sink, const SceneView &sc, TraversalStack &s
     return out;
 }
 
-template <bool ENV = false> struct NullSink {
-    static constexpr bool has_env = ENV;
+template <int FLAGS = kSceneRough> struct NullSink {
+    static constexpr int flags = FLAGS;
+    static constexpr bool has_env = (FLAGS & kSceneEnv) != 0;
     PSDR_HD void add_env(int, float) {}
     PSDR_HD void add_tri(int, int, float) {}
     PSDR_HD void add_texel(int, float) {}
@@ -564,6 +565,7 @@ struct PrimaryGrad {
 };
 // Routes add_tri(primary triangle, word < 21) into registers, everything else to the real sink.
 template <class Sink> struct PrimarySink {
+    static constexpr int flags = Sink::flags;
     static constexpr bool has_env = Sink::has_env;
     Sink &real; PrimaryGrad &pg;
     PSDR_HD void add_env(int w, float v) { real.add_env(w, v); }
@@ -582,7 +584,7 @@ template <class Sink> struct PrimarySink {
 // Back-propagates the adjoints of a PATH-SPACE vertex (k >= 1) into its triangle row and returns the
 // adjoint of the previous vertex' position (wi_k = to_local_k(-(p_k - p_{k-1}) / t)).
 template <class Sink> PSDR_HD Vec3f path_vertex_backward(Sink &sink, const SceneView &sc, const Its<float> &v, const Vec3f &prev_p, VertexAdj va) {
-    const TangentView<0, Sink::has_env> tv0{};
+    const TangentView<0, Sink::flags> tv0{};
     const TriRow<float> T = load_tri<float>(sc, tv0, v.tri);
     const bool face = (sc.d.tri_mesh[v.tri] & PSDR_TRI_FACE_NORMALS) != 0;
     const ShNormal sn = shading_normal(T, face, v.hu, v.hv);
@@ -609,7 +611,7 @@ PSDR_HD Vec3f camera_sample_reverse(RealSink &real_sink, PrimaryGrad &pg, PathRe
     pg.clear();
     PrimarySink<RealSink> sink(real_sink, pg);
     using Sink = PrimarySink<RealSink>;
-    const TangentView<0, Sink::has_env> tv0{};
+    const TangentView<0, Sink::flags> tv0{};
     Rng rng; rng.init(slot, jump);
     const float j0 = rng.next(), j1 = rng.next();
     const int W = sc.d.width;
@@ -682,12 +684,12 @@ PSDR_HD Vec3f camera_sample_reverse(RealSink &real_sink, PrimaryGrad &pg, PathRe
     // ---- sweep 1 (values): record (c_k, f_k), build the suffix radiances T_k
     int nv = 0;
     {
-        NullSink<Sink::has_env> ns; VertexAdj dummy; dummy.clear();
+        NullSink<Sink::flags> ns; VertexAdj dummy; dummy.clear();
         Rng r1 = rng;
         Its<float> cur = its;
         Vec3f beta(1.f);
         for (int k = 0; k < depth; ++k) {
-            const VertexOut vo = vertex_eval<false, NullSink<Sink::has_env>>(ns, sc, st, r1, cur, nB, nL, Vec3f(0.f), Vec3f(0.f), dummy, nrays);
+            const VertexOut vo = vertex_eval<false, NullSink<Sink::flags>>(ns, sc, st, r1, cur, nB, nL, Vec3f(0.f), Vec3f(0.f), dummy, nrays);
             rec.put_cf(k, vo.c, vo.f); nv = k + 1;
             result = result + beta * vo.c;
             if (!vo.next_valid) break;
@@ -754,7 +756,7 @@ PSDR_HD void primary_edge_reverse(Sink &sink, const SceneView &sc, TraversalStac
     const int W = sc.d.width, H = sc.d.height;
     const int ix = (int) floorf(px * (float) W), iy = (int) floorf(py * (float) H);
     const bool valid = ix >= 0 && ix < W && iy >= 0 && iy < H;
-    const TangentView<0, Sink::has_env> tv0{};
+    const TangentView<0, Sink::flags> tv0{};
     const RayT<float> ray_p = primary_ray<float>(sc, tv0, px + kEdgeEpsilon * nx, py + kEdgeEpsilon * ny);
     const RayT<float> ray_n = primary_ray<float>(sc, tv0, px - kEdgeEpsilon * nx, py - kEdgeEpsilon * ny);
     const Vec3f Ln = Li<float, float>(sc, tv0, st, lp, rng, ray_n, valid, nrays);
@@ -776,7 +778,7 @@ PSDR_HD void primary_edge_reverse(Sink &sink, const SceneView &sc, TraversalStac
 template <class Sink>
 PSDR_HD void secondary_edge_reverse(Sink &sink, const SceneView &sc, TraversalStack &st, const float s3[3], float scale,
                                     const float *__restrict__ adj_img, uint32_t &nrays) {
-    const TangentView<0, Sink::has_env> tv0{};
+    const TangentView<0, Sink::flags> tv0{};
     float s1 = s3[0], pdf0;
     const int k = sample_reuse(sc.d.sec_cmf, sc.d.sec_pmf, sc.d.sec_sum, sc.d.num_sec_edges, s1, pdf0);
     const float *se = sc.d.sec_edge + (size_t) k * PSDR_SEDGE_STRIDE;

@@ -988,6 +988,7 @@ class Scene(Object):
                 raise RuntimeError("Unsupported BSDF: " + b.type_name())
             rec.append(r)
         tb["bsdf_rec"] = torch.tensor(rec if rec else [[0] * 16], dtype=torch.int32, device=d).contiguous()
+        tb["material_mask"] = sum({1 << r[0] for r in rec}) if rec else 0      # BSDF types present (psdr_scene_desc.material_mask)
         env_tex = put(self.m_emitter_env.radiance) if self.m_emitter_env is not None else [0, 0, 0]
         tb["texels"] = (torch.cat(pool) if pool else torch.zeros(1, device=d)).to(torch.float32).contiguous()
         tb["mesh_bsdf"] = torch.tensor([bsdf_ids.get(id(m.bsdf), -1) for m in self.m_meshes], dtype=torch.int32, device=d)
@@ -1144,6 +1145,7 @@ def make_desc(tb, guide=None, device=None):
     d.cam = p(tb["cam"])
     d.sec_edge, d.sec_cmf, d.sec_pmf, d.sec_sum = p(tb["sec_edge"]), p(tb["sec_cmf"]), p(tb["sec_pmf"]), tb["sec_sum"]
     d.prim_edge, d.prim_cmf, d.prim_pmf, d.prim_sum = p(tb["prim_edge"]), p(tb["prim_cmf"]), p(tb["prim_pmf"]), tb["prim_sum"]
+    d.material_mask = int(tb.get("material_mask", 0))
     d.env_emitter = int(tb.get("env_emitter", -1))
     if d.env_emitter >= 0:
         for i in range(3):

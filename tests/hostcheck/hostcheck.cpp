@@ -59,8 +59,8 @@ int hostcheck_render(const psdr_scene_desc *d, const psdr_render_opts *o, int mo
     nthreads = std::max(1, nthreads);
     std::vector<std::vector<double>> acc(nthreads, std::vector<double>(n3, 0.0)), dacc(nthreads, std::vector<double>(mode ? n3 : 0, 0.0));
     LiParams lp{o->integrator, o->bsdf_samples, o->light_samples, o->max_depth, o->hide_emitters, o->field};
-    TangentView<1, true> tv1; tv1.t[0] = tan ? *tan : psdr_tangents{};
-    const TangentView<0, true> tv0{};   // ENV = true: the host check always carries the env-map code
+    TangentView<1, kSceneAll> tv1; tv1.t[0] = tan ? *tan : psdr_tangents{};
+    const TangentView<0, kSceneAll> tv0{};   // the host check always carries the env-map and rough-conductor code
     const int nsp = o->spp_end - o->spp_begin;
     if (o->spp > 0 && nsp > 0) {
         const RngJump jump = make_rng_jump(o->rng_offset[0]);
@@ -129,7 +129,7 @@ int hostcheck_guide(const psdr_scene_desc *d, const int *reso, int nrounds, floa
     hs.sc.d.guide_cmf = nullptr; hs.sc.d.num_guide_cells = 0;
     const long long cells = (long long) reso[0] * reso[1] * reso[2], n = cells * reso[3];
     std::vector<double> m(cells, 0.0);
-    const TangentView<0, true> tv0{};   // ENV = true: the host check always carries the env-map code
+    const TangentView<0, kSceneAll> tv0{};   // the host check always carries the env-map and rough-conductor code
     const RngJump nojump{1ull, 0ull};
     pfor(cells, std::max(1, nthreads), [&](long long a, long long b, int) {
         TraversalStack st; uint32_t nr = 0;
@@ -158,6 +158,7 @@ int hostcheck_guide(const psdr_scene_desc *d, const int *reso, int nrounds, floa
 
 namespace {
 struct HostSink {
+    static constexpr int flags = kSceneAll;
     static constexpr bool has_env = true;
     psdr_grads g;
     void add_env(int w, float v) const { put(g.g_env_f, w, v); }
