@@ -55,15 +55,20 @@ def measured_traffic(kernel_key):
     bench.py itself cannot read PMC counters."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), key=os.path.getmtime)
+    try:                      # the summary tools/summarize_prof.py wrote last (file times do not survive a checkout)
+        latest = os.path.join(ROOT, "profiles", json.load(open(os.path.join(ROOT, "profiles", "latest.json")))["traffic"])
+        files = [f for f in files if f != latest] + [latest]
+    except Exception:
+        pass
     for f in reversed(files):
         try:
             d = json.load(open(f))
             for name, v in d["kernels"].items():
                 if "k_camera" in name and kernel_key in name and "rev" not in name:
-                    return v["hbm_bytes_per_launch"], os.path.relpath(f, ROOT)
+                    return v["hbm_bytes_per_launch"], v.get("valu_wave_insts_per_launch"), os.path.relpath(f, ROOT)
         except Exception:
             continue
-    return None, None
+    return None, None, None
 
 
 def main():
@@ -149,9 +154,14 @@ def main():
     dom_rays = rays["d"][0] if ms_d >= ms_c else rays["c"][0]
     abytes = algorithmic_bytes(local_slots, dom_rays, ms_d >= ms_c)
     achieved = abytes / (dom_ms * 1e-3) / 1e9
-    traffic, traffic_src = measured_traffic("Dual<3>" if ms_d >= ms_c else "float, float")
+    traffic, valu_insts, traffic_src = measured_traffic("Dual<3>" if ms_d >= ms_c else "float, float")
+    # the fused kernel keeps the path state in registers, so the stream-model bytes are NOT moved (frac can
+    # exceed 1); what binds it is VALU issue: wave-instructions x 4 cycles (wave64 on a 16-lane SIMD) over the
+    # SIMD-cycles of the launch (1024 SIMDs at 2.4 GHz), instruction count from the committed PMC summary
+    valu_frac = None if not valu_insts else round(valu_insts * 4.0 / (dom_ms * 1e-3 * 2.4e9 * 1024.0), 4)
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(achieved / 8000.0, 5), "traffic": traffic, "traffic_source": traffic_src, "kernel": dom,
+                "valu_issue_frac": valu_frac,
                 "kernel_ms": round(dom_ms, 4), "rays_per_slot": round(dom_rays / local_slots, 4),
                 "algorithmic_bytes_per_launch": abytes,
                 "render_c_ms": round(ms_c, 4), "render_d_ms": round(ms_d, 4)}

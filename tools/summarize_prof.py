@@ -35,10 +35,20 @@ for f in ("pmc_FETCH_SIZE.txt", "pmc_WRITE_SIZE.txt"):
         m = re.search(r"(k_[a-z_]+<[^(]*>|k_[a-z_]+)\(.*?(FETCH_SIZE|WRITE_SIZE)\s+dispatches=(\d+)\s+total=([0-9.e+]+)\s+per_dispatch=([0-9.e+]+)", line)
         if m:
             traffic.setdefault(m.group(1).strip(), {})[m.group(2)] = float(m.group(5))
+# VALU wave-instructions per launch (SQ_INSTS_VALU): bench.py turns them into the VALU issue fraction
+valu = {}
+fp = os.path.join(src, "pmc_SQ_WAVES.txt")
+if os.path.exists(fp):
+    for line in open(fp):
+        m = re.search(r"(k_[a-z_]+<[^(]*>|k_[a-z_]+)\(.*?SQ_INSTS_VALU\s+dispatches=(\d+)\s+total=([0-9.e+]+)\s+per_dispatch=([0-9.e+]+)", line)
+        if m:
+            valu[m.group(1).strip()] = float(m.group(4))
 tj = {k: {"fetch_kib": v.get("FETCH_SIZE"), "write_kib": v.get("WRITE_SIZE"),
-          "hbm_bytes_per_launch": (2.0 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * 1024.0} for k, v in traffic.items()}
+          "hbm_bytes_per_launch": (2.0 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * 1024.0,
+          "valu_wave_insts_per_launch": valu.get(k)} for k, v in traffic.items()}
 os.makedirs("profiles", exist_ok=True)
 json.dump({"tag": tag, "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate 1-step passes of bench.py; bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024", "kernels": tj},
           open(os.path.join("profiles", tag + "_traffic.json"), "w"), indent=1)
+json.dump({"tag": tag, "traffic": tag + "_traffic.json", "summary": tag + "_summary.txt"}, open(os.path.join("profiles", "latest.json"), "w"))
 open(os.path.join("profiles", tag + "_summary.txt"), "w").write("\n".join(out) + "\n")
 print("\n".join(out))
