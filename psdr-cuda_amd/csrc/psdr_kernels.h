@@ -388,15 +388,17 @@ template <int FL> struct DeviceSink {
 #ifndef PSDR_WAVES_REV
 #define PSDR_WAVES_REV 2
 #endif
-template <int FL>
-__global__ __launch_bounds__(kBlock, PSDR_WAVES_REV) void k_camera_rev(LaunchCtx cx, DeviceSink<FL> sink, int spp, int s_begin, int nsp, long long n, float inv_spp,
+#ifndef PSDR_WAVES_REV_MAT
+#define PSDR_WAVES_REV_MAT 3
+#endif
+template <int FL, bool GEO>
+__global__ __launch_bounds__(kBlock, (GEO ? PSDR_WAVES_REV : PSDR_WAVES_REV_MAT)) void k_camera_rev(LaunchCtx cx, DeviceSink<FL> sink, int spp, int s_begin, int nsp, long long n, float inv_spp,
                                                        const float *__restrict__ adj_img, float *__restrict__ img,
                                                        unsigned long long *counters) {
     __shared__ float cache[kSinkCacheWords];
     TraversalStack st; setup_lds(cx, st);
     sink.begin(cache);
     uint32_t nrays = 0;
-    const bool geo = sink.g.g_tri_info != nullptr || sink.g.g_cam_to_world != nullptr;
     const long long nceil = (n + kBlock - 1) / kBlock * kBlock;
     for (long long j = (long long) blockIdx.x * kBlock + threadIdx.x; j < nceil; j += (long long) gridDim.x * kBlock) {
         const bool in = j < n;
@@ -412,11 +414,11 @@ __global__ __launch_bounds__(kBlock, PSDR_WAVES_REV) void k_camera_rev(LaunchCtx
             const uint64_t slot = (uint64_t) pixel * (uint64_t) spp + (uint64_t) s;
             const float *a = adj_img + (size_t) pixel * 3;
             const Vec3f adj{a[0] * inv_spp, a[1] * inv_spp, a[2] * inv_spp};
-            const Vec3f r = camera_sample_reverse(sink, pg, rec, cx.sc, st, cx.lp, cx.jump, pixel, slot, adj, nrays, geo);
+            const Vec3f r = camera_sample_reverse<GEO>(sink, pg, rec, cx.sc, st, cx.lp, cx.jump, pixel, slot, adj, nrays);
             v[0] = r.x * inv_spp; v[1] = r.y * inv_spp; v[2] = r.z * inv_spp;
         }
         // primary-triangle row: one add per run of lanes that hit the same triangle
-        if (sink.g.g_tri_info != nullptr) {
+        if (GEO && sink.g.g_tri_info != nullptr) {
             const bool head = wave_run_sum<kPrimaryWords>(pg.tri, pg.w);
             if (head && pg.tri >= 0) {
 #pragma unroll
@@ -591,8 +593,13 @@ int render_rev(psdr_scene_s *h, const psdr_render_opts *o, const float *adj_img,
         const int rec_bytes = depth * 6 * kBlock * 4;
         plan_lds(h, cx, rec_bytes + kSinkCacheWords * 4);          // stage less of the scene: the record + cache live in LDS too
         cx.off_pathrec = lds_bytes(cx, h);
-        hipLaunchKernelGGL(k_camera_rev<FL>, dim3(launch_blocks(h, n)), dim3(kBlock), lds_bytes(cx, h) + rec_bytes, s, cx, sink, o->spp, o->spp_begin, nsp, n,
-                           1.f / (float) o->spp, adj_img, out_img, h->d_counters);
+        // material-only gradients (no triangle / camera table wanted) run the variant without the geometric adjoints
+        if (grads->g_tri_info != nullptr || grads->g_cam_to_world != nullptr)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_camera_rev<FL, true>), dim3(launch_blocks(h, n)), dim3(kBlock), lds_bytes(cx, h) + rec_bytes, s, cx, sink, o->spp,
+                               o->spp_begin, nsp, n, 1.f / (float) o->spp, adj_img, out_img, h->d_counters);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_camera_rev<FL, false>), dim3(launch_blocks(h, n)), dim3(kBlock), lds_bytes(cx, h) + rec_bytes, s, cx, sink, o->spp,
+                               o->spp_begin, nsp, n, 1.f / (float) o->spp, adj_img, out_img, h->d_counters);
         HIP_TRY(hipGetLastError());
     }
     if (o->sppe > 0 && o->sppe_end > o->sppe_begin && h->desc.num_prim_edges > 0 && grads->g_prim_edge) {

@@ -581,6 +581,25 @@ template <class Sink> struct PrimarySink {
     PSDR_HD void add_pedge(int e, int w, float v) { real.add_pedge(e, w, v); }
 };
 
+// Drops every geometry adjoint AT COMPILE TIME (material-only gradients: texels, emitter radiance, the
+// environment-map record): with these empty members the whole geometric adjoint chain of the estimators
+// -- frames, Moeller-Trumbore, path-space directions, the LDS adds of triangle rows -- is dead code.
+template <class Sink> struct MaterialSink {
+    static constexpr int flags = Sink::flags;
+    static constexpr bool has_env = Sink::has_env;
+    Sink &real;
+    PSDR_HD MaterialSink(Sink &r, PrimaryGrad &) : real(r) {}
+    PSDR_HD void add_tri(int, int, float) {}
+    PSDR_HD void add_cam(int, float) {}
+    PSDR_HD void add_sedge(int, int, float) {}
+    PSDR_HD void add_pedge(int, int, float) {}
+    PSDR_HD void add_texel(int i, float v) { real.add_texel(i, v); }
+    PSDR_HD void add_rad(int e, int c, float v) { real.add_rad(e, c, v); }
+    PSDR_HD void add_env(int w, float v) { real.add_env(w, v); }
+};
+template <bool GEO, class RealSink> struct CameraSinkOf { using type = PrimarySink<RealSink>; };
+template <class RealSink> struct CameraSinkOf<false, RealSink> { using type = MaterialSink<RealSink>; };
+
 // Back-propagates the adjoints of a PATH-SPACE vertex (k >= 1) into its triangle row and returns the
 // adjoint of the previous vertex' position (wi_k = to_local_k(-(p_k - p_{k-1}) / t)).
 template <class Sink> PSDR_HD Vec3f path_vertex_backward(Sink &sink, const SceneView &sc, const Its<float> &v, const Vec3f &prev_p, VertexAdj va) {
@@ -603,14 +622,16 @@ template <class Sink> PSDR_HD Vec3f path_vertex_backward(Sink &sink, const Scene
 
 // One camera sample in reverse mode (Integrator::__render<true> + enoki.backward).
 //   adj = dLoss/d(pixel) / spp.   Returns the primal sample value.
-//   geo: a geometry gradient (triangle table / camera) is wanted -> solid-angle form of the primary hit and
-//        its adjoint chain; otherwise the on-surface form, exactly like forward mode (psdr_device.h Li)
-template <class RealSink>
+//   GEO: a geometry gradient (triangle table / camera) is wanted -> solid-angle form of the primary hit and
+//        the geometric adjoint chain; otherwise the on-surface form, exactly like forward mode
+//        (psdr_device.h Li), and every geometry adjoint is compiled out (MaterialSink)
+template <bool GEO, class RealSink>
 PSDR_HD Vec3f camera_sample_reverse(RealSink &real_sink, PrimaryGrad &pg, PathRec &rec, const SceneView &sc, TraversalStack &st, const LiParams &lp,
-                                    const RngJump &jump, int pixel, uint64_t slot, const Vec3f &adj, uint32_t &nrays, bool geo = true) {
+                                    const RngJump &jump, int pixel, uint64_t slot, const Vec3f &adj, uint32_t &nrays) {
+    constexpr bool geo = GEO;
     pg.clear();
-    PrimarySink<RealSink> sink(real_sink, pg);
-    using Sink = PrimarySink<RealSink>;
+    using Sink = typename CameraSinkOf<GEO, RealSink>::type;
+    Sink sink(real_sink, pg);
     const TangentView<0, Sink::flags> tv0{};
     Rng rng; rng.init(slot, jump);
     const float j0 = rng.next(), j1 = rng.next();

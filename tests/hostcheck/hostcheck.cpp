@@ -189,8 +189,9 @@ extern "C" int hostcheck_render_rev(const psdr_scene_desc *d, const psdr_render_
             const float inv = 1.f / o->spp;
             const Vec3f a{adj[pixel * 3] * inv, adj[pixel * 3 + 1] * inv, adj[pixel * 3 + 2] * inv};
             PrimaryGrad pg; PathRec rec;
-            const Vec3f r = camera_sample_reverse(sink, pg, rec, hs.sc, st, lp, jump, pixel, (uint64_t) pixel * o->spp + s, a, nr,
-                                                  grads->g_tri_info != nullptr || grads->g_cam_to_world != nullptr);
+            const bool geo = grads->g_tri_info != nullptr || grads->g_cam_to_world != nullptr;
+            const Vec3f r = geo ? camera_sample_reverse<true>(sink, pg, rec, hs.sc, st, lp, jump, pixel, (uint64_t) pixel * o->spp + s, a, nr)
+                                : camera_sample_reverse<false>(sink, pg, rec, hs.sc, st, lp, jump, pixel, (uint64_t) pixel * o->spp + s, a, nr);
             if (pg.tri >= 0) for (int w = 0; w < kPrimaryWords; ++w) sink.add_tri(pg.tri, w, pg.w[w]);
             acc[pixel * 3] += r.x * inv; acc[pixel * 3 + 1] += r.y * inv; acc[pixel * 3 + 2] += r.z * inv;
         }
