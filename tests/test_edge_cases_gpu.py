@@ -1,0 +1,117 @@
+"""Edge cases of the C ABI on the GPU: degenerate and minimal inputs, limits and error paths
+(the reference asserts on most of these: integrator.cpp:65,74; scene.cpp:57,427)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+import psdr_cuda
+from helpers import GpuScene, load_scene, rel_l2
+from psdr_cuda import _abi
+from psdr_cuda.scene import look_at
+
+pytestmark = pytest.mark.gpu
+
+
+def tiny_scene(verts, faces, emitter=True, res=16, spp=4, extra=None):
+    """one mesh (optionally emissive) + optional second mesh, seen from z = +5"""
+    sc = psdr_cuda.Scene()
+    sc.opts.width = sc.opts.height = res
+    sc.opts.spp, sc.opts.sppe, sc.opts.sppse, sc.opts.log_level = spp, 0, 0, 0
+    cam = psdr_cuda.PerspectiveCamera(40.0, 0.1, 1e3)
+    cam.to_world = look_at([0, 0, 5], [0, 0, 0], [0, 1, 0])
+    sc.add_sensor(cam)
+    b = psdr_cuda.Diffuse([0.5, 0.6, 0.7]); b.id = "b"
+    sc.add_bsdf(b)
+    m = psdr_cuda.Mesh()
+    m.use_face_normals = True
+    m.set_geometry(np.asarray(verts, np.float32), np.asarray(faces, np.int32))
+    sc.add_mesh(m, b, emitter_radiance=[3.0, 2.0, 1.0] if emitter else None)
+    if extra is not None:
+        m2 = psdr_cuda.Mesh()
+        m2.use_face_normals = True
+        m2.set_geometry(np.asarray(extra[0], np.float32), np.asarray(extra[1], np.int32))
+        sc.add_mesh(m2, b)
+    sc.finalize()
+    sc.configure()
+    return sc
+
+
+TRI = ([[-1, -1, 0], [1, -1, 0], [0, 1, 0]], [[0, 1, 2]])
+
+
+def test_single_triangle_scene_root_is_a_leaf():
+    tb = tiny_scene(*TRI).tables(0)
+    assert tb["num_tris"] == 1
+    for kw in (dict(bsdf_samples=1, light_samples=1), dict(integrator=_abi.INTEGRATOR_PATH, max_depth=3),
+               dict(integrator=_abi.INTEGRATOR_FIELD, field=_abi.FIELDS["depth"])):
+        o = _abi.make_opts(spp=4, **kw)
+        img, ref = GpuScene(tb).render_c(o), oracle.render(tb, o)
+        assert np.isfinite(img).all() and rel_l2(img, ref) < 1e-5 and img.max() > 0
+
+
+def test_two_meshes_emitter_facing_a_receiver():
+    quad = ([[-1, -1, -1], [1, -1, -1], [1, 1, -1], [-1, 1, -1]], [[0, 1, 2], [0, 2, 3]])
+    light = ([[-0.5, -0.5, 1], [0.5, -0.5, 1], [0.5, 0.5, 1], [-0.5, 0.5, 1]], [[0, 2, 1], [0, 3, 2]])     # faces -z, towards the quad
+    sc = tiny_scene(light[0], light[1], True, extra=quad)
+    tb = sc.tables(0)
+    o = _abi.make_opts(spp=4, bsdf_samples=1, light_samples=1)
+    img, ref = GpuScene(tb).render_c(o), oracle.render(tb, o)
+    assert rel_l2(img, ref) < 1e-5 and img.mean() > 0
+
+
+def test_degenerate_triangle_is_never_hit_and_never_sampled():
+    verts = [[-1, -1, 0], [1, -1, 0], [0, 1, 0], [2, 2, 0], [2, 2, 0], [2, 2, 0]]          # second face: zero area
+    tb = tiny_scene(verts, [[0, 1, 2], [3, 4, 5]]).tables(0)
+    assert float(tb["tri_info"][1, 21]) == 0.0
+    g = GpuScene(tb)
+    o = _abi.make_opts(spp=8, bsdf_samples=1, light_samples=1)
+    img = g.render_c(o)
+    assert np.isfinite(img).all() and rel_l2(img, oracle.render(tb, o)) < 1e-5
+    rays_o = np.tile(np.array([[2.0, 2.0, 5.0]], np.float32), (64, 1))
+    rays_d = np.tile(np.array([[0.0, 0.0, -1.0]], np.float32), (64, 1))
+    _, tri, _, _ = g.trace(rays_o, rays_d)
+    assert (tri == -1).all()
+
+
+def test_scene_without_emitter_fails_like_the_reference():
+    tb = tiny_scene(*TRI, emitter=False).tables(0)
+    g = GpuScene(tb)
+    with pytest.raises(RuntimeError, match="No Emitter!"):
+        g.render_c(_abi.make_opts(spp=4, bsdf_samples=1, light_samples=1))
+    img = g.render_c(_abi.make_opts(spp=4, integrator=_abi.INTEGRATOR_FIELD, field=_abi.FIELDS["silhouette"]))     # needs no emitter
+    assert 0.0 < img.mean() < 1.0
+
+
+def test_limits_and_empty_work():
+    sc, _ = load_scene("cbox", res=16, spp=4)
+    tb = sc.tables(0)
+    g = GpuScene(tb)
+    with pytest.raises(RuntimeError, match="Too many samples"):
+        g.render_c(_abi.make_opts(spp=2 ** 24))                   # 16*16*2^24 > INT_MAX, integrator.cpp:74
+    with pytest.raises(RuntimeError, match="Invalid spp shard range"):
+        g.render_c(_abi.make_opts(spp=4, spp_range=(2, 9)))
+    with pytest.raises(RuntimeError, match="bsdf_samples \\+ light_samples"):
+        g.render_c(_abi.make_opts(spp=4, bsdf_samples=0, light_samples=0))
+    empty = g.render_c(_abi.make_opts(spp=4, spp_range=(2, 2)))   # a rank that owns no sample: zero image, no error
+    assert empty.shape == (256, 3) and not empty.any()
+    assert not g.render_c(_abi.make_opts(spp=0)).any()
+    t = {"texels": torch.ones_like(tb["texels"])}
+    with pytest.raises(RuntimeError, match="K must be 1 or 3"):
+        g.render_d_fwd(_abi.make_opts(spp=4), [t, t])
+    with pytest.raises(RuntimeError, match="max_depth > 8"):
+        g.render_d_rev(_abi.make_opts(spp=4, integrator=_abi.INTEGRATOR_PATH, max_depth=9), np.ones((256, 3), np.float32), want=["texels"])
+
+
+def test_null_arguments_and_unconfigured_handle():
+    lib = _abi.load_hip()
+    assert lib.psdr_render_c(None, None, None, None) != 0 and b"null argument" in lib.psdr_last_error()
+    h = C.c_void_p()
+    assert lib.psdr_scene_create(C.byref(h)) == 0
+    o = _abi.make_opts(spp=1)
+    buf = torch.zeros(3, device="cuda")
+    assert lib.psdr_render_c(h, C.byref(o), buf.data_ptr(), None) != 0 and b"Scene not loaded yet!" in lib.psdr_last_error()
+    assert lib.psdr_bvh_build(h, None) != 0
+    assert lib.psdr_scene_destroy(h) == 0

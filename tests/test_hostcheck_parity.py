@@ -123,3 +123,14 @@ def test_guided_secondary_edges():
     _, ref_d = oracle.render(tb, o, mode=1, tangents=tan, guide=guide)
     _, dimg = host_render(tb, o, mode=1, tangents=tan, guide=guide)
     assert np.abs(ref_d).max() > 0 and rel_l2(dimg, ref_d) < 1e-3
+
+
+def test_minimal_and_degenerate_scenes():
+    """1-triangle scene (the BVH root is a leaf) and a mesh with a zero-area face: product code vs oracle"""
+    from test_edge_cases_gpu import TRI, tiny_scene
+    for verts, faces in (TRI, ([[-1, -1, 0], [1, -1, 0], [0, 1, 0], [2, 2, 0], [2, 2, 0], [2, 2, 0]], [[0, 1, 2], [3, 4, 5]])):
+        tb = tiny_scene(verts, faces).tables(0)
+        for kw in (OPTS["direct11"], OPTS["path4"], OPTS["field_pos"]):
+            o = _abi.make_opts(spp=4, **kw)
+            a, b = host_render(tb, o), oracle.render(tb, o)
+            assert np.isfinite(a).all() and rel_l2(a, b) < 2e-5
