@@ -207,8 +207,14 @@ int psdr_scene_set_tables(psdr_scene_t h, const psdr_scene_desc *desc);
 
 /* Replaces Scene_OptiX::configure + the OptiX GAS build
    (src/scene/scene_optix.cpp:34-72, include/psdr/scene/optix.h:277-340):
-   builds the BVH over tri_info (p0,e1,e2) of the current tables. */
+   builds the BVH over tri_info (p0,e1,e2) of the current tables.  When the triangle count is
+   unchanged since the last build (an optimisation loop moving vertices) the tree is refitted on
+   the device instead of rebuilt (OptiX's build is a device build too); it is rebuilt when the
+   refitted boxes have grown by 30 % in area or after 64 refits.  PSDR_BVH_REFIT=0 in the
+   environment forces a rebuild every time. */
 int psdr_bvh_build(psdr_scene_t h, void *stream);
+/* out = { full builds, refits, inner nodes, tree depth } of this handle (diagnostics) */
+int psdr_bvh_stats(psdr_scene_t h, int32_t out[4]);
 
 /* Replaces Scene_OptiX::ray_intersect + the OptiX programs
    (scene_optix.cpp:81-126, cuda/psdr_cuda.cu:9-45): closest hit with

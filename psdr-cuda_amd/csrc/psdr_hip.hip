@@ -4,6 +4,8 @@
 #include "psdr_host.h"
 #include "psdr_bvh_build.h"
 
+#include <cstdlib>
+
 namespace {
 // ------------------------------------------------------------------------------- k_trace
 __global__ __launch_bounds__(kBlock) void k_trace(LaunchCtx cx, int m, const float *__restrict__ ox, const float *__restrict__ oy,
@@ -21,6 +23,57 @@ __global__ __launch_bounds__(kBlock) void k_trace(LaunchCtx cx, int m, const flo
     }
 }
 
+
+// ------------------------------------------------------------------------------- BVH refit
+// Between two Scene::configure() calls of an optimisation loop the topology stays and the vertices move a
+// little: instead of the host rebuild (D2H of the triangle table, SAH build, H2D: ~2.5 ms for 5 k
+// triangles, ~10 ms for 50 k) the tree is REFITTED on the device -- leaf triangles re-read from the new
+// table, boxes recomputed bottom-up level by level (breadth-first node order = levels are contiguous).
+// Always correct (boxes are recomputed from the actual triangles); the summed box area of the inner nodes
+// tells when the tree has degraded enough to be rebuilt.
+__global__ __launch_bounds__(kBlock) void k_refit_leaves(float4 *__restrict__ btris, const float *__restrict__ tri_info, int n) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const int id = __float_as_int(btris[(size_t) i * 3].w);
+    const float *r = tri_info + (size_t) id * PSDR_TRI_STRIDE;
+    float4 a{r[0], r[1], r[2], 0.f};
+    a.w = __int_as_float(id);
+    btris[(size_t) i * 3] = a;
+    btris[(size_t) i * 3 + 1] = float4{r[3], r[4], r[5], 0.f};
+    btris[(size_t) i * 3 + 2] = float4{r[6], r[7], r[8], 0.f};
+}
+__device__ __forceinline__ void child_box(const BvhNode *nodes, const float4 *btris, int32_t c, float pad, float *lo, float *hi) {
+    for (int k = 0; k < 3; ++k) { lo[k] = INFINITY; hi[k] = -INFINITY; }
+    if (c < 0) {
+        const int enc = ~c, first = enc >> 3, cnt = (enc & 7) + 1;
+        for (int i = 0; i < cnt; ++i) {
+            const float4 a = btris[(size_t) (first + i) * 3], b = btris[(size_t) (first + i) * 3 + 1], e = btris[(size_t) (first + i) * 3 + 2];
+            const float p[3] = {a.x, a.y, a.z}, q[3] = {a.x + b.x, a.y + b.y, a.z + b.z}, w[3] = {a.x + e.x, a.y + e.y, a.z + e.z};
+            for (int k = 0; k < 3; ++k) { lo[k] = fminf(lo[k], fminf(p[k], fminf(q[k], w[k]))); hi[k] = fmaxf(hi[k], fmaxf(p[k], fmaxf(q[k], w[k]))); }
+        }
+        for (int k = 0; k < 3; ++k) { lo[k] -= pad; hi[k] += pad; }
+    } else {
+        const BvhNode &n = nodes[c];
+        for (int k = 0; k < 3; ++k) { lo[k] = fminf(n.lo0[k], n.lo1[k]); hi[k] = fmaxf(n.hi0[k], n.hi1[k]); }
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_refit_level(BvhNode *__restrict__ nodes, const float4 *__restrict__ btris, int first, int count, float pad,
+                                                        float *__restrict__ area_sum) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    float area = 0.f;
+    if (i < count) {
+        BvhNode n = nodes[first + i];
+        child_box(nodes, btris, n.c0, pad, n.lo0, n.hi0);
+        child_box(nodes, btris, n.c1, pad, n.lo1, n.hi1);
+        nodes[first + i] = n;
+        const float dx = fmaxf(n.hi0[0], n.hi1[0]) - fminf(n.lo0[0], n.lo1[0]), dy = fmaxf(n.hi0[1], n.hi1[1]) - fminf(n.lo0[1], n.lo1[1]),
+                    dz = fmaxf(n.hi0[2], n.hi1[2]) - fminf(n.lo0[2], n.lo1[2]);
+        area = dx * dy + dy * dz + dz * dx;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) area += __shfl_down(area, off, 64);
+    if ((threadIdx.x & 63) == 0 && area != 0.f) atomicAdd(area_sum, area);
+}
 
 thread_local std::string g_err;
 }  // namespace
@@ -141,6 +194,7 @@ int psdr_scene_create(psdr_scene_t *out) {
     if (e != hipSuccess) { delete h; return fail(std::string("hipMalloc: ") + hipGetErrorString(e)); }
     int dev = 0; hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) h->num_cus = prop.multiProcessorCount;
+    if (const char *e2 = std::getenv("PSDR_BVH_REFIT")) h->refit_enabled = std::atoi(e2) != 0;      // 0: always rebuild on the host
     *out = h;
     return 0;
 }
@@ -150,6 +204,7 @@ int psdr_scene_destroy(psdr_scene_t h) {
     if (h->d_nodes) (void) hipFree(h->d_nodes);
     if (h->d_btris) (void) hipFree(h->d_btris);
     if (h->d_counters) (void) hipFree(h->d_counters);
+    if (h->d_refit_area) (void) hipFree(h->d_refit_area);
     if (h->d_ws) (void) hipFree(h->d_ws);
     if (h->d_hot_map) (void) hipFree(h->d_hot_map);
     if (h->d_hot_tris) (void) hipFree(h->d_hot_tris);
@@ -180,6 +235,25 @@ int psdr_bvh_build(psdr_scene_t h, void *stream) {
     if (!h || !h->have_tables) return fail("Scene not loaded yet!");
     hipStream_t s = (hipStream_t) stream;
     const int T = h->desc.num_tris;
+    // ---- refit: same triangle count as the tree on the device and the tree has not degraded
+    if (h->refit_enabled && h->tree_tris == T && h->num_nodes > 0 && h->refits_since_build < kMaxRefits) {
+        float prev_area = h->built_area;
+        if (h->refits_since_build > 0) HIP_TRY(hipMemcpy(&prev_area, h->d_refit_area, sizeof(float), hipMemcpyDeviceToHost));   // of the PREVIOUS refit: done long ago
+        if (prev_area <= kRefitAreaGrowth * h->built_area) {
+            HIP_TRY(hipMemsetAsync(h->d_refit_area, 0, sizeof(float), s));
+            hipLaunchKernelGGL(k_refit_leaves, dim3((h->num_btris + kBlock - 1) / kBlock), dim3(kBlock), 0, s, h->d_btris, h->desc.tri_info, h->num_btris);
+            for (int l = (int) h->level_start.size() - 2; l >= 0; --l) {
+                const int first = h->level_start[l], count = h->level_start[l + 1] - first;
+                hipLaunchKernelGGL(k_refit_level, dim3((count + kBlock - 1) / kBlock), dim3(kBlock), 0, s, h->d_nodes, h->d_btris, first, count, h->bvh_pad,
+                                   h->d_refit_area);
+            }
+            HIP_TRY(hipGetLastError());
+            h->refits_since_build++;
+            h->num_refits++;
+            h->have_bvh = true;
+            return 0;
+        }
+    }
     std::vector<float> rows((size_t) T * PSDR_TRI_STRIDE);
     HIP_TRY(hipMemcpyAsync(rows.data(), h->desc.tri_info, rows.size() * sizeof(float), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
@@ -230,6 +304,25 @@ int psdr_bvh_build(psdr_scene_t h, void *stream) {
     h->root = root;
     h->bvh_depth = b.max_depth; h->num_nodes = (int) b.nodes.size(); h->num_btris = (int) b.btris.size() / 3;
     h->have_bvh = true;
+    // what the refit path needs: the levels of the breadth-first node order, the padding, the reference area
+    h->tree_tris = T; h->refits_since_build = 0; h->num_builds++; h->bvh_pad = b.pad;
+    h->level_start.clear();
+    double area = 0.0;
+    if (root >= 0) {
+        std::vector<int> depth(b.nodes.size(), 0);
+        for (size_t i = 0; i < b.nodes.size(); ++i) {
+            const BvhNode &n = b.nodes[i];
+            if (n.c0 >= 0) depth[n.c0] = depth[i] + 1;
+            if (n.c1 >= 0) depth[n.c1] = depth[i] + 1;
+            if (i == 0 || depth[i] != depth[i - 1]) h->level_start.push_back((int) i);
+            const float dx = std::max(n.hi0[0], n.hi1[0]) - std::min(n.lo0[0], n.lo1[0]), dy = std::max(n.hi0[1], n.hi1[1]) - std::min(n.lo0[1], n.lo1[1]),
+                        dz = std::max(n.hi0[2], n.hi1[2]) - std::min(n.lo0[2], n.lo1[2]);
+            area += dx * dy + dy * dz + dz * dx;
+        }
+        h->level_start.push_back((int) b.nodes.size());
+    }
+    h->built_area = (float) area;
+    if (!h->d_refit_area) HIP_TRY(hipMalloc(&h->d_refit_area, sizeof(float)));
     return 0;
 }
 
@@ -295,6 +388,12 @@ int psdr_guide_build(psdr_scene_t h, const psdr_render_opts *o, const int32_t re
     if (n <= 0 || n > 0x7fffffffLL) return fail("psdr_guide_build: invalid resolution");
     HIP_TRY(hipMemsetAsync(out_mass, 0, sizeof(float) * cells, s));
     return variant_of(h)->guide(h, cx, reso, nrounds, n, out_mass, s);
+}
+
+int psdr_bvh_stats(psdr_scene_t h, int32_t out[4]) {
+    if (!h || !out) return fail("psdr_bvh_stats: null argument");
+    out[0] = h->num_builds; out[1] = h->num_refits; out[2] = h->num_nodes; out[3] = h->bvh_depth;
+    return 0;
 }
 
 int psdr_get_counters(psdr_scene_t h, uint64_t out[4]) {

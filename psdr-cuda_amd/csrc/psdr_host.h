@@ -81,6 +81,12 @@ struct psdr_scene_s {
     int num_cus = 256;
     std::vector<int32_t> emitter_i;
     int bvh_depth = 0, num_nodes = 0, num_btris = 0;
+    // device refit of the tree between rebuilds (psdr_hip.hip k_refit_*)
+    bool refit_enabled = true;
+    int tree_tris = -1, refits_since_build = 0, num_builds = 0, num_refits = 0;
+    std::vector<int> level_start;          // breadth-first node order: first node of every level (+ end)
+    float bvh_pad = 0.f, built_area = 0.f;
+    float *d_refit_area = nullptr;
     int32_t *d_hot_map = nullptr, *d_hot_tris = nullptr; int hot_rows = 0; size_t hot_cap = 0;   // reverse sink: LDS-cached triangle rows
     void *d_ws = nullptr; size_t ws_bytes = 0;
     int last_path_depth = 0; float path_survival = -1.f;   // rays traced / rays of fully surviving paths (last PathTracer call)          // wavefront path-state streams + counters          // host copy of desc.emitter_i (hot-row ranges of the reverse sink)
@@ -97,6 +103,8 @@ bool use_wavefront(const psdr_scene_s *h, const psdr_render_opts *o);
 SinkLayout make_sink_layout(const psdr_scene_s *h, const psdr_grads *g);
 int check_counts(const psdr_scene_s *h, const psdr_render_opts *o);
 int begin_call(psdr_scene_s *h, hipStream_t s);
+constexpr int kMaxRefits = 64;              // full SAH rebuild at least this often
+constexpr float kRefitAreaGrowth = 1.3f;    // ... or when the summed inner-box area grew by 30 %
 
 // entry points of one kernel variant (one scene flag set)
 struct VariantOps {

@@ -83,7 +83,7 @@ TANGENT_FIELDS = ("tri_info", "texels", "emitter_rad", "cam_to_world", "sec_edge
 # every symbol include/psdr_hip.h declares (checked by tests/test_abi.py)
 HIP_SYMBOLS = (
     "psdr_last_error", "psdr_version", "psdr_abi_struct_sizes", "psdr_scene_create", "psdr_scene_destroy", "psdr_scene_set_tables",
-    "psdr_bvh_build", "psdr_trace", "psdr_render_c", "psdr_render_d_fwd", "psdr_render_d_rev",
+    "psdr_bvh_build", "psdr_bvh_stats", "psdr_trace", "psdr_render_c", "psdr_render_d_fwd", "psdr_render_d_rev",
     "psdr_guide_build", "psdr_get_counters",
 )
 

@@ -276,15 +276,13 @@ class PerspectiveCamera(Sensor):
         self.m_enable_edges = False
         if scene.opts.sppe > 0:
             rows = []
-            for mesh in scene.m_meshes:
-                if not mesh.enable_edges or mesh._edge_indices is None or mesh._edge_indices.shape[0] == 0:
-                    continue
-                ei = mesh._edge_indices_dev
-                tinfo = mesh._triangle_info
-                psdr_assert(bool((ei[:, 2] >= 0).all()))
+            bt = scene._batch
+            ei = bt["tp"]["edges"]
+            if ei is not None:
+                tinfo, vpos, facen = bt["tri_info"], bt["v_world"], bt["tp"]["edge_face_normals"]
                 valid = ei[:, 3] >= 0
-                f1 = torch.where(valid, ei[:, 3], torch.zeros_like(ei[:, 3])).long()
-                f0 = ei[:, 2].long()
+                f1 = torch.where(valid, ei[:, 3], torch.zeros_like(ei[:, 3]))
+                f0 = ei[:, 2]
                 vm = valid.unsqueeze(-1).to(torch.float32)
                 e0 = _normalize(cam_pos - tinfo[f0, 0:3])
                 # masked gather reads zeros for invalid lanes: normalize(cam_pos - 0)
@@ -292,22 +290,20 @@ class PerspectiveCamera(Sensor):
                 n0 = tinfo[f0, 18:21]
                 n1 = tinfo[f1, 18:21] * vm
                 d0, d1, dn = (e0 * n0).sum(-1), (e1 * n1).sum(-1), (n0 * n1).sum(-1)
-                if mesh.use_face_normals:
-                    skip = valid & (((d0 < Epsilon) & (d1 < Epsilon)) | (dn > 1.0 - Epsilon))
-                    keep = ~skip
-                else:
-                    keep = (~valid) | ((d0 > Epsilon) ^ (d1 > Epsilon))
+                keep_face = ~(valid & (((d0 < Epsilon) & (d1 < Epsilon)) | (dn > 1.0 - Epsilon)))      # face-normal meshes
+                keep_smooth = (~valid) | ((d0 > Epsilon) ^ (d1 > Epsilon))                             # smooth-shaded meshes
+                keep = torch.where(facen, keep_face, keep_smooth)
                 info = ei[keep.detach()]
-                psdr_assert(info.shape[0] > 0)
-                p0 = mesh._vertex_positions[info[:, 0].long()]
-                p1 = mesh._vertex_positions[info[:, 1].long()]
-                q0 = transform_pos(w2s, p0)[:, :2]
-                q1 = transform_pos(w2s, p1)[:, :2]
-                e = (q1 - q0).detach()
-                ln = torch.sqrt((e * e).sum(-1))
-                e = e / ln.unsqueeze(-1)
-                nrm = torch.stack([-e[:, 1], e[:, 0]], dim=-1)
-                rows.append(torch.cat([q0, q1, nrm, ln.unsqueeze(-1), torch.zeros_like(ln).unsqueeze(-1)], dim=-1))
+                if info.shape[0] > 0:
+                    p0 = vpos[info[:, 0]]
+                    p1 = vpos[info[:, 1]]
+                    q0 = transform_pos(w2s, p0)[:, :2]
+                    q1 = transform_pos(w2s, p1)[:, :2]
+                    e = (q1 - q0).detach()
+                    ln = torch.sqrt((e * e).sum(-1))
+                    e = e / ln.unsqueeze(-1)
+                    nrm = torch.stack([-e[:, 1], e[:, 0]], dim=-1)
+                    rows.append(torch.cat([q0, q1, nrm, ln.unsqueeze(-1), torch.zeros_like(ln).unsqueeze(-1)], dim=-1))
             if rows:
                 pe = torch.cat(rows, dim=0).contiguous()
                 d = DiscreteDistribution(); d.init(pe[:, 6].detach())
@@ -446,7 +442,7 @@ class Mesh(Object):
         self._triangle_info = None
         self._vertex_positions = None
         self._sec_edge_info = None
-        self._face_distrb = None
+        self._face_distrb_cache = None
 
     # -- loading ---------------------------------------------------------------
     def load(self, filename, verbose=False):
@@ -505,7 +501,21 @@ class Mesh(Object):
 
     @property
     def vertex_normals(self):
+        if self._vertex_normals_raw is None and self._vertex_positions_raw is not None:
+            _, self._vertex_normals_raw = process_mesh(self._vertex_positions_raw, self._face_indices)
         return Vector3fD._wrap(self._vertex_normals_raw)
+
+    @property
+    def _face_distrb(self):
+        """face-area distribution (mesh.cpp:248-249), built on first use after a configure"""
+        if self._face_distrb_cache is None and self._triangle_info is not None:
+            self._face_distrb_cache = DiscreteDistribution()
+            self._face_distrb_cache.init(self._triangle_info[:, 21].detach())
+        return self._face_distrb_cache
+
+    @_face_distrb.setter
+    def _face_distrb(self, v):
+        self._face_distrb_cache = v
 
     @property
     def vertex_uv(self):
@@ -536,7 +546,7 @@ class Mesh(Object):
         if self.enable_edges and self._edge_indices is None:
             self._edge_indices = build_edge_indices(self._face_indices.cpu().numpy())
             self._edge_indices_dev = torch.as_tensor(self._edge_indices, device=_dev())
-        _, self._vertex_normals_raw = process_mesh(self._vertex_positions_raw, self._face_indices)
+        self._vertex_normals_raw = None       # lazy (vertex_normals property)
         to_world = self._to_world_left @ self._to_world_raw @ self._to_world_right
         self._vertex_positions = transform_pos(to_world, self._vertex_positions_raw)
         self._triangle_info, _ = process_mesh(self._vertex_positions, self._face_indices)
@@ -548,8 +558,7 @@ class Mesh(Object):
             fu = self._face_uv_indices.long()
             self._triangle_uv = torch.cat([self._vertex_uv[fu[:, 0]], self._vertex_uv[fu[:, 1]],
                                            self._vertex_uv[fu[:, 2]]], dim=-1)
-        self._face_distrb = DiscreteDistribution()
-        self._face_distrb.init(face_areas.detach())
+        self._face_distrb = None              # lazy (property above)
         self._sec_edge_info = None
         if self.enable_edges and self._edge_indices is not None and self._edge_indices.shape[0] > 0:
             ei = self._edge_indices_dev
@@ -727,6 +736,8 @@ class Scene(Object):
         self._rng_offset = [0, 0, 0]
         self._configured = False
         self._version = 0
+        self._topo = None
+        self._batch = None
 
     def __del__(self):
         try:
@@ -892,6 +903,88 @@ class Scene(Object):
         self.num_sensors, self.num_meshes = len(self.m_sensors), len(self.m_meshes)
         self.m_loaded = True
 
+    # -- batched mesh pipeline ----------------------------------------------------
+    # The reference configures mesh by mesh (mesh.cpp:215-274) inside one Enoki trace; as eager torch ops
+    # that is ~90 tiny kernels per mesh.  Here the static topology of ALL meshes is concatenated once
+    # (global vertex / face / edge ids) and every configure() runs ONE transform, ONE process_mesh and ONE
+    # edge pass over the whole scene; the per-mesh views (`mesh._triangle_info`, ...) are slices of it.
+    def _batch_topology(self):
+        key = tuple((id(m), m.num_vertices, m.num_faces, m.enable_edges, m.use_face_normals,
+                     None if m._edge_indices is None else m._edge_indices.shape[0]) for m in self.m_meshes)
+        if self._topo is not None and self._topo["key"] == key:
+            return self._topo
+        d = _dev()
+        v_off, f_off, faces, vmesh, tmesh, edges, eface = [0], [0], [], [], [], [], []
+        for i, m in enumerate(self.m_meshes):
+            if m.enable_edges and m._edge_indices is None:
+                m._edge_indices = build_edge_indices(m._face_indices.cpu().numpy())
+                m._edge_indices_dev = torch.as_tensor(m._edge_indices, device=d)
+            faces.append(m._face_indices.long() + v_off[-1])
+            vmesh.append(torch.full((m.num_vertices,), i, dtype=torch.int64, device=d))
+            tmesh.append(torch.full((m.num_faces,), i, dtype=torch.int64, device=d))
+            if m.enable_edges and m._edge_indices is not None and m._edge_indices.shape[0] > 0:
+                e = m._edge_indices_dev.long()
+                g = torch.stack([e[:, 0] + v_off[-1], e[:, 1] + v_off[-1], e[:, 2] + f_off[-1],
+                                 torch.where(e[:, 3] >= 0, e[:, 3] + f_off[-1], e[:, 3]), e[:, 4] + v_off[-1]], dim=-1)
+                edges.append(g)
+                eface.append(torch.full((g.shape[0],), bool(m.use_face_normals), dtype=torch.bool, device=d))
+            v_off.append(v_off[-1] + m.num_vertices)
+            f_off.append(f_off[-1] + m.num_faces)
+        flags = [(i | (_abi.TRI_FACE_NORMALS if m.use_face_normals else 0)) for i, m in enumerate(self.m_meshes)]
+        self._topo = {
+            "key": key, "v_off": v_off, "f_off": f_off, "faces": torch.cat(faces), "vmesh": torch.cat(vmesh),
+            "tmesh": torch.cat(tmesh),
+            "tri_mesh": torch.cat([torch.full((m.num_faces,), fl, dtype=torch.int32, device=d) for m, fl in zip(self.m_meshes, flags)]).contiguous(),
+            "edges": torch.cat(edges) if edges else None, "edge_face_normals": torch.cat(eface) if eface else None,
+        }
+        return self._topo
+
+    def _configure_meshes(self):
+        """world positions, triangle table, areas and per-mesh views for all meshes at once"""
+        tp = self._batch_topology()
+        meshes = self.m_meshes
+        for m in meshes:
+            if m.bsdf is not None:
+                psdr_assert(not m.bsdf.anisotropic() or not m.use_face_normals)
+        mats = torch.bmm(torch.bmm(torch.stack([m._to_world_left for m in meshes]), torch.stack([m._to_world_raw for m in meshes])),
+                         torch.stack([m._to_world_right for m in meshes]))
+        v_raw = torch.cat([m._vertex_positions_raw for m in meshes], dim=0)
+        mv = mats[tp["vmesh"]]                                                     # [V,4,4]
+        h = (mv[:, :3, :3] * v_raw.unsqueeze(1)).sum(-1) + mv[:, :3, 3]
+        w = (mv[:, 3, :3] * v_raw).sum(-1) + mv[:, 3, 3]
+        v_world = h / w.unsqueeze(-1)                                              # transform_pos, transform.h:84-88
+        tri_info, _ = process_mesh(v_world, tp["faces"])
+        areas = torch.zeros(len(meshes), device=v_world.device).index_add(0, tp["tmesh"], tri_info[:, 21].detach()).tolist()   # one sync
+        for i, m in enumerate(meshes):
+            m._vertex_positions = v_world[tp["v_off"][i]:tp["v_off"][i + 1]]
+            m._triangle_info = tri_info[tp["f_off"][i]:tp["f_off"][i + 1]]
+            m._vertex_normals_raw = None
+            m.m_total_area = float(areas[i])
+            m.m_inv_total_area = 1.0 / m.m_total_area
+            m._face_distrb = None
+            m._sec_edge_info = None
+            m._triangle_uv = None
+            if m.m_has_uv:
+                fu = m._face_uv_indices.long()
+                m._triangle_uv = torch.cat([m._vertex_uv[fu[:, 0]], m._vertex_uv[fu[:, 1]], m._vertex_uv[fu[:, 2]]], dim=-1)
+            m.m_ready = True
+        return tp, v_world, tri_info
+
+    def _secondary_edges(self, tp, v_world, tri_info):
+        """SecondaryEdgeInfo of every mesh with edges (mesh.cpp:251-270 + coplanar filter), one pass"""
+        ei = tp["edges"]
+        if ei is None:
+            return None
+        is_b = ei[:, 3] < 0
+        p0 = v_world[ei[:, 0]]
+        e1 = v_world[ei[:, 1]] - p0
+        n0 = tri_info[ei[:, 2], 18:21]
+        n1 = tri_info[torch.where(is_b, torch.zeros_like(ei[:, 3]), ei[:, 3]), 18:21] * (~is_b).unsqueeze(-1).to(torch.float32)
+        p2 = v_world[ei[:, 4]]
+        keep = ((n0 * n1).sum(-1) < 1.0 - EdgeEpsilon).detach()
+        info = torch.cat([p0, e1, n0, n1, p2, is_b.to(torch.float32).unsqueeze(-1)], dim=-1)
+        return info[keep]
+
     # -- configure (src/scene/scene.cpp:56-278) ---------------------------------
     def configure(self):
         psdr_assert(self.m_loaded, "Scene not loaded yet!")
@@ -907,26 +1000,12 @@ class Scene(Object):
                     self._rng_offset[k] = 0
         psdr_assert(self.m_meshes, "Missing meshes!")
         psdr_assert(self.m_sensors, "Missing sensor!")
-        tri_rows, uv_rows, tri_mesh, sec_rows = [], [], [], []
         has_uv = any(m.m_has_uv for m in self.m_meshes)
-        face_offset = [0]
-
-        def add_mesh_rows(i, mesh):
-            mesh.configure()
-            tri_rows.append(mesh._triangle_info)
-            flag = _abi.TRI_FACE_NORMALS if mesh.use_face_normals else 0
-            tri_mesh.append(torch.full((mesh.num_faces,), i | flag, dtype=torch.int32, device=d))
-            if has_uv:
-                uv_rows.append(mesh._triangle_uv if mesh._triangle_uv is not None
-                               else torch.zeros(mesh.num_faces, 6, device=d))
-            if o.sppse > 0 and mesh.enable_edges and mesh._sec_edge_info is not None:
-                sec_rows.append(mesh._sec_edge_info)
-            face_offset.append(face_offset[-1] + mesh.num_faces)
-        for i, mesh in enumerate(self.m_meshes):
-            add_mesh_rows(i, mesh)
+        tp, v_world, tri_info22 = self._configure_meshes()
+        self._batch = {"tp": tp, "v_world": v_world, "tri_info": tri_info22}       # the sensors' edge pass reads it
         # AABB over the meshes, scene.cpp:88-101 (m_upper starts at numeric_limits<float>::min(), the
         # smallest POSITIVE float: kept as is)
-        allv = torch.cat([m._vertex_positions.detach() for m in self.m_meshes], dim=0)
+        allv = v_world.detach()
         self.m_lower = allv.min(dim=0)[0]
         self.m_upper = torch.clamp(allv.max(dim=0)[0], min=float(np.finfo(np.float32).tiny))
 
@@ -955,15 +1034,18 @@ class Scene(Object):
             self.m_meshes.append(bound)
             self.num_meshes = len(self.m_meshes)
             self.m_has_bound_mesh = True
-            add_mesh_rows(len(self.m_meshes) - 1, bound)
+            tp, v_world, tri_info22 = self._configure_meshes()        # once: the mesh list just grew (no edges on the box)
+            self._batch = {"tp": tp, "v_world": v_world, "tri_info": tri_info22}
             if o.log_level > 0:
                 self.log("Bounding mesh added for environmental lighting.")
 
+        face_offset = tp["f_off"]
         T = face_offset[-1]
-        tri_info = torch.cat([torch.cat(tri_rows, dim=0), torch.zeros(T, 2, device=d)], dim=-1).contiguous()
-        tb = {"tri_info": tri_info, "tri_mesh": torch.cat(tri_mesh).contiguous(), "num_tris": T,
+        tri_info = torch.cat([tri_info22, torch.zeros(T, 2, device=d)], dim=-1).contiguous()
+        tb = {"tri_info": tri_info, "tri_mesh": tp["tri_mesh"], "num_tris": T,
               "tri_uv": None, "face_offset": face_offset}
         if has_uv:
+            uv_rows = [m._triangle_uv if m._triangle_uv is not None else torch.zeros(m.num_faces, 6, device=d) for m in self.m_meshes]
             tb["tri_uv"] = torch.cat([torch.cat(uv_rows, dim=0).detach(), torch.zeros(T, 2, device=d)], dim=-1).contiguous()
 
         # BSDF records + texel pool
@@ -1041,8 +1123,9 @@ class Scene(Object):
             tb.update(env_emitter=-1, env_tex=[0, 0, 0], env_reso=[0, 0], env_f=None, env_cmf=None, env_pmf=None, env_sum=0.0)
 
         # secondary edges, scene.cpp:219-244
-        if o.sppse > 0 and sec_rows:
-            se = torch.cat(sec_rows, dim=0).contiguous()
+        se_all = self._secondary_edges(tp, v_world, tri_info22) if o.sppse > 0 else None
+        if se_all is not None and se_all.shape[0] > 0:
+            se = se_all.contiguous()
             e1 = se[:, 3:6].detach()
             sd = DiscreteDistribution(); sd.init(torch.sqrt((e1 * e1).sum(-1)))
             tb.update(sec_edge=se, sec_cmf=sd.m_cmf, sec_pmf=sd.m_pmf, sec_sum=sd.m_sum, num_sec_edges=int(se.shape[0]))
