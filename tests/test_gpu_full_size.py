@@ -81,3 +81,30 @@ def test_c3_bunny_vertex_gradient_dot_product():
     lhs, rhs = float((adj.astype(np.float64) * dimg[0]).sum()), dot_tables(grads, tan)
     scale = float(np.abs(adj.astype(np.float64) * dimg[0]).sum())
     assert abs(lhs - rhs) < 5e-3 * scale, (lhs, rhs, scale)
+
+
+def test_c4_one_gpu_share_of_1024x1024_spp512():
+    """BASELINE config C4: cbox_bunny 1024x1024, global spp 512 sharded over 8 GPUs = 64 spp per GPU
+    (67 108 864 slots, < INT_MAX, integrator.cpp:74).  Size-independent properties of one GPU's share:
+    the share is the sum of its sub-shards (the all-reduce identity), it is normalised by the GLOBAL spp,
+    its stream indices are the global ones, and it agrees statistically with an independent low-res render."""
+    sc, _ = load_scene("cbox_bunny", res=1024, spp=512)
+    tb = sc.tables(0)
+    g = GpuScene(tb)
+    kw = dict(bsdf_samples=1, light_samples=1, spp=512)
+    share = g.render_c(_abi.make_opts(spp_range=(64, 128), **kw))                    # rank 1 of 8
+    assert g.counters()[1] == 1024 * 1024 * 64
+    assert np.isfinite(share).all()
+    halves = g.render_c(_abi.make_opts(spp_range=(64, 96), **kw)) + g.render_c(_abi.make_opts(spp_range=(96, 128), **kw))
+    assert rel_l2(halves, share) < 1e-5
+    # normalised by the global spp: 8 such shares make the image; one share carries 1/8 of the energy
+    sc2, _ = load_scene("cbox_bunny", res=64, spp=64)
+    low = oracle.render(sc2.tables(0), _abi.make_opts(bsdf_samples=1, light_samples=1, spp=64))
+    assert abs(8.0 * share.mean() / low.mean() - 1.0) < 0.02
+    # the same share at a 16x16 crop-sized problem equals the oracle sample for sample (global stream ids)
+    sc3, _ = load_scene("cbox_bunny", res=32, spp=512)
+    tb3 = sc3.tables(0)
+    o3 = _abi.make_opts(spp_range=(64, 128), **kw)
+    a, b = GpuScene(tb3).render_c(o3), oracle.render(tb3, o3)
+    bad = (np.abs(a - b).max(1) > 1e-3 * (1 + np.abs(b).max(1))).mean()
+    assert bad < 0.01 and rel_l2(a, b) < 2e-2
