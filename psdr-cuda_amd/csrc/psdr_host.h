@@ -67,19 +67,19 @@ struct SinkLayout {
     int total;
 };
 
+// The scene handle behind psdr_scene_t: the caller's tables, the BVH on the device and per-handle scratch.
 struct psdr_scene_s {
-    psdr_scene_desc desc{};
+    psdr_scene_desc desc{};                // caller-owned device tables (psdr_scene_set_tables)
     bool have_tables = false;
     bool has_rough = true;                 // a RoughConductor may be present (desc.material_mask)
+    int num_cus = 256;
+
+    // BVH on the device (psdr_bvh_build)
     BvhNode *d_nodes = nullptr;
     float4 *d_btris = nullptr;
     size_t cap_nodes = 0, cap_btris = 0;
     int32_t root = 0;
     bool have_bvh = false;
-    unsigned long long *d_counters = nullptr;
-    uint64_t slots[3] = {0, 0, 0};
-    int num_cus = 256;
-    std::vector<int32_t> emitter_i;
     int bvh_depth = 0, num_nodes = 0, num_btris = 0;
     // device refit of the tree between rebuilds (psdr_hip.hip k_refit_*)
     bool refit_enabled = true;
@@ -87,11 +87,23 @@ struct psdr_scene_s {
     std::vector<int> level_start;          // breadth-first node order: first node of every level (+ end)
     float bvh_pad = 0.f, built_area = 0.f;
     float *d_refit_area = nullptr;
-    int32_t *d_hot_map = nullptr, *d_hot_tris = nullptr; int hot_rows = 0; size_t hot_cap = 0;   // reverse sink: LDS-cached triangle rows
-    void *d_ws = nullptr; size_t ws_bytes = 0;
-    int last_path_depth = 0; float path_survival = -1.f;   // rays traced / rays of fully surviving paths (last PathTracer call)          // wavefront path-state streams + counters          // host copy of desc.emitter_i (hot-row ranges of the reverse sink)
-};
 
+    // counters of the last render call (psdr_get_counters)
+    unsigned long long *d_counters = nullptr;
+    uint64_t slots[3] = {0, 0, 0};
+    int last_path_depth = 0;
+    float path_survival = -1.f;            // rays traced / rays of fully surviving paths (last PathTracer call)
+
+    // reverse-mode gradient sink: triangle rows cached in LDS (chosen at build time)
+    std::vector<int32_t> emitter_i;        // host copy of desc.emitter_i (the emitter meshes' rows are hot)
+    int32_t *d_hot_map = nullptr, *d_hot_tris = nullptr;
+    int hot_rows = 0;
+    size_t hot_cap = 0;
+
+    // wavefront PathTracer: path-state streams + stream counters
+    void *d_ws = nullptr;
+    size_t ws_bytes = 0;
+};
 
 namespace psdr_host {
 int fail(const std::string &m);
