@@ -818,7 +818,7 @@ PSDR_HD Vec3<M> camera_sample(const SceneView &sc, const TVT &tv, TraversalStack
 // One primary-edge slot: Integrator::render_primary_edges (integrator.cpp:98-119) +
 // PerspectiveCamera::sample_primary_edge (perspective.cpp:158-200).  Returns the pixel (or -1);
 // tan[k][c] = d value / d P_k (the primal part is exactly zero: value -= detach(value)).
-template <int K, int FL>
+template <int K, int INTEG = -1, int FL = kSceneRough>
 PSDR_HD int primary_edge_sample(const SceneView &sc, const TangentView<K, FL> &tv, TraversalStack &st, const LiParams &lp, const RngJump &jump,
                                 uint64_t slot, float inv_sppe, float tan[K][3], uint32_t &nrays) {
     Rng rng; rng.init(slot, jump);
@@ -832,11 +832,17 @@ PSDR_HD int primary_edge_sample(const SceneView &sc, const TangentView<K, FL> &t
     const int ix = (int) floorf(px * (float) W), iy = (int) floorf(py * (float) H);
     const bool valid = ix >= 0 && ix < W && iy >= 0 && iy < H;
     const TangentView<0, FL> tv0{};
-    const RayT<float> ray_p = primary_ray<float>(sc, tv0, px + kEdgeEpsilon * nx, py + kEdgeEpsilon * ny);
-    const RayT<float> ray_n = primary_ray<float>(sc, tv0, px - kEdgeEpsilon * nx, py - kEdgeEpsilon * ny);
-    const Vec3f Ln = Li<float, float>(sc, tv0, st, lp, rng, ray_n, valid, nrays);
-    const Vec3f Lp = Li<float, float>(sc, tv0, st, lp, rng, ray_p, valid, nrays);
+    // Li on the two sides of the edge (ray_n first, then ray_p: the order the reference draws them in,
+    // integrator.cpp:107-112) -- one loop body, so the estimator is instantiated once
+    Vec3f L2[2];
+#pragma unroll 1
+    for (int side = 0; side < 2; ++side) {
+        const float sg = side == 0 ? -kEdgeEpsilon : kEdgeEpsilon;
+        const RayT<float> ray = primary_ray<float>(sc, tv0, px + sg * nx, py + sg * ny);
+        L2[side] = Li<float, float, INTEG>(sc, tv0, st, lp, rng, ray, valid, nrays);
+    }
     if (!valid) return -1;
+    const Vec3f Ln = L2[0], Lp = L2[1];
     const Vec3f dL{(Ln.x - Lp.x) / pdf, (Ln.y - Lp.y) / pdf, (Ln.z - Lp.z) / pdf};
     const float xdn = px * nx + py * ny;
     const bool fin[3] = {isfinite(xdn * dL.x), isfinite(xdn * dL.y), isfinite(xdn * dL.z)};

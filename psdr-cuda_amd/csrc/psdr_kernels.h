@@ -245,14 +245,17 @@ __global__ __launch_bounds__(kBlock, (is_ad<M>() ? 2 : 4)) void k_wf_bounce(Laun
 }
 
 // ------------------------------------------------------------------------ k_primary_edge
-template <int K, int FL>
-__global__ __launch_bounds__(kBlock) void k_primary_edge(LaunchCtx cx, TangentView<K, FL> tv, long long i0, long long n, float inv_sppe,
+#ifndef PSDR_WAVES_PE
+#define PSDR_WAVES_PE 4
+#endif
+template <int K, int FL, int INTEG>
+__global__ __launch_bounds__(kBlock, PSDR_WAVES_PE) void k_primary_edge(LaunchCtx cx, TangentView<K, FL> tv, long long i0, long long n, float inv_sppe,
                                                          float *__restrict__ dimg, long long plane, unsigned long long *counters) {
     TraversalStack st; setup_lds(cx, st);
     uint32_t nrays = 0;
     for (long long j = (long long) blockIdx.x * kBlock + threadIdx.x; j < n; j += (long long) gridDim.x * kBlock) {
         float tan[K][3];
-        const int pixel = primary_edge_sample<K>(cx.sc, tv, st, cx.lp, cx.jump, (uint64_t) (i0 + j), inv_sppe, tan, nrays);
+        const int pixel = primary_edge_sample<K, INTEG>(cx.sc, tv, st, cx.lp, cx.jump, (uint64_t) (i0 + j), inv_sppe, tan, nrays);
         if (pixel >= 0) {
 #pragma unroll
             for (int k = 0; k < K; ++k)
@@ -439,16 +442,23 @@ __global__ __launch_bounds__(kBlock, (GEO ? PSDR_WAVES_REV : PSDR_WAVES_REV_MAT)
     count_rays(counters, nrays);
 }
 
-template <int FL>
-__global__ __launch_bounds__(kBlock) void k_primary_edge_rev(LaunchCtx cx, DeviceSink<FL> sink, long long i0, long long n, float inv_sppe,
-                                                             const float *__restrict__ adj_img, unsigned long long *counters) {
-    __shared__ float cache[kSinkCacheWords];
+// The primary-edge term only produces gradients of the edge table (the two Li values are detached): a sink
+// without the LDS gradient cache, so the kernel is not held at 2 workgroups per CU by 24 KB of static LDS.
+template <int FL> struct PrimaryEdgeSink {
+    static constexpr int flags = FL;
+    static constexpr bool has_env = (FL & kSceneEnv) != 0;
+    float *g_prim_edge;
+    __device__ __forceinline__ void add_pedge(int e, int word, float v) const {
+        if (v != 0.f && isfinite(v)) atomicAdd(g_prim_edge + (size_t) e * PSDR_PEDGE_STRIDE + word, v);
+    }
+};
+template <int FL, int INTEG>
+__global__ __launch_bounds__(kBlock, PSDR_WAVES_PE) void k_primary_edge_rev(LaunchCtx cx, PrimaryEdgeSink<FL> sink, long long i0, long long n, float inv_sppe,
+                                                                            const float *__restrict__ adj_img, unsigned long long *counters) {
     TraversalStack st; setup_lds(cx, st);
-    sink.begin(cache);
     uint32_t nrays = 0;
     for (long long j = (long long) blockIdx.x * kBlock + threadIdx.x; j < n; j += (long long) gridDim.x * kBlock)
-        primary_edge_reverse(sink, cx.sc, st, cx.lp, cx.jump, (uint64_t) (i0 + j), inv_sppe, adj_img, nrays);
-    sink.end();
+        primary_edge_reverse<INTEG>(sink, cx.sc, st, cx.lp, cx.jump, (uint64_t) (i0 + j), inv_sppe, adj_img, nrays);
     count_rays(counters, nrays);
 }
 
@@ -562,8 +572,15 @@ int render_fwd(psdr_scene_s *h, const psdr_render_opts *o, const psdr_tangents *
         if (int rc = make_ctx(h, o, 1, cx)) return rc;
         const long long i0 = WH * o->sppe_begin, n = WH * (o->sppe_end - o->sppe_begin);
         h->slots[1] += (uint64_t) n;
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_primary_edge<K, FL>), dim3(launch_blocks(h, n)), dim3(kBlock), lds_bytes(cx, h), s, cx, tv, i0, n,
-                           1.f / (float) o->sppe, dimg, WH * 3, h->d_counters);
+#define PSDR_LAUNCH_PE(INTEG)                                                                                                        \
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_primary_edge<K, FL, INTEG>), dim3(launch_blocks(h, n)), dim3(kBlock), lds_bytes(cx, h), s, cx, tv, i0, n,   \
+                           1.f / (float) o->sppe, dimg, WH * 3, h->d_counters)
+        switch (o->integrator) {
+            case PSDR_INTEGRATOR_DIRECT: PSDR_LAUNCH_PE(PSDR_INTEGRATOR_DIRECT); break;
+            case PSDR_INTEGRATOR_PATH: PSDR_LAUNCH_PE(PSDR_INTEGRATOR_PATH); break;
+            default: PSDR_LAUNCH_PE(PSDR_INTEGRATOR_FIELD); break;
+        }
+#undef PSDR_LAUNCH_PE
         HIP_TRY(hipGetLastError());
     }
     if (o->sppse > 0 && o->sppse_end > o->sppse_begin && h->desc.num_sec_edges > 0 && o->integrator == PSDR_INTEGRATOR_DIRECT) {
@@ -607,8 +624,16 @@ int render_rev(psdr_scene_s *h, const psdr_render_opts *o, const float *adj_img,
         if (int rc = make_ctx(h, o, 1, cx)) return rc;
         const long long i0 = WH * o->sppe_begin, n = WH * (o->sppe_end - o->sppe_begin);
         h->slots[1] += (uint64_t) n;
-        hipLaunchKernelGGL(k_primary_edge_rev<FL>, dim3(launch_blocks(h, n)), dim3(kBlock), lds_bytes(cx, h), s, cx, sink, i0, n, 1.f / (float) o->sppe, adj_img,
-                           h->d_counters);
+        const PrimaryEdgeSink<FL> pe_sink{grads->g_prim_edge};
+#define PSDR_LAUNCH_PER(INTEG)                                                                                                       \
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_primary_edge_rev<FL, INTEG>), dim3(launch_blocks(h, n)), dim3(kBlock), lds_bytes(cx, h), s, cx, pe_sink, i0, n, \
+                           1.f / (float) o->sppe, adj_img, h->d_counters)
+        switch (o->integrator) {
+            case PSDR_INTEGRATOR_DIRECT: PSDR_LAUNCH_PER(PSDR_INTEGRATOR_DIRECT); break;
+            case PSDR_INTEGRATOR_PATH: PSDR_LAUNCH_PER(PSDR_INTEGRATOR_PATH); break;
+            default: PSDR_LAUNCH_PER(PSDR_INTEGRATOR_FIELD); break;
+        }
+#undef PSDR_LAUNCH_PER
         HIP_TRY(hipGetLastError());
     }
     if (o->sppse > 0 && o->sppse_end > o->sppse_begin && h->desc.num_sec_edges > 0 && o->integrator == PSDR_INTEGRATOR_DIRECT) {

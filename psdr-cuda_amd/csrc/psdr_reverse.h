@@ -765,7 +765,7 @@ PSDR_HD Vec3f camera_sample_reverse(RealSink &real_sink, PrimaryGrad &pg, PathRe
 
 // One primary-edge slot in reverse mode (integrator.cpp:98-119): value = x_dot_n * dL / pdf / sppe with
 // x_dot_n = dot(lerp(p0, p1, u), n) the only differentiable factor -> gradient w.r.t. the edge table.
-template <class Sink>
+template <int INTEG = -1, class Sink>
 PSDR_HD void primary_edge_reverse(Sink &sink, const SceneView &sc, TraversalStack &st, const LiParams &lp, const RngJump &jump, uint64_t slot,
                                   float inv_sppe, const float *__restrict__ adj_img, uint32_t &nrays) {
     Rng rng; rng.init(slot, jump);
@@ -778,11 +778,15 @@ PSDR_HD void primary_edge_reverse(Sink &sink, const SceneView &sc, TraversalStac
     const int ix = (int) floorf(px * (float) W), iy = (int) floorf(py * (float) H);
     const bool valid = ix >= 0 && ix < W && iy >= 0 && iy < H;
     const TangentView<0, Sink::flags> tv0{};
-    const RayT<float> ray_p = primary_ray<float>(sc, tv0, px + kEdgeEpsilon * nx, py + kEdgeEpsilon * ny);
-    const RayT<float> ray_n = primary_ray<float>(sc, tv0, px - kEdgeEpsilon * nx, py - kEdgeEpsilon * ny);
-    const Vec3f Ln = Li<float, float>(sc, tv0, st, lp, rng, ray_n, valid, nrays);
-    const Vec3f Lp = Li<float, float>(sc, tv0, st, lp, rng, ray_p, valid, nrays);
+    Vec3f L2[2];
+#pragma unroll 1
+    for (int side = 0; side < 2; ++side) {
+        const float sg = side == 0 ? -kEdgeEpsilon : kEdgeEpsilon;
+        const RayT<float> ray = primary_ray<float>(sc, tv0, px + sg * nx, py + sg * ny);
+        L2[side] = Li<float, float, INTEG>(sc, tv0, st, lp, rng, ray, valid, nrays);
+    }
     if (!valid) return;
+    const Vec3f Ln = L2[0], Lp = L2[1];
     const float *a = adj_img + (size_t) (iy * W + ix) * 3;
     const float xdn = px * nx + py * ny;
     float g = 0.f;
