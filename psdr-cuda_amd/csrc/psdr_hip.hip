@@ -5,6 +5,7 @@
 #include "psdr_bvh_build.h"
 
 #include <cstdlib>
+#include <rocprim/rocprim.hpp>
 
 namespace {
 // ------------------------------------------------------------------------------- k_trace
@@ -73,6 +74,30 @@ __global__ __launch_bounds__(kBlock) void k_refit_level(BvhNode *__restrict__ no
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) area += __shfl_down(area, off, 64);
     if ((threadIdx.x & 63) == 0 && area != 0.f) atomicAdd(area_sum, area);
+}
+
+// --------------------------------------------------------------------- primary-edge slot order
+// A primary-edge slot draws a random silhouette edge, so consecutive slots land on unrelated pixels and
+// the two Li evaluations of a wave start from 64 unrelated camera rays.  The sample streams are stateless
+// (slot id -> stream), hence the slots may be evaluated in ANY order: this pre-pass computes the pixel of
+// every slot (one draw + the edge CDF search) and a radix sort by pixel gives an order in which the lanes
+// of a wave share their pixel neighbourhood, like the interior term.  The image is the same sum.
+__global__ __launch_bounds__(kBlock) void k_primary_edge_keys(SceneView sc, RngJump jump, long long i0, long long n, uint32_t *__restrict__ keys,
+                                                              uint32_t *__restrict__ vals) {
+    const long long j = (long long) blockIdx.x * kBlock + threadIdx.x;
+    if (j >= n) return;
+    Rng rng; rng.init((uint64_t) (i0 + j), jump);
+    float u = rng.next(), pmf;
+    const int k = sample_reuse(sc.d.prim_cmf, sc.d.prim_pmf, sc.d.prim_sum, sc.d.num_prim_edges, u, pmf);
+    const float *pe = sc.d.prim_edge + (size_t) k * PSDR_PEDGE_STRIDE;
+    const float px = pe[0] * (1.f - u) + pe[2] * u, py = pe[1] * (1.f - u) + pe[3] * u;
+    const int W = sc.d.width, H = sc.d.height;
+    const int ix = (int) floorf(px * (float) W), iy = (int) floorf(py * (float) H);
+    const bool valid = ix >= 0 && ix < W && iy >= 0 && iy < H;
+    // 8x8 pixel tiles, row-major inside: neighbours in the order are neighbours on the screen
+    const uint32_t tile = valid ? (uint32_t) ((iy >> 3) * ((W + 7) >> 3) + (ix >> 3)) : 0x3ffffffu;
+    keys[j] = valid ? ((tile << 6) | (uint32_t) (((iy & 7) << 3) | (ix & 7))) : 0xffffffffu;
+    vals[j] = (uint32_t) j;
 }
 
 thread_local std::string g_err;
@@ -164,6 +189,31 @@ int begin_call(psdr_scene_s *h, hipStream_t s) {
 }
 
 
+// Order in which the primary-edge slots [i0, i0 + n) are evaluated (see k_primary_edge_keys); *order = nullptr
+// keeps the natural order (tiny launches, or PSDR_SORT_EDGES=0).
+int primary_edge_order(psdr_scene_s *h, const LaunchCtx &cx, long long i0, long long n, const uint32_t **order, hipStream_t s) {
+    *order = nullptr;
+    if (!h->sort_edges || n < 65536 || n > 0x7fffffffLL) return 0;
+    size_t temp = 0;
+    const unsigned end_bit = 32;
+    uint32_t *nul = nullptr;
+    HIP_TRY(rocprim::radix_sort_pairs(nullptr, temp, nul, nul, nul, nul, (size_t) n, 0, end_bit, s));
+    const size_t need = 4 * sizeof(uint32_t) * (size_t) n + temp + 256;
+    if (need > h->sort_bytes) {
+        if (h->d_sort) (void) hipFree(h->d_sort);
+        h->d_sort = nullptr; h->sort_bytes = 0;
+        HIP_TRY(hipMalloc(&h->d_sort, need));
+        h->sort_bytes = need;
+    }
+    uint32_t *k_in = reinterpret_cast<uint32_t *>(h->d_sort), *k_out = k_in + n, *v_in = k_out + n, *v_out = v_in + n;
+    void *tmp = reinterpret_cast<void *>((reinterpret_cast<uintptr_t>(v_out + n) + 255) & ~(uintptr_t) 255);
+    hipLaunchKernelGGL(k_primary_edge_keys, dim3((unsigned) ((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, cx.sc, cx.jump, i0, n, k_in, v_in);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(rocprim::radix_sort_pairs(tmp, temp, k_in, k_out, v_in, v_out, (size_t) n, 0, end_bit, s));
+    *order = v_out;
+    return 0;
+}
+
 // kernel variant of the scene: bit 0 = environment map present, bit 1 = a rough conductor may be present
 const VariantOps *variant_of(const psdr_scene_s *h) {
     const int fl = (h->desc.env_emitter >= 0 ? kSceneEnv : 0) | (h->has_rough ? kSceneRough : 0);
@@ -195,6 +245,7 @@ int psdr_scene_create(psdr_scene_t *out) {
     int dev = 0; hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) h->num_cus = prop.multiProcessorCount;
     if (const char *e2 = std::getenv("PSDR_BVH_REFIT")) h->refit_enabled = std::atoi(e2) != 0;      // 0: always rebuild on the host
+    if (const char *e3 = std::getenv("PSDR_SORT_EDGES")) h->sort_edges = std::atoi(e3) != 0;        // 0: primary-edge slots in natural order
     *out = h;
     return 0;
 }
@@ -205,6 +256,7 @@ int psdr_scene_destroy(psdr_scene_t h) {
     if (h->d_btris) (void) hipFree(h->d_btris);
     if (h->d_counters) (void) hipFree(h->d_counters);
     if (h->d_refit_area) (void) hipFree(h->d_refit_area);
+    if (h->d_sort) (void) hipFree(h->d_sort);
     if (h->d_ws) (void) hipFree(h->d_ws);
     if (h->d_hot_map) (void) hipFree(h->d_hot_map);
     if (h->d_hot_tris) (void) hipFree(h->d_hot_tris);

@@ -100,6 +100,11 @@ struct psdr_scene_s {
     int hot_rows = 0;
     size_t hot_cap = 0;
 
+    // primary-edge slots sorted by pixel (psdr_hip.hip primary_edge_order)
+    bool sort_edges = true;
+    void *d_sort = nullptr;
+    size_t sort_bytes = 0;
+
     // wavefront PathTracer: path-state streams + stream counters
     void *d_ws = nullptr;
     size_t ws_bytes = 0;
@@ -115,6 +120,7 @@ bool use_wavefront(const psdr_scene_s *h, const psdr_render_opts *o);
 SinkLayout make_sink_layout(const psdr_scene_s *h, const psdr_grads *g);
 int check_counts(const psdr_scene_s *h, const psdr_render_opts *o);
 int begin_call(psdr_scene_s *h, hipStream_t s);
+int primary_edge_order(psdr_scene_s *h, const LaunchCtx &cx, long long i0, long long n, const uint32_t **order, hipStream_t s);
 constexpr int kMaxRefits = 64;              // full SAH rebuild at least this often
 constexpr float kRefitAreaGrowth = 1.3f;    // ... or when the summed inner-box area grew by 30 %
 

@@ -250,12 +250,14 @@ __global__ __launch_bounds__(kBlock, (is_ad<M>() ? 2 : 4)) void k_wf_bounce(Laun
 #endif
 template <int K, int FL, int INTEG>
 __global__ __launch_bounds__(kBlock, PSDR_WAVES_PE) void k_primary_edge(LaunchCtx cx, TangentView<K, FL> tv, long long i0, long long n, float inv_sppe,
-                                                         float *__restrict__ dimg, long long plane, unsigned long long *counters) {
+                                                         float *__restrict__ dimg, long long plane, unsigned long long *counters,
+                                                         const uint32_t *__restrict__ order) {
     TraversalStack st; setup_lds(cx, st);
     uint32_t nrays = 0;
     for (long long j = (long long) blockIdx.x * kBlock + threadIdx.x; j < n; j += (long long) gridDim.x * kBlock) {
         float tan[K][3];
-        const int pixel = primary_edge_sample<K, INTEG>(cx.sc, tv, st, cx.lp, cx.jump, (uint64_t) (i0 + j), inv_sppe, tan, nrays);
+        const long long jj = order ? (long long) order[j] : j;          // pixel-sorted evaluation order (psdr_hip.hip)
+        const int pixel = primary_edge_sample<K, INTEG>(cx.sc, tv, st, cx.lp, cx.jump, (uint64_t) (i0 + jj), inv_sppe, tan, nrays);
         if (pixel >= 0) {
 #pragma unroll
             for (int k = 0; k < K; ++k)
@@ -454,11 +456,24 @@ template <int FL> struct PrimaryEdgeSink {
 };
 template <int FL, int INTEG>
 __global__ __launch_bounds__(kBlock, PSDR_WAVES_PE) void k_primary_edge_rev(LaunchCtx cx, PrimaryEdgeSink<FL> sink, long long i0, long long n, float inv_sppe,
-                                                                            const float *__restrict__ adj_img, unsigned long long *counters) {
+                                                                            const float *__restrict__ adj_img, unsigned long long *counters,
+                                                                            const uint32_t *__restrict__ order) {
     TraversalStack st; setup_lds(cx, st);
     uint32_t nrays = 0;
-    for (long long j = (long long) blockIdx.x * kBlock + threadIdx.x; j < n; j += (long long) gridDim.x * kBlock)
-        primary_edge_reverse<INTEG>(sink, cx.sc, st, cx.lp, cx.jump, (uint64_t) (i0 + j), inv_sppe, adj_img, nrays);
+    const long long nceil = (n + kBlock - 1) / kBlock * kBlock;
+    for (long long j = (long long) blockIdx.x * kBlock + threadIdx.x; j < nceil; j += (long long) gridDim.x * kBlock) {
+        float w[4] = {0.f, 0.f, 0.f, 0.f};
+        int edge = -1;
+        if (j < n)
+            edge = primary_edge_reverse_values<INTEG, FL>(cx.sc, st, cx.lp, cx.jump, (uint64_t) (i0 + (order ? (long long) order[j] : j)), inv_sppe, adj_img,
+                                                          nrays, w);
+        // pixel-sorted slots: neighbouring lanes mostly sit on the same edge -> one atomic per run of equal edges
+        const bool head = wave_run_sum<4>(edge, w);
+        if (head && edge >= 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sink.add_pedge(edge, i, w[i]);
+        }
+    }
     count_rays(counters, nrays);
 }
 
@@ -572,9 +587,11 @@ int render_fwd(psdr_scene_s *h, const psdr_render_opts *o, const psdr_tangents *
         if (int rc = make_ctx(h, o, 1, cx)) return rc;
         const long long i0 = WH * o->sppe_begin, n = WH * (o->sppe_end - o->sppe_begin);
         h->slots[1] += (uint64_t) n;
+        const uint32_t *order = nullptr;
+        if (int rc = primary_edge_order(h, cx, i0, n, &order, s)) return rc;
 #define PSDR_LAUNCH_PE(INTEG)                                                                                                        \
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_primary_edge<K, FL, INTEG>), dim3(launch_blocks(h, n)), dim3(kBlock), lds_bytes(cx, h), s, cx, tv, i0, n,   \
-                           1.f / (float) o->sppe, dimg, WH * 3, h->d_counters)
+                           1.f / (float) o->sppe, dimg, WH * 3, h->d_counters, order)
         switch (o->integrator) {
             case PSDR_INTEGRATOR_DIRECT: PSDR_LAUNCH_PE(PSDR_INTEGRATOR_DIRECT); break;
             case PSDR_INTEGRATOR_PATH: PSDR_LAUNCH_PE(PSDR_INTEGRATOR_PATH); break;
@@ -625,9 +642,11 @@ int render_rev(psdr_scene_s *h, const psdr_render_opts *o, const float *adj_img,
         const long long i0 = WH * o->sppe_begin, n = WH * (o->sppe_end - o->sppe_begin);
         h->slots[1] += (uint64_t) n;
         const PrimaryEdgeSink<FL> pe_sink{grads->g_prim_edge};
+        const uint32_t *order = nullptr;
+        if (int rc = primary_edge_order(h, cx, i0, n, &order, s)) return rc;
 #define PSDR_LAUNCH_PER(INTEG)                                                                                                       \
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_primary_edge_rev<FL, INTEG>), dim3(launch_blocks(h, n)), dim3(kBlock), lds_bytes(cx, h), s, cx, pe_sink, i0, n, \
-                           1.f / (float) o->sppe, adj_img, h->d_counters)
+                           1.f / (float) o->sppe, adj_img, h->d_counters, order)
         switch (o->integrator) {
             case PSDR_INTEGRATOR_DIRECT: PSDR_LAUNCH_PER(PSDR_INTEGRATOR_DIRECT); break;
             case PSDR_INTEGRATOR_PATH: PSDR_LAUNCH_PER(PSDR_INTEGRATOR_PATH); break;

@@ -765,9 +765,12 @@ PSDR_HD Vec3f camera_sample_reverse(RealSink &real_sink, PrimaryGrad &pg, PathRe
 
 // One primary-edge slot in reverse mode (integrator.cpp:98-119): value = x_dot_n * dL / pdf / sppe with
 // x_dot_n = dot(lerp(p0, p1, u), n) the only differentiable factor -> gradient w.r.t. the edge table.
-template <int INTEG = -1, class Sink>
-PSDR_HD void primary_edge_reverse(Sink &sink, const SceneView &sc, TraversalStack &st, const LiParams &lp, const RngJump &jump, uint64_t slot,
-                                  float inv_sppe, const float *__restrict__ adj_img, uint32_t &nrays) {
+// Returns the edge (or -1) and w[4] = the gradient of its (p0.x, p0.y, p1.x, p1.y) words, so that a kernel can
+// combine the lanes of a wave that landed on the same edge before touching memory.
+template <int INTEG, int FL>
+PSDR_HD int primary_edge_reverse_values(const SceneView &sc, TraversalStack &st, const LiParams &lp, const RngJump &jump, uint64_t slot,
+                                        float inv_sppe, const float *__restrict__ adj_img, uint32_t &nrays, float w[4]) {
+    w[0] = w[1] = w[2] = w[3] = 0.f;
     Rng rng; rng.init(slot, jump);
     float u = rng.next(), pmf;
     const int k = sample_reuse(sc.d.prim_cmf, sc.d.prim_pmf, sc.d.prim_sum, sc.d.num_prim_edges, u, pmf);
@@ -777,7 +780,7 @@ PSDR_HD void primary_edge_reverse(Sink &sink, const SceneView &sc, TraversalStac
     const int W = sc.d.width, H = sc.d.height;
     const int ix = (int) floorf(px * (float) W), iy = (int) floorf(py * (float) H);
     const bool valid = ix >= 0 && ix < W && iy >= 0 && iy < H;
-    const TangentView<0, Sink::flags> tv0{};
+    const TangentView<0, FL> tv0{};
     Vec3f L2[2];
 #pragma unroll 1
     for (int side = 0; side < 2; ++side) {
@@ -785,7 +788,7 @@ PSDR_HD void primary_edge_reverse(Sink &sink, const SceneView &sc, TraversalStac
         const RayT<float> ray = primary_ray<float>(sc, tv0, px + sg * nx, py + sg * ny);
         L2[side] = Li<float, float, INTEG>(sc, tv0, st, lp, rng, ray, valid, nrays);
     }
-    if (!valid) return;
+    if (!valid) return -1;
     const Vec3f Ln = L2[0], Lp = L2[1];
     const float *a = adj_img + (size_t) (iy * W + ix) * 3;
     const float xdn = px * nx + py * ny;
@@ -794,9 +797,18 @@ PSDR_HD void primary_edge_reverse(Sink &sink, const SceneView &sc, TraversalStac
 #pragma unroll
     for (int c = 0; c < 3; ++c) if (isfinite(xdn * dL[c])) g += a[c] * dL[c];
     g *= inv_sppe;
-    if (g == 0.f || !isfinite(g)) return;
-    sink.add_pedge(k, 0, g * (1.f - u) * nx); sink.add_pedge(k, 1, g * (1.f - u) * ny);
-    sink.add_pedge(k, 2, g * u * nx); sink.add_pedge(k, 3, g * u * ny);
+    if (g == 0.f || !isfinite(g)) return -1;
+    w[0] = g * (1.f - u) * nx; w[1] = g * (1.f - u) * ny; w[2] = g * u * nx; w[3] = g * u * ny;
+    return k;
+}
+template <int INTEG = -1, class Sink>
+PSDR_HD void primary_edge_reverse(Sink &sink, const SceneView &sc, TraversalStack &st, const LiParams &lp, const RngJump &jump, uint64_t slot,
+                                  float inv_sppe, const float *__restrict__ adj_img, uint32_t &nrays) {
+    float w[4];
+    const int k = primary_edge_reverse_values<INTEG, Sink::flags>(sc, st, lp, jump, slot, inv_sppe, adj_img, nrays, w);
+    if (k < 0) return;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sink.add_pedge(k, i, w[i]);
 }
 
 // One secondary-edge slot in reverse mode (direct.cpp:225-316): result = value0 * dot(n, u2(theta)).
