@@ -177,3 +177,19 @@ def test_kernel_variant_choice_does_not_change_the_image(scene):
     ga = GpuScene(tb).render_d_rev(o, adj, want=["texels"])[1]["texels"]
     gb = GpuScene(tb0).render_d_rev(o, adj, want=["texels"])[1]["texels"]
     assert rel_l2(ga, gb) < 1e-4
+
+
+def test_anisotropic_rough_conductor_matches_oracle():
+    from test_rough_conductor import metal_floor
+    import torch
+    tb = metal_floor(0.1, 0.4, res=32, spp=16).tables(0)
+    g = GpuScene(tb)
+    for kind in ("direct11", "direct20", "path3"):
+        o = _abi.make_opts(spp=16, **OPTS[kind])
+        img, ref = g.render_c(o), oracle.render(tb, o)
+        assert rel_l2(img, ref) < 1e-4, kind
+    t = {"texels": torch.rand(tb["texels"].shape, generator=torch.Generator().manual_seed(1))}
+    o = _abi.make_opts(spp=16, **OPTS["path3"])
+    _, d = g.render_d_fwd(o, [t])
+    _, rd = oracle.render(tb, o, mode=1, tangents=t)
+    assert rel_l2(d[0], rd) < 2e-3
