@@ -11,6 +11,13 @@ for p in (os.path.join(ROOT, "psdr-cuda_amd"), os.path.join(ROOT, "oracle"), os.
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # a fresh checkout has no built artefacts (they are git-ignored): build them once (hipcc cross-compiles
+    # without a GPU; on the GPU box the prebuilt files travel with the snapshot)
+    libs = (os.path.join(ROOT, "psdr-cuda_amd", "lib", "libpsdr_hip.so"), os.path.join(ROOT, "oracle", "libpsdr_oracle.so"),
+            os.path.join(ROOT, "tests", "hostcheck", "libhostcheck.so"))
+    if not all(os.path.exists(p) for p in libs):
+        import __graft_entry__
+        __graft_entry__.build()
 
 
 def pytest_collection_modifyitems(config, items):
