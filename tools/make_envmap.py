@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Writes the synthetic latitude-longitude environment map used by the env-map fixtures
 (psdr-cuda_amd/data/envmaps/synthetic_sky_64x32.exr): a smooth sky gradient, a warm ground, a bright
-"sun" lobe and a dimmer coloured lobe -- HDR, strictly positive, analytic (no photograph)."""
+"sun" lobe and a dimmer coloured lobe (both away from the u = 0|1 seam, where Bitmap::eval does not wrap)
+-- HDR, strictly positive, analytic (no photograph)."""
 import os
 import sys
 
@@ -27,7 +28,7 @@ def lobe(direction, sharp):
 up = np.clip(d[..., 1], 0, 1)[..., None]
 down = np.clip(-d[..., 1], 0, 1)[..., None]
 img = 0.15 + up * np.array([0.25, 0.45, 0.9]) + down * np.array([0.35, 0.25, 0.15])
-img = img + lobe([0.4, 0.7, -0.6], 25.0)[..., None] * np.array([30.0, 26.0, 18.0])
+img = img + lobe([-0.4, 0.7, 0.6], 25.0)[..., None] * np.array([30.0, 26.0, 18.0])
 img = img + lobe([-0.8, 0.2, 0.5], 6.0)[..., None] * np.array([1.0, 2.5, 1.5])
 out = os.path.join(ROOT, "psdr-cuda_amd", "data", "envmaps", "synthetic_sky_64x32.exr")
 save_exr_rgb(out, img.astype(np.float32))
