@@ -467,6 +467,7 @@ class Mesh(Object):
             self._face_uv_indices = torch.as_tensor(np.asarray(uv_faces, dtype=np.int32), device=d)
         self._edge_indices = build_edge_indices(faces, fname) if self.enable_edges else None
         self._edge_indices_dev = None if self._edge_indices is None else torch.as_tensor(self._edge_indices, device=d)
+        self._topo_version = getattr(self, "_topo_version", 0) + 1      # the scene's batched topology is rebuilt
         self.m_ready = False
 
     # -- python surface (src/psdr.cpp:242-265) ----------------------------------
@@ -909,7 +910,7 @@ class Scene(Object):
     # (global vertex / face / edge ids) and every configure() runs ONE transform, ONE process_mesh and ONE
     # edge pass over the whole scene; the per-mesh views (`mesh._triangle_info`, ...) are slices of it.
     def _batch_topology(self):
-        key = tuple((id(m), m.num_vertices, m.num_faces, m.enable_edges, m.use_face_normals,
+        key = tuple((id(m), getattr(m, "_topo_version", 0), m.num_vertices, m.num_faces, m.enable_edges, m.use_face_normals,
                      None if m._edge_indices is None else m._edge_indices.shape[0]) for m in self.m_meshes)
         if self._topo is not None and self._topo["key"] == key:
             return self._topo

@@ -241,3 +241,28 @@ def test_two_sensors_share_the_scene_tables():
     bad = xml[:j] + second.replace("</sensor>", '<film type="hdrfilm"><integer name="width" value="8"/><integer name="height" value="8"/></film></sensor>') + xml[j:]
     with pytest.raises(RuntimeError, match="Duplicate film node"):
         psdr_cuda.Scene().load_string(bad, False)
+
+
+def test_batched_configure_equals_mesh_by_mesh_and_tracks_topology_changes():
+    """Scene.configure batches all meshes; the tables equal the per-mesh Mesh.configure() results, and reloading
+    a mesh's geometry (same counts) rebuilds the concatenated topology"""
+    sc, _ = load_scene("cbox_bunny", res=8, spp=1, sppe=1, sppse=1)
+    tb = sc.tables(0)
+    off = 0
+    for m in sc.m_meshes:
+        info_batched = tb["tri_info"][off:off + m.num_faces, :22].clone()
+        m.configure()                                    # the stand-alone path (mesh.cpp:215-274)
+        assert torch.allclose(m._triangle_info, info_batched, rtol=1e-5, atol=1e-5)
+        off += m.num_faces
+    assert off == tb["num_tris"]
+    n_sec = tb["num_sec_edges"]
+    assert n_sec > 0 and tb["num_prim_edges"] > 0
+    # same geometry again, faces reversed: counts are equal, the tables must still follow
+    m = sc.m_meshes[0]
+    v = m._vertex_positions_raw.cpu().numpy()
+    f = m._face_indices.cpu().numpy()[:, ::-1].copy()
+    before = sc.tables(0)["tri_info"][0, 18:21].clone()
+    m.set_geometry(v, f)
+    sc.configure()
+    after = sc.tables(0)["tri_info"][0, 18:21]
+    assert torch.allclose(after, -before, atol=1e-6)     # flipped winding -> flipped face normal
