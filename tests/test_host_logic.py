@@ -76,7 +76,7 @@ def test_error_messages_follow_the_reference():
     with pytest.raises(RuntimeError, match="Missing BSDF reference"):
         psdr_cuda.Scene().load_string(xml.replace('<ref id="red"/>', ''))
     with pytest.raises(RuntimeError, match="Unsupported BSDF"):
-        psdr_cuda.Scene().load_string(xml.replace('type="diffuse" id="red"', 'type="plastic" id="red"'))
+        psdr_cuda.Scene().load_string(xml.replace('id="red" type="diffuse"', 'id="red" type="plastic"'))
     s2 = psdr_cuda.Scene()
     s2.load_file(scene_path("cbox"), False)
     with pytest.raises(RuntimeError, match="Scene already loaded!"):
