@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -22,8 +23,12 @@ struct Builder {
     std::vector<float4> btris;
     int max_depth = 0;
     float pad = 0.f;
-    static constexpr int kMaxLeaf = 4;              // leaf encoding holds 1..8
-    static constexpr float kTraversalCost = 1.0f;   // node visit / triangle test (both ~40-50 VALU ops)
+    int kMaxLeaf = 4;                  // leaf encoding holds 1..8
+    float kTraversalCost = 1.0f;       // node visit / triangle test (both ~40-50 VALU ops)
+    Builder() {                        // experiment knobs (tools only): PSDR_BVH_MAXLEAF, PSDR_BVH_TCOST
+        if (const char *e = std::getenv("PSDR_BVH_MAXLEAF")) kMaxLeaf = std::max(1, std::min(8, std::atoi(e)));
+        if (const char *e = std::getenv("PSDR_BVH_TCOST")) kTraversalCost = (float) std::atof(e);
+    }
 
     static float area(const float *lo, const float *hi) {
         const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
