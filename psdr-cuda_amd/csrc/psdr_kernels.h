@@ -70,7 +70,11 @@ __device__ __forceinline__ void count_rays(unsigned long long *counters, uint32_
 #ifndef PSDR_WAVES_DG
 #define PSDR_WAVES_DG 2
 #endif
-template <class G, class R> constexpr int camera_waves() { return !is_ad<R>() ? PSDR_WAVES_C : (is_ad<G>() ? PSDR_WAVES_DG : PSDR_WAVES_DM); }
+// geometry duals: K = 1 fits 3 waves/SIMD without spills in DirectIntegrator form (C2 direct 2.5 -> 2.0 ms, path3
+// 6.7 -> 5.8 ms); K = 3 would spill > 400 registers there and stays at PSDR_WAVES_DG
+template <class G, class R> constexpr int camera_waves() {
+    return !is_ad<R>() ? PSDR_WAVES_C : (is_ad<G>() ? (ad_traits<G>::K == 1 ? 3 : PSDR_WAVES_DG) : PSDR_WAVES_DM);
+}
 template <class G, class R, int INTEG, int FL>
 __global__ __launch_bounds__(kBlock, (camera_waves<G, R>())) void k_camera(LaunchCtx cx, TV<R, FL> tv, int spp, int s_begin, int nsp, long long n, float inv_spp,
                                                    float *__restrict__ img, float *__restrict__ dimg, long long plane,
