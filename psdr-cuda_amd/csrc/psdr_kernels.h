@@ -400,7 +400,7 @@ template <int FL> struct DeviceSink {
 #ifndef PSDR_WAVES_REV_MAT
 #define PSDR_WAVES_REV_MAT 3
 #endif
-template <int FL, bool GEO>
+template <int FL, bool GEO, int INTEG>
 __global__ __launch_bounds__(kBlock, (GEO ? PSDR_WAVES_REV : PSDR_WAVES_REV_MAT)) void k_camera_rev(LaunchCtx cx, DeviceSink<FL> sink, int spp, int s_begin, int nsp, long long n, float inv_spp,
                                                        const float *__restrict__ adj_img, float *__restrict__ img,
                                                        unsigned long long *counters) {
@@ -423,7 +423,7 @@ __global__ __launch_bounds__(kBlock, (GEO ? PSDR_WAVES_REV : PSDR_WAVES_REV_MAT)
             const uint64_t slot = (uint64_t) pixel * (uint64_t) spp + (uint64_t) s;
             const float *a = adj_img + (size_t) pixel * 3;
             const Vec3f adj{a[0] * inv_spp, a[1] * inv_spp, a[2] * inv_spp};
-            const Vec3f r = camera_sample_reverse<GEO>(sink, pg, rec, cx.sc, st, cx.lp, cx.jump, pixel, slot, adj, nrays);
+            const Vec3f r = camera_sample_reverse<GEO, INTEG>(sink, pg, rec, cx.sc, st, cx.lp, cx.jump, pixel, slot, adj, nrays);
             v[0] = r.x * inv_spp; v[1] = r.y * inv_spp; v[2] = r.z * inv_spp;
         }
         // primary-triangle row: one add per run of lanes that hit the same triangle
@@ -631,13 +631,18 @@ int render_rev(psdr_scene_s *h, const psdr_render_opts *o, const float *adj_img,
         const int rec_bytes = depth * 6 * kBlock * 4;
         plan_lds(h, cx, rec_bytes + kSinkCacheWords * 4);          // stage less of the scene: the record + cache live in LDS too
         cx.off_pathrec = lds_bytes(cx, h);
-        // material-only gradients (no triangle / camera table wanted) run the variant without the geometric adjoints
-        if (grads->g_tri_info != nullptr || grads->g_cam_to_world != nullptr)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_camera_rev<FL, true>), dim3(launch_blocks(h, n)), dim3(kBlock), lds_bytes(cx, h) + rec_bytes, s, cx, sink, o->spp,
-                               o->spp_begin, nsp, n, 1.f / (float) o->spp, adj_img, out_img, h->d_counters);
-        else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_camera_rev<FL, false>), dim3(launch_blocks(h, n)), dim3(kBlock), lds_bytes(cx, h) + rec_bytes, s, cx, sink, o->spp,
-                               o->spp_begin, nsp, n, 1.f / (float) o->spp, adj_img, out_img, h->d_counters);
+        // material-only gradients (no triangle / camera table wanted) run the variant without the geometric adjoints;
+        // the integrator is a compile-time parameter as in the forward kernels (direct: no path record / replay loop)
+        const bool geo = grads->g_tri_info != nullptr || grads->g_cam_to_world != nullptr;
+#define PSDR_LAUNCH_REV(GEO, INTEG)                                                                                                  \
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_camera_rev<FL, GEO, INTEG>), dim3(launch_blocks(h, n)), dim3(kBlock), lds_bytes(cx, h) + rec_bytes, s, cx, sink, \
+                           o->spp, o->spp_begin, nsp, n, 1.f / (float) o->spp, adj_img, out_img, h->d_counters)
+        switch (o->integrator) {
+            case PSDR_INTEGRATOR_DIRECT: if (geo) PSDR_LAUNCH_REV(true, PSDR_INTEGRATOR_DIRECT); else PSDR_LAUNCH_REV(false, PSDR_INTEGRATOR_DIRECT); break;
+            case PSDR_INTEGRATOR_PATH: if (geo) PSDR_LAUNCH_REV(true, PSDR_INTEGRATOR_PATH); else PSDR_LAUNCH_REV(false, PSDR_INTEGRATOR_PATH); break;
+            default: if (geo) PSDR_LAUNCH_REV(true, PSDR_INTEGRATOR_FIELD); else PSDR_LAUNCH_REV(false, PSDR_INTEGRATOR_FIELD); break;
+        }
+#undef PSDR_LAUNCH_REV
         HIP_TRY(hipGetLastError());
     }
     if (o->sppe > 0 && o->sppe_end > o->sppe_begin && h->desc.num_prim_edges > 0 && grads->g_prim_edge) {

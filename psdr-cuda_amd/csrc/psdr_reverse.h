@@ -663,7 +663,8 @@ template <class Sink> PSDR_HD Vec3f path_vertex_backward(Sink &sink, const Scene
 //   GEO: a geometry gradient (triangle table / camera) is wanted -> solid-angle form of the primary hit and
 //        the geometric adjoint chain; otherwise the on-surface form, exactly like forward mode
 //        (psdr_device.h Li), and every geometry adjoint is compiled out (MaterialSink)
-template <bool GEO, class RealSink>
+//   INTEG >= 0: integrator fixed at compile time (as in the forward kernels); -1: run-time switch
+template <bool GEO, int INTEG = -1, class RealSink>
 PSDR_HD Vec3f camera_sample_reverse(RealSink &real_sink, PrimaryGrad &pg, PathRec &rec, const SceneView &sc, TraversalStack &st, const LiParams &lp,
                                     const RngJump &jump, int pixel, uint64_t slot, const Vec3f &adj, uint32_t &nrays) {
     constexpr bool geo = GEO;
@@ -706,7 +707,8 @@ PSDR_HD Vec3f camera_sample_reverse(RealSink &real_sink, PrimaryGrad &pg, PathRe
 
     VertexAdj va0; va0.clear();                 // adjoints of the primary vertex; its solid-angle chain runs last
     Vec3f result(0.f);
-    if (lp.integrator == PSDR_INTEGRATOR_FIELD) {
+    const int integ = INTEG >= 0 ? INTEG : lp.integrator;
+    if (integ == PSDR_INTEGRATOR_FIELD) {
         // FieldExtractionIntegrator (field.cpp:34-54): position / depth / geoNormal carry derivatives
         float a_t = 0.f;
         switch (lp.field) {
@@ -730,7 +732,7 @@ PSDR_HD Vec3f camera_sample_reverse(RealSink &real_sink, PrimaryGrad &pg, PathRe
         return result;
     }
 
-    const bool direct = lp.integrator == PSDR_INTEGRATOR_DIRECT;
+    const bool direct = integ == PSDR_INTEGRATOR_DIRECT;
     const int nB = direct ? lp.bsdf_samples : 1, nL = direct ? lp.light_samples : 1;
     const int depth = direct ? 1 : (lp.max_depth < kMaxRevDepth ? lp.max_depth : kMaxRevDepth);
 
