@@ -152,3 +152,35 @@ def test_bvh_refit_between_configures_matches_a_rebuild():
     sc.configure(); integ.renderC(sc)
     lib.psdr_bvh_stats(sc._native, stats)
     assert stats[0] == 2
+
+
+@pytest.mark.parametrize("n_tris,seed", [(1, 0), (2, 1), (3, 2), (5, 3), (17, 4), (100, 5), (1000, 6), (5000, 7)])
+def test_trace_fuzz_random_triangle_soups(n_tris, seed):
+    """closest hit on random triangle soups (overlapping, sliver and tiny triangles, all leaf sizes of the
+    SAH-terminated tree) against the oracle's independent traversal: same triangle, same barycentrics"""
+    rng = np.random.default_rng(seed)
+    centres = rng.uniform(-1, 1, (n_tris, 1, 3))
+    size = rng.choice([0.02, 0.2, 1.0], (n_tris, 1, 1))
+    tri = centres + size * rng.normal(size=(n_tris, 3, 3))
+    if n_tris > 10:
+        tri[3, 2] = tri[3, 0] + 1e-7 * (tri[3, 1] - tri[3, 0])          # a sliver
+        tri[4] = tri[4, :1]                                              # a degenerate point triangle
+    verts = tri.reshape(-1, 3).astype(np.float32)
+    faces = np.arange(n_tris * 3, dtype=np.int32).reshape(-1, 3)
+    tb = tiny_scene(verts, faces, res=8, spp=1).tables(0)
+    g = GpuScene(tb)
+    m = 20000
+    o = rng.uniform(-3, 3, (m, 3)).astype(np.float32)
+    target = rng.uniform(-1, 1, (m, 3)).astype(np.float32)
+    d = target - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    _, t_gpu, u_gpu, v_gpu = g.trace(o, d)
+    _, t_ref, u_ref, v_ref = oracle.trace(tb, o, d)
+    same = t_gpu == t_ref
+    assert same.mean() > 0.998, (n_tris, same.mean())                   # rays through shared edges / coincident hits may differ
+    hit = same & (t_ref >= 0)
+    if n_tris >= 17:
+        assert hit.sum() > 100
+    if hit.any():
+        assert np.abs(u_gpu[hit] - u_ref[hit]).max() < 2e-3 and np.abs(v_gpu[hit] - v_ref[hit]).max() < 2e-3
+    assert ((t_gpu < 0) == (t_ref < 0))[same].all()
