@@ -184,3 +184,53 @@ def test_trace_fuzz_random_triangle_soups(n_tris, seed):
     if hit.any():
         assert np.abs(u_gpu[hit] - u_ref[hit]).max() < 2e-3 and np.abs(v_gpu[hit] - v_ref[hit]).max() < 2e-3
     assert ((t_gpu < 0) == (t_ref < 0))[same].all()
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_render_fuzz_random_scenes(seed):
+    """random emitter + random diffuse / rough-conductor triangle soups (intersecting, back-facing, slivers):
+    finite images, GPU == oracle up to isolated samples, reverse mode == forward mode"""
+    from helpers import random_tangents, dot_tables
+    rng = np.random.default_rng(100 + seed)
+    sc = psdr_cuda.Scene()
+    sc.opts.width = sc.opts.height = 24
+    sc.opts.spp, sc.opts.sppe, sc.opts.sppse, sc.opts.log_level = 8, 0, 0, 0
+    cam = psdr_cuda.PerspectiveCamera(45.0, 0.1, 1e3)
+    cam.to_world = look_at([0, 0, 6], [0, 0, 0], [0, 1, 0])
+    sc.add_sensor(cam)
+    diffuse = psdr_cuda.Diffuse(rng.uniform(0.2, 0.9, 3)); diffuse.id = "d"
+    metal = psdr_cuda.RoughConductor(float(rng.uniform(0.05, 0.5)), (0.2, 0.9, 1.1), (3.9, 2.4, 2.2)); metal.id = "m"
+    black = psdr_cuda.Diffuse([0.0, 0.0, 0.0]); black.id = "k"
+    for b in (diffuse, metal, black):
+        sc.add_bsdf(b)
+
+    def soup(n, spread, size):
+        c = rng.uniform(-spread, spread, (n, 1, 3))
+        t = c + size * rng.normal(size=(n, 3, 3))
+        return t.reshape(-1, 3).astype(np.float32), np.arange(3 * n, dtype=np.int32).reshape(-1, 3)
+    for bsdf, n, emit in ((black, 6, [8.0, 6.0, 4.0]), (diffuse, int(rng.integers(20, 120)), None), (metal, int(rng.integers(20, 120)), None)):
+        m = psdr_cuda.Mesh()
+        m.use_face_normals = True
+        m.enable_edges = False                         # a soup is not a manifold
+        v, f = soup(n, 1.5, 0.6)
+        m.set_geometry(v, f)
+        sc.add_mesh(m, bsdf, emitter_radiance=emit)
+    sc.finalize()
+    sc.configure()
+    tb = sc.tables(0)
+    g = GpuScene(tb)
+    adj = rng.random((24 * 24, 3)).astype(np.float32)
+    for kw in (dict(bsdf_samples=1, light_samples=1), dict(integrator=_abi.INTEGRATOR_PATH, max_depth=3)):
+        o = _abi.make_opts(spp=8, **kw)
+        img, ref = g.render_c(o), oracle.render(tb, o)
+        assert np.isfinite(img).all()
+        bad = (np.abs(img - ref).max(1) > 2e-3 * (1 + np.abs(ref).max(1))).mean()
+        assert bad < 0.03, (seed, kw, bad)
+        for name in ("texels", "tri_info"):
+            tan = random_tangents(tb, [name], seed=seed)
+            _, dimg = g.render_d_fwd(o, [tan])
+            assert np.isfinite(dimg[0]).all()
+            _, grads = g.render_d_rev(o, adj, want=[name], with_image=False)
+            lhs, rhs = float((adj.astype(np.float64) * dimg[0]).sum()), dot_tables(grads, tan)
+            scale = float(np.abs(adj.astype(np.float64) * dimg[0]).sum())
+            assert abs(lhs - rhs) <= 2e-2 * max(scale, 1e-6), (seed, kw, name, lhs, rhs, scale)
