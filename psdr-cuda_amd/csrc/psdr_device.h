@@ -72,6 +72,7 @@ struct TraversalStack {
 };
 
 PSDR_HD int __float_as_int_hd(float f) { union { float f; int i; } c; c.f = f; return c.i; }
+PSDR_HD float __int_as_float_hd(int i) { union { float f; int i; } c; c.i = i; return c.f; }
 
 PSDR_HD float slab(const float *lo, const float *hi, const Vec3f &o, const Vec3f &inv, float tmax) {
     // returns entry distance or +inf if the box is missed.  NaNs (0*inf) drop out of fmin/fmax.
@@ -83,6 +84,18 @@ PSDR_HD float slab(const float *lo, const float *hi, const Vec3f &o, const Vec3f
     const float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.f));
     const float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax));
     return t0 <= t1 ? t0 : INFINITY;
+}
+
+// The leaf test of closest_hit on ONE known triangle (reverse mode replays the hits recorded in its value
+// sweep): the same arithmetic, hence the same (u, v, t) as the traversal that found the triangle.
+PSDR_HD Hit hit_on_triangle(int tri, const Vec3f &p0, const Vec3f &e1, const Vec3f &e2, const Vec3f &o, const Vec3f &d) {
+    const Vec3f h = cross(d, e2);
+    const float det = dot(e1, h);
+    const float f = 1.f / det;
+    const Vec3f s{o.x - p0.x, o.y - p0.y, o.z - p0.z};
+    const Vec3f q = cross(s, e1);
+    Hit r; r.tri = tri; r.u = f * dot(s, h); r.v = f * dot(d, q); r.t = f * dot(e2, q);
+    return r;
 }
 
 // Replaces __raygen__/__closesthit__/__miss__ (cuda/psdr_cuda.cu:9-45): closest hit with

@@ -628,7 +628,7 @@ int render_rev(psdr_scene_s *h, const psdr_render_opts *o, const float *adj_img,
         const long long n = WH * nsp;
         h->slots[0] += (uint64_t) n;
         const int depth = o->integrator == PSDR_INTEGRATOR_PATH ? std::min(o->max_depth, kMaxRevDepth) : 1;
-        const int rec_bytes = depth * 6 * kBlock * 4;
+        const int rec_bytes = depth * kPathRecWords * kBlock * 4;
         plan_lds(h, cx, rec_bytes + kSinkCacheWords * 4);          // stage less of the scene: the record + cache live in LDS too
         cx.off_pathrec = lds_bytes(cx, h);
         // material-only gradients (no triangle / camera table wanted) run the variant without the geometric adjoints;

@@ -339,6 +339,31 @@ PSDR_HD Vec3f camera_space_dir(const SceneView &sc, float sx, float sy) {
     return normalize(Vec3f{v4[0] / v4[3], v4[1] / v4[3], v4[2] / v4[3]});
 }
 
+constexpr int kMaxRevDepth = 8;
+constexpr int kPathRecWords = 8;
+
+// Per-lane record of (c_k, f_k) and the two hit triangles along the path (8 words per vertex).  On the device it lives in LDS
+// (one column per lane) -- a register array indexed by the run-time vertex number would be demoted to
+// scratch, and the scratch of all resident waves (hundreds of MB) thrashes the caches.
+struct PathRec {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float *base;   // &lds[threadIdx.x], stride kBlock
+    __device__ __forceinline__ void put(int k, int c, float v) { base[(k * kPathRecWords + c) * kBlock] = v; }
+    __device__ __forceinline__ float get(int k, int c) const { return base[(k * kPathRecWords + c) * kBlock]; }
+#else
+    float a[kMaxRevDepth * kPathRecWords];
+    void put(int k, int c, float v) { a[k * kPathRecWords + c] = v; }
+    float get(int k, int c) const { return a[k * kPathRecWords + c]; }
+#endif
+    // triangles the two rays of vertex k arrived at in sweep 1 (-1: miss): sweep 2 re-intersects THAT triangle
+    // instead of walking the tree again
+    PSDR_HD void put_tri(int k, int which, int tri) { put(k, 6 + which, __int_as_float_hd(tri)); }
+    PSDR_HD int tri(int k, int which) const { return __float_as_int_hd(get(k, 6 + which)); }
+    PSDR_HD void put_cf(int k, const Vec3f &c, const Vec3f &f) { put(k, 0, c.x); put(k, 1, c.y); put(k, 2, c.z); put(k, 3, f.x); put(k, 4, f.y); put(k, 5, f.z); }
+    PSDR_HD Vec3f c(int k) const { return {get(k, 0), get(k, 1), get(k, 2)}; }
+    PSDR_HD Vec3f f(int k) const { return {get(k, 3), get(k, 4), get(k, 5)}; }
+};
+
 // What one vertex hands back to the path loop
 struct VertexOut {
     Vec3f c;            // sum of the emitter contributions gathered at this vertex (unit throughput)
@@ -371,9 +396,11 @@ PSDR_HD Its<float> make_path_vertex(const SceneView &sc, const Vec3f &origin, in
 //   a_f : adjoint of the continuation throughput f_k (= a * beta_k * T_{k+1}); zero for DirectIntegrator
 // Adjoints of THIS vertex' position / frame / wi / uv accumulate in `va`; everything that belongs to
 // other triangles (next vertex, emitter) is scattered straight into the sink.
-template <bool BACKWARD, class Sink>
+//   REPLAY (one BSDF and one light sample per vertex): the value sweep records the triangle each of the two
+//   rays arrived at in rec[k]; the BACKWARD sweep re-intersects that triangle instead of tracing again.
+template <bool BACKWARD, bool REPLAY, class Sink>
 PSDR_HD VertexOut vertex_eval(Sink &sink, const SceneView &sc, TraversalStack &st, Rng &rng, const Its<float> &its, int nB, int nL,
-                              const Vec3f &a_c, const Vec3f &a_f, VertexAdj &va, uint32_t &nrays) {
+                              const Vec3f &a_c, const Vec3f &a_f, VertexAdj &va, uint32_t &nrays, PathRec &rec, int k) {
     const TangentView<0, Sink::flags> tv0{};
     VertexOut out; out.c = Vec3f(0.f); out.f = Vec3f(0.f); out.next_valid = false;
     // the bounding mesh of the environment map has no BSDF (direct.cpp:54-57): nothing is gathered there and
@@ -382,17 +409,24 @@ PSDR_HD VertexOut vertex_eval(Sink &sink, const SceneView &sc, TraversalStack &s
     constexpr bool kEnv = Sink::has_env;
     const BsdfRev<Sink> brev(sc, sc.d.mesh_bsdf[its.mesh]);
     const Bsdf<float, float> &bsdf = brev.b;
+    if (REPLAY && !BACKWARD) { rec.put_tri(k, 0, -1); rec.put_tri(k, 1, -1); }
     for (int i = 0; i < nB; ++i) {
         const float s[3] = {rng.next(), rng.next(), rng.next()};
         Vec3f wo_s; float pdf_s;
         const bool ok = bsdf.sample(sc, tv0, its, s, true, wo_s, pdf_s);
         if (!ok) continue;
         const RayT<float> ray1{its.p, its.sh.to_world(wo_s)};
-        nrays++;
-        const Hit h1 = closest_hit(sc, st, ray1.o, ray1.d, INFINITY);
+        Hit h1;
+        if (REPLAY && BACKWARD) h1.tri = rec.tri(k, 0);
+        else {
+            nrays++;
+            h1 = closest_hit(sc, st, ray1.o, ray1.d, INFINITY);
+            if (REPLAY) rec.put_tri(k, 0, h1.tri);
+        }
         if (h1.tri < 0) continue;
         const int tm = sc.d.tri_mesh[h1.tri], mesh1 = tm & ~PSDR_TRI_FACE_NORMALS;
         const TriRow<float> T1 = load_tri<float>(sc, tv0, h1.tri);
+        if (REPLAY && BACKWARD) h1 = hit_on_triangle(h1.tri, T1.p0, T1.e1, T1.e2, ray1.o, ray1.d);
         const Vec3f p1 = bary_point(T1.p0, T1.e1, T1.e2, h1.u, h1.v);
         const Vec3f dvec = p1 - its.p;
         const float t1 = norm(dvec);
@@ -486,12 +520,18 @@ PSDR_HD VertexOut vertex_eval(Sink &sink, const SceneView &sc, TraversalStack &s
         const Vec3f wov = psp - its.p;
         const float d2 = dot(wov, wov), dist = sqrtf(fmaxf(d2, 0.f));
         const Vec3f wo = wov / dist;
-        nrays++;
-        const Hit h2 = closest_hit(sc, st, its.p, wo, INFINITY);
+        Hit h2;
+        if (REPLAY && BACKWARD) h2.tri = rec.tri(k, 1);
+        else {
+            nrays++;
+            h2 = closest_hit(sc, st, its.p, wo, INFINITY);
+            if (REPLAY) rec.put_tri(k, 1, h2.tri);
+        }
         if (h2.tri < 0) continue;
         const int tm2 = sc.d.tri_mesh[h2.tri], mesh2 = tm2 & ~PSDR_TRI_FACE_NORMALS;
         const int e2 = sc.d.mesh_emitter[mesh2];
         const TriRow<float> T2 = load_tri<float>(sc, tv0, h2.tri);
+        if (REPLAY && BACKWARD) h2 = hit_on_triangle(h2.tri, T2.p0, T2.e1, T2.e2, its.p, wo);
         const Vec3f p2 = bary_point(T2.p0, T2.e1, T2.e2, h2.u, h2.v);
         const float t2 = norm(p2 - its.p);
         if (!(t2 > dist - kShadowEpsilon && e2 >= 0)) continue;
@@ -568,26 +608,6 @@ template <int FLAGS = kSceneRough> struct NullSink {
     PSDR_HD void add_cam(int, float) {}
     PSDR_HD void add_sedge(int, int, float) {}
     PSDR_HD void add_pedge(int, int, float) {}
-};
-
-constexpr int kMaxRevDepth = 8;
-
-// Per-lane record of (c_k, f_k) along the path (6 floats per vertex).  On the device it lives in LDS
-// (one column per lane) -- a register array indexed by the run-time vertex number would be demoted to
-// scratch, and the scratch of all resident waves (hundreds of MB) thrashes the caches.
-struct PathRec {
-#if defined(__HIP_DEVICE_COMPILE__)
-    float *base;   // &lds[threadIdx.x], stride kBlock
-    __device__ __forceinline__ void put(int k, int c, float v) { base[(k * 6 + c) * kBlock] = v; }
-    __device__ __forceinline__ float get(int k, int c) const { return base[(k * 6 + c) * kBlock]; }
-#else
-    float a[kMaxRevDepth * 6];
-    void put(int k, int c, float v) { a[k * 6 + c] = v; }
-    float get(int k, int c) const { return a[k * 6 + c]; }
-#endif
-    PSDR_HD void put_cf(int k, const Vec3f &c, const Vec3f &f) { put(k, 0, c.x); put(k, 1, c.y); put(k, 2, c.z); put(k, 3, f.x); put(k, 4, f.y); put(k, 5, f.z); }
-    PSDR_HD Vec3f c(int k) const { return {get(k, 0), get(k, 1), get(k, 2)}; }
-    PSDR_HD Vec3f f(int k) const { return {get(k, 3), get(k, 4), get(k, 5)}; }
 };
 
 // Gradient of the PRIMARY triangle row of one camera sample (p0 e1 e2 n0 n1 n2 fn = words 0..20).
@@ -735,6 +755,8 @@ PSDR_HD Vec3f camera_sample_reverse(RealSink &real_sink, PrimaryGrad &pg, PathRe
     const bool direct = integ == PSDR_INTEGRATOR_DIRECT;
     const int nB = direct ? lp.bsdf_samples : 1, nL = direct ? lp.light_samples : 1;
     const int depth = direct ? 1 : (lp.max_depth < kMaxRevDepth ? lp.max_depth : kMaxRevDepth);
+    // sweep 2 replays the hits of sweep 1 (always for the PathTracer; DirectIntegrator with <= 1 sample of each kind)
+    const bool replay = INTEG == PSDR_INTEGRATOR_PATH || (nB <= 1 && nL <= 1);
 
     const int e0 = sc.d.mesh_emitter[its.mesh];
     const bool env0 = Sink::has_env && !lp.hide_emitters && e0 >= 0 && e0 == sc.d.env_emitter;
@@ -750,7 +772,8 @@ PSDR_HD Vec3f camera_sample_reverse(RealSink &real_sink, PrimaryGrad &pg, PathRe
         Its<float> cur = its;
         Vec3f beta(1.f);
         for (int k = 0; k < depth; ++k) {
-            const VertexOut vo = vertex_eval<false, NullSink<Sink::flags>>(ns, sc, st, r1, cur, nB, nL, Vec3f(0.f), Vec3f(0.f), dummy, nrays);
+            const VertexOut vo = replay ? vertex_eval<false, true, NullSink<Sink::flags>>(ns, sc, st, r1, cur, nB, nL, Vec3f(0.f), Vec3f(0.f), dummy, nrays, rec, k)
+                                        : vertex_eval<false, false, NullSink<Sink::flags>>(ns, sc, st, r1, cur, nB, nL, Vec3f(0.f), Vec3f(0.f), dummy, nrays, rec, k);
             rec.put_cf(k, vo.c, vo.f); nv = k + 1;
             result = result + beta * vo.c;
             if (!vo.next_valid) break;
@@ -778,7 +801,8 @@ PSDR_HD Vec3f camera_sample_reverse(RealSink &real_sink, PrimaryGrad &pg, PathRe
             const Vec3f a_c = adj * beta;
             const Vec3f a_f = (k + 1 < nv) ? a_c * rec.c(k) : Vec3f(0.f);
             VertexAdj va; va.clear();
-            const VertexOut vo = vertex_eval<true, Sink>(sink, sc, st, rng, cur, nB, nL, a_c, a_f, k == 0 ? va0 : va, nrays);
+            const VertexOut vo = replay ? vertex_eval<true, true, Sink>(sink, sc, st, rng, cur, nB, nL, a_c, a_f, k == 0 ? va0 : va, nrays, rec, k)
+                                        : vertex_eval<true, false, Sink>(sink, sc, st, rng, cur, nB, nL, a_c, a_f, k == 0 ? va0 : va, nrays, rec, k);
             if (k >= 1) {
                 const Vec3f a_prev = path_vertex_backward(sink, sc, cur, prev.p, va);
                 if (k == 1) acc(va0.p, a_prev);
