@@ -25,6 +25,7 @@ static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
 constexpr int kBvhStack = 40;     // builder guarantees depth <= kBvhStack - 2
 constexpr int kBlock = 256;
 
+constexpr int kTinyTris = 16;
 struct SceneView {
     psdr_scene_desc d;
     const BvhNode *nodes;
@@ -35,6 +36,11 @@ struct SceneView {
     // n_lbtris leaf triangles and the first n_ltri TriangleInfo rows.
     int32_t n_lnodes, n_lbtris, n_ltri;
     int32_t off_lnodes, off_lbtris, off_ltri;
+    // Tiny scenes (<= kTinyTris triangles, e.g. the 12-triangle Cornell box): the leaf triangles travel IN THE
+    // KERNEL ARGUMENTS and closest_hit tests all of them in order -- wave-uniform s_load from the kernarg
+    // segment into SGPRs, no tree, no per-lane node fetches, no stack traffic, no divergence between lanes.
+    int32_t n_tiny;
+    float4 tiny[kTinyTris * 3];
 };
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -98,10 +104,33 @@ PSDR_HD Hit hit_on_triangle(int tri, const Vec3f &p0, const Vec3f &e1, const Vec
     return r;
 }
 
+// Moeller-Trumbore on one leaf triangle (p0 | id, e1, e2); keeps the closer hit in `best` (the OptiX built-in
+// triangle test is closed source).  A precomputed plane form (18 FMAs) was measured: no faster in the tree
+// walk (latency-, not ALU-bound) and less accurate.
+PSDR_HD void leaf_triangle_test(const float4 &a, const float4 &b, const float4 &c, const Vec3f &o, const Vec3f &d, Hit &best) {
+    const Vec3f e1{b.x, b.y, b.z}, e2{c.x, c.y, c.z};
+    const Vec3f h = cross(d, e2);
+    const float det = dot(e1, h);
+    const float f = 1.f / det;
+    const Vec3f s{o.x - a.x, o.y - a.y, o.z - a.z};
+    const float u = f * dot(s, h);
+    const Vec3f q = cross(s, e1);
+    const float v = f * dot(d, q);
+    const float t = f * dot(e2, q);
+    if (det != 0.f && u >= 0.f && u <= 1.f && v >= 0.f && u + v <= 1.f && t >= kRayEpsilon && t <= best.t &&
+        (t < best.t || best.tri < 0)) {
+        best.t = t; best.u = u; best.v = v; best.tri = __float_as_int_hd(a.w);
+    }
+}
+
 // Replaces __raygen__/__closesthit__/__miss__ (cuda/psdr_cuda.cu:9-45): closest hit with
 // t in [RayEpsilon, tmax], both faces; (u,v) = barycentric weights of vertex 1 and 2.
 PSDR_HD Hit closest_hit(const SceneView &sc, TraversalStack &st, const Vec3f &o, const Vec3f &d, float tmax) {
     Hit best; best.tri = -1; best.u = best.v = -1.f; best.t = tmax;
+    if (sc.n_tiny > 0) {
+        for (int i = 0; i < sc.n_tiny; ++i) leaf_triangle_test(sc.tiny[i * 3], sc.tiny[i * 3 + 1], sc.tiny[i * 3 + 2], o, d, best);
+        return best;
+    }
     const Vec3f inv{1.f / d.x, 1.f / d.y, 1.f / d.z};
     int sp = 0;
     int32_t cur = sc.root;
@@ -143,21 +172,7 @@ PSDR_HD Hit closest_hit(const SceneView &sc, TraversalStack &st, const Vec3f &o,
                 else
 #endif
                 { a = sc.btris[(first + i) * 3]; b = sc.btris[(first + i) * 3 + 1]; c = sc.btris[(first + i) * 3 + 2]; }
-                // Moeller-Trumbore (the OptiX built-in triangle test is closed source).  A precomputed plane form
-                // (18 FMAs) was measured: no faster here (the loop is latency-, not ALU-bound) and less accurate.
-                const Vec3f e1{b.x, b.y, b.z}, e2{c.x, c.y, c.z};
-                const Vec3f h = cross(d, e2);
-                const float det = dot(e1, h);
-                const float f = 1.f / det;
-                const Vec3f s{o.x - a.x, o.y - a.y, o.z - a.z};
-                const float u = f * dot(s, h);
-                const Vec3f q = cross(s, e1);
-                const float v = f * dot(d, q);
-                const float t = f * dot(e2, q);
-                if (det != 0.f && u >= 0.f && u <= 1.f && v >= 0.f && u + v <= 1.f && t >= kRayEpsilon && t <= best.t &&
-                    (t < best.t || best.tri < 0)) {
-                    best.t = t; best.u = u; best.v = v; best.tri = __float_as_int_hd(a.w);
-                }
+                leaf_triangle_test(a, b, c, o, d, best);
             }
             cur = sp > 0 ? st.get(--sp) : kDone;
         }

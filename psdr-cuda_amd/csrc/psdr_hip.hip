@@ -138,6 +138,8 @@ int make_ctx(psdr_scene_s *h, const psdr_render_opts *o, int sampler, LaunchCtx 
     if (o->integrator == PSDR_INTEGRATOR_DIRECT && !(o->bsdf_samples >= 0 && o->light_samples >= 0 && o->bsdf_samples + o->light_samples > 0))
         return fail("DirectIntegrator: bsdf_samples + light_samples must be positive");
     cx.sc.d = h->desc; cx.sc.nodes = h->d_nodes; cx.sc.btris = h->d_btris; cx.sc.root = h->root;
+    cx.sc.n_tiny = h->n_tiny;
+    std::memcpy(cx.sc.tiny, h->tiny, sizeof(h->tiny));
     plan_lds(h, cx);
     cx.lp = LiParams{o->integrator, o->bsdf_samples, o->light_samples, o->max_depth, o->hide_emitters, o->field};
     cx.jump = make_rng_jump(o->rng_offset[sampler]);
@@ -245,6 +247,7 @@ int psdr_scene_create(psdr_scene_t *out) {
     int dev = 0; hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) h->num_cus = prop.multiProcessorCount;
     if (const char *e2 = std::getenv("PSDR_BVH_REFIT")) h->refit_enabled = std::atoi(e2) != 0;      // 0: always rebuild on the host
+    if (const char *e4 = std::getenv("PSDR_TINY_SCENE")) h->tiny_enabled = std::atoi(e4) != 0;      // 0: walk the tree even for <= 16 triangles
     if (const char *e3 = std::getenv("PSDR_SORT_EDGES")) h->sort_edges = std::atoi(e3) != 0;        // 0: primary-edge slots in natural order
     *out = h;
     return 0;
@@ -288,7 +291,8 @@ int psdr_bvh_build(psdr_scene_t h, void *stream) {
     hipStream_t s = (hipStream_t) stream;
     const int T = h->desc.num_tris;
     // ---- refit: same triangle count as the tree on the device and the tree has not degraded
-    if (h->refit_enabled && h->tree_tris == T && h->num_nodes > 0 && h->refits_since_build < kMaxRefits) {
+    const bool tiny = h->tiny_enabled && T <= kTinyTris;        // the triangles travel in the kernel arguments: host copy needed
+    if (h->refit_enabled && !tiny && h->tree_tris == T && h->num_nodes > 0 && h->refits_since_build < kMaxRefits) {
         float prev_area = h->built_area;
         if (h->refits_since_build > 0) HIP_TRY(hipMemcpy(&prev_area, h->d_refit_area, sizeof(float), hipMemcpyDeviceToHost));   // of the PREVIOUS refit: done long ago
         if (prev_area <= kRefitAreaGrowth * h->built_area) {
@@ -356,6 +360,8 @@ int psdr_bvh_build(psdr_scene_t h, void *stream) {
     h->root = root;
     h->bvh_depth = b.max_depth; h->num_nodes = (int) b.nodes.size(); h->num_btris = (int) b.btris.size() / 3;
     h->have_bvh = true;
+    h->n_tiny = tiny ? h->num_btris : 0;
+    if (tiny) std::memcpy(h->tiny, b.btris.data(), b.btris.size() * sizeof(float4));
     // what the refit path needs: the levels of the breadth-first node order, the padding, the reference area
     h->tree_tris = T; h->refits_since_build = 0; h->num_builds++; h->bvh_pad = b.pad;
     h->level_start.clear();
@@ -385,6 +391,8 @@ int psdr_trace(psdr_scene_t h, int32_t m, const float *ox, const float *oy, cons
     if (m <= 0) return 0;
     LaunchCtx cx{};
     cx.sc.d = h->desc; cx.sc.nodes = h->d_nodes; cx.sc.btris = h->d_btris; cx.sc.root = h->root;
+    cx.sc.n_tiny = h->n_tiny;
+    std::memcpy(cx.sc.tiny, h->tiny, sizeof(h->tiny));
     plan_lds(h, cx);
     hipLaunchKernelGGL(k_trace, dim3(launch_blocks(h, m)), dim3(kBlock), lds_bytes(cx, h), (hipStream_t) stream, cx, m, ox, oy, oz, dx, dy, dz, tmax,
                        out_shape, out_tri, out_u, out_v);

@@ -88,6 +88,11 @@ struct psdr_scene_s {
     float bvh_pad = 0.f, built_area = 0.f;
     float *d_refit_area = nullptr;
 
+    // tiny scenes: the leaf triangles as they travel in the kernel arguments (SceneView::tiny)
+    bool tiny_enabled = true;
+    int n_tiny = 0;
+    float4 tiny[kTinyTris * 3] = {};
+
     // counters of the last render call (psdr_get_counters)
     unsigned long long *d_counters = nullptr;
     uint64_t slots[3] = {0, 0, 0};

@@ -5,6 +5,8 @@
 #include "../../psdr-cuda_amd/csrc/psdr_bvh_build.h"
 #include "../../psdr-cuda_amd/csrc/psdr_reverse.h"
 
+#include <cstdlib>
+#include <cstring>
 #include <thread>
 #include <vector>
 
@@ -12,7 +14,7 @@ using namespace psdr;
 
 namespace {
 struct HostScene {
-    SceneView sc;
+    SceneView sc{};
     Builder b;
 };
 bool setup(HostScene &hs, const psdr_scene_desc *d) {
@@ -21,6 +23,12 @@ bool setup(HostScene &hs, const psdr_scene_desc *d) {
     int32_t root = 0;
     if (hs.b.run(d->tri_info, d->num_tris, root)) return false;
     hs.sc.nodes = hs.b.nodes.data(); hs.sc.btris = hs.b.btris.data(); hs.sc.root = root;
+    // tiny scenes take the all-triangles path of closest_hit, as psdr_bvh_build arranges on the device
+    const char *e = std::getenv("PSDR_TINY_SCENE");
+    if (d->num_tris <= kTinyTris && !(e && std::atoi(e) == 0)) {
+        hs.sc.n_tiny = (int32_t) (hs.b.btris.size() / 3);
+        std::memcpy(hs.sc.tiny, hs.b.btris.data(), hs.b.btris.size() * sizeof(float4));
+    }
     return true;
 }
 template <class F> void pfor(long long n, int nt, F f) {

@@ -154,7 +154,7 @@ def test_bvh_refit_between_configures_matches_a_rebuild():
     assert stats[0] == 2
 
 
-@pytest.mark.parametrize("n_tris,seed", [(1, 0), (2, 1), (3, 2), (5, 3), (17, 4), (100, 5), (1000, 6), (5000, 7)])
+@pytest.mark.parametrize("n_tris,seed", [(1, 0), (2, 1), (3, 2), (5, 3), (12, 8), (16, 9), (17, 4), (100, 5), (1000, 6), (5000, 7)])
 def test_trace_fuzz_random_triangle_soups(n_tris, seed):
     """closest hit on random triangle soups (overlapping, sliver and tiny triangles, all leaf sizes of the
     SAH-terminated tree) against the oracle's independent traversal: same triangle, same barycentrics"""
@@ -184,6 +184,31 @@ def test_trace_fuzz_random_triangle_soups(n_tris, seed):
     if hit.any():
         assert np.abs(u_gpu[hit] - u_ref[hit]).max() < 2e-3 and np.abs(v_gpu[hit] - v_ref[hit]).max() < 2e-3
     assert ((t_gpu < 0) == (t_ref < 0))[same].all()
+
+
+def test_tiny_scene_all_triangles_path_equals_the_tree_walk(monkeypatch):
+    """<= 16 triangles: the leaf triangles travel in the kernel arguments and closest_hit tests them all
+    (SceneView::tiny); PSDR_TINY_SCENE=0 walks the tree instead -- same hits bit for bit, same image, same
+    gradients; a 17-triangle scene takes the tree"""
+    from helpers import camera_rays
+    sc, _ = load_scene("cbox", res=48, spp=8)
+    tb = sc.tables(0)
+    assert tb["num_tris"] == 12
+    o_, d_ = camera_rays(tb, 100_000, seed=3)
+    opts = _abi.make_opts(spp=8, integrator=_abi.INTEGRATOR_PATH, max_depth=3)
+    adj = np.random.default_rng(0).random((48 * 48, 3)).astype(np.float32)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("PSDR_TINY_SCENE", mode)       # read when the handle is created
+        g = GpuScene(tb)
+        out[mode] = (g.trace(o_, d_), g.render_c(opts), g.render_d_rev(opts, adj, want=["tri_info", "texels"], with_image=False)[1])
+    (sa, ta, ua, va), (sb, tb_, ub, vb) = out["1"][0], out["0"][0]
+    same = ta == tb_
+    assert same.mean() > 0.9999                            # only rays through an edge shared by two triangles may differ
+    assert (ua[same] == ub[same]).all() and (va[same] == vb[same]).all() and (sa[same] == sb[same]).all()
+    assert rel_l2(out["1"][1], out["0"][1]) < 1e-6
+    for k in ("tri_info", "texels"):
+        assert rel_l2(out["1"][2][k], out["0"][2][k]) < 1e-4, k
 
 
 @pytest.mark.parametrize("seed", [0, 1, 2, 3])
