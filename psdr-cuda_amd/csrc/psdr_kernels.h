@@ -57,6 +57,12 @@ __device__ __forceinline__ void count_rays(unsigned long long *counters, uint32_
 
 // ------------------------------------------------------------------------------ k_camera
 // n = W*H*nsp slots of this shard, pixel-major: slot j -> pixel j / nsp, sample s_begin + j % nsp.
+// n <= INT_MAX (check_counts), so this is 32-bit unsigned arithmetic: a 64-bit division by the run-time
+// nsp costs ~170 VALU instructions per slot.
+__device__ __forceinline__ void slot_to_pixel(long long j, int nsp, int &pixel, int &s) {
+    const uint32_t ju = (uint32_t) j, q = ju / (uint32_t) nsp;
+    pixel = (int) q; s = (int) (ju - q * (uint32_t) nsp);
+}
 // Occupancy targets (waves per SIMD) of the camera kernel.  The kernel is latency/dependency bound
 // (rocprof r01: 43 % of wave cycles waiting at 2 waves/SIMD), so trading registers for resident
 // waves pays: measured 6.2 -> 4.6 ms (renderC, 4 waves) and 12.5 -> 7.0 ms (renderD K=3 material-only, 2 waves,
@@ -86,12 +92,13 @@ __global__ __launch_bounds__(kBlock, (camera_waves<G, R>())) void k_camera(Launc
     const long long nceil = (n + kBlock - 1) / kBlock * kBlock;
     for (long long j = (long long) blockIdx.x * kBlock + threadIdx.x; j < nceil; j += (long long) gridDim.x * kBlock) {
         const bool in = j < n;
-        const int pixel = in ? (int) (j / nsp) : 0x7fffffff;
+        int pixel = 0x7fffffff, s_in = 0;
+        if (in) slot_to_pixel(j, nsp, pixel, s_in);
         float v[NV];
 #pragma unroll
         for (int i = 0; i < NV; ++i) v[i] = 0.f;
         if (in) {
-            const int s = s_begin + (int) (j % nsp);
+            const int s = s_begin + s_in;
             const uint64_t slot = (uint64_t) pixel * (uint64_t) spp + (uint64_t) s;
             const Vec3<R> r = camera_sample<G, R, INTEG>(cx.sc, tv, st, cx.lp, cx.jump, pixel, slot, nrays);
             v[0] = val(r.x) * inv_spp; v[1] = val(r.y) * inv_spp; v[2] = val(r.z) * inv_spp;
@@ -187,14 +194,15 @@ __global__ __launch_bounds__(kBlock, (is_ad<M>() ? 2 : 4)) void k_wf_camera(Laun
     for (long long jj = (long long) blockIdx.x * kBlock + threadIdx.x; jj < nceil; jj += (long long) gridDim.x * kBlock) {
         const bool in = jj < n;
         const long long j = j0 + jj;
-        const int pixel = in ? (int) (j / nsp) : 0;
+        int pixel = 0, s_in = 0;
+        if (in) slot_to_pixel(j, nsp, pixel, s_in);
         Vec3<M> r = zero3<M>(), beta = zero3<M>();
         Its<float> next; next.tri = -1; next.hu = next.hv = 0.f;
         Vec3f origin(0.f), dir(0.f);
         bool alive = false;
         uint32_t slot = 0;
         if (in) {
-            slot = (uint32_t) ((uint64_t) pixel * (uint64_t) spp + (uint64_t) (s_begin + (int) (j % nsp)));
+            slot = (uint32_t) ((uint64_t) pixel * (uint64_t) spp + (uint64_t) (s_begin + s_in));
             r = zero_nonfinite(wavefront_camera_vertex<M>(cx.sc, tv, st, cx.lp, cx.jump, pixel, slot, nrays, next, beta, origin, alive));
             if (alive) { Vec3f d = next.p - origin; const float t = norm(d); dir = d / t; }
         }
@@ -411,7 +419,8 @@ __global__ __launch_bounds__(kBlock, (GEO ? PSDR_WAVES_REV : PSDR_WAVES_REV_MAT)
     const long long nceil = (n + kBlock - 1) / kBlock * kBlock;
     for (long long j = (long long) blockIdx.x * kBlock + threadIdx.x; j < nceil; j += (long long) gridDim.x * kBlock) {
         const bool in = j < n;
-        const int pixel = in ? (int) (j / nsp) : 0x7fffffff;
+        int pixel = 0x7fffffff, s_in = 0;
+        if (in) slot_to_pixel(j, nsp, pixel, s_in);
         float v[3] = {0.f, 0.f, 0.f};
         PrimaryGrad pg; pg.clear();
         PathRec rec;
@@ -419,7 +428,7 @@ __global__ __launch_bounds__(kBlock, (GEO ? PSDR_WAVES_REV : PSDR_WAVES_REV_MAT)
         rec.base = reinterpret_cast<float *>(psdr_dyn_lds + cx.off_pathrec) + threadIdx.x;
 #endif
         if (in) {
-            const int s = s_begin + (int) (j % nsp);
+            const int s = s_begin + s_in;
             const uint64_t slot = (uint64_t) pixel * (uint64_t) spp + (uint64_t) s;
             const float *a = adj_img + (size_t) pixel * 3;
             const Vec3f adj{a[0] * inv_spp, a[1] * inv_spp, a[2] * inv_spp};
