@@ -128,26 +128,34 @@ __global__ __launch_bounds__(kBlock, (camera_waves<G, R>())) void k_camera(Launc
 // ----------------------------------------------------------------------- wavefront mode
 // PathTracer as a wavefront: stage 0 (camera ray, primary vertex) then one kernel per bounce over SoA
 // path-state streams in HBM.  Live paths are compacted between stages with a wave ballot + prefix
-// popcount and ONE atomic per wave on the stream counter, so every bounce kernel runs on dense
-// waves.  Record = pixel, slot, triangle, (u,v), arrival direction, throughput (+K tangents):
-// 44 + 12 K bytes, all streams coalesced.
+// popcount and one atomic per wave on a stream counter, so every bounce kernel runs on dense waves.
+// Record = pixel, slot, triangle, (u,v), arrival direction, throughput (+K tangents): 44 + 12 K bytes, all
+// streams coalesced.
+// The stream is split into kWfSub SUB-STREAMS, each with its own counter on its own 128-byte line; block b
+// appends to (and, in the next stage, consumes) sub-stream b % kWfSub.  With ONE counter the 262 k waves of a
+// C2 stage serialised on a single L2 atomic (3-5 ns each: ~1 ms per stage, C2 PathTracer(3) 6.6 ms);
+// wave-private segments without any atomic were measured too: as fast on C2 (3.0 ms) but 10 % slower on
+// open scenes, where the waves' survivor counts differ and the next stage inherits the imbalance.
+constexpr int kWfSub = 64, kWfCountStride = 32;
 struct PathStream {
     int32_t *pixel; uint32_t *slot; int32_t *tri; float *hu, *hv; float *dir; float *beta;   // dir: [3][cap], beta: [3(1+K)][cap]
     long long cap;
+    int32_t *count;       // [kWfSub * kWfCountStride] records in each sub-stream
+    long long sub_cap;    // records per sub-stream
 };
 
 template <class M>
-__device__ __forceinline__ void stream_push(const PathStream &out, int *counter, bool alive, int pixel, uint32_t slot, const Its<float> &next,
+__device__ __forceinline__ void stream_push(const PathStream &out, bool alive, int pixel, uint32_t slot, const Its<float> &next,
                                             const Vec3f &dir, const Vec3<M> &beta) {
     constexpr int K = ad_traits<M>::K;
     const unsigned long long mask = __ballot(alive);
     if (mask == 0ull) return;
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, sub = blockIdx.x % kWfSub;
     int base = 0;
-    if (lane == __ffsll((long long) mask) - 1) base = atomicAdd(counter, (int) __popcll(mask));
+    if (lane == __ffsll((long long) mask) - 1) base = atomicAdd(out.count + sub * kWfCountStride, (int) __popcll(mask));
     base = __shfl(base, __ffsll((long long) mask) - 1, 64);
     if (!alive) return;
-    const long long i = base + __popcll(mask & ((1ull << lane) - 1ull));
+    const long long i = (long long) sub * out.sub_cap + base + __popcll(mask & ((1ull << lane) - 1ull));
     out.pixel[i] = pixel; out.slot[i] = slot; out.tri[i] = next.tri; out.hu[i] = next.hu; out.hv[i] = next.hv;
     out.dir[i] = dir.x; out.dir[out.cap + i] = dir.y; out.dir[2 * out.cap + i] = dir.z;
     out.beta[i] = val(beta.x); out.beta[out.cap + i] = val(beta.y); out.beta[2 * out.cap + i] = val(beta.z);
@@ -187,7 +195,7 @@ __device__ __forceinline__ void splat_runs(int pixel, bool valid, const Vec3<M> 
 template <class M, int FL>
 __global__ __launch_bounds__(kBlock, (is_ad<M>() ? 2 : 4)) void k_wf_camera(LaunchCtx cx, TV<M, FL> tv, int spp, int s_begin, int nsp, long long j0, long long n,
                                                         float inv_spp, float *__restrict__ img, float *__restrict__ dimg, long long plane,
-                                                        PathStream out, int *out_count, int want_next, unsigned long long *counters) {
+                                                        PathStream out, int want_next, unsigned long long *counters) {
     TraversalStack st; setup_lds(cx, st);
     uint32_t nrays = 0;
     const long long nceil = (n + kBlock - 1) / kBlock * kBlock;
@@ -207,22 +215,26 @@ __global__ __launch_bounds__(kBlock, (is_ad<M>() ? 2 : 4)) void k_wf_camera(Laun
             if (alive) { Vec3f d = next.p - origin; const float t = norm(d); dir = d / t; }
         }
         splat_runs<M>(pixel, in, r, inv_spp, img, dimg, plane);
-        stream_push<M>(out, out_count, alive && want_next, pixel, slot, next, dir, beta);
+        if (want_next) stream_push<M>(out, alive, pixel, slot, next, dir, beta);
     }
     count_rays(counters, nrays);
 }
 
+// One bounce: block b consumes its share of sub-stream b % kWfSub (grid-stride over the blocks of that
+// sub-stream; gridDim.x is a multiple of kWfSub) and appends the surviving paths to the same sub-stream of `out`.
 template <class M, int FL>
 __global__ __launch_bounds__(kBlock, (is_ad<M>() ? 2 : 4)) void k_wf_bounce(LaunchCtx cx, TV<M, FL> tv, float inv_spp, float *__restrict__ img,
-                                                        float *__restrict__ dimg, long long plane, PathStream in, const int *in_count,
-                                                        PathStream out, int *out_count, int want_next, unsigned long long *counters) {
+                                                        float *__restrict__ dimg, long long plane, PathStream in,
+                                                        PathStream out, int want_next, unsigned long long *counters) {
     constexpr int K = ad_traits<M>::K;
     TraversalStack st; setup_lds(cx, st);
     uint32_t nrays = 0;
-    const long long n = *in_count;
-    const long long nceil = (n + kBlock - 1) / kBlock * kBlock;
-    for (long long j = (long long) blockIdx.x * kBlock + threadIdx.x; j < nceil; j += (long long) gridDim.x * kBlock) {
-        const bool live = j < n;
+    const int sub = blockIdx.x % kWfSub, per = gridDim.x / kWfSub;
+    const long long in_base = (long long) sub * in.sub_cap;
+    const int n = in.count[sub * kWfCountStride];
+    for (int base = (blockIdx.x / kWfSub) * kBlock; base < n; base += per * kBlock) {
+        const bool live = base + (int) threadIdx.x < n;
+        const long long j = in_base + base + threadIdx.x;
         int pixel = -1; uint32_t slot = 0;
         Vec3<M> r = zero3<M>(), beta = zero3<M>();
         Its<float> next; next.tri = -1; next.hu = next.hv = 0.f;
@@ -251,7 +263,7 @@ __global__ __launch_bounds__(kBlock, (is_ad<M>() ? 2 : 4)) void k_wf_bounce(Laun
             }
         }
         splat_runs<M>(pixel, live, r, inv_spp, img, dimg, plane);
-        stream_push<M>(out, out_count, alive && want_next, pixel, slot, next, dir, beta);
+        if (want_next) stream_push<M>(out, alive, pixel, slot, next, dir, beta);
     }
     count_rays(counters, nrays);
 }
@@ -536,6 +548,7 @@ int run_camera(psdr_scene_s *h, const psdr_render_opts *o, const TV<R, FL> &tv, 
 // PathTracer interior term as a wavefront (see k_wf_camera / k_wf_bounce).  M = float or Dual<K>
 // with plain-fp32 geometry.
 constexpr long long kWfChunk = 1ll << 25;
+constexpr int kWfMaxDepth = 256;         // counter sets (use_wavefront: max_depth <= 250)
 template <class M, int FL>
 int run_camera_wavefront(psdr_scene_s *h, const psdr_render_opts *o, const TV<M, FL> &tv, float *img, float *dimg, hipStream_t s) {
     constexpr int K = ad_traits<M>::K;
@@ -546,36 +559,45 @@ int run_camera_wavefront(psdr_scene_s *h, const psdr_render_opts *o, const TV<M,
     const long long cap = std::min(n, kWfChunk);
     const int depth = o->max_depth;
     const size_t words = 8 + 3 * (1 + K);
-    const size_t need = 2 * words * 4 * (size_t) cap + 256 * sizeof(int);
+    // sub-streams: block b appends to sub-stream b % kWfSub, at most ceil(blocks / kWfSub) * trips * kBlock records each
+    const long long max_blocks = ((long long) h->num_cus * 16 + kWfSub - 1) / kWfSub * kWfSub;
+    const long long cap_alloc = cap + max_blocks * kBlock;
+    const size_t cnt_bytes = (size_t) kWfMaxDepth * kWfSub * kWfCountStride * sizeof(int32_t);
+    const size_t need = 2 * words * 4 * (size_t) cap_alloc + cnt_bytes;
     if (need > h->ws_bytes) {
         if (h->d_ws) (void) hipFree(h->d_ws);
         h->d_ws = nullptr; h->ws_bytes = 0;
         HIP_TRY(hipMalloc(&h->d_ws, need));
         h->ws_bytes = need;
     }
-    int *cnt = reinterpret_cast<int *>(h->d_ws);
+    int32_t *cnt = reinterpret_cast<int32_t *>(h->d_ws);
     PathStream st[2];
     for (int i = 0; i < 2; ++i) {
-        float *b = reinterpret_cast<float *>(reinterpret_cast<char *>(h->d_ws) + 256 * sizeof(int)) + (size_t) i * words * cap;
-        st[i].cap = cap;
-        st[i].pixel = reinterpret_cast<int32_t *>(b); st[i].slot = reinterpret_cast<uint32_t *>(b + cap); st[i].tri = reinterpret_cast<int32_t *>(b + 2 * cap);
-        st[i].hu = b + 3 * cap; st[i].hv = b + 4 * cap; st[i].dir = b + 5 * cap; st[i].beta = b + 8 * cap;
+        float *b = reinterpret_cast<float *>(reinterpret_cast<char *>(h->d_ws) + cnt_bytes) + (size_t) i * words * cap_alloc;
+        const long long c = cap_alloc;
+        st[i].cap = c;
+        st[i].pixel = reinterpret_cast<int32_t *>(b); st[i].slot = reinterpret_cast<uint32_t *>(b + c); st[i].tri = reinterpret_cast<int32_t *>(b + 2 * c);
+        st[i].hu = b + 3 * c; st[i].hv = b + 4 * c; st[i].dir = b + 5 * c; st[i].beta = b + 8 * c;
     }
     h->slots[0] += (uint64_t) n;
     const float inv_spp = 1.f / (float) o->spp;
     for (long long j0 = 0; j0 < n; j0 += cap) {
         const long long cn = std::min(cap, n - j0);
-        HIP_TRY(hipMemsetAsync(cnt, 0, 256 * sizeof(int), s));
         LaunchCtx cx;
         if (int rc = make_ctx(h, o, 0, cx)) return rc;
-        const int blocks = launch_blocks(h, cn);
+        HIP_TRY(hipMemsetAsync(cnt, 0, (size_t) std::min(depth, kWfMaxDepth) * kWfSub * kWfCountStride * sizeof(int32_t), s));
+        const int blocks = (launch_blocks(h, cn) + kWfSub - 1) / kWfSub * kWfSub;
+        const long long trips = (cn + (long long) blocks * kBlock - 1) / ((long long) blocks * kBlock);
+        st[0].sub_cap = st[1].sub_cap = (blocks / kWfSub) * trips * kBlock;
+        st[0].count = cnt;
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wf_camera<M, FL>), dim3(blocks), dim3(kBlock), lds_bytes(cx, h), s, cx, tv, o->spp, o->spp_begin, nsp, j0, cn,
-                           inv_spp, img, dimg, WH * 3, st[0], cnt + 1, depth > 1 ? 1 : 0, h->d_counters);
+                           inv_spp, img, dimg, WH * 3, st[0], depth > 1 ? 1 : 0, h->d_counters);
         HIP_TRY(hipGetLastError());
         for (int k = 1; k < depth; ++k) {
+            st[k & 1].count = cnt + (size_t) k * kWfSub * kWfCountStride;      // a fresh (zeroed) counter set per stage
             cx.jump = make_rng_jump(o->rng_offset[0] + 2 + 5 * (uint64_t) k);
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wf_bounce<M, FL>), dim3(blocks), dim3(kBlock), lds_bytes(cx, h), s, cx, tv, inv_spp, img, dimg, WH * 3,
-                               st[(k - 1) & 1], cnt + k, st[k & 1], cnt + k + 1, k + 1 < depth ? 1 : 0, h->d_counters);
+                               st[(k - 1) & 1], st[k & 1], k + 1 < depth ? 1 : 0, h->d_counters);
             HIP_TRY(hipGetLastError());
         }
     }

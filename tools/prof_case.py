@@ -19,6 +19,8 @@ else:
     sc, _ = load_scene(scene, res=res, spp=spp)
 tb = sc.tables(0); g = GpuScene(tb)
 kw = dict(bsdf_samples=1, light_samples=1) if integ == "direct" else dict(integrator=_abi.INTEGRATOR_PATH, max_depth=depth)
+if os.environ.get("PSDR_PROF_WAVEFRONT"):
+    kw["flags"] = _abi.FLAG_WAVEFRONT if os.environ["PSDR_PROF_WAVEFRONT"] == "1" else _abi.FLAG_FUSED
 o = _abi.make_opts(spp=spp, **kw)
 adj = np.random.default_rng(0).random((res * res, 3)).astype(np.float32)
 tan = random_tangents(tb, ["tri_info", "texels"])
