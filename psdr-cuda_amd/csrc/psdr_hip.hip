@@ -186,7 +186,7 @@ SinkLayout make_sink_layout(const psdr_scene_s *h, const psdr_grads *g) {
 
 int begin_call(psdr_scene_s *h, hipStream_t s) {
     h->slots[0] = h->slots[1] = h->slots[2] = 0; h->last_path_depth = 0;
-    HIP_TRY(hipMemsetAsync(h->d_counters, 0, sizeof(unsigned long long) * 4, s));
+    HIP_TRY(hipMemsetAsync(h->d_counters, 0, sizeof(unsigned long long) * kRayCounters * kRayCounterStride, s));
     return 0;
 }
 
@@ -242,7 +242,7 @@ int psdr_abi_struct_sizes(int32_t out[4]) {
 int psdr_scene_create(psdr_scene_t *out) {
     if (!out) return fail("psdr_scene_create: null output");
     psdr_scene_s *h = new psdr_scene_s();
-    hipError_t e = hipMalloc(&h->d_counters, sizeof(unsigned long long) * 4);
+    hipError_t e = hipMalloc(&h->d_counters, sizeof(unsigned long long) * kRayCounters * kRayCounterStride);
     if (e != hipSuccess) { delete h; return fail(std::string("hipMalloc: ") + hipGetErrorString(e)); }
     int dev = 0; hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) h->num_cus = prop.multiProcessorCount;
@@ -458,8 +458,9 @@ int psdr_bvh_stats(psdr_scene_t h, int32_t out[4]) {
 
 int psdr_get_counters(psdr_scene_t h, uint64_t out[4]) {
     if (!h || !out) return fail("psdr_get_counters: null argument");
-    unsigned long long c[4] = {0, 0, 0, 0};
-    HIP_TRY(hipMemcpy(c, h->d_counters, sizeof(c), hipMemcpyDeviceToHost));
+    unsigned long long all[kRayCounters * kRayCounterStride], c[1] = {0};
+    HIP_TRY(hipMemcpy(all, h->d_counters, sizeof(all), hipMemcpyDeviceToHost));
+    for (int i = 0; i < kRayCounters; ++i) c[0] += all[i * kRayCounterStride];
     out[0] = c[0]; out[1] = h->slots[0]; out[2] = h->slots[1]; out[3] = h->slots[2];
     if (h->last_path_depth > 0 && h->slots[0] > 0 && h->slots[1] == 0 && h->slots[2] == 0)
         h->path_survival = (float) ((double) c[0] / ((double) h->slots[0] * (1.0 + 2.0 * h->last_path_depth)));

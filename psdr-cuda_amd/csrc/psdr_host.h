@@ -116,6 +116,8 @@ struct psdr_scene_s {
     size_t ws_bytes = 0;
 };
 
+constexpr int kRayCounters = 64, kRayCounterStride = 16;     // d_counters: 64 counters, 128 bytes apart
+
 namespace psdr_host {
 int fail(const std::string &m);
 int launch_blocks(const psdr_scene_s *h, long long n);

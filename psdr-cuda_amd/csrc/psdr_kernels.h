@@ -48,11 +48,13 @@ template <int N> __device__ __forceinline__ bool wave_run_sum(int key, float (&v
     return head;
 }
 
+// Rays traced by the launch: one atomic per wave at kernel end, spread over kRayCounters counters on their own
+// 128-byte lines (same-address L2 atomics serialise at 3-5 ns each; psdr_get_counters sums them).
 __device__ __forceinline__ void count_rays(unsigned long long *counters, uint32_t nrays) {
     uint32_t s = nrays;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-    if ((threadIdx.x & 63) == 0 && s) atomicAdd(counters, (unsigned long long) s);
+    if ((threadIdx.x & 63) == 0 && s) atomicAdd(counters + (blockIdx.x % kRayCounters) * kRayCounterStride, (unsigned long long) s);
 }
 
 // ------------------------------------------------------------------------------ k_camera
