@@ -30,8 +30,8 @@ import torch  # noqa: E402
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--res", type=int, default=512)
     ap.add_argument("--spp", type=int, default=64, help="samples per pixel PER GPU")
     ap.add_argument("--max-depth", type=int, default=3)
@@ -123,6 +123,11 @@ def main():
             kern_ms["render_d"].append(ev[2].elapsed_time(ev[3]))
             rays["c"], rays["d"] = rays_c, rays_d
 
+    # The first launch of a kernel loads its code object (8 ms) and the next three run 3-8 % slow while the clocks
+    # ramp (tools/var_probe.py): a few untimed passes as part of the setup, so that a small --warmup still
+    # measures the steady state.  The W warm-up steps of the contract follow.
+    for _ in range(6):
+        step(False)
     for _ in range(args.warmup):
         step(False)
     torch.cuda.synchronize()
