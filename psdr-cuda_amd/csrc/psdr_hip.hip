@@ -181,6 +181,10 @@ SinkLayout make_sink_layout(const psdr_scene_s *h, const psdr_grads *g) {
         if (rows > 0) { L.hot_off = off; L.hot_rows = rows; L.hot_map = h->d_hot_map; L.hot_tris = h->d_hot_tris; off += rows * PSDR_TRI_STRIDE; }
     }
     L.total = off;
+    L.stride = off | 1;
+    L.rep = 1;
+    static const int max_rep = std::getenv("PSDR_SINK_REP") ? std::atoi(std::getenv("PSDR_SINK_REP")) : 16;
+    while (L.rep * 2 <= max_rep && L.rep * 2 * L.stride <= kSinkCacheWords) L.rep *= 2;
     return L;
 }
 

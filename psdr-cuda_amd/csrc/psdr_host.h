@@ -54,6 +54,9 @@ __device__ __forceinline__ void setup_lds(const LaunchCtx &cx, TraversalStack &s
 //            radiances (if they fit), and the "hot" triangle rows = the whole table when it is small,
 //            otherwise the emitter meshes' rows (every light sample lands on them) plus the
 //            largest-area triangles (walls, floors: the rows most path vertices land on)
+//            The cache is REPLICATED up to 16 times when it is small (lane -> copy lane % rep): ds_add_f32 of
+//            lanes that land on the same word serialise (64 lanes on one albedo texel or one wall row = 64 LDS
+//            cycles; the C2 geometry-gradient kernel kept the LDS pipeline busy 80 cycles per instruction)
 //   level 3  hardware global_atomic_add_f32 on the gradient table for the incoherent remainder
 // The cache is flushed with one global atomic per non-zero cached word per workgroup.
 // Non-finite pieces are dropped (forward mode zeroes non-finite tangents, zero_nonfinite).
@@ -66,6 +69,7 @@ struct SinkLayout {
     int hot_off, hot_rows;                   // cached triangle rows: slot = hot_map[tri] (-1 = not cached)
     const int32_t *hot_map, *hot_tris;       // [T] tri -> slot, [hot_rows] slot -> tri
     int total;
+    int rep, stride;                         // copies of the cache (power of two) and their distance in words (odd)
 };
 
 // The scene handle behind psdr_scene_t: the caller's tables, the BVH on the device and per-handle scratch.

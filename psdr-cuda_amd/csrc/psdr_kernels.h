@@ -361,7 +361,8 @@ template <int FL> struct DeviceSink {
     static constexpr bool has_env = (FL & kSceneEnv) != 0;
     psdr_grads g;
     SinkLayout L;
-    float *lds;
+    float *lds;           // THIS lane's copy of the cache (lane & (rep - 1))
+    float *lds0;          // copy 0
     float cam[16];
     __device__ __forceinline__ static bool ok(float v) { return v != 0.f && isfinite(v); }
     __device__ __forceinline__ void glob(float *base, size_t i, float v) const { if (base != nullptr && ok(v)) atomicAdd(base + i, v); }
@@ -385,8 +386,9 @@ template <int FL> struct DeviceSink {
     __device__ __forceinline__ void add_pedge(int e, int word, float v) const { glob(g.g_prim_edge, (size_t) e * PSDR_PEDGE_STRIDE + word, v); }
 
     __device__ __forceinline__ void begin(float *cache) {
-        lds = cache;
-        for (int i = threadIdx.x; i < L.total; i += kBlock) cache[i] = 0.f;
+        lds0 = cache;
+        lds = cache + (threadIdx.x & (L.rep - 1)) * L.stride;
+        for (int i = threadIdx.x; i < L.rep * L.stride; i += kBlock) cache[i] = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) cam[i] = 0.f;
         __syncthreads();
@@ -398,12 +400,13 @@ template <int FL> struct DeviceSink {
                 float v = cam[i];
 #pragma unroll
                 for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-                if ((threadIdx.x & 63) == 0 && v != 0.f) atomicAdd(lds + L.cam_off + i, v);
+                if ((threadIdx.x & 63) == 0 && v != 0.f) atomicAdd(lds0 + L.cam_off + i, v);
             }
         }
         __syncthreads();
         for (int i = threadIdx.x; i < L.total; i += kBlock) {
-            const float v = lds[i];
+            float v = lds0[i];
+            for (int r = 1; r < L.rep; ++r) v += lds0[r * L.stride + i];
             if (v == 0.f) continue;
             if (i >= L.cam_off && i < L.cam_off + 16) { atomicAdd(g.g_cam_to_world + (i - L.cam_off), v); continue; }
             if (L.tex_n && i >= L.tex_off && i < L.tex_off + L.tex_n) { atomicAdd(g.g_texels + (i - L.tex_off), v); continue; }

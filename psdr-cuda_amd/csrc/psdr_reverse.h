@@ -814,15 +814,30 @@ PSDR_HD Vec3f camera_sample_reverse(RealSink &real_sink, PrimaryGrad &pg, PathRe
     }
     // ---- primary vertex: wi = to_local(-d), frame(sh_n(bu,bv)), uv(bu,bv), p = o + t d, (bu,bv,t) = MT(tri0, ray)
     if (geo) {
-        Vec3f a_d = a_d_le0 - (its.sh.s * va0.wi.x + its.sh.t * va0.wi.y + its.sh.n * va0.wi.z);
-        acc(va0.s, ray.d * (-va0.wi.x)); acc(va0.t, ray.d * (-va0.wi.y)); acc(va0.n, ray.d * (-va0.wi.z));
-        const Vec3f a_shn = va0.n + frame_vjp(sn0.n, va0.s, va0.t);
+        // The primary vertex is REBUILT here (ray, triangle row, Moeller-Trumbore, shading frame: ~150 VALU) instead
+        // of staying live across the two sweeps: ~60 registers less in a kernel that spills at 2 waves / SIMD.
+        // The triangle index goes through an opaque copy so that the compiler does not merge the two evaluations.
+        int tri_b = h0.tri;
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(tri_b));
+#endif
+        const Vec3f dcam_b = camera_space_dir(sc, sx, sy);
+        const RayT<float> ray_b = primary_ray<float>(sc, tv0, sx, sy);
+        const TriRow<float> Tb = load_tri<float>(sc, tv0, tri_b);
+        float bu_b, bv_b, t_b;
+        moeller_trumbore(Tb.p0, Tb.e1, Tb.e2, ray_b, bu_b, bv_b, t_b);
+        const ShNormal sn_b = shading_normal(Tb, face0, bu_b, bv_b);
+        const Frame<float> sh_b(sn_b.n);
+        const float *qb = sc.d.tri_uv ? sc.d.tri_uv + (size_t) tri_b * PSDR_TRIUV_STRIDE : nullptr;
+        Vec3f a_d = a_d_le0 - (sh_b.s * va0.wi.x + sh_b.t * va0.wi.y + sh_b.n * va0.wi.z);
+        acc(va0.s, ray_b.d * (-va0.wi.x)); acc(va0.t, ray_b.d * (-va0.wi.y)); acc(va0.n, ray_b.d * (-va0.wi.z));
+        const Vec3f a_shn = va0.n + frame_vjp(sn_b.n, va0.s, va0.t);
         float abu = 0.f, abv = 0.f;
-        shading_normal_vjp(sink, h0.tri, T0, sn0, bu, bv, a_shn, abu, abv);
-        if (q) { abu += va0.u * (q[2] - q[0]) + va0.v * (q[3] - q[1]); abv += va0.u * (q[4] - q[0]) + va0.v * (q[5] - q[1]); }
-        const MtAdj ma = mt_vjp(T0.p0, T0.e1, T0.e2, ray, abu, abv, dot(va0.p, ray.d));
-        scatter_vec(sink, h0.tri, 0, ma.p0); scatter_vec(sink, h0.tri, 3, ma.e1); scatter_vec(sink, h0.tri, 6, ma.e2);
-        camera_ray_vjp(sink, sc, dcam, va0.p + ma.o, a_d + va0.p * t0 + ma.d);
+        shading_normal_vjp(sink, tri_b, Tb, sn_b, bu_b, bv_b, a_shn, abu, abv);
+        if (qb) { abu += va0.u * (qb[2] - qb[0]) + va0.v * (qb[3] - qb[1]); abv += va0.u * (qb[4] - qb[0]) + va0.v * (qb[5] - qb[1]); }
+        const MtAdj ma = mt_vjp(Tb.p0, Tb.e1, Tb.e2, ray_b, abu, abv, dot(va0.p, ray_b.d));
+        scatter_vec(sink, tri_b, 0, ma.p0); scatter_vec(sink, tri_b, 3, ma.e1); scatter_vec(sink, tri_b, 6, ma.e2);
+        camera_ray_vjp(sink, sc, dcam_b, va0.p + ma.o, a_d + va0.p * t_b + ma.d);
     }
     return result;
 }
