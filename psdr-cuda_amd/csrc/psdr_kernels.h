@@ -425,8 +425,14 @@ template <int FL> struct DeviceSink {
 #ifndef PSDR_WAVES_REV_MAT
 #define PSDR_WAVES_REV_MAT 3
 #endif
+// geometry adjoints: 2 waves/SIMD (248 VGPRs for the PathTracer, more for the rough-conductor variants); the
+// diffuse DirectIntegrator instance needs 187 and runs faster at 3 (C2 direct all gradients 4.1 -> 3.4 ms), the
+// others lose 50-100 % there to spills
+template <int FL, bool GEO, int INTEG> constexpr int rev_waves() {
+    return !GEO ? PSDR_WAVES_REV_MAT : ((INTEG == PSDR_INTEGRATOR_DIRECT && !(FL & kSceneRough)) ? 3 : PSDR_WAVES_REV);
+}
 template <int FL, bool GEO, int INTEG>
-__global__ __launch_bounds__(kBlock, (GEO ? PSDR_WAVES_REV : PSDR_WAVES_REV_MAT)) void k_camera_rev(LaunchCtx cx, DeviceSink<FL> sink, int spp, int s_begin, int nsp, long long n, float inv_spp,
+__global__ __launch_bounds__(kBlock, (rev_waves<FL, GEO, INTEG>())) void k_camera_rev(LaunchCtx cx, DeviceSink<FL> sink, int spp, int s_begin, int nsp, long long n, float inv_spp,
                                                        const float *__restrict__ adj_img, float *__restrict__ img,
                                                        unsigned long long *counters) {
     __shared__ float cache[kSinkCacheWords];
