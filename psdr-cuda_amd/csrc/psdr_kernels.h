@@ -366,9 +366,14 @@ template <int FL> struct DeviceSink {
     float cam[16];
     __device__ __forceinline__ static bool ok(float v) { return v != 0.f && isfinite(v); }
     __device__ __forceinline__ void glob(float *base, size_t i, float v) const { if (base != nullptr && ok(v)) atomicAdd(base + i, v); }
-    __device__ __forceinline__ void add_tri(int tri, int word, float v) const {
+    // The ~20 words of one vertex' row adjoint arrive one add_tri at a time: the tri -> cache slot lookup (a
+    // global load that the compiler cannot hoist across the atomics) is remembered for the last triangle
+    // (C2 PathTracer(3): 370 -> 90 global loads per slot).
+    int last_tri, last_slot;
+    __device__ __forceinline__ void add_tri(int tri, int word, float v) {
         if (g.g_tri_info == nullptr || !ok(v)) return;
-        const int slot = L.hot_rows ? L.hot_map[tri] : -1;
+        if (tri != last_tri) { last_tri = tri; last_slot = L.hot_rows ? L.hot_map[tri] : -1; }
+        const int slot = last_slot;
         if (slot >= 0 && slot < L.hot_rows) atomicAdd(lds + L.hot_off + slot * PSDR_TRI_STRIDE + word, v);
         else atomicAdd(g.g_tri_info + (size_t) tri * PSDR_TRI_STRIDE + word, v);
     }
@@ -387,6 +392,7 @@ template <int FL> struct DeviceSink {
 
     __device__ __forceinline__ void begin(float *cache) {
         lds0 = cache;
+        last_tri = -1; last_slot = -1;
         lds = cache + (threadIdx.x & (L.rep - 1)) * L.stride;
         for (int i = threadIdx.x; i < L.rep * L.stride; i += kBlock) cache[i] = 0.f;
 #pragma unroll

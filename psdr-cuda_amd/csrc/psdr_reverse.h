@@ -691,6 +691,11 @@ PSDR_HD Vec3f camera_sample_reverse(RealSink &real_sink, PrimaryGrad &pg, PathRe
     pg.clear();
     using Sink = typename CameraSinkOf<GEO, RealSink>::type;
     Sink sink(real_sink, pg);
+    // the two sweeps scatter straight into the real sink; only the adjoint chain of the PRIMARY vertex (run last,
+    // all on one triangle row that the lanes of a wave share) goes through the register accumulators of
+    // PrimarySink -- so those 21 registers are not live across the sweeps
+    auto &sweep = [&]() -> auto & { if constexpr (GEO) return real_sink; else return sink; }();
+    using SweepSink = std::remove_reference_t<decltype(sweep)>;
     const TangentView<0, Sink::flags> tv0{};
     Rng rng; rng.init(slot, jump);
     const float j0 = rng.next(), j1 = rng.next();
@@ -783,9 +788,9 @@ PSDR_HD Vec3f camera_sample_reverse(RealSink &real_sink, PrimaryGrad &pg, PathRe
     }
     // masked(value, ~isfinite(value)) = 0 (integrator.cpp:87): a zeroed sample has no gradient either
     if (!(isfinite(result.x) && isfinite(result.y) && isfinite(result.z))) return zero_nonfinite(result);
-    if (le0) { sink.add_rad(e0, 0, adj.x); sink.add_rad(e0, 1, adj.y); sink.add_rad(e0, 2, adj.z); }
+    if (le0) { sweep.add_rad(e0, 0, adj.x); sweep.add_rad(e0, 1, adj.y); sweep.add_rad(e0, 2, adj.z); }
     Vec3f a_d_le0(0.f);                         // d Le(primary) / d ray direction (environment map seen directly)
-    if (env0) { if constexpr (Sink::has_env) a_d_le0 = env_eval_vjp(sink, sc, ray.d, adj); }
+    if (env0) { if constexpr (Sink::has_env) a_d_le0 = env_eval_vjp(sweep, sc, ray.d, adj); }
     // suffix radiances T_{k+1} overwrite c_k in place (T_nv = 0): afterwards rec.c(k) == T_{k+1}
     {
         Vec3f T(0.f);
@@ -801,12 +806,12 @@ PSDR_HD Vec3f camera_sample_reverse(RealSink &real_sink, PrimaryGrad &pg, PathRe
             const Vec3f a_c = adj * beta;
             const Vec3f a_f = (k + 1 < nv) ? a_c * rec.c(k) : Vec3f(0.f);
             VertexAdj va; va.clear();
-            const VertexOut vo = replay ? vertex_eval<true, true, Sink>(sink, sc, st, rng, cur, nB, nL, a_c, a_f, k == 0 ? va0 : va, nrays, rec, k)
-                                        : vertex_eval<true, false, Sink>(sink, sc, st, rng, cur, nB, nL, a_c, a_f, k == 0 ? va0 : va, nrays, rec, k);
+            const VertexOut vo = replay ? vertex_eval<true, true, SweepSink>(sweep, sc, st, rng, cur, nB, nL, a_c, a_f, k == 0 ? va0 : va, nrays, rec, k)
+                                        : vertex_eval<true, false, SweepSink>(sweep, sc, st, rng, cur, nB, nL, a_c, a_f, k == 0 ? va0 : va, nrays, rec, k);
             if (k >= 1) {
-                const Vec3f a_prev = path_vertex_backward(sink, sc, cur, prev.p, va);
+                const Vec3f a_prev = path_vertex_backward(sweep, sc, cur, prev.p, va);
                 if (k == 1) acc(va0.p, a_prev);
-                else scatter_point(sink, prev.tri, prev.hu, prev.hv, a_prev);
+                else scatter_point(sweep, prev.tri, prev.hu, prev.hv, a_prev);
             }
             if (!vo.next_valid || k + 1 >= nv) break;
             beta = beta * vo.f; prev = cur; cur = vo.next;
