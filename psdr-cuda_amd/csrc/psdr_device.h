@@ -117,8 +117,9 @@ PSDR_HD void leaf_triangle_test(const float4 &a, const float4 &b, const float4 &
     const Vec3f q = cross(s, e1);
     const float v = f * dot(d, q);
     const float t = f * dot(e2, q);
-    if (det != 0.f && u >= 0.f && u <= 1.f && v >= 0.f && u + v <= 1.f && t >= kRayEpsilon && t <= best.t &&
-        (t < best.t || best.tri < 0)) {
+    // det != 0 and u <= 1 of the textbook test are implied: det == 0 makes u, v infinite or NaN (every comparison
+    // below fails), and v >= 0 with u + v <= 1 gives u <= 1 in floating point too (fl(u + v) >= u)
+    if (u >= 0.f && v >= 0.f && u + v <= 1.f && t >= kRayEpsilon && t <= best.t && (t < best.t || best.tri < 0)) {
         best.t = t; best.u = u; best.v = v; best.tri = __float_as_int_hd(a.w);
     }
 }
