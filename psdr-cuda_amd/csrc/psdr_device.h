@@ -119,7 +119,9 @@ PSDR_HD void leaf_triangle_test(const float4 &a, const float4 &b, const float4 &
     const float t = f * dot(e2, q);
     // det != 0 and u <= 1 of the textbook test are implied: det == 0 makes u, v infinite or NaN (every comparison
     // below fails), and v >= 0 with u + v <= 1 gives u <= 1 in floating point too (fl(u + v) >= u)
-    if (u >= 0.f && v >= 0.f && u + v <= 1.f && t >= kRayEpsilon && t <= best.t && (t < best.t || best.tri < 0)) {
+    // closest_hit starts from the open upper bound next_above(tmax), so "t <= tmax, the first of equal hits wins"
+    // is the single strict comparison t < best.t
+    if (u >= 0.f && v >= 0.f && u + v <= 1.f && t >= kRayEpsilon && t < best.t) {
         best.t = t; best.u = u; best.v = v; best.tri = __float_as_int_hd(a.w);
     }
 }
@@ -127,7 +129,8 @@ PSDR_HD void leaf_triangle_test(const float4 &a, const float4 &b, const float4 &
 // Replaces __raygen__/__closesthit__/__miss__ (cuda/psdr_cuda.cu:9-45): closest hit with
 // t in [RayEpsilon, tmax], both faces; (u,v) = barycentric weights of vertex 1 and 2.
 PSDR_HD Hit closest_hit(const SceneView &sc, TraversalStack &st, const Vec3f &o, const Vec3f &d, float tmax) {
-    Hit best; best.tri = -1; best.u = best.v = -1.f; best.t = tmax;
+    Hit best; best.tri = -1; best.u = best.v = -1.f;
+    best.t = (tmax > 0.f && tmax < INFINITY) ? __int_as_float_hd(__float_as_int_hd(tmax) + 1) : tmax;   // accept t <= tmax
     if (sc.n_tiny > 0) {
         for (int i = 0; i < sc.n_tiny; ++i) leaf_triangle_test(sc.tiny[i * 3], sc.tiny[i * 3 + 1], sc.tiny[i * 3 + 2], o, d, best);
         return best;

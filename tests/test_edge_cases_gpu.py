@@ -211,6 +211,33 @@ def test_tiny_scene_all_triangles_path_equals_the_tree_walk(monkeypatch):
         assert rel_l2(out["1"][2][k], out["0"][2][k]) < 1e-4, k
 
 
+@pytest.mark.parametrize("scene", ["cbox", "cbox_bunny"])
+def test_trace_respects_tmax(scene):
+    """psdr_trace: hits with t in [RayEpsilon, tmax] only -- a tmax short of the wall misses, a generous one hits,
+    tmax = 0 / negative never hits; same answers as the oracle (all-triangles path and tree walk)"""
+    from helpers import camera_rays
+    sc, _ = load_scene(scene, res=16, spp=1)
+    tb = sc.tables(0)
+    g = GpuScene(tb)
+    o, d = camera_rays(tb, 20_000, seed=5)
+    _, tri, u, v = g.trace(o, d)
+    info = tb["tri_info"].cpu().numpy()
+    hit = tri >= 0
+    assert hit.mean() > 0.9
+    p = info[tri, 0:3] + u[:, None] * info[tri, 3:6] + v[:, None] * info[tri, 6:9]
+    dist = np.where(hit, np.linalg.norm(p - o, axis=1), 1.0).astype(np.float32)
+    rng = np.random.default_rng(1)
+    for scale in (0.5, 0.999, 1.001, 2.0, 0.0, -1.0):
+        tmax = (dist * scale).astype(np.float32)
+        _, t_gpu, _, _ = g.trace(o, d, tmax)
+        _, t_ref, _, _ = oracle.trace(tb, o, d, tmax)
+        assert (t_gpu == t_ref).mean() > 0.999, scale
+        if scale <= 0.999:
+            assert (t_gpu[hit] != tri[hit]).all()            # nothing closer than the closest hit
+        if scale >= 1.001:
+            assert (t_gpu[hit] == tri[hit]).mean() > 0.999
+
+
 @pytest.mark.parametrize("seed", [0, 1, 2, 3])
 def test_render_fuzz_random_scenes(seed):
     """random emitter + random diffuse / rough-conductor triangle soups (intersecting, back-facing, slivers):
