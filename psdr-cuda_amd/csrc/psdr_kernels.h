@@ -68,7 +68,8 @@ __device__ __forceinline__ void slot_to_pixel(long long j, int nsp, int &pixel, 
 // Occupancy targets (waves per SIMD) of the camera kernel.  The kernel is latency/dependency bound
 // (rocprof r01: 43 % of wave cycles waiting at 2 waves/SIMD), so trading registers for resident
 // waves pays: measured 6.2 -> 4.6 ms (renderC, 4 waves) and 12.5 -> 7.0 ms (renderD K=3 material-only, 2 waves,
-// no spills) on C2; 5 waves (renderC) and 3-4 waves (Dual<3>) spill and lose.
+// no spills) on C2.  These are the defaults of the general variants; camera_waves() adds a wave where the
+// leaner instances take it.
 #ifndef PSDR_WAVES_C
 #define PSDR_WAVES_C 4
 #endif
@@ -80,11 +81,16 @@ __device__ __forceinline__ void slot_to_pixel(long long j, int nsp, int &pixel, 
 #endif
 // geometry duals: K = 1 fits 3 waves/SIMD without spills in DirectIntegrator form (C2 direct 2.5 -> 2.0 ms, path3
 // 6.7 -> 5.8 ms); K = 3 would spill > 400 registers there and stays at PSDR_WAVES_DG
-template <class G, class R> constexpr int camera_waves() {
-    return !is_ad<R>() ? PSDR_WAVES_C : (is_ad<G>() ? (ad_traits<G>::K == 1 ? 3 : PSDR_WAVES_DG) : PSDR_WAVES_DM);
+// the plain diffuse / area-light variant (FL == 0) is lean enough for one more wave: renderC 5 waves/SIMD (C2
+// PathTracer(3) 2.06 -> 1.89 ms), material duals of the PathTracer 4 (2.85 -> 2.66 ms); the rough-conductor
+// variants lose 10 % there (C5 renderC 5.0 -> 5.5 ms) and the DirectIntegrator K = 3 instance 20 %
+template <class G, class R, int INTEG, int FL> constexpr int camera_waves() {
+    if (!is_ad<R>()) return FL == 0 ? PSDR_WAVES_C + 1 : PSDR_WAVES_C;
+    if (is_ad<G>()) return ad_traits<G>::K == 1 ? 3 : PSDR_WAVES_DG;
+    return (FL == 0 && INTEG == PSDR_INTEGRATOR_PATH) ? PSDR_WAVES_DM + 1 : PSDR_WAVES_DM;
 }
 template <class G, class R, int INTEG, int FL>
-__global__ __launch_bounds__(kBlock, (camera_waves<G, R>())) void k_camera(LaunchCtx cx, TV<R, FL> tv, int spp, int s_begin, int nsp, long long n, float inv_spp,
+__global__ __launch_bounds__(kBlock, (camera_waves<G, R, INTEG, FL>())) void k_camera(LaunchCtx cx, TV<R, FL> tv, int spp, int s_begin, int nsp, long long n, float inv_spp,
                                                    float *__restrict__ img, float *__restrict__ dimg, long long plane,
                                                    unsigned long long *counters) {
     constexpr int K = ad_traits<R>::K;
