@@ -183,7 +183,8 @@ SinkLayout make_sink_layout(const psdr_scene_s *h, const psdr_grads *g) {
     L.total = off;
     L.stride = off | 1;
     L.rep = 1;
-    static const int max_rep = std::getenv("PSDR_SINK_REP") ? std::atoi(std::getenv("PSDR_SINK_REP")) : 16;
+    // 2 copies bought 6 % on C2, more nothing: 4 at most, so that a small scene's cache stays a few KB of LDS
+    static const int max_rep = std::getenv("PSDR_SINK_REP") ? std::atoi(std::getenv("PSDR_SINK_REP")) : 4;
     while (L.rep * 2 <= max_rep && L.rep * 2 * L.stride <= kSinkCacheWords) L.rep *= 2;
     return L;
 }

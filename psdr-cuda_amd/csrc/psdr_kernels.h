@@ -50,6 +50,13 @@ template <int N> __device__ __forceinline__ bool wave_run_sum(int key, float (&v
 
 // Rays traced by the launch: one atomic per wave at kernel end, spread over kRayCounters counters on their own
 // 128-byte lines (same-address L2 atomics serialise at 3-5 ns each; psdr_get_counters sums them).
+__device__ __forceinline__ float *dyn_lds_floats(int byte_offset) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return reinterpret_cast<float *>(psdr_dyn_lds + byte_offset);
+#else
+    (void) byte_offset; return nullptr;
+#endif
+}
 __device__ __forceinline__ void count_rays(unsigned long long *counters, uint32_t nrays) {
     uint32_t s = nrays;
 #pragma unroll
@@ -441,15 +448,15 @@ template <int FL> struct DeviceSink {
 // diffuse DirectIntegrator instance needs 187 and runs faster at 3 (C2 direct all gradients 4.1 -> 3.4 ms), the
 // others lose 50-100 % there to spills
 template <int FL, bool GEO, int INTEG> constexpr int rev_waves() {
-    return !GEO ? PSDR_WAVES_REV_MAT : ((INTEG == PSDR_INTEGRATOR_DIRECT && !(FL & kSceneRough)) ? 3 : PSDR_WAVES_REV);
+    if (!GEO) return FL == 0 ? PSDR_WAVES_REV_MAT + 1 : PSDR_WAVES_REV_MAT;   // plain diffuse variant: 130 VGPRs, C2 texel gradient 3.4 -> 2.8 ms
+    return (INTEG == PSDR_INTEGRATOR_DIRECT && !(FL & kSceneRough)) ? 3 : PSDR_WAVES_REV;
 }
 template <int FL, bool GEO, int INTEG>
 __global__ __launch_bounds__(kBlock, (rev_waves<FL, GEO, INTEG>())) void k_camera_rev(LaunchCtx cx, DeviceSink<FL> sink, int spp, int s_begin, int nsp, long long n, float inv_spp,
                                                        const float *__restrict__ adj_img, float *__restrict__ img,
                                                        unsigned long long *counters) {
-    __shared__ float cache[kSinkCacheWords];
     TraversalStack st; setup_lds(cx, st);
-    sink.begin(cache);
+    sink.begin(dyn_lds_floats(cx.off_sink));
     uint32_t nrays = 0;
     const long long nceil = (n + kBlock - 1) / kBlock * kBlock;
     for (long long j = (long long) blockIdx.x * kBlock + threadIdx.x; j < nceil; j += (long long) gridDim.x * kBlock) {
@@ -528,9 +535,8 @@ __global__ __launch_bounds__(kBlock, PSDR_WAVES_PE) void k_primary_edge_rev(Laun
 template <int FL>
 __global__ __launch_bounds__(kBlock) void k_secondary_edge_rev(LaunchCtx cx, DeviceSink<FL> sink, long long i0, long long n, float inv_sppse,
                                                                const float *__restrict__ adj_img, unsigned long long *counters) {
-    __shared__ float cache[kSinkCacheWords];
     TraversalStack st; setup_lds(cx, st);
-    sink.begin(cache);
+    sink.begin(dyn_lds_floats(cx.off_sink));
     uint32_t nrays = 0;
     const bool guided = cx.sc.d.guide_cmf != nullptr && cx.sc.d.num_guide_cells > 0;
     for (long long j = (long long) blockIdx.x * kBlock + threadIdx.x; j < n; j += (long long) gridDim.x * kBlock) {
@@ -683,14 +689,18 @@ int render_rev(psdr_scene_s *h, const psdr_render_opts *o, const float *adj_img,
         h->slots[0] += (uint64_t) n;
         const int depth = o->integrator == PSDR_INTEGRATOR_PATH ? std::min(o->max_depth, kMaxRevDepth) : 1;
         const int rec_bytes = depth * kPathRecWords * kBlock * 4;
-        plan_lds(h, cx, rec_bytes + kSinkCacheWords * 4);          // stage less of the scene: the record + cache live in LDS too
+        const int cache_bytes = sink_bytes(sink.L);
+        plan_lds(h, cx, rec_bytes + cache_bytes);                  // stage less of the scene: the record + cache live in LDS too
         cx.off_pathrec = lds_bytes(cx, h);
+        cx.off_sink = cx.off_pathrec + rec_bytes;
+        const int dyn_bytes = cx.off_sink + cache_bytes;
         // material-only gradients (no triangle / camera table wanted) run the variant without the geometric adjoints;
         // the integrator is a compile-time parameter as in the forward kernels (direct: no path record / replay loop)
         const bool geo = grads->g_tri_info != nullptr || grads->g_cam_to_world != nullptr;
 #define PSDR_LAUNCH_REV(GEO, INTEG)                                                                                                  \
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_camera_rev<FL, GEO, INTEG>), dim3(launch_blocks(h, n)), dim3(kBlock), lds_bytes(cx, h) + rec_bytes, s, cx, sink, \
-                           o->spp, o->spp_begin, nsp, n, 1.f / (float) o->spp, adj_img, out_img, h->d_counters)
+        do { if (dyn_bytes > 48 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_camera_rev<FL, GEO, INTEG>), hipFuncAttributeMaxDynamicSharedMemorySize, dyn_bytes)); \
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_camera_rev<FL, GEO, INTEG>), dim3(launch_blocks(h, n)), dim3(kBlock), dyn_bytes, s, cx, sink, \
+                           o->spp, o->spp_begin, nsp, n, 1.f / (float) o->spp, adj_img, out_img, h->d_counters); } while (0)
         switch (o->integrator) {
             case PSDR_INTEGRATOR_DIRECT: if (geo) PSDR_LAUNCH_REV(true, PSDR_INTEGRATOR_DIRECT); else PSDR_LAUNCH_REV(false, PSDR_INTEGRATOR_DIRECT); break;
             case PSDR_INTEGRATOR_PATH: if (geo) PSDR_LAUNCH_REV(true, PSDR_INTEGRATOR_PATH); else PSDR_LAUNCH_REV(false, PSDR_INTEGRATOR_PATH); break;
@@ -723,7 +733,13 @@ int render_rev(psdr_scene_s *h, const psdr_render_opts *o, const float *adj_img,
         if (int rc = make_ctx(h, o, 2, cx)) return rc;
         const long long i0 = WH * o->sppse_begin, n = WH * (o->sppse_end - o->sppse_begin);
         h->slots[2] += (uint64_t) n;
-        hipLaunchKernelGGL(k_secondary_edge_rev<FL>, dim3(launch_blocks(h, n)), dim3(kBlock), lds_bytes(cx, h), s, cx, sink, i0, n, 1.f / (float) o->sppse,
+        const int cache_bytes = sink_bytes(sink.L);
+        plan_lds(h, cx, cache_bytes);
+        cx.off_sink = lds_bytes(cx, h);
+        const int dyn_bytes = cx.off_sink + cache_bytes;
+        if (dyn_bytes > 48 * 1024)
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_secondary_edge_rev<FL>), hipFuncAttributeMaxDynamicSharedMemorySize, dyn_bytes));
+        hipLaunchKernelGGL(k_secondary_edge_rev<FL>, dim3(launch_blocks(h, n)), dim3(kBlock), dyn_bytes, s, cx, sink, i0, n, 1.f / (float) o->sppse,
                            adj_img, h->d_counters);
         HIP_TRY(hipGetLastError());
     }
