@@ -116,9 +116,14 @@ int launch_blocks(const psdr_scene_s *h, long long n) {
 // per CU) filled with the top of the BVH, then the leaf triangles, then the TriangleInfo rows.
 constexpr int kLdsBudget = 40 * 1024;
 int plan_lds(const psdr_scene_s *h, LaunchCtx &cx, int reserved) {
+    // the plain diffuse variant runs renderC at 5 workgroups per CU: 28 KB each (C4 PathTracer(3) 40.0 -> 37.6 ms,
+    // C3 3.26 -> 3.15 ms; 32 KB is already one workgroup less)
+    static const int forced = std::getenv("PSDR_LDS_BUDGET") ? std::atoi(std::getenv("PSDR_LDS_BUDGET")) : 0;
+    const bool lean = !h->has_rough && h->desc.env_emitter < 0;
+    const int budget = forced ? forced : (lean ? 28 * 1024 : kLdsBudget);
     const int stack_entries = std::min(kBvhStack, h->bvh_depth + 2);
     const int stack_bytes = stack_entries * kBlock * 4;
-    int room = std::max(0, kLdsBudget - reserved - stack_bytes);
+    int room = std::max(0, budget - reserved - stack_bytes);
     SceneView &sc = cx.sc;
     int off = 0;
     sc.n_lnodes = std::min(h->num_nodes, room / 64); sc.off_lnodes = off; off += sc.n_lnodes * 64; room -= sc.n_lnodes * 64;
