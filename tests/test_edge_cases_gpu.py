@@ -211,6 +211,28 @@ def test_tiny_scene_all_triangles_path_equals_the_tree_walk(monkeypatch):
         assert rel_l2(out["1"][2][k], out["0"][2][k]) < 1e-4, k
 
 
+def test_deep_paths_reverse_on_the_large_scene():
+    """PathTracer depth 4 and 8 in reverse mode on the ~50 k-triangle interior: traversal stacks + 8-vertex path
+    records + the gradient cache exceed the default 64 KB of dynamic LDS (hipFuncSetAttribute); dot-product
+    identity against forward mode; depth 9 is refused"""
+    from helpers import dot_tables, random_tangents
+    from psdr_cuda.fixtures import make_interior_scene
+    sc = make_interior_scene(seed=0, n_objects=10, res=48, spp=4); sc.configure()
+    tb = sc.tables(0)
+    g = GpuScene(tb)
+    adj = np.random.default_rng(0).random((48 * 48, 3)).astype(np.float32)
+    for depth in (4, 8):
+        o = _abi.make_opts(spp=4, integrator=_abi.INTEGRATOR_PATH, max_depth=depth)
+        for names in (["tri_info"], ["texels"]):
+            tan = random_tangents(tb, names, seed=3)
+            _, d = g.render_d_fwd(o, [tan])
+            _, grads = g.render_d_rev(o, adj, want=names, with_image=False)
+            lhs, rhs = float((adj.astype(np.float64) * d[0]).sum()), dot_tables(grads, tan)
+            assert abs(lhs - rhs) < 3e-3 * np.abs(adj * d[0]).sum(), (depth, names, lhs, rhs)
+    with pytest.raises(Exception, match="max_depth > 8"):
+        g.render_d_rev(_abi.make_opts(spp=4, integrator=_abi.INTEGRATOR_PATH, max_depth=9), adj, want=["texels"], with_image=False)
+
+
 @pytest.mark.parametrize("scene", ["cbox", "cbox_bunny"])
 def test_trace_respects_tmax(scene):
     """psdr_trace: hits with t in [RayEpsilon, tmax] only -- a tmax short of the wall misses, a generous one hits,
