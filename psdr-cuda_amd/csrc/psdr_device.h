@@ -132,6 +132,9 @@ PSDR_HD Hit closest_hit(const SceneView &sc, TraversalStack &st, const Vec3f &o,
     Hit best; best.tri = -1; best.u = best.v = -1.f;
     best.t = (tmax > 0.f && tmax < INFINITY) ? __int_as_float_hd(__float_as_int_hd(tmax) + 1) : tmax;   // accept t <= tmax
     if (sc.n_tiny > 0) {
+        // unrolled by 12 (six quads, the Cornell box): the scalar loads of the following triangles are in flight
+        // while one is tested (+3.5 % on C2; by 4: +2 %, by 6: the K = 3 kernel spills)
+#pragma unroll 12
         for (int i = 0; i < sc.n_tiny; ++i) leaf_triangle_test(sc.tiny[i * 3], sc.tiny[i * 3 + 1], sc.tiny[i * 3 + 2], o, d, best);
         return best;
     }
