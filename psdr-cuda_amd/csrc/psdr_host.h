@@ -128,7 +128,7 @@ constexpr int kRayCounters = 64, kRayCounterStride = 16;     // d_counters: 64 c
 
 namespace psdr_host {
 int fail(const std::string &m);
-int launch_blocks(const psdr_scene_s *h, long long n);
+int launch_blocks(const psdr_scene_s *h, long long n, int per_cu = 16);
 int plan_lds(const psdr_scene_s *h, LaunchCtx &cx, int reserved = 0);
 int lds_bytes(const LaunchCtx &cx, const psdr_scene_s *h);
 int make_ctx(psdr_scene_s *h, const psdr_render_opts *o, int sampler, LaunchCtx &cx);

@@ -561,7 +561,7 @@ int run_camera(psdr_scene_s *h, const psdr_render_opts *o, const TV<R, FL> &tv, 
     const long long n = WH * nsp;
     h->slots[0] += (uint64_t) n;
 #define PSDR_LAUNCH_CAMERA(INTEG)                                                                                                  \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_camera<G, R, INTEG, FL>), dim3(launch_blocks(h, n)), dim3(kBlock), lds_bytes(cx, h), s, cx, tv, o->spp, \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_camera<G, R, INTEG, FL>), dim3(launch_blocks(h, n, h->has_rough ? 16 : 40)), dim3(kBlock), lds_bytes(cx, h), s, cx, tv, o->spp, \
                        o->spp_begin, nsp, n, 1.f / (float) o->spp, img, dimg, WH * 3, h->d_counters)
     switch (o->integrator) {
         case PSDR_INTEGRATOR_DIRECT: PSDR_LAUNCH_CAMERA(PSDR_INTEGRATOR_DIRECT); break;
