@@ -106,10 +106,9 @@ thread_local std::string g_err;
 namespace psdr_host {
 int fail(const std::string &m) { g_err = m; return 1; }
 
-// Grid of the grid-stride kernels: at most per_cu workgroups per CU.  The forward camera kernels take 40 (samples
-// of different image regions cost differently, finer workgroups balance better: C2 +4.5 %, C4 PathTracer(3) shard
-// 37.4 -> 34.0 ms, C3 3.16 -> 2.95 ms); the reverse kernels zero and flush a gradient cache per workgroup and
-// are 3-6 % faster at 16, as are the launches of the rough-conductor variants that stage 40 KB per workgroup.
+// Grid of the grid-stride kernels: at most per_cu workgroups per CU (16 by default; the forward camera kernels
+// choose theirs, psdr_kernels.h camera_blocks_per_cu; the reverse kernels zero and flush a gradient cache per
+// workgroup and are flat between 8 and 24).
 int launch_blocks(const psdr_scene_s *h, long long n, int per_cu) {
     static const int forced = std::getenv("PSDR_BLOCKS_PER_CU") ? std::atoi(std::getenv("PSDR_BLOCKS_PER_CU")) : 0;
     const long long need = (n + kBlock - 1) / kBlock;

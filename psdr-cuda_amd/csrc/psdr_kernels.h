@@ -551,6 +551,16 @@ __global__ __launch_bounds__(kBlock) void k_secondary_edge_rev(LaunchCtx cx, Dev
 
 
 // ============================================================================ launch drivers
+// Grid of the forward camera kernels: finer workgroups balance image regions of different cost better (C2 +4.5 %,
+// C4 PathTracer(3) shard 37.4 -> 34.2 ms at 40 per CU instead of 16), but every workgroup stages its share of the
+// scene in LDS first: on a 4 M-slot launch of an open scene (bunny_light) 40 per CU is 9-15 % SLOWER.  So: 40 when
+// nothing is staged (tiny scene) or when a workgroup still makes >= 8 trips of its grid-stride loop, else 16.
+inline int camera_blocks_per_cu(const psdr_scene_s *h, long long n) {
+    if (h->has_rough) return 16;
+    if (h->n_tiny > 0) return 40;
+    const long long fit = n / ((long long) kBlock * h->num_cus * 8);
+    return (int) std::max(16LL, std::min(40LL, fit));
+}
 template <class G, class R, int FL>
 int run_camera(psdr_scene_s *h, const psdr_render_opts *o, const TV<R, FL> &tv, float *img, float *dimg, hipStream_t s) {
     const long long WH = (long long) h->desc.width * h->desc.height;
@@ -561,7 +571,7 @@ int run_camera(psdr_scene_s *h, const psdr_render_opts *o, const TV<R, FL> &tv, 
     const long long n = WH * nsp;
     h->slots[0] += (uint64_t) n;
 #define PSDR_LAUNCH_CAMERA(INTEG)                                                                                                  \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_camera<G, R, INTEG, FL>), dim3(launch_blocks(h, n, h->has_rough ? 16 : 40)), dim3(kBlock), lds_bytes(cx, h), s, cx, tv, o->spp, \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_camera<G, R, INTEG, FL>), dim3(launch_blocks(h, n, camera_blocks_per_cu(h, n))), dim3(kBlock), lds_bytes(cx, h), s, cx, tv, o->spp, \
                        o->spp_begin, nsp, n, 1.f / (float) o->spp, img, dimg, WH * 3, h->d_counters)
     switch (o->integrator) {
         case PSDR_INTEGRATOR_DIRECT: PSDR_LAUNCH_CAMERA(PSDR_INTEGRATOR_DIRECT); break;
@@ -589,7 +599,7 @@ int run_camera_wavefront(psdr_scene_s *h, const psdr_render_opts *o, const TV<M,
     const int depth = o->max_depth;
     const size_t words = 8 + 3 * (1 + K);
     // sub-streams: block b appends to sub-stream b % kWfSub, at most ceil(blocks / kWfSub) * trips * kBlock records each
-    const long long max_blocks = ((long long) h->num_cus * 16 + kWfSub - 1) / kWfSub * kWfSub;
+    const long long max_blocks = ((long long) launch_blocks(h, cap) + kWfSub - 1) / kWfSub * kWfSub;   // >= the grid of any chunk
     const long long cap_alloc = cap + max_blocks * kBlock;
     const size_t cnt_bytes = (size_t) kWfMaxDepth * kWfSub * kWfCountStride * sizeof(int32_t);
     const size_t need = 2 * words * 4 * (size_t) cap_alloc + cnt_bytes;
