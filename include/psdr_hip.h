@@ -101,7 +101,7 @@ typedef struct psdr_scene_desc {
     int32_t num_tris, num_meshes, num_bsdfs, num_emitters;
     int32_t num_sec_edges, num_prim_edges, num_texels, num_guide_cells;
 
-    const float   *tri_info;             /* [T][PSDR_TRI_STRIDE]   scene.cpp:205-216 */
+    const float   *tri_info;             /* [T][PSDR_TRI_STRIDE]   scene.cpp:205-216; MUST be 16-byte aligned (rows are staged as float4) */
     const float   *tri_uv;               /* [T][PSDR_TRIUV_STRIDE] or NULL (all zero) */
     const int32_t *tri_mesh;             /* [T] */
     const int32_t *mesh_bsdf;            /* [M] bsdf id (Mesh::m_bsdf); -1 = the bounding mesh of the
@@ -152,7 +152,7 @@ typedef struct psdr_scene_desc {
 typedef struct psdr_render_opts {
     int32_t integrator;                  /* PSDR_INTEGRATOR_* */
     int32_t bsdf_samples, light_samples; /* DirectIntegrator ctor, direct.cpp:32-34 */
-    int32_t max_depth;                   /* PathTracer */
+    int32_t max_depth;                   /* PathTracer; psdr_render_d_rev supports max_depth <= 8 (per-lane path record in LDS) */
     int32_t hide_emitters;               /* DirectIntegrator::m_hide_emitters */
     int32_t field;                       /* PSDR_FIELD_* */
     int32_t spp, sppe, sppse;            /* GLOBAL counts: normalisation + RNG stream index */

@@ -15,14 +15,44 @@ from psdr_cuda import _abi  # noqa: E402
 from psdr_cuda.scene import make_desc  # noqa: E402
 
 
+ORACLE_LIB_PATH = os.path.join(_HERE, "libpsdr_oracle.so")
+_oracle = None
+
+
 def build():
     subprocess.check_call(["make", "-C", _HERE, "-s"])
 
 
+def load_oracle():
+    """Load oracle/libpsdr_oracle.so (tests / smoke / cpu_baseline only; the product package has no
+    reference to it)."""
+    global _oracle
+    if _oracle is not None:
+        return _oracle
+    if not os.path.exists(ORACLE_LIB_PATH):
+        raise RuntimeError("oracle not built: run `make -C oracle`")
+    L = C.CDLL(ORACLE_LIB_PATH)
+    vp, i32 = C.c_void_p, C.c_int32
+    SceneDesc, RenderOpts, Tangents = _abi.SceneDesc, _abi.RenderOpts, _abi.Tangents
+    L.psdr_oracle_last_error.restype = C.c_char_p
+    L.psdr_oracle_trace.argtypes = [C.POINTER(SceneDesc), i32] + [vp] * 7 + [vp] * 4
+    L.psdr_oracle_render.argtypes = [C.POINTER(SceneDesc), C.POINTER(RenderOpts), i32, C.POINTER(Tangents), vp, vp,
+                                     i32, i32]
+    L.psdr_oracle_guide_build.argtypes = [C.POINTER(SceneDesc), C.POINTER(RenderOpts), C.POINTER(i32), i32, vp, i32]
+    L.psdr_oracle_rng.argtypes = [C.c_uint64, C.c_uint64, i32, vp]
+    L.psdr_oracle_pcg32_raw.argtypes = [C.c_uint64, C.c_uint64, i32, vp]
+    L.psdr_oracle_sample_reuse.argtypes = [vp, vp, C.c_float, i32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.psdr_oracle_sample_reuse.restype = i32
+    L.psdr_oracle_draws_per_camera_sample.argtypes = [C.POINTER(RenderOpts)]
+    L.psdr_oracle_draws_per_camera_sample.restype = i32
+    _oracle = L
+    return L
+
+
 def lib():
-    if not os.path.exists(_abi.ORACLE_LIB_PATH):
+    if not os.path.exists(ORACLE_LIB_PATH):
         build()
-    return _abi.load_oracle()
+    return load_oracle()
 
 
 def _cpu_tables(tb):

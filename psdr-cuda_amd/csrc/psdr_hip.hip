@@ -199,6 +199,7 @@ SinkLayout make_sink_layout(const psdr_scene_s *h, const psdr_grads *g) {
 }
 
 int begin_call(psdr_scene_s *h, hipStream_t s) {
+    h->last_stream = s;
     h->slots[0] = h->slots[1] = h->slots[2] = 0; h->last_path_depth = 0;
     HIP_TRY(hipMemsetAsync(h->d_counters, 0, sizeof(unsigned long long) * kRayCounters * kRayCounterStride, s));
     return 0;
@@ -259,7 +260,10 @@ int psdr_scene_create(psdr_scene_t *out) {
     hipError_t e = hipMalloc(&h->d_counters, sizeof(unsigned long long) * kRayCounters * kRayCounterStride);
     if (e != hipSuccess) { delete h; return fail(std::string("hipMalloc: ") + hipGetErrorString(e)); }
     int dev = 0; hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) h->num_cus = prop.multiProcessorCount;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) {
+        h->num_cus = prop.multiProcessorCount;
+        h->lds_limit = (int) std::min<size_t>(prop.sharedMemPerBlock, 160 * 1024);
+    }
     if (const char *e2 = std::getenv("PSDR_BVH_REFIT")) h->refit_enabled = std::atoi(e2) != 0;      // 0: always rebuild on the host
     if (const char *e4 = std::getenv("PSDR_TINY_SCENE")) h->tiny_enabled = std::atoi(e4) != 0;      // 0: walk the tree even for <= 16 triangles
     if (const char *e3 = std::getenv("PSDR_SORT_EDGES")) h->sort_edges = std::atoi(e3) != 0;        // 0: primary-edge slots in natural order
@@ -283,19 +287,30 @@ int psdr_scene_destroy(psdr_scene_t h) {
 
 int psdr_scene_set_tables(psdr_scene_t h, const psdr_scene_desc *desc) {
     if (!h || !desc) return fail("psdr_scene_set_tables: null argument");
-    if (desc->num_tris <= 0 || !desc->tri_info || !desc->tri_mesh) return fail("Missing meshes!");
-    if (!desc->cam) return fail("Missing sensor!");
-    if (h->have_tables && (desc->tri_info != h->desc.tri_info || desc->num_tris != h->desc.num_tris)) h->have_bvh = false;
-    h->desc = *desc;
+    // validate a local copy; the handle keeps its previous tables when the call fails
+    psdr_scene_desc d = *desc;
+    if (d.num_tris <= 0 || !d.tri_info || !d.tri_mesh) return fail("Missing meshes!");
+    if (!d.cam) return fail("Missing sensor!");
+    if (reinterpret_cast<uintptr_t>(d.tri_info) & 15) return fail("psdr_scene_set_tables: tri_info must be 16-byte aligned");
+    if (d.width <= 0 || d.height <= 0) return fail("Invalid film resolution");
+    if (d.num_meshes <= 0 || !d.mesh_bsdf || !d.mesh_emitter) return fail("psdr_scene_set_tables: mesh_bsdf / mesh_emitter missing");
+    if (d.num_bsdfs > 0 && (!d.bsdf_rec || !d.texels)) return fail("psdr_scene_set_tables: bsdf_rec / texels missing");
+    if (d.num_emitters > 0 && (!d.emitter_f || !d.emitter_i)) return fail("psdr_scene_set_tables: emitter tables missing");
+    if (d.num_emitters > 1 && (!d.emitter_cmf || !d.emitter_pmf)) return fail("psdr_scene_set_tables: emitter distribution missing");
+    if (d.num_sec_edges > 0 && (!d.sec_edge || !d.sec_cmf || !d.sec_pmf)) return fail("psdr_scene_set_tables: secondary-edge tables missing");
+    if (d.num_prim_edges > 0 && (!d.prim_edge || !d.prim_cmf || !d.prim_pmf)) return fail("psdr_scene_set_tables: primary-edge tables missing");
+    if (d.num_guide_cells > 0 && (!d.guide_cmf || !d.guide_pmf)) return fail("psdr_scene_set_tables: guiding tables missing");
     // no environment map unless its record is given (a zero-initialised desc means "none")
-    if (!h->desc.env_f) h->desc.env_emitter = -1;
-    // material_mask = 0: unknown -> serve every BSDF type
-    h->has_rough = h->desc.material_mask == 0 || (h->desc.material_mask & (1u << PSDR_BSDF_ROUGHCONDUCTOR)) != 0;
-    if (h->desc.env_emitter >= 0) {
-        if (h->desc.env_emitter >= h->desc.num_emitters || !h->desc.env_cmf || !h->desc.env_pmf || h->desc.env_reso[0] <= 0 ||
-            h->desc.env_reso[1] <= 0 || h->desc.env_tex[1] < 2 || h->desc.env_tex[2] < 2)
+    if (!d.env_f) d.env_emitter = -1;
+    if (d.env_emitter >= 0) {
+        if (d.env_emitter >= d.num_emitters || !d.env_cmf || !d.env_pmf || d.env_reso[0] <= 0 || d.env_reso[1] <= 0 || d.env_tex[1] < 2 ||
+            d.env_tex[2] < 2)
             return fail("psdr_scene_set_tables: inconsistent environment-map record");
     }
+    if (h->have_tables && (d.tri_info != h->desc.tri_info || d.num_tris != h->desc.num_tris)) h->have_bvh = false;
+    h->desc = d;
+    // material_mask = 0: unknown -> serve every BSDF type
+    h->has_rough = d.material_mask == 0 || (d.material_mask & (1u << PSDR_BSDF_ROUGHCONDUCTOR)) != 0;
     h->have_tables = true;
     return 0;
 }
@@ -308,8 +323,12 @@ int psdr_bvh_build(psdr_scene_t h, void *stream) {
     const bool tiny = h->tiny_enabled && T <= kTinyTris;        // the triangles travel in the kernel arguments: host copy needed
     if (h->refit_enabled && !tiny && h->tree_tris == T && h->num_nodes > 0 && h->refits_since_build < kMaxRefits) {
         float prev_area = h->built_area;
-        if (h->refits_since_build > 0) HIP_TRY(hipMemcpy(&prev_area, h->d_refit_area, sizeof(float), hipMemcpyDeviceToHost));   // of the PREVIOUS refit: done long ago
+        if (h->refits_since_build > 0) {        // of the PREVIOUS refit (done long ago), read on the stream that wrote it
+            HIP_TRY(hipMemcpyAsync(&prev_area, h->d_refit_area, sizeof(float), hipMemcpyDeviceToHost, h->refit_stream));
+            HIP_TRY(hipStreamSynchronize(h->refit_stream));
+        }
         if (prev_area <= kRefitAreaGrowth * h->built_area) {
+            h->refit_stream = s;
             HIP_TRY(hipMemsetAsync(h->d_refit_area, 0, sizeof(float), s));
             hipLaunchKernelGGL(k_refit_leaves, dim3((h->num_btris + kBlock - 1) / kBlock), dim3(kBlock), 0, s, h->d_btris, h->desc.tri_info, h->num_btris);
             for (int l = (int) h->level_start.size() - 2; l >= 0; --l) {
@@ -442,7 +461,9 @@ int psdr_render_d_rev(psdr_scene_t h, const psdr_render_opts *o, const float *ad
     if (!h || !o || !adj_img || !grads) return fail("psdr_render_d_rev: null argument");
     if (!h->have_tables) return fail("Scene not loaded yet!");
     if (int rc = check_counts(h, o)) return rc;
-    if (o->integrator == PSDR_INTEGRATOR_PATH && o->max_depth > kMaxRevDepth) return fail("psdr_render_d_rev: max_depth > 8 is not supported");
+    if (o->integrator == PSDR_INTEGRATOR_PATH && o->max_depth > kMaxRevDepth)
+        return fail("psdr_render_d_rev: PathTracer max_depth > 8 is not supported in reverse mode (the per-lane path record lives in LDS: "
+                    "8 KB per depth level and workgroup); use forward mode (psdr_render_d_fwd) for deeper paths");
     hipStream_t s = (hipStream_t) stream;
     if (int rc = begin_call(h, s)) return rc;
     return variant_of(h)->render_rev(h, o, adj_img, out_img, grads, s);
@@ -473,7 +494,10 @@ int psdr_bvh_stats(psdr_scene_t h, int32_t out[4]) {
 int psdr_get_counters(psdr_scene_t h, uint64_t out[4]) {
     if (!h || !out) return fail("psdr_get_counters: null argument");
     unsigned long long all[kRayCounters * kRayCounterStride], c[1] = {0};
-    HIP_TRY(hipMemcpy(all, h->d_counters, sizeof(all), hipMemcpyDeviceToHost));
+    // ordered behind the launches of the last render call on ITS stream (a blocking null-stream copy is not
+    // ordered against a non-blocking caller stream)
+    HIP_TRY(hipMemcpyAsync(all, h->d_counters, sizeof(all), hipMemcpyDeviceToHost, h->last_stream));
+    HIP_TRY(hipStreamSynchronize(h->last_stream));
     for (int i = 0; i < kRayCounters; ++i) c[0] += all[i * kRayCounterStride];
     out[0] = c[0]; out[1] = h->slots[0]; out[2] = h->slots[1]; out[3] = h->slots[2];
     if (h->last_path_depth > 0 && h->slots[0] > 0 && h->slots[1] == 0 && h->slots[2] == 0)

@@ -82,6 +82,7 @@ struct psdr_scene_s {
     bool have_tables = false;
     bool has_rough = true;                 // a RoughConductor may be present (desc.material_mask)
     int num_cus = 256;
+    int lds_limit = 64 * 1024;             // hipDeviceProp_t::sharedMemPerBlock (160 KB on gfx950)
 
     // BVH on the device (psdr_bvh_build)
     BvhNode *d_nodes = nullptr;
@@ -104,6 +105,8 @@ struct psdr_scene_s {
 
     // counters of the last render call (psdr_get_counters)
     unsigned long long *d_counters = nullptr;
+    hipStream_t last_stream = nullptr;     // stream of the last render call (psdr_get_counters reads behind it)
+    hipStream_t refit_stream = nullptr;    // stream of the last device refit
     uint64_t slots[3] = {0, 0, 0};
     int last_path_depth = 0;
     float path_survival = -1.f;            // rays traced / rays of fully surviving paths (last PathTracer call)

@@ -704,6 +704,8 @@ int render_rev(psdr_scene_s *h, const psdr_render_opts *o, const float *adj_img,
         cx.off_pathrec = lds_bytes(cx, h);
         cx.off_sink = cx.off_pathrec + rec_bytes;
         const int dyn_bytes = cx.off_sink + cache_bytes;
+        if (dyn_bytes > h->lds_limit) return fail("psdr_render_d_rev: the launch needs " + std::to_string(dyn_bytes) + " bytes of LDS per workgroup (path record of " +
+                                                  std::to_string(depth) + " levels + traversal stacks + gradient cache), the device offers " + std::to_string(h->lds_limit));
         // material-only gradients (no triangle / camera table wanted) run the variant without the geometric adjoints;
         // the integrator is a compile-time parameter as in the forward kernels (direct: no path record / replay loop)
         const bool geo = grads->g_tri_info != nullptr || grads->g_cam_to_world != nullptr;

@@ -1,10 +1,8 @@
-"""ctypes mirror of include/psdr_hip.h and the loaders for the two libraries that implement it.
+"""ctypes mirror of include/psdr_hip.h and the loader of the library that implements it.
 
-* ``load_hip()``    -> libpsdr_hip.so, the product (HIP/gfx950 kernels).  Fails loudly when the
-                       library is missing; there is NO CPU fallback in the product path.
-* ``load_oracle()`` -> oracle/libpsdr_oracle.so, the CPU restatement.  Test infrastructure only:
-                       may be imported from tests/, __graft_entry__.smoke() and bench.py's
-                       cpu_baseline leg, never from the render path.
+``load_hip()`` -> libpsdr_hip.so, the product (HIP/gfx950 kernels).  Fails loudly when the library is
+missing; there is NO CPU fallback in the product path.  (The CPU oracle has its own loader in
+oracle/oracle.py: test infrastructure, not part of this package.)
 """
 import ctypes as C
 import os
@@ -88,10 +86,8 @@ HIP_SYMBOLS = (
 )
 
 HIP_LIB_PATH = os.environ.get("PSDR_HIP_LIB") or os.path.join(PKG_ROOT, "lib", "libpsdr_hip.so")   # env override: kernel A/B experiments
-ORACLE_LIB_PATH = os.path.join(REPO_ROOT, "oracle", "libpsdr_oracle.so")
 
 _hip = None
-_oracle = None
 
 
 def load_hip():
@@ -132,30 +128,6 @@ def check(lib, rc):
     if rc != 0:
         msg = lib.psdr_last_error()
         raise RuntimeError(msg.decode() if msg else "psdr_hip call failed (rc=%d)" % rc)
-
-
-def load_oracle():
-    """Load the CPU oracle (tests / smoke / cpu_baseline only)."""
-    global _oracle
-    if _oracle is not None:
-        return _oracle
-    if not os.path.exists(ORACLE_LIB_PATH):
-        raise RuntimeError("oracle not built: run `make -C oracle`")
-    lib = C.CDLL(ORACLE_LIB_PATH)
-    vp, i32 = C.c_void_p, C.c_int32
-    lib.psdr_oracle_last_error.restype = C.c_char_p
-    lib.psdr_oracle_trace.argtypes = [C.POINTER(SceneDesc), i32] + [vp] * 7 + [vp] * 4
-    lib.psdr_oracle_render.argtypes = [C.POINTER(SceneDesc), C.POINTER(RenderOpts), i32, C.POINTER(Tangents), vp, vp,
-                                       i32, i32]
-    lib.psdr_oracle_guide_build.argtypes = [C.POINTER(SceneDesc), C.POINTER(RenderOpts), C.POINTER(i32), i32, vp, i32]
-    lib.psdr_oracle_rng.argtypes = [C.c_uint64, C.c_uint64, i32, vp]
-    lib.psdr_oracle_pcg32_raw.argtypes = [C.c_uint64, C.c_uint64, i32, vp]
-    lib.psdr_oracle_sample_reuse.argtypes = [vp, vp, C.c_float, i32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
-    lib.psdr_oracle_sample_reuse.restype = i32
-    lib.psdr_oracle_draws_per_camera_sample.argtypes = [C.POINTER(RenderOpts)]
-    lib.psdr_oracle_draws_per_camera_sample.restype = i32
-    _oracle = lib
-    return lib
 
 
 def make_opts(integrator=INTEGRATOR_DIRECT, bsdf_samples=1, light_samples=1, max_depth=1, hide_emitters=False,

@@ -124,9 +124,13 @@ class Integrator(Object):
             scene._native = h
         desc, keep = make_desc(tb, guide)
         _abi.check(lib, lib.psdr_scene_set_tables(scene._native, C.byref(desc)))
-        if getattr(scene, "_bvh_version", -1) != scene._version:
+        # the tree on the handle belongs to ONE set of tables: rebuild / refit whenever the tables submitted now are
+        # not the ones it was built for (a renderD result differentiated after a later configure() brings its own,
+        # older tables back -- and the next render call the newer ones again)
+        stamp = tb.get("version", scene._version)
+        if getattr(scene, "_bvh_version", None) != stamp:
             _abi.check(lib, lib.psdr_bvh_build(scene._native, _stream_ptr()))
-            scene._bvh_version = scene._version
+            scene._bvh_version = stamp
         return lib, keep
 
     def _render_c(self, scene, tb, opts, guide, interior_only=False):

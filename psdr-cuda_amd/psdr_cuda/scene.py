@@ -1132,10 +1132,11 @@ class Scene(Object):
             tb.update(sec_edge=se, sec_cmf=sd.m_cmf, sec_pmf=sd.m_pmf, sec_sum=sd.m_sum, num_sec_edges=int(se.shape[0]))
         else:
             tb.update(sec_edge=None, sec_cmf=None, sec_pmf=None, sec_sum=0.0, num_sec_edges=0)
-        self._tables = tb
         self._version += 1
+        tb["version"] = self._version          # stamps the tables: the BVH on the native handle is tied to it (Integrator._prepare)
+        self._tables = tb
         self._configured = True
-        self._bvh_version = -1
+        self._bvh_version = None
         if o.log_level > 0:
             self.log("AABB: [lower = %s, upper = %s]" % (self.m_lower.tolist(), self.m_upper.tolist()))
             if o.sppe > 0:
