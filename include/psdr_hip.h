@@ -138,6 +138,13 @@ typedef struct psdr_scene_desc {
        an all-diffuse scene runs the kernel variant compiled without the GGX / conductor-Fresnel code.
        Bits that are clear MUST be right: a cleared type is evaluated as diffuse. */
     uint32_t       material_mask;
+    /* [E][2] global triangle ids of the one or two faces adjacent to every secondary edge (second = -1 on a
+       boundary edge), or NULL.  Not in the reference's SecondaryEdgeInfo (edge.h:27-65): the two rays that
+       eval_secondary_edge (direct.cpp:246-254) starts ON the edge cannot hit these faces again in exact
+       arithmetic (a line meets a plane once, at the edge point); in fp32 the rounded edge point lets a grazing
+       ray re-hit them just above RayEpsilon -- ~3e-3 of the boundary term.  With the table the two rays skip
+       the adjacent faces; without it they are traced as the reference does. */
+    const int32_t *sec_edge_faces;
 } psdr_scene_desc;
 
 /* psdr_render_opts.flags: execution strategy of the PathTracer interior term.

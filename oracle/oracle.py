@@ -45,6 +45,8 @@ def load_oracle():
     L.psdr_oracle_sample_reuse.restype = i32
     L.psdr_oracle_draws_per_camera_sample.argtypes = [C.POINTER(RenderOpts)]
     L.psdr_oracle_draws_per_camera_sample.restype = i32
+    L.psdr_oracle_set_reference_form.argtypes = [i32]
+    L.psdr_oracle_set_reference_form.restype = None
     _oracle = L
     return L
 
@@ -59,10 +61,14 @@ def _cpu_tables(tb):
     return {k: (v.detach().cpu() if isinstance(v, torch.Tensor) else v) for k, v in tb.items()}
 
 
-def render(tb, opts, mode=0, tangents=None, guide=None, precision=0, nthreads=None):
+def render(tb, opts, mode=0, tangents=None, guide=None, precision=0, nthreads=None, reference_form=False):
     """mode 0: renderC -> img [H*W,3]; mode 1: renderD forward -> (img, dimg).
-    tangents: dict name -> tensor (names of _abi.TANGENT_FIELDS)."""
+    tangents: dict name -> tensor (names of _abi.TANGENT_FIELDS).
+    reference_form: evaluate the reference's literal expressions (p = ray(t) for the solid-angle hit, edge rays that
+    may re-hit the faces adjacent to their edge) instead of the fp32-robust forms the product uses; identical in
+    exact arithmetic (psdr_oracle.cpp g_reference_form)."""
     L = lib()
+    L.psdr_oracle_set_reference_form(1 if reference_form else 0)
     tb = _cpu_tables(tb)
     if guide is not None:
         guide = (guide[0], guide[1].cpu(), guide[2].cpu(), guide[3])

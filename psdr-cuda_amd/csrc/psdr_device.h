@@ -107,7 +107,9 @@ PSDR_HD Hit hit_on_triangle(int tri, const Vec3f &p0, const Vec3f &e1, const Vec
 // Moeller-Trumbore on one leaf triangle (p0 | id, e1, e2); keeps the closer hit in `best` (the OptiX built-in
 // triangle test is closed source).  A precomputed plane form (18 FMAs) was measured: no faster in the tree
 // walk (latency-, not ALU-bound) and less accurate.
-PSDR_HD void leaf_triangle_test(const float4 &a, const float4 &b, const float4 &c, const Vec3f &o, const Vec3f &d, Hit &best) {
+// IGN: skip the triangles ig0 / ig1 (the faces adjacent to a secondary edge, for the rays that start ON that edge).
+template <bool IGN = false>
+PSDR_HD void leaf_triangle_test(const float4 &a, const float4 &b, const float4 &c, const Vec3f &o, const Vec3f &d, Hit &best, int ig0 = -1, int ig1 = -1) {
     const Vec3f e1{b.x, b.y, b.z}, e2{c.x, c.y, c.z};
     const Vec3f h = cross(d, e2);
     const float det = dot(e1, h);
@@ -121,21 +123,22 @@ PSDR_HD void leaf_triangle_test(const float4 &a, const float4 &b, const float4 &
     // below fails), and v >= 0 with u + v <= 1 gives u <= 1 in floating point too (fl(u + v) >= u)
     // closest_hit starts from the open upper bound next_above(tmax), so "t <= tmax, the first of equal hits wins"
     // is the single strict comparison t < best.t
-    if (u >= 0.f && v >= 0.f && u + v <= 1.f && t >= kRayEpsilon && t < best.t) {
-        best.t = t; best.u = u; best.v = v; best.tri = __float_as_int_hd(a.w);
-    }
+    bool hit = u >= 0.f && v >= 0.f && u + v <= 1.f && t >= kRayEpsilon && t < best.t;
+    if (IGN) { const int id = __float_as_int_hd(a.w); hit = hit && id != ig0 && id != ig1; }
+    if (hit) { best.t = t; best.u = u; best.v = v; best.tri = __float_as_int_hd(a.w); }
 }
 
 // Replaces __raygen__/__closesthit__/__miss__ (cuda/psdr_cuda.cu:9-45): closest hit with
 // t in [RayEpsilon, tmax], both faces; (u,v) = barycentric weights of vertex 1 and 2.
-PSDR_HD Hit closest_hit(const SceneView &sc, TraversalStack &st, const Vec3f &o, const Vec3f &d, float tmax) {
+template <bool IGN = false>
+PSDR_HD Hit closest_hit(const SceneView &sc, TraversalStack &st, const Vec3f &o, const Vec3f &d, float tmax, int ig0 = -1, int ig1 = -1) {
     Hit best; best.tri = -1; best.u = best.v = -1.f;
     best.t = (tmax > 0.f && tmax < INFINITY) ? __int_as_float_hd(__float_as_int_hd(tmax) + 1) : tmax;   // accept t <= tmax
     if (sc.n_tiny > 0) {
         // unrolled by 12 (six quads, the Cornell box): the scalar loads of the following triangles are in flight
         // while one is tested (+3.5 % on C2; by 4: +2 %, by 6: the K = 3 kernel spills)
 #pragma unroll 12
-        for (int i = 0; i < sc.n_tiny; ++i) leaf_triangle_test(sc.tiny[i * 3], sc.tiny[i * 3 + 1], sc.tiny[i * 3 + 2], o, d, best);
+        for (int i = 0; i < sc.n_tiny; ++i) leaf_triangle_test<IGN>(sc.tiny[i * 3], sc.tiny[i * 3 + 1], sc.tiny[i * 3 + 2], o, d, best, ig0, ig1);
         return best;
     }
     const Vec3f inv{1.f / d.x, 1.f / d.y, 1.f / d.z};
@@ -179,7 +182,7 @@ PSDR_HD Hit closest_hit(const SceneView &sc, TraversalStack &st, const Vec3f &o,
                 else
 #endif
                 { a = sc.btris[(first + i) * 3]; b = sc.btris[(first + i) * 3 + 1]; c = sc.btris[(first + i) * 3 + 2]; }
-                leaf_triangle_test(a, b, c, o, d, best);
+                leaf_triangle_test<IGN>(a, b, c, o, d, best, ig0, ig1);
             }
             cur = sp > 0 ? st.get(--sp) : kDone;
         }
@@ -283,13 +286,15 @@ enum HitForm { kDetached = 0, kPathSpace = 1, kSolidAngle = 2 };
 //   kDetached  : C types; barycentrics from the traversal, J = 1
 //   kPathSpace : D types, barycentrics DETACHED (point rides on the moving triangle), J = A/detach(A)
 //   kSolidAngle: D types, differentiable Moeller-Trumbore on the chosen triangle, J = 1
+// ig0 / ig1 >= 0: triangles the ray must not hit (rays that start on a secondary edge, psdr_scene_desc::sec_edge_faces).
 template <class R, class TVT> PSDR_HD Its<R> intersect(const SceneView &sc, const TVT &tv, TraversalStack &st, const RayT<R> &ray,
-                                                       bool active, HitForm form, uint32_t &nrays) {
+                                                       bool active, HitForm form, uint32_t &nrays, int ig0 = -1, int ig1 = -1) {
     Its<R> its;
     its.valid = false; its.tri = its.mesh = -1; its.J = R(1.f); its.t = R(INFINITY);
     if (!active) return its;
     nrays++;
-    const Hit h = closest_hit(sc, st, val(ray.o), val(ray.d), INFINITY);
+    const Hit h = (ig0 >= 0 || ig1 >= 0) ? closest_hit<true>(sc, st, val(ray.o), val(ray.d), INFINITY, ig0, ig1)
+                                         : closest_hit<false>(sc, st, val(ray.o), val(ray.d), INFINITY);
     if (h.tri < 0) return its;
     its.valid = true; its.tri = h.tri; its.hu = h.u; its.hv = h.v;
     const int tm = sc.d.tri_mesh[h.tri];
@@ -311,7 +316,12 @@ template <class R, class TVT> PSDR_HD Its<R> intersect(const SceneView &sc, cons
         R t;
         moeller_trumbore(T.p0, T.e1, T.e2, ray, bu, bv, t);
         Vec3<R> sh_n = (tm & PSDR_TRI_FACE_NORMALS) ? its.n : normalize(bary_point(T.n0, T.n1 - T.n0, T.n2 - T.n0, bu, bv));
-        its.p = ray.o + ray.d * t;
+        // The reference writes p = ray(t) (scene.cpp:368).  Same point, same derivative, evaluated ON the triangle:
+        // o + t d sits up to |o - p| * 2^-22 off the surface (4e-4 at the bunny scenes' 400 units), and a grazing
+        // continuation ray that starts below it re-hits its own face above RayEpsilon = 1e-3 -- a one-sided loss of
+        // ~2e-3 of the interior gradient in ANY fp32 evaluation of the literal form (fp32 against fp64,
+        // tests/test_projections_gpu.py); with the point on the surface fp32 agrees with fp64 to ~1e-4.
+        its.p = bary_point(T.p0, T.e1, T.e2, bu, bv);
         its.t = t;
         its.sh = Frame<R>(sh_n);
         its.wi = its.sh.to_local(-ray.d);
@@ -892,6 +902,41 @@ PSDR_HD int primary_edge_sample(const SceneView &sc, const TangentView<K, FL> &t
     return iy * W + ix;
 }
 
+// |x1 - p1| with x1 = where the camera ray through the film projection of p1 meets the plane of triangle `tri`
+// (perspective.cpp:139-155, then :120-136, then utils.h:66-77), p1 = point (hu, hv) of triangle tri_c, in DOUBLE from the fp32 tables: the visibility test of
+// eval_secondary_edge (direct.cpp:262).  ~100 fp64 operations for the ~1.5 % of the boundary samples that get here.
+PSDR_HD double camera_return_distance(const SceneView &sc, int tri_c, float hu, float hv, int tri) {
+    const float *cam = sc.d.cam;
+    const float *w2s = cam + PSDR_CAM_WORLD_TO_SAMPLE, *s2c = cam + PSDR_CAM_SAMPLE_TO_CAMERA, *tw = cam + PSDR_CAM_TO_WORLD;
+    // p1 rebuilt ON its triangle in double from the traversal barycentrics: an fp32 p1 sits up to 5e-5 off the plane,
+    // which a grazing camera ray turns into |x1 - p1| ~ 1e-3
+    const float *rc = sc.d.tri_info + (size_t) tri_c * PSDR_TRI_STRIDE;
+    const double px = (double) rc[0] + (double) hu * rc[3] + (double) hv * rc[6], py = (double) rc[1] + (double) hu * rc[4] + (double) hv * rc[7],
+                 pz = (double) rc[2] + (double) hu * rc[5] + (double) hv * rc[8];
+    double v[4], c[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = (double) w2s[r * 4] * px + (double) w2s[r * 4 + 1] * py + (double) w2s[r * 4 + 2] * pz + (double) w2s[r * 4 + 3];
+    const double qx = v[0] / v[3], qy = v[1] / v[3];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) c[r] = (double) s2c[r * 4] * qx + (double) s2c[r * 4 + 1] * qy + (double) s2c[r * 4 + 3];
+    double dx = c[0] / c[3], dy = c[1] / c[3], dz = c[2] / c[3];
+    const double inv = 1.0 / sqrt(dx * dx + dy * dy + dz * dz);
+    dx *= inv; dy *= inv; dz *= inv;
+    const double w = tw[15];
+    const double o[3] = {tw[3] / w, tw[7] / w, tw[11] / w};
+    const double d[3] = {tw[0] * dx + tw[1] * dy + tw[2] * dz, tw[4] * dx + tw[5] * dy + tw[6] * dz, tw[8] * dx + tw[9] * dy + tw[10] * dz};
+    const float *row = sc.d.tri_info + (size_t) tri * PSDR_TRI_STRIDE;
+    const double p0[3] = {row[0], row[1], row[2]}, e1[3] = {row[3], row[4], row[5]}, e2[3] = {row[6], row[7], row[8]};
+    const double h[3] = {d[1] * e2[2] - d[2] * e2[1], d[2] * e2[0] - d[0] * e2[2], d[0] * e2[1] - d[1] * e2[0]};
+    const double f = 1.0 / (e1[0] * h[0] + e1[1] * h[1] + e1[2] * h[2]);
+    const double s_[3] = {o[0] - p0[0], o[1] - p0[1], o[2] - p0[2]};
+    const double u = f * (s_[0] * h[0] + s_[1] * h[1] + s_[2] * h[2]);
+    const double q[3] = {s_[1] * e1[2] - s_[2] * e1[1], s_[2] * e1[0] - s_[0] * e1[2], s_[0] * e1[1] - s_[1] * e1[0]};
+    const double vv = f * (d[0] * q[0] + d[1] * q[1] + d[2] * q[2]);
+    const double x[3] = {p0[0] + u * e1[0] + vv * e2[0] - px, p0[1] + u * e1[1] + vv * e2[1] - py, p0[2] + u * e1[2] + vv * e2[2] - pz};
+    return sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+}
+
 // HyperCubeDistribution<3>::sample_reuse (src/core/cube_distrb.cpp:41-48)
 PSDR_HD float guide_sample_reuse(const SceneView &sc, float s[3]) {
     float pmf;
@@ -938,9 +983,11 @@ PSDR_HD int secondary_edge_sample(const SceneView &sc, const TVT &tv, TraversalS
     const float bpdf = pdf0 * ps2.pdf * (distSqr / cosTheta);
     // -- eval_secondary_edge
     const Vec3f dir = normalize(p2 - p0);
-    const Its<float> its2 = intersect<float>(sc, tv0, st, RayT<float>{p0, dir}, valid, kDetached, nrays);
+    // the two rays that start ON the edge skip its adjacent faces when the caller supplies them (psdr_hip.h sec_edge_faces)
+    const int f0 = sc.d.sec_edge_faces ? sc.d.sec_edge_faces[2 * k] : -1, f1 = sc.d.sec_edge_faces ? sc.d.sec_edge_faces[2 * k + 1] : -1;
+    const Its<float> its2 = intersect<float>(sc, tv0, st, RayT<float>{p0, dir}, valid, kDetached, nrays, f0, f1);
     valid = valid && its2.valid && norm(its2.p - p2) < kShadowEpsilon;
-    const Its<float> its1c = intersect<float>(sc, tv0, st, RayT<float>{p0, -dir}, valid, kDetached, nrays);
+    const Its<float> its1c = intersect<float>(sc, tv0, st, RayT<float>{p0, -dir}, valid, kDetached, nrays, f0, f1);
     valid = valid && its1c.valid;
     if (!valid) return -1;
     const Vec3f p1 = its1c.p;
@@ -948,7 +995,12 @@ PSDR_HD int secondary_edge_sample(const SceneView &sc, const TVT &tv, TraversalS
     if (!sample_direct(sc, p1, pixel, qx, qy, sensor_val)) return -1;
     const RayT<R> camera_ray = primary_ray<R>(sc, tv, qx, qy);
     const Its<R> its1 = intersect<R>(sc, tv, st, camera_ray, true, ad ? kSolidAngle : kDetached, nrays);
-    if (!(its1.valid && norm(val(its1.p) - p1) < kShadowEpsilon)) return -1;
+    // "the camera sees p1" (direct.cpp:262: |its1.p - p1| < ShadowEpsilon).  The camera ray goes through the film
+    // projection of p1, so the test measures how far projection + ray generation (two fp32 matrices, inverse to each
+    // other only to fp32 accuracy) carry the ray from p1 on a grazing surface 1000 units away -- of the order of
+    // ShadowEpsilon itself.  In fp32 the decision flips for high-weight samples (5e-3 of the cbox_bunny boundary
+    // term against an fp64 evaluation); camera_return_distance evaluates the same quantity in double.
+    if (!(its1.valid && camera_return_distance(sc, its1c.tri, its1c.hu, its1c.hv, its1.tri) < (double) kShadowEpsilon)) return -1;
     const float dist = norm(p2 - p1), cos2 = fabsf(dot(bn, dir));
     const Vec3f ev = cross(edge, dir);
     const float sinphi = norm(ev);

@@ -715,7 +715,7 @@ PSDR_HD Vec3f camera_sample_reverse(RealSink &real_sink, PrimaryGrad &pg, PathRe
     Its<float> its;
     if (geo) {
         moeller_trumbore(T0.p0, T0.e1, T0.e2, ray, bu, bv, t0);
-        its.p = ray.o + ray.d * t0;
+        its.p = bary_point(T0.p0, T0.e1, T0.e2, bu, bv);        // = ray(t0), evaluated on the triangle (psdr_device.h intersect)
     } else {
         bu = h0.u; bv = h0.v;
         its.p = bary_point(T0.p0, T0.e1, T0.e2, bu, bv);
@@ -746,14 +746,14 @@ PSDR_HD Vec3f camera_sample_reverse(RealSink &real_sink, PrimaryGrad &pg, PathRe
         }
         if (!(isfinite(result.x) && isfinite(result.y) && isfinite(result.z))) return zero_nonfinite(result);
         if (!geo) return result;
-        // fold a_t into the chain below through p = o + t d  (depth == t)
+        // p = p0 + bu e1 + bv e2 with (bu, bv, t) = MT(tri0, ray)  (depth == t)
         const Vec3f a_shn = va0.n + frame_vjp(sn0.n, va0.s, va0.t);
-        float abu = 0.f, abv = 0.f;
+        float abu = dot(va0.p, T0.e1), abv = dot(va0.p, T0.e2);
         shading_normal_vjp(sink, h0.tri, T0, sn0, bu, bv, a_shn, abu, abv);
         if (q) { abu += va0.u * (q[2] - q[0]) + va0.v * (q[3] - q[1]); abv += va0.u * (q[4] - q[0]) + va0.v * (q[5] - q[1]); }
-        const MtAdj ma = mt_vjp(T0.p0, T0.e1, T0.e2, ray, abu, abv, a_t + dot(va0.p, ray.d));
-        scatter_vec(sink, h0.tri, 0, ma.p0); scatter_vec(sink, h0.tri, 3, ma.e1); scatter_vec(sink, h0.tri, 6, ma.e2);
-        camera_ray_vjp(sink, sc, dcam, va0.p + ma.o, va0.p * t0 + ma.d);
+        const MtAdj ma = mt_vjp(T0.p0, T0.e1, T0.e2, ray, abu, abv, a_t);
+        scatter_vec(sink, h0.tri, 0, ma.p0 + va0.p); scatter_vec(sink, h0.tri, 3, ma.e1 + va0.p * bu); scatter_vec(sink, h0.tri, 6, ma.e2 + va0.p * bv);
+        camera_ray_vjp(sink, sc, dcam, ma.o, ma.d);
         return result;
     }
 
@@ -817,7 +817,7 @@ PSDR_HD Vec3f camera_sample_reverse(RealSink &real_sink, PrimaryGrad &pg, PathRe
             beta = beta * vo.f; prev = cur; cur = vo.next;
         }
     }
-    // ---- primary vertex: wi = to_local(-d), frame(sh_n(bu,bv)), uv(bu,bv), p = o + t d, (bu,bv,t) = MT(tri0, ray)
+    // ---- primary vertex: wi = to_local(-d), frame(sh_n(bu,bv)), uv(bu,bv), p = p0 + bu e1 + bv e2, (bu,bv,t) = MT(tri0, ray)
     if (geo) {
         // The primary vertex is REBUILT here (ray, triangle row, Moeller-Trumbore, shading frame: ~150 VALU) instead
         // of staying live across the two sweeps: ~60 registers less in a kernel that spills at 2 waves / SIMD.
@@ -837,12 +837,12 @@ PSDR_HD Vec3f camera_sample_reverse(RealSink &real_sink, PrimaryGrad &pg, PathRe
         Vec3f a_d = a_d_le0 - (sh_b.s * va0.wi.x + sh_b.t * va0.wi.y + sh_b.n * va0.wi.z);
         acc(va0.s, ray_b.d * (-va0.wi.x)); acc(va0.t, ray_b.d * (-va0.wi.y)); acc(va0.n, ray_b.d * (-va0.wi.z));
         const Vec3f a_shn = va0.n + frame_vjp(sn_b.n, va0.s, va0.t);
-        float abu = 0.f, abv = 0.f;
+        float abu = dot(va0.p, Tb.e1), abv = dot(va0.p, Tb.e2);
         shading_normal_vjp(sink, tri_b, Tb, sn_b, bu_b, bv_b, a_shn, abu, abv);
         if (qb) { abu += va0.u * (qb[2] - qb[0]) + va0.v * (qb[3] - qb[1]); abv += va0.u * (qb[4] - qb[0]) + va0.v * (qb[5] - qb[1]); }
-        const MtAdj ma = mt_vjp(Tb.p0, Tb.e1, Tb.e2, ray_b, abu, abv, dot(va0.p, ray_b.d));
-        scatter_vec(sink, tri_b, 0, ma.p0); scatter_vec(sink, tri_b, 3, ma.e1); scatter_vec(sink, tri_b, 6, ma.e2);
-        camera_ray_vjp(sink, sc, dcam_b, va0.p + ma.o, a_d + va0.p * t_b + ma.d);
+        const MtAdj ma = mt_vjp(Tb.p0, Tb.e1, Tb.e2, ray_b, abu, abv, 0.f);
+        scatter_vec(sink, tri_b, 0, ma.p0 + va0.p); scatter_vec(sink, tri_b, 3, ma.e1 + va0.p * bu_b); scatter_vec(sink, tri_b, 6, ma.e2 + va0.p * bv_b);
+        camera_ray_vjp(sink, sc, dcam_b, ma.o, a_d + ma.d);
     }
     return result;
 }
@@ -920,9 +920,10 @@ PSDR_HD void secondary_edge_reverse(Sink &sink, const SceneView &sc, TraversalSt
     bool valid = cosTheta > kEpsilon && (is_boundary ? sgn0 != 0 : sgn0 * sgn1 < 0);
     const float bpdf = pdf0 * ps2.pdf * (distSqr / cosTheta);
     const Vec3f dir = normalize(p2 - p0);
-    const Its<float> its2 = intersect<float>(sc, tv0, st, RayT<float>{p0, dir}, valid, kDetached, nrays);
+    const int f0 = sc.d.sec_edge_faces ? sc.d.sec_edge_faces[2 * k] : -1, f1 = sc.d.sec_edge_faces ? sc.d.sec_edge_faces[2 * k + 1] : -1;
+    const Its<float> its2 = intersect<float>(sc, tv0, st, RayT<float>{p0, dir}, valid, kDetached, nrays, f0, f1);
     valid = valid && its2.valid && norm(its2.p - p2) < kShadowEpsilon;
-    const Its<float> its1c = intersect<float>(sc, tv0, st, RayT<float>{p0, -dir}, valid, kDetached, nrays);
+    const Its<float> its1c = intersect<float>(sc, tv0, st, RayT<float>{p0, -dir}, valid, kDetached, nrays, f0, f1);
     if (!(valid && its1c.valid)) return;
     const Vec3f p1 = its1c.p;
     int pixel; float qx, qy, sensor_val;
@@ -935,8 +936,8 @@ PSDR_HD void secondary_edge_reverse(Sink &sink, const SceneView &sc, TraversalSt
     const TriRow<float> Tc = load_tri<float>(sc, tv0, hc.tri);
     float cu, cv, ct;
     moeller_trumbore(Tc.p0, Tc.e1, Tc.e2, cam, cu, cv, ct);
-    const Vec3f x1 = cam.o + cam.d * ct;                                  // its1.p (solid-angle form)
-    if (!(norm(x1 - p1) < kShadowEpsilon)) return;
+    const Vec3f x1 = bary_point(Tc.p0, Tc.e1, Tc.e2, cu, cv);            // its1.p (solid-angle form, on the triangle)
+    if (!(camera_return_distance(sc, its1c.tri, its1c.hu, its1c.hv, hc.tri) < (double) kShadowEpsilon)) return;        // psdr_device.h secondary_edge_sample
     const float dist = norm(p2 - p1), cos2 = fabsf(dot(bn, dir));
     const Vec3f ev = cross(edge, dir);
     const float sinphi = norm(ev);
@@ -976,10 +977,10 @@ PSDR_HD void secondary_edge_reverse(Sink &sink, const SceneView &sc, TraversalSt
     sink.add_sedge(k, 0, a_w.x); sink.add_sedge(k, 1, a_w.y); sink.add_sedge(k, 2, a_w.z);
     sink.add_sedge(k, 3, a_w.x * s1); sink.add_sedge(k, 4, a_w.y * s1); sink.add_sedge(k, 5, a_w.z * s1);
     const Vec3f a_x1 = ma.o - a_w;
-    // x1 = o + t d with (.,.,t) = MT(triangle C, camera ray)
-    const MtAdj mc = mt_vjp(Tc.p0, Tc.e1, Tc.e2, cam, 0.f, 0.f, dot(a_x1, cam.d));
-    scatter_vec(sink, hc.tri, 0, mc.p0); scatter_vec(sink, hc.tri, 3, mc.e1); scatter_vec(sink, hc.tri, 6, mc.e2);
-    camera_ray_vjp(sink, sc, dcam, a_x1 + mc.o, a_x1 * ct + mc.d);
+    // x1 = p0 + u e1 + v e2 with (u, v, .) = MT(triangle C, camera ray)
+    const MtAdj mc = mt_vjp(Tc.p0, Tc.e1, Tc.e2, cam, dot(a_x1, Tc.e1), dot(a_x1, Tc.e2), 0.f);
+    scatter_vec(sink, hc.tri, 0, mc.p0 + a_x1); scatter_vec(sink, hc.tri, 3, mc.e1 + a_x1 * cu); scatter_vec(sink, hc.tri, 6, mc.e2 + a_x1 * cv);
+    camera_ray_vjp(sink, sc, dcam, mc.o, mc.d);
 }
 
 }  // namespace psdr

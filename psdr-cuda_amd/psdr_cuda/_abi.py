@@ -50,6 +50,7 @@ class SceneDesc(C.Structure):
         ("env_emitter", C.c_int32), ("env_tex", C.c_int32 * 3), ("env_reso", C.c_int32 * 2),
         ("env_f", _fp), ("env_cmf", _fp), ("env_pmf", _fp), ("env_sum", C.c_float),
         ("material_mask", C.c_uint32),
+        ("sec_edge_faces", _fp),
     ]
 
 

@@ -984,6 +984,7 @@ class Scene(Object):
         p2 = v_world[ei[:, 4]]
         keep = ((n0 * n1).sum(-1) < 1.0 - EdgeEpsilon).detach()
         info = torch.cat([p0, e1, n0, n1, p2, is_b.to(torch.float32).unsqueeze(-1)], dim=-1)
+        self._sec_edge_faces = ei[keep][:, 2:4].to(torch.int32).contiguous()      # adjacent faces (global ids; -1 = none)
         return info[keep]
 
     # -- configure (src/scene/scene.cpp:56-278) ---------------------------------
@@ -1129,9 +1130,10 @@ class Scene(Object):
             se = se_all.contiguous()
             e1 = se[:, 3:6].detach()
             sd = DiscreteDistribution(); sd.init(torch.sqrt((e1 * e1).sum(-1)))
-            tb.update(sec_edge=se, sec_cmf=sd.m_cmf, sec_pmf=sd.m_pmf, sec_sum=sd.m_sum, num_sec_edges=int(se.shape[0]))
+            tb.update(sec_edge=se, sec_cmf=sd.m_cmf, sec_pmf=sd.m_pmf, sec_sum=sd.m_sum, num_sec_edges=int(se.shape[0]),
+                      sec_edge_faces=self._sec_edge_faces)
         else:
-            tb.update(sec_edge=None, sec_cmf=None, sec_pmf=None, sec_sum=0.0, num_sec_edges=0)
+            tb.update(sec_edge=None, sec_cmf=None, sec_pmf=None, sec_sum=0.0, num_sec_edges=0, sec_edge_faces=None)
         self._version += 1
         tb["version"] = self._version          # stamps the tables: the BVH on the native handle is tied to it (Integrator._prepare)
         self._tables = tb
@@ -1229,6 +1231,7 @@ def make_desc(tb, guide=None, device=None):
     d.emitter_cmf, d.emitter_pmf, d.emitter_sum = p(tb["emitter_cmf"]), p(tb["emitter_pmf"]), tb["emitter_sum"]
     d.cam = p(tb["cam"])
     d.sec_edge, d.sec_cmf, d.sec_pmf, d.sec_sum = p(tb["sec_edge"]), p(tb["sec_cmf"]), p(tb["sec_pmf"]), tb["sec_sum"]
+    d.sec_edge_faces = p(tb.get("sec_edge_faces"), torch.int32)
     d.prim_edge, d.prim_cmf, d.prim_pmf, d.prim_sum = p(tb["prim_edge"]), p(tb["prim_cmf"]), p(tb["prim_pmf"]), tb["prim_sum"]
     d.material_mask = int(tb.get("material_mask", 0))
     d.env_emitter = int(tb.get("env_emitter", -1))

@@ -34,7 +34,8 @@ def test_config5_full_scene_gpu():
     o = _abi.make_opts(spp=8, bsdf_samples=1, light_samples=1)
     img, ref = g.render_c(o), oracle.render(tb, o)
     bad = (np.abs(img - ref).max(1) > 1e-3 * (1 + np.abs(ref).max(1))).mean()
-    assert bad < 0.01 and rel_l2(img, ref) < 3e-2, (bad, rel_l2(img, ref))
+    print("C5 renderC: rel-L2 %.2e, pixels off by > 1e-3: %.2e" % (rel_l2(img, ref), bad))
+    assert bad < 2e-3 and rel_l2(img, ref) < 1e-3, (bad, rel_l2(img, ref))
     # roughness derivative: every alpha texel moves together (material_roughness, differential.py:28-31)
     rec = tb["bsdf_rec"].cpu().numpy()
     t = torch.zeros_like(tb["texels"])
@@ -43,6 +44,7 @@ def test_config5_full_scene_gpu():
     _, dref = oracle.render(tb, o, mode=1, tangents={"texels": t})
     _, dimg = g.render_d_fwd(o, [{"texels": t}])
     bad = (np.abs(dimg[0] - dref).max(1) > 2e-3 * (1 + np.abs(dref).max(1))).mean()
+    print("C5 roughness derivative: rel-L2 %.2e, pixels off by > 2e-3: %.2e" % (rel_l2(dimg[0], dref), bad))
     assert np.abs(dref).max() > 0 and bad < 0.02, bad
     # vertex (triangle-table) + roughness gradients in reverse mode == forward mode
     adj = np.random.default_rng(0).random((128 * 128, 3)).astype(np.float32)

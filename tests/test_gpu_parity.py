@@ -1,7 +1,8 @@
 """GPU parity tests (run with `-m gpu` on the MI355X box): the HIP path, called through the C ABI,
 against the CPU oracle on the same seeded inputs.  Tolerances:
-  * hits: identical triangle ids except rays within fp32 round-off of a shared edge (<= 0.1 %);
-    barycentrics <= 1e-4 abs.
+  * hits (the oracle traces in double = the exact hit): identical triangle ids except rays within fp32
+    round-off of a shared edge (<= 0.1 %); barycentrics <= 1e-4 abs for 99.99 % of the hits, <= 2e-3 for all
+    (edge-on triangles).
   * images (fp32, same RNG streams): rel-L2 <= 1e-4 on scenes whose samples are well conditioned
     (cbox: 12 large triangles); on bunny scenes isolated ill-conditioned samples (fp32
     Moeller-Trumbore derivatives of edge-on triangles seen from ~1000 units, DESIGN.md
@@ -33,7 +34,11 @@ def test_trace_matches_oracle(scene):
     assert np.array_equal(shape[same], so[same])
     hit = same & (tri >= 0)
     assert hit.sum() > n * 0.2
-    assert np.abs(u[hit] - su[hit]).max() < 1e-4 and np.abs(v[hit] - sv[hit]).max() < 1e-4
+    # the oracle traces in double (the exact hit): fp32 Moeller-Trumbore is within 1e-5 of it except on edge-on
+    # triangles (|det| tiny), where a handful of rays reach 1e-3
+    du = np.maximum(np.abs(u[hit] - su[hit]), np.abs(v[hit] - sv[hit]))
+    print("%s: barycentric error vs the exact hit: max %.1e, 99.99th percentile %.1e" % (scene, du.max(), np.percentile(du, 99.99)))
+    assert np.percentile(du, 99.99) < 1e-4 and du.max() < 2e-3
     assert np.all(u[tri < 0] == -1.0)
     # incoherent bounce rays
     info = tb["tri_info"].cpu().numpy()
@@ -78,7 +83,8 @@ def test_render_c_bunny():
     ref = oracle.render(tb, o)
     img = GpuScene(tb).render_c(o)
     bad = (np.abs(img - ref).max(axis=1) > 1e-3 * (1 + np.abs(ref).max(axis=1))).mean()
-    assert bad < 0.01 and rel_l2(img, ref) < 2e-2, (bad, rel_l2(img, ref))
+    print("cbox_bunny renderC: rel-L2 %.2e, pixels off by > 1e-3: %.2e" % (rel_l2(img, ref), bad))
+    assert bad < 2e-3 and rel_l2(img, ref) < 1e-3, (bad, rel_l2(img, ref))
 
 
 def test_shards_sum_to_full_render():
@@ -99,9 +105,9 @@ def test_render_d_fwd_matches_oracle(scene, mesh, kind):
     o = _abi.make_opts(spp=8, sppe=8, sppse=8 if kind.startswith("direct") else 0, **OPTS[kind])
     ref_img, ref_d = oracle.render(tb, o, mode=1, tangents=tan)
     img, dimg = GpuScene(tb).render_d_fwd(o, [tan])
-    tol = 2e-2 if kind == "path3" else 1e-4     # PathTracer D mode: off-surface primary points
-    assert rel_l2(img, ref_img) < tol, rel_l2(img, ref_img)
-    assert rel_l2(dimg[0], ref_d) < max(tol, 1e-3), rel_l2(dimg[0], ref_d)
+    print("%s %s renderD: image rel-L2 %.2e, derivative image rel-L2 %.2e" % (scene, kind, rel_l2(img, ref_img), rel_l2(dimg[0], ref_d)))
+    assert rel_l2(img, ref_img) < 1e-4, rel_l2(img, ref_img)
+    assert rel_l2(dimg[0], ref_d) < 1e-3, rel_l2(dimg[0], ref_d)
 
 
 def test_render_d_albedo_k3():
@@ -117,8 +123,8 @@ def test_render_d_albedo_k3():
     img, dimg = GpuScene(tb).render_d_fwd(o, sets)
     for c in range(3):
         _, ref = oracle.render(tb, o, mode=1, tangents=sets[c])
-        assert rel_l2(dimg[c], ref) < 2e-2
-        assert abs(dimg[c].sum() - ref.sum()) < 1e-3 * abs(ref.sum())
+        assert rel_l2(dimg[c], ref) < 1e-3, rel_l2(dimg[c], ref)
+        assert abs(dimg[c].sum() - ref.sum()) < 1e-4 * abs(ref.sum())
 
 
 def test_guiding_grid_matches_oracle():
