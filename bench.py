@@ -1,23 +1,35 @@
 #!/usr/bin/env python
 """bench.py -- headline benchmark of the MI355X-native path-space differentiable renderer.
 
-Workload (BASELINE.json configs[1]): cbox 512x512, spp = 64, PathTracer(max_depth=3);
-one "step" = one renderC pass + one renderD pass w.r.t. the diffuse albedo of BSDF[0]
-(forward mode, K = 3: d image / d (r, g, b) in a single pass) over synthetic data (the bundled
-Cornell-box fixture, 12 triangles).  Metric: Mpath-samples/s = camera sample slots evaluated by
-both passes / wall seconds / 1e6, inputs resident in HBM, device-synchronised.
+Workload (BASELINE.json configs[1]): cbox 512x512, spp = 64, PathTracer(max_depth=3), derivative w.r.t. the diffuse
+albedo of BSDF[0].  One "step" is what the reference's harness runs per pass (examples/run_test.py:44-147), THROUGH THE
+DROP-IN SURFACE:
+    run_orig pass   img  = integrator.renderC(scene)
+    run_ad pass     P = FloatD(0); set_requires_gradient(P); reflectance.data = base + P; scene.configure()
+                    imgD = integrator.renderD(scene); enoki.forward(P); d = enoki.gradient(imgD)
+Metric: Mpath-samples/s = camera sample slots of the two passes / wall seconds / 1e6 (2 * W * H * spp per step),
+scene tables resident in HBM, device-synchronised.  `value` is this surface-inclusive rate; the same work as bare
+C-ABI launches (psdr_render_c + psdr_render_d_fwd, no Python / torch table chain) is reported beside it as
+`kernel_only`, and the reverse-mode variant of the AD pass (loss.backward -> psdr_render_d_rev) as `reverse`.
 
-Multi-GPU (`--gpus N` under torch.distributed.run): the spp of every pixel are sharded across the
-ranks (weak scaling: per-GPU spp fixed at 64, global spp = 64*N) and the image / derivative-image
-buffers are summed with ONE RCCL all-reduce per render call.
+Multi-GPU (`--gpus N` under torch.distributed.run): the spp of every pixel are sharded across the ranks (weak
+scaling: per-GPU spp fixed at 64, global spp = 64 * N) and the image / derivative-image buffers are summed with ONE
+RCCL all-reduce per render call.
+
+`--pmc-child` (internal): a short run of the kernel-only launches under `rocprofv3 --pmc`, spawned by the parent to
+MEASURE the VALU instruction count and the HBM traffic of the dominant kernel in this very run.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
-import ctypes as C
+import csv
+import glob
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -25,6 +37,11 @@ sys.path.insert(0, os.path.join(ROOT, "psdr-cuda_amd"))
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
+
+# MI355X (MI355X_MICROARCH.md): 256 CUs x 4 SIMDs, 2.4 GHz; a wave64 VALU instruction occupies its SIMD for 4 cycles
+# (16 lanes per cycle); non-packed fp32 FMA peak 256 * 4 * 16 * 2 * 2.4e9 = 78.6 TFLOP/s; HBM3E 8 TB/s.
+N_SIMD, CLOCK_HZ, HBM_BPS = 1024, 2.4e9, 8.0e12
+VALU_PEAK_WAVE_INSTS_PER_S = N_SIMD * CLOCK_HZ / 4.0          # 6.144e11 wave-instructions / s
 
 
 def parse():
@@ -37,38 +54,139 @@ def parse():
     ap.add_argument("--max-depth", type=int, default=3)
     ap.add_argument("--scene", default="cbox")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
-def algorithmic_bytes(slots, rays, derivative):
-    """SURVEY.md 8(d) wavefront-stream model: 292 B per traced ray + 12 B splat per camera slot;
-    renderD adds 88 B per ray + 12 B per slot."""
+def stream_model_bytes(slots, rays, derivative):
+    """SURVEY.md 8(d) wavefront-stream model: 292 B per traced ray + 12 B splat per camera slot; renderD adds 88 B per
+    ray + 12 B per slot.  The fused kernels keep the path state in registers and do NOT move these bytes: reported as
+    `stream_model_equiv` only."""
     b = 292.0 * rays + 12.0 * slots
     if derivative:
         b += 88.0 * rays + 12.0 * slots
     return b
 
 
-def measured_traffic(kernel_key):
-    """HBM bytes per launch of the dominant kernel from the newest committed PMC summary
-    (profiles/*_traffic.json, written by tools/summarize_prof.py from separate rocprofv3 --pmc passes);
-    bench.py itself cannot read PMC counters."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), key=os.path.getmtime)
-    try:                      # the summary tools/summarize_prof.py wrote last (file times do not survive a checkout)
-        latest = os.path.join(ROOT, "profiles", json.load(open(os.path.join(ROOT, "profiles", "latest.json")))["traffic"])
-        files = [f for f in files if f != latest] + [latest]
-    except Exception:
-        pass
-    for f in reversed(files):
-        try:
-            d = json.load(open(f))
-            for name, v in d["kernels"].items():
-                if "k_camera" in name and kernel_key in name and "rev" not in name:
-                    return v["hbm_bytes_per_launch"], v.get("valu_wave_insts_per_launch"), os.path.relpath(f, ROOT)
-        except Exception:
-            continue
-    return None, None, None
+class Workload:
+    """Scene + integrator + the two call sequences (surface / bare C ABI)."""
+
+    def __init__(self, args, world):
+        import enoki as ek
+        import psdr_cuda
+        from enoki.cuda_autodiff import Float32 as FloatD, Vector3f as Vector3fD
+        from psdr_cuda.fixtures import scene_path
+        self.ek, self.FloatD, self.Vector3fD = ek, FloatD, Vector3fD
+        sc = psdr_cuda.Scene()
+        sc.load_file(scene_path(args.scene), False)
+        sc.opts.width = sc.opts.height = args.res
+        sc.opts.spp = args.spp * world              # global spp; each rank renders its 1/world share
+        sc.opts.sppe = sc.opts.sppse = 0            # albedo has no boundary term (SURVEY 8, C2)
+        sc.opts.log_level = 0
+        self.sc = sc
+        self.refl = sc.param_map["BSDF[0]"].reflectance
+        self.base = ek.detach(self.refl.data)
+        self.integ = psdr_cuda.PathTracer(max_depth=args.max_depth)
+        sc.configure()
+
+    # ---- through the drop-in surface (examples/run_test.py run_orig + run_ad, one pass each)
+    def surface_step(self):
+        ek = self.ek
+        img = self.integ.renderC(self.sc)
+        P = self.FloatD(0.)
+        ek.set_requires_gradient(P)
+        self.refl.data = self.Vector3fD(self.base) + P
+        self.sc.configure()
+        imgD = self.integ.renderD(self.sc)
+        ek.forward(P, free_graph=True)
+        return img, imgD, ek.gradient(imgD)
+
+    def surface_reverse_step(self):
+        """renderD + a torch loss + enoki.backward (docs/inverse_diff_render.rst): the gradient scatter-add path."""
+        ek = self.ek
+        r = self.Vector3fD(self.base)
+        ek.set_requires_gradient(r)
+        self.refl.data = r
+        self.sc.configure()
+        imgD = self.integ.renderD(self.sc)
+        ek.backward(self.FloatD._wrap(imgD.t.sum().reshape(1)))
+        return ek.gradient(r)
+
+    # ---- the same work as bare C-ABI launches
+    def kernel_setup(self, K):
+        self.refl.data = self.Vector3fD(self.base)
+        self.sc.configure()
+        self.tb = self.sc.tables(0)
+        self.opts = self.integ._opts(self.sc, with_edges=False)
+        self.tsets = []
+        for c in range(K):
+            t = torch.zeros_like(self.tb["texels"])
+            if K == 1:
+                t[0:3] = 1.0
+            else:
+                t[c] = 1.0
+            self.tsets.append([None, t, None, None, None, None, None])
+        self.adj = torch.ones(self.tb["width"] * self.tb["height"] * 3, device="cuda")
+
+    def kernel_c(self):
+        return self.integ._render_c(self.sc, self.tb, self.opts, None)
+
+    def kernel_d(self):
+        return self.integ._render_fwd(self.sc, self.tb, self.opts, None, self.tsets)
+
+    def kernel_rev(self):
+        tb = dict(self.tb)
+        tx = tb["texels"].detach().requires_grad_(True)
+        tb["texels"] = tx
+        return self.integ._render_rev(self.sc, tb, self.opts, None, self.adj)
+
+
+def timed(fn, n):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ms = []
+    for _ in range(n):
+        e0.record(); fn(); e1.record()
+        torch.cuda.synchronize()
+        ms.append(e0.elapsed_time(e1))
+    return float(np.mean(ms))
+
+
+def pmc_passes(args):
+    """VALU wave-instructions and HBM bytes per launch of the dominant kernels, measured NOW: this script re-runs
+    itself (--pmc-child: a few kernel-only launches) under `rocprofv3 --pmc`, one pass per counter group, and parses
+    the counter CSV.  FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE tallies 64 B per 128 B request, so
+    reads are doubled (MI355X_MICROARCH.md, HBM section).  Returns {} when rocprofv3 is unavailable."""
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return {}
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="psdr_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        for group in ("SQ_INSTS_VALU", "FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, group)
+            cmd = [exe, "--pmc", group, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
+                   "--pmc-child", "--res", str(args.res), "--spp", str(args.spp), "--max-depth", str(args.max_depth), "--scene", args.scene]
+            try:
+                subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
+            except Exception:
+                return {}
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if not files:
+                return {}
+            acc = {}
+            for r in csv.DictReader(open(files[0])):
+                name = r.get("Kernel_Name", "")
+                if "k_camera" not in name or r.get("Counter_Name") != group:
+                    continue
+                key = "rev" if "k_camera_rev" in name else ("d" if "Dual<" in name else "c")
+                acc.setdefault(key, []).append(float(r["Counter_Value"]))
+            for key, vals in acc.items():
+                out.setdefault(key, {})[group] = float(np.mean(vals))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return out
 
 
 def main():
@@ -84,59 +202,26 @@ def main():
         import torch.distributed as dist
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
-    import psdr_cuda
     from psdr_cuda import _abi
-    from psdr_cuda.fixtures import scene_path
+    w = Workload(args, world)
 
-    sc = psdr_cuda.Scene()
-    sc.load_file(scene_path(args.scene), False)
-    sc.opts.width = sc.opts.height = args.res
-    sc.opts.spp = args.spp * world              # global spp; each rank renders its 1/world share
-    sc.opts.sppe = sc.opts.sppse = 0            # albedo has no boundary term
-    sc.opts.log_level = 0
-    sc.configure()
-    integ = psdr_cuda.PathTracer(max_depth=args.max_depth)
-    tb = sc.tables(0)
-    opts = integ._opts(sc, with_edges=False)
-    tangent_sets = []
-    for c in range(3):
-        t = torch.zeros_like(tb["texels"])
-        t[c] = 1.0
-        tangent_sets.append([None, t, None, None, None, None, None])
+    if args.pmc_child:                      # counted launches only: 2 x (renderC, renderD K=1, reverse)
+        w.kernel_setup(1)
+        for _ in range(2):
+            w.kernel_c(); w.kernel_d(); w.kernel_rev()
+        torch.cuda.synchronize()
+        return
 
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-    kern_ms = {"render_c": [], "render_d": []}
-    rays = {}
-
-    def step(record):
-        ev[0].record()
-        integ._render_c(sc, tb, opts, None)
-        ev[1].record()
-        rays_c = integ.last_counters
-        ev[2].record()
-        integ._render_fwd(sc, tb, opts, None, tangent_sets)
-        ev[3].record()
-        rays_d = integ.last_counters
-        if record:
-            torch.cuda.synchronize()
-            kern_ms["render_c"].append(ev[0].elapsed_time(ev[1]))
-            kern_ms["render_d"].append(ev[2].elapsed_time(ev[3]))
-            rays["c"], rays["d"] = rays_c, rays_d
-
-    # The first launch of a kernel loads its code object (8 ms) and the next three run 3-8 % slow while the clocks
-    # ramp (tools/var_probe.py): a few untimed passes as part of the setup, so that a small --warmup still
-    # measures the steady state.  The W warm-up steps of the contract follow.
-    for _ in range(6):
-        step(False)
+    # ---- the timed region: K surface steps (W warm-up steps before it; nothing else runs untimed in front)
     for _ in range(args.warmup):
-        step(False)
+        w.surface_step()
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step(True)
+        w.surface_step()
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -146,40 +231,81 @@ def main():
         tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-
-    slots_per_pass = args.res * args.res * args.spp * world          # whole job
-    samples = 2.0 * slots_per_pass * args.steps
-    value = samples / dt / 1e6
-
-    # roofline of the dominant kernel (rank 0's launch; HIP events on the launch stream)
     local_slots = args.res * args.res * args.spp
-    ms_c, ms_d = float(np.mean(kern_ms["render_c"])), float(np.mean(kern_ms["render_d"]))
-    dom = "k_camera<Dual<3>> (renderD)" if ms_d >= ms_c else "k_camera<float> (renderC)"
-    dom_ms = max(ms_c, ms_d)
-    dom_rays = rays["d"][0] if ms_d >= ms_c else rays["c"][0]
-    abytes = algorithmic_bytes(local_slots, dom_rays, ms_d >= ms_c)
-    achieved = abytes / (dom_ms * 1e-3) / 1e9
-    traffic, valu_insts, traffic_src = measured_traffic("Dual<3>" if ms_d >= ms_c else "float, float")
-    # the fused kernel keeps the path state in registers, so the stream-model bytes are NOT moved (frac can
-    # exceed 1); what binds it is VALU issue: wave-instructions x 4 cycles (wave64 on a 16-lane SIMD) over the
-    # SIMD-cycles of the launch (1024 SIMDs at 2.4 GHz), instruction count from the committed PMC summary
-    valu_frac = None if not valu_insts else round(valu_insts * 4.0 / (dom_ms * 1e-3 * 2.4e9 * 1024.0), 4)
-    roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
-                "frac": round(achieved / 8000.0, 5), "traffic": traffic, "traffic_source": traffic_src, "kernel": dom,
-                "valu_issue_frac": valu_frac,
-                "kernel_ms": round(dom_ms, 4), "rays_per_slot": round(dom_rays / local_slots, 4),
-                "algorithmic_bytes_per_launch": abytes,
-                "render_c_ms": round(ms_c, 4), "render_d_ms": round(ms_d, 4)}
+    slots_per_pass = local_slots * world                             # whole job
+    value = 2.0 * slots_per_pass * args.steps / dt / 1e6
 
-    cpu = None
+    # ---- beside it: the surface with reverse mode, the bare kernels (HIP events on the launch stream), host shares
+    n_side = max(5, min(20, args.steps))
+    ms_rev_surface = timed(w.surface_reverse_step, n_side)
+    t1 = time.perf_counter()
+    for _ in range(n_side):
+        w.refl.data = w.Vector3fD(w.base); w.sc.configure()
+    torch.cuda.synchronize()
+    ms_configure = (time.perf_counter() - t1) / n_side * 1e3
+    w.kernel_setup(1)
+    for _ in range(3):
+        w.kernel_c(); w.kernel_d(); w.kernel_rev()
+    ms_c = timed(w.kernel_c, n_side); rays_c = w.integ.last_counters[0]
+    ms_d1 = timed(w.kernel_d, n_side); rays_d = w.integ.last_counters[0]
+    ms_rev = timed(w.kernel_rev, n_side)
+    w.kernel_setup(3)
+    w.kernel_d()
+    ms_d3 = timed(w.kernel_d, n_side)
+    kernel_only = {"value": round(2.0 * slots_per_pass / ((ms_c + ms_d1) * 1e-3) / 1e6, 1), "unit": "Mpath-samples/s",
+                   "render_c_ms": round(ms_c, 4), "render_d_fwd_k1_ms": round(ms_d1, 4), "render_d_fwd_k3_ms": round(ms_d3, 4),
+                   "render_d_rev_ms": round(ms_rev, 4),
+                   "note": "psdr_render_c + psdr_render_d_fwd (K=1) launches of the same samples; K=3 = d/d(r,g,b) in one pass (round-1 headline form); "
+                           "rev = psdr_render_d_rev, texel gradient"}
+    surface = {"ms_per_step": round(dt / args.steps * 1e3, 4), "configure_ms": round(ms_configure, 4),
+               "reverse_step_ms": round(ms_rev_surface, 4),
+               "note": "step = renderC + [configure + renderD + enoki.forward] (one launch each: renderD is rendered by the forward-mode kernel); "
+                       "reverse_step = configure + renderD + enoki.backward (primal launch + psdr_render_d_rev)"}
+
+    # ---- roofline of the dominant kernel: VALU issue (not HBM: the path state lives in registers)
+    pmc = {} if (args.no_pmc or rank != 0 or world != 1) else pmc_passes(args)
+    dom_key, dom_ms, dom_name = ("d", ms_d1, "k_camera<float, Dual<1>, PATH> (renderD fwd)") if ms_d1 >= ms_c else ("c", ms_c, "k_camera<float, float, PATH> (renderC)")
+    dom_rays = rays_d if dom_key == "d" else rays_c
+    valu = pmc.get(dom_key, {}).get("SQ_INSTS_VALU")
+    fetch, write = pmc.get(dom_key, {}).get("FETCH_SIZE"), pmc.get(dom_key, {}).get("WRITE_SIZE")
+    traffic = None if fetch is None or write is None else (2.0 * fetch + write) * 1024.0
+    achieved = None if valu is None else valu / (dom_ms * 1e-3)
+    # algorithmic floor: VALU lane-instructions a traced ray NEEDS on this scene -- 12 triangle tests x 27 (Moeller-Trumbore
+    # with SGPR operands, csrc/psdr_device.h leaf_triangle_test) + ~150 for hit reconstruction, sampling and shading of its
+    # path vertex -- over the lane-instructions the launch issued (64 per wave-instruction)
+    floor_lane_insts = (12 * 27 + 150) * float(dom_rays)
+    roofline = {
+        "bound": "valu", "kernel": dom_name, "kernel_ms": round(dom_ms, 4),
+        "achieved": None if achieved is None else round(achieved / 1e9, 3), "peak": round(VALU_PEAK_WAVE_INSTS_PER_S / 1e9, 3),
+        "unit": "G wave-instructions/s", "frac": None if achieved is None else round(min(achieved / VALU_PEAK_WAVE_INSTS_PER_S, 1.0), 4),
+        "frac_uncapped": None if achieved is None else round(achieved / VALU_PEAK_WAVE_INSTS_PER_S, 4),
+        "peak_note": "1024 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction (MI355X_MICROARCH.md); an instruction whose upper or lower 32 "
+                     "lanes are all inactive takes 2 cycles, hence frac_uncapped can exceed 1",
+        "valu_wave_insts_per_launch": valu, "algorithmic_floor_frac": None if valu is None else round(floor_lane_insts / (valu * 64.0), 4),
+        "traffic": traffic, "hbm_measured_frac": None if traffic is None else round(traffic / (dom_ms * 1e-3) / HBM_BPS, 5),
+        "traffic_note": "(2 * FETCH_SIZE + WRITE_SIZE) KiB per launch from rocprofv3 --pmc passes run by this script; image + derivative image = %.1f MB"
+                        % (local_slots / args.spp * 12 * 2 / 1e6),
+        "rays_per_slot": round(dom_rays / local_slots, 4),
+        "stream_model_equiv": {"bytes_per_launch": stream_model_bytes(local_slots, dom_rays, dom_key == "d"),
+                               "GBps": round(stream_model_bytes(local_slots, dom_rays, dom_key == "d") / (dom_ms * 1e-3) / 1e9, 1),
+                               "note": "SURVEY 8(d) wavefront-stream bytes; NOT moved by the fused kernel, not a roofline"},
+        "other_kernels": {k: {"valu_wave_insts": v.get("SQ_INSTS_VALU"), "hbm_bytes": None if "FETCH_SIZE" not in v or "WRITE_SIZE" not in v else (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0}
+                          for k, v in pmc.items() if k != dom_key},
+    }
+
+    cpu, grad = None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import oracle
+        import psdr_cuda
+        from psdr_cuda.fixtures import scene_path
+        # ---- CPU baseline: the oracle (a port of the reference's estimator) on the host cores, bounded sample
+        w.kernel_setup(1)
+        tbc = {k: (v.detach().cpu() if isinstance(v, torch.Tensor) else v) for k, v in w.tb.items()}
         cspp = 2
         o = _abi.make_opts(integrator=_abi.INTEGRATOR_PATH, max_depth=args.max_depth, spp=cspp)
-        tbc = {k: (v.detach().cpu() if isinstance(v, torch.Tensor) else v) for k, v in tb.items()}
-        tt = torch.zeros_like(tbc["texels"]); tt[0:3] = 1.0
         cores = os.cpu_count() or 1
+        tt = torch.zeros_like(tbc["texels"]); tt[0:3] = 1.0
         oracle.render(tbc, _abi.make_opts(integrator=_abi.INTEGRATOR_PATH, max_depth=args.max_depth, spp=1), nthreads=cores)
         c0 = time.perf_counter()
         reps = 0
@@ -188,16 +314,11 @@ def main():
             oracle.render(tbc, o, mode=1, tangents={"texels": tt}, nthreads=cores)
             reps += 1
         cdt = time.perf_counter() - c0
-        cpu = {"value": round(2.0 * args.res * args.res * cspp * reps / cdt / 1e6, 4), "unit": "Mpath-samples/s",
-               "cores": cores, "kind": "port",
-               "sample": "%d x (renderC + renderD fwd K=1) of the same scene at %dx%d spp=%d, oracle fp32, %d threads"
-                         % (reps, args.res, args.res, cspp, cores)}
-
-    # the metric's parity half: gradient rel-L2 of the HIP path against the CPU oracle, same RNG streams,
-    # at a size the oracle finishes in a second (tests/ hold the full parity suite)
-    grad = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        import oracle
+        cpu = {"value": round(2.0 * args.res * args.res * cspp * reps / cdt / 1e6, 4), "unit": "Mpath-samples/s", "cores": cores, "kind": "port",
+               "sample": "%d x (renderC + renderD fwd K=1) of the same scene at %dx%d spp=%d, oracle fp32, %d threads" % (reps, args.res, args.res, cspp, cores)}
+        # ---- the metric's parity half: d image / d albedo, HIP vs the oracle on the same sample streams, at a size the
+        # oracle finishes in a second.  Three references: fp32 in the product's forms, fp32 in the reference's literal
+        # forms, fp64 literal (= the exact value of the reference's estimator).  tests/ hold the full parity suite.
         gres, gspp = 64, 8
         sc2 = psdr_cuda.Scene()
         sc2.load_file(scene_path(args.scene), False)
@@ -205,20 +326,24 @@ def main():
         sc2.opts.spp, sc2.opts.sppe, sc2.opts.sppse, sc2.opts.log_level = gspp, 0, 0, 0
         sc2.configure()
         tb2 = sc2.tables(0)
-        o2 = integ._opts(sc2, with_edges=False)
+        o2 = w.integ._opts(sc2, with_edges=False)
         ts2 = []
         for c in range(3):
             t = torch.zeros_like(tb2["texels"]); t[c] = 1.0
             ts2.append([None, t, None, None, None, None, None])
-        _, dimgs = integ._render_fwd(sc2, tb2, o2, None, ts2)
-        worst = 0.0
-        for c in range(3):
-            ref = oracle.render(tb2, o2, mode=1, tangents={"texels": ts2[c][1]})[1].reshape(-1)
-            got = dimgs[c].cpu().numpy().astype(np.float64)
-            worst = max(worst, float(np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-30)))
-        grad = {"rel_l2": round(worst, 8), "bound": 1e-3,
-                "check": "d image / d albedo(r,g,b), %s %dx%d spp=%d PathTracer(max_depth=%d), HIP vs CPU oracle on the same sample streams"
-                         % (args.scene, gres, gres, gspp, args.max_depth)}
+        _, dimgs = w.integ._render_fwd(sc2, tb2, o2, None, ts2)
+
+        def worst(**kw):
+            r = 0.0
+            for c in range(3):
+                ref = oracle.render(tb2, o2, mode=1, tangents={"texels": ts2[c][1]}, **kw)[1].reshape(-1).astype(np.float64)
+                got = dimgs[c].cpu().numpy().astype(np.float64)
+                r = max(r, float(np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-30)))
+            return round(r, 8)
+        grad = {"rel_l2": worst(precision=1, reference_form=True), "bound": 1e-3,
+                "rel_l2_vs_fp32_same_forms": worst(precision=0), "rel_l2_vs_fp32_reference_forms": worst(precision=0, reference_form=True),
+                "check": "d image / d albedo(r,g,b), %s %dx%d spp=%d PathTracer(max_depth=%d), HIP vs CPU oracle on the same sample streams; rel_l2 = against "
+                         "fp64 in the reference's literal forms" % (args.scene, gres, gres, gspp, args.max_depth)}
 
     if rank == 0:
         out = {
@@ -226,10 +351,13 @@ def main():
             "value": round(value, 3), "unit": "Mpath-samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s %dx%d spp=%d/GPU PathTracer(max_depth=%d) renderC + renderD(fwd, K=3) w.r.t. diffuse albedo"
+            "config": {"workload": "%s %dx%d spp=%d/GPU PathTracer(max_depth=%d): renderC + configure + renderD + enoki.forward w.r.t. diffuse albedo, through the psdr_cuda surface"
                                    % (args.scene, args.res, args.res, args.spp, args.max_depth),
-                       "triangles": int(tb["num_tris"]), "global_spp": args.spp * world,
-                       "parallelism": "spp-shard x%d, one all-reduce per render call" % world},
+                       "triangles": int(w.tb["num_tris"]), "global_spp": args.spp * world, "world_size": world,
+                       "device": torch.cuda.get_device_name(local_rank), "local_rank": local_rank,
+                       "allreduce_bytes_per_step": 0 if world == 1 else int(args.res * args.res * 3 * 4 * 3),
+                       "parallelism": "spp-shard x%d, one all-reduce per render call ([image] for renderC, [image || derivative image] for renderD)" % world},
+            "surface": surface, "kernel_only": kernel_only,
             "roofline": roofline, "cpu_baseline": cpu, "grad_rel_l2": grad,
         }
         print(json.dumps(out))

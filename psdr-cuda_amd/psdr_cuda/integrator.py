@@ -53,10 +53,38 @@ class _RenderNode:
         return [self.tb.get(k) for k in _AD_KEYS] if self.tb is not None else [None] * len(_AD_KEYS)
 
     def render_forward(self, tangents):
-        return self.integrator._render_fwd(self.scene, self.tb, self.opts, self.guide, [tangents])[1][0].reshape(-1, 3)
+        img, dimgs = self.integrator._render_fwd(self.scene, self.tb, self.opts, self.guide, [tangents])
+        self.primal = img.reshape(-1, 3)           # by-product of the forward-mode launch: renderD's value
+        return dimgs[0].reshape(-1, 3)
 
     def release(self):
         pass
+
+
+class _LazyImage(Vector3fD):
+    """What renderD returns when a scene parameter requires a gradient: the image is rendered when it is first
+    LOOKED AT.  `renderD(); enoki.forward(P); enoki.gradient(img)` -- the reference harness' sequence,
+    examples/run_test.py:95-142 -- then costs ONE launch (the forward-mode kernel produces image and derivative image
+    together) instead of a primal launch plus a forward-mode launch; any other use (numpy(), a torch loss for
+    enoki.backward) renders the primal through the autograd bridge on first access of `.t`."""
+
+    @classmethod
+    def _make(cls, node, inputs):
+        o = cls.__new__(cls)
+        o._node, o._inputs, o._t = node, inputs, None
+        return o
+
+    @property
+    def t(self):
+        if self._t is None:
+            primal = getattr(self._node, "primal", None)
+            self._t = primal if primal is not None else _RenderFn.apply(self._node, *self._inputs)
+            self._inputs = None
+        return self._t
+
+    @t.setter
+    def t(self, v):
+        self._t = v
 
 
 class _RenderFn(torch.autograd.Function):
@@ -127,7 +155,7 @@ class Integrator(Object):
         # the tree on the handle belongs to ONE set of tables: rebuild / refit whenever the tables submitted now are
         # not the ones it was built for (a renderD result differentiated after a later configure() brings its own,
         # older tables back -- and the next render call the newer ones again)
-        stamp = tb.get("version", scene._version)
+        stamp = tb.get("geo_version", scene._version)      # a material-only configure() keeps the geometry stamp
         if getattr(scene, "_bvh_version", None) != stamp:
             _abi.check(lib, lib.psdr_bvh_build(scene._native, _stream_ptr()))
             scene._bvh_version = stamp
@@ -216,13 +244,12 @@ class Integrator(Object):
         node = _RenderNode(self, scene, sensor_id, tb, opts, guide)
         inputs = node.input_tensors()
         if any(t is not None and t.requires_grad for t in inputs):
-            img_t = _RenderFn.apply(node, *inputs)
+            img = _LazyImage._make(node, inputs)           # rendered on first use (see _LazyImage)
         else:
-            img_t = self._render_c(scene, tb, opts, guide, interior_only=True).reshape(-1, 3)
-        torch.cuda.synchronize()
+            img = Vector3fD._wrap(self._render_c(scene, tb, opts, guide, interior_only=True).reshape(-1, 3))
+            img._node = node
+            torch.cuda.synchronize()
         self._advance_rng(scene, opts)
-        img = Vector3fD._wrap(img_t)
-        img._node = node
         ek.register_render_node(img)
         if scene.opts.log_level:
             self.log("Rendered in %g seconds." % (time.perf_counter() - t0))

@@ -266,3 +266,57 @@ def test_batched_configure_equals_mesh_by_mesh_and_tracks_topology_changes():
     sc.configure()
     after = sc.tables(0)["tri_info"][0, 18:21]
     assert torch.allclose(after, -before, atol=1e-6)     # flipped winding -> flipped face normal
+
+
+def test_material_only_configure_reuses_the_geometry_tables():
+    """Scene.configure() rebuilds only the texel pool when nothing but BSDF parameters changed (Scene._static_key),
+    and everything when a vertex / transform / camera / option changed or carries a gradient."""
+    import torch
+    import enoki as ek
+    from enoki.cuda_autodiff import Float32 as FloatD, Vector3f as Vector3fD, Matrix4f as Matrix4fD
+    from helpers import load_scene
+    sc, _ = load_scene("cbox_occluder", res=16, spp=2, sppe=2, sppse=2)
+    t0 = sc.tables(0)
+    refl = sc.param_map["BSDF[0]"].reflectance
+    refl.data = Vector3fD([0.1, 0.2, 0.3])
+    sc.configure()
+    t1 = sc.tables(0)
+    assert t1["tri_info"] is t0["tri_info"] and t1["sec_edge"] is t0["sec_edge"] and t1["cam"] is t0["cam"]     # reused
+    assert t1["geo_version"] == t0["geo_version"] and t1["version"] != t0["version"]
+    assert torch.allclose(t1["texels"][:3], torch.tensor([0.1, 0.2, 0.3])) and not torch.equal(t1["texels"], t0["texels"])
+    fresh, _ = load_scene("cbox_occluder", res=16, spp=2, sppe=2, sppse=2)
+    fresh.param_map["BSDF[0]"].reflectance.data = Vector3fD([0.1, 0.2, 0.3])
+    fresh.configure()
+    tf = fresh.tables(0)
+    for k, v in tf.items():
+        if isinstance(v, torch.Tensor):
+            assert torch.equal(v, t1[k]), k
+        elif k not in ("version", "geo_version"):
+            assert v == t1[k], k
+    # a material parameter WITH a gradient still takes the fast path (the geometry carries none) and keeps its graph
+    P = FloatD(0.)
+    ek.set_requires_gradient(P)
+    refl.data = Vector3fD([0.1, 0.2, 0.3]) + P
+    sc.configure()
+    t2 = sc.tables(0)
+    assert t2["tri_info"] is t0["tri_info"] and t2["texels"].requires_grad
+    # geometry changes: a transform, a vertex tensor written in place, an option
+    sc.param_map["Mesh[1]"].set_transform(Matrix4fD.translate(Vector3fD([1.0, 0.0, 0.0])))
+    sc.configure()
+    t3 = sc.tables(0)
+    assert t3["tri_info"] is not t0["tri_info"] and not torch.equal(t3["tri_info"], t0["tri_info"]) and t3["geo_version"] != t0["geo_version"]
+    sc.m_meshes[0]._vertex_positions_raw[0, 0] += 1.0          # in place: same tensor, new version counter
+    sc.configure()
+    t4 = sc.tables(0)
+    assert not torch.equal(t4["tri_info"], t3["tri_info"])
+    sc.opts.sppse = 0
+    sc.configure()
+    assert sc.tables(0)["num_sec_edges"] == 0
+    # a geometry parameter with a gradient: never cached
+    Q = FloatD(0.)
+    ek.set_requires_gradient(Q)
+    sc.param_map["Mesh[1]"].set_transform(Matrix4fD.translate(Vector3fD([1.0, 0.0, 0.0]) * Q))
+    sc.configure()
+    a = sc.tables(0)["tri_info"]
+    sc.configure()
+    assert sc.tables(0)["tri_info"] is not a and sc.tables(0)["tri_info"].requires_grad

@@ -1,6 +1,8 @@
 #!/usr/bin/env python
 """Developer tool (GPU box): where the GPU-vs-fp64-oracle difference of the vertex-gradient projections comes from --
-per term (interior / primary edge / secondary edge), GPU reverse and forward mode against the oracle in fp32 and fp64."""
+per term (interior / primary edge / secondary edge): the oracle in fp32 in the reference's LITERAL forms, the oracle in fp32 in
+the product's robust forms, GPU forward and reverse mode -- all against the oracle in fp64, literal forms (the exact
+value of the reference's estimator).  Columns are errors relative to sum|A dI| of the term."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in ("psdr-cuda_amd", "oracle", "tests", "tests/golden"):
@@ -37,13 +39,15 @@ for name, (a_, b_, c_) in (("interior", (spp, 0, 0)), ("primary", (0, spp, 0)), 
         tan = dict(zip(AD_KEYS, _jvp_wrt([tb2.get(k) for k in AD_KEYS], P)))
         d64 = oracle.render(tb2, o, mode=1, tangents=tan, precision=1)[1].astype(np.float64)
         d32 = oracle.render(tb2, o, mode=1, tangents=tan, precision=0)[1].astype(np.float64)
+        d32lit = oracle.render(tb2, o, mode=1, tangents=tan, precision=0, reference_form=True)[1].astype(np.float64)
+        d64 = oracle.render(tb2, o, mode=1, tangents=tan, precision=1, reference_form=True)[1].astype(np.float64)
         dg = g.render_d_fwd(o, [tan])[1][0].astype(np.float64)
         A = adj.astype(np.float64)
-        b64, b32, af = (A * d64).sum(), (A * d32).sum(), (A * dg).sum()
+        b64, b32, af, b32lit = (A * d64).sum(), (A * d32).sum(), (A * dg).sum(), (A * d32lit).sum()
         ar = float((gV * fields[i].double()).sum())
         sc_ = np.abs(A * d64).sum()
-        rows.append((b64, (b32 - b64) / sc_, (af - b64) / sc_, (ar - b64) / sc_, (ar - af) / sc_, sc_))
+        rows.append((b64, (b32lit - b64) / sc_, (b32 - b64) / sc_, (af - b64) / sc_, (ar - b64) / sc_, (ar - af) / sc_, sc_))
     print("== %s  (errors relative to sum|A dI|)" % name)
-    print("      b_fp64        oracle32-64   gpu_fwd-64    gpu_rev-64    gpu_rev-fwd   scale")
+    print("      b_fp64(lit)   fp32lit-64    fp32robust-64 gpu_fwd-64    gpu_rev-64    gpu_rev-fwd   scale")
     for r in rows:
-        print("  %+.6e  %+.2e  %+.2e  %+.2e  %+.2e  %.3e" % r)
+        print("  %+.6e  %+.2e  %+.2e  %+.2e  %+.2e  %+.2e  %.3e" % r)
