@@ -68,3 +68,55 @@ def make_interior_scene(seed=0, n_objects=10, res=64, spp=4, sppe=0, sppse=0):
         add("bunny/bunny_low.obj", b, xf, face_normals=False, mid="bunny%d" % i)
     sc.finalize()
     return sc
+
+
+def make_tree_scene(seed=0, n_leaves=600, res=64, spp=0, sppe=0, sppse=16):
+    """Stand-in for the reference's `tree` scenario (examples/config.py:90-109; its 24 130-face tree0.obj is not shipped):
+    an area light, a seeded procedural tree -- a six-sided trunk plus `n_leaves` free-standing leaf triangles, i.e. almost
+    only BOUNDARY edges -- and a ground plane.  Like the reference's harness (run_test.py:56-58, "no_edge": [0, 2]) the
+    light and the plane are loaded with enable_edges = False, so every secondary edge belongs to the tree.
+    Returns an unconfigured Scene; Mesh[1] is the tree."""
+    import numpy as np
+    from . import Scene, Mesh, Diffuse, PerspectiveCamera
+    from .scene import look_at
+    rng = np.random.default_rng(seed)
+    sc = Scene()
+    sc.opts.width = sc.opts.height = res
+    sc.opts.spp, sc.opts.sppe, sc.opts.sppse, sc.opts.log_level = spp, sppe, sppse, 0
+    cam = PerspectiveCamera(30.0, 0.01, 1e4)
+    cam.to_world = look_at([0.0, 8.0, 30.0], [0.0, 6.0, 0.0], [0.0, 1.0, 0.0])
+    sc.add_sensor(cam)
+
+    def bsdf(rgb, name):
+        b = Diffuse(list(rgb)); b.id = name; sc.add_bsdf(b); return b
+    black, grey, green = bsdf((0, 0, 0), "light"), bsdf((0.7, 0.7, 0.7), "floor"), bsdf((0.4, 0.55, 0.4), "tree")
+
+    def add(verts, faces, b, edges, emitter=None, mid=""):
+        m = Mesh()
+        m.set_geometry(np.asarray(verts, dtype=np.float32), np.asarray(faces, dtype=np.int32), fname="<%s>" % mid)
+        m.use_face_normals, m.enable_edges, m.id = True, edges, mid
+        sc.add_mesh(m, b, emitter)
+    # light: a 6 x 6 quad up and to the right, facing the crown
+    c, n = np.array([9.0, 17.0, 9.0]), np.array([-9.0, -9.0, -9.0]) / np.sqrt(243.0)
+    a = np.cross(n, [0.0, 1.0, 0.0]); a /= np.linalg.norm(a); b_ = np.cross(n, a)
+    add([c - 3 * a - 3 * b_, c + 3 * a - 3 * b_, c + 3 * a + 3 * b_, c - 3 * a + 3 * b_], [[0, 1, 2], [0, 2, 3]], black, False,
+        emitter=[400.0, 400.0, 400.0], mid="light")
+    # tree: trunk (closed six-sided prism) + leaves
+    verts, faces = [], []
+    for k in range(6):
+        ang = 2 * np.pi * k / 6
+        verts += [[0.5 * np.cos(ang), 0.0, 0.5 * np.sin(ang)], [0.35 * np.cos(ang), 6.0, 0.35 * np.sin(ang)]]
+    for k in range(6):
+        i0, i1, j0, j1 = 2 * k, 2 * k + 1, 2 * ((k + 1) % 6), 2 * ((k + 1) % 6) + 1
+        faces += [[i0, i1, j1], [i0, j1, j0]]
+    for _ in range(n_leaves):
+        ctr = np.array([0.0, 8.5, 0.0]) + rng.normal(size=3) * np.array([2.2, 1.6, 2.2])
+        d1, d2 = rng.normal(size=3), rng.normal(size=3)
+        d1 *= rng.uniform(0.35, 0.7) / np.linalg.norm(d1); d2 *= rng.uniform(0.35, 0.7) / np.linalg.norm(d2)
+        i = len(verts)
+        verts += [list(ctr), list(ctr + d1), list(ctr + d2)]
+        faces.append([i, i + 1, i + 2])
+    add(verts, faces, green, True, mid="tree")
+    add([[-25, 0, -25], [-25, 0, 25], [25, 0, 25], [25, 0, -25]], [[0, 1, 2], [0, 2, 3]], grey, False, mid="plane")
+    sc.finalize()
+    return sc
