@@ -10,6 +10,86 @@
 
 namespace psdr {
 
+// -------------------------------------------------------------------- tiny-scene primitives
+// The triangles of a tiny scene travel in the kernel arguments (SceneView::tiny) and every ray tests all of them.  Two
+// triangles that form a PARALLELOGRAM -- a wall of the Cornell box, fan-triangulated (a, b, c), (a, c, d) -- are tested as
+// ONE primitive: Moeller-Trumbore on (p0, e1, e2) = (b, a - b, c - b), the corner that belongs to one triangle only and
+// the edges to the shared diagonal, yields the plane coordinates (s, t) of the hit; 0 <= s, t <= 1 is the parallelogram,
+// s + t <= 1 the first triangle, otherwise the second; the barycentrics of either triangle are an affine map of (s, t)
+// with coefficients in {-1, 0, 1} (a lone triangle is a primitive whose map is the identity: bit-identical to the leaf
+// test).  12 wall triangles -> 6 tests on the Cornell box.  Pairs are formed only when all four corners are exact in
+// fp32 (p0 + e1, p0 + e2, p0 + e1 + e2 reproduce the stored vertices).
+//   prim = (p0 | idA + (idB << 16), idB = 0xffff: none), (e1 | codeA), (e2 | codeB)
+//   u = k0 + k1 s + k2 t,  v = k3 + k4 s + k5 t,  code = sum (k_i + 2) << 3 i
+inline void pack_tiny_prims(const std::vector<float4> &tris, std::vector<float4> &prims) {
+    const int n = (int) tris.size() / 3;
+    std::vector<char> used((size_t) n, 0);
+    struct V { float x[3]; bool operator==(const V &o) const { return x[0] == o.x[0] && x[1] == o.x[1] && x[2] == o.x[2]; } };
+    auto vtx = [&](int t, int k) {
+        const float4 &a = tris[(size_t) t * 3], &b = tris[(size_t) t * 3 + 1], &c = tris[(size_t) t * 3 + 2];
+        V v{{a.x, a.y, a.z}};
+        if (k == 1) { v.x[0] += b.x; v.x[1] += b.y; v.x[2] += b.z; }
+        if (k == 2) { v.x[0] += c.x; v.x[1] += c.y; v.x[2] += c.z; }
+        return v;
+    };
+    auto tri_id = [&](int t) { int32_t id; std::memcpy(&id, &tris[(size_t) t * 3].w, 4); return id; };
+    // barycentric map of a triangle whose vertices sit at the plane coordinates c[0..2] (each 0 = (0,0), 1 = (1,0), 2 = (0,1), 3 = (1,1))
+    auto map_code = [](const int c[3], int32_t &code) {
+        static const int cs[4] = {0, 1, 0, 1}, ct[4] = {0, 0, 1, 1};
+        const int a = cs[c[1]] - cs[c[0]], b = cs[c[2]] - cs[c[0]], cc = ct[c[1]] - ct[c[0]], d = ct[c[2]] - ct[c[0]];
+        const int det = a * d - b * cc;
+        if (det != 1 && det != -1) return false;
+        const int m00 = d * det, m01 = -b * det, m10 = -cc * det, m11 = a * det;          // inverse of [[a, b], [cc, d]]
+        const int k[6] = {-(m00 * cs[c[0]] + m01 * ct[c[0]]), m00, m01, -(m10 * cs[c[0]] + m11 * ct[c[0]]), m10, m11};
+        code = 0;
+        for (int q = 0; q < 6; ++q) code |= (k[q] + 2) << (3 * q);
+        return true;
+    };
+    prims.clear();
+    for (int i = 0; i < n; ++i) {
+        if (used[i]) continue;
+        used[i] = 1;
+        bool paired = false;
+        for (int j = i + 1; j < n && !paired; ++j) {
+            if (used[j]) continue;
+            for (int k0 = 0; k0 < 3 && !paired; ++k0) {          // k0: the vertex of i that is NOT on the shared diagonal
+                const V p0 = vtx(i, k0), s1 = vtx(i, (k0 + 1) % 3), s2 = vtx(i, (k0 + 2) % 3);
+                V e1, e2, c1, c2, c3;
+                for (int a = 0; a < 3; ++a) {
+                    e1.x[a] = s1.x[a] - p0.x[a]; e2.x[a] = s2.x[a] - p0.x[a];
+                    c1.x[a] = p0.x[a] + e1.x[a]; c2.x[a] = p0.x[a] + e2.x[a]; c3.x[a] = e1.x[a] + (e2.x[a] + p0.x[a]);      // bary_point order
+                }
+                if (!(c1 == s1) || !(c2 == s2)) continue;
+                const V corner[4] = {p0, s1, s2, c3};
+                int ca[3], cb[3];
+                bool ok = true;
+                for (int k = 0; k < 3 && ok; ++k) {
+                    ca[k] = cb[k] = -1;
+                    const V va = vtx(i, k), vb = vtx(j, k);
+                    for (int q = 0; q < 4; ++q) { if (va == corner[q]) ca[k] = q; if (q > 0 && vb == corner[q]) cb[k] = q; }
+                    ok = ca[k] >= 0 && cb[k] > 0;
+                }
+                if (!ok || cb[0] == cb[1] || cb[0] == cb[2] || cb[1] == cb[2]) continue;
+                int32_t codeA, codeB;
+                if (!map_code(ca, codeA) || !map_code(cb, codeB)) continue;
+                float4 a{p0.x[0], p0.x[1], p0.x[2], 0.f}, b{e1.x[0], e1.x[1], e1.x[2], 0.f}, c{e2.x[0], e2.x[1], e2.x[2], 0.f};
+                const int32_t ids = tri_id(i) | (tri_id(j) << 16);
+                std::memcpy(&a.w, &ids, 4); std::memcpy(&b.w, &codeA, 4); std::memcpy(&c.w, &codeB, 4);
+                prims.push_back(a); prims.push_back(b); prims.push_back(c);
+                used[j] = 1; paired = true;
+            }
+        }
+        if (!paired) {                                             // lone triangle: identity map
+            float4 a = tris[(size_t) i * 3], b = tris[(size_t) i * 3 + 1], c = tris[(size_t) i * 3 + 2];
+            const int cid[3] = {0, 1, 2};
+            int32_t code; map_code(cid, code);
+            const int32_t ids = tri_id(i) | (0xffff << 16);
+            std::memcpy(&a.w, &ids, 4); std::memcpy(&b.w, &code, 4); std::memcpy(&c.w, &code, 4);
+            prims.push_back(a); prims.push_back(b); prims.push_back(c);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------- BVH builder
 // Host binned-SAH builder (replaces the OptiX GAS build, include/psdr/scene/optix.h:277-340).
 // Scenes of this path are small (12 .. ~50k triangles) and the tree is rebuilt on every

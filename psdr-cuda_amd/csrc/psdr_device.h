@@ -130,15 +130,50 @@ PSDR_HD void leaf_triangle_test(const float4 &a, const float4 &b, const float4 &
 
 // Replaces __raygen__/__closesthit__/__miss__ (cuda/psdr_cuda.cu:9-45): closest hit with
 // t in [RayEpsilon, tmax], both faces; (u,v) = barycentric weights of vertex 1 and 2.
+// One primitive of a tiny scene (psdr_bvh_build.h pack_tiny_prims): a triangle or a parallelogram of two triangles.
+// best.(u, v) hold the plane coordinates (s, t) of the primitive; (ids, code) remember the winning primitive's triangle
+// ids and barycentric map; resolve_tiny_hit turns them into (triangle, u, v) once per ray.
+template <bool IGN = false>
+PSDR_HD void tiny_prim_test(const float4 &a, const float4 &b, const float4 &c, const Vec3f &o, const Vec3f &d, Hit &best, int &ids, int &codeA, int &codeB,
+                            int ig0 = -1, int ig1 = -1) {
+    const Vec3f e1{b.x, b.y, b.z}, e2{c.x, c.y, c.z};
+    const Vec3f h = cross(d, e2);
+    const float det = dot(e1, h);
+    const float f = 1.f / det;
+    const Vec3f s{o.x - a.x, o.y - a.y, o.z - a.z};
+    const float u = f * dot(s, h);
+    const Vec3f q = cross(s, e1);
+    const float v = f * dot(d, q);
+    const float t = f * dot(e2, q);
+    const int id2 = __float_as_int_hd(a.w);                        // wave-uniform (kernel argument)
+    const bool quad = ((uint32_t) id2 >> 16) != 0xffffu;
+    const bool inside = quad ? (u <= 1.f && v <= 1.f) : (u + v <= 1.f);
+    bool hit = u >= 0.f && v >= 0.f && inside && t >= kRayEpsilon && t < best.t;
+    if (IGN) { const int id = (quad && u + v > 1.f) ? (int) ((uint32_t) id2 >> 16) : (id2 & 0xffff); hit = hit && id != ig0 && id != ig1; }
+    if (hit) { best.t = t; best.u = u; best.v = v; ids = id2; codeA = __float_as_int_hd(b.w); codeB = __float_as_int_hd(c.w); }
+}
+PSDR_HD void resolve_tiny_hit(Hit &best, int ids, int codeA, int codeB) {
+    if (ids == -1) return;                                          // no hit
+    const bool second = ((uint32_t) ids >> 16) != 0xffffu && best.u + best.v > 1.f;
+    const int code = second ? codeB : codeA;
+    auto k = [&](int i) { return (float) (((code >> (3 * i)) & 7) - 2); };
+    const float s = best.u, t = best.v;
+    best.tri = second ? (int) ((uint32_t) ids >> 16) : (ids & 0xffff);
+    best.u = k(0) + (k(1) * s + k(2) * t);
+    best.v = k(3) + (k(4) * s + k(5) * t);
+}
+
 template <bool IGN = false>
 PSDR_HD Hit closest_hit(const SceneView &sc, TraversalStack &st, const Vec3f &o, const Vec3f &d, float tmax, int ig0 = -1, int ig1 = -1) {
     Hit best; best.tri = -1; best.u = best.v = -1.f;
     best.t = (tmax > 0.f && tmax < INFINITY) ? __int_as_float_hd(__float_as_int_hd(tmax) + 1) : tmax;   // accept t <= tmax
     if (sc.n_tiny > 0) {
-        // unrolled by 12 (six quads, the Cornell box): the scalar loads of the following triangles are in flight
-        // while one is tested (+3.5 % on C2; by 4: +2 %, by 6: the K = 3 kernel spills)
-#pragma unroll 12
-        for (int i = 0; i < sc.n_tiny; ++i) leaf_triangle_test<IGN>(sc.tiny[i * 3], sc.tiny[i * 3 + 1], sc.tiny[i * 3 + 2], o, d, best, ig0, ig1);
+        // n_tiny PRIMITIVES (triangles, or parallelograms of two triangles: pack_tiny_prims), unrolled by 6 (the six
+        // walls of the Cornell box): the scalar loads of the following primitives are in flight while one is tested
+        int ids = -1, codeA = 0, codeB = 0;
+#pragma unroll 6
+        for (int i = 0; i < sc.n_tiny; ++i) tiny_prim_test<IGN>(sc.tiny[i * 3], sc.tiny[i * 3 + 1], sc.tiny[i * 3 + 2], o, d, best, ids, codeA, codeB, ig0, ig1);
+        resolve_tiny_hit(best, ids, codeA, codeB);
         return best;
     }
     const Vec3f inv{1.f / d.x, 1.f / d.y, 1.f / d.z};

@@ -393,8 +393,13 @@ int psdr_bvh_build(psdr_scene_t h, void *stream) {
     h->root = root;
     h->bvh_depth = b.max_depth; h->num_nodes = (int) b.nodes.size(); h->num_btris = (int) b.btris.size() / 3;
     h->have_bvh = true;
-    h->n_tiny = tiny ? h->num_btris : 0;
-    if (tiny) std::memcpy(h->tiny, b.btris.data(), b.btris.size() * sizeof(float4));
+    h->n_tiny = 0;
+    if (tiny) {
+        std::vector<float4> prims;
+        pack_tiny_prims(b.btris, prims);           // walls as parallelograms: half the tests
+        h->n_tiny = (int) prims.size() / 3;
+        std::memcpy(h->tiny, prims.data(), prims.size() * sizeof(float4));
+    }
     // what the refit path needs: the levels of the breadth-first node order, the padding, the reference area
     h->tree_tris = T; h->refits_since_build = 0; h->num_builds++; h->bvh_pad = b.pad;
     h->level_start.clear();

@@ -115,7 +115,18 @@ class Integrator(Object):
     def __init__(self):
         super().__init__()
         self._guide = {}
-        self.last_counters = None
+        self._counters_src, self._counters_val, self._calls = None, None, 0
+
+    @property
+    def last_counters(self):
+        """(rays traced, camera / primary-edge / secondary-edge slots) of the last render call; read from the device on
+        first access (a host synchronisation -- the render calls themselves do not wait for the GPU)."""
+        if self._counters_val is None and self._counters_src is not None:
+            lib, scene = self._counters_src
+            c = (C.c_uint64 * 4)()
+            lib.psdr_get_counters(scene._native, c)
+            self._counters_val = tuple(int(x) for x in c)
+        return self._counters_val
 
     # ---- option block -----------------------------------------------------------
     def _opts(self, scene, with_edges):
@@ -214,9 +225,12 @@ class Integrator(Object):
         return grads
 
     def _counters(self, lib, scene):
-        c = (C.c_uint64 * 4)()
-        lib.psdr_get_counters(scene._native, c)
-        self.last_counters = tuple(int(x) for x in c)
+        """The counters stay on the device until somebody looks (last_counters); the library's fused-vs-wavefront choice
+        for PathTracer calls feeds on them, so the first calls on a scene and every 64th fetch them."""
+        self._counters_src, self._counters_val = (lib, scene), None
+        self._calls += 1
+        if self._kind == _abi.INTEGRATOR_PATH and (self._calls <= 2 or self._calls % 64 == 0):
+            _ = self.last_counters
 
     # ---- public API (src/psdr.cpp:282-285) -------------------------------------------
     def renderC(self, scene, sensor_id=0):
@@ -226,9 +240,9 @@ class Integrator(Object):
         tb = scene.tables(sensor_id)
         opts = self._opts(scene, with_edges=False)
         img = self._render_c(scene, tb, opts, None)
-        torch.cuda.synchronize()
         self._advance_rng(scene, opts)
         if scene.opts.log_level:
+            torch.cuda.synchronize()                     # only the log line needs the time; the image is stream-ordered
             self.log("Rendered in %g seconds." % (time.perf_counter() - t0))
         return Vector3fC._wrap(img.reshape(-1, 3))
 
@@ -248,10 +262,10 @@ class Integrator(Object):
         else:
             img = Vector3fD._wrap(self._render_c(scene, tb, opts, guide, interior_only=True).reshape(-1, 3))
             img._node = node
-            torch.cuda.synchronize()
         self._advance_rng(scene, opts)
         ek.register_render_node(img)
         if scene.opts.log_level:
+            torch.cuda.synchronize()
             self.log("Rendered in %g seconds." % (time.perf_counter() - t0))
         return img
 

@@ -26,8 +26,10 @@ bool setup(HostScene &hs, const psdr_scene_desc *d) {
     // tiny scenes take the all-triangles path of closest_hit, as psdr_bvh_build arranges on the device
     const char *e = std::getenv("PSDR_TINY_SCENE");
     if (d->num_tris <= kTinyTris && !(e && std::atoi(e) == 0)) {
-        hs.sc.n_tiny = (int32_t) (hs.b.btris.size() / 3);
-        std::memcpy(hs.sc.tiny, hs.b.btris.data(), hs.b.btris.size() * sizeof(float4));
+        std::vector<float4> prims;
+        pack_tiny_prims(hs.b.btris, prims);
+        hs.sc.n_tiny = (int32_t) (prims.size() / 3);
+        std::memcpy(hs.sc.tiny, prims.data(), prims.size() * sizeof(float4));
     }
     return true;
 }

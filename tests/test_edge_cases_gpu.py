@@ -187,9 +187,10 @@ def test_trace_fuzz_random_triangle_soups(n_tris, seed):
 
 
 def test_tiny_scene_all_triangles_path_equals_the_tree_walk(monkeypatch):
-    """<= 16 triangles: the leaf triangles travel in the kernel arguments and closest_hit tests them all
-    (SceneView::tiny); PSDR_TINY_SCENE=0 walks the tree instead -- same hits bit for bit, same image, same
-    gradients; a 17-triangle scene takes the tree"""
+    """<= 16 triangles: the geometry travels in the kernel arguments and closest_hit tests all of it (SceneView::tiny),
+    two triangles of a wall as ONE parallelogram whose plane coordinates are mapped to the hit triangle's barycentrics
+    (pack_tiny_prims); PSDR_TINY_SCENE=0 walks the tree instead -- same triangles, barycentrics equal to rounding, same
+    image, same gradients; a 17-triangle scene takes the tree"""
     from helpers import camera_rays
     sc, _ = load_scene("cbox", res=48, spp=8)
     tb = sc.tables(0)
@@ -205,8 +206,9 @@ def test_tiny_scene_all_triangles_path_equals_the_tree_walk(monkeypatch):
     (sa, ta, ua, va), (sb, tb_, ub, vb) = out["1"][0], out["0"][0]
     same = ta == tb_
     assert same.mean() > 0.9999                            # only rays through an edge shared by two triangles may differ
-    assert (ua[same] == ub[same]).all() and (va[same] == vb[same]).all() and (sa[same] == sb[same]).all()
-    assert rel_l2(out["1"][1], out["0"][1]) < 1e-6
+    print("tiny vs tree barycentrics: max |du| %.1e |dv| %.1e, triangles differ on %.1e of the rays" % (np.abs(ua[same] - ub[same]).max(), np.abs(va[same] - vb[same]).max(), 1 - same.mean()))
+    assert np.abs(ua[same] - ub[same]).max() < 1e-5 and np.abs(va[same] - vb[same]).max() < 1e-5 and (sa[same] == sb[same]).all()
+    assert rel_l2(out["1"][1], out["0"][1]) < 1e-5
     for k in ("tri_info", "texels"):
         assert rel_l2(out["1"][2][k], out["0"][2][k]) < 1e-4, k
 
