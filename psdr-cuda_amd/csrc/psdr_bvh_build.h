@@ -264,4 +264,137 @@ struct Builder {
 };
 
 
+// ------------------------------------------------------------------- two-level tree (forest)
+// Scenes made of a few small meshes (walls, lights) and a few large ones (objects): every mesh with at least
+// kMinBlasTris triangles gets its OWN tree; the triangles of the others stay "inline" (tested by every ray in a
+// wave-uniform loop, SceneView::tiny).  The trees share one node array, ordered by LEVEL across the forest (all
+// roots first, then all depth-1 nodes, ...): a prefix is still "the top of every tree" (LDS staging) and a level is
+// still one contiguous range (device refit, bottom-up).  Used when the scene fits the kernel-argument tables:
+// <= kTinyTris inline triangles and 1..kMaxBlas trees; otherwise the single tree above serves the scene.
+struct ForestBuilder {
+    std::vector<BvhNode> nodes;
+    std::vector<float4> btris;
+    std::vector<float4> inline_tris;          // p0 | id, e1, e2 per inline triangle
+    std::vector<int32_t> inline_ids;
+    std::vector<int32_t> roots;               // encoded like a child, one per tree
+    std::vector<int> level_start;
+    int max_depth = 0;
+    float pad = 0.f;
+
+    static bool eligible(const int32_t *tri_mesh, int T, int num_meshes) {
+        std::vector<int> cnt((size_t) std::max(num_meshes, 1), 0);
+        for (int i = 0; i < T; ++i) {
+            const int m = tri_mesh[i] & ~PSDR_TRI_FACE_NORMALS;
+            if (m < 0 || m >= num_meshes) return false;
+            cnt[m]++;
+        }
+        int n_inline = 0, n_blas = 0;
+        for (int c : cnt) { if (c >= kMinBlasTris) n_blas++; else n_inline += c; }
+        return n_blas >= 1 && n_blas <= kMaxBlas && n_inline <= 2 * kTinyTris;      // primitives after pairing are checked by the caller
+    }
+
+    const char *run(const float *rows, const int32_t *tri_mesh, int T, int num_meshes) {
+        std::vector<std::vector<int32_t>> ids((size_t) num_meshes);
+        for (int i = 0; i < T; ++i) ids[tri_mesh[i] & ~PSDR_TRI_FACE_NORMALS].push_back(i);
+        // the padding of the whole scene (Builder::run derives it from ITS triangles): one value for every tree
+        float slo[3] = {INFINITY, INFINITY, INFINITY}, shi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int i = 0; i < T; ++i) {
+            const float *r = rows + (size_t) i * PSDR_TRI_STRIDE;
+            for (int k = 0; k < 3; ++k) {
+                const float p = r[k], q = r[k] + r[3 + k], w = r[k] + r[6 + k];
+                if (!std::isfinite(p) || !std::isfinite(q) || !std::isfinite(w)) return "psdr_bvh_build: non-finite vertex";
+                slo[k] = std::min(slo[k], std::min(p, std::min(q, w))); shi[k] = std::max(shi[k], std::max(p, std::max(q, w)));
+            }
+        }
+        pad = std::max(1e-6f, 1e-5f * std::max(shi[0] - slo[0], std::max(shi[1] - slo[1], shi[2] - slo[2])));
+        struct Tree { std::vector<BvhNode> nodes; std::vector<int> depth; int32_t root; int btri_base; };
+        std::vector<Tree> trees;
+        std::vector<float> sub;
+        for (int m = 0; m < num_meshes; ++m) {
+            const std::vector<int32_t> &id = ids[m];
+            if ((int) id.size() < kMinBlasTris) {
+                for (int32_t t : id) {
+                    const float *r = rows + (size_t) t * PSDR_TRI_STRIDE;
+                    float4 a{r[0], r[1], r[2], 0.f};
+                    std::memcpy(&a.w, &t, 4);
+                    inline_tris.push_back(a); inline_tris.push_back(float4{r[3], r[4], r[5], 0.f}); inline_tris.push_back(float4{r[6], r[7], r[8], 0.f});
+                    inline_ids.push_back(t);
+                }
+                continue;
+            }
+            sub.resize(id.size() * PSDR_TRI_STRIDE);
+            for (size_t i = 0; i < id.size(); ++i) std::memcpy(&sub[i * PSDR_TRI_STRIDE], rows + (size_t) id[i] * PSDR_TRI_STRIDE, PSDR_TRI_STRIDE * sizeof(float));
+            Builder b;
+            int32_t root = 0;
+            if (const char *err = b.run(sub.data(), (int) id.size(), root)) return err;
+            // Builder padded its boxes with ITS pad; re-pad consistently is unnecessary (boxes only need to contain
+            // the triangles), but the device refit uses one pad: take the larger
+            pad = std::max(pad, b.pad);
+            Tree t; t.root = root; t.btri_base = (int) btris.size() / 3;
+            for (size_t i = 0; i < b.btris.size(); i += 3) {          // local -> global triangle ids
+                float4 a = b.btris[i];
+                int32_t local; std::memcpy(&local, &a.w, 4);
+                const int32_t global = id[(size_t) local];
+                std::memcpy(&a.w, &global, 4);
+                btris.push_back(a); btris.push_back(b.btris[i + 1]); btris.push_back(b.btris[i + 2]);
+            }
+            auto fix_leaf = [&](int32_t c) { if (c >= 0) return c; const int enc = ~c; return (int32_t) ~((((enc >> 3) + t.btri_base) << 3) | (enc & 7)); };
+            t.nodes = b.nodes;
+            t.depth.assign(t.nodes.size(), 0);
+            for (size_t i = 0; i < t.nodes.size(); ++i) {             // breadth-first order: children come after their parent
+                BvhNode &n = t.nodes[i];
+                if (n.c0 >= 0) t.depth[n.c0] = t.depth[i] + 1; else n.c0 = fix_leaf(n.c0);
+                if (n.c1 >= 0) t.depth[n.c1] = t.depth[i] + 1; else n.c1 = fix_leaf(n.c1);
+            }
+            if (t.root < 0) t.root = fix_leaf(t.root);
+            max_depth = std::max(max_depth, b.max_depth);
+            trees.push_back(std::move(t));
+        }
+        // forest-wide level order
+        std::vector<std::vector<int>> newid(trees.size());
+        int next = 0, level = 0;
+        bool any = true;
+        for (size_t k = 0; k < trees.size(); ++k) newid[k].assign(trees[k].nodes.size(), -1);
+        while (any) {
+            any = false;
+            level_start.push_back(next);
+            for (size_t k = 0; k < trees.size(); ++k)
+                for (size_t i = 0; i < trees[k].nodes.size(); ++i)
+                    if (trees[k].depth[i] == level) { newid[k][i] = next++; any = true; }
+            if (!any) level_start.pop_back();
+            ++level;
+        }
+        level_start.push_back(next);
+        nodes.assign((size_t) next, BvhNode{});
+        for (size_t k = 0; k < trees.size(); ++k) {
+            for (size_t i = 0; i < trees[k].nodes.size(); ++i) {
+                BvhNode n = trees[k].nodes[i];
+                if (n.c0 >= 0) n.c0 = newid[k][n.c0];
+                if (n.c1 >= 0) n.c1 = newid[k][n.c1];
+                nodes[(size_t) newid[k][i]] = n;
+            }
+            roots.push_back(trees[k].root >= 0 ? newid[k][trees[k].root] : trees[k].root);
+        }
+        if (max_depth > kBvhStack - 2) return "psdr_bvh_build: tree too deep for the traversal stack";
+        return nullptr;
+    }
+    // box of tree k = union of its root's child boxes (a single-leaf tree: the box of its triangles)
+    void tree_box(int k, float *lo, float *hi) const {
+        const int32_t r = roots[(size_t) k];
+        for (int a = 0; a < 3; ++a) { lo[a] = INFINITY; hi[a] = -INFINITY; }
+        if (r >= 0) {
+            const BvhNode &n = nodes[(size_t) r];
+            for (int a = 0; a < 3; ++a) { lo[a] = std::min(n.lo0[a], n.lo1[a]); hi[a] = std::max(n.hi0[a], n.hi1[a]); }
+        } else {
+            const int enc = ~r, first = enc >> 3, cnt = (enc & 7) + 1;
+            for (int i = 0; i < cnt; ++i) {
+                const float4 a = btris[(size_t) (first + i) * 3], b = btris[(size_t) (first + i) * 3 + 1], c = btris[(size_t) (first + i) * 3 + 2];
+                const float p[3] = {a.x, a.y, a.z}, q[3] = {a.x + b.x, a.y + b.y, a.z + b.z}, w[3] = {a.x + c.x, a.y + c.y, a.z + c.z};
+                for (int x = 0; x < 3; ++x) { lo[x] = std::min(lo[x], std::min(p[x], std::min(q[x], w[x]))); hi[x] = std::max(hi[x], std::max(p[x], std::max(q[x], w[x]))); }
+            }
+            for (int x = 0; x < 3; ++x) { lo[x] -= pad; hi[x] += pad; }
+        }
+    }
+};
+
 }  // namespace psdr

@@ -26,6 +26,8 @@ constexpr int kBvhStack = 40;     // builder guarantees depth <= kBvhStack - 2
 constexpr int kBlock = 256;
 
 constexpr int kTinyTris = 16;
+constexpr int kMaxBlas = 16;
+constexpr int kMinBlasTris = 64;      // meshes below this size stay inline in the top level
 struct SceneView {
     psdr_scene_desc d;
     const BvhNode *nodes;
@@ -41,6 +43,13 @@ struct SceneView {
     // segment into SGPRs, no tree, no per-lane node fetches, no stack traffic, no divergence between lanes.
     int32_t n_tiny;
     float4 tiny[kTinyTris * 3];
+    // Two-level tree (psdr_bvh_build.h ForestBuilder; scenes of a few small meshes plus a few large ones -- a room with
+    // objects): the triangles of the small meshes are the primitives above, every large mesh has its OWN tree in `nodes`,
+    // and its box + root travel in the kernel arguments too.  A closest-hit query first tests the inline primitives
+    // and the tree boxes in a wave-uniform loop (SGPR operands, no divergence); only a ray whose segment [0, t_best]
+    // enters a box walks that tree.  In a room most rays never do (cbox_bunny: 7-14 % of the bounce rays).
+    int32_t n_blas;
+    float4 blas_lo[kMaxBlas], blas_hi[kMaxBlas];      // lo.w = root of the tree (encoded like a child)
 };
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -163,26 +172,15 @@ PSDR_HD void resolve_tiny_hit(Hit &best, int ids, int codeA, int codeB) {
     best.v = k(3) + (k(4) * s + k(5) * t);
 }
 
+// Tree walk from `root` (encoded like a child), keeping the closer hit in `best` (strict: the first of equal hits wins).
+// "while-while" traversal: every lane first walks inner nodes until it holds a leaf (or is done), THEN
+// the wave tests leaf triangles together -- the two phases have very different lengths, and in one
+// merged loop lanes sitting at a leaf would idle through the others' node steps and vice versa.
 template <bool IGN = false>
-PSDR_HD Hit closest_hit(const SceneView &sc, TraversalStack &st, const Vec3f &o, const Vec3f &d, float tmax, int ig0 = -1, int ig1 = -1) {
-    Hit best; best.tri = -1; best.u = best.v = -1.f;
-    best.t = (tmax > 0.f && tmax < INFINITY) ? __int_as_float_hd(__float_as_int_hd(tmax) + 1) : tmax;   // accept t <= tmax
-    if (sc.n_tiny > 0) {
-        // n_tiny PRIMITIVES (triangles, or parallelograms of two triangles: pack_tiny_prims), unrolled by 6 (the six
-        // walls of the Cornell box): the scalar loads of the following primitives are in flight while one is tested
-        int ids = -1, codeA = 0, codeB = 0;
-#pragma unroll 6
-        for (int i = 0; i < sc.n_tiny; ++i) tiny_prim_test<IGN>(sc.tiny[i * 3], sc.tiny[i * 3 + 1], sc.tiny[i * 3 + 2], o, d, best, ids, codeA, codeB, ig0, ig1);
-        resolve_tiny_hit(best, ids, codeA, codeB);
-        return best;
-    }
-    const Vec3f inv{1.f / d.x, 1.f / d.y, 1.f / d.z};
+PSDR_HD void walk_tree(const SceneView &sc, TraversalStack &st, const Vec3f &o, const Vec3f &d, const Vec3f &inv, int32_t root, Hit &best, int ig0 = -1, int ig1 = -1) {
     int sp = 0;
-    int32_t cur = sc.root;
+    int32_t cur = root;
     constexpr int32_t kDone = 0x7fffffff;        // never a node index (node count < 2^28)
-    // "while-while" traversal: every lane first walks inner nodes until it holds a leaf (or is done), THEN
-    // the wave tests leaf triangles together -- the two phases have very different lengths, and in one
-    // merged loop lanes sitting at a leaf would idle through the others' node steps and vice versa.
     while (cur != kDone) {
         while (cur >= 0 && cur != kDone) {
             BvhNode n;
@@ -222,6 +220,49 @@ PSDR_HD Hit closest_hit(const SceneView &sc, TraversalStack &st, const Vec3f &o,
             cur = sp > 0 ? st.get(--sp) : kDone;
         }
     }
+}
+
+PSDR_HD bool blas_box(const SceneView &sc, int k, const Vec3f &o, const Vec3f &inv, float tmax, float &t_entry) {
+    const float lo[3] = {sc.blas_lo[k].x, sc.blas_lo[k].y, sc.blas_lo[k].z}, hi[3] = {sc.blas_hi[k].x, sc.blas_hi[k].y, sc.blas_hi[k].z};
+    return slab(lo, hi, o, inv, tmax, t_entry);
+}
+
+template <bool IGN = false>
+PSDR_HD Hit closest_hit(const SceneView &sc, TraversalStack &st, const Vec3f &o, const Vec3f &d, float tmax, int ig0 = -1, int ig1 = -1) {
+    Hit best; best.tri = -1; best.u = best.v = -1.f;
+    best.t = (tmax > 0.f && tmax < INFINITY) ? __int_as_float_hd(__float_as_int_hd(tmax) + 1) : tmax;   // accept t <= tmax
+    const Vec3f inv{1.f / d.x, 1.f / d.y, 1.f / d.z};
+    if (sc.n_tiny > 0 || sc.n_blas > 0) {
+        // n_tiny PRIMITIVES (triangles, or parallelograms of two triangles: pack_tiny_prims), unrolled by 6 (the six
+        // walls of the Cornell box): the scalar loads of the following primitives are in flight while one is tested
+        int ids = -1, codeA = 0, codeB = 0;
+#pragma unroll 6
+        for (int i = 0; i < sc.n_tiny; ++i) tiny_prim_test<IGN>(sc.tiny[i * 3], sc.tiny[i * 3 + 1], sc.tiny[i * 3 + 2], o, d, best, ids, codeA, codeB, ig0, ig1);
+        resolve_tiny_hit(best, ids, codeA, codeB);
+        // two-level tree: the trees whose box the segment [0, t_best] enters, NEAREST box first (a hit in a near object
+        // prunes the far ones); every round re-tests the remaining boxes against the current t_best -- wave-uniform
+        // loops over SGPR operands, 16 VALU instructions per box
+        if (sc.n_blas == 1) {
+            float te;
+            if (blas_box(sc, 0, o, inv, best.t, te)) walk_tree<IGN>(sc, st, o, d, inv, __float_as_int_hd(sc.blas_lo[0].w), best, ig0, ig1);
+            return best;
+        }
+        uint32_t cand = (1u << sc.n_blas) - 1u;
+        while (cand) {
+            int32_t root = 0; float near_t = INFINITY; uint32_t pick = 0;
+            for (int k = 0; k < sc.n_blas; ++k) {
+                if (!((cand >> k) & 1u)) continue;
+                float te;
+                if (!blas_box(sc, k, o, inv, best.t, te)) cand &= ~(1u << k);
+                else if (te < near_t) { near_t = te; root = __float_as_int_hd(sc.blas_lo[k].w); pick = 1u << k; }
+            }
+            if (!pick) break;
+            cand &= ~pick;
+            walk_tree<IGN>(sc, st, o, d, inv, root, best, ig0, ig1);
+        }
+        return best;
+    }
+    walk_tree<IGN>(sc, st, o, d, inv, sc.root, best, ig0, ig1);
     return best;
 }
 

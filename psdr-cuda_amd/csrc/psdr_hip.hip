@@ -76,6 +76,25 @@ __global__ __launch_bounds__(kBlock) void k_refit_level(BvhNode *__restrict__ no
     if ((threadIdx.x & 63) == 0 && area != 0.f) atomicAdd(area_sum, area);
 }
 
+// Two-level trees: what the kernel arguments carry (inline triangles, tree boxes) after a device refit --
+// gathered into one small buffer, read back with one copy.
+__global__ void k_gather_top(float4 *__restrict__ top, const BvhNode *__restrict__ nodes, const float *__restrict__ tri_info,
+                             const int32_t *__restrict__ inline_ids, int n_inline, int n_blas) {
+    const int i = threadIdx.x;
+    if (i < n_inline) {
+        const int id = inline_ids[i];
+        const float *r = tri_info + (size_t) id * PSDR_TRI_STRIDE;
+        float4 a{r[0], r[1], r[2], 0.f};
+        a.w = __int_as_float(id);
+        top[i * 3] = a; top[i * 3 + 1] = float4{r[3], r[4], r[5], 0.f}; top[i * 3 + 2] = float4{r[6], r[7], r[8], 0.f};
+    }
+    if (i < n_blas) {            // roots are the first n_blas nodes (level 0 of the forest)
+        const BvhNode &n = nodes[i];
+        top[psdr_host::kMaxInlineTris * 3 + i] = float4{fminf(n.lo0[0], n.lo1[0]), fminf(n.lo0[1], n.lo1[1]), fminf(n.lo0[2], n.lo1[2]), 0.f};
+        top[psdr_host::kMaxInlineTris * 3 + kMaxBlas + i] = float4{fmaxf(n.hi0[0], n.hi1[0]), fmaxf(n.hi0[1], n.hi1[1]), fmaxf(n.hi0[2], n.hi1[2]), 0.f};
+    }
+}
+
 // --------------------------------------------------------------------- primary-edge slot order
 // A primary-edge slot draws a random silhouette edge, so consecutive slots land on unrelated pixels and
 // the two Li evaluations of a wave start from 64 unrelated camera rays.  The sample streams are stateless
@@ -140,6 +159,15 @@ int plan_lds(const psdr_scene_s *h, LaunchCtx &cx, int reserved) {
 }
 int lds_bytes(const LaunchCtx &cx, const psdr_scene_s *h) { return cx.off_stack + std::min(kBvhStack, h->bvh_depth + 2) * kBlock * 4; }
 
+// the part of the tree that travels in the kernel arguments (tiny scenes, two-level trees)
+void fill_top(const psdr_scene_s *h, SceneView &sc) {
+    sc.n_tiny = h->n_tiny;
+    std::memcpy(sc.tiny, h->tiny, sizeof(h->tiny));
+    sc.n_blas = h->n_blas;
+    std::memcpy(sc.blas_lo, h->blas_lo, sizeof(h->blas_lo));
+    std::memcpy(sc.blas_hi, h->blas_hi, sizeof(h->blas_hi));
+}
+
 int make_ctx(psdr_scene_s *h, const psdr_render_opts *o, int sampler, LaunchCtx &cx) {
     if (!h->have_tables) return fail("Scene not loaded yet!");
     if (!h->have_bvh) return fail("Input scene must be configured!");
@@ -147,8 +175,7 @@ int make_ctx(psdr_scene_s *h, const psdr_render_opts *o, int sampler, LaunchCtx 
     if (o->integrator == PSDR_INTEGRATOR_DIRECT && !(o->bsdf_samples >= 0 && o->light_samples >= 0 && o->bsdf_samples + o->light_samples > 0))
         return fail("DirectIntegrator: bsdf_samples + light_samples must be positive");
     cx.sc.d = h->desc; cx.sc.nodes = h->d_nodes; cx.sc.btris = h->d_btris; cx.sc.root = h->root;
-    cx.sc.n_tiny = h->n_tiny;
-    std::memcpy(cx.sc.tiny, h->tiny, sizeof(h->tiny));
+    fill_top(h, cx.sc);
     plan_lds(h, cx);
     cx.lp = LiParams{o->integrator, o->bsdf_samples, o->light_samples, o->max_depth, o->hide_emitters, o->field};
     cx.jump = make_rng_jump(o->rng_offset[sampler]);
@@ -173,7 +200,13 @@ bool use_wavefront(const psdr_scene_s *h, const psdr_render_opts *o) {
     if (o->integrator != PSDR_INTEGRATOR_PATH || o->max_depth > 250) return false;
     if (o->flags & PSDR_FLAG_FUSED) return false;
     if (o->flags & PSDR_FLAG_WAVEFRONT) return true;
-    return o->max_depth >= 2 && h->path_survival >= 0.f && h->path_survival < 0.55f;
+    if (o->max_depth < 2 || h->path_survival < 0.f) return false;
+    if (h->path_survival < 0.55f) return true;                      // open scene: most paths die early, compaction pays
+    // closed two-level scene (a room with objects), large launch: the class-binned wavefront (psdr_kernels.h) is ahead of
+    // the fused kernel -- C4 shard (67 M slots) 27.5 against 29.6 ms; at 4 M slots its extra launches and stream traffic
+    // cost more than they save (3.7 against 2.9 ms)
+    const long long n = (long long) h->desc.width * h->desc.height * (o->spp_end - o->spp_begin);
+    return h->n_blas > 0 && h->wf_binned && n >= (1ll << 25);
 }
 
 SinkLayout make_sink_layout(const psdr_scene_s *h, const psdr_grads *g) {
@@ -266,6 +299,8 @@ int psdr_scene_create(psdr_scene_t *out) {
     }
     if (const char *e2 = std::getenv("PSDR_BVH_REFIT")) h->refit_enabled = std::atoi(e2) != 0;      // 0: always rebuild on the host
     if (const char *e4 = std::getenv("PSDR_TINY_SCENE")) h->tiny_enabled = std::atoi(e4) != 0;      // 0: walk the tree even for <= 16 triangles
+    if (const char *e5 = std::getenv("PSDR_TWO_LEVEL")) h->two_level_enabled = std::atoi(e5) != 0;  // 0: one tree over all triangles
+    if (const char *e7 = std::getenv("PSDR_WF_BINNED")) h->wf_binned = std::atoi(e7) != 0;          // 0: wavefront streams not binned by cost class
     if (const char *e3 = std::getenv("PSDR_SORT_EDGES")) h->sort_edges = std::atoi(e3) != 0;        // 0: primary-edge slots in natural order
     *out = h;
     return 0;
@@ -281,6 +316,8 @@ int psdr_scene_destroy(psdr_scene_t h) {
     if (h->d_ws) (void) hipFree(h->d_ws);
     if (h->d_hot_map) (void) hipFree(h->d_hot_map);
     if (h->d_hot_tris) (void) hipFree(h->d_hot_tris);
+    if (h->d_top) (void) hipFree(h->d_top);
+    if (h->d_inline_ids) (void) hipFree(h->d_inline_ids);
     delete h;
     return 0;
 }
@@ -321,7 +358,7 @@ int psdr_bvh_build(psdr_scene_t h, void *stream) {
     const int T = h->desc.num_tris;
     // ---- refit: same triangle count as the tree on the device and the tree has not degraded
     const bool tiny = h->tiny_enabled && T <= kTinyTris;        // the triangles travel in the kernel arguments: host copy needed
-    if (h->refit_enabled && !tiny && h->tree_tris == T && h->num_nodes > 0 && h->refits_since_build < kMaxRefits) {
+    if (h->refit_enabled && !tiny && h->refit_ok && h->tree_tris == T && h->num_nodes > 0 && h->refits_since_build < kMaxRefits) {
         float prev_area = h->built_area;
         if (h->refits_since_build > 0) {        // of the PREVIOUS refit (done long ago), read on the stream that wrote it
             HIP_TRY(hipMemcpyAsync(&prev_area, h->d_refit_area, sizeof(float), hipMemcpyDeviceToHost, h->refit_stream));
@@ -337,6 +374,22 @@ int psdr_bvh_build(psdr_scene_t h, void *stream) {
                                    h->d_refit_area);
             }
             HIP_TRY(hipGetLastError());
+            if (h->n_blas > 0) {          // the kernel arguments carry the inline primitives and the tree boxes: fetch the refitted ones
+                float4 top[kMaxInlineTris * 3 + 2 * kMaxBlas];
+                hipLaunchKernelGGL(k_gather_top, dim3(1), dim3(64), 0, s, h->d_top, h->d_nodes, h->desc.tri_info, h->d_inline_ids, h->n_inline, h->n_blas);
+                HIP_TRY(hipMemcpyAsync(top, h->d_top, sizeof(top), hipMemcpyDeviceToHost, s));
+                HIP_TRY(hipStreamSynchronize(s));
+                std::vector<float4> tris(top, top + 3 * (size_t) h->n_inline), prims;
+                pack_tiny_prims(tris, prims);
+                if ((int) prims.size() / 3 > kTinyTris) return fail("psdr_bvh_build: inline primitives no longer fit after the refit");
+                h->n_tiny = (int) prims.size() / 3;
+                if (!prims.empty()) std::memcpy(h->tiny, prims.data(), prims.size() * sizeof(float4));
+                for (int k = 0; k < h->n_blas; ++k) {
+                    const float w = h->blas_lo[k].w;
+                    h->blas_lo[k] = top[kMaxInlineTris * 3 + k]; h->blas_lo[k].w = w;
+                    h->blas_hi[k] = top[kMaxInlineTris * 3 + kMaxBlas + k];
+                }
+            }
             h->refits_since_build++;
             h->num_refits++;
             h->have_bvh = true;
@@ -349,21 +402,38 @@ int psdr_bvh_build(psdr_scene_t h, void *stream) {
     h->emitter_i.assign((size_t) std::max(h->desc.num_emitters, 0) * PSDR_EMITTER_I_STRIDE, 0);
     if (h->desc.num_emitters > 0 && h->desc.emitter_i)
         HIP_TRY(hipMemcpy(h->emitter_i.data(), h->desc.emitter_i, h->emitter_i.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    // ---- which tree: two-level (a few small meshes + a few large ones) or one tree over everything
+    std::vector<int32_t> tri_mesh;
+    bool forest = false;
+    if (h->two_level_enabled && h->tiny_enabled && T > kTinyTris && h->desc.num_meshes > 0) {
+        tri_mesh.resize((size_t) T);
+        HIP_TRY(hipMemcpy(tri_mesh.data(), h->desc.tri_mesh, tri_mesh.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+        forest = ForestBuilder::eligible(tri_mesh.data(), T, h->desc.num_meshes);
+    }
     Builder b;
+    ForestBuilder fb;
+    std::vector<float4> top_prims;
     int32_t root = 0;
-    if (const char *err = b.run(rows.data(), T, root)) return fail(err);
-    if (b.nodes.size() > h->cap_nodes) {
+    if (forest) {
+        if (const char *err = fb.run(rows.data(), tri_mesh.data(), T, h->desc.num_meshes)) return fail(err);
+        pack_tiny_prims(fb.inline_tris, top_prims);
+        if ((int) top_prims.size() / 3 > kTinyTris) { forest = false; fb = ForestBuilder(); }        // too many inline primitives: one tree
+    }
+    if (!forest) { if (const char *err = b.run(rows.data(), T, root)) return fail(err); }
+    std::vector<BvhNode> &nodes = forest ? fb.nodes : b.nodes;
+    std::vector<float4> &btris = forest ? fb.btris : b.btris;
+    if (nodes.size() > h->cap_nodes) {
         if (h->d_nodes) (void) hipFree(h->d_nodes);
-        h->cap_nodes = std::max<size_t>(b.nodes.size(), 16);
+        h->cap_nodes = std::max<size_t>(nodes.size(), 16);
         HIP_TRY(hipMalloc(&h->d_nodes, h->cap_nodes * sizeof(BvhNode)));
     }
-    if (b.btris.size() > h->cap_btris) {
+    if (btris.size() > h->cap_btris) {
         if (h->d_btris) (void) hipFree(h->d_btris);
-        h->cap_btris = b.btris.size();
+        h->cap_btris = btris.size();
         HIP_TRY(hipMalloc(&h->d_btris, h->cap_btris * sizeof(float4)));
     }
-    if (!b.nodes.empty()) HIP_TRY(hipMemcpyAsync(h->d_nodes, b.nodes.data(), b.nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(h->d_btris, b.btris.data(), b.btris.size() * sizeof(float4), hipMemcpyHostToDevice, s));
+    if (!nodes.empty()) HIP_TRY(hipMemcpyAsync(h->d_nodes, nodes.data(), nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(h->d_btris, btris.data(), btris.size() * sizeof(float4), hipMemcpyHostToDevice, s));
     HIP_TRY(hipStreamSynchronize(s));     // host vectors die at return
     {   // hot rows of the reverse-mode gradient cache: emitter triangles first, then by decreasing area
         constexpr int kMaxHotRows = 200;
@@ -391,32 +461,54 @@ int psdr_bvh_build(psdr_scene_t h, void *stream) {
         h->hot_rows = (int) tris.size();
     }
     h->root = root;
-    h->bvh_depth = b.max_depth; h->num_nodes = (int) b.nodes.size(); h->num_btris = (int) b.btris.size() / 3;
+    h->bvh_depth = forest ? fb.max_depth : b.max_depth; h->num_nodes = (int) nodes.size(); h->num_btris = (int) btris.size() / 3;
     h->have_bvh = true;
-    h->n_tiny = 0;
-    if (tiny) {
+    h->n_tiny = 0; h->n_blas = 0; h->n_inline = 0;
+    if (forest) {
+        h->n_tiny = (int) top_prims.size() / 3;
+        if (h->n_tiny) std::memcpy(h->tiny, top_prims.data(), top_prims.size() * sizeof(float4));
+        h->n_inline = (int) fb.inline_ids.size();
+        h->n_blas = (int) fb.roots.size();
+        for (int k = 0; k < h->n_blas; ++k) {
+            float lo[3], hi[3];
+            fb.tree_box(k, lo, hi);
+            h->blas_lo[k] = float4{lo[0], lo[1], lo[2], 0.f}; h->blas_hi[k] = float4{hi[0], hi[1], hi[2], 0.f};
+            std::memcpy(&h->blas_lo[k].w, &fb.roots[(size_t) k], 4);
+        }
+        if (!h->d_top) HIP_TRY(hipMalloc(&h->d_top, sizeof(float4) * (kMaxInlineTris * 3 + 2 * kMaxBlas)));
+        if (!h->d_inline_ids) HIP_TRY(hipMalloc(&h->d_inline_ids, sizeof(int32_t) * kMaxInlineTris));
+        if (h->n_inline) HIP_TRY(hipMemcpy(h->d_inline_ids, fb.inline_ids.data(), sizeof(int32_t) * (size_t) h->n_inline, hipMemcpyHostToDevice));
+    } else if (tiny) {
         std::vector<float4> prims;
         pack_tiny_prims(b.btris, prims);           // walls as parallelograms: half the tests
         h->n_tiny = (int) prims.size() / 3;
         std::memcpy(h->tiny, prims.data(), prims.size() * sizeof(float4));
     }
     // what the refit path needs: the levels of the breadth-first node order, the padding, the reference area
-    h->tree_tris = T; h->refits_since_build = 0; h->num_builds++; h->bvh_pad = b.pad;
+    h->tree_tris = T; h->refits_since_build = 0; h->num_builds++; h->bvh_pad = forest ? fb.pad : b.pad;
     h->level_start.clear();
     double area = 0.0;
-    if (root >= 0) {
+    auto node_area = [](const BvhNode &n) {
+        const float dx = std::max(n.hi0[0], n.hi1[0]) - std::min(n.lo0[0], n.lo1[0]), dy = std::max(n.hi0[1], n.hi1[1]) - std::min(n.lo0[1], n.lo1[1]),
+                    dz = std::max(n.hi0[2], n.hi1[2]) - std::min(n.lo0[2], n.lo1[2]);
+        return (double) (dx * dy + dy * dz + dz * dx);
+    };
+    if (forest) {
+        h->level_start = fb.level_start;
+        for (const BvhNode &n : nodes) area += node_area(n);
+    } else if (root >= 0) {
         std::vector<int> depth(b.nodes.size(), 0);
         for (size_t i = 0; i < b.nodes.size(); ++i) {
             const BvhNode &n = b.nodes[i];
             if (n.c0 >= 0) depth[n.c0] = depth[i] + 1;
             if (n.c1 >= 0) depth[n.c1] = depth[i] + 1;
             if (i == 0 || depth[i] != depth[i - 1]) h->level_start.push_back((int) i);
-            const float dx = std::max(n.hi0[0], n.hi1[0]) - std::min(n.lo0[0], n.lo1[0]), dy = std::max(n.hi0[1], n.hi1[1]) - std::min(n.lo0[1], n.lo1[1]),
-                        dz = std::max(n.hi0[2], n.hi1[2]) - std::min(n.lo0[2], n.lo1[2]);
-            area += dx * dy + dy * dz + dz * dx;
+            area += node_area(n);
         }
         h->level_start.push_back((int) b.nodes.size());
     }
+    h->refit_ok = true;
+    if (forest) for (int32_t r : fb.roots) if (r < 0) h->refit_ok = false;     // k_gather_top reads the roots as nodes 0 .. n_blas-1
     h->built_area = (float) area;
     if (!h->d_refit_area) HIP_TRY(hipMalloc(&h->d_refit_area, sizeof(float)));
     return 0;
@@ -429,8 +521,7 @@ int psdr_trace(psdr_scene_t h, int32_t m, const float *ox, const float *oy, cons
     if (m <= 0) return 0;
     LaunchCtx cx{};
     cx.sc.d = h->desc; cx.sc.nodes = h->d_nodes; cx.sc.btris = h->d_btris; cx.sc.root = h->root;
-    cx.sc.n_tiny = h->n_tiny;
-    std::memcpy(cx.sc.tiny, h->tiny, sizeof(h->tiny));
+    fill_top(h, cx.sc);
     plan_lds(h, cx);
     hipLaunchKernelGGL(k_trace, dim3(launch_blocks(h, m)), dim3(kBlock), lds_bytes(cx, h), (hipStream_t) stream, cx, m, ox, oy, oz, dx, dy, dz, tmax,
                        out_shape, out_tri, out_u, out_v);

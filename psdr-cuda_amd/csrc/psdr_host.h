@@ -102,6 +102,13 @@ struct psdr_scene_s {
     bool tiny_enabled = true;
     int n_tiny = 0;
     float4 tiny[kTinyTris * 3] = {};
+    // two-level tree (psdr_bvh_build.h ForestBuilder): boxes + roots of the per-mesh trees, as they travel in the
+    // kernel arguments; d_top / d_inline_ids serve the refresh after a device refit
+    bool two_level_enabled = true, refit_ok = true, wf_binned = true;
+    int n_blas = 0, n_inline = 0;
+    float4 blas_lo[kMaxBlas] = {}, blas_hi[kMaxBlas] = {};
+    float4 *d_top = nullptr;
+    int32_t *d_inline_ids = nullptr;
 
     // counters of the last render call (psdr_get_counters)
     unsigned long long *d_counters = nullptr;
@@ -134,6 +141,8 @@ int fail(const std::string &m);
 int launch_blocks(const psdr_scene_s *h, long long n, int per_cu = 16);
 int plan_lds(const psdr_scene_s *h, LaunchCtx &cx, int reserved = 0);
 int lds_bytes(const LaunchCtx &cx, const psdr_scene_s *h);
+void fill_top(const psdr_scene_s *h, SceneView &sc);
+constexpr int kMaxInlineTris = 2 * kTinyTris;      // inline triangles of a two-level tree before pairing
 int make_ctx(psdr_scene_s *h, const psdr_render_opts *o, int sampler, LaunchCtx &cx);
 bool use_wavefront(const psdr_scene_s *h, const psdr_render_opts *o);
 SinkLayout make_sink_layout(const psdr_scene_s *h, const psdr_grads *g);

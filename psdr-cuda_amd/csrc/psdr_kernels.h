@@ -152,17 +152,40 @@ __global__ __launch_bounds__(kBlock, (camera_waves<G, R, INTEG, FL>())) void k_c
 // wave-private segments without any atomic were measured too: as fast on C2 (3.0 ms) but 10 % slower on
 // open scenes, where the waves' survivor counts differ and the next stage inherits the imbalance.
 constexpr int kWfSub = 64, kWfCountStride = 32;
+// Two-level scenes (SceneView::n_blas > 0) run the wavefront BINNED BY COST CLASS: in a room most bounce rays only meet
+// the walls (uniform, ~200 VALU) while the few that enter an object's box walk its tree (1 500 - 4 000), and a wave
+// pays for its most expensive lane -- SIMD efficiency 16-23 % on the bounce rays of cbox_bunny (tools/simd_sim).  The
+// sample streams are stateless, so the two rays a surviving path will trace at its NEXT vertex are known when its
+// record is written: classify_next samples them and tests them against the tree boxes (2 bits: BSDF ray / light ray
+// enters a box), and the record goes to the sub-stream of its class.  The next stage consumes the sub-streams chunk
+// by chunk (256 records, expensive classes first, dynamic grabs of kWfGrab chunks from one counter): its waves are
+// class-pure -- three quarters of them never touch a tree, the rest walk with all lanes busy.
+constexpr int kWfGroups = 16, kWfClasses = 4, kWfGrab = 8;
+constexpr int kWfStageInts = (kWfSub + 1) * kWfCountStride;       // per stage: 64 sub-stream counters + the chunk-grab counter
 struct PathStream {
     int32_t *pixel; uint32_t *slot; int32_t *tri; float *hu, *hv; float *dir; float *beta;   // dir: [3][cap], beta: [3(1+K)][cap]
     long long cap;
-    int32_t *count;       // [kWfSub * kWfCountStride] records in each sub-stream
+    int32_t *count;       // [kWfSub * kWfCountStride] records in each sub-stream (+ the grab counter behind them)
     long long sub_cap;    // records per sub-stream
+    int32_t binned;       // 1: sub-stream = (3 - class) * kWfGroups + chunk % kWfGroups, consumed by dynamic chunk grabs
 };
+
+template <class M>
+__device__ __forceinline__ void stream_write(const PathStream &out, long long i, int pixel, uint32_t slot, const Its<float> &next, const Vec3f &dir, const Vec3<M> &beta) {
+    constexpr int K = ad_traits<M>::K;
+    out.pixel[i] = pixel; out.slot[i] = slot; out.tri[i] = next.tri; out.hu[i] = next.hu; out.hv[i] = next.hv;
+    out.dir[i] = dir.x; out.dir[out.cap + i] = dir.y; out.dir[2 * out.cap + i] = dir.z;
+    out.beta[i] = val(beta.x); out.beta[out.cap + i] = val(beta.y); out.beta[2 * out.cap + i] = val(beta.z);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        out.beta[(3 + 3 * k) * out.cap + i] = tangent(beta.x, k); out.beta[(4 + 3 * k) * out.cap + i] = tangent(beta.y, k);
+        out.beta[(5 + 3 * k) * out.cap + i] = tangent(beta.z, k);
+    }
+}
 
 template <class M>
 __device__ __forceinline__ void stream_push(const PathStream &out, bool alive, int pixel, uint32_t slot, const Its<float> &next,
                                             const Vec3f &dir, const Vec3<M> &beta) {
-    constexpr int K = ad_traits<M>::K;
     const unsigned long long mask = __ballot(alive);
     if (mask == 0ull) return;
     const int lane = threadIdx.x & 63, sub = blockIdx.x % kWfSub;
@@ -171,13 +194,61 @@ __device__ __forceinline__ void stream_push(const PathStream &out, bool alive, i
     base = __shfl(base, __ffsll((long long) mask) - 1, 64);
     if (!alive) return;
     const long long i = (long long) sub * out.sub_cap + base + __popcll(mask & ((1ull << lane) - 1ull));
-    out.pixel[i] = pixel; out.slot[i] = slot; out.tri[i] = next.tri; out.hu[i] = next.hu; out.hv[i] = next.hv;
-    out.dir[i] = dir.x; out.dir[out.cap + i] = dir.y; out.dir[2 * out.cap + i] = dir.z;
-    out.beta[i] = val(beta.x); out.beta[out.cap + i] = val(beta.y); out.beta[2 * out.cap + i] = val(beta.z);
+    stream_write<M>(out, i, pixel, slot, next, dir, beta);
+}
+
+// Cost class of the two rays the path will trace at the vertex `next` (arrival direction `dir`) in the stage whose
+// sample streams start at `jump_next`: bit 0 = the BSDF-sampled ray enters a tree box, bit 1 = the light ray does.  The
+// same vertex reconstruction, the same draws and the same sampling routines as direct_step, on plain floats; the box
+// test ignores t_best (conservative: class 0 NEVER walks a tree).
+template <class TVT>
+__device__ __forceinline__ int classify_next(const SceneView &sc, const TVT &, const RngJump &jump_next, uint32_t slot, const Its<float> &next, const Vec3f &dir) {
+    const TangentView<0, TVT::flags> tv0{};
+    const Its<float> its = path_vertex_from_record(sc, tv0, next.tri, next.hu, next.hv, dir);
+    const int bsdf_id = sc.d.mesh_bsdf[its.mesh];
+    if (bsdf_id < 0) return 0;
+    auto enters = [&](const Vec3f &o, const Vec3f &d, float tmax) {
+        const Vec3f inv{1.f / d.x, 1.f / d.y, 1.f / d.z};
+        bool any = false;
+        for (int k = 0; k < sc.n_blas; ++k) { float te; any = any || blas_box(sc, k, o, inv, tmax, te); }
+        return any;
+    };
+    Rng rng; rng.init((uint64_t) slot, jump_next);
+    const float s[3] = {rng.next(), rng.next(), rng.next()};
+    const float s0 = rng.next(), s1 = rng.next();
+    int cls = 0;
+    const Bsdf<float, float> bsdf(sc, bsdf_id);
+    Vec3f wo_s; float pdf_s;
+    if (bsdf.sample(sc, tv0, its, s, true, wo_s, pdf_s)) {
+        const Vec3f d1 = its.sh.s * wo_s.x + its.sh.t * wo_s.y + its.sh.n * wo_s.z;
+        if (enters(its.p, d1, INFINITY)) cls |= 1;
+    }
+    const PosSample<float> ps = sample_emitter_position<float>(sc, tv0, its.p, s0, s1, false);
+    if (ps.valid) {
+        Vec3f wo = ps.p - its.p;
+        const float dist = sqrtf(fmaxf(dot(wo, wo), 0.f));
+        wo = wo / dist;
+        if (enters(its.p, wo, dist)) cls |= 2;
+    }
+    return cls;
+}
+
+// Binned push: `chunk` = index of the 256-record chunk this workgroup is processing (spreads the records over
+// kWfGroups sub-streams per class whatever block happens to process the chunk).
+template <class M>
+__device__ __forceinline__ void stream_push_binned(const PathStream &out, bool alive, int cls, long long chunk, int pixel, uint32_t slot, const Its<float> &next,
+                                                   const Vec3f &dir, const Vec3<M> &beta) {
+    const int lane = threadIdx.x & 63, group = (int) (chunk % kWfGroups);
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-        out.beta[(3 + 3 * k) * out.cap + i] = tangent(beta.x, k); out.beta[(4 + 3 * k) * out.cap + i] = tangent(beta.y, k);
-        out.beta[(5 + 3 * k) * out.cap + i] = tangent(beta.z, k);
+    for (int c = 0; c < kWfClasses; ++c) {
+        const bool mine = alive && cls == c;
+        const unsigned long long mask = __ballot(mine);
+        if (mask == 0ull) continue;
+        const int sub = (kWfClasses - 1 - c) * kWfGroups + group;              // expensive classes first
+        int base = 0;
+        if (lane == __ffsll((long long) mask) - 1) base = atomicAdd(out.count + sub * kWfCountStride, (int) __popcll(mask));
+        base = __shfl(base, __ffsll((long long) mask) - 1, 64);
+        if (mine) stream_write<M>(out, (long long) sub * out.sub_cap + base + __popcll(mask & ((1ull << lane) - 1ull)), pixel, slot, next, dir, beta);
     }
 }
 
@@ -210,7 +281,7 @@ __device__ __forceinline__ void splat_runs(int pixel, bool valid, const Vec3<M> 
 template <class M, int FL>
 __global__ __launch_bounds__(kBlock, (is_ad<M>() ? 2 : 4)) void k_wf_camera(LaunchCtx cx, TV<M, FL> tv, int spp, int s_begin, int nsp, long long j0, long long n,
                                                         float inv_spp, float *__restrict__ img, float *__restrict__ dimg, long long plane,
-                                                        PathStream out, int want_next, unsigned long long *counters) {
+                                                        PathStream out, int want_next, unsigned long long *counters, RngJump jump_next) {
     TraversalStack st; setup_lds(cx, st);
     uint32_t nrays = 0;
     const long long nceil = (n + kBlock - 1) / kBlock * kBlock;
@@ -230,55 +301,100 @@ __global__ __launch_bounds__(kBlock, (is_ad<M>() ? 2 : 4)) void k_wf_camera(Laun
             if (alive) { Vec3f d = next.p - origin; const float t = norm(d); dir = d / t; }
         }
         splat_runs<M>(pixel, in, r, inv_spp, img, dimg, plane);
-        if (want_next) stream_push<M>(out, alive, pixel, slot, next, dir, beta);
+        if (want_next) {
+            if (out.binned) stream_push_binned<M>(out, alive, alive ? classify_next(cx.sc, tv, jump_next, slot, next, dir) : 0, jj / kBlock, pixel, slot, next, dir, beta);
+            else stream_push<M>(out, alive, pixel, slot, next, dir, beta);
+        }
     }
     count_rays(counters, nrays);
 }
 
 // One bounce: block b consumes its share of sub-stream b % kWfSub (grid-stride over the blocks of that
 // sub-stream; gridDim.x is a multiple of kWfSub) and appends the surviving paths to the same sub-stream of `out`.
+// One record of a bounce stage: rebuild the vertex, direct step, splat, push the continuation.
+template <class M, int FL>
+__device__ __forceinline__ void wf_bounce_record(const LaunchCtx &cx, const TV<M, FL> &tv, TraversalStack &st, float inv_spp, float *__restrict__ img,
+                                                 float *__restrict__ dimg, long long plane, const PathStream &in, const PathStream &out, int want_next,
+                                                 const RngJump &jump_next, bool live, long long j, long long chunk, uint32_t &nrays) {
+    constexpr int K = ad_traits<M>::K;
+    int pixel = -1; uint32_t slot = 0;
+    Vec3<M> r = zero3<M>(), beta = zero3<M>();
+    Its<float> next; next.tri = -1; next.hu = next.hv = 0.f;
+    Vec3f dir(0.f);
+    bool alive = false;
+    if (live) {
+        pixel = in.pixel[j]; slot = in.slot[j];
+        const Vec3f din{in.dir[j], in.dir[in.cap + j], in.dir[2 * in.cap + j]};
+        beta.x = M(in.beta[j]); beta.y = M(in.beta[in.cap + j]); beta.z = M(in.beta[2 * in.cap + j]);
+        if constexpr (K > 0) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                beta.x.d[k] = in.beta[(3 + 3 * k) * in.cap + j]; beta.y.d[k] = in.beta[(4 + 3 * k) * in.cap + j];
+                beta.z.d[k] = in.beta[(5 + 3 * k) * in.cap + j];
+            }
+        }
+        const Its<float> its = path_vertex_from_record(cx.sc, tv, in.tri[j], in.hu[j], in.hv[j], din);
+        Vec3<M> f;
+        const Vec3<M> c = wavefront_bounce_vertex<M>(cx.sc, tv, st, cx.jump, (uint64_t) slot, its, nrays, next, f, alive);
+        r = zero_nonfinite(beta * c);
+        if (alive) {
+            beta = beta * f;
+            const Vec3f b = val(beta);
+            alive = b.x != 0.f || b.y != 0.f || b.z != 0.f;
+            Vec3f d = next.p - its.p; const float t = norm(d); dir = d / t;
+        }
+    }
+    splat_runs<M>(pixel, live, r, inv_spp, img, dimg, plane);
+    if (want_next) {
+        if (out.binned) stream_push_binned<M>(out, alive, alive ? classify_next(cx.sc, tv, jump_next, slot, next, dir) : 0, chunk, pixel, slot, next, dir, beta);
+        else stream_push<M>(out, alive, pixel, slot, next, dir, beta);
+    }
+}
+
+// One bounce.  Plain streams: block b consumes its share of sub-stream b % kWfSub (grid-stride over the blocks of that
+// sub-stream; gridDim.x is a multiple of kWfSub) and appends the surviving paths to the same sub-stream of `out`.
+// Binned streams: the 64 sub-streams form one list of 256-record chunks (expensive classes first) that the workgroups
+// grab kWfGrab at a time from one counter.
 template <class M, int FL>
 __global__ __launch_bounds__(kBlock, (is_ad<M>() ? 2 : 4)) void k_wf_bounce(LaunchCtx cx, TV<M, FL> tv, float inv_spp, float *__restrict__ img,
                                                         float *__restrict__ dimg, long long plane, PathStream in,
-                                                        PathStream out, int want_next, unsigned long long *counters) {
-    constexpr int K = ad_traits<M>::K;
+                                                        PathStream out, int want_next, unsigned long long *counters, RngJump jump_next) {
     TraversalStack st; setup_lds(cx, st);
     uint32_t nrays = 0;
-    const int sub = blockIdx.x % kWfSub, per = gridDim.x / kWfSub;
-    const long long in_base = (long long) sub * in.sub_cap;
-    const int n = in.count[sub * kWfCountStride];
-    for (int base = (blockIdx.x / kWfSub) * kBlock; base < n; base += per * kBlock) {
-        const bool live = base + (int) threadIdx.x < n;
-        const long long j = in_base + base + threadIdx.x;
-        int pixel = -1; uint32_t slot = 0;
-        Vec3<M> r = zero3<M>(), beta = zero3<M>();
-        Its<float> next; next.tri = -1; next.hu = next.hv = 0.f;
-        Vec3f dir(0.f);
-        bool alive = false;
-        if (live) {
-            pixel = in.pixel[j]; slot = in.slot[j];
-            const Vec3f din{in.dir[j], in.dir[in.cap + j], in.dir[2 * in.cap + j]};
-            beta.x = M(in.beta[j]); beta.y = M(in.beta[in.cap + j]); beta.z = M(in.beta[2 * in.cap + j]);
-            if constexpr (K > 0) {
+    if (in.binned) {
+        __shared__ int s_pref[kWfSub + 1];
+        __shared__ int s_grab;
+        if (threadIdx.x < kWfSub) {
+            int c = (in.count[threadIdx.x * kWfCountStride] + kBlock - 1) / kBlock;          // chunks of this sub-stream
 #pragma unroll
-                for (int k = 0; k < K; ++k) {
-                    beta.x.d[k] = in.beta[(3 + 3 * k) * in.cap + j]; beta.y.d[k] = in.beta[(4 + 3 * k) * in.cap + j];
-                    beta.z.d[k] = in.beta[(5 + 3 * k) * in.cap + j];
-                }
-            }
-            const Its<float> its = path_vertex_from_record(cx.sc, tv, in.tri[j], in.hu[j], in.hv[j], din);
-            Vec3<M> f;
-            const Vec3<M> c = wavefront_bounce_vertex<M>(cx.sc, tv, st, cx.jump, (uint64_t) slot, its, nrays, next, f, alive);
-            r = zero_nonfinite(beta * c);
-            if (alive) {
-                beta = beta * f;
-                const Vec3f b = val(beta);
-                alive = b.x != 0.f || b.y != 0.f || b.z != 0.f;
-                Vec3f d = next.p - its.p; const float t = norm(d); dir = d / t;
+            for (int off = 1; off < kWfSub; off <<= 1) { const int o = __shfl_up(c, off, 64); if ((int) threadIdx.x >= off) c += o; }
+            s_pref[threadIdx.x + 1] = c;
+            if (threadIdx.x == 0) s_pref[0] = 0;
+        }
+        __syncthreads();
+        const int total = s_pref[kWfSub];
+        for (;;) {
+            if (threadIdx.x == 0) s_grab = atomicAdd(in.count + kWfSub * kWfCountStride, kWfGrab);
+            __syncthreads();
+            const int c0 = s_grab;
+            __syncthreads();
+            if (c0 >= total) break;
+            const int c1 = min(c0 + kWfGrab, total);
+            for (int c = c0; c < c1; ++c) {
+                int lo = 0, hi = kWfSub - 1;                                                    // sub-stream of chunk c
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_pref[mid + 1] <= c) lo = mid + 1; else hi = mid; }
+                const int off = (c - s_pref[lo]) * kBlock + (int) threadIdx.x;
+                const bool live = off < in.count[lo * kWfCountStride];
+                wf_bounce_record<M, FL>(cx, tv, st, inv_spp, img, dimg, plane, in, out, want_next, jump_next, live, (long long) lo * in.sub_cap + off, c, nrays);
             }
         }
-        splat_runs<M>(pixel, live, r, inv_spp, img, dimg, plane);
-        if (want_next) stream_push<M>(out, alive, pixel, slot, next, dir, beta);
+    } else {
+        const int sub = blockIdx.x % kWfSub, per = gridDim.x / kWfSub;
+        const long long in_base = (long long) sub * in.sub_cap;
+        const int n = in.count[sub * kWfCountStride];
+        for (int base = (blockIdx.x / kWfSub) * kBlock; base < n; base += per * kBlock)
+            wf_bounce_record<M, FL>(cx, tv, st, inv_spp, img, dimg, plane, in, out, want_next, jump_next, base + (int) threadIdx.x < n, in_base + base + threadIdx.x,
+                                    base / kBlock, nrays);
     }
     count_rays(counters, nrays);
 }
@@ -557,7 +673,7 @@ __global__ __launch_bounds__(kBlock) void k_secondary_edge_rev(LaunchCtx cx, Dev
 // nothing is staged (tiny scene) or when a workgroup still makes >= 8 trips of its grid-stride loop, else 16.
 inline int camera_blocks_per_cu(const psdr_scene_s *h, long long n) {
     if (h->has_rough) return 16;
-    if (h->n_tiny > 0) return 40;
+    if (h->n_tiny > 0 && h->n_blas == 0) return 40;
     const long long fit = n / ((long long) kBlock * h->num_cus * 8);
     return (int) std::max(16LL, std::min(40LL, fit));
 }
@@ -595,13 +711,16 @@ int run_camera_wavefront(psdr_scene_s *h, const psdr_render_opts *o, const TV<M,
     const int nsp = o->spp_end - o->spp_begin;
     if (o->spp <= 0 || nsp <= 0) return 0;
     const long long n = WH * nsp;
-    const long long cap = std::min(n, kWfChunk);
+    const bool binned = h->n_blas > 0 && h->wf_binned;
+    const long long cap = std::min(n, binned ? kWfChunk / 2 : kWfChunk);
     const int depth = o->max_depth;
     const size_t words = 8 + 3 * (1 + K);
-    // sub-streams: block b appends to sub-stream b % kWfSub, at most ceil(blocks / kWfSub) * trips * kBlock records each
+    // plain: block b appends to sub-stream b % kWfSub, at most ceil(blocks / kWfSub) * trips * kBlock records each.
+    // binned: the records of chunk c go to group c % kWfGroups of their class; a class can take all of a group
     const long long max_blocks = ((long long) launch_blocks(h, cap) + kWfSub - 1) / kWfSub * kWfSub;   // >= the grid of any chunk
-    const long long cap_alloc = cap + max_blocks * kBlock;
-    const size_t cnt_bytes = (size_t) kWfMaxDepth * kWfSub * kWfCountStride * sizeof(int32_t);
+    const long long binned_sub_cap = (((cap + kBlock - 1) / kBlock + kWfSub) / kWfGroups + 2) * kBlock;
+    const long long cap_alloc = binned ? binned_sub_cap * kWfSub : cap + max_blocks * kBlock;
+    const size_t cnt_bytes = (size_t) kWfMaxDepth * kWfStageInts * sizeof(int32_t);
     const size_t need = 2 * words * 4 * (size_t) cap_alloc + cnt_bytes;
     if (need > h->ws_bytes) {
         if (h->d_ws) (void) hipFree(h->d_ws);
@@ -617,6 +736,7 @@ int run_camera_wavefront(psdr_scene_s *h, const psdr_render_opts *o, const TV<M,
         st[i].cap = c;
         st[i].pixel = reinterpret_cast<int32_t *>(b); st[i].slot = reinterpret_cast<uint32_t *>(b + c); st[i].tri = reinterpret_cast<int32_t *>(b + 2 * c);
         st[i].hu = b + 3 * c; st[i].hv = b + 4 * c; st[i].dir = b + 5 * c; st[i].beta = b + 8 * c;
+        st[i].binned = binned ? 1 : 0;
     }
     h->slots[0] += (uint64_t) n;
     const float inv_spp = 1.f / (float) o->spp;
@@ -624,19 +744,19 @@ int run_camera_wavefront(psdr_scene_s *h, const psdr_render_opts *o, const TV<M,
         const long long cn = std::min(cap, n - j0);
         LaunchCtx cx;
         if (int rc = make_ctx(h, o, 0, cx)) return rc;
-        HIP_TRY(hipMemsetAsync(cnt, 0, (size_t) std::min(depth, kWfMaxDepth) * kWfSub * kWfCountStride * sizeof(int32_t), s));
+        HIP_TRY(hipMemsetAsync(cnt, 0, (size_t) std::min(depth, kWfMaxDepth) * kWfStageInts * sizeof(int32_t), s));
         const int blocks = (launch_blocks(h, cn) + kWfSub - 1) / kWfSub * kWfSub;
         const long long trips = (cn + (long long) blocks * kBlock - 1) / ((long long) blocks * kBlock);
-        st[0].sub_cap = st[1].sub_cap = (blocks / kWfSub) * trips * kBlock;
+        st[0].sub_cap = st[1].sub_cap = binned ? binned_sub_cap : (blocks / kWfSub) * trips * kBlock;
         st[0].count = cnt;
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wf_camera<M, FL>), dim3(blocks), dim3(kBlock), lds_bytes(cx, h), s, cx, tv, o->spp, o->spp_begin, nsp, j0, cn,
-                           inv_spp, img, dimg, WH * 3, st[0], depth > 1 ? 1 : 0, h->d_counters);
+                           inv_spp, img, dimg, WH * 3, st[0], depth > 1 ? 1 : 0, h->d_counters, make_rng_jump(o->rng_offset[0] + 2 + 5));
         HIP_TRY(hipGetLastError());
         for (int k = 1; k < depth; ++k) {
-            st[k & 1].count = cnt + (size_t) k * kWfSub * kWfCountStride;      // a fresh (zeroed) counter set per stage
+            st[k & 1].count = cnt + (size_t) k * kWfStageInts;      // a fresh (zeroed) counter set per stage
             cx.jump = make_rng_jump(o->rng_offset[0] + 2 + 5 * (uint64_t) k);
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wf_bounce<M, FL>), dim3(blocks), dim3(kBlock), lds_bytes(cx, h), s, cx, tv, inv_spp, img, dimg, WH * 3,
-                               st[(k - 1) & 1], st[k & 1], k + 1 < depth ? 1 : 0, h->d_counters);
+                               st[(k - 1) & 1], st[k & 1], k + 1 < depth ? 1 : 0, h->d_counters, make_rng_jump(o->rng_offset[0] + 2 + 5 * (uint64_t) (k + 1)));
             HIP_TRY(hipGetLastError());
         }
     }
