@@ -63,10 +63,13 @@ extern __shared__ __attribute__((aligned(16))) unsigned char psdr_dyn_lds[];
 //                the code, 7.1 ms with a run-time branch)
 //   kSceneRough  a RoughConductor BSDF exists (GGX + conductor Fresnel, and in reverse mode their Dual<8>
 //                adjoints: diffuse-only scenes run renderD K=3 15 % and reverse mode 40 % faster without)
-constexpr int kSceneEnv = 1, kSceneRough = 2, kSceneAll = 3;
+//   kSceneForest the scene has a two-level tree (SceneView::n_blas > 0): the box loop, the per-tree walks and the
+//                class-binned streams exist only in these instances (with a run-time switch instead the Cornell-box
+//                kernels spilled twice as many SGPRs: C2 renderC 1.41 -> 1.80 ms)
+constexpr int kSceneEnv = 1, kSceneRough = 2, kSceneAll = 3, kSceneForest = 4;
 template <int K, int FLAGS = kSceneRough> struct TangentView {
     static constexpr int flags = FLAGS;
-    static constexpr bool has_env = (FLAGS & kSceneEnv) != 0, has_rough = (FLAGS & kSceneRough) != 0;
+    static constexpr bool has_env = (FLAGS & kSceneEnv) != 0, has_rough = (FLAGS & kSceneRough) != 0, forest = (FLAGS & kSceneForest) != 0;
     psdr_tangents t[K > 0 ? K : 1];
 };
 
@@ -227,18 +230,22 @@ PSDR_HD bool blas_box(const SceneView &sc, int k, const Vec3f &o, const Vec3f &i
     return slab(lo, hi, o, inv, tmax, t_entry);
 }
 
-template <bool IGN = false>
+// FOREST: 1 = the instance serves two-level scenes only, 0 = never (no box loop / per-tree walks in the code), -1 = decided at
+// run time (k_trace, host tests).
+template <bool IGN = false, int FOREST = -1>
 PSDR_HD Hit closest_hit(const SceneView &sc, TraversalStack &st, const Vec3f &o, const Vec3f &d, float tmax, int ig0 = -1, int ig1 = -1) {
     Hit best; best.tri = -1; best.u = best.v = -1.f;
     best.t = (tmax > 0.f && tmax < INFINITY) ? __int_as_float_hd(__float_as_int_hd(tmax) + 1) : tmax;   // accept t <= tmax
     const Vec3f inv{1.f / d.x, 1.f / d.y, 1.f / d.z};
-    if (sc.n_tiny > 0 || sc.n_blas > 0) {
+    const bool forest = FOREST < 0 ? sc.n_blas > 0 : FOREST == 1;
+    if (sc.n_tiny > 0 || forest) {
         // n_tiny PRIMITIVES (triangles, or parallelograms of two triangles: pack_tiny_prims), unrolled by 6 (the six
         // walls of the Cornell box): the scalar loads of the following primitives are in flight while one is tested
         int ids = -1, codeA = 0, codeB = 0;
 #pragma unroll 6
         for (int i = 0; i < sc.n_tiny; ++i) tiny_prim_test<IGN>(sc.tiny[i * 3], sc.tiny[i * 3 + 1], sc.tiny[i * 3 + 2], o, d, best, ids, codeA, codeB, ig0, ig1);
         resolve_tiny_hit(best, ids, codeA, codeB);
+        if (!forest) return best;
         // two-level tree: the trees whose box the segment [0, t_best] enters, NEAREST box first (a hit in a near object
         // prunes the far ones); every round re-tests the remaining boxes against the current t_best -- wave-uniform
         // loops over SGPR operands, 16 VALU instructions per box
@@ -369,8 +376,9 @@ template <class R, class TVT> PSDR_HD Its<R> intersect(const SceneView &sc, cons
     its.valid = false; its.tri = its.mesh = -1; its.J = R(1.f); its.t = R(INFINITY);
     if (!active) return its;
     nrays++;
-    const Hit h = (ig0 >= 0 || ig1 >= 0) ? closest_hit<true>(sc, st, val(ray.o), val(ray.d), INFINITY, ig0, ig1)
-                                         : closest_hit<false>(sc, st, val(ray.o), val(ray.d), INFINITY);
+    constexpr int F = TVT::forest ? 1 : 0;
+    const Hit h = (ig0 >= 0 || ig1 >= 0) ? closest_hit<true, F>(sc, st, val(ray.o), val(ray.d), INFINITY, ig0, ig1)
+                                         : closest_hit<false, F>(sc, st, val(ray.o), val(ray.d), INFINITY);
     if (h.tri < 0) return its;
     its.valid = true; its.tri = h.tri; its.hu = h.u; its.hv = h.v;
     const int tm = sc.d.tri_mesh[h.tri];

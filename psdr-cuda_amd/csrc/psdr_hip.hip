@@ -17,7 +17,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(LaunchCtx cx, int m, const flo
     TraversalStack st; setup_lds(cx, st);
     const SceneView &sc = cx.sc;
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < m; i += gridDim.x * kBlock) {
-        const Hit h = closest_hit(sc, st, Vec3f{ox[i], oy[i], oz[i]}, Vec3f{dx[i], dy[i], dz[i]}, tmax[i]);
+        const Hit h = closest_hit<false, -1>(sc, st, Vec3f{ox[i], oy[i], oz[i]}, Vec3f{dx[i], dy[i], dz[i]}, tmax[i]);
         out_tri[i] = h.tri;
         out_shape[i] = h.tri >= 0 ? (sc.d.tri_mesh[h.tri] & ~PSDR_TRI_FACE_NORMALS) : -1;
         out_u[i] = h.u; out_v[i] = h.v;
@@ -266,12 +266,14 @@ int primary_edge_order(psdr_scene_s *h, const LaunchCtx &cx, long long i0, long 
 
 // kernel variant of the scene: bit 0 = environment map present, bit 1 = a rough conductor may be present
 const VariantOps *variant_of(const psdr_scene_s *h) {
-    const int fl = (h->desc.env_emitter >= 0 ? kSceneEnv : 0) | (h->has_rough ? kSceneRough : 0);
+    const int fl = (h->desc.env_emitter >= 0 ? kSceneEnv : 0) | (h->has_rough ? kSceneRough : 0) | (h->n_blas > 0 ? kSceneForest : 0);
     switch (fl) {
         case 0: return variant_ops_0();
         case 1: return variant_ops_1();
         case 2: return variant_ops_2();
-        default: return variant_ops_3();
+        case 3: return variant_ops_3();
+        case 4: return variant_ops_4();
+        default: return variant_ops_6();      // 6; psdr_bvh_build never builds a two-level tree under an environment map
     }
 }
 }  // namespace psdr_host
@@ -405,7 +407,7 @@ int psdr_bvh_build(psdr_scene_t h, void *stream) {
     // ---- which tree: two-level (a few small meshes + a few large ones) or one tree over everything
     std::vector<int32_t> tri_mesh;
     bool forest = false;
-    if (h->two_level_enabled && h->tiny_enabled && T > kTinyTris && h->desc.num_meshes > 0) {
+    if (h->two_level_enabled && h->tiny_enabled && T > kTinyTris && h->desc.num_meshes > 0 && h->desc.env_emitter < 0) {
         tri_mesh.resize((size_t) T);
         HIP_TRY(hipMemcpy(tri_mesh.data(), h->desc.tri_mesh, tri_mesh.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
         forest = ForestBuilder::eligible(tri_mesh.data(), T, h->desc.num_meshes);

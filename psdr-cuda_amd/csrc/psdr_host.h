@@ -164,6 +164,8 @@ const VariantOps *variant_ops_0();
 const VariantOps *variant_ops_1();
 const VariantOps *variant_ops_2();
 const VariantOps *variant_ops_3();
+const VariantOps *variant_ops_4();      // two-level tree (kSceneForest), diffuse
+const VariantOps *variant_ops_6();      // two-level tree, rough conductor
 }  // namespace psdr_host
 
 #define HIP_TRY(expr)                                                                              \

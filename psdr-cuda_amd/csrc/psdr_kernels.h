@@ -92,9 +92,12 @@ __device__ __forceinline__ void slot_to_pixel(long long j, int nsp, int &pixel, 
 // PathTracer(3) 2.06 -> 1.89 ms), material duals of the PathTracer 4 (2.85 -> 2.66 ms); the rough-conductor
 // variants lose 10 % there (C5 renderC 5.0 -> 5.5 ms) and the DirectIntegrator K = 3 instance 20 %
 template <class G, class R, int INTEG, int FL> constexpr int camera_waves() {
-    if (!is_ad<R>()) return FL == 0 ? PSDR_WAVES_C + 1 : PSDR_WAVES_C;
+    constexpr bool lean = (FL & (kSceneEnv | kSceneRough)) == 0;          // plain diffuse / area light (with or without a two-level tree)
+    if (!is_ad<R>()) return lean ? PSDR_WAVES_C + 1 : PSDR_WAVES_C;
     if (is_ad<G>()) return ad_traits<G>::K == 1 ? 3 : PSDR_WAVES_DG;
-    return (FL == 0 && INTEG == PSDR_INTEGRATOR_PATH) ? PSDR_WAVES_DM + 1 : PSDR_WAVES_DM;
+    // PathTracer material duals of the lean variant: K = 1 fits 4 waves / SIMD without spilling (C2 1.67 ms); K = 3 spills
+    // 150 VGPRs there and runs faster at 3 (3.37 -> 2.99 ms)
+    return (lean && INTEG == PSDR_INTEGRATOR_PATH && ad_traits<R>::K == 1) ? PSDR_WAVES_DM + 1 : PSDR_WAVES_DM;
 }
 template <class G, class R, int INTEG, int FL>
 __global__ __launch_bounds__(kBlock, (camera_waves<G, R, INTEG, FL>())) void k_camera(LaunchCtx cx, TV<R, FL> tv, int spp, int s_begin, int nsp, long long n, float inv_spp,
@@ -302,8 +305,10 @@ __global__ __launch_bounds__(kBlock, (is_ad<M>() ? 2 : 4)) void k_wf_camera(Laun
         }
         splat_runs<M>(pixel, in, r, inv_spp, img, dimg, plane);
         if (want_next) {
-            if (out.binned) stream_push_binned<M>(out, alive, alive ? classify_next(cx.sc, tv, jump_next, slot, next, dir) : 0, jj / kBlock, pixel, slot, next, dir, beta);
-            else stream_push<M>(out, alive, pixel, slot, next, dir, beta);
+            if constexpr ((FL & kSceneForest) != 0) {
+                if (out.binned) stream_push_binned<M>(out, alive, alive ? classify_next(cx.sc, tv, jump_next, slot, next, dir) : 0, jj / kBlock, pixel, slot, next, dir, beta);
+                else stream_push<M>(out, alive, pixel, slot, next, dir, beta);
+            } else stream_push<M>(out, alive, pixel, slot, next, dir, beta);
         }
     }
     count_rays(counters, nrays);
@@ -346,8 +351,10 @@ __device__ __forceinline__ void wf_bounce_record(const LaunchCtx &cx, const TV<M
     }
     splat_runs<M>(pixel, live, r, inv_spp, img, dimg, plane);
     if (want_next) {
-        if (out.binned) stream_push_binned<M>(out, alive, alive ? classify_next(cx.sc, tv, jump_next, slot, next, dir) : 0, chunk, pixel, slot, next, dir, beta);
-        else stream_push<M>(out, alive, pixel, slot, next, dir, beta);
+        if constexpr ((FL & kSceneForest) != 0) {
+            if (out.binned) stream_push_binned<M>(out, alive, alive ? classify_next(cx.sc, tv, jump_next, slot, next, dir) : 0, chunk, pixel, slot, next, dir, beta);
+            else stream_push<M>(out, alive, pixel, slot, next, dir, beta);
+        } else stream_push<M>(out, alive, pixel, slot, next, dir, beta);
     }
 }
 
@@ -361,7 +368,9 @@ __global__ __launch_bounds__(kBlock, (is_ad<M>() ? 2 : 4)) void k_wf_bounce(Laun
                                                         PathStream out, int want_next, unsigned long long *counters, RngJump jump_next) {
     TraversalStack st; setup_lds(cx, st);
     uint32_t nrays = 0;
-    if (in.binned) {
+    bool binned = false;
+    if constexpr ((FL & kSceneForest) != 0) binned = in.binned != 0;
+    if (binned) {
         __shared__ int s_pref[kWfSub + 1];
         __shared__ int s_grab;
         if (threadIdx.x < kWfSub) {
@@ -564,7 +573,7 @@ template <int FL> struct DeviceSink {
 // diffuse DirectIntegrator instance needs 187 and runs faster at 3 (C2 direct all gradients 4.1 -> 3.4 ms), the
 // others lose 50-100 % there to spills
 template <int FL, bool GEO, int INTEG> constexpr int rev_waves() {
-    if (!GEO) return FL == 0 ? PSDR_WAVES_REV_MAT + 1 : PSDR_WAVES_REV_MAT;   // plain diffuse variant: 130 VGPRs, C2 texel gradient 3.4 -> 2.8 ms
+    if (!GEO) return (FL & (kSceneEnv | kSceneRough)) == 0 ? PSDR_WAVES_REV_MAT + 1 : PSDR_WAVES_REV_MAT;   // plain diffuse variant: 130 VGPRs, C2 texel gradient 3.4 -> 2.8 ms
     return (INTEG == PSDR_INTEGRATOR_DIRECT && !(FL & kSceneRough)) ? 3 : PSDR_WAVES_REV;
 }
 template <int FL, bool GEO, int INTEG>
@@ -711,7 +720,7 @@ int run_camera_wavefront(psdr_scene_s *h, const psdr_render_opts *o, const TV<M,
     const int nsp = o->spp_end - o->spp_begin;
     if (o->spp <= 0 || nsp <= 0) return 0;
     const long long n = WH * nsp;
-    const bool binned = h->n_blas > 0 && h->wf_binned;
+    const bool binned = (FL & kSceneForest) != 0 && h->n_blas > 0 && h->wf_binned;
     const long long cap = std::min(n, binned ? kWfChunk / 2 : kWfChunk);
     const int depth = o->max_depth;
     const size_t words = 8 + 3 * (1 + K);

@@ -420,7 +420,7 @@ PSDR_HD VertexOut vertex_eval(Sink &sink, const SceneView &sc, TraversalStack &s
         if (REPLAY && BACKWARD) h1.tri = rec.tri(k, 0);
         else {
             nrays++;
-            h1 = closest_hit(sc, st, ray1.o, ray1.d, INFINITY);
+            h1 = closest_hit<false, (Sink::flags & kSceneForest) ? 1 : 0>(sc, st, ray1.o, ray1.d, INFINITY);
             if (REPLAY) rec.put_tri(k, 0, h1.tri);
         }
         if (h1.tri < 0) continue;
@@ -524,7 +524,7 @@ PSDR_HD VertexOut vertex_eval(Sink &sink, const SceneView &sc, TraversalStack &s
         if (REPLAY && BACKWARD) h2.tri = rec.tri(k, 1);
         else {
             nrays++;
-            h2 = closest_hit(sc, st, its.p, wo, INFINITY);
+            h2 = closest_hit<false, (Sink::flags & kSceneForest) ? 1 : 0>(sc, st, its.p, wo, INFINITY);
             if (REPLAY) rec.put_tri(k, 1, h2.tri);
         }
         if (h2.tri < 0) continue;
@@ -704,7 +704,7 @@ PSDR_HD Vec3f camera_sample_reverse(RealSink &real_sink, PrimaryGrad &pg, PathRe
     const Vec3f dcam = camera_space_dir(sc, sx, sy);
     const RayT<float> ray = primary_ray<float>(sc, tv0, sx, sy);
     nrays++;
-    const Hit h0 = closest_hit(sc, st, ray.o, ray.d, INFINITY);
+    const Hit h0 = closest_hit<false, (RealSink::flags & kSceneForest) ? 1 : 0>(sc, st, ray.o, ray.d, INFINITY);
     if (h0.tri < 0) return Vec3f(0.f);
     pg.tri = h0.tri;
     const int tm0 = sc.d.tri_mesh[h0.tri];
@@ -931,7 +931,7 @@ PSDR_HD void secondary_edge_reverse(Sink &sink, const SceneView &sc, TraversalSt
     const Vec3f dcam = camera_space_dir(sc, qx, qy);
     const RayT<float> cam = primary_ray<float>(sc, tv0, qx, qy);
     nrays++;
-    const Hit hc = closest_hit(sc, st, cam.o, cam.d, INFINITY);
+    const Hit hc = closest_hit<false, (Sink::flags & kSceneForest) ? 1 : 0>(sc, st, cam.o, cam.d, INFINITY);
     if (hc.tri < 0) return;
     const TriRow<float> Tc = load_tri<float>(sc, tv0, hc.tri);
     float cu, cv, ct;

@@ -1,9 +1,10 @@
 // psdr_variant.hip -- one kernel variant of libpsdr_hip.so: every kernel of psdr_kernels.h instantiated for the
-// scene flag set PSDR_VARIANT_FLAGS (0..3: bit 0 environment map, bit 1 rough conductor).  Compiled four times.
+// scene flag set PSDR_VARIANT_FLAGS (bit 0 environment map, bit 1 rough conductor, bit 2 two-level tree).  Compiled six
+// times: 0..3, 4, 6 (a two-level tree is never built under an environment map).
 #include "psdr_kernels.h"
 
 #ifndef PSDR_VARIANT_FLAGS
-#error "compile with -DPSDR_VARIANT_FLAGS=0|1|2|3"
+#error "compile with -DPSDR_VARIANT_FLAGS=0|1|2|3|4|6"
 #endif
 #define PSDR_CAT2(a, b) a##b
 #define PSDR_CAT(a, b) PSDR_CAT2(a, b)
