@@ -9,7 +9,7 @@ OUT=$R/gpurun_out/prof/$TAG
 export TMPDIR=/tmp
 mkdir -p $OUT /tmp/prof_$TAG
 cd /tmp
-ARGS="--no-cpu-baseline $*"
+ARGS="--no-cpu-baseline --no-pmc $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG/kt -o kt -- python $R/bench.py --steps 5 --warmup 2 $ARGS > $OUT/kt_bench.log 2>&1
 find /tmp/prof_$TAG/kt -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
 for PASS in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SMEM SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VALU"; do
