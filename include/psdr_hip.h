@@ -145,6 +145,17 @@ typedef struct psdr_scene_desc {
        ray re-hit them just above RayEpsilon -- ~3e-3 of the boundary term.  With the table the two rays skip
        the adjacent faces; without it they are traced as the reference does. */
     const int32_t *sec_edge_faces;
+    /* [Ep][4] per primary edge: 1 / depth along the viewing direction (dot(vertex - camera, normalize(cam[PSDR_CAM_DIR])))
+       of its two end points, then the global ids of its adjacent faces as int32 bit patterns (second = first on a boundary
+       edge); or NULL.  When present the primary-edge term runs the reference's PSDR_PRIMARY_EDGE_VIS_CHECK variant
+       (macros.h:13, integrator.cpp:105-108, perspective.cpp:91-96,171-196): an edge sample counts only if the edge point
+       itself is visible from the camera (the ray through it with tmax = distance - 100 ShadowEpsilon hits nothing).  The
+       reference keeps the sample-space z of the end points and unprojects the interpolated point; 1 / depth is affine along
+       the film segment in the same way and distance = depth / cos is the same number in exact arithmetic, but
+       sample-space z = far (1 - near / depth) / (far - near) holds only 3-4 digits of the depth in fp32 (near 0.1, depth
+       500: +-0.15 units against the 1e-3 margin), and the edge's own faces -- met exactly AT the distance -- are skipped
+       rather than left to round-off. */
+    const float   *prim_edge_z;
 } psdr_scene_desc;
 
 /* psdr_render_opts.flags: execution strategy of the PathTracer interior term.

@@ -944,6 +944,23 @@ PSDR_HD Vec3<M> camera_sample(const SceneView &sc, const TVT &tv, TraversalStack
     return zero_nonfinite(Li<G, M, INTEG>(sc, tv, st, lp, rng, ray, true, nrays));
 }
 
+// PSDR_PRIMARY_EDGE_VIS_CHECK (macros.h:13; integrator.cpp:105-108, perspective.cpp:171-196), active when the caller supplies
+// psdr_scene_desc::prim_edge_z (PSDR_PRIMARY_EDGE_VIS_CHECK, integrator.cpp:105-108, perspective.cpp:171-196): the point of
+// edge k at parameter u must itself be visible from the camera -- the camera ray through it, cut 100 ShadowEpsilon before
+// the point, hits nothing.  Row k = (1 / depth of the end points along the viewing direction, the adjacent faces): the
+// reference interpolates sample-space z and unprojects, which in exact arithmetic is the same distance depth / cos; the
+// edge's own faces, met AT that distance, are left out of the search instead of to fp32 round-off.
+template <class TVT>
+PSDR_HD bool primary_edge_point_visible(const SceneView &sc, const TVT &tv0, TraversalStack &st, int k, float u, float px, float py, uint32_t &nrays) {
+    const float *z = sc.d.prim_edge_z + (size_t) k * 4;
+    const float depth = 1.f / (z[0] * (1.f - u) + z[1] * u);
+    const Vec3f cd = normalize(Vec3f{sc.d.cam[PSDR_CAM_DIR], sc.d.cam[PSDR_CAM_DIR + 1], sc.d.cam[PSDR_CAM_DIR + 2]});
+    const RayT<float> ray = primary_ray<float>(sc, tv0, px, py);
+    const float tmax = depth / dot(ray.d, cd) - 100.f * kShadowEpsilon;
+    nrays++;
+    return closest_hit<true, TVT::forest ? 1 : 0>(sc, st, ray.o, ray.d, tmax, __float_as_int_hd(z[2]), __float_as_int_hd(z[3])).tri < 0;
+}
+
 // One primary-edge slot: Integrator::render_primary_edges (integrator.cpp:98-119) +
 // PerspectiveCamera::sample_primary_edge (perspective.cpp:158-200).  Returns the pixel (or -1);
 // tan[k][c] = d value / d P_k (the primal part is exactly zero: value -= detach(value)).
@@ -959,8 +976,9 @@ PSDR_HD int primary_edge_sample(const SceneView &sc, const TangentView<K, FL> &t
     const float px = pe[0] * (1.f - u) + pe[2] * u, py = pe[1] * (1.f - u) + pe[3] * u;
     const int W = sc.d.width, H = sc.d.height;
     const int ix = (int) floorf(px * (float) W), iy = (int) floorf(py * (float) H);
-    const bool valid = ix >= 0 && ix < W && iy >= 0 && iy < H;
+    bool valid = ix >= 0 && ix < W && iy >= 0 && iy < H;
     const TangentView<0, FL> tv0{};
+    if (sc.d.prim_edge_z != nullptr && valid) valid = primary_edge_point_visible(sc, tv0, st, k, u, px, py, nrays);
     // Li on the two sides of the edge (ray_n first, then ray_p: the order the reference draws them in,
     // integrator.cpp:107-112) -- one loop body, so the estimator is instantiated once
     Vec3f L2[2];

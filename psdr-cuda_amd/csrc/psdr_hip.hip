@@ -338,6 +338,7 @@ int psdr_scene_set_tables(psdr_scene_t h, const psdr_scene_desc *desc) {
     if (d.num_emitters > 1 && (!d.emitter_cmf || !d.emitter_pmf)) return fail("psdr_scene_set_tables: emitter distribution missing");
     if (d.num_sec_edges > 0 && (!d.sec_edge || !d.sec_cmf || !d.sec_pmf)) return fail("psdr_scene_set_tables: secondary-edge tables missing");
     if (d.num_prim_edges > 0 && (!d.prim_edge || !d.prim_cmf || !d.prim_pmf)) return fail("psdr_scene_set_tables: primary-edge tables missing");
+    if (d.num_prim_edges <= 0) d.prim_edge_z = nullptr;
     if (d.num_guide_cells > 0 && (!d.guide_cmf || !d.guide_pmf)) return fail("psdr_scene_set_tables: guiding tables missing");
     // no environment map unless its record is given (a zero-initialised desc means "none")
     if (!d.env_f) d.env_emitter = -1;

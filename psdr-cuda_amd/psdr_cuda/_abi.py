@@ -51,6 +51,7 @@ class SceneDesc(C.Structure):
         ("env_f", _fp), ("env_cmf", _fp), ("env_pmf", _fp), ("env_sum", C.c_float),
         ("material_mask", C.c_uint32),
         ("sec_edge_faces", _fp),
+        ("prim_edge_z", _fp),
     ]
 
 

@@ -45,6 +45,9 @@ class RenderOption:
         self.sppe = int(spp if sppe is None else sppe)
         self.sppse = int(self.sppe if sppse is None else sppse)   # reference leaves it uninitialised in the 3/4-arg ctor
         self.log_level = 1
+        # the reference's compile-time variant PSDR_PRIMARY_EDGE_VIS_CHECK (include/psdr/macros.h:13) as a run-time option:
+        # a primary-edge sample counts only if the edge point itself is visible from the camera
+        self.primary_edge_vis_check = False
 
     def __repr__(self):
         return "[width: %d, height: %d, spp: %d, sppe: %d, sppse: %d, log_level: %d]" % (

@@ -270,12 +270,12 @@ class PerspectiveCamera(Sensor):
         cam[51:54] = cam_dir.detach()
         cam[54] = inv_area
         out = {"cam": cam.contiguous(), "cam_to_world": tw, "prim_edge": None, "prim_cmf": None, "prim_pmf": None,
-               "prim_sum": 0.0, "num_prim_edges": 0}
+               "prim_sum": 0.0, "num_prim_edges": 0, "prim_edge_z": None}
 
         # ---- primary-edge list, perspective.cpp:39-111
         self.m_enable_edges = False
         if scene.opts.sppe > 0:
-            rows = []
+            rows, zs = [], []
             bt = scene._batch
             ei = bt["tp"]["edges"]
             if ei is not None:
@@ -297,8 +297,15 @@ class PerspectiveCamera(Sensor):
                 if info.shape[0] > 0:
                     p0 = vpos[info[:, 0]]
                     p1 = vpos[info[:, 1]]
-                    q0 = transform_pos(w2s, p0)[:, :2]
-                    q1 = transform_pos(w2s, p1)[:, :2]
+                    q0f, q1f = transform_pos(w2s, p0), transform_pos(w2s, p1)
+                    q0, q1 = q0f[:, :2], q1f[:, :2]
+                    # PSDR_PRIMARY_EDGE_VIS_CHECK: (1 / camera-space depth of the two end points, the adjacent faces as int bits).
+                    # 1 / depth is affine along the film segment like the reference's sample-space z, but keeps fp32
+                    # precision (sample-space z = 1 - near / depth loses 3-4 digits at near = 0.1, depth = 500)
+                    cd = _normalize(cam_dir.detach())
+                    iz = [1.0 / ((pp.detach() - cam_pos.detach()) * cd).sum(-1) for pp in (p0, p1)]
+                    fb = [torch.where(info[:, 3] >= 0, info[:, c], info[:, 2]).to(torch.int32).view(torch.float32) for c in (2, 3)]
+                    zs.append(torch.stack(iz + fb, dim=-1))
                     e = (q1 - q0).detach()
                     ln = torch.sqrt((e * e).sum(-1))
                     e = e / ln.unsqueeze(-1)
@@ -309,6 +316,8 @@ class PerspectiveCamera(Sensor):
                 d = DiscreteDistribution(); d.init(pe[:, 6].detach())
                 out.update(prim_edge=pe, prim_cmf=d.m_cmf, prim_pmf=d.m_pmf, prim_sum=d.m_sum,
                            num_prim_edges=int(pe.shape[0]))
+                if getattr(scene.opts, "primary_edge_vis_check", False):
+                    out["prim_edge_z"] = torch.cat(zs, dim=0).contiguous()
                 self.m_enable_edges = True
         return out
 
@@ -432,6 +441,7 @@ class Mesh(Object):
         self.num_faces = 0
         self._vertex_positions_raw = None
         self._vertex_normals_raw = None
+        self._vertex_offset = None          # [V] displacement along the raw vertex normal (None = 0), see vertex_offset
         self._vertex_uv = None
         self._face_indices = None
         self._face_uv_indices = None
@@ -501,6 +511,32 @@ class Mesh(Object):
         self.m_ready = False
 
     @property
+    def vertex_offset(self):
+        """Per-vertex displacement along the raw vertex normal: m_vertex_positions = to_world * (raw + offset * normal_raw).
+        The reference builds this parameter only when PSDR_MESH_ENABLE_1D_VERTEX_OFFSET is defined (include/psdr/macros.h:12,
+        shape/mesh.h:37-39,71-80, mesh.cpp:226-232, psdr.cpp:259); here it is always available and costs nothing while unset."""
+        if self._vertex_offset is None:
+            return FloatD._wrap(torch.zeros(self.num_vertices, device=_dev()))
+        return FloatD._wrap(self._vertex_offset)
+
+    @vertex_offset.setter
+    def vertex_offset(self, v):
+        t = v.t if isinstance(v, ek.ArrayBase) else torch.as_tensor(np.asarray(v, dtype=np.float32), device=_dev())
+        t = t.reshape(-1)
+        if t.numel() == 1:
+            t = t.expand(self.num_vertices)
+        psdr_assert(t.shape[0] == self.num_vertices, "vertex_offset: wrong size")
+        self._vertex_offset = t
+        self.m_ready = False
+
+    def _raw_positions(self):
+        """Object-space positions the transform is applied to (mesh.cpp:226-232)."""
+        if self._vertex_offset is None:
+            return self._vertex_positions_raw
+        _, n_raw = process_mesh(self._vertex_positions_raw, self._face_indices)
+        return self._vertex_positions_raw + n_raw * self._vertex_offset.unsqueeze(-1)
+
+    @property
     def vertex_normals(self):
         if self._vertex_normals_raw is None and self._vertex_positions_raw is not None:
             _, self._vertex_normals_raw = process_mesh(self._vertex_positions_raw, self._face_indices)
@@ -549,7 +585,7 @@ class Mesh(Object):
             self._edge_indices_dev = torch.as_tensor(self._edge_indices, device=_dev())
         self._vertex_normals_raw = None       # lazy (vertex_normals property)
         to_world = self._to_world_left @ self._to_world_raw @ self._to_world_right
-        self._vertex_positions = transform_pos(to_world, self._vertex_positions_raw)
+        self._vertex_positions = transform_pos(to_world, self._raw_positions())
         self._triangle_info, _ = process_mesh(self._vertex_positions, self._face_indices)
         face_areas = self._triangle_info[:, 21]
         self.m_total_area = float(face_areas.detach().sum().item())
@@ -949,7 +985,7 @@ class Scene(Object):
                 psdr_assert(not m.bsdf.anisotropic() or not m.use_face_normals)
         mats = torch.bmm(torch.bmm(torch.stack([m._to_world_left for m in meshes]), torch.stack([m._to_world_raw for m in meshes])),
                          torch.stack([m._to_world_right for m in meshes]))
-        v_raw = torch.cat([m._vertex_positions_raw for m in meshes], dim=0)
+        v_raw = torch.cat([m._raw_positions() for m in meshes], dim=0)
         mv = mats[tp["vmesh"]]                                                     # [V,4,4]
         h = (mv[:, :3, :3] * v_raw.unsqueeze(1)).sum(-1) + mv[:, :3, 3]
         w = (mv[:, 3, :3] * v_raw).sum(-1) + mv[:, 3, 3]
@@ -1036,7 +1072,7 @@ class Scene(Object):
             return None, None
         ts = []
         for m in self.m_meshes:
-            ts += [m._vertex_positions_raw, m._to_world_raw, m._to_world_left, m._to_world_right]
+            ts += [m._vertex_positions_raw, m._to_world_raw, m._to_world_left, m._to_world_right, m._vertex_offset]
         for sn in self.m_sensors:
             ts.append(sn._to_world)
         for e in self.m_emitters:
@@ -1044,8 +1080,8 @@ class Scene(Object):
         if any(t is not None and t.requires_grad for t in ts):
             return None, None
         o = self.opts
-        scalars = (o.width, o.height, o.sppe > 0, o.sppse > 0, len(self.m_meshes), len(self.m_sensors), len(self.m_emitters),
-                   tuple((id(m), m.enable_edges, m.use_face_normals, m.m_has_uv, id(m.m_emitter), getattr(m, "_topo_version", 0)) for m in self.m_meshes),
+        scalars = (o.width, o.height, o.sppe > 0, o.sppse > 0, bool(getattr(o, "primary_edge_vis_check", False)), len(self.m_meshes), len(self.m_sensors), len(self.m_emitters),
+                   tuple((id(m), m.enable_edges, m.use_face_normals, m.m_has_uv, id(m.m_emitter), getattr(m, "_topo_version", 0), m._vertex_offset is None) for m in self.m_meshes),
                    tuple((type(sn).__name__, getattr(sn, "m_fov_x", None), getattr(sn, "m_near_clip", None), getattr(sn, "m_far_clip", None)) for sn in self.m_sensors),
                    tuple((type(e).__name__, id(e.m_mesh)) for e in self.m_emitters),
                    tuple(self._sample_count))
@@ -1291,6 +1327,7 @@ def make_desc(tb, guide=None, device=None):
     d.cam = p(tb["cam"])
     d.sec_edge, d.sec_cmf, d.sec_pmf, d.sec_sum = p(tb["sec_edge"]), p(tb["sec_cmf"]), p(tb["sec_pmf"]), tb["sec_sum"]
     d.sec_edge_faces = p(tb.get("sec_edge_faces"), torch.int32)
+    d.prim_edge_z = p(tb.get("prim_edge_z"))
     d.prim_edge, d.prim_cmf, d.prim_pmf, d.prim_sum = p(tb["prim_edge"]), p(tb["prim_cmf"]), p(tb["prim_pmf"]), tb["prim_sum"]
     d.material_mask = int(tb.get("material_mask", 0))
     d.env_emitter = int(tb.get("env_emitter", -1))
