@@ -499,8 +499,19 @@ template <int FL> struct DeviceSink {
     static constexpr bool has_env = (FL & kSceneEnv) != 0;
     psdr_grads g;
     SinkLayout L;
-    float *lds;           // THIS lane's copy of the cache (lane & (rep - 1))
-    float *lds0;          // copy 0
+    // the cache is addressed through LDS-address-space pointers: with generic pointers the compiler merges the two arms of
+    // "cached ? LDS add : global add" into ONE flat_atomic_add_f32 on a selected address (137 of them in the PathTracer
+    // geometry kernel) -- a flat atomic goes through the texture-address path, counts against vmcnt AND lgkmcnt, and every
+    // later wait for a load or a path-record read then waits for it as well
+    typedef __attribute__((address_space(3))) float lds_float;
+    lds_float *lds;       // THIS lane's copy of the cache (lane & (rep - 1))
+    lds_float *lds0;      // copy 0
+#ifdef PSDR_EXP_CHEAP_SINK      // experiment: what the kernel costs when the LDS adds are free (one register add keeps the adjoint chain alive)
+    mutable float exp_acc = 0.f;
+    __device__ __forceinline__ void lds_add(lds_float *p, float v) const { exp_acc += v + __builtin_bit_cast(float, (int) (size_t) p); }
+#else
+    __device__ __forceinline__ static void lds_add(lds_float *p, float v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+#endif
     float cam[16];
     __device__ __forceinline__ static bool ok(float v) { return v != 0.f && isfinite(v); }
     __device__ __forceinline__ void glob(float *base, size_t i, float v) const { if (base != nullptr && ok(v)) atomicAdd(base + i, v); }
@@ -512,39 +523,42 @@ template <int FL> struct DeviceSink {
         if (g.g_tri_info == nullptr || !ok(v)) return;
         if (tri != last_tri) { last_tri = tri; last_slot = L.hot_rows ? L.hot_map[tri] : -1; }
         const int slot = last_slot;
-        if (slot >= 0 && slot < L.hot_rows) atomicAdd(lds + L.hot_off + slot * PSDR_TRI_STRIDE + word, v);
+        if (slot >= 0 && slot < L.hot_rows) lds_add(lds + L.hot_off + slot * PSDR_TRI_STRIDE + word, v);
         else atomicAdd(g.g_tri_info + (size_t) tri * PSDR_TRI_STRIDE + word, v);
     }
     __device__ __forceinline__ void add_texel(int idx, float v) const {
         if (g.g_texels == nullptr || !ok(v)) return;
-        if (L.tex_n) atomicAdd(lds + L.tex_off + idx, v); else atomicAdd(g.g_texels + idx, v);
+        if (L.tex_n) lds_add(lds + L.tex_off + idx, v); else atomicAdd(g.g_texels + idx, v);
     }
     __device__ __forceinline__ void add_rad(int e, int c, float v) const {
         if (g.g_emitter_rad == nullptr || !ok(v)) return;
-        if (L.rad_n) atomicAdd(lds + L.rad_off + e * 3 + c, v); else atomicAdd(g.g_emitter_rad + e * 3 + c, v);
+        if (L.rad_n) lds_add(lds + L.rad_off + e * 3 + c, v); else atomicAdd(g.g_emitter_rad + e * 3 + c, v);
     }
     __device__ __forceinline__ void add_cam(int word, float v) { if (ok(v)) cam[word] += v; }
-    __device__ __forceinline__ void add_env(int word, float v) const { if (L.env_n && ok(v)) atomicAdd(lds + L.env_off + word, v); }
+    __device__ __forceinline__ void add_env(int word, float v) const { if (L.env_n && ok(v)) lds_add(lds + L.env_off + word, v); }
     __device__ __forceinline__ void add_sedge(int e, int word, float v) const { glob(g.g_sec_edge, (size_t) e * PSDR_SEDGE_STRIDE + word, v); }
     __device__ __forceinline__ void add_pedge(int e, int word, float v) const { glob(g.g_prim_edge, (size_t) e * PSDR_PEDGE_STRIDE + word, v); }
 
     __device__ __forceinline__ void begin(float *cache) {
-        lds0 = cache;
+        lds0 = (lds_float *) cache;
         last_tri = -1; last_slot = -1;
-        lds = cache + (threadIdx.x & (L.rep - 1)) * L.stride;
-        for (int i = threadIdx.x; i < L.rep * L.stride; i += kBlock) cache[i] = 0.f;
+        lds = lds0 + (threadIdx.x & (L.rep - 1)) * L.stride;
+        for (int i = threadIdx.x; i < L.rep * L.stride; i += kBlock) lds0[i] = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) cam[i] = 0.f;
         __syncthreads();
     }
     __device__ __forceinline__ void end() {
+#ifdef PSDR_EXP_CHEAP_SINK
+        if (exp_acc == 123.456f) lds0[0] = exp_acc;
+#endif
         if (g.g_cam_to_world != nullptr) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 float v = cam[i];
 #pragma unroll
                 for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-                if ((threadIdx.x & 63) == 0 && v != 0.f) atomicAdd(lds0 + L.cam_off + i, v);
+                if ((threadIdx.x & 63) == 0 && v != 0.f) lds_add(lds0 + L.cam_off + i, v);
             }
         }
         __syncthreads();

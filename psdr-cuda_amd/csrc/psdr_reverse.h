@@ -52,6 +52,24 @@ struct VertexAdj {
     PSDR_HD void clear() { p = s = t = n = wi = Vec3f(0.f); u = v = 0.f; }
 };
 
+// Pending adjoint of ONE path vertex' triangle row: its position (scattered as p0 + u e1 + v e2), face normal and area.  A vertex
+// receives adjoints from three consecutive iterations of the replay sweep (the BSDF sample that found it, its own frame /
+// direction chain, the direction chain of the vertex after it), all at the same (u, v): they are summed here and the row is
+// touched once -- 13 adds per vertex instead of 34 (an LDS float add costs ~3 cycles per active LANE on gfx950,
+// tools/micro/lds_atomics2.hip: the adds, not the arithmetic, were a third of the PathTracer geometry kernel).
+struct RowAdj {
+    Vec3f p, fn; float area;
+    PSDR_HD void clear() { p = fn = Vec3f(0.f); area = 0.f; }
+};
+PSDR_HD float finite_or_zero(float v) { return isfinite(v) ? v : 0.f; }
+PSDR_HD void acc_finite(Vec3f &d, const Vec3f &v) { d.x += finite_or_zero(v.x); d.y += finite_or_zero(v.y); d.z += finite_or_zero(v.z); }
+template <class Sink> PSDR_HD void scatter_point(Sink &sink, int tri, float u, float v, const Vec3f &ap);
+template <class Sink> PSDR_HD void scatter_vec(Sink &sink, int tri, int word, const Vec3f &a);
+template <class Sink> PSDR_HD void flush_row_normal_area(Sink &sink, int tri, const RowAdj &r) {
+    scatter_vec(sink, tri, 18, r.fn);
+    sink.add_tri(tri, 21, r.area);
+}
+
 // Gradient sink interface (duck-typed): add_tri(tri, word, g), add_texel(idx, g), add_rad(e, c, g),
 // add_cam(word, g), add_sedge(edge, word, g), add_pedge(edge, word, g).
 
@@ -400,7 +418,7 @@ PSDR_HD Its<float> make_path_vertex(const SceneView &sc, const Vec3f &origin, in
 //   rays arrived at in rec[k]; the BACKWARD sweep re-intersects that triangle instead of tracing again.
 template <bool BACKWARD, bool REPLAY, class Sink>
 PSDR_HD VertexOut vertex_eval(Sink &sink, const SceneView &sc, TraversalStack &st, Rng &rng, const Its<float> &its, int nB, int nL,
-                              const Vec3f &a_c, const Vec3f &a_f, VertexAdj &va, uint32_t &nrays, PathRec &rec, int k) {
+                              const Vec3f &a_c, const Vec3f &a_f, VertexAdj &va, uint32_t &nrays, PathRec &rec, int k, RowAdj *next_row = nullptr) {
     const TangentView<0, Sink::flags> tv0{};
     VertexOut out; out.c = Vec3f(0.f); out.f = Vec3f(0.f); out.next_valid = false;
     // the bounding mesh of the environment map has no BSDF (direct.cpp:54-57): nothing is gathered there and
@@ -478,10 +496,12 @@ PSDR_HD VertexOut vertex_eval(Sink &sink, const SceneView &sc, TraversalStack &s
         const float a_J = a_cfac * cfac;
         a_pdf0 += -a_cfac * cfac / pdf0;
         const float a_pdf_s = a_pdf0 * G;                      // pdf0 = pdf_s * detach(G)
-        sink.add_tri(h1.tri, 21, a_J / T1.area);               // J = A / detach(A)
         const float a_cosv = a_G * (cosv < 0.f ? -1.f : 1.f) / (t1 * t1);
         float a_t1 = -2.f * a_G * G / t1;
-        scatter_vec(sink, h1.tri, 18, wo * (-a_cosv));         // cosv = -fn . wo
+        // the row of the next vertex: J = A / detach(A), cosv = -fn . wo, and (below) its position
+        const bool merge = next_row != nullptr && i == 0;
+        if (merge) { next_row->area += finite_or_zero(a_J / T1.area); acc_finite(next_row->fn, wo * (-a_cosv)); }
+        else { sink.add_tri(h1.tri, 21, a_J / T1.area); scatter_vec(sink, h1.tri, 18, wo * (-a_cosv)); }
         acc(a_wo, T1.fn * (-a_cosv));
         Vec3f a_wol(0.f);
         brev.eval_vjp(sink, tv0, its, wol, a_fv, va.wi, a_wol, va.u, va.v);
@@ -491,7 +511,8 @@ PSDR_HD VertexOut vertex_eval(Sink &sink, const SceneView &sc, TraversalStack &s
         Vec3f a_dvec = a_wo / t1;                              // wo = dvec / t1 ; t1 = |dvec|
         a_t1 += -dot(a_wo, wo) / t1;
         acc(a_dvec, wo * a_t1);
-        scatter_point(sink, h1.tri, h1.u, h1.v, a_dvec);
+        if (merge) acc_finite(next_row->p, a_dvec);
+        else scatter_point(sink, h1.tri, h1.u, h1.v, a_dvec);
         acc(va.p, -a_dvec);
     }
     for (int i = 0; i < nL; ++i) {
@@ -660,7 +681,7 @@ template <class RealSink> struct CameraSinkOf<false, RealSink> { using type = Ma
 
 // Back-propagates the adjoints of a PATH-SPACE vertex (k >= 1) into its triangle row and returns the
 // adjoint of the previous vertex' position (wi_k = to_local_k(-(p_k - p_{k-1}) / t)).
-template <class Sink> PSDR_HD Vec3f path_vertex_backward(Sink &sink, const SceneView &sc, const Its<float> &v, const Vec3f &prev_p, VertexAdj va) {
+template <class Sink> PSDR_HD Vec3f path_vertex_backward(Sink &sink, const SceneView &sc, const Its<float> &v, const Vec3f &prev_p, VertexAdj va, RowAdj &row) {
     const TangentView<0, Sink::flags> tv0{};
     const TriRow<float> T = load_tri<float>(sc, tv0, v.tri);
     const bool face = (sc.d.tri_mesh[v.tri] & PSDR_TRI_FACE_NORMALS) != 0;
@@ -672,9 +693,10 @@ template <class Sink> PSDR_HD Vec3f path_vertex_backward(Sink &sink, const Scene
     acc(va.s, dir * (-va.wi.x)); acc(va.t, dir * (-va.wi.y)); acc(va.n, dir * (-va.wi.z));
     const Vec3f a_shn = va.n + frame_vjp(sn.n, va.s, va.t);
     float abu = 0.f, abv = 0.f;
-    shading_normal_vjp(sink, v.tri, T, sn, v.hu, v.hv, a_shn, abu, abv);      // barycentrics detached: abu/abv dropped
+    if (face) acc_finite(row.fn, a_shn);
+    else shading_normal_vjp(sink, v.tri, T, sn, v.hu, v.hv, a_shn, abu, abv);   // barycentrics detached: abu/abv dropped
     const Vec3f a_dvec = (a_dir - dir * dot(dir, a_dir)) / t;
-    scatter_point(sink, v.tri, v.hu, v.hv, va.p + a_dvec);
+    acc_finite(row.p, va.p + a_dvec);
     return -a_dvec;
 }
 
@@ -786,6 +808,9 @@ PSDR_HD Vec3f camera_sample_reverse(RealSink &real_sink, PrimaryGrad &pg, PathRe
             if (!(beta.x != 0.f || beta.y != 0.f || beta.z != 0.f)) break;
         }
     }
+#ifdef PSDR_EXP_VALUE_ONLY
+    return result;
+#endif
     // masked(value, ~isfinite(value)) = 0 (integrator.cpp:87): a zeroed sample has no gradient either
     if (!(isfinite(result.x) && isfinite(result.y) && isfinite(result.z))) return zero_nonfinite(result);
     if (le0) { sweep.add_rad(e0, 0, adj.x); sweep.add_rad(e0, 1, adj.y); sweep.add_rad(e0, 2, adj.z); }
@@ -801,20 +826,32 @@ PSDR_HD Vec3f camera_sample_reverse(RealSink &real_sink, PrimaryGrad &pg, PathRe
     {
         Its<float> cur = its;
         Vec3f beta(1.f);
-        Its<float> prev = its;       // vertex k-1
+        Vec3f prev_p = its.p;        // vertex k-1: position and where its pending point adjoint goes
+        int prev_tri = -1; float prev_u = 0.f, prev_v = 0.f;
+        Vec3f pend_p(0.f);           // adjoint of p_{k-1} still waiting for the direction chain of vertex k
+        RowAdj row_cur; row_cur.clear();      // row of vertex k, fed by the BSDF sample of iteration k-1
         for (int k = 0; k < nv; ++k) {
             const Vec3f a_c = adj * beta;
             const Vec3f a_f = (k + 1 < nv) ? a_c * rec.c(k) : Vec3f(0.f);
             VertexAdj va; va.clear();
-            const VertexOut vo = replay ? vertex_eval<true, true, SweepSink>(sweep, sc, st, rng, cur, nB, nL, a_c, a_f, k == 0 ? va0 : va, nrays, rec, k)
-                                        : vertex_eval<true, false, SweepSink>(sweep, sc, st, rng, cur, nB, nL, a_c, a_f, k == 0 ? va0 : va, nrays, rec, k);
+            RowAdj row_next; row_next.clear();
+            const VertexOut vo = replay ? vertex_eval<true, true, SweepSink>(sweep, sc, st, rng, cur, nB, nL, a_c, a_f, k == 0 ? va0 : va, nrays, rec, k, &row_next)
+                                        : vertex_eval<true, false, SweepSink>(sweep, sc, st, rng, cur, nB, nL, a_c, a_f, k == 0 ? va0 : va, nrays, rec, k, &row_next);
             if (k >= 1) {
-                const Vec3f a_prev = path_vertex_backward(sweep, sc, cur, prev.p, va);
+                const Vec3f a_prev = path_vertex_backward(sweep, sc, cur, prev_p, va, row_cur);
                 if (k == 1) acc(va0.p, a_prev);
-                else scatter_point(sweep, prev.tri, prev.hu, prev.hv, a_prev);
+                else { acc_finite(pend_p, a_prev); scatter_point(sweep, prev_tri, prev_u, prev_v, pend_p); }
+                flush_row_normal_area(sweep, cur.tri, row_cur);
+                pend_p = row_cur.p;
             }
-            if (!vo.next_valid || k + 1 >= nv) break;
-            beta = beta * vo.f; prev = cur; cur = vo.next;
+            if (!vo.next_valid || k + 1 >= nv) {
+                if (k >= 1) scatter_point(sweep, cur.tri, cur.hu, cur.hv, pend_p);
+                if (vo.next_valid) { scatter_point(sweep, vo.next.tri, vo.next.hu, vo.next.hv, row_next.p); flush_row_normal_area(sweep, vo.next.tri, row_next); }
+                break;
+            }
+            beta = beta * vo.f;
+            prev_p = cur.p; prev_tri = cur.tri; prev_u = cur.hu; prev_v = cur.hv;
+            cur = vo.next; row_cur = row_next;
         }
     }
     // ---- primary vertex: wi = to_local(-d), frame(sh_n(bu,bv)), uv(bu,bv), p = p0 + bu e1 + bv e2, (bu,bv,t) = MT(tri0, ray)
