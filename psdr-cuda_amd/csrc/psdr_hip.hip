@@ -228,6 +228,16 @@ SinkLayout make_sink_layout(const psdr_scene_s *h, const psdr_grads *g) {
     // 2 copies bought 6 % on C2, more nothing: 4 at most, so that a small scene's cache stays a few KB of LDS
     static const int max_rep = std::getenv("PSDR_SINK_REP") ? std::atoi(std::getenv("PSDR_SINK_REP")) : 4;
     while (L.rep * 2 <= max_rep && L.rep * 2 * L.stride <= kSinkCacheWords) L.rep *= 2;
+    // lane-private rows: the leading hot slots are emitter 0's triangles (build_bvh)
+    static const bool priv_on = !(std::getenv("PSDR_SINK_PRIVATE") && std::atoi(std::getenv("PSDR_SINK_PRIVATE")) == 0);
+    L.priv_tri[0] = L.priv_tri[1] = -1; L.priv_slot[0] = L.priv_slot[1] = 0; L.priv_emitter = -1;
+    if (priv_on && L.hot_rows > 0 && h->desc.num_emitters > 0 && h->desc.env_emitter != 0) {
+        const int32_t *ei = h->emitter_i.data();
+        const int n = std::min(std::min(ei[2], 2), L.hot_rows);
+        for (int r = 0; r < n; ++r) { L.priv_tri[r] = ei[1] + r; L.priv_slot[r] = r; }
+        L.priv_rows = n;
+        if (n > 0) { L.priv_off = (L.rep * L.stride + 3) / 4 * 4; if (L.rad_n) L.priv_emitter = 0; }
+    }
     return L;
 }
 

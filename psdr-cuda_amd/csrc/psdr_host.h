@@ -74,7 +74,13 @@ struct SinkLayout {
     const int32_t *hot_map, *hot_tris;       // [T] tri -> slot, [hot_rows] slot -> tri
     int total;
     int rep, stride;                         // copies of the cache (power of two) and their distance in words (odd)
+    // lane-private accumulators (plain LDS read-add-write, no atomics) for the rows EVERY light sample lands on: the first one
+    // or two triangles of emitter 0 (an area-light quad) and its radiance.  kPrivWords words per lane behind the cache copies.
+    int priv_off, priv_rows;                 // priv_rows = 0: off
+    int priv_tri[2], priv_slot[2], priv_emitter;
 };
+constexpr int kPrivRowWords = 13;            // position (p0, e1, e2: 9), face normal (3), area (1)
+constexpr int kPrivWords = 2 * kPrivRowWords + 3;
 
 // The scene handle behind psdr_scene_t: the caller's tables, the BVH on the device and per-handle scratch.
 struct psdr_scene_s {
@@ -146,7 +152,7 @@ constexpr int kMaxInlineTris = 2 * kTinyTris;      // inline triangles of a two-
 int make_ctx(psdr_scene_s *h, const psdr_render_opts *o, int sampler, LaunchCtx &cx);
 bool use_wavefront(const psdr_scene_s *h, const psdr_render_opts *o);
 SinkLayout make_sink_layout(const psdr_scene_s *h, const psdr_grads *g);
-inline int sink_bytes(const SinkLayout &L) { return (L.rep * L.stride * 4 + 15) / 16 * 16; }
+inline int sink_bytes(const SinkLayout &L) { return L.priv_rows > 0 ? (L.priv_off + kPrivWords * kBlock) * 4 : (L.rep * L.stride * 4 + 15) / 16 * 16; }
 int check_counts(const psdr_scene_s *h, const psdr_render_opts *o);
 int begin_call(psdr_scene_s *h, hipStream_t s);
 int primary_edge_order(psdr_scene_s *h, const LaunchCtx &cx, long long i0, long long n, const uint32_t **order, hipStream_t s);

@@ -526,12 +526,29 @@ template <int FL> struct DeviceSink {
         if (slot >= 0 && slot < L.hot_rows) lds_add(lds + L.hot_off + slot * PSDR_TRI_STRIDE + word, v);
         else atomicAdd(g.g_tri_info + (size_t) tri * PSDR_TRI_STRIDE + word, v);
     }
+    // One whole row adjoint (position at (u, v), face normal, area).  The rows every light sample lands on have lane-private
+    // accumulators: a plain LDS read-add-write per word (conflict-free: word * kBlock + lane) instead of an LDS float atomic
+    // at ~3 cycles per active lane.  false: not such a row, the caller scatters word by word.
+    lds_float *priv;      // this lane's column of the private block
+    __device__ __forceinline__ static float finite(float v) { return isfinite(v) ? v : 0.f; }
+    __device__ __forceinline__ bool add_row(int tri, float u, float v, const Vec3f &ap, const Vec3f &afn, float aarea) {
+        if (L.priv_rows == 0 || g.g_tri_info == nullptr) return false;
+        const bool r0 = tri == L.priv_tri[0], r1 = tri == L.priv_tri[1];
+        if (!(r0 || r1)) return false;
+        lds_float *q = priv + (r1 ? kPrivRowWords * kBlock : 0);
+        const Vec3f a{finite(ap.x), finite(ap.y), finite(ap.z)};
+        const float w[kPrivRowWords] = {a.x, a.y, a.z, u * a.x, u * a.y, u * a.z, v * a.x, v * a.y, v * a.z, finite(afn.x), finite(afn.y), finite(afn.z), finite(aarea)};
+#pragma unroll
+        for (int i = 0; i < kPrivRowWords; ++i) q[i * kBlock] += w[i];
+        return true;
+    }
     __device__ __forceinline__ void add_texel(int idx, float v) const {
         if (g.g_texels == nullptr || !ok(v)) return;
         if (L.tex_n) lds_add(lds + L.tex_off + idx, v); else atomicAdd(g.g_texels + idx, v);
     }
     __device__ __forceinline__ void add_rad(int e, int c, float v) const {
         if (g.g_emitter_rad == nullptr || !ok(v)) return;
+        if (e == L.priv_emitter) { priv[(2 * kPrivRowWords + c) * kBlock] += v; return; }
         if (L.rad_n) lds_add(lds + L.rad_off + e * 3 + c, v); else atomicAdd(g.g_emitter_rad + e * 3 + c, v);
     }
     __device__ __forceinline__ void add_cam(int word, float v) { if (ok(v)) cam[word] += v; }
@@ -544,6 +561,11 @@ template <int FL> struct DeviceSink {
         last_tri = -1; last_slot = -1;
         lds = lds0 + (threadIdx.x & (L.rep - 1)) * L.stride;
         for (int i = threadIdx.x; i < L.rep * L.stride; i += kBlock) lds0[i] = 0.f;
+        priv = lds0 + L.priv_off + threadIdx.x;
+        if (L.priv_rows > 0) {
+#pragma unroll 1
+            for (int i = 0; i < kPrivWords; ++i) priv[i * kBlock] = 0.f;
+        }
 #pragma unroll
         for (int i = 0; i < 16; ++i) cam[i] = 0.f;
         __syncthreads();
@@ -559,6 +581,22 @@ template <int FL> struct DeviceSink {
 #pragma unroll
                 for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
                 if ((threadIdx.x & 63) == 0 && v != 0.f) lds_add(lds0 + L.cam_off + i, v);
+            }
+        }
+        if (L.priv_rows > 0) {
+            // private columns -> the cache words they stand for: thread t sums word (t & 31) over 32 of the 256 lanes
+            __syncthreads();
+            const int w = threadIdx.x & 31, part = threadIdx.x >> 5;
+            if (w < kPrivWords) {
+                float sum = 0.f;
+                for (int l = 0; l < 32; ++l) sum += lds0[L.priv_off + w * kBlock + part * 32 + ((l + threadIdx.x) & 31)];
+                if (sum != 0.f) {
+                    if (w < 2 * kPrivRowWords) {
+                        const int r = w / kPrivRowWords, c = w % kPrivRowWords;
+                        const int word = c < 9 ? c : c + 9;                                    // 9..11 -> face normal (18..20), 12 -> area (21)
+                        if (r < L.priv_rows) lds_add(lds0 + L.hot_off + L.priv_slot[r] * PSDR_TRI_STRIDE + word, sum);
+                    } else lds_add(lds0 + L.rad_off + L.priv_emitter * 3 + (w - 2 * kPrivRowWords), sum);
+                }
             }
         }
         __syncthreads();
@@ -842,6 +880,14 @@ int render_rev(psdr_scene_s *h, const psdr_render_opts *o, const float *adj_img,
         h->slots[0] += (uint64_t) n;
         const int depth = o->integrator == PSDR_INTEGRATOR_PATH ? std::min(o->max_depth, kMaxRevDepth) : 1;
         const int rec_bytes = depth * kPathRecWords * kBlock * 4;
+        // lane-private emitter rows (30 KB) only where they do not cost a resident workgroup (C5 PathTracer(3): stacks 22 KB +
+        // record 24 KB + cache 19 KB + 30 KB = one workgroup per CU instead of two, 11.5 -> 19.4 ms)
+        const int wg_per_cu = (o->integrator == PSDR_INTEGRATOR_DIRECT && !(FL & kSceneRough)) ? 3 : 2;       // rev_waves<FL, true, INTEG>
+        {
+            LaunchCtx probe = cx;
+            const int floor_bytes = plan_lds(h, probe, 1 << 30) + rec_bytes;                                    // stacks only + record
+            if (sink.L.priv_rows > 0 && floor_bytes + sink_bytes(sink.L) > h->lds_limit / wg_per_cu) { sink.L.priv_rows = 0; sink.L.priv_emitter = -1; }
+        }
         const int cache_bytes = sink_bytes(sink.L);
         plan_lds(h, cx, rec_bytes + cache_bytes);                  // stage less of the scene: the record + cache live in LDS too
         cx.off_pathrec = lds_bytes(cx, h);
@@ -888,6 +934,7 @@ int render_rev(psdr_scene_s *h, const psdr_render_opts *o, const float *adj_img,
         if (int rc = make_ctx(h, o, 2, cx)) return rc;
         const long long i0 = WH * o->sppse_begin, n = WH * (o->sppse_end - o->sppse_begin);
         h->slots[2] += (uint64_t) n;
+        sink.L.priv_rows = 0; sink.L.priv_emitter = -1;            // boundary samples land on the emitter once per slot: no private rows
         const int cache_bytes = sink_bytes(sink.L);
         plan_lds(h, cx, cache_bytes);
         cx.off_sink = lds_bytes(cx, h);

@@ -70,6 +70,16 @@ template <class Sink> PSDR_HD void flush_row_normal_area(Sink &sink, int tri, co
     sink.add_tri(tri, 21, r.area);
 }
 
+// A sink may take a whole row adjoint at once (DeviceSink::add_row: lane-private accumulators for the emitter's rows)
+template <class Sink, class = void> struct SinkTakesRows : std::false_type {};
+template <class Sink> struct SinkTakesRows<Sink, std::void_t<decltype(std::declval<Sink &>().add_row(0, 0.f, 0.f, std::declval<const Vec3f &>(), std::declval<const Vec3f &>(), 0.f))>> : std::true_type {};
+template <class Sink> PSDR_HD void scatter_row(Sink &sink, int tri, float u, float v, const Vec3f &ap, const Vec3f &afn, float aarea) {
+    if constexpr (SinkTakesRows<Sink>::value) { if (sink.add_row(tri, u, v, ap, afn, aarea)) return; }
+    scatter_point(sink, tri, u, v, ap);
+    scatter_vec(sink, tri, 18, afn);
+    sink.add_tri(tri, 21, aarea);
+}
+
 // Gradient sink interface (duck-typed): add_tri(tri, word, g), add_texel(idx, g), add_rad(e, c, g),
 // add_cam(word, g), add_sedge(edge, word, g), add_pedge(edge, word, g).
 
@@ -599,10 +609,11 @@ PSDR_HD VertexOut vertex_eval(Sink &sink, const SceneView &sc, TraversalStack &s
         const Vec3f a_fv = a_val * cfac;
         const float a_cfac = dot(a_val, f);
         const float a_G = a_cfac / pspdf;
-        if (!env_s) sink.add_tri(etri, 21, a_cfac * cfac / e_area);     // ps.J = A_e / detach(A_e)
+        const float a_earea = a_cfac * cfac / e_area;                   // ps.J = A_e / detach(A_e)
         const float a_cosv = a_G * (cosv < 0.f ? -1.f : 1.f) / d2;
         float a_d2 = -a_G * G / d2;
-        scatter_vec(sink, h2.tri, 18, wo * (-a_cosv));
+        const bool one_row = !env_s && h2.tri == etri;                  // sampled point and hit on the same triangle (the rule): one row update
+        if (!one_row) { if (!env_s) sink.add_tri(etri, 21, a_earea); scatter_vec(sink, h2.tri, 18, wo * (-a_cosv)); }
         acc(a_wo, T2.fn * (-a_cosv));
         Vec3f a_wl(0.f);
         brev.eval_vjp(sink, tv0, its, wl, a_fv, va.wi, a_wl, va.u, va.v);
@@ -613,7 +624,8 @@ PSDR_HD VertexOut vertex_eval(Sink &sink, const SceneView &sc, TraversalStack &s
         const float a_dist = -dot(a_wo, wo) / dist;
         a_d2 += a_dist / (2.f * dist);
         acc(a_wov, wov * (2.f * a_d2));
-        if (!env_s) scatter_point(sink, etri, ba, bb, a_wov);
+        if (one_row) scatter_row(sink, etri, ba, bb, a_wov, wo * (-a_cosv), a_earea);
+        else if (!env_s) scatter_point(sink, etri, ba, bb, a_wov);
         acc(va.p, -a_wov);
     }
     return out;
@@ -846,7 +858,7 @@ PSDR_HD Vec3f camera_sample_reverse(RealSink &real_sink, PrimaryGrad &pg, PathRe
             }
             if (!vo.next_valid || k + 1 >= nv) {
                 if (k >= 1) scatter_point(sweep, cur.tri, cur.hu, cur.hv, pend_p);
-                if (vo.next_valid) { scatter_point(sweep, vo.next.tri, vo.next.hu, vo.next.hv, row_next.p); flush_row_normal_area(sweep, vo.next.tri, row_next); }
+                if (vo.next_valid) scatter_row(sweep, vo.next.tri, vo.next.hu, vo.next.hv, row_next.p, row_next.fn, row_next.area);
                 break;
             }
             beta = beta * vo.f;
