@@ -119,6 +119,12 @@ __global__ __launch_bounds__(kBlock) void k_primary_edge_keys(SceneView sc, RngJ
     vals[j] = (uint32_t) j;
 }
 
+#include "psdr_lbvh.h"
+__global__ void k_scatter_hot(int32_t *__restrict__ map, const int32_t *__restrict__ tris, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) map[tris[i]] = i;
+}
+
 thread_local std::string g_err;
 }  // namespace
 
@@ -274,6 +280,140 @@ int primary_edge_order(psdr_scene_s *h, const LaunchCtx &cx, long long i0, long 
     return 0;
 }
 
+// ---- device tree (psdr_lbvh.h).  Layout of the scratch block: what the refit needs first, the build temporaries behind.
+struct LbvhScratch {
+    LbvhInfo *info; uint32_t *bounds; int32_t *node_parent, *leaf_parent; uint32_t *arrivals;
+    uint32_t *keys, *keys2; int32_t *vals, *vals2; void *sort_tmp; size_t sort_tmp_bytes, total;
+};
+LbvhScratch lbvh_layout(void *base, int T, size_t sort_tmp_bytes) {
+    LbvhScratch L{};
+    size_t off = 0;
+    auto take = [&](size_t bytes) { void *p = base ? (char *) base + off : nullptr; off += (bytes + 255) & ~(size_t) 255; return p; };
+    L.info = (LbvhInfo *) take(sizeof(LbvhInfo)); L.bounds = (uint32_t *) take(6 * 4);
+    L.node_parent = (int32_t *) take((size_t) T * 4); L.leaf_parent = (int32_t *) take((size_t) T * 4);
+    L.arrivals = (uint32_t *) take((size_t) T * 4);
+    L.keys = (uint32_t *) take((size_t) T * 4); L.keys2 = (uint32_t *) take((size_t) T * 4);
+    L.vals = (int32_t *) take((size_t) T * 4); L.vals2 = (int32_t *) take((size_t) T * 4);
+    L.sort_tmp = take(sort_tmp_bytes); L.sort_tmp_bytes = sort_tmp_bytes;
+    L.total = off;
+    return L;
+}
+int lbvh_fit(psdr_scene_s *h, const LbvhScratch &L, float pad, hipStream_t s) {
+    const int T = h->desc.num_tris;
+    HIP_TRY(hipMemsetAsync(L.arrivals, 0, (size_t) T * 4, s));
+    HIP_TRY(hipMemsetAsync(h->d_refit_area, 0, sizeof(float), s));
+    hipLaunchKernelGGL(k_lbvh_fit, dim3((T + kBlock - 1) / kBlock), dim3(kBlock), 0, s, T, h->d_nodes, h->d_btris, L.node_parent, L.leaf_parent, L.arrivals,
+                       h->d_refit_area, pad);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+// refit of a device-built tree: leaf triangles re-read from the table (k_refit_leaves), then the bottom-up pass again
+int lbvh_refit(psdr_scene_s *h, hipStream_t s) {
+    const int T = h->tree_tris;
+    const LbvhScratch L = lbvh_layout(h->d_lbvh, T, 0);
+    hipLaunchKernelGGL(k_refit_leaves, dim3((T + kBlock - 1) / kBlock), dim3(kBlock), 0, s, h->d_btris, h->desc.tri_info, T);
+    return lbvh_fit(h, L, h->bvh_pad, s);
+}
+// Builds the tree on the device.  fallback = true (and 0 returned): the host builder has to do it (too few triangles, tree
+// deeper than the traversal stack).
+int lbvh_build(psdr_scene_s *h, hipStream_t s, bool &fallback) {
+    const int T = h->desc.num_tris;
+    fallback = T <= kLbvhLeaf;
+    if (fallback) return 0;
+    size_t t1 = 0, t2 = 0;
+    uint32_t *nk = nullptr; int32_t *nv = nullptr;
+    HIP_TRY(rocprim::radix_sort_pairs(nullptr, t1, nk, nk, nv, nv, (size_t) T, 0, 30, s));
+    HIP_TRY(rocprim::radix_sort_pairs_desc(nullptr, t2, nk, nk, nv, nv, (size_t) T, 0, 32, s));
+    const size_t sort_tmp = std::max(t1, t2);
+    const size_t need = lbvh_layout(nullptr, T, sort_tmp).total;
+    if (need > h->lbvh_bytes) {
+        if (h->d_lbvh) (void) hipFree(h->d_lbvh);
+        h->d_lbvh = nullptr; h->lbvh_bytes = 0;
+        HIP_TRY(hipMalloc(&h->d_lbvh, need));
+        h->lbvh_bytes = need;
+    }
+    const LbvhScratch L = lbvh_layout(h->d_lbvh, T, sort_tmp);
+    if ((size_t) (T - 1) > h->cap_nodes) {
+        if (h->d_nodes) (void) hipFree(h->d_nodes);
+        h->cap_nodes = std::max<size_t>((size_t) T, 16);
+        HIP_TRY(hipMalloc(&h->d_nodes, h->cap_nodes * sizeof(BvhNode)));
+    }
+    if ((size_t) T * 3 > h->cap_btris) {
+        if (h->d_btris) (void) hipFree(h->d_btris);
+        h->cap_btris = (size_t) T * 3;
+        HIP_TRY(hipMalloc(&h->d_btris, h->cap_btris * sizeof(float4)));
+    }
+    if (!h->d_refit_area) HIP_TRY(hipMalloc(&h->d_refit_area, sizeof(float)));
+    const dim3 gT((T + kBlock - 1) / kBlock), blk(kBlock);
+    HIP_TRY(hipMemsetAsync(L.info, 0, sizeof(LbvhInfo), s));
+    HIP_TRY(hipMemsetAsync(L.bounds, 0xff, 3 * 4, s));
+    HIP_TRY(hipMemsetAsync(L.bounds + 3, 0, 3 * 4, s));
+    hipLaunchKernelGGL(k_lbvh_bounds, gT, blk, 0, s, h->desc.tri_info, T, L.bounds, L.info);
+    hipLaunchKernelGGL(k_lbvh_codes, gT, blk, 0, s, h->desc.tri_info, T, L.bounds, L.keys, L.vals, L.info);
+    HIP_TRY(hipGetLastError());
+    size_t tmp_bytes = L.sort_tmp_bytes;
+    HIP_TRY(rocprim::radix_sort_pairs(L.sort_tmp, tmp_bytes, L.keys, L.keys2, L.vals, L.vals2, (size_t) T, 0, 30, s));
+    HIP_TRY(hipMemsetAsync(L.leaf_parent, 0xff, (size_t) T * 4, s));
+    hipLaunchKernelGGL(k_lbvh_tris, gT, blk, 0, s, h->desc.tri_info, T, L.vals2, h->d_btris);
+    hipLaunchKernelGGL(k_lbvh_hierarchy, gT, blk, 0, s, L.keys2, T, h->d_nodes, L.node_parent, L.leaf_parent);
+    HIP_TRY(hipGetLastError());
+    // the padding of the leaf boxes is a function of the scene extent: fetch it with the validity flag before the fit
+    LbvhInfo info{};
+    HIP_TRY(hipMemcpyAsync(&info, L.info, sizeof(info), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (info.bad) return fail("psdr_bvh_build: non-finite vertex");
+    if (int rc = lbvh_fit(h, L, info.pad, s)) return rc;
+    hipLaunchKernelGGL(k_lbvh_depth, gT, blk, 0, s, T, L.node_parent, L.leaf_parent, L.info);
+    // hot rows of the gradient cache: emitter triangles, then the largest triangles (area keys sorted on the device)
+    constexpr int kMaxHotRows = 200;
+    hipLaunchKernelGGL(k_lbvh_area_keys, gT, blk, 0, s, h->desc.tri_info, T, L.keys, L.vals);
+    HIP_TRY(hipGetLastError());
+    tmp_bytes = L.sort_tmp_bytes;
+    HIP_TRY(rocprim::radix_sort_pairs_desc(L.sort_tmp, tmp_bytes, L.keys, L.keys2, L.vals, L.vals2, (size_t) T, 0, 32, s));
+    float area = 0.f;
+    const int top = std::min(T, kMaxHotRows);
+    std::vector<int32_t> by_area((size_t) top);
+    HIP_TRY(hipMemcpyAsync(&info, L.info, sizeof(info), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&area, h->d_refit_area, sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(by_area.data(), L.vals2, (size_t) top * 4, hipMemcpyDeviceToHost, s));
+    h->emitter_i.assign((size_t) std::max(h->desc.num_emitters, 0) * PSDR_EMITTER_I_STRIDE, 0);
+    if (h->desc.num_emitters > 0 && h->desc.emitter_i)
+        HIP_TRY(hipMemcpyAsync(h->emitter_i.data(), h->desc.emitter_i, h->emitter_i.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (info.depth > kBvhStack - 2) { fallback = true; return 0; }
+    std::vector<int32_t> tris;
+    {
+        auto add = [&](int t) {
+            if (t < 0 || t >= T || (int) tris.size() >= kMaxHotRows) return;
+            if (std::find(tris.begin(), tris.end(), t) == tris.end()) tris.push_back(t);
+        };
+        for (int e = 0; e < h->desc.num_emitters; ++e) {
+            const int32_t *ei = h->emitter_i.data() + (size_t) e * PSDR_EMITTER_I_STRIDE;
+            for (int f = 0; f < ei[2] && f < 64; ++f) add(ei[1] + f);
+        }
+        for (int i = 0; i < top; ++i) add(by_area[(size_t) i]);
+    }
+    if ((size_t) T > h->hot_cap) {
+        if (h->d_hot_map) (void) hipFree(h->d_hot_map);
+        if (h->d_hot_tris) (void) hipFree(h->d_hot_tris);
+        h->hot_cap = (size_t) T;
+        HIP_TRY(hipMalloc(&h->d_hot_map, h->hot_cap * sizeof(int32_t)));
+        HIP_TRY(hipMalloc(&h->d_hot_tris, kMaxHotRows * sizeof(int32_t)));
+    }
+    HIP_TRY(hipMemsetAsync(h->d_hot_map, 0xff, (size_t) T * sizeof(int32_t), s));
+    HIP_TRY(hipMemcpyAsync(h->d_hot_tris, tris.data(), tris.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_scatter_hot, dim3(1), dim3(256), 0, s, h->d_hot_map, h->d_hot_tris, (int) tris.size());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s));            // `tris` dies at return
+    h->hot_rows = (int) tris.size();
+    h->root = 0; h->bvh_depth = info.depth; h->num_nodes = T - 1; h->num_btris = T;
+    h->n_tiny = 0; h->n_blas = 0; h->n_inline = 0;
+    h->tree_tris = T; h->refits_since_build = 0; h->num_builds++; h->bvh_pad = info.pad; h->built_area = area;
+    h->level_start.clear();
+    h->refit_ok = true; h->lbvh = true; h->have_bvh = true;
+    return 0;
+}
+
 // kernel variant of the scene: bit 0 = environment map present, bit 1 = a rough conductor may be present
 const VariantOps *variant_of(const psdr_scene_s *h) {
     const int fl = (h->desc.env_emitter >= 0 ? kSceneEnv : 0) | (h->has_rough ? kSceneRough : 0) | (h->n_blas > 0 ? kSceneForest : 0);
@@ -313,6 +453,7 @@ int psdr_scene_create(psdr_scene_t *out) {
     if (const char *e4 = std::getenv("PSDR_TINY_SCENE")) h->tiny_enabled = std::atoi(e4) != 0;      // 0: walk the tree even for <= 16 triangles
     if (const char *e5 = std::getenv("PSDR_TWO_LEVEL")) h->two_level_enabled = std::atoi(e5) != 0;  // 0: one tree over all triangles
     if (const char *e7 = std::getenv("PSDR_WF_BINNED")) h->wf_binned = std::atoi(e7) != 0;          // 0: wavefront streams not binned by cost class
+    if (const char *e8 = std::getenv("PSDR_BVH_BUILD")) h->bvh_device_mode = std::string(e8) == "device" ? 1 : (std::string(e8) == "host" ? 0 : -1);
     if (const char *e3 = std::getenv("PSDR_SORT_EDGES")) h->sort_edges = std::atoi(e3) != 0;        // 0: primary-edge slots in natural order
     *out = h;
     return 0;
@@ -330,6 +471,7 @@ int psdr_scene_destroy(psdr_scene_t h) {
     if (h->d_hot_tris) (void) hipFree(h->d_hot_tris);
     if (h->d_top) (void) hipFree(h->d_top);
     if (h->d_inline_ids) (void) hipFree(h->d_inline_ids);
+    if (h->d_lbvh) (void) hipFree(h->d_lbvh);
     delete h;
     return 0;
 }
@@ -377,6 +519,14 @@ int psdr_bvh_build(psdr_scene_t h, void *stream) {
             HIP_TRY(hipMemcpyAsync(&prev_area, h->d_refit_area, sizeof(float), hipMemcpyDeviceToHost, h->refit_stream));
             HIP_TRY(hipStreamSynchronize(h->refit_stream));
         }
+        if (prev_area <= kRefitAreaGrowth * h->built_area && h->lbvh) {
+            h->refit_stream = s;
+            if (int rc = lbvh_refit(h, s)) return rc;
+            h->refits_since_build++;
+            h->num_refits++;
+            h->have_bvh = true;
+            return 0;
+        }
         if (prev_area <= kRefitAreaGrowth * h->built_area) {
             h->refit_stream = s;
             HIP_TRY(hipMemsetAsync(h->d_refit_area, 0, sizeof(float), s));
@@ -408,6 +558,13 @@ int psdr_bvh_build(psdr_scene_t h, void *stream) {
             h->have_bvh = true;
             return 0;
         }
+    }
+    // ---- build on the device: large tables (the host build is a D2H of the table + a single-threaded SAH build), or on request
+    h->lbvh = false;
+    if (!tiny && (h->bvh_device_mode == 1 || (h->bvh_device_mode < 0 && T >= kLbvhAutoTris))) {
+        bool fallback = false;
+        if (int rc = lbvh_build(h, s, fallback)) return rc;
+        if (!fallback) return 0;
     }
     std::vector<float> rows((size_t) T * PSDR_TRI_STRIDE);
     HIP_TRY(hipMemcpyAsync(rows.data(), h->desc.tri_info, rows.size() * sizeof(float), hipMemcpyDeviceToHost, s));

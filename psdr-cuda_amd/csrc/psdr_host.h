@@ -104,6 +104,13 @@ struct psdr_scene_s {
     float bvh_pad = 0.f, built_area = 0.f;
     float *d_refit_area = nullptr;
 
+    // tree built on the device (psdr_lbvh.h): -1 = by size, 0 = never (host SAH), 1 = always; scratch kept for the refit
+    int bvh_device_mode = -1;
+    bool lbvh = false;
+    int lbvh_leaves = 0;
+    void *d_lbvh = nullptr;
+    size_t lbvh_bytes = 0;
+
     // tiny scenes: the leaf triangles as they travel in the kernel arguments (SceneView::tiny)
     bool tiny_enabled = true;
     int n_tiny = 0;

@@ -1,0 +1,158 @@
+"""The tree built ON THE DEVICE (csrc/psdr_lbvh.h: Morton codes, rocPRIM sort, Karras radix tree, bottom-up fit) -- what the
+reference's OptiX GAS build does at every configure() (include/psdr/scene/optix.h:277-340, scene.cpp:247-248).  The closest
+hit does not depend on the tree: a device-built tree must return the host-built tree's hits, the oracle's images, and survive a
+refit.  PSDR_BVH_BUILD=device forces it (by default only tables of >= 2^18 triangles take it)."""
+import os
+import time
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from helpers import GpuScene, camera_rays, load_scene, rel_l2
+from psdr_cuda import _abi
+
+pytestmark = pytest.mark.gpu
+
+
+class forced_build:
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        self.old = os.environ.get("PSDR_BVH_BUILD")
+        os.environ["PSDR_BVH_BUILD"] = self.mode
+
+    def __exit__(self, *a):
+        if self.old is None:
+            del os.environ["PSDR_BVH_BUILD"]
+        else:
+            os.environ["PSDR_BVH_BUILD"] = self.old
+
+
+def bvh_stats(g):
+    import ctypes as C
+    out = (C.c_int32 * 4)()
+    _abi.check(g.lib, g.lib.psdr_bvh_stats(g.h, out))
+    return dict(builds=out[0], refits=out[1], nodes=out[2], depth=out[3])
+
+
+def bounce_rays(tb, tri, u, v, seed):
+    info = tb["tri_info"].cpu().numpy()
+    idx = np.nonzero(tri >= 0)[0][:100_000]
+    p = info[tri[idx], 0:3] + u[idx, None] * info[tri[idx], 3:6] + v[idx, None] * info[tri[idx], 6:9]
+    d = np.random.default_rng(seed).normal(size=p.shape).astype(np.float32)
+    return p.astype(np.float32), d / np.linalg.norm(d, axis=1, keepdims=True)
+
+
+@pytest.mark.parametrize("scene", ["cbox_bunny", "bunny_light"])
+def test_device_tree_returns_the_host_trees_hits(scene):
+    sc, _ = load_scene(scene, res=64)
+    tb = sc.tables(0)
+    with forced_build("host"):
+        gh = GpuScene(tb)
+    with forced_build("device"):
+        gd = GpuScene(tb)
+    sh, sd = bvh_stats(gh), bvh_stats(gd)
+    T = tb["tri_info"].shape[0]
+    assert sd["nodes"] == T - 1 and 0 < sd["depth"] <= 38, sd                      # the radix tree over T triangles (node array; subtrees of <= 4 are leaves)
+    print("%s: host tree %s, device tree %s" % (scene, sh, sd))
+    o, d = camera_rays(tb, 200_000, seed=3)
+    for rays in ((o, d), None):
+        if rays is None:
+            rays = bounce_rays(tb, a[1], a[2], a[3], 4)
+        a, b = gh.trace(*rays), gd.trace(*rays)
+        same = a[1] == b[1]
+        assert same.mean() > 0.9995, same.mean()                               # equal-distance hits on shared edges may resolve differently
+        assert np.array_equal(a[0][same], b[0][same])
+        hit = same & (a[1] >= 0)
+        # (the host tree of these scenes is the two-level one: walls are tested as parallelograms, a few ulp apart)
+        assert hit.sum() > 20_000 and np.abs(a[2][hit] - b[2][hit]).max() < 1e-5 and np.abs(a[3][hit] - b[3][hit]).max() < 1e-5
+    # rendered through the device tree: the oracle's image / derivative image
+    opt = _abi.make_opts(spp=8, bsdf_samples=1, light_samples=1)
+    sc2, _ = load_scene(scene, res=48, spp=8)
+    tb2 = sc2.tables(0)
+    with forced_build("device"):
+        g2 = GpuScene(tb2)
+    img, ref = g2.render_c(opt), oracle.render(tb2, opt)
+    assert rel_l2(img, ref) < 1e-3, rel_l2(img, ref)
+
+
+def test_device_tree_refit_follows_the_vertices():
+    sc, _ = load_scene("cbox_bunny", res=64)
+    tb = sc.tables(0)
+    with forced_build("device"):
+        g = GpuScene(tb)
+    assert bvh_stats(g)["builds"] == 1
+    # move the bunny (Mesh[1]) by writing new rows into the table the handle points at, then psdr_bvh_build again: a refit
+    f0, f1 = int(tb["face_offset"][1]), int(tb["face_offset"][2])
+    rows = g.tb["tri_info"]
+    rows[f0:f1, 0] += 7.5
+    rows[f0:f1, 2] -= 3.0
+    torch.cuda.synchronize()
+    _abi.check(g.lib, g.lib.psdr_bvh_build(g.h, None))
+    st = bvh_stats(g)
+    assert st["builds"] == 1 and st["refits"] == 1, st
+    tb_moved = dict(tb); tb_moved["tri_info"] = rows.detach().cpu()
+    with forced_build("host"):
+        fresh = GpuScene(tb_moved)
+    o, d = camera_rays(tb_moved, 200_000, seed=5)
+    a, b = fresh.trace(o, d), g.trace(o, d)
+    same = a[1] == b[1]
+    assert same.mean() > 0.9995 and (a[1] >= f0).sum() > 1000
+    hit = same & (a[1] >= 0)
+    assert np.abs(a[2][hit] - b[2][hit]).max() < 1e-5
+
+
+def test_large_table_is_built_on_the_device_by_default(tmp_path):
+    """A 2 x 363 x 363 = 263 538-triangle height field: above the 2^18 threshold the library builds on the device by itself."""
+    import psdr_cuda
+    from psdr_cuda.scene import look_at
+    n = 364
+    xs = np.linspace(-200.0, 200.0, n)
+    X, Z = np.meshgrid(xs, xs, indexing="ij")
+    Y = 30.0 * np.sin(X * 0.05) * np.cos(Z * 0.04) + 5.0 * np.sin(X * 0.31 + Z * 0.17)
+    idx = np.arange(n * n).reshape(n, n)
+    a, b, c, d = idx[:-1, :-1].ravel(), idx[1:, :-1].ravel(), idx[1:, 1:].ravel(), idx[:-1, 1:].ravel()
+    faces = np.concatenate([np.stack([a, c, b], 1), np.stack([a, d, c], 1)])
+    path = tmp_path / "field.obj"
+    with open(path, "w") as f:
+        f.write("".join("v %.6f %.6f %.6f\n" % t for t in zip(X.ravel(), Y.ravel(), Z.ravel())))
+        f.write("".join("f %d %d %d\n" % tuple(r + 1) for r in faces))
+    sc = psdr_cuda.Scene()
+    sc.opts.width = sc.opts.height = 64
+    sc.opts.spp, sc.opts.sppe, sc.opts.sppse, sc.opts.log_level = 4, 0, 0, 0
+    cam = psdr_cuda.PerspectiveCamera(40.0, 0.1, 1e4)
+    cam.to_world = look_at([0, 260, 420], [0, 0, 0], [0, 1, 0])
+    sc.add_sensor(cam)
+    white = psdr_cuda.Diffuse([0.8, 0.8, 0.8]); white.id = "white"; sc.add_bsdf(white)
+    black = psdr_cuda.Diffuse([0.0, 0.0, 0.0]); black.id = "black"; sc.add_bsdf(black)
+    from psdr_cuda.fixtures import DATA_DIR
+    light = psdr_cuda.Mesh(); light.load(os.path.join(DATA_DIR, "objects", "cbox", "emitter.obj"))
+    xf = np.eye(4); xf[:3, 3] = [0, 120, 0]
+    light._to_world_raw = torch.as_tensor(xf, dtype=torch.float32, device=light._to_world_raw.device)
+    sc.add_mesh(light, black, [30.0, 30.0, 30.0])
+    field = psdr_cuda.Mesh(); field.load(str(path)); field.enable_edges = False
+    sc.add_mesh(field, white, None)
+    sc.finalize(); sc.configure()
+    tb = sc.tables(0)
+    T = tb["tri_info"].shape[0]
+    assert T >= 1 << 18
+    torch.cuda.synchronize()
+    t0 = time.perf_counter(); g = GpuScene(tb); torch.cuda.synchronize(); t_dev = time.perf_counter() - t0
+    st = bvh_stats(g)
+    assert st["nodes"] == T - 1, st                                              # the radix tree, not the SAH tree
+    with forced_build("host"):
+        t0 = time.perf_counter(); gh = GpuScene(tb); torch.cuda.synchronize(); t_host = time.perf_counter() - t0
+    print("T = %d: handle + build on the device %.1f ms (depth %d), on the host %.1f ms (depth %d)" % (T, t_dev * 1e3, st["depth"], t_host * 1e3, bvh_stats(gh)["depth"]))
+    o, d = camera_rays(tb, 200_000, seed=7)
+    a, b = gh.trace(o, d), g.trace(o, d)
+    same = a[1] == b[1]
+    assert same.mean() > 0.999 and (a[1] >= 0).mean() > 0.3
+    hit = same & (a[1] >= 0)
+    assert np.abs(a[2][hit] - b[2][hit]).max() < 1e-5
+    so, stri, su, sv = oracle.trace(tb, o[:20000], d[:20000])
+    assert (stri == b[1][:20000]).mean() > 0.999
+    opt = _abi.make_opts(spp=4, bsdf_samples=1, light_samples=1)
+    assert rel_l2(g.render_c(opt), gh.render_c(opt)) < 1e-4
