@@ -142,6 +142,10 @@ struct psdr_scene_s {
     void *d_sort = nullptr;
     size_t sort_bytes = 0;
 
+    // split reverse launch: per-path records between the value kernel and the adjoint kernel
+    void *d_rev = nullptr;
+    size_t rev_bytes = 0;
+
     // wavefront PathTracer: path-state streams + stream counters
     void *d_ws = nullptr;
     size_t ws_bytes = 0;

@@ -628,18 +628,21 @@ template <int FL, bool GEO, int INTEG> constexpr int rev_waves() {
     if (!GEO) return (FL & (kSceneEnv | kSceneRough)) == 0 ? PSDR_WAVES_REV_MAT + 1 : PSDR_WAVES_REV_MAT;   // plain diffuse variant: 130 VGPRs, C2 texel gradient 3.4 -> 2.8 ms
     return (INTEG == PSDR_INTEGRATOR_DIRECT && !(FL & kSceneRough)) ? 3 : PSDR_WAVES_REV;
 }
-template <int FL, bool GEO, int INTEG>
-__global__ __launch_bounds__(kBlock, (rev_waves<FL, GEO, INTEG>())) void k_camera_rev(LaunchCtx cx, DeviceSink<FL> sink, int spp, int s_begin, int nsp, long long n, float inv_spp,
-                                                       const float *__restrict__ adj_img, float *__restrict__ img,
-                                                       unsigned long long *counters) {
+// STAGE 0: value sweep + adjoint sweep per slot.  Split launch (tree scenes, render_rev): STAGE 1 = the value sweep alone at 3
+// workgroups per CU -- the tree walks are latency-bound and the adjoint code's registers hold the fused kernel at 2 -- writing a
+// record per path to `disk`; STAGE 2 = the adjoint sweep from that record: no traversal, no stacks in LDS.
+template <int FL, bool GEO, int INTEG, int STAGE = 0>
+__global__ __launch_bounds__(kBlock, (STAGE == 1 ? 3 : rev_waves<FL, GEO, INTEG>())) void k_camera_rev(LaunchCtx cx, DeviceSink<FL> sink, int spp, int s_begin, int nsp, long long j0,
+                                                       long long n, float inv_spp, const float *__restrict__ adj_img, float *__restrict__ img,
+                                                       unsigned long long *counters, float *__restrict__ disk, long long disk_stride) {
     TraversalStack st; setup_lds(cx, st);
-    sink.begin(dyn_lds_floats(cx.off_sink));
+    if (STAGE != 1) sink.begin(dyn_lds_floats(cx.off_sink));
     uint32_t nrays = 0;
     const long long nceil = (n + kBlock - 1) / kBlock * kBlock;
-    for (long long j = (long long) blockIdx.x * kBlock + threadIdx.x; j < nceil; j += (long long) gridDim.x * kBlock) {
-        const bool in = j < n;
+    for (long long jj = (long long) blockIdx.x * kBlock + threadIdx.x; jj < nceil; jj += (long long) gridDim.x * kBlock) {
+        const bool in = jj < n;
         int pixel = 0x7fffffff, s_in = 0;
-        if (in) slot_to_pixel(j, nsp, pixel, s_in);
+        if (in) slot_to_pixel(j0 + jj, nsp, pixel, s_in);
         float v[3] = {0.f, 0.f, 0.f};
         PrimaryGrad pg; pg.clear();
         PathRec rec;
@@ -651,18 +654,19 @@ __global__ __launch_bounds__(kBlock, (rev_waves<FL, GEO, INTEG>())) void k_camer
             const uint64_t slot = (uint64_t) pixel * (uint64_t) spp + (uint64_t) s;
             const float *a = adj_img + (size_t) pixel * 3;
             const Vec3f adj{a[0] * inv_spp, a[1] * inv_spp, a[2] * inv_spp};
-            const Vec3f r = camera_sample_reverse<GEO, INTEG>(sink, pg, rec, cx.sc, st, cx.lp, cx.jump, pixel, slot, adj, nrays);
+            const RevDisk dk{disk + jj, disk_stride};
+            const Vec3f r = camera_sample_reverse<GEO, INTEG, STAGE>(sink, pg, rec, cx.sc, st, cx.lp, cx.jump, pixel, slot, adj, nrays, dk);
             v[0] = r.x * inv_spp; v[1] = r.y * inv_spp; v[2] = r.z * inv_spp;
         }
         // primary-triangle row: one add per run of lanes that hit the same triangle
-        if (GEO && sink.g.g_tri_info != nullptr) {
+        if (STAGE != 1 && GEO && sink.g.g_tri_info != nullptr) {
             const bool head = wave_run_sum<kPrimaryWords>(pg.tri, pg.w);
             if (head && pg.tri >= 0) {
 #pragma unroll
                 for (int w = 0; w < kPrimaryWords; ++w) sink.add_tri(pg.tri, w, pg.w[w]);
             }
         }
-        if (img != nullptr) {
+        if (STAGE != 2 && img != nullptr) {
             const bool head = wave_segmented_sum<3>(pixel, v);
             if (head && in) {
                 float *p = img + (size_t) pixel * 3;
@@ -672,7 +676,7 @@ __global__ __launch_bounds__(kBlock, (rev_waves<FL, GEO, INTEG>())) void k_camer
             }
         }
     }
-    sink.end();
+    if (STAGE != 1) sink.end();
     count_rays(counters, nrays);
 }
 
@@ -880,33 +884,71 @@ int render_rev(psdr_scene_s *h, const psdr_render_opts *o, const float *adj_img,
         h->slots[0] += (uint64_t) n;
         const int depth = o->integrator == PSDR_INTEGRATOR_PATH ? std::min(o->max_depth, kMaxRevDepth) : 1;
         const int rec_bytes = depth * kPathRecWords * kBlock * 4;
-        // lane-private emitter rows (30 KB) only where they do not cost a resident workgroup (C5 PathTracer(3): stacks 22 KB +
-        // record 24 KB + cache 19 KB + 30 KB = one workgroup per CU instead of two, 11.5 -> 19.4 ms)
+        const bool geo = grads->g_tri_info != nullptr || grads->g_cam_to_world != nullptr;
         const int wg_per_cu = (o->integrator == PSDR_INTEGRATOR_DIRECT && !(FL & kSceneRough)) ? 3 : 2;       // rev_waves<FL, true, INTEG>
+        // Split launch: a scene with a tree to walk, geometry gradients (the register-heavy kernel), hits replayable.
+        const int split_env = std::getenv("PSDR_REV_SPLIT") ? std::atoi(std::getenv("PSDR_REV_SPLIT")) : -1;
+        const bool replayable = o->integrator == PSDR_INTEGRATOR_PATH || (o->integrator == PSDR_INTEGRATOR_DIRECT && o->bsdf_samples <= 1 && o->light_samples <= 1);
+        const bool has_tree = h->num_nodes > 0 && (h->n_tiny == 0 || h->n_blas > 0);
+        // measured (tools/rev_split_probe.py, 4 M slots): PathTracer(3) cbox_bunny 6.8 -> 4.8 ms, bunny_light 5.6 -> 3.9, 50 k-triangle interior
+        // 11.4 -> 9.4, PathTracer(6) 21 -> 12 / 13 -> 7.3 / 36 -> 20; the DirectIntegrator (three rays per slot) only gains on the
+        // large tree (3.8 -> 3.3 ms; bunny scenes 2.0 -> 2.4); the 12-triangle box neither way
+        const bool worth = o->integrator == PSDR_INTEGRATOR_PATH ? o->max_depth >= 2 : h->num_nodes >= 16384;
+        const bool split = geo && replayable && split_env != 0 && (split_env == 1 || (has_tree && worth && n >= (1ll << 20)));
+        LaunchCtx cx2 = cx;                                         // adjoint kernel of a split launch: nothing staged, no stacks
+        if (split) { cx2.sc.n_lnodes = cx2.sc.n_lbtris = cx2.sc.n_ltri = 0; cx2.off_stack = 0; }
+        // lane-private emitter rows (30 KB) only where they do not cost a resident workgroup (C5 PathTracer(3) fused: stacks 22 KB +
+        // record 24 KB + cache 19 KB + 30 KB = one workgroup per CU instead of two, 11.5 -> 19.4 ms)
         {
             LaunchCtx probe = cx;
-            const int floor_bytes = plan_lds(h, probe, 1 << 30) + rec_bytes;                                    // stacks only + record
+            const int floor_bytes = (split ? 0 : plan_lds(h, probe, 1 << 30)) + rec_bytes;                      // stacks only + record
             if (sink.L.priv_rows > 0 && floor_bytes + sink_bytes(sink.L) > h->lds_limit / wg_per_cu) { sink.L.priv_rows = 0; sink.L.priv_emitter = -1; }
         }
         const int cache_bytes = sink_bytes(sink.L);
-        plan_lds(h, cx, rec_bytes + cache_bytes);                  // stage less of the scene: the record + cache live in LDS too
+        plan_lds(h, cx, split ? rec_bytes : rec_bytes + cache_bytes);   // stage less of the scene: the record (+ cache) live in LDS too
         cx.off_pathrec = lds_bytes(cx, h);
         cx.off_sink = cx.off_pathrec + rec_bytes;
-        const int dyn_bytes = cx.off_sink + cache_bytes;
-        if (dyn_bytes > h->lds_limit) return fail("psdr_render_d_rev: the launch needs " + std::to_string(dyn_bytes) + " bytes of LDS per workgroup (path record of " +
+        cx2.off_pathrec = 0; cx2.off_sink = rec_bytes;
+        const int dyn1 = cx.off_pathrec + rec_bytes;                   // value kernel of a split launch
+        const int dyn_bytes = split ? rec_bytes + cache_bytes : cx.off_sink + cache_bytes;
+        if (std::max(dyn_bytes, split ? dyn1 : 0) > h->lds_limit) return fail("psdr_render_d_rev: the launch needs " + std::to_string(dyn_bytes) + " bytes of LDS per workgroup (path record of " +
                                                   std::to_string(depth) + " levels + traversal stacks + gradient cache), the device offers " + std::to_string(h->lds_limit));
         // material-only gradients (no triangle / camera table wanted) run the variant without the geometric adjoints;
         // the integrator is a compile-time parameter as in the forward kernels (direct: no path record / replay loop)
-        const bool geo = grads->g_tri_info != nullptr || grads->g_cam_to_world != nullptr;
-#define PSDR_LAUNCH_REV(GEO, INTEG)                                                                                                  \
-        do { if (dyn_bytes > 48 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_camera_rev<FL, GEO, INTEG>), hipFuncAttributeMaxDynamicSharedMemorySize, dyn_bytes)); \
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_camera_rev<FL, GEO, INTEG>), dim3(launch_blocks(h, n)), dim3(kBlock), dyn_bytes, s, cx, sink, \
-                           o->spp, o->spp_begin, nsp, n, 1.f / (float) o->spp, adj_img, out_img, h->d_counters); } while (0)
+#define PSDR_LAUNCH_REV_K(GEO, INTEG, STAGE, CX, BYTES, J0, N, IMG, DISK, STRIDE)                                                    \
+        do { if ((BYTES) > 48 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_camera_rev<FL, GEO, INTEG, STAGE>), hipFuncAttributeMaxDynamicSharedMemorySize, (BYTES))); \
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_camera_rev<FL, GEO, INTEG, STAGE>), dim3(launch_blocks(h, (N))), dim3(kBlock), (BYTES), s, CX, sink, \
+                           o->spp, o->spp_begin, nsp, (long long) (J0), (long long) (N), 1.f / (float) o->spp, adj_img, IMG, h->d_counters, DISK, (long long) (STRIDE)); } while (0)
+#define PSDR_LAUNCH_REV(GEO, INTEG) PSDR_LAUNCH_REV_K(GEO, INTEG, 0, cx, dyn_bytes, 0, n, out_img, (float *) nullptr, 0)
+        if (split) {
+            // records of one chunk of slots live in a scratch buffer (2 + 5 depth words per slot); chunks bound its size
+            const int words = kRevDiskHead + kRevDiskPerVertex * depth;
+            const long long chunk = std::min<long long>(n, 1ll << 24);
+            const size_t need = (size_t) chunk * words * sizeof(float);
+            if (need > h->rev_bytes) {
+                if (h->d_rev) (void) hipFree(h->d_rev);
+                h->d_rev = nullptr; h->rev_bytes = 0;
+                HIP_TRY(hipMalloc(&h->d_rev, need));
+                h->rev_bytes = need;
+            }
+            float *disk = reinterpret_cast<float *>(h->d_rev);
+            for (long long c0 = 0; c0 < n; c0 += chunk) {
+                const long long nc = std::min(chunk, n - c0);
+                if (o->integrator == PSDR_INTEGRATOR_PATH) {
+                    PSDR_LAUNCH_REV_K(true, PSDR_INTEGRATOR_PATH, 1, cx, dyn1, c0, nc, out_img, disk, chunk);
+                    PSDR_LAUNCH_REV_K(true, PSDR_INTEGRATOR_PATH, 2, cx2, dyn_bytes, c0, nc, (float *) nullptr, disk, chunk);
+                } else {
+                    PSDR_LAUNCH_REV_K(true, PSDR_INTEGRATOR_DIRECT, 1, cx, dyn1, c0, nc, out_img, disk, chunk);
+                    PSDR_LAUNCH_REV_K(true, PSDR_INTEGRATOR_DIRECT, 2, cx2, dyn_bytes, c0, nc, (float *) nullptr, disk, chunk);
+                }
+            }
+        } else
         switch (o->integrator) {
             case PSDR_INTEGRATOR_DIRECT: if (geo) PSDR_LAUNCH_REV(true, PSDR_INTEGRATOR_DIRECT); else PSDR_LAUNCH_REV(false, PSDR_INTEGRATOR_DIRECT); break;
             case PSDR_INTEGRATOR_PATH: if (geo) PSDR_LAUNCH_REV(true, PSDR_INTEGRATOR_PATH); else PSDR_LAUNCH_REV(false, PSDR_INTEGRATOR_PATH); break;
             default: if (geo) PSDR_LAUNCH_REV(true, PSDR_INTEGRATOR_FIELD); else PSDR_LAUNCH_REV(false, PSDR_INTEGRATOR_FIELD); break;
         }
+#undef PSDR_LAUNCH_REV_K
 #undef PSDR_LAUNCH_REV
         HIP_TRY(hipGetLastError());
     }

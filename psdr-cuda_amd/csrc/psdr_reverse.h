@@ -392,6 +392,18 @@ struct PathRec {
     PSDR_HD Vec3f f(int k) const { return {get(k, 3), get(k, 4), get(k, 5)}; }
 };
 
+// Split reverse launch (tree scenes): the value sweep runs as its own kernel at the occupancy of a forward kernel and leaves,
+// per path, what the adjoint kernel needs instead of tracing again -- the primary triangle, the number of vertices, and per
+// vertex the suffix radiance T_{k+1} and the two triangles its rays arrived at.  One column per path, word w at p[w * stride].
+constexpr int kRevDiskHead = 2, kRevDiskPerVertex = 5;
+struct RevDisk {
+    float *p; long long stride;
+    PSDR_HD void put(int w, float v) const { p[(long long) w * stride] = v; }
+    PSDR_HD float get(int w) const { return p[(long long) w * stride]; }
+    PSDR_HD void puti(int w, int v) const { put(w, __int_as_float_hd(v)); }
+    PSDR_HD int geti(int w) const { return __float_as_int_hd(get(w)); }
+};
+
 // What one vertex hands back to the path loop
 struct VertexOut {
     Vec3f c;            // sum of the emitter contributions gathered at this vertex (unit throughput)
@@ -718,9 +730,10 @@ template <class Sink> PSDR_HD Vec3f path_vertex_backward(Sink &sink, const Scene
 //        the geometric adjoint chain; otherwise the on-surface form, exactly like forward mode
 //        (psdr_device.h Li), and every geometry adjoint is compiled out (MaterialSink)
 //   INTEG >= 0: integrator fixed at compile time (as in the forward kernels); -1: run-time switch
-template <bool GEO, int INTEG = -1, class RealSink>
+//   STAGE 0: both sweeps in one kernel.  1: the value sweep only, record written to `disk`.  2: the adjoint sweep only, from `disk`.
+template <bool GEO, int INTEG = -1, int STAGE = 0, class RealSink>
 PSDR_HD Vec3f camera_sample_reverse(RealSink &real_sink, PrimaryGrad &pg, PathRec &rec, const SceneView &sc, TraversalStack &st, const LiParams &lp,
-                                    const RngJump &jump, int pixel, uint64_t slot, const Vec3f &adj, uint32_t &nrays) {
+                                    const RngJump &jump, int pixel, uint64_t slot, const Vec3f &adj, uint32_t &nrays, const RevDisk &disk = RevDisk{nullptr, 0}) {
     constexpr bool geo = GEO;
     pg.clear();
     using Sink = typename CameraSinkOf<GEO, RealSink>::type;
@@ -737,13 +750,22 @@ PSDR_HD Vec3f camera_sample_reverse(RealSink &real_sink, PrimaryGrad &pg, PathRe
     const float sx = ((float) (pixel % W) + j0) / (float) W, sy = ((float) (pixel / W) + j1) / (float) sc.d.height;
     const Vec3f dcam = camera_space_dir(sc, sx, sy);
     const RayT<float> ray = primary_ray<float>(sc, tv0, sx, sy);
-    nrays++;
-    const Hit h0 = closest_hit<false, (RealSink::flags & kSceneForest) ? 1 : 0>(sc, st, ray.o, ray.d, INFINITY);
-    if (h0.tri < 0) return Vec3f(0.f);
+    Hit h0;
+    int nv = 0;
+    if constexpr (STAGE == 2) {
+        h0.tri = disk.geti(0);
+        if (h0.tri < 0) return Vec3f(0.f);
+        nv = disk.geti(1);
+    } else {
+        nrays++;
+        h0 = closest_hit<false, (RealSink::flags & kSceneForest) ? 1 : 0>(sc, st, ray.o, ray.d, INFINITY);
+        if (h0.tri < 0) { if constexpr (STAGE == 1) disk.puti(0, -1); return Vec3f(0.f); }
+    }
     pg.tri = h0.tri;
     const int tm0 = sc.d.tri_mesh[h0.tri];
     const bool face0 = (tm0 & PSDR_TRI_FACE_NORMALS) != 0;
     const TriRow<float> T0 = load_tri<float>(sc, tv0, h0.tri);
+    if constexpr (STAGE == 2) h0 = hit_on_triangle(h0.tri, T0.p0, T0.e1, T0.e2, ray.o, ray.d);       // the leaf test's arithmetic: the same (u, v)
     // solid-angle form (scene.cpp:355-376)
     float bu, bv, t0;
     Its<float> its;
@@ -804,8 +826,7 @@ PSDR_HD Vec3f camera_sample_reverse(RealSink &real_sink, PrimaryGrad &pg, PathRe
     if (env0) result = env_eval_direction<float>(sc, tv0, ray.d);
 
     // ---- sweep 1 (values): record (c_k, f_k), build the suffix radiances T_k
-    int nv = 0;
-    {
+    if constexpr (STAGE != 2) {
         NullSink<Sink::flags> ns; VertexAdj dummy; dummy.clear();
         Rng r1 = rng;
         Its<float> cur = its;
@@ -824,14 +845,34 @@ PSDR_HD Vec3f camera_sample_reverse(RealSink &real_sink, PrimaryGrad &pg, PathRe
     return result;
 #endif
     // masked(value, ~isfinite(value)) = 0 (integrator.cpp:87): a zeroed sample has no gradient either
-    if (!(isfinite(result.x) && isfinite(result.y) && isfinite(result.z))) return zero_nonfinite(result);
-    if (le0) { sweep.add_rad(e0, 0, adj.x); sweep.add_rad(e0, 1, adj.y); sweep.add_rad(e0, 2, adj.z); }
+    if constexpr (STAGE != 2) {
+        if (!(isfinite(result.x) && isfinite(result.y) && isfinite(result.z))) { if constexpr (STAGE == 1) disk.puti(0, -1); return zero_nonfinite(result); }
+    }
     Vec3f a_d_le0(0.f);                         // d Le(primary) / d ray direction (environment map seen directly)
-    if (env0) { if constexpr (Sink::has_env) a_d_le0 = env_eval_vjp(sweep, sc, ray.d, adj); }
+    if constexpr (STAGE != 1) {
+        if (le0) { sweep.add_rad(e0, 0, adj.x); sweep.add_rad(e0, 1, adj.y); sweep.add_rad(e0, 2, adj.z); }
+        if (env0) { if constexpr (Sink::has_env) a_d_le0 = env_eval_vjp(sweep, sc, ray.d, adj); }
+    }
     // suffix radiances T_{k+1} overwrite c_k in place (T_nv = 0): afterwards rec.c(k) == T_{k+1}
-    {
+    if constexpr (STAGE != 2) {
         Vec3f T(0.f);
         for (int k = nv - 1; k >= 0; --k) { const Vec3f Tk = rec.c(k) + rec.f(k) * T; rec.put(k, 0, T.x); rec.put(k, 1, T.y); rec.put(k, 2, T.z); T = Tk; }
+    }
+    if constexpr (STAGE == 1) {
+        disk.puti(0, h0.tri); disk.puti(1, nv);
+        for (int k = 0; k < nv; ++k) {
+            const int w = kRevDiskHead + k * kRevDiskPerVertex;
+            disk.put(w, rec.get(k, 0)); disk.put(w + 1, rec.get(k, 1)); disk.put(w + 2, rec.get(k, 2));
+            disk.puti(w + 3, rec.tri(k, 0)); disk.puti(w + 4, rec.tri(k, 1));
+        }
+        return result;
+    }
+    if constexpr (STAGE == 2) {
+        for (int k = 0; k < nv; ++k) {
+            const int w = kRevDiskHead + k * kRevDiskPerVertex;
+            rec.put(k, 0, disk.get(w)); rec.put(k, 1, disk.get(w + 1)); rec.put(k, 2, disk.get(w + 2));
+            rec.put_tri(k, 0, disk.geti(w + 3)); rec.put_tri(k, 1, disk.geti(w + 4));
+        }
     }
 
     // ---- sweep 2: replay the same random numbers, differentiate vertex by vertex

@@ -100,3 +100,39 @@ def test_gpu_reverse_matches_host_reverse():
     _, gg = GpuScene(tb).render_d_rev(o, adj)
     for n in gh:
         assert rel_l2(gg[n], gh[n]) < 1e-3, n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["direct11", "path3"])
+def test_split_reverse_launch_equals_the_fused_kernel(kind):
+    """Tree scenes run reverse mode as two kernels -- the value sweep at the occupancy of a forward kernel, leaving a record per
+    path (primary triangle, vertex count, suffix radiances, the triangles the rays arrived at), then the adjoint sweep from the
+    record, without traversal (csrc/psdr_kernels.h render_rev).  Same samples, same arithmetic: the gradients of the one-kernel
+    launch up to the order of the float adds.  PSDR_REV_SPLIT = 1 / 0 forces either (default: by scene and launch size)."""
+    import os
+    import numpy as np
+    from helpers import GpuScene, load_scene, rel_l2
+    from psdr_cuda import _abi
+    kw = dict(bsdf_samples=1, light_samples=1) if kind == "direct11" else dict(integrator=_abi.INTEGRATOR_PATH, max_depth=3)
+    sc, _ = load_scene("cbox_bunny", res=96, spp=8)
+    tb = sc.tables(0)
+    g = GpuScene(tb)
+    o = _abi.make_opts(spp=8, **kw)
+    adj = np.random.default_rng(3).random((96 * 96, 3)).astype(np.float32)
+    out = {}
+    old = os.environ.get("PSDR_REV_SPLIT")
+    try:
+        for mode in ("0", "1"):
+            os.environ["PSDR_REV_SPLIT"] = mode
+            img, grads = g.render_d_rev(o, adj, want=["tri_info", "texels", "emitter_rad", "cam_to_world"])
+            out[mode] = (img, grads, g.counters()[0])
+    finally:
+        if old is None:
+            del os.environ["PSDR_REV_SPLIT"]
+        else:
+            os.environ["PSDR_REV_SPLIT"] = old
+    assert out["0"][2] == out["1"][2]                                       # the same rays traced
+    assert rel_l2(out["1"][0], out["0"][0]) < 1e-6
+    for k in ("tri_info", "texels", "emitter_rad", "cam_to_world"):
+        a, b = out["0"][1][k], out["1"][1][k]
+        assert np.abs(a).max() > 0 and rel_l2(b, a) < 2e-5, (k, rel_l2(b, a))
