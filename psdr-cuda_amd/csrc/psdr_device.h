@@ -920,6 +920,24 @@ PSDR_HD Vec3<M> wavefront_camera_vertex(const SceneView &sc, const TVT &tv, Trav
     if (nvalid) { const Vec3f b = val(beta); alive = b.x != 0.f || b.y != 0.f || b.z != 0.f; }
     return result;
 }
+// Wavefront mode with binned streams: the camera stage stops at the primary hit (emitted radiance seen directly) and hands
+// the hit over as a stream record -- the direct step at the primary vertex then runs as bounce stage 0, class-pure like the
+// others (its sample streams continue behind the two pixel jitter draws: the stage-0 jump).
+template <class M, class TVT>
+PSDR_HD Vec3<M> wavefront_primary_vertex(const SceneView &sc, const TVT &tv, TraversalStack &st, const LiParams &lp, const RngJump &jump,
+                                         int pixel, uint64_t slot, uint32_t &nrays, Its<float> &next, Vec3f &dir, bool &alive) {
+    Rng rng; rng.init(slot, jump);
+    const float j0 = rng.next(), j1 = rng.next();
+    const int W = sc.d.width;
+    const float sx = ((float) (pixel % W) + j0) / (float) W, sy = ((float) (pixel / W) + j1) / (float) sc.d.height;
+    const RayT<float> ray = primary_ray<float>(sc, tv, sx, sy);
+    const Its<float> its = intersect<float>(sc, tv, st, ray, true, kDetached, nrays);
+    alive = its.valid;
+    if (!its.valid) return zero3<M>();
+    next = its;
+    { const Vec3f d = its.p - ray.o; dir = d / norm(d); }      // the direction intersect() derives wi from
+    return lp.hide_emitters ? zero3<M>() : Le<M>(sc, tv, its, true);
+}
 // Wavefront mode, stage k >= 1: the direct step at a path vertex read back from the stream.
 template <class M, class TVT>
 PSDR_HD Vec3<M> wavefront_bounce_vertex(const SceneView &sc, const TVT &tv, TraversalStack &st, const RngJump &jump_k, uint64_t slot,

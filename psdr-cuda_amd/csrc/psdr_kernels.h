@@ -298,10 +298,17 @@ __global__ __launch_bounds__(kBlock, (is_ad<M>() ? 2 : 4)) void k_wf_camera(Laun
         Vec3f origin(0.f), dir(0.f);
         bool alive = false;
         uint32_t slot = 0;
+        bool primary_only = false;
+        if constexpr ((FL & kSceneForest) != 0) primary_only = out.binned != 0 && want_next;
         if (in) {
             slot = (uint32_t) ((uint64_t) pixel * (uint64_t) spp + (uint64_t) (s_begin + s_in));
-            r = zero_nonfinite(wavefront_camera_vertex<M>(cx.sc, tv, st, cx.lp, cx.jump, pixel, slot, nrays, next, beta, origin, alive));
-            if (alive) { Vec3f d = next.p - origin; const float t = norm(d); dir = d / t; }
+            if (primary_only) {
+                r = zero_nonfinite(wavefront_primary_vertex<M>(cx.sc, tv, st, cx.lp, cx.jump, pixel, slot, nrays, next, dir, alive));
+                beta = Vec3<M>{M(1.f), M(1.f), M(1.f)};
+            } else {
+                r = zero_nonfinite(wavefront_camera_vertex<M>(cx.sc, tv, st, cx.lp, cx.jump, pixel, slot, nrays, next, beta, origin, alive));
+                if (alive) { Vec3f d = next.p - origin; const float t = norm(d); dir = d / t; }
+            }
         }
         splat_runs<M>(pixel, in, r, inv_spp, img, dimg, plane);
         if (want_next) {
@@ -785,7 +792,7 @@ int run_camera_wavefront(psdr_scene_s *h, const psdr_render_opts *o, const TV<M,
     const long long max_blocks = ((long long) launch_blocks(h, cap) + kWfSub - 1) / kWfSub * kWfSub;   // >= the grid of any chunk
     const long long binned_sub_cap = (((cap + kBlock - 1) / kBlock + kWfSub) / kWfGroups + 2) * kBlock;
     const long long cap_alloc = binned ? binned_sub_cap * kWfSub : cap + max_blocks * kBlock;
-    const size_t cnt_bytes = (size_t) kWfMaxDepth * kWfStageInts * sizeof(int32_t);
+    const size_t cnt_bytes = (size_t) (kWfMaxDepth + 1) * kWfStageInts * sizeof(int32_t);
     const size_t need = 2 * words * 4 * (size_t) cap_alloc + cnt_bytes;
     if (need > h->ws_bytes) {
         if (h->d_ws) (void) hipFree(h->d_ws);
@@ -809,11 +816,26 @@ int run_camera_wavefront(psdr_scene_s *h, const psdr_render_opts *o, const TV<M,
         const long long cn = std::min(cap, n - j0);
         LaunchCtx cx;
         if (int rc = make_ctx(h, o, 0, cx)) return rc;
-        HIP_TRY(hipMemsetAsync(cnt, 0, (size_t) std::min(depth, kWfMaxDepth) * kWfStageInts * sizeof(int32_t), s));
+        HIP_TRY(hipMemsetAsync(cnt, 0, (size_t) (std::min(depth, kWfMaxDepth) + 1) * kWfStageInts * sizeof(int32_t), s));
         const int blocks = (launch_blocks(h, cn) + kWfSub - 1) / kWfSub * kWfSub;
         const long long trips = (cn + (long long) blocks * kBlock - 1) / ((long long) blocks * kBlock);
         st[0].sub_cap = st[1].sub_cap = binned ? binned_sub_cap : (blocks / kWfSub) * trips * kBlock;
         st[0].count = cnt;
+        if (binned) {
+            // camera stage = primary hit only; the direct step at the primary vertex is bounce stage 0 (binned like the rest):
+            // stage k reads stream k & 1 (counter set k) and appends to stream (k + 1) & 1 (set k + 1)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wf_camera<M, FL>), dim3(blocks), dim3(kBlock), lds_bytes(cx, h), s, cx, tv, o->spp, o->spp_begin, nsp, j0, cn,
+                               inv_spp, img, dimg, WH * 3, st[0], 1, h->d_counters, make_rng_jump(o->rng_offset[0] + 2));
+            HIP_TRY(hipGetLastError());
+            for (int k = 0; k < depth; ++k) {
+                st[(k + 1) & 1].count = cnt + (size_t) (k + 1) * kWfStageInts;
+                cx.jump = make_rng_jump(o->rng_offset[0] + 2 + 5 * (uint64_t) k);
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wf_bounce<M, FL>), dim3(blocks), dim3(kBlock), lds_bytes(cx, h), s, cx, tv, inv_spp, img, dimg, WH * 3,
+                                   st[k & 1], st[(k + 1) & 1], k + 1 < depth ? 1 : 0, h->d_counters, make_rng_jump(o->rng_offset[0] + 2 + 5 * (uint64_t) (k + 1)));
+                HIP_TRY(hipGetLastError());
+            }
+            continue;
+        }
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wf_camera<M, FL>), dim3(blocks), dim3(kBlock), lds_bytes(cx, h), s, cx, tv, o->spp, o->spp_begin, nsp, j0, cn,
                            inv_spp, img, dimg, WH * 3, st[0], depth > 1 ? 1 : 0, h->d_counters, make_rng_jump(o->rng_offset[0] + 2 + 5));
         HIP_TRY(hipGetLastError());

@@ -817,7 +817,7 @@ PSDR_HD Vec3f camera_sample_reverse(RealSink &real_sink, PrimaryGrad &pg, PathRe
     const int nB = direct ? lp.bsdf_samples : 1, nL = direct ? lp.light_samples : 1;
     const int depth = direct ? 1 : (lp.max_depth < kMaxRevDepth ? lp.max_depth : kMaxRevDepth);
     // sweep 2 replays the hits of sweep 1 (always for the PathTracer; DirectIntegrator with <= 1 sample of each kind)
-    const bool replay = INTEG == PSDR_INTEGRATOR_PATH || (nB <= 1 && nL <= 1);
+    const bool replay = STAGE != 0 || INTEG == PSDR_INTEGRATOR_PATH || (nB <= 1 && nL <= 1);      // a split launch is only made when the hits can be replayed
 
     const int e0 = sc.d.mesh_emitter[its.mesh];
     const bool env0 = Sink::has_env && !lp.hide_emitters && e0 >= 0 && e0 == sc.d.env_emitter;
