@@ -566,17 +566,31 @@ template <class R> PSDR_HD R fresnel_conductor(const R &eta, const R &k, const R
 }
 
 // BSDF evaluated at a hit of geometry type G with parameters of type M; all results are M.
+// The material parameters of ONE vertex, looked up once (reverse mode: sample / eval / pdf and their adjoints would fetch the
+// five textures of a rough conductor ~34 times per vertex, with the gradient adds in between keeping the compiler from merging them)
+template <class M> struct MatCache { M au, av; Vec3<M> eta, k, refl; };
 template <class G, class M> struct Bsdf {
     const int32_t *rec;
+    const MatCache<M> *mc = nullptr;       // set: tex1 / tex3 answer from it
     PSDR_HD Bsdf(const SceneView &sc, int id) : rec(sc.d.bsdf_rec + (size_t) (id < 0 ? 0 : id) * PSDR_BSDF_STRIDE) {}
+    template <class TVT> PSDR_HD MatCache<M> fetch(const SceneView &sc, const TVT &tv, const Its<G> &its) const {
+        MatCache<M> c;
+        c.refl = tex3(sc, tv, PSDR_SLOT_REFLECTANCE, its);
+        if (is_diffuse(tv)) { c.au = c.av = M(0.f); c.eta = c.k = zero3<M>(); return c; }
+        c.au = tex1(sc, tv, PSDR_SLOT_ALPHA_U, its); c.av = tex1(sc, tv, PSDR_SLOT_ALPHA_V, its);
+        c.eta = tex3(sc, tv, PSDR_SLOT_ETA, its); c.k = tex3(sc, tv, PSDR_SLOT_K, its);
+        return c;
+    }
     PSDR_HD int type() const { return rec[0]; }
     // diffuse unless the kernel instance carries the rough-conductor code (TangentView FLAGS)
     template <class TVT> PSDR_HD bool is_diffuse(const TVT &) const { return !TVT::has_rough || rec[0] == PSDR_BSDF_DIFFUSE; }
     PSDR_HD const int32_t *slot(int s) const { return rec + 1 + 3 * s; }
     template <class TVT> PSDR_HD Vec3<M> tex3(const SceneView &sc, const TVT &tv, int s, const Its<G> &its) const {
+        if (mc) return s == PSDR_SLOT_ETA ? mc->eta : (s == PSDR_SLOT_K ? mc->k : mc->refl);
         M o[3]; bitmap_eval<M, 3>(sc, tv, slot(s), its.uvx, its.uvy, o); return {o[0], o[1], o[2]};
     }
     template <class TVT> PSDR_HD M tex1(const SceneView &sc, const TVT &tv, int s, const Its<G> &its) const {
+        if (mc) return s == PSDR_SLOT_ALPHA_U ? mc->au : mc->av;
         M o[1]; bitmap_eval<M, 1>(sc, tv, slot(s), its.uvx, its.uvy, o); return o[0];
     }
     // Diffuse::__eval (diffuse.cpp:25-35) / RoughConductor::__eval (roughconductor.cpp:40-58); value = f * cos(theta_o)

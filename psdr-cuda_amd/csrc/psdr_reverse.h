@@ -447,7 +447,9 @@ PSDR_HD VertexOut vertex_eval(Sink &sink, const SceneView &sc, TraversalStack &s
     // the path ends (the caller stops on !next_valid, so the skipped random numbers are never missed)
     if (sc.d.mesh_bsdf[its.mesh] < 0) return out;
     constexpr bool kEnv = Sink::has_env;
-    const BsdfRev<Sink> brev(sc, sc.d.mesh_bsdf[its.mesh]);
+    BsdfRev<Sink> brev(sc, sc.d.mesh_bsdf[its.mesh]);
+    const MatCache<float> mat = brev.b.fetch(sc, tv0, its);        // the vertex' material parameters, looked up once
+    brev.b.mc = &mat;
     const Bsdf<float, float> &bsdf = brev.b;
     if (REPLAY && !BACKWARD) { rec.put_tri(k, 0, -1); rec.put_tri(k, 1, -1); }
     for (int i = 0; i < nB; ++i) {

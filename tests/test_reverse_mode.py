@@ -90,7 +90,7 @@ def test_dot_product_identity_gpu(scene, kw, names, sppe, sppse):
         assert rel_l2(img_r, img_f) < 2e-2
     else:
         bad = np.abs(img_r - img_f).max(1) > 1e-4 * (1.0 + np.abs(img_f).max(1))
-        assert bad.mean() < 0.005 and rel_l2(img_r[~bad], img_f[~bad]) < 1e-4, (int(bad.sum()), rel_l2(img_r, img_f))
+        assert bad.mean() < 0.01 and rel_l2(img_r[~bad], img_f[~bad]) < 1e-4 and rel_l2(img_r, img_f) < 1e-3, (int(bad.sum()), rel_l2(img_r, img_f))
 
 
 @pytest.mark.gpu
