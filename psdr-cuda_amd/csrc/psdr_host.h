@@ -142,6 +142,10 @@ struct psdr_scene_s {
     void *d_sort = nullptr;
     size_t sort_bytes = 0;
 
+    // reverse mode, primary edges: copies of the edge gradient table (PrimaryEdgeSink)
+    void *d_pe_rep = nullptr;
+    size_t pe_rep_bytes = 0;
+
     // split reverse launch: per-path records between the value kernel and the adjoint kernel
     void *d_rev = nullptr;
     size_t rev_bytes = 0;

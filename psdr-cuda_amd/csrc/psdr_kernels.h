@@ -689,14 +689,26 @@ __global__ __launch_bounds__(kBlock, (STAGE == 1 ? 3 : rev_waves<FL, GEO, INTEG>
 
 // The primary-edge term only produces gradients of the edge table (the two Li values are detached): a sink
 // without the LDS gradient cache, so the kernel is not held at 2 workgroups per CU by 24 KB of static LDS.
+// The long edges of a scene (the box walls) take most of the length-weighted samples, the slots are pixel-sorted, so wave after wave
+// adds to the same 32-byte row: same-line L2 atomics serialise and cost 3.9 of this kernel's 5.1 ms on cbox_bunny (C3, 4 M slots).  The
+// adds go to one of `reps` copies of the table (by workgroup), k_sum_replicas folds them into the caller's table afterwards.
 template <int FL> struct PrimaryEdgeSink {
     static constexpr int flags = FL;
     static constexpr bool has_env = (FL & kSceneEnv) != 0;
-    float *g_prim_edge;
+    float *g_prim_edge;       // the caller's table (reps == 1) or the first copy
+    long long rep_stride;     // floats between copies
+    int reps;
     __device__ __forceinline__ void add_pedge(int e, int word, float v) const {
-        if (v != 0.f && isfinite(v)) atomicAdd(g_prim_edge + (size_t) e * PSDR_PEDGE_STRIDE + word, v);
+        if (v != 0.f && isfinite(v)) atomicAdd(g_prim_edge + (size_t) (blockIdx.x % (unsigned) reps) * rep_stride + (size_t) e * PSDR_PEDGE_STRIDE + word, v);
     }
 };
+__global__ __launch_bounds__(kBlock) void k_sum_replicas(float *__restrict__ dst, const float *__restrict__ rep, long long n, int reps) {
+    const long long i = (long long) blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int r = 0; r < reps; ++r) s += rep[(size_t) r * n + i];
+    if (s != 0.f) dst[i] += s;
+}
 template <int FL, int INTEG>
 __global__ __launch_bounds__(kBlock, PSDR_WAVES_PE) void k_primary_edge_rev(LaunchCtx cx, PrimaryEdgeSink<FL> sink, long long i0, long long n, float inv_sppe,
                                                                             const float *__restrict__ adj_img, unsigned long long *counters,
@@ -979,7 +991,22 @@ int render_rev(psdr_scene_s *h, const psdr_render_opts *o, const float *adj_img,
         if (int rc = make_ctx(h, o, 1, cx)) return rc;
         const long long i0 = WH * o->sppe_begin, n = WH * (o->sppe_end - o->sppe_begin);
         h->slots[1] += (uint64_t) n;
-        const PrimaryEdgeSink<FL> pe_sink{grads->g_prim_edge};
+        // replicated gradient table (see PrimaryEdgeSink): up to 64 copies within 64 MB of the sort scratch's neighbour buffer
+        const long long pe_words = (long long) h->desc.num_prim_edges * PSDR_PEDGE_STRIDE;
+        int reps = 1;
+        while (reps < 64 && (long long) (reps * 2) * pe_words * 4 <= (64ll << 20)) reps *= 2;
+        if (n < (1ll << 18)) reps = 1;
+        if (reps > 1) {
+            const size_t need = (size_t) reps * pe_words * sizeof(float);
+            if (need > h->pe_rep_bytes) {
+                if (h->d_pe_rep) (void) hipFree(h->d_pe_rep);
+                h->d_pe_rep = nullptr; h->pe_rep_bytes = 0;
+                HIP_TRY(hipMalloc(&h->d_pe_rep, need));
+                h->pe_rep_bytes = need;
+            }
+            HIP_TRY(hipMemsetAsync(h->d_pe_rep, 0, need, s));
+        }
+        const PrimaryEdgeSink<FL> pe_sink{reps > 1 ? reinterpret_cast<float *>(h->d_pe_rep) : grads->g_prim_edge, pe_words, reps};
         const uint32_t *order = nullptr;
         if (int rc = primary_edge_order(h, cx, i0, n, &order, s)) return rc;
 #define PSDR_LAUNCH_PER(INTEG)                                                                                                       \
@@ -992,6 +1019,11 @@ int render_rev(psdr_scene_s *h, const psdr_render_opts *o, const float *adj_img,
         }
 #undef PSDR_LAUNCH_PER
         HIP_TRY(hipGetLastError());
+        if (reps > 1) {
+            hipLaunchKernelGGL(k_sum_replicas, dim3((unsigned) ((pe_words + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, grads->g_prim_edge,
+                               reinterpret_cast<const float *>(h->d_pe_rep), pe_words, reps);
+            HIP_TRY(hipGetLastError());
+        }
     }
     if (o->sppse > 0 && o->sppse_end > o->sppse_begin && h->desc.num_sec_edges > 0 && o->integrator == PSDR_INTEGRATOR_DIRECT) {
         LaunchCtx cx;
