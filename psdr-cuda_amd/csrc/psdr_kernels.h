@@ -204,10 +204,12 @@ __device__ __forceinline__ void stream_push(const PathStream &out, bool alive, i
 // sample streams start at `jump_next`: bit 0 = the BSDF-sampled ray enters a tree box, bit 1 = the light ray does.  The
 // same vertex reconstruction, the same draws and the same sampling routines as direct_step, on plain floats; the box
 // test ignores t_best (conservative: class 0 NEVER walks a tree).
+// `next` is the complete vertex the current stage just produced (position, frame, wi): no need to rebuild it from the record as the
+// next stage will -- a direction one ulp apart can at worst put a record into a cheaper class than its walk turns out to be.
 template <class TVT>
-__device__ __forceinline__ int classify_next(const SceneView &sc, const TVT &, const RngJump &jump_next, uint32_t slot, const Its<float> &next, const Vec3f &dir) {
+__device__ __forceinline__ int classify_next(const SceneView &sc, const TVT &, const RngJump &jump_next, uint32_t slot, const Its<float> &next, const Vec3f &) {
     const TangentView<0, TVT::flags> tv0{};
-    const Its<float> its = path_vertex_from_record(sc, tv0, next.tri, next.hu, next.hv, dir);
+    const Its<float> &its = next;
     const int bsdf_id = sc.d.mesh_bsdf[its.mesh];
     if (bsdf_id < 0) return 0;
     auto enters = [&](const Vec3f &o, const Vec3f &d, float tmax) {

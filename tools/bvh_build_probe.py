@@ -12,10 +12,12 @@ from psdr_cuda.fixtures import make_interior_scene
 
 
 def timeit(fn, reps=3):
-    fn(); torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(reps):
-        fn()
-    torch.cuda.synchronize(); return (time.perf_counter() - t0) / reps * 1e3
+    """median of individually timed calls after one warm-up call"""
+    fn(); torch.cuda.synchronize()
+    ts = []
+    for _ in range(max(reps, 3)):
+        t0 = time.perf_counter(); fn(); torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
+    return sorted(ts)[len(ts) // 2]
 
 
 def tables(name):

@@ -11,12 +11,13 @@ from psdr_cuda import _abi
 
 
 def timeit(fn, reps=3):
+    """median of `reps` individually timed calls after one warm-up call (a host-side stall -- the caching allocator returning blocks, a
+    page-in -- lands in one repetition, not in the figure)"""
     fn(); torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        fn()
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / reps * 1e3
+    ts = []
+    for _ in range(max(reps, 3)):
+        t0 = time.perf_counter(); fn(); torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
+    return sorted(ts)[len(ts) // 2]
 
 
 def run(name, tb, spp, spp_range, depths=(3,)):
