@@ -283,8 +283,11 @@ __device__ __forceinline__ void splat_runs(int pixel, bool valid, const Vec3<M> 
     }
 }
 
+#ifndef PSDR_WF_WAVES
+#define PSDR_WF_WAVES 4
+#endif
 template <class M, int FL>
-__global__ __launch_bounds__(kBlock, (is_ad<M>() ? 2 : 4)) void k_wf_camera(LaunchCtx cx, TV<M, FL> tv, int spp, int s_begin, int nsp, long long j0, long long n,
+__global__ __launch_bounds__(kBlock, (is_ad<M>() ? 2 : PSDR_WF_WAVES)) void k_wf_camera(LaunchCtx cx, TV<M, FL> tv, int spp, int s_begin, int nsp, long long j0, long long n,
                                                         float inv_spp, float *__restrict__ img, float *__restrict__ dimg, long long plane,
                                                         PathStream out, int want_next, unsigned long long *counters, RngJump jump_next) {
     TraversalStack st; setup_lds(cx, st);
@@ -372,7 +375,7 @@ __device__ __forceinline__ void wf_bounce_record(const LaunchCtx &cx, const TV<M
 // Binned streams: the 64 sub-streams form one list of 256-record chunks (expensive classes first) that the workgroups
 // grab kWfGrab at a time from one counter.
 template <class M, int FL>
-__global__ __launch_bounds__(kBlock, (is_ad<M>() ? 2 : 4)) void k_wf_bounce(LaunchCtx cx, TV<M, FL> tv, float inv_spp, float *__restrict__ img,
+__global__ __launch_bounds__(kBlock, (is_ad<M>() ? 2 : PSDR_WF_WAVES)) void k_wf_bounce(LaunchCtx cx, TV<M, FL> tv, float inv_spp, float *__restrict__ img,
                                                         float *__restrict__ dimg, long long plane, PathStream in,
                                                         PathStream out, int want_next, unsigned long long *counters, RngJump jump_next) {
     TraversalStack st; setup_lds(cx, st);
@@ -797,7 +800,11 @@ int run_camera_wavefront(psdr_scene_s *h, const psdr_render_opts *o, const TV<M,
     const int nsp = o->spp_end - o->spp_begin;
     if (o->spp <= 0 || nsp <= 0) return 0;
     const long long n = WH * nsp;
-    const bool binned = (FL & kSceneForest) != 0 && h->n_blas > 0 && h->wf_binned;
+    // class-binned streams pay where most paths survive every bounce (rooms); in an open scene the streams thin out quickly and the 64
+    // sub-streams of mostly empty chunks cost more than the classes save (bunny_light PathTracer(3) 4.9 against 3.3 ms plain,
+    // PathTracer(6) 8.7 against 3.6)
+    const bool open_scene = h->path_survival >= 0.f && h->path_survival < 0.55f;
+    const bool binned = (FL & kSceneForest) != 0 && h->n_blas > 0 && h->wf_binned && !open_scene;
     const long long cap = std::min(n, binned ? kWfChunk / 2 : kWfChunk);
     const int depth = o->max_depth;
     const size_t words = 8 + 3 * (1 + K);
