@@ -589,7 +589,9 @@ int psdr_bvh_build(psdr_scene_t h, void *stream) {
     if (forest) {
         if (const char *err = fb.run(rows.data(), tri_mesh.data(), T, h->desc.num_meshes)) return fail(err);
         pack_tiny_prims(fb.inline_tris, top_prims);
-        if ((int) top_prims.size() / 3 > kTinyTris) { forest = false; fb = ForestBuilder(); }        // too many inline primitives: one tree
+        // too many inline primitives: one tree.  Too few: nothing room-like to keep out of the trees (two bunnies and a light quad:
+        // PathTracer(3) 2.9 ms on one tree against 3.1 on the forest) -- the two-level tree is for walls around objects
+        if ((int) top_prims.size() / 3 > kTinyTris || (int) fb.inline_tris.size() / 3 < 6) { forest = false; fb = ForestBuilder(); }
     }
     if (!forest) { if (const char *err = b.run(rows.data(), T, root)) return fail(err); }
     std::vector<BvhNode> &nodes = forest ? fb.nodes : b.nodes;
