@@ -96,6 +96,7 @@ def extra(which):
         tb = sc.tables(0); g = GpuScene(tb); n = 1024 * 1024 * 64
         for name, kw in (("direct11", dict(bsdf_samples=1, light_samples=1)), ("path3", dict(integrator=_abi.INTEGRATOR_PATH, max_depth=3))):
             o = _abi.make_opts(spp=512, spp_range=(0, 64), **kw)
+            g.render_c(o); g.counters()          # as the psdr_cuda surface does on the first calls: the library learns the path survival ratio
             ms = timeit(lambda: g.render_c(o), reps=2); r = g.counters()[0] / n
             print("C4 shard %-9s renderC (67M slots) %8.2f ms  %7.0f Msamples/s  rays/slot %.2f" % (name, ms, n / ms / 1e3, r))
     if "c5" in which:
