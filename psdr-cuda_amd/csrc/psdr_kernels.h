@@ -167,6 +167,8 @@ constexpr int kWfGroups = 16, kWfClasses = 4, kWfGrab = 8;
 constexpr int kWfStageInts = (kWfSub + 1) * kWfCountStride;       // per stage: 64 sub-stream counters + the chunk-grab counter
 struct PathStream {
     int32_t *pixel; uint32_t *slot; int32_t *tri; float *hu, *hv; float *dir; float *beta;   // dir: [3][cap], beta: [3(1+K)][cap]
+    float *acc;           // [3(1+K)][cap] radiance gathered so far: a sample is splatted ONCE, when its path ends, so that a non-finite
+                          // contribution zeroes the whole sample as the fused kernel and the reference do (integrator.cpp:87)
     long long cap;
     int32_t *count;       // [kWfSub * kWfCountStride] records in each sub-stream (+ the grab counter behind them)
     long long sub_cap;    // records per sub-stream
@@ -174,21 +176,25 @@ struct PathStream {
 };
 
 template <class M>
-__device__ __forceinline__ void stream_write(const PathStream &out, long long i, int pixel, uint32_t slot, const Its<float> &next, const Vec3f &dir, const Vec3<M> &beta) {
+__device__ __forceinline__ void stream_write(const PathStream &out, long long i, int pixel, uint32_t slot, const Its<float> &next, const Vec3f &dir, const Vec3<M> &beta,
+                                             const Vec3<M> &acc) {
     constexpr int K = ad_traits<M>::K;
     out.pixel[i] = pixel; out.slot[i] = slot; out.tri[i] = next.tri; out.hu[i] = next.hu; out.hv[i] = next.hv;
     out.dir[i] = dir.x; out.dir[out.cap + i] = dir.y; out.dir[2 * out.cap + i] = dir.z;
     out.beta[i] = val(beta.x); out.beta[out.cap + i] = val(beta.y); out.beta[2 * out.cap + i] = val(beta.z);
+    out.acc[i] = val(acc.x); out.acc[out.cap + i] = val(acc.y); out.acc[2 * out.cap + i] = val(acc.z);
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         out.beta[(3 + 3 * k) * out.cap + i] = tangent(beta.x, k); out.beta[(4 + 3 * k) * out.cap + i] = tangent(beta.y, k);
         out.beta[(5 + 3 * k) * out.cap + i] = tangent(beta.z, k);
+        out.acc[(3 + 3 * k) * out.cap + i] = tangent(acc.x, k); out.acc[(4 + 3 * k) * out.cap + i] = tangent(acc.y, k);
+        out.acc[(5 + 3 * k) * out.cap + i] = tangent(acc.z, k);
     }
 }
 
 template <class M>
 __device__ __forceinline__ void stream_push(const PathStream &out, bool alive, int pixel, uint32_t slot, const Its<float> &next,
-                                            const Vec3f &dir, const Vec3<M> &beta) {
+                                            const Vec3f &dir, const Vec3<M> &beta, const Vec3<M> &acc) {
     const unsigned long long mask = __ballot(alive);
     if (mask == 0ull) return;
     const int lane = threadIdx.x & 63, sub = blockIdx.x % kWfSub;
@@ -197,7 +203,7 @@ __device__ __forceinline__ void stream_push(const PathStream &out, bool alive, i
     base = __shfl(base, __ffsll((long long) mask) - 1, 64);
     if (!alive) return;
     const long long i = (long long) sub * out.sub_cap + base + __popcll(mask & ((1ull << lane) - 1ull));
-    stream_write<M>(out, i, pixel, slot, next, dir, beta);
+    stream_write<M>(out, i, pixel, slot, next, dir, beta, acc);
 }
 
 // Cost class of the two rays the path will trace at the vertex `next` (arrival direction `dir`) in the stage whose
@@ -242,7 +248,7 @@ __device__ __forceinline__ int classify_next(const SceneView &sc, const TVT &, c
 // kWfGroups sub-streams per class whatever block happens to process the chunk).
 template <class M>
 __device__ __forceinline__ void stream_push_binned(const PathStream &out, bool alive, int cls, long long chunk, int pixel, uint32_t slot, const Its<float> &next,
-                                                   const Vec3f &dir, const Vec3<M> &beta) {
+                                                   const Vec3f &dir, const Vec3<M> &beta, const Vec3<M> &acc) {
     const int lane = threadIdx.x & 63, group = (int) (chunk % kWfGroups);
 #pragma unroll
     for (int c = 0; c < kWfClasses; ++c) {
@@ -253,7 +259,7 @@ __device__ __forceinline__ void stream_push_binned(const PathStream &out, bool a
         int base = 0;
         if (lane == __ffsll((long long) mask) - 1) base = atomicAdd(out.count + sub * kWfCountStride, (int) __popcll(mask));
         base = __shfl(base, __ffsll((long long) mask) - 1, 64);
-        if (mine) stream_write<M>(out, (long long) sub * out.sub_cap + base + __popcll(mask & ((1ull << lane) - 1ull)), pixel, slot, next, dir, beta);
+        if (mine) stream_write<M>(out, (long long) sub * out.sub_cap + base + __popcll(mask & ((1ull << lane) - 1ull)), pixel, slot, next, dir, beta, acc);
     }
 }
 
@@ -308,19 +314,21 @@ __global__ __launch_bounds__(kBlock, (is_ad<M>() ? 2 : PSDR_WF_WAVES)) void k_wf
         if (in) {
             slot = (uint32_t) ((uint64_t) pixel * (uint64_t) spp + (uint64_t) (s_begin + s_in));
             if (primary_only) {
-                r = zero_nonfinite(wavefront_primary_vertex<M>(cx.sc, tv, st, cx.lp, cx.jump, pixel, slot, nrays, next, dir, alive));
+                r = wavefront_primary_vertex<M>(cx.sc, tv, st, cx.lp, cx.jump, pixel, slot, nrays, next, dir, alive);
                 beta = Vec3<M>{M(1.f), M(1.f), M(1.f)};
             } else {
-                r = zero_nonfinite(wavefront_camera_vertex<M>(cx.sc, tv, st, cx.lp, cx.jump, pixel, slot, nrays, next, beta, origin, alive));
+                r = wavefront_camera_vertex<M>(cx.sc, tv, st, cx.lp, cx.jump, pixel, slot, nrays, next, beta, origin, alive);
                 if (alive) { Vec3f d = next.p - origin; const float t = norm(d); dir = d / t; }
             }
         }
-        splat_runs<M>(pixel, in, r, inv_spp, img, dimg, plane);
+        // a path that goes on carries its radiance along; one that ends here is splatted now
+        const bool goes_on = want_next && alive;
+        splat_runs<M>(pixel, in && !goes_on, zero_nonfinite(r), inv_spp, img, dimg, plane);
         if (want_next) {
             if constexpr ((FL & kSceneForest) != 0) {
-                if (out.binned) stream_push_binned<M>(out, alive, alive ? classify_next(cx.sc, tv, jump_next, slot, next, dir) : 0, jj / kBlock, pixel, slot, next, dir, beta);
-                else stream_push<M>(out, alive, pixel, slot, next, dir, beta);
-            } else stream_push<M>(out, alive, pixel, slot, next, dir, beta);
+                if (out.binned) stream_push_binned<M>(out, alive, alive ? classify_next(cx.sc, tv, jump_next, slot, next, dir) : 0, jj / kBlock, pixel, slot, next, dir, beta, r);
+                else stream_push<M>(out, alive, pixel, slot, next, dir, beta, r);
+            } else stream_push<M>(out, alive, pixel, slot, next, dir, beta, r);
         }
     }
     count_rays(counters, nrays);
@@ -350,10 +358,19 @@ __device__ __forceinline__ void wf_bounce_record(const LaunchCtx &cx, const TV<M
                 beta.z.d[k] = in.beta[(5 + 3 * k) * in.cap + j];
             }
         }
+        Vec3<M> acc;
+        acc.x = M(in.acc[j]); acc.y = M(in.acc[in.cap + j]); acc.z = M(in.acc[2 * in.cap + j]);
+        if constexpr (K > 0) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                acc.x.d[k] = in.acc[(3 + 3 * k) * in.cap + j]; acc.y.d[k] = in.acc[(4 + 3 * k) * in.cap + j];
+                acc.z.d[k] = in.acc[(5 + 3 * k) * in.cap + j];
+            }
+        }
         const Its<float> its = path_vertex_from_record(cx.sc, tv, in.tri[j], in.hu[j], in.hv[j], din);
         Vec3<M> f;
         const Vec3<M> c = wavefront_bounce_vertex<M>(cx.sc, tv, st, cx.jump, (uint64_t) slot, its, nrays, next, f, alive);
-        r = zero_nonfinite(beta * c);
+        r = acc + beta * c;
         if (alive) {
             beta = beta * f;
             const Vec3f b = val(beta);
@@ -361,12 +378,13 @@ __device__ __forceinline__ void wf_bounce_record(const LaunchCtx &cx, const TV<M
             Vec3f d = next.p - its.p; const float t = norm(d); dir = d / t;
         }
     }
-    splat_runs<M>(pixel, live, r, inv_spp, img, dimg, plane);
+    const bool goes_on = want_next && alive;
+    splat_runs<M>(pixel, live && !goes_on, zero_nonfinite(r), inv_spp, img, dimg, plane);
     if (want_next) {
         if constexpr ((FL & kSceneForest) != 0) {
-            if (out.binned) stream_push_binned<M>(out, alive, alive ? classify_next(cx.sc, tv, jump_next, slot, next, dir) : 0, chunk, pixel, slot, next, dir, beta);
-            else stream_push<M>(out, alive, pixel, slot, next, dir, beta);
-        } else stream_push<M>(out, alive, pixel, slot, next, dir, beta);
+            if (out.binned) stream_push_binned<M>(out, alive, alive ? classify_next(cx.sc, tv, jump_next, slot, next, dir) : 0, chunk, pixel, slot, next, dir, beta, r);
+            else stream_push<M>(out, alive, pixel, slot, next, dir, beta, r);
+        } else stream_push<M>(out, alive, pixel, slot, next, dir, beta, r);
     }
 }
 
@@ -807,7 +825,7 @@ int run_camera_wavefront(psdr_scene_s *h, const psdr_render_opts *o, const TV<M,
     const bool binned = (FL & kSceneForest) != 0 && h->n_blas > 0 && h->wf_binned && !open_scene;
     const long long cap = std::min(n, binned ? kWfChunk / 2 : kWfChunk);
     const int depth = o->max_depth;
-    const size_t words = 8 + 3 * (1 + K);
+    const size_t words = 8 + 6 * (1 + K);
     // plain: block b appends to sub-stream b % kWfSub, at most ceil(blocks / kWfSub) * trips * kBlock records each.
     // binned: the records of chunk c go to group c % kWfGroups of their class; a class can take all of a group
     const long long max_blocks = ((long long) launch_blocks(h, cap) + kWfSub - 1) / kWfSub * kWfSub;   // >= the grid of any chunk
@@ -828,7 +846,7 @@ int run_camera_wavefront(psdr_scene_s *h, const psdr_render_opts *o, const TV<M,
         const long long c = cap_alloc;
         st[i].cap = c;
         st[i].pixel = reinterpret_cast<int32_t *>(b); st[i].slot = reinterpret_cast<uint32_t *>(b + c); st[i].tri = reinterpret_cast<int32_t *>(b + 2 * c);
-        st[i].hu = b + 3 * c; st[i].hv = b + 4 * c; st[i].dir = b + 5 * c; st[i].beta = b + 8 * c;
+        st[i].hu = b + 3 * c; st[i].hv = b + 4 * c; st[i].dir = b + 5 * c; st[i].beta = b + 8 * c; st[i].acc = b + (8 + 3 * (1 + K)) * c;
         st[i].binned = binned ? 1 : 0;
     }
     h->slots[0] += (uint64_t) n;
