@@ -170,7 +170,7 @@ typedef struct psdr_scene_desc {
 typedef struct psdr_render_opts {
     int32_t integrator;                  /* PSDR_INTEGRATOR_* */
     int32_t bsdf_samples, light_samples; /* DirectIntegrator ctor, direct.cpp:32-34 */
-    int32_t max_depth;                   /* PathTracer; psdr_render_d_rev supports max_depth <= 8 (per-lane path record in LDS) */
+    int32_t max_depth;                   /* PathTracer; psdr_render_d_rev: up to 8 the per-lane path record lives in LDS, up to 250 in HBM */
     int32_t hide_emitters;               /* DirectIntegrator::m_hide_emitters */
     int32_t field;                       /* PSDR_FIELD_* */
     int32_t spp, sppe, sppse;            /* GLOBAL counts: normalisation + RNG stream index */

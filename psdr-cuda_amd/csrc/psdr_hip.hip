@@ -329,6 +329,7 @@ int lbvh_build(psdr_scene_s *h, hipStream_t s, bool &fallback) {
     if (need > h->lbvh_bytes) {
         if (h->d_lbvh) (void) hipFree(h->d_lbvh);
     if (h->d_rev) (void) hipFree(h->d_rev);
+    if (h->d_rev_deep) (void) hipFree(h->d_rev_deep);
     if (h->d_pe_rep) (void) hipFree(h->d_pe_rep);
         h->d_lbvh = nullptr; h->lbvh_bytes = 0;
         HIP_TRY(hipMalloc(&h->d_lbvh, need));
@@ -731,9 +732,8 @@ int psdr_render_d_rev(psdr_scene_t h, const psdr_render_opts *o, const float *ad
     if (!h || !o || !adj_img || !grads) return fail("psdr_render_d_rev: null argument");
     if (!h->have_tables) return fail("Scene not loaded yet!");
     if (int rc = check_counts(h, o)) return rc;
-    if (o->integrator == PSDR_INTEGRATOR_PATH && o->max_depth > kMaxRevDepth)
-        return fail("psdr_render_d_rev: PathTracer max_depth > 8 is not supported in reverse mode (the per-lane path record lives in LDS: "
-                    "8 KB per depth level and workgroup); use forward mode (psdr_render_d_fwd) for deeper paths");
+    if (o->integrator == PSDR_INTEGRATOR_PATH && o->max_depth > kMaxRevDepthDeep)
+        return fail("psdr_render_d_rev: PathTracer max_depth > 250 is not supported in reverse mode");
     hipStream_t s = (hipStream_t) stream;
     if (int rc = begin_call(h, s)) return rc;
     return variant_of(h)->render_rev(h, o, adj_img, out_img, grads, s);

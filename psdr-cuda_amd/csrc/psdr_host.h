@@ -146,6 +146,10 @@ struct psdr_scene_s {
     void *d_pe_rep = nullptr;
     size_t pe_rep_bytes = 0;
 
+    // reverse mode, paths deeper than the LDS record: per-thread path records
+    void *d_rev_deep = nullptr;
+    size_t rev_deep_bytes = 0;
+
     // split reverse launch: per-path records between the value kernel and the adjoint kernel
     void *d_rev = nullptr;
     size_t rev_bytes = 0;

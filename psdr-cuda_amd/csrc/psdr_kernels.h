@@ -664,7 +664,7 @@ template <int FL, bool GEO, int INTEG> constexpr int rev_waves() {
 template <int FL, bool GEO, int INTEG, int STAGE = 0>
 __global__ __launch_bounds__(kBlock, (STAGE == 1 ? 3 : rev_waves<FL, GEO, INTEG>())) void k_camera_rev(LaunchCtx cx, DeviceSink<FL> sink, int spp, int s_begin, int nsp, long long j0,
                                                        long long n, float inv_spp, const float *__restrict__ adj_img, float *__restrict__ img,
-                                                       unsigned long long *counters, float *__restrict__ disk, long long disk_stride) {
+                                                       unsigned long long *counters, float *__restrict__ disk, long long disk_stride, float *__restrict__ deep) {
     TraversalStack st; setup_lds(cx, st);
     if (STAGE != 1) sink.begin(dyn_lds_floats(cx.off_sink));
     uint32_t nrays = 0;
@@ -678,6 +678,7 @@ __global__ __launch_bounds__(kBlock, (STAGE == 1 ? 3 : rev_waves<FL, GEO, INTEG>
         PathRec rec;
 #if defined(__HIP_DEVICE_COMPILE__)
         rec.base = reinterpret_cast<float *>(psdr_dyn_lds + cx.off_pathrec) + threadIdx.x;
+        if (INTEG != PSDR_INTEGRATOR_DIRECT && deep != nullptr) { rec.deep = deep; rec.deep_stride = gridDim.x * kBlock; rec.deep_col = blockIdx.x * kBlock + threadIdx.x; }
 #endif
         if (in) {
             const int s = s_begin + s_in;
@@ -943,8 +944,21 @@ int render_rev(psdr_scene_s *h, const psdr_render_opts *o, const float *adj_img,
         if (int rc = make_ctx(h, o, 0, cx)) return rc;
         const long long n = WH * nsp;
         h->slots[0] += (uint64_t) n;
-        const int depth = o->integrator == PSDR_INTEGRATOR_PATH ? std::min(o->max_depth, kMaxRevDepth) : 1;
-        const int rec_bytes = depth * kPathRecWords * kBlock * 4;
+        const int depth = o->integrator == PSDR_INTEGRATOR_PATH ? std::min(o->max_depth, kMaxRevDepthDeep) : 1;
+        // up to kMaxRevDepth vertices the per-lane path record lives in LDS; deeper paths keep it in HBM, one column per thread of the grid
+        const bool deep_rec = depth > kMaxRevDepth;
+        const int rec_bytes = deep_rec ? 0 : depth * kPathRecWords * kBlock * 4;
+        float *deep = nullptr;
+        if (deep_rec) {
+            const size_t need = (size_t) launch_blocks(h, n) * kBlock * depth * kPathRecWords * sizeof(float);
+            if (need > h->rev_deep_bytes) {
+                if (h->d_rev_deep) (void) hipFree(h->d_rev_deep);
+                h->d_rev_deep = nullptr; h->rev_deep_bytes = 0;
+                HIP_TRY(hipMalloc(&h->d_rev_deep, need));
+                h->rev_deep_bytes = need;
+            }
+            deep = reinterpret_cast<float *>(h->d_rev_deep);
+        }
         const bool geo = grads->g_tri_info != nullptr || grads->g_cam_to_world != nullptr;
         const int wg_per_cu = (o->integrator == PSDR_INTEGRATOR_DIRECT && !(FL & kSceneRough)) ? 3 : 2;       // rev_waves<FL, true, INTEG>
         // Split launch: a scene with a tree to walk, geometry gradients (the register-heavy kernel), hits replayable.
@@ -979,7 +993,7 @@ int render_rev(psdr_scene_s *h, const psdr_render_opts *o, const float *adj_img,
 #define PSDR_LAUNCH_REV_K(GEO, INTEG, STAGE, CX, BYTES, J0, N, IMG, DISK, STRIDE)                                                    \
         do { if ((BYTES) > 48 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_camera_rev<FL, GEO, INTEG, STAGE>), hipFuncAttributeMaxDynamicSharedMemorySize, (BYTES))); \
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_camera_rev<FL, GEO, INTEG, STAGE>), dim3(launch_blocks(h, (N))), dim3(kBlock), (BYTES), s, CX, sink, \
-                           o->spp, o->spp_begin, nsp, (long long) (J0), (long long) (N), 1.f / (float) o->spp, adj_img, IMG, h->d_counters, DISK, (long long) (STRIDE)); } while (0)
+                           o->spp, o->spp_begin, nsp, (long long) (J0), (long long) (N), 1.f / (float) o->spp, adj_img, IMG, h->d_counters, DISK, (long long) (STRIDE), deep); } while (0)
 #define PSDR_LAUNCH_REV(GEO, INTEG) PSDR_LAUNCH_REV_K(GEO, INTEG, 0, cx, dyn_bytes, 0, n, out_img, (float *) nullptr, 0)
         if (split) {
             // records of one chunk of slots live in a scratch buffer (2 + 5 depth words per slot); chunks bound its size

@@ -367,19 +367,28 @@ PSDR_HD Vec3f camera_space_dir(const SceneView &sc, float sx, float sy) {
     return normalize(Vec3f{v4[0] / v4[3], v4[1] / v4[3], v4[2] / v4[3]});
 }
 
-constexpr int kMaxRevDepth = 8;
+constexpr int kMaxRevDepth = 8;          // path vertices whose record fits in LDS (8 KB per vertex and workgroup)
+constexpr int kMaxRevDepthDeep = 250;    // beyond: the record lives in HBM (render_rev), as deep as the forward wavefront goes
 constexpr int kPathRecWords = 8;
 
 // Per-lane record of (c_k, f_k) and the two hit triangles along the path (8 words per vertex).  On the device it lives in LDS
 // (one column per lane) -- a register array indexed by the run-time vertex number would be demoted to
-// scratch, and the scratch of all resident waves (hundreds of MB) thrashes the caches.
+// scratch, and the scratch of all resident waves (hundreds of MB) thrashes the caches.  Paths deeper than kMaxRevDepth keep
+// it in HBM instead: one column per resident thread of the (persistent) grid, word w of thread t at deep[w * threads + t].
 struct PathRec {
 #if defined(__HIP_DEVICE_COMPILE__)
-    float *base;   // &lds[threadIdx.x], stride kBlock
-    __device__ __forceinline__ void put(int k, int c, float v) { base[(k * kPathRecWords + c) * kBlock] = v; }
-    __device__ __forceinline__ float get(int k, int c) const { return base[(k * kPathRecWords + c) * kBlock]; }
+    float *base;                 // &lds[threadIdx.x], stride kBlock
+    float *deep = nullptr;       // HBM block of the launch (wave-uniform: stays in scalar registers) or null
+    uint32_t deep_stride = 0;    // threads of the grid
+    uint32_t deep_col = 0;       // this thread's column
+    __device__ __forceinline__ void put(int k, int c, float v) {
+        if (deep) deep[(size_t) (k * kPathRecWords + c) * deep_stride + deep_col] = v; else base[(k * kPathRecWords + c) * kBlock] = v;
+    }
+    __device__ __forceinline__ float get(int k, int c) const {
+        return deep ? deep[(size_t) (k * kPathRecWords + c) * deep_stride + deep_col] : base[(k * kPathRecWords + c) * kBlock];
+    }
 #else
-    float a[kMaxRevDepth * kPathRecWords];
+    float a[kMaxRevDepthDeep * kPathRecWords];
     void put(int k, int c, float v) { a[k * kPathRecWords + c] = v; }
     float get(int k, int c) const { return a[k * kPathRecWords + c]; }
 #endif
@@ -817,7 +826,7 @@ PSDR_HD Vec3f camera_sample_reverse(RealSink &real_sink, PrimaryGrad &pg, PathRe
 
     const bool direct = integ == PSDR_INTEGRATOR_DIRECT;
     const int nB = direct ? lp.bsdf_samples : 1, nL = direct ? lp.light_samples : 1;
-    const int depth = direct ? 1 : (lp.max_depth < kMaxRevDepth ? lp.max_depth : kMaxRevDepth);
+    const int depth = direct ? 1 : (lp.max_depth < kMaxRevDepthDeep ? lp.max_depth : kMaxRevDepthDeep);
     // sweep 2 replays the hits of sweep 1 (always for the PathTracer; DirectIntegrator with <= 1 sample of each kind)
     const bool replay = STAGE != 0 || INTEG == PSDR_INTEGRATOR_PATH || (nB <= 1 && nL <= 1);      // a split launch is only made when the hits can be replayed
 
