@@ -87,6 +87,28 @@ class _LazyImage(Vector3fD):
         self._t = v
 
 
+class _ReducingImage(Vector3fC):
+    """renderC on several GPUs: the all-reduce of the image is issued asynchronously and joined when the image is first LOOKED AT, so
+    that the next render call's kernel (the harness renders renderD right after renderC) runs while the ring moves the 3 W H floats."""
+
+    @classmethod
+    def _make(cls, t, work):
+        o = cls.__new__(cls)
+        o._t, o._work = t, work
+        return o
+
+    @property
+    def t(self):
+        if self._work is not None:
+            self._work.wait()                     # nccl: the current stream waits for the collective; gloo: the host does
+            self._work = None
+        return self._t
+
+    @t.setter
+    def t(self, v):
+        self._work, self._t = None, v
+
+
 class _RenderFn(torch.autograd.Function):
     """torch.autograd bridge for reverse mode: forward = primal image, backward = psdr_render_d_rev."""
 
@@ -172,15 +194,17 @@ class Integrator(Object):
             scene._bvh_version = stamp
         return lib, keep
 
-    def _render_c(self, scene, tb, opts, guide, interior_only=False):
+    def _render_c(self, scene, tb, opts, guide, interior_only=False, defer_reduce=False):
         lib, keep = self._prepare(scene, tb, guide)
         img = torch.empty(tb["width"] * tb["height"] * 3, dtype=torch.float32, device="cuda")
         _abi.check(lib, lib.psdr_render_c(scene._native, C.byref(opts), img.data_ptr(), _stream_ptr()))
         self._counters(lib, scene)
         dist = _dist()
+        if dist and defer_reduce:
+            return img, dist.all_reduce(img, async_op=True)
         if dist:
             dist.all_reduce(img)
-        return img
+        return (img, None) if defer_reduce else img
 
     def _render_fwd(self, scene, tb, opts, guide, tangent_sets):
         lib, keep = self._prepare(scene, tb, guide)
@@ -239,11 +263,13 @@ class Integrator(Object):
         t0 = time.perf_counter()
         tb = scene.tables(sensor_id)
         opts = self._opts(scene, with_edges=False)
-        img = self._render_c(scene, tb, opts, None)
+        img, work = self._render_c(scene, tb, opts, None, defer_reduce=True)
         self._advance_rng(scene, opts)
         if scene.opts.log_level:
             torch.cuda.synchronize()                     # only the log line needs the time; the image is stream-ordered
             self.log("Rendered in %g seconds." % (time.perf_counter() - t0))
+        if work is not None:
+            return _ReducingImage._make(img.reshape(-1, 3), work)
         return Vector3fC._wrap(img.reshape(-1, 3))
 
     def renderD(self, scene, sensor_id=0):
