@@ -245,17 +245,25 @@ class PerspectiveCamera(Sensor):
         W, H = scene.opts.width, scene.opts.height
         aspect = float(W) / float(H)
         tw = self._to_world
-        det = torch.det(tw[:3, :3].detach().double()).item()
-        psdr_assert(abs(det - 1.0) < 1e-4, "Sensor transformation should not involve scaling!")   # sensor.cpp:8-12
-        c2s = (np.diag([-0.5, -0.5 * aspect, 1.0, 1.0]) @
-               np.array([[1, 0, 0, -1.0], [0, 1, 0, -1.0 / aspect], [0, 0, 1, 0], [0, 0, 0, 1.0]]) @
-               perspective(self.m_fov_x, self.m_near_clip, self.m_far_clip))
-        s2c = np.linalg.inv(c2s)
-        c2s_t = torch.as_tensor(c2s, dtype=torch.float32, device=tw.device)
-        s2c_t = torch.as_tensor(s2c, dtype=torch.float32, device=tw.device)
-        w2s = c2s_t @ torch.linalg.inv(tw)
-        cam_pos = transform_pos(tw, torch.zeros(1, 3, device=tw.device))[0]
-        cam_dir = transform_dir(tw, torch.tensor([[0., 0., 1.]], device=tw.device))[0]
+        # what depends on the pose only is looked at again when the pose tensor changed (the determinant check reads a value back to
+        # the host, the inverse of a pose without gradient is a constant), what depends on the lens only when the lens changed
+        pose_key = (id(tw), tw.data_ptr(), tw._version)
+        if getattr(self, "_pose_key", None) != pose_key:
+            det = torch.det(tw[:3, :3].detach().double()).item()
+            psdr_assert(abs(det - 1.0) < 1e-4, "Sensor transformation should not involve scaling!")   # sensor.cpp:8-12
+            self._pose_key, self._pose_inv = pose_key, (None if tw.requires_grad else torch.linalg.inv(tw))
+        lens_key = (self.m_fov_x, self.m_near_clip, self.m_far_clip, aspect, str(tw.device))
+        if getattr(self, "_lens_key", None) != lens_key:
+            c2s = (np.diag([-0.5, -0.5 * aspect, 1.0, 1.0]) @
+                   np.array([[1, 0, 0, -1.0], [0, 1, 0, -1.0 / aspect], [0, 0, 1, 0], [0, 0, 0, 1.0]]) @
+                   perspective(self.m_fov_x, self.m_near_clip, self.m_far_clip))
+            s2c = np.linalg.inv(c2s)
+            self._lens_key = lens_key
+            self._lens = (c2s, s2c, torch.as_tensor(c2s, dtype=torch.float32, device=tw.device), torch.as_tensor(s2c, dtype=torch.float32, device=tw.device))
+        c2s, s2c, c2s_t, s2c_t = self._lens
+        w2s = c2s_t @ (self._pose_inv if self._pose_inv is not None else torch.linalg.inv(tw))
+        cam_pos = tw[:3, 3] / tw[3, 3]            # transform_pos(to_world, origin)
+        cam_dir = tw[:3, 2]                       # transform_dir(to_world, (0, 0, 1))
 
         def tp(x, y):
             v = np.array([x, y, 0.0, 1.0]); r = s2c @ v
