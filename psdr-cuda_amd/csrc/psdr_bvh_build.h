@@ -104,7 +104,8 @@ struct Builder {
     int max_depth = 0;
     float pad = 0.f;
     int kMaxLeaf = 4;                  // leaf encoding holds 1..8
-    float kTraversalCost = 1.0f;       // node visit / triangle test (both ~40-50 VALU ops)
+    float kTraversalCost = 2.0f;       // node visit / triangle test: a visit is two slab tests, a stack access and two dependent loads --
+                                       // measured (tools/bvh_param_sweep.py): 2.0 is 4-5 % ahead of 1.0 on cbox_bunny and the 50 k-triangle interior, 3.0 no better
     Builder() {                        // experiment knobs (tools only): PSDR_BVH_MAXLEAF, PSDR_BVH_TCOST
         if (const char *e = std::getenv("PSDR_BVH_MAXLEAF")) kMaxLeaf = std::max(1, std::min(8, std::atoi(e)));
         if (const char *e = std::getenv("PSDR_BVH_TCOST")) kTraversalCost = (float) std::atof(e);
