@@ -95,7 +95,10 @@ PSDR_HD float __int_as_float_hd(int i) { union { float f; int i; } c; c.i = i; r
 PSDR_HD bool slab(const float *lo, const float *hi, const Vec3f &o, const Vec3f &inv, float tmax, float &t_entry) {
     // hit test of one box + entry distance.  NaNs (0*inf) drop out of fmin/fmax.
     // (lo - o) * inv is kept as two operations: folding it into fma(lo, inv, -o * inv) loses the exact
-    // difference near the origin of the ray and was measured 2.5x SLOWER on cbox_bunny paths.
+    // difference near the origin of the ray and was measured 2.5x SLOWER on cbox_bunny paths.  Also measured and dropped: both
+    // children of a node on packed fp32 (boxes interleaved per axis, v_pk_add_f32 / v_pk_mul_f32: 12 instead of 24 instructions
+    // per visit, same bits) -- C4 fused 29.3 -> 31.3 ms, C3 direct renderC 1.15 -> 1.34 ms: a packed fp32 instruction is no
+    // cheaper than the two it replaces here, and the broadcast operands cost moves.
     const float ax = (lo[0] - o.x) * inv.x, bx = (hi[0] - o.x) * inv.x;
     const float ay = (lo[1] - o.y) * inv.y, by = (hi[1] - o.y) * inv.y;
     const float az = (lo[2] - o.z) * inv.z, bz = (hi[2] - o.z) * inv.z;
