@@ -265,18 +265,16 @@ class PerspectiveCamera(Sensor):
         cam_pos = tw[:3, 3] / tw[3, 3]            # transform_pos(to_world, origin)
         cam_dir = tw[:3, 2]                       # transform_dir(to_world, (0, 0, 1))
 
-        def tp(x, y):
-            v = np.array([x, y, 0.0, 1.0]); r = s2c @ v
-            return r[:3] / r[3]
-        v00, v10, v11, vc = tp(0, 0), tp(1, 0), tp(1, 1), tp(.5, .5)
-        inv_area = float(np.dot(vc, vc) / (np.linalg.norm(v00 - v10) * np.linalg.norm(v11 - v10)))
-        cam = torch.zeros(_abi.CAM_WORDS, dtype=torch.float32, device=tw.device)
-        cam[0:16] = s2c_t.reshape(-1)
-        cam[16:32] = tw.detach().reshape(-1)
-        cam[32:48] = w2s.detach().reshape(-1)
-        cam[48:51] = cam_pos.detach()
-        cam[51:54] = cam_dir.detach()
-        cam[54] = inv_area
+        if getattr(self, "_cam_tail_key", None) != lens_key:
+            def tp(x, y):
+                v = np.array([x, y, 0.0, 1.0]); r = s2c @ v
+                return r[:3] / r[3]
+            v00, v10, v11, vc = tp(0, 0), tp(1, 0), tp(1, 1), tp(.5, .5)
+            inv_area = float(np.dot(vc, vc) / (np.linalg.norm(v00 - v10) * np.linalg.norm(v11 - v10)))
+            self._cam_tail_key = lens_key
+            self._cam_tail = torch.tensor([inv_area] + [0.0] * (_abi.CAM_WORDS - 55), dtype=torch.float32, device=tw.device)
+        # words 0..15 sample_to_camera, 16..31 to_world, 32..47 world_to_sample, 48..50 position, 51..53 direction, 54 1 / film area
+        cam = torch.cat([s2c_t.reshape(-1), tw.detach().reshape(-1), w2s.detach().reshape(-1), cam_pos.detach(), cam_dir.detach(), self._cam_tail])
         out = {"cam": cam.contiguous(), "cam_to_world": tw, "prim_edge": None, "prim_cmf": None, "prim_pmf": None,
                "prim_sum": 0.0, "num_prim_edges": 0, "prim_edge_z": None}
 
@@ -991,8 +989,16 @@ class Scene(Object):
         for m in meshes:
             if m.bsdf is not None:
                 psdr_assert(not m.bsdf.anisotropic() or not m.use_face_normals)
-        mats = torch.bmm(torch.bmm(torch.stack([m._to_world_left for m in meshes]), torch.stack([m._to_world_raw for m in meshes])),
-                         torch.stack([m._to_world_right for m in meshes]))
+        # the per-mesh transforms: the product is kept while none of its factors changed or carries a gradient (an optimisation of vertex
+        # positions leaves them alone: two batched 4x4 products and three stacks less per configure)
+        parts = [t for m in meshes for t in (m._to_world_left, m._to_world_raw, m._to_world_right)]
+        mats_key = None if any(t.requires_grad for t in parts) else tuple((id(t), t.data_ptr(), t._version) for t in parts)
+        if mats_key is not None and getattr(self, "_mats_key", None) == mats_key:
+            mats = self._mats
+        else:
+            mats = torch.bmm(torch.bmm(torch.stack([m._to_world_left for m in meshes]), torch.stack([m._to_world_raw for m in meshes])),
+                             torch.stack([m._to_world_right for m in meshes]))
+            self._mats_key, self._mats = mats_key, (mats if mats_key is not None else None)
         v_raw = torch.cat([m._raw_positions() for m in meshes], dim=0)
         mv = mats[tp["vmesh"]]                                                     # [V,4,4]
         h = (mv[:, :3, :3] * v_raw.unsqueeze(1)).sum(-1) + mv[:, :3, 3]
