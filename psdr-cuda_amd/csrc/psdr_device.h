@@ -1089,8 +1089,38 @@ PSDR_HD float guide_sample_reuse(const SceneView &sc, float s[3]) {
 
 // DirectIntegrator::eval_secondary_edge (direct.cpp:225-316) + Scene::sample_boundary_segment_direct
 // (scene.cpp:456-492).  R = float: returns value0 (guiding, pixel -1); R = Dual<K>: tangent-only value.
+// What decides whether a secondary-edge slot evaluates anything at all (sample_boundary_segment_direct + the first two rays of
+// eval_secondary_edge, direct.cpp:225-262): the boundary segment must reach the emitter sample from the edge point and continue
+// backwards onto a surface.  A few per cent of the slots pass.  The same draws and the same float arithmetic as
+// secondary_edge_sample / secondary_edge_reverse, which repeat it for the survivors of a split launch (k_secondary_edge_filter).
+template <int FL>
+PSDR_HD bool secondary_edge_survives(const SceneView &sc, TraversalStack &st, const float s3[3], uint32_t &nrays) {
+    const TangentView<0, FL> tv0{};
+    float s1 = s3[0], pdf0;
+    const int k = sample_reuse(sc.d.sec_cmf, sc.d.sec_pmf, sc.d.sec_sum, sc.d.num_sec_edges, s1, pdf0);
+    const float *se = sc.d.sec_edge + (size_t) k * PSDR_SEDGE_STRIDE;
+    const Vec3f ep0{se[0], se[1], se[2]}, ee1{se[3], se[4], se[5]}, n0{se[6], se[7], se[8]}, n1{se[9], se[10], se[11]};
+    const bool is_boundary = se[15] != 0.f;
+    const Vec3f p0 = ee1 * s1 + ep0;
+    const PosSample<float> ps2 = sample_emitter_position<float>(sc, tv0, p0, s3[1], s3[2], false);
+    const Vec3f p2 = ps2.p, bn = ps2.n;
+    Vec3f e = p2 - p0;
+    const float distSqr = dot(e, e);
+    e = e / sqrtf(fmaxf(distSqr, 0.f));
+    const float cosTheta = -dot(bn, e);
+    const float d0n = dot(n0, e), d1n = dot(n1, e);
+    const int sgn0 = d0n > kEdgeEpsilon ? 1 : (d0n < -kEdgeEpsilon ? -1 : 0), sgn1 = d1n > kEdgeEpsilon ? 1 : (d1n < -kEdgeEpsilon ? -1 : 0);
+    bool valid = cosTheta > kEpsilon && (is_boundary ? sgn0 != 0 : sgn0 * sgn1 < 0);
+    const Vec3f dir = normalize(p2 - p0);
+    const int f0 = sc.d.sec_edge_faces ? sc.d.sec_edge_faces[2 * k] : -1, f1 = sc.d.sec_edge_faces ? sc.d.sec_edge_faces[2 * k + 1] : -1;
+    const Its<float> its2 = intersect<float>(sc, tv0, st, RayT<float>{p0, dir}, valid, kDetached, nrays, f0, f1);
+    valid = valid && its2.valid && norm(its2.p - p2) < kShadowEpsilon;
+    const Its<float> its1c = intersect<float>(sc, tv0, st, RayT<float>{p0, -dir}, valid, kDetached, nrays, f0, f1);
+    return valid && its1c.valid;
+}
+
 template <class R, class TVT>
-PSDR_HD int secondary_edge_sample(const SceneView &sc, const TVT &tv, TraversalStack &st, const float s3[3], Vec3<R> &out, uint32_t &nrays) {
+PSDR_HD int secondary_edge_sample(const SceneView &sc, const TVT &tv, TraversalStack &st, const float s3[3], Vec3<R> &out, uint32_t &nrays, bool count_first = true) {
     constexpr bool ad = is_ad<R>();
     out = zero3<R>();
     const TangentView<0, TVT::flags> tv0{};
@@ -1122,9 +1152,11 @@ PSDR_HD int secondary_edge_sample(const SceneView &sc, const TVT &tv, TraversalS
     const Vec3f dir = normalize(p2 - p0);
     // the two rays that start ON the edge skip its adjacent faces when the caller supplies them (psdr_hip.h sec_edge_faces)
     const int f0 = sc.d.sec_edge_faces ? sc.d.sec_edge_faces[2 * k] : -1, f1 = sc.d.sec_edge_faces ? sc.d.sec_edge_faces[2 * k + 1] : -1;
-    const Its<float> its2 = intersect<float>(sc, tv0, st, RayT<float>{p0, dir}, valid, kDetached, nrays, f0, f1);
+    uint32_t counted_before = 0;                 // split launch: secondary_edge_survives already traced (and counted) these two
+    uint32_t &n12 = count_first ? nrays : counted_before;
+    const Its<float> its2 = intersect<float>(sc, tv0, st, RayT<float>{p0, dir}, valid, kDetached, n12, f0, f1);
     valid = valid && its2.valid && norm(its2.p - p2) < kShadowEpsilon;
-    const Its<float> its1c = intersect<float>(sc, tv0, st, RayT<float>{p0, -dir}, valid, kDetached, nrays, f0, f1);
+    const Its<float> its1c = intersect<float>(sc, tv0, st, RayT<float>{p0, -dir}, valid, kDetached, n12, f0, f1);
     valid = valid && its1c.valid;
     if (!valid) return -1;
     const Vec3f p1 = its1c.p;

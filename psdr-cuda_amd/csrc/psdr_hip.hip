@@ -329,6 +329,7 @@ int lbvh_build(psdr_scene_s *h, hipStream_t s, bool &fallback) {
     if (need > h->lbvh_bytes) {
         if (h->d_lbvh) (void) hipFree(h->d_lbvh);
     if (h->d_rev) (void) hipFree(h->d_rev);
+    if (h->d_se_list) (void) hipFree(h->d_se_list);
     if (h->d_rev_deep) (void) hipFree(h->d_rev_deep);
     if (h->d_pe_rep) (void) hipFree(h->d_pe_rep);
         h->d_lbvh = nullptr; h->lbvh_bytes = 0;

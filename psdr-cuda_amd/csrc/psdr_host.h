@@ -150,6 +150,10 @@ struct psdr_scene_s {
     void *d_rev_deep = nullptr;
     size_t rev_deep_bytes = 0;
 
+    // split secondary-edge launch: survivor counter (first 256 bytes) + slot list
+    void *d_se_list = nullptr;
+    size_t se_list_bytes = 0;
+
     // split reverse launch: per-path records between the value kernel and the adjoint kernel
     void *d_rev = nullptr;
     size_t rev_bytes = 0;

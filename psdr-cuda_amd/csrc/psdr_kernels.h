@@ -464,19 +464,53 @@ __global__ __launch_bounds__(kBlock, PSDR_WAVES_PE) void k_primary_edge(LaunchCt
 }
 
 // ---------------------------------------------------------------------- k_secondary_edge
+// Split launch of the secondary-edge term (forward and reverse): only a few per cent of the slots get past the first two rays, yet the
+// dual-number / adjoint code that the survivors need holds the full kernels at 2 waves/SIMD while all of them walk the tree.  The filter
+// traces those two rays for every slot at the occupancy of a plain kernel and compacts the survivors' slot numbers (one atomic per
+// wave); the full kernel then runs over that list.
+template <int FL>
+__global__ __launch_bounds__(kBlock, 4) void k_secondary_edge_filter(LaunchCtx cx, long long i0, long long n, uint32_t *__restrict__ list, int *__restrict__ list_n,
+                                                                      unsigned long long *counters) {
+    TraversalStack st; setup_lds(cx, st);
+    uint32_t nrays = 0;
+    const bool guided = cx.sc.d.guide_cmf != nullptr && cx.sc.d.num_guide_cells > 0;
+    const long long nceil = (n + kBlock - 1) / kBlock * kBlock;
+    for (long long j = (long long) blockIdx.x * kBlock + threadIdx.x; j < nceil; j += (long long) gridDim.x * kBlock) {
+        bool keep = false;
+        if (j < n) {
+            Rng rng; rng.init((uint64_t) (i0 + j), cx.jump);
+            float s3[3] = {rng.next(), rng.next(), rng.next()};
+            if (guided) (void) guide_sample_reuse(cx.sc, s3);
+            keep = secondary_edge_survives<FL>(cx.sc, st, s3, nrays);
+        }
+        const unsigned long long mask = __ballot(keep);
+        if (mask != 0ull) {
+            const int lane = threadIdx.x & 63, leader = __ffsll((long long) mask) - 1;
+            int base = 0;
+            if (lane == leader) base = atomicAdd(list_n, (int) __popcll(mask));
+            base = __shfl(base, leader, 64);
+            if (keep) list[base + __popcll(mask & ((1ull << lane) - 1ull))] = (uint32_t) j;
+        }
+    }
+    count_rays(counters, nrays);
+}
+
 template <int K, int FL>
 __global__ __launch_bounds__(kBlock) void k_secondary_edge(LaunchCtx cx, TangentView<K, FL> tv, long long i0, long long n, float inv_sppse,
-                                                           float *__restrict__ dimg, long long plane, unsigned long long *counters) {
+                                                           float *__restrict__ dimg, long long plane, unsigned long long *counters,
+                                                           const uint32_t *__restrict__ list, const int *__restrict__ list_n) {
     using R = Dual<K>;
     TraversalStack st; setup_lds(cx, st);
     uint32_t nrays = 0;
     const bool guided = cx.sc.d.guide_cmf != nullptr && cx.sc.d.num_guide_cells > 0;
-    for (long long j = (long long) blockIdx.x * kBlock + threadIdx.x; j < n; j += (long long) gridDim.x * kBlock) {
+    if (list != nullptr) n = *list_n;
+    for (long long jj = (long long) blockIdx.x * kBlock + threadIdx.x; jj < n; jj += (long long) gridDim.x * kBlock) {
+        const long long j = list != nullptr ? (long long) list[jj] : jj;
         Rng rng; rng.init((uint64_t) (i0 + j), cx.jump);
         float s3[3] = {rng.next(), rng.next(), rng.next()};
         const float pdf0 = guided ? guide_sample_reuse(cx.sc, s3) : 1.f;
         Vec3<R> value;
-        const int pixel = secondary_edge_sample<R>(cx.sc, tv, st, s3, value, nrays);
+        const int pixel = secondary_edge_sample<R>(cx.sc, tv, st, s3, value, nrays, list == nullptr);
         if (pixel >= 0) {
             value = zero_nonfinite(value);
             const float scale = (pdf0 > kEpsilon ? 1.f / pdf0 : 1.f) * inv_sppse;
@@ -758,16 +792,19 @@ __global__ __launch_bounds__(kBlock, PSDR_WAVES_PE) void k_primary_edge_rev(Laun
 
 template <int FL>
 __global__ __launch_bounds__(kBlock) void k_secondary_edge_rev(LaunchCtx cx, DeviceSink<FL> sink, long long i0, long long n, float inv_sppse,
-                                                               const float *__restrict__ adj_img, unsigned long long *counters) {
+                                                               const float *__restrict__ adj_img, unsigned long long *counters,
+                                                               const uint32_t *__restrict__ list, const int *__restrict__ list_n) {
     TraversalStack st; setup_lds(cx, st);
     sink.begin(dyn_lds_floats(cx.off_sink));
     uint32_t nrays = 0;
     const bool guided = cx.sc.d.guide_cmf != nullptr && cx.sc.d.num_guide_cells > 0;
-    for (long long j = (long long) blockIdx.x * kBlock + threadIdx.x; j < n; j += (long long) gridDim.x * kBlock) {
+    if (list != nullptr) n = *list_n;
+    for (long long jj = (long long) blockIdx.x * kBlock + threadIdx.x; jj < n; jj += (long long) gridDim.x * kBlock) {
+        const long long j = list != nullptr ? (long long) list[jj] : jj;
         Rng rng; rng.init((uint64_t) (i0 + j), cx.jump);
         float s3[3] = {rng.next(), rng.next(), rng.next()};
         const float pdf0 = guided ? guide_sample_reuse(cx.sc, s3) : 1.f;
-        secondary_edge_reverse(sink, cx.sc, st, s3, (pdf0 > kEpsilon ? 1.f / pdf0 : 1.f) * inv_sppse, adj_img, nrays);
+        secondary_edge_reverse(sink, cx.sc, st, s3, (pdf0 > kEpsilon ? 1.f / pdf0 : 1.f) * inv_sppse, adj_img, nrays, list == nullptr);
     }
     sink.end();
     count_rays(counters, nrays);
@@ -890,6 +927,28 @@ int run_camera_wavefront(psdr_scene_s *h, const psdr_render_opts *o, const TV<M,
     return 0;
 }
 
+// Filter pass of a split secondary-edge launch: *list / *list_n on the device, nullptr when the launch is too small to split.
+template <int FL>
+int secondary_edge_filter(psdr_scene_s *h, const LaunchCtx &cx, long long i0, long long n, const uint32_t **list, const int **list_n, hipStream_t s) {
+    *list = nullptr; *list_n = nullptr;
+    const int split_env = std::getenv("PSDR_SEDGE_SPLIT") ? std::atoi(std::getenv("PSDR_SEDGE_SPLIT")) : -1;
+    if (split_env == 0 || (split_env < 0 && n < (1ll << 18)) || n > 0x7fffffffLL) return 0;
+    const size_t need = 256 + (size_t) n * sizeof(uint32_t);
+    if (need > h->se_list_bytes) {
+        if (h->d_se_list) (void) hipFree(h->d_se_list);
+        h->d_se_list = nullptr; h->se_list_bytes = 0;
+        HIP_TRY(hipMalloc(&h->d_se_list, need));
+        h->se_list_bytes = need;
+    }
+    int *cnt = reinterpret_cast<int *>(h->d_se_list);
+    uint32_t *lst = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(h->d_se_list) + 256);
+    HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(int), s));
+    hipLaunchKernelGGL(k_secondary_edge_filter<FL>, dim3(launch_blocks(h, n)), dim3(kBlock), lds_bytes(cx, h), s, cx, i0, n, lst, cnt, h->d_counters);
+    HIP_TRY(hipGetLastError());
+    *list = lst; *list_n = cnt;
+    return 0;
+}
+
 template <int K, int FL>
 int render_fwd(psdr_scene_s *h, const psdr_render_opts *o, const psdr_tangents *tangents, float *img, float *dimg, hipStream_t s) {
     const long long WH = (long long) h->desc.width * h->desc.height;
@@ -926,8 +985,10 @@ int render_fwd(psdr_scene_s *h, const psdr_render_opts *o, const psdr_tangents *
         if (int rc = make_ctx(h, o, 2, cx)) return rc;
         const long long i0 = WH * o->sppse_begin, n = WH * (o->sppse_end - o->sppse_begin);
         h->slots[2] += (uint64_t) n;
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_secondary_edge<K, FL>), dim3(launch_blocks(h, n)), dim3(kBlock), lds_bytes(cx, h), s, cx, tv, i0, n,
-                           1.f / (float) o->sppse, dimg, WH * 3, h->d_counters);
+        const uint32_t *list = nullptr; const int *list_n = nullptr;
+        if (int rc = secondary_edge_filter<FL>(h, cx, i0, n, &list, &list_n, s)) return rc;
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_secondary_edge<K, FL>), dim3(launch_blocks(h, list ? std::max(n / 16, 1ll << 16) : n)), dim3(kBlock), lds_bytes(cx, h), s, cx, tv, i0, n,
+                           1.f / (float) o->sppse, dimg, WH * 3, h->d_counters, list, list_n);
         HIP_TRY(hipGetLastError());
     }
     return 0;
@@ -1078,8 +1139,14 @@ int render_rev(psdr_scene_s *h, const psdr_render_opts *o, const float *adj_img,
         const int dyn_bytes = cx.off_sink + cache_bytes;
         if (dyn_bytes > 48 * 1024)
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_secondary_edge_rev<FL>), hipFuncAttributeMaxDynamicSharedMemorySize, dyn_bytes));
-        hipLaunchKernelGGL(k_secondary_edge_rev<FL>, dim3(launch_blocks(h, n)), dim3(kBlock), dyn_bytes, s, cx, sink, i0, n, 1.f / (float) o->sppse,
-                           adj_img, h->d_counters);
+        const uint32_t *list = nullptr; const int *list_n = nullptr;
+        {
+            LaunchCtx cxf;                                          // the filter stages the scene like a forward kernel (no gradient cache in LDS)
+            if (int rc = make_ctx(h, o, 2, cxf)) return rc;
+            if (int rc = secondary_edge_filter<FL>(h, cxf, i0, n, &list, &list_n, s)) return rc;
+        }
+        hipLaunchKernelGGL(k_secondary_edge_rev<FL>, dim3(launch_blocks(h, list ? std::max(n / 16, 1ll << 16) : n)), dim3(kBlock), dyn_bytes, s, cx, sink, i0, n, 1.f / (float) o->sppse,
+                           adj_img, h->d_counters, list, list_n);
         HIP_TRY(hipGetLastError());
     }
     return 0;

@@ -1000,7 +1000,7 @@ PSDR_HD void primary_edge_reverse(Sink &sink, const SceneView &sc, TraversalStac
 // One secondary-edge slot in reverse mode (direct.cpp:225-316): result = value0 * dot(n, u2(theta)).
 template <class Sink>
 PSDR_HD void secondary_edge_reverse(Sink &sink, const SceneView &sc, TraversalStack &st, const float s3[3], float scale,
-                                    const float *__restrict__ adj_img, uint32_t &nrays) {
+                                    const float *__restrict__ adj_img, uint32_t &nrays, bool count_first = true) {
     const TangentView<0, Sink::flags> tv0{};
     float s1 = s3[0], pdf0;
     const int k = sample_reuse(sc.d.sec_cmf, sc.d.sec_pmf, sc.d.sec_sum, sc.d.num_sec_edges, s1, pdf0);
@@ -1023,9 +1023,11 @@ PSDR_HD void secondary_edge_reverse(Sink &sink, const SceneView &sc, TraversalSt
     const float bpdf = pdf0 * ps2.pdf * (distSqr / cosTheta);
     const Vec3f dir = normalize(p2 - p0);
     const int f0 = sc.d.sec_edge_faces ? sc.d.sec_edge_faces[2 * k] : -1, f1 = sc.d.sec_edge_faces ? sc.d.sec_edge_faces[2 * k + 1] : -1;
-    const Its<float> its2 = intersect<float>(sc, tv0, st, RayT<float>{p0, dir}, valid, kDetached, nrays, f0, f1);
+    uint32_t counted_before = 0;                 // split launch: secondary_edge_survives already traced (and counted) these two
+    uint32_t &n12 = count_first ? nrays : counted_before;
+    const Its<float> its2 = intersect<float>(sc, tv0, st, RayT<float>{p0, dir}, valid, kDetached, n12, f0, f1);
     valid = valid && its2.valid && norm(its2.p - p2) < kShadowEpsilon;
-    const Its<float> its1c = intersect<float>(sc, tv0, st, RayT<float>{p0, -dir}, valid, kDetached, nrays, f0, f1);
+    const Its<float> its1c = intersect<float>(sc, tv0, st, RayT<float>{p0, -dir}, valid, kDetached, n12, f0, f1);
     if (!(valid && its1c.valid)) return;
     const Vec3f p1 = its1c.p;
     int pixel; float qx, qy, sensor_val;
