@@ -136,3 +136,36 @@ def test_split_reverse_launch_equals_the_fused_kernel(kind):
     for k in ("tri_info", "texels", "emitter_rad", "cam_to_world"):
         a, b = out["0"][1][k], out["1"][1][k]
         assert np.abs(a).max() > 0 and rel_l2(b, a) < 2e-5, (k, rel_l2(b, a))
+
+
+@pytest.mark.gpu
+def test_secondary_edge_split_launch_equals_one_kernel():
+    """The secondary-edge term runs as a filter kernel (the two rays every slot traces; survivors compacted) plus the full kernel over
+    the survivors, forward and reverse (csrc/psdr_kernels.h k_secondary_edge_filter).  Same samples, same arithmetic: the derivative
+    image and the gradients of the one-kernel launch up to the order of the float adds, and the same number of rays."""
+    import os
+    from helpers import tangents_wrt
+    sc, P = load_scene("cbox_occluder", res=64, spp=0, sppe=0, sppse=32, translate=(1, (1.0, 0.5, 0.0)))
+    tb = sc.tables(0)
+    g = GpuScene(tb)
+    o = _abi.make_opts(spp=0, sppe=0, sppse=32, bsdf_samples=1, light_samples=1)
+    tan = tangents_wrt(tb, P)
+    adj = np.random.default_rng(4).random((64 * 64, 3)).astype(np.float32)
+    out = {}
+    old = os.environ.get("PSDR_SEDGE_SPLIT")
+    try:
+        for mode in ("0", "1"):
+            os.environ["PSDR_SEDGE_SPLIT"] = mode
+            _, d = g.render_d_fwd(o, [tan]); rays_f = g.counters()[0]
+            _, grads = g.render_d_rev(o, adj, want=["tri_info", "sec_edge", "cam_to_world"], with_image=False); rays_r = g.counters()[0]
+            out[mode] = (d[0], grads, rays_f, rays_r)
+    finally:
+        if old is None:
+            os.environ.pop("PSDR_SEDGE_SPLIT", None)
+        else:
+            os.environ["PSDR_SEDGE_SPLIT"] = old
+    assert out["0"][2] == out["1"][2] and out["0"][3] == out["1"][3]
+    assert np.abs(out["0"][0]).max() > 0 and rel_l2(out["1"][0], out["0"][0]) < 1e-5
+    for k in ("tri_info", "sec_edge", "cam_to_world"):
+        a, b = out["0"][1][k], out["1"][1][k]
+        assert np.abs(a).max() > 0 and rel_l2(b, a) < 2e-5, (k, rel_l2(b, a))
