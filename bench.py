@@ -135,11 +135,15 @@ class Workload:
     def kernel_d(self):
         return self.integ._render_fwd(self.sc, self.tb, self.opts, None, self.tsets)
 
-    def kernel_rev(self):
+    def kernel_rev(self, names=("texels",)):
         tb = dict(self.tb)
-        tx = tb["texels"].detach().requires_grad_(True)
-        tb["texels"] = tx
+        for n in names:
+            tb[n] = tb[n].detach().requires_grad_(True)
         return self.integ._render_rev(self.sc, tb, self.opts, None, self.adj)
+
+    def kernel_rev_all(self):
+        """every gradient table of the interior term at once: texels, emitter radiance, triangle rows (geometry), camera pose"""
+        return self.kernel_rev(("texels", "emitter_rad", "tri_info", "cam_to_world"))
 
 
 def timed(fn, n):
@@ -249,14 +253,16 @@ def main():
     ms_c = timed(w.kernel_c, n_side); rays_c = w.integ.last_counters[0]
     ms_d1 = timed(w.kernel_d, n_side); rays_d = w.integ.last_counters[0]
     ms_rev = timed(w.kernel_rev, n_side)
+    w.kernel_rev_all()
+    ms_rev_all = timed(w.kernel_rev_all, n_side)
     w.kernel_setup(3)
     w.kernel_d()
     ms_d3 = timed(w.kernel_d, n_side)
     kernel_only = {"value": round(2.0 * slots_per_pass / ((ms_c + ms_d1) * 1e-3) / 1e6, 1), "unit": "Mpath-samples/s",
                    "render_c_ms": round(ms_c, 4), "render_d_fwd_k1_ms": round(ms_d1, 4), "render_d_fwd_k3_ms": round(ms_d3, 4),
-                   "render_d_rev_ms": round(ms_rev, 4),
+                   "render_d_rev_ms": round(ms_rev, 4), "render_d_rev_all_ms": round(ms_rev_all, 4),
                    "note": "psdr_render_c + psdr_render_d_fwd (K=1) launches of the same samples; K=3 = d/d(r,g,b) in one pass (round-1 headline form); "
-                           "rev = psdr_render_d_rev, texel gradient"}
+                           "rev = psdr_render_d_rev, texel gradient; rev_all = texels + emitter radiance + triangle rows (geometry) + camera pose"}
     surface = {"ms_per_step": round(dt / args.steps * 1e3, 4), "configure_ms": round(ms_configure, 4),
                "reverse_step_ms": round(ms_rev_surface, 4),
                "note": "step = renderC + [configure + renderD + enoki.forward] (one launch each: renderD is rendered by the forward-mode kernel); "
