@@ -200,11 +200,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP render path has no CPU fallback)")
+    # PSDR_BENCH_ONE_GPU=1 (developer switch, not a measurement): every rank on cuda:0 over gloo, so that the multi-rank code of this
+    # script -- sharded spp, the all-reduces inside the render calls, the max-over-ranks clock -- can be EXECUTED on a one-GPU box
+    one_gpu = os.environ.get("PSDR_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if one_gpu:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     from psdr_cuda import _abi
     w = Workload(args, world)

@@ -103,3 +103,21 @@ def test_two_ranks_on_one_gpu_reproduce_the_single_process_results(tmp_path):
 
 if __name__ == "__main__":
     main()
+
+
+def test_bench_multi_rank_path_executes_on_one_gpu():
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one process per rank), with the developer switch
+    PSDR_BENCH_ONE_GPU=1: both ranks on cuda:0 over gloo.  Not a measurement -- it EXECUTES the script's multi-rank code: sharded spp, the
+    (deferred) image all-reduce of renderC, the [image || derivative image] all-reduce, the max-over-ranks clock, rank 0's JSON line."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PSDR_BENCH_ONE_GPU="1")
+    port = 29700 + os.getpid() % 1000
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-pmc",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                       # rank 0 alone prints
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["world_size"] == 2 and d["config"]["global_spp"] == 128
+    assert d["value"] > 0 and d["config"]["allreduce_bytes_per_step"] == 3 * 512 * 512 * 3 * 4
