@@ -97,6 +97,9 @@ template <class G, class R, int INTEG, int FL> constexpr int camera_waves() {
     if (is_ad<G>()) return ad_traits<G>::K == 1 ? 3 : PSDR_WAVES_DG;
     // PathTracer material duals of the lean variant: K = 1 fits 4 waves / SIMD without spilling (C2 1.67 ms); K = 3 spills
     // 150 VGPRs there and runs faster at 3 (3.37 -> 2.99 ms)
+    // rough-conductor PathTracer with three tangent sets on a scene without trees: 204 VGPRs spilled at 3 waves, none at 2
+    // (cbox_rough K = 3: 8.65 -> 6.60 ms; with a two-level tree to walk the third wave is worth more than the spills: 7.4 against 8.1 ms)
+    if ((FL & kSceneRough) != 0 && (FL & kSceneForest) == 0 && INTEG == PSDR_INTEGRATOR_PATH && ad_traits<R>::K == 3) return 2;
     return (lean && INTEG == PSDR_INTEGRATOR_PATH && ad_traits<R>::K == 1) ? PSDR_WAVES_DM + 1 : PSDR_WAVES_DM;
 }
 template <class G, class R, int INTEG, int FL>
