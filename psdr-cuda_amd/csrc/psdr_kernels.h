@@ -94,7 +94,9 @@ __device__ __forceinline__ void slot_to_pixel(long long j, int nsp, int &pixel, 
 template <class G, class R, int INTEG, int FL> constexpr int camera_waves() {
     constexpr bool lean = (FL & (kSceneEnv | kSceneRough)) == 0;          // plain diffuse / area light (with or without a two-level tree)
     if (!is_ad<R>()) return lean ? PSDR_WAVES_C + 1 : PSDR_WAVES_C;
-    if (is_ad<G>()) return ad_traits<G>::K == 1 ? 3 : PSDR_WAVES_DG;
+    // (the rough-conductor PathTracer spills 79 VGPRs at 3 waves: without trees to walk 2 waves are faster, cbox_rough K = 1 geometry
+    // 8.15 -> 6.9 ms; with a two-level tree the third wave wins, 7.4 against 8.8 ms)
+    if (is_ad<G>()) return ad_traits<G>::K == 1 ? (((FL & kSceneRough) != 0 && (FL & kSceneForest) == 0 && INTEG == PSDR_INTEGRATOR_PATH) ? 2 : 3) : PSDR_WAVES_DG;
     // PathTracer material duals of the lean variant: K = 1 fits 4 waves / SIMD without spilling (C2 1.67 ms); K = 3 spills
     // 150 VGPRs there and runs faster at 3 (3.37 -> 2.99 ms)
     // rough-conductor PathTracer with three tangent sets on a scene without trees: 204 VGPRs spilled at 3 waves, none at 2
