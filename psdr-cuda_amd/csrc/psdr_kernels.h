@@ -91,21 +91,22 @@ __device__ __forceinline__ void slot_to_pixel(long long j, int nsp, int &pixel, 
 // the plain diffuse / area-light variant (FL == 0) is lean enough for one more wave: renderC 5 waves/SIMD (C2
 // PathTracer(3) 2.06 -> 1.89 ms), material duals of the PathTracer 4 (2.85 -> 2.66 ms); the rough-conductor
 // variants lose 10 % there (C5 renderC 5.0 -> 5.5 ms) and the DirectIntegrator K = 3 instance 20 %
-template <class G, class R, int INTEG, int FL> constexpr int camera_waves() {
+template <class G, class R, int INTEG, int FL, bool NOTREE = false> constexpr int camera_waves() {
     constexpr bool lean = (FL & (kSceneEnv | kSceneRough)) == 0;          // plain diffuse / area light (with or without a two-level tree)
     if (!is_ad<R>()) return lean ? PSDR_WAVES_C + 1 : PSDR_WAVES_C;
-    // (the rough-conductor PathTracer spills 79 VGPRs at 3 waves: without trees to walk 2 waves are faster, cbox_rough K = 1 geometry
-    // 8.15 -> 6.9 ms; with a two-level tree the third wave wins, 7.4 against 8.8 ms)
-    if (is_ad<G>()) return ad_traits<G>::K == 1 ? (((FL & kSceneRough) != 0 && (FL & kSceneForest) == 0 && INTEG == PSDR_INTEGRATOR_PATH) ? 2 : 3) : PSDR_WAVES_DG;
+    // NOTREE (the launch serves a scene whose primitives all travel in the kernel arguments, run_camera): the rough-conductor PathTracer
+    // spills 79 (geometry duals, K = 1) / 204 (material duals, K = 3) VGPRs at 3 waves, none at 2 -- without a tree walk whose latency the third
+    // wave would hide, 2 waves are faster (cbox_rough: 8.15 -> 6.9 ms and 8.65 -> 6.4 ms); with trees the third wave wins (interior: 7.4
+    // against 8.8 and 8.1 ms)
+    constexpr bool rough_path_notree = NOTREE && (FL & kSceneRough) != 0 && INTEG == PSDR_INTEGRATOR_PATH;
+    if (is_ad<G>()) return ad_traits<G>::K == 1 ? (rough_path_notree ? 2 : 3) : PSDR_WAVES_DG;
     // PathTracer material duals of the lean variant: K = 1 fits 4 waves / SIMD without spilling (C2 1.67 ms); K = 3 spills
     // 150 VGPRs there and runs faster at 3 (3.37 -> 2.99 ms)
-    // rough-conductor PathTracer with three tangent sets on a scene without trees: 204 VGPRs spilled at 3 waves, none at 2
-    // (cbox_rough K = 3: 8.65 -> 6.60 ms; with a two-level tree to walk the third wave is worth more than the spills: 7.4 against 8.1 ms)
-    if ((FL & kSceneRough) != 0 && (FL & kSceneForest) == 0 && INTEG == PSDR_INTEGRATOR_PATH && ad_traits<R>::K == 3) return 2;
+    if (rough_path_notree && ad_traits<R>::K == 3) return 2;
     return (lean && INTEG == PSDR_INTEGRATOR_PATH && ad_traits<R>::K == 1) ? PSDR_WAVES_DM + 1 : PSDR_WAVES_DM;
 }
-template <class G, class R, int INTEG, int FL>
-__global__ __launch_bounds__(kBlock, (camera_waves<G, R, INTEG, FL>())) void k_camera(LaunchCtx cx, TV<R, FL> tv, int spp, int s_begin, int nsp, long long n, float inv_spp,
+template <class G, class R, int INTEG, int FL, bool NOTREE = false>
+__global__ __launch_bounds__(kBlock, (camera_waves<G, R, INTEG, FL, NOTREE>())) void k_camera(LaunchCtx cx, TV<R, FL> tv, int spp, int s_begin, int nsp, long long n, float inv_spp,
                                                    float *__restrict__ img, float *__restrict__ dimg, long long plane,
                                                    unsigned long long *counters) {
     constexpr int K = ad_traits<R>::K;
@@ -836,16 +837,23 @@ int run_camera(psdr_scene_s *h, const psdr_render_opts *o, const TV<R, FL> &tv, 
     if (int rc = make_ctx(h, o, 0, cx)) return rc;
     const long long n = WH * nsp;
     h->slots[0] += (uint64_t) n;
-#define PSDR_LAUNCH_CAMERA(INTEG)                                                                                                  \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_camera<G, R, INTEG, FL>), dim3(launch_blocks(h, n, camera_blocks_per_cu(h, n))), dim3(kBlock), lds_bytes(cx, h), s, cx, tv, o->spp, \
+#define PSDR_LAUNCH_CAMERA_T(INTEG, NOTREE)                                                                                        \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_camera<G, R, INTEG, FL, NOTREE>), dim3(launch_blocks(h, n, camera_blocks_per_cu(h, n))), dim3(kBlock), lds_bytes(cx, h), s, cx, tv, o->spp, \
                        o->spp_begin, nsp, n, 1.f / (float) o->spp, img, dimg, WH * 3, h->d_counters)
+#define PSDR_LAUNCH_CAMERA(INTEG) PSDR_LAUNCH_CAMERA_T(INTEG, false)
+    // a second instance of the kernel exists only where the occupancy choice differs between scenes with and without a tree
+    constexpr bool two = camera_waves<G, R, PSDR_INTEGRATOR_PATH, FL, true>() != camera_waves<G, R, PSDR_INTEGRATOR_PATH, FL, false>();
+    const bool notree = h->n_tiny > 0 && h->n_blas == 0;
     switch (o->integrator) {
         case PSDR_INTEGRATOR_DIRECT: PSDR_LAUNCH_CAMERA(PSDR_INTEGRATOR_DIRECT); break;
-        case PSDR_INTEGRATOR_PATH: PSDR_LAUNCH_CAMERA(PSDR_INTEGRATOR_PATH); break;
+        case PSDR_INTEGRATOR_PATH:
+            if constexpr (two) { if (notree) { PSDR_LAUNCH_CAMERA_T(PSDR_INTEGRATOR_PATH, true); break; } }
+            PSDR_LAUNCH_CAMERA(PSDR_INTEGRATOR_PATH); break;
         case PSDR_INTEGRATOR_FIELD: PSDR_LAUNCH_CAMERA(PSDR_INTEGRATOR_FIELD); break;
         default: return fail("Unknown integrator");
     }
 #undef PSDR_LAUNCH_CAMERA
+#undef PSDR_LAUNCH_CAMERA_T
     HIP_TRY(hipGetLastError());
     return 0;
 }
