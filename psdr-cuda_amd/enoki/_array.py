@@ -20,12 +20,30 @@ def _cls(kind, ad):
     return _CLASSES[(kind, bool(ad) and kind not in ("i", "b"))]
 
 
+def _from_host(x, dtype):
+    """Device tensor from host data WITHOUT a synchronous copy.  A blocking host-to-device copy queues behind whatever kernel is running
+    and holds the host until it ends: `P = FloatD(0.)` right after `renderC` cost the harness' step the whole render kernel (1.4 ms of
+    3.4) before the next call could even be prepared.  A scalar becomes a fill kernel; small arrays go through pinned memory."""
+    dev = default_device()
+    if isinstance(x, (bool, int, float)) or (isinstance(x, np.generic) and np.ndim(x) == 0):
+        return torch.full((1,), x, dtype=dtype, device=dev)
+    arr = np.asarray(x)
+    if dev.type != "cuda":
+        return torch.as_tensor(arr, device=dev).to(dtype)
+    if arr.ndim == 0 or arr.size == 1:
+        return torch.full(tuple(arr.shape) if arr.ndim else (1,), arr.reshape(-1)[0].item(), dtype=dtype, device=dev)
+    host = torch.as_tensor(arr).to(dtype)
+    if host.numel() <= 4096:
+        return host.pin_memory().to(dev, non_blocking=True)
+    return host.to(dev)
+
+
 def _as_tensor(x, dtype=torch.float32):
     if isinstance(x, ArrayBase):
         return x.t
     if isinstance(x, torch.Tensor):
         return x
-    return torch.as_tensor(np.asarray(x), dtype=dtype, device=default_device())
+    return _from_host(x, dtype)
 
 
 class ArrayBase:
@@ -48,8 +66,7 @@ class ArrayBase:
                 t = a.to(device=dev, dtype=self._dtype)      # arrays live on the render device
                 t = self._coerce(t, None)
             else:
-                arr = np.asarray(a, dtype=np.float64 if self._dtype.is_floating_point else None)
-                t = torch.as_tensor(arr, device=dev).to(self._dtype)
+                t = _from_host(a, self._dtype)
                 t = self._coerce(t, None)
         else:
             cols = _KIND_COLS.get(k, 0)
