@@ -303,23 +303,101 @@ template <class Sink> struct BsdfRev {
     }
 
     // adjoint of the SAMPLED pdf: pdf_s = pdf(its, wo_s(wi, alpha; xi))  (roughconductor.cpp:79-92 keeps this
-    // dependency alive; Diffuse: constant)
+    // dependency alive; Diffuse: constant).  Written out by hand -- the value chain of GGX::sample / visible11 (psdr_device.h) once,
+    // then its adjoint backwards: ~250 flops instead of pushing five tangents through the chain on Dual<5> numbers (6x the
+    // registers of every intermediate, in a kernel that spills).  The reflected direction's half vector IS the sampled normal m,
+    // so pdf_s = D(m) G1(wi, m) / (4 wi.z) with m = m(wi, alpha; xi).  Branches (clamps, safe_sqrt, the masks of D and G1) follow the
+    // value like the dual-number forms do (psdr_math.h max_ / min_ / safe_sqrt).
     template <class TVT> PSDR_HD void sampled_pdf_vjp(Sink &sink, const TVT &tv0, const Its<float> &its, const float s[3], float apdf, Vec3f &awi,
                                  float &auvx, float &auvy) const {
         if (b.is_diffuse(tv0) || apdf == 0.f) return;
-        using D5 = Dual<5>;
         const RcParams p = rc_params(tv0, its);
-        auto sd = [](float v, int i) { D5 r(v); r.d[i] = 1.f; return r; };
-        const Vec3<D5> dwi{sd(its.wi.x, 0), sd(its.wi.y, 1), sd(its.wi.z, 2)};
-        const GGX<D5> g{sd(p.au, 3), sd(p.av, 4)};
-        const Vec3<D5> m = g.sample(dwi, s[0], s[1]);
-        const Vec3<D5> wo = m * (2.f * dot(dwi, m)) - dwi;
-        const Vec3<D5> h = normalize(wo + dwi);
-        const D5 r = g.eval(h) * g.smith_g1(dwi, h) / (4.f * dwi.z);
-        awi.x += apdf * r.d[0]; awi.y += apdf * r.d[1]; awi.z += apdf * r.d[2];
-        const float a3 = apdf * r.d[3], a4 = apdf * r.d[4];
-        bitmap_vjp<Sink, 1>(sink, sc, b.slot(PSDR_SLOT_ALPHA_U), its.uvx, its.uvy, &a3, auvx, auvy);
-        bitmap_vjp<Sink, 1>(sink, sc, b.slot(PSDR_SLOT_ALPHA_V), its.uvx, its.uvy, &a4, auvx, auvy);
+        const float au = p.au, av = p.av;
+        const Vec3f wi = its.wi;
+        // ---- values
+        const Vec3f v{au * wi.x, av * wi.y, wi.z};
+        const float L = norm(v);
+        const Vec3f wp = v / L;
+        const float st2 = wp.x * wp.x + wp.y * wp.y;
+        const bool has_phi = !(fabsf(st2) <= 4.f * kEpsilon);
+        float sp = 0.f, cp = 1.f, inv = 0.f;
+        bool sp_free = false, cp_free = false;                  // inside the clamp: the derivative passes
+        if (has_phi) {
+            inv = 1.f / sqrtf(st2);
+            const float rs = wp.y * inv, rc = wp.x * inv;
+            sp_free = rs > -1.f && rs < 1.f; cp_free = rc > -1.f && rc < 1.f;
+            sp = fminf(fmaxf(rs, -1.f), 1.f); cp = fminf(fmaxf(rc, -1.f), 1.f);
+        }
+        float px, py;
+        concentric_disk(s[0], s[1], px, py);
+        const float c = wp.z, sh = 0.5f * (1.f + c), k0 = sqrtf(fmaxf(1.f - px * px, 0.f));
+        const float y = k0 * (1.f - sh) + py * sh;
+        const float zarg = 1.f - (px * px + y * y), z = zarg > 0.f ? sqrtf(zarg) : 0.f;
+        const float sarg = 1.f - c * c, si = sarg > 0.f ? sqrtf(sarg) : 0.f;
+        const float nrm = 1.f / (si * y + c * z);
+        const float slx = (c * y - si * z) * nrm, sly = px * nrm;
+        const float b0 = cp * slx - sp * sly, b1 = sp * slx + cp * sly;
+        const Vec3f u{-(b0 * au), -(b1 * av), 1.f};
+        const float Lu = norm(u);
+        const Vec3f m = u / Lu;
+        const float q = sqr(m.x / au) + sqr(m.y / av) + sqr(m.z);
+        const float D = 1.f / (kPi * au * av * sqr(q));
+        if (!(D * m.z > 1e-5f)) return;                          // D masked to zero: pdf_s = 0, nothing depends on anything
+        const float xy = sqr(au * wi.x) + sqr(av * wi.y);
+        const bool g_zero = dot(wi, m) * wi.z <= 0.f, g_one = xy == 0.f;
+        const float iz2 = 1.f / sqr(wi.z), tt = xy * iz2, sq = sqrtf(1.f + tt);
+        const float G1 = g_zero ? 0.f : (g_one ? 1.f : 2.f / (1.f + sq));
+        const float inv4 = 1.f / (4.f * wi.z);
+        const float F = D * G1 * inv4;
+        // ---- adjoints
+        float a_au = 0.f, a_av = 0.f;
+        Vec3f a_wi(0.f);
+        const float a_D = apdf * G1 * inv4, a_G1 = apdf * D * inv4;
+        a_wi.z += -apdf * F / wi.z;
+        if (!g_zero && !g_one && a_G1 != 0.f) {                  // G1 = 2 / (1 + sqrt(1 + xy / wi.z^2))
+            const float a_t = -a_G1 / (sqr(1.f + sq) * sq);                        // d/dt [2 / (1 + sqrt(1 + t))] = -1 / ((1 + sq)^2 sq)
+            const float a_xy = a_t * iz2;
+            a_wi.z += a_t * (-2.f * tt / wi.z);
+            a_wi.x += a_xy * 2.f * au * au * wi.x; a_wi.y += a_xy * 2.f * av * av * wi.y;
+            a_au += a_xy * 2.f * au * wi.x * wi.x; a_av += a_xy * 2.f * av * wi.y * wi.y;
+        }
+        // D = 1 / (pi au av q^2)
+        const float a_q = a_D * (-2.f * D / q);
+        a_au += -a_D * D / au - a_q * 2.f * sqr(m.x) / (au * au * au);
+        a_av += -a_D * D / av - a_q * 2.f * sqr(m.y) / (av * av * av);
+        const Vec3f a_m{a_q * 2.f * m.x / (au * au), a_q * 2.f * m.y / (av * av), a_q * 2.f * m.z};
+        // m = u / |u|, u = (-b0 au, -b1 av, 1)
+        const Vec3f a_u = (a_m - m * dot(m, a_m)) / Lu;
+        const float a_s0 = -a_u.x, a_s1 = -a_u.y;               // s0 = b0 au, s1 = b1 av
+        a_au += a_s0 * b0; a_av += a_s1 * b1;
+        const float a_b0 = a_s0 * au, a_b1 = a_s1 * av;
+        float a_cp = a_b0 * slx + a_b1 * sly, a_sp = -a_b0 * sly + a_b1 * slx;
+        const float a_slx = a_b0 * cp + a_b1 * sp, a_sly = -a_b0 * sp + a_b1 * cp;
+        // visible11: slx = (c y - si z) nrm, sly = px nrm, nrm = 1 / (si y + c z)
+        const float a_nrm = a_slx * (c * y - si * z) + a_sly * px;
+        float a_c = a_slx * y * nrm, a_y = a_slx * c * nrm, a_si = -a_slx * z * nrm, a_z = -a_slx * si * nrm;
+        const float a_den = -a_nrm * nrm * nrm;
+        a_si += a_den * y; a_y += a_den * si; a_c += a_den * z; a_z += a_den * c;
+        if (si > 0.f) a_c += a_si * (-c / si);                   // safe_sqrt: no derivative at or below zero
+        if (z > 0.f) a_y += a_z * (-y / z);
+        a_c += 0.5f * a_y * (py - k0);                           // y = k0 (1 - sh) + py sh, sh = (1 + c) / 2
+        // phi: sp = clamp(wp.y inv), cp = clamp(wp.x inv), inv = st2^(-1/2)
+        Vec3f a_wp{0.f, 0.f, a_c};
+        if (has_phi) {
+            if (!sp_free) a_sp = 0.f;
+            if (!cp_free) a_cp = 0.f;
+            const float a_inv = a_sp * wp.y + a_cp * wp.x;
+            a_wp.y += a_sp * inv; a_wp.x += a_cp * inv;
+            const float a_st2 = a_inv * (-0.5f * inv * inv * inv);
+            a_wp.x += a_st2 * 2.f * wp.x; a_wp.y += a_st2 * 2.f * wp.y;
+        }
+        // wp = v / |v|, v = (au wi.x, av wi.y, wi.z)
+        const Vec3f a_v = (a_wp - wp * dot(wp, a_wp)) / L;
+        a_wi.x += a_v.x * au; a_wi.y += a_v.y * av; a_wi.z += a_v.z;
+        a_au += a_v.x * wi.x; a_av += a_v.y * wi.y;
+        acc(awi, a_wi);
+        bitmap_vjp<Sink, 1>(sink, sc, b.slot(PSDR_SLOT_ALPHA_U), its.uvx, its.uvy, &a_au, auvx, auvy);
+        bitmap_vjp<Sink, 1>(sink, sc, b.slot(PSDR_SLOT_ALPHA_V), its.uvx, its.uvy, &a_av, auvx, auvy);
     }
 };
 
