@@ -92,13 +92,21 @@ def main():
 def extra(which):
     if "c4" in which:
         # one GPU's shard of C4: cbox_bunny 1024x1024, 64 of the 512 spp
-        sc, P = load_scene("cbox_bunny", res=1024, spp=512, sppe=0, sppse=0)
+        sc, P = load_scene("cbox_bunny", res=1024, spp=512, sppe=0, sppse=0, translate=(1, (1.0, 0.0, 0.0)))
         tb = sc.tables(0); g = GpuScene(tb); n = 1024 * 1024 * 64
         for name, kw in (("direct11", dict(bsdf_samples=1, light_samples=1)), ("path3", dict(integrator=_abi.INTEGRATOR_PATH, max_depth=3))):
             o = _abi.make_opts(spp=512, spp_range=(0, 64), **kw)
             g.render_c(o); g.counters()          # as the psdr_cuda surface does on the first calls: the library learns the path survival ratio
             ms = timeit(lambda: g.render_c(o), reps=2); r = g.counters()[0] / n
             print("C4 shard %-9s renderC (67M slots) %8.2f ms  %7.0f Msamples/s  rays/slot %.2f" % (name, ms, n / ms / 1e3, r))
+            # the renderD half of the shard: forward K = 1 (rigid translation of the bunny: geometry duals) and reverse (triangle rows + texels)
+            adj = np.random.default_rng(0).random((1024 * 1024, 3)).astype(np.float32)
+            tan = tangents_wrt(tb, P) if P is not None else None
+            if tan is not None:
+                ms = timeit(lambda: g.render_d_fwd(o, [tan]), reps=2)
+                print("C4 shard %-9s renderD fwd K=1 geo (67M slots) %8.2f ms  %7.0f Msamples/s" % (name, ms, n / ms / 1e3))
+            ms = timeit(lambda: g.render_d_rev(o, adj, want=["tri_info", "texels"], with_image=False), reps=2)
+            print("C4 shard %-9s renderD rev tri+texels (67M slots) %8.2f ms  %7.0f Msamples/s" % (name, ms, n / ms / 1e3))
     if "c5" in which:
         from psdr_cuda.fixtures import make_interior_scene
         res, spp = 512, 16
