@@ -38,10 +38,14 @@ sys.path.insert(0, os.path.join(ROOT, "psdr-cuda_amd"))
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-# MI355X (MI355X_MICROARCH.md): 256 CUs x 4 SIMDs, 2.4 GHz; a wave64 VALU instruction occupies its SIMD for 4 cycles
-# (16 lanes per cycle); non-packed fp32 FMA peak 256 * 4 * 16 * 2 * 2.4e9 = 78.6 TFLOP/s; HBM3E 8 TB/s.
+# MI355X (MI355X_MICROARCH.md): 256 CUs x 4 SIMD-32 units, 2.4 GHz; a wave64 VALU instruction occupies its SIMD for 2 cycles
+# (32 lanes per cycle; `v_fma_f32 (wave64) 2 cyc`), i.e. 1024 * 2.4e9 / 2 = 1228.8 G wave-instructions/s = the 157.3 TFLOP/s
+# fp32 vector peak; measured by tools/micro/valu_rate.hip (profiles/r03_valu_rate.txt).  HBM3E 8 TB/s.
 N_SIMD, CLOCK_HZ, HBM_BPS = 1024, 2.4e9, 8.0e12
-VALU_PEAK_WAVE_INSTS_PER_S = N_SIMD * CLOCK_HZ / 4.0          # 6.144e11 wave-instructions / s
+VALU_PEAK_WAVE_INSTS_PER_S = N_SIMD * CLOCK_HZ / 2.0          # 1.2288e12 wave-instructions / s
+# VALU lane-instructions one primitive test costs (Moeller-Trumbore with SGPR operands, csrc/psdr_device.h tiny_prim_test) and
+# the rest of a traced ray's share of its path vertex (hit reconstruction, sampling, shading): DESIGN.md section 3
+FLOOR_VALU_PER_PRIM_TEST, FLOOR_VALU_PER_RAY_REST = 27, 150
 
 
 def parse():
@@ -53,6 +57,10 @@ def parse():
     ap.add_argument("--spp", type=int, default=64, help="samples per pixel PER GPU")
     ap.add_argument("--max-depth", type=int, default=3)
     ap.add_argument("--scene", default="cbox")
+    ap.add_argument("--config", default="c2", choices=("c2", "c4"),
+                    help="c2 (default, the headline): cbox 512x512 spp 64 PER GPU, albedo derivative, weak scaling.  c4: cbox_bunny 1024x1024, "
+                         "GLOBAL spp 512 sharded over the ranks (strong scaling), renderC + renderD + enoki.backward w.r.t. the bunny's vertex "
+                         "positions and the albedo texels (gradient-buffer all-reduce)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
@@ -168,9 +176,9 @@ def pmc_passes(args):
     tmp = tempfile.mkdtemp(prefix="psdr_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
     try:
-        for group in ("SQ_INSTS_VALU", "FETCH_SIZE", "WRITE_SIZE"):
-            d = os.path.join(tmp, group)
-            cmd = [exe, "--pmc", group, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
+        for group in ("SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES", "FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, group.split()[0])
+            cmd = [exe, "--pmc"] + group.split() + ["--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
                    "--pmc-child", "--res", str(args.res), "--spp", str(args.spp), "--max-depth", str(args.max_depth), "--scene", args.scene]
             try:
                 subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
@@ -182,19 +190,122 @@ def pmc_passes(args):
             acc = {}
             for r in csv.DictReader(open(files[0])):
                 name = r.get("Kernel_Name", "")
-                if "k_camera" not in name or r.get("Counter_Name") != group:
+                if "k_camera" not in name or r.get("Counter_Name") not in group.split():
                     continue
                 key = "rev" if "k_camera_rev" in name else ("d" if "Dual<" in name else "c")
-                acc.setdefault(key, []).append(float(r["Counter_Value"]))
-            for key, vals in acc.items():
-                out.setdefault(key, {})[group] = float(np.mean(vals))
+                acc.setdefault((key, r["Counter_Name"]), []).append(float(r["Counter_Value"]))
+            for (key, cname), vals in acc.items():
+                out.setdefault(key, {})[cname] = float(np.mean(vals))
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     return out
 
 
+def relaunch_under_torchrun(args):
+    """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run, one process per GPU (what the driver's own
+    command line does for N > 1).  PSDR_BENCH_ONE_GPU=1 (developer switch) lets the N ranks share cuda:0 over gloo."""
+    import socket
+    n_dev = torch.cuda.device_count()
+    if n_dev < args.gpus and os.environ.get("PSDR_BENCH_ONE_GPU") != "1":
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible" % (args.gpus, n_dev))
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execvpe(sys.executable, cmd, env)
+
+
+def rank_devices(dist, local_rank):
+    """[(rank, device index, device name, PCI bus id)] of every rank + the RCCL version (rank 0 prints them in `config`)."""
+    props = torch.cuda.get_device_properties(local_rank)
+    mine = {"rank": dist.get_rank() if dist else 0, "device": local_rank, "name": props.name,
+            "pci_bus_id": getattr(props, "pci_bus_id", None), "uuid": str(getattr(props, "uuid", ""))}
+    if not dist:
+        return [mine], None
+    allr = [None] * dist.get_world_size()
+    dist.all_gather_object(allr, mine)
+    try:
+        v = torch.cuda.nccl.version()
+        v = ".".join(str(x) for x in v) if isinstance(v, tuple) else str(v)
+    except Exception:
+        v = None
+    return allr, v
+
+
+def run_c4(args, world, rank, local_rank, dist, devices, rccl):
+    """BASELINE configs[3]: cbox_bunny 1024x1024, GLOBAL spp 512 sharded over the ranks (strong scaling), PathTracer(3).  Step = renderC +
+    [configure + renderD + enoki.backward] w.r.t. the bunny's vertex positions and the albedo texels: per step one image all-reduce
+    (renderC), one of the primal image of renderD and one of the flat gradient buffer [triangle rows || texels]."""
+    import enoki as ek
+    import psdr_cuda
+    from enoki.cuda_autodiff import Float32 as FloatD, Vector3f as Vector3fD
+    from psdr_cuda.fixtures import scene_path
+    res, spp = (args.res if args.res != 512 else 1024), (args.spp if args.spp != 64 else 512)
+    sc = psdr_cuda.Scene()
+    sc.load_file(scene_path("cbox_bunny"), False)
+    sc.opts.width = sc.opts.height = res
+    sc.opts.spp, sc.opts.sppe, sc.opts.sppse, sc.opts.log_level = spp, 0, 0, 0
+    integ = psdr_cuda.PathTracer(max_depth=args.max_depth)
+    refl = sc.param_map["BSDF[0]"].reflectance
+    base = ek.detach(refl.data)
+    mesh = sc.param_map["Mesh[1]"]                      # the bunny (cbox_bunny.xml)
+    v0 = ek.detach(mesh.vertex_positions)
+    sc.configure()
+
+    def step():
+        img = integ.renderC(sc)
+        r = Vector3fD(base); ek.set_requires_gradient(r); refl.data = r
+        v = Vector3fD(v0); ek.set_requires_gradient(v); mesh.vertex_positions = v
+        sc.configure()
+        imgD = integ.renderD(sc)
+        ek.backward(FloatD._wrap(imgD.t.sum().reshape(1)))
+        return img, ek.gradient(v), ek.gradient(r)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist:
+        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    value = 2.0 * res * res * spp * args.steps / dt / 1e6
+    T = int(sc.tables(0)["num_tris"])
+    grad_words = T * 24 + int(sc.tables(0)["texels"].numel())
+    if rank == 0:
+        gv = out[1].numpy()
+        print(json.dumps({
+            "metric": "Mpath-samples/s renderC+renderD, cbox_bunny 1024x1024 spp=512 sharded (BASELINE configs[3])",
+            "value": round(value, 3), "unit": "Mpath-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "cbox_bunny %dx%d GLOBAL spp=%d (%d per GPU) PathTracer(max_depth=%d): renderC + configure + renderD + enoki.backward "
+                                   "w.r.t. the bunny's vertex positions and the albedo texels, through the psdr_cuda surface"
+                                   % (res, res, spp, spp // world, args.max_depth),
+                       "triangles": T, "global_spp": spp, "world_size": world, "devices": devices, "rccl_version": rccl,
+                       "allreduce_bytes_per_step": 0 if world == 1 else int(2 * res * res * 3 * 4 + grad_words * 4),
+                       "parallelism": "spp-shard x%d; all-reduces per step: [image] (renderC), [image] (renderD primal), [triangle-row || texel gradients]" % world},
+            "grad_check": {"finite": bool(np.isfinite(gv).all()), "abs_max_vertex_grad": float(np.abs(gv).max())},
+        }))
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.pmc_child:
+        relaunch_under_torchrun(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -214,6 +325,12 @@ def main():
         else:
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
+    devices, rccl = rank_devices(dist, local_rank)
+    if args.config == "c4":
+        run_c4(args, world, rank, local_rank, dist, devices, rccl)
+        if dist:
+            dist.destroy_process_group()
+        return
     from psdr_cuda import _abi
     w = Workload(args, world)
 
@@ -284,18 +401,23 @@ def main():
     fetch, write = pmc.get(dom_key, {}).get("FETCH_SIZE"), pmc.get(dom_key, {}).get("WRITE_SIZE")
     traffic = None if fetch is None or write is None else (2.0 * fetch + write) * 1024.0
     achieved = None if valu is None else valu / (dom_ms * 1e-3)
-    # algorithmic floor: VALU lane-instructions a traced ray NEEDS on this scene -- 12 triangle tests x 27 (Moeller-Trumbore
-    # with SGPR operands, csrc/psdr_device.h leaf_triangle_test) + ~150 for hit reconstruction, sampling and shading of its
-    # path vertex -- over the lane-instructions the launch issued (64 per wave-instruction)
-    floor_lane_insts = (12 * 27 + 150) * float(dom_rays)
+    # algorithmic floor: VALU lane-instructions a traced ray NEEDS on this scene -- one test per PRIMITIVE the kernel holds (the 12 wall
+    # triangles of the Cornell box are 6 parallelograms, psdr_bvh_build.h pack_tiny_prims) x 27 (Moeller-Trumbore with SGPR operands) +
+    # ~150 for hit reconstruction, sampling and shading of its path vertex -- over the lane-instructions issued (64 per wave-instruction)
+    n_prims = int(_abi.scene_stats(w.sc._native).get("n_tiny", 0)) or int(w.tb["num_tris"])
+    floor_lane_insts = (n_prims * FLOOR_VALU_PER_PRIM_TEST + FLOOR_VALU_PER_RAY_REST) * float(dom_rays)
+    dpm = pmc.get(dom_key, {})
+    wave_cycles = dpm.get("SQ_WAVE_CYCLES")
     roofline = {
         "bound": "valu", "kernel": dom_name, "kernel_ms": round(dom_ms, 4),
         "achieved": None if achieved is None else round(achieved / 1e9, 3), "peak": round(VALU_PEAK_WAVE_INSTS_PER_S / 1e9, 3),
-        "unit": "G wave-instructions/s", "frac": None if achieved is None else round(min(achieved / VALU_PEAK_WAVE_INSTS_PER_S, 1.0), 4),
-        "frac_uncapped": None if achieved is None else round(achieved / VALU_PEAK_WAVE_INSTS_PER_S, 4),
-        "peak_note": "1024 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction (MI355X_MICROARCH.md); an instruction whose upper or lower 32 "
-                     "lanes are all inactive takes 2 cycles, hence frac_uncapped can exceed 1",
+        "unit": "G wave-instructions/s", "frac": None if achieved is None else round(achieved / VALU_PEAK_WAVE_INSTS_PER_S, 4),
+        "peak_note": "1024 SIMD-32 units x 2.4 GHz / 2 cycles per wave64 VALU instruction (MI355X_MICROARCH.md; tools/micro/valu_rate.hip measures it)",
         "valu_wave_insts_per_launch": valu, "algorithmic_floor_frac": None if valu is None else round(floor_lane_insts / (valu * 64.0), 4),
+        "primitives_tested_per_ray": n_prims,
+        "wait_any_frac": None if not wave_cycles or "SQ_WAIT_ANY" not in dpm else round(dpm["SQ_WAIT_ANY"] / wave_cycles, 4),
+        "wait_inst_any_frac": None if not wave_cycles or "SQ_WAIT_INST_ANY" not in dpm else round(dpm["SQ_WAIT_INST_ANY"] / wave_cycles, 4),
+        "valu_active_frac_of_wave_cycles": None if not wave_cycles or "SQ_ACTIVE_INST_VALU" not in dpm else round(dpm["SQ_ACTIVE_INST_VALU"] / wave_cycles, 4),
         "traffic": traffic, "hbm_measured_frac": None if traffic is None else round(traffic / (dom_ms * 1e-3) / HBM_BPS, 5),
         "traffic_note": "(2 * FETCH_SIZE + WRITE_SIZE) KiB per launch from rocprofv3 --pmc passes run by this script; image + derivative image = %.1f MB"
                         % (local_slots / args.spp * 12 * 2 / 1e6),
@@ -368,7 +490,7 @@ def main():
             "config": {"workload": "%s %dx%d spp=%d/GPU PathTracer(max_depth=%d): renderC + configure + renderD + enoki.forward w.r.t. diffuse albedo, through the psdr_cuda surface"
                                    % (args.scene, args.res, args.res, args.spp, args.max_depth),
                        "triangles": int(w.tb["num_tris"]), "global_spp": args.spp * world, "world_size": world,
-                       "device": torch.cuda.get_device_name(local_rank), "local_rank": local_rank,
+                       "device": torch.cuda.get_device_name(local_rank), "local_rank": local_rank, "devices": devices, "rccl_version": rccl,
                        "allreduce_bytes_per_step": 0 if world == 1 else int(args.res * args.res * 3 * 4 * 3),
                        "parallelism": "spp-shard x%d, one all-reduce per render call ([image] for renderC, [image || derivative image] for renderD)" % world},
             "surface": surface, "kernel_only": kernel_only,

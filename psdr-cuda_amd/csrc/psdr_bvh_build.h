@@ -291,6 +291,10 @@ struct ForestBuilder {
         }
         int n_inline = 0, n_blas = 0;
         for (int c : cnt) { if (c >= kMinBlasTris) n_blas++; else n_inline += c; }
+        // an inline primitive packs two GLOBAL triangle ids into 16 bits each (pack_tiny_prims, 0xffff = none): a room whose walls
+        // are listed behind >= 65535 triangles of other meshes keeps the single tree
+        for (int i = 0xffff; i < T; ++i)
+            if (cnt[tri_mesh[i] & ~PSDR_TRI_FACE_NORMALS] < kMinBlasTris) return false;
         return n_blas >= 1 && n_blas <= kMaxBlas && n_inline <= 2 * kTinyTris;      // primitives after pairing are checked by the caller
     }
 

@@ -328,10 +328,6 @@ int lbvh_build(psdr_scene_s *h, hipStream_t s, bool &fallback) {
     const size_t need = lbvh_layout(nullptr, T, sort_tmp).total;
     if (need > h->lbvh_bytes) {
         if (h->d_lbvh) (void) hipFree(h->d_lbvh);
-    if (h->d_rev) (void) hipFree(h->d_rev);
-    if (h->d_se_list) (void) hipFree(h->d_se_list);
-    if (h->d_rev_deep) (void) hipFree(h->d_rev_deep);
-    if (h->d_pe_rep) (void) hipFree(h->d_pe_rep);
         h->d_lbvh = nullptr; h->lbvh_bytes = 0;
         HIP_TRY(hipMalloc(&h->d_lbvh, need));
         h->lbvh_bytes = need;
@@ -476,6 +472,10 @@ int psdr_scene_destroy(psdr_scene_t h) {
     if (h->d_top) (void) hipFree(h->d_top);
     if (h->d_inline_ids) (void) hipFree(h->d_inline_ids);
     if (h->d_lbvh) (void) hipFree(h->d_lbvh);
+    if (h->d_rev) (void) hipFree(h->d_rev);
+    if (h->d_se_list) (void) hipFree(h->d_se_list);
+    if (h->d_rev_deep) (void) hipFree(h->d_rev_deep);
+    if (h->d_pe_rep) (void) hipFree(h->d_pe_rep);
     delete h;
     return 0;
 }
@@ -532,6 +532,7 @@ int psdr_bvh_build(psdr_scene_t h, void *stream) {
             return 0;
         }
         if (prev_area <= kRefitAreaGrowth * h->built_area) {
+            bool refit_fits = true;
             h->refit_stream = s;
             HIP_TRY(hipMemsetAsync(h->d_refit_area, 0, sizeof(float), s));
             hipLaunchKernelGGL(k_refit_leaves, dim3((h->num_btris + kBlock - 1) / kBlock), dim3(kBlock), 0, s, h->d_btris, h->desc.tri_info, h->num_btris);
@@ -548,19 +549,25 @@ int psdr_bvh_build(psdr_scene_t h, void *stream) {
                 HIP_TRY(hipStreamSynchronize(s));
                 std::vector<float4> tris(top, top + 3 * (size_t) h->n_inline), prims;
                 pack_tiny_prims(tris, prims);
-                if ((int) prims.size() / 3 > kTinyTris) return fail("psdr_bvh_build: inline primitives no longer fit after the refit");
-                h->n_tiny = (int) prims.size() / 3;
-                if (!prims.empty()) std::memcpy(h->tiny, prims.data(), prims.size() * sizeof(float4));
-                for (int k = 0; k < h->n_blas; ++k) {
-                    const float w = h->blas_lo[k].w;
-                    h->blas_lo[k] = top[kMaxInlineTris * 3 + k]; h->blas_lo[k].w = w;
-                    h->blas_hi[k] = top[kMaxInlineTris * 3 + kMaxBlas + k];
+                // moved wall vertices may no longer pair into parallelograms: more than kTinyTris primitives -> full rebuild below
+                // (which then picks a single tree)
+                refit_fits = (int) prims.size() / 3 <= kTinyTris;
+                if (refit_fits) {
+                    h->n_tiny = (int) prims.size() / 3;
+                    if (!prims.empty()) std::memcpy(h->tiny, prims.data(), prims.size() * sizeof(float4));
+                    for (int k = 0; k < h->n_blas; ++k) {
+                        const float w = h->blas_lo[k].w;
+                        h->blas_lo[k] = top[kMaxInlineTris * 3 + k]; h->blas_lo[k].w = w;
+                        h->blas_hi[k] = top[kMaxInlineTris * 3 + kMaxBlas + k];
+                    }
                 }
             }
-            h->refits_since_build++;
-            h->num_refits++;
-            h->have_bvh = true;
-            return 0;
+            if (refit_fits) {
+                h->refits_since_build++;
+                h->num_refits++;
+                h->have_bvh = true;
+                return 0;
+            }
         }
     }
     // ---- build on the device: large tables (the host build is a D2H of the table + a single-threaded SAH build), or on request
@@ -759,6 +766,13 @@ int psdr_guide_build(psdr_scene_t h, const psdr_render_opts *o, const int32_t re
 int psdr_bvh_stats(psdr_scene_t h, int32_t out[4]) {
     if (!h || !out) return fail("psdr_bvh_stats: null argument");
     out[0] = h->num_builds; out[1] = h->num_refits; out[2] = h->num_nodes; out[3] = h->bvh_depth;
+    return 0;
+}
+
+int psdr_scene_info(psdr_scene_t h, int32_t out[8]) {
+    if (!h || !out) return fail("psdr_scene_info: null argument");
+    out[0] = h->n_tiny; out[1] = h->n_blas; out[2] = h->n_inline; out[3] = h->num_btris; out[4] = h->lbvh ? 1 : 0;
+    out[5] = out[6] = out[7] = 0;
     return 0;
 }
 

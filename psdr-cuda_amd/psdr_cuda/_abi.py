@@ -83,7 +83,7 @@ TANGENT_FIELDS = ("tri_info", "texels", "emitter_rad", "cam_to_world", "sec_edge
 # every symbol include/psdr_hip.h declares (checked by tests/test_abi.py)
 HIP_SYMBOLS = (
     "psdr_last_error", "psdr_version", "psdr_abi_struct_sizes", "psdr_scene_create", "psdr_scene_destroy", "psdr_scene_set_tables",
-    "psdr_bvh_build", "psdr_bvh_stats", "psdr_trace", "psdr_render_c", "psdr_render_d_fwd", "psdr_render_d_rev",
+    "psdr_bvh_build", "psdr_bvh_stats", "psdr_scene_info", "psdr_trace", "psdr_render_c", "psdr_render_d_fwd", "psdr_render_d_rev",
     "psdr_guide_build", "psdr_get_counters",
 )
 
@@ -114,6 +114,7 @@ def load_hip():
     lib.psdr_render_d_rev.argtypes = [vp, C.POINTER(RenderOpts), vp, vp, C.POINTER(Grads), vp]
     lib.psdr_guide_build.argtypes = [vp, C.POINTER(RenderOpts), C.POINTER(i32), i32, vp, vp]
     lib.psdr_get_counters.argtypes = [vp, C.POINTER(C.c_uint64)]
+    lib.psdr_scene_info.argtypes = [vp, C.POINTER(i32)]
     for name in HIP_SYMBOLS:
         if name not in ("psdr_last_error", "psdr_version"):
             getattr(lib, name).restype = C.c_int
@@ -130,6 +131,14 @@ def check(lib, rc):
     if rc != 0:
         msg = lib.psdr_last_error()
         raise RuntimeError(msg.decode() if msg else "psdr_hip call failed (rc=%d)" % rc)
+
+
+def scene_stats(handle):
+    """psdr_scene_info as a dict (what psdr_bvh_build chose for the handle's current tables)."""
+    lib = load_hip()
+    out = (C.c_int32 * 8)()
+    check(lib, lib.psdr_scene_info(handle, out))
+    return {"n_tiny": out[0], "n_blas": out[1], "n_inline": out[2], "leaf_tris": out[3], "device_built": out[4]}
 
 
 def make_opts(integrator=INTEGRATOR_DIRECT, bsdf_samples=1, light_samples=1, max_depth=1, hide_emitters=False,

@@ -78,7 +78,11 @@ class _LazyImage(Vector3fD):
     def t(self):
         if self._t is None:
             primal = getattr(self._node, "primal", None)
-            self._t = primal if primal is not None else _RenderFn.apply(self._node, *self._inputs)
+            if primal is not None:
+                self._t = primal
+            else:
+                with torch.enable_grad():          # a first look under no_grad() must not cache an image without autograd history
+                    self._t = _RenderFn.apply(self._node, *self._inputs)
             self._inputs = None
         return self._t
 

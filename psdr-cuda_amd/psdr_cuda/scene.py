@@ -252,6 +252,7 @@ class PerspectiveCamera(Sensor):
             det = torch.det(tw[:3, :3].detach().double()).item()
             psdr_assert(abs(det - 1.0) < 1e-4, "Sensor transformation should not involve scaling!")   # sensor.cpp:8-12
             self._pose_key, self._pose_inv = pose_key, (None if tw.requires_grad else torch.linalg.inv(tw))
+            self._pose_alive = tw                  # the keyed tensor stays alive: its id / allocator block cannot be recycled under the key
         lens_key = (self.m_fov_x, self.m_near_clip, self.m_far_clip, aspect, str(tw.device))
         if getattr(self, "_lens_key", None) != lens_key:
             c2s = (np.diag([-0.5, -0.5 * aspect, 1.0, 1.0]) @
@@ -999,6 +1000,7 @@ class Scene(Object):
             mats = torch.bmm(torch.bmm(torch.stack([m._to_world_left for m in meshes]), torch.stack([m._to_world_raw for m in meshes])),
                              torch.stack([m._to_world_right for m in meshes]))
             self._mats_key, self._mats = mats_key, (mats if mats_key is not None else None)
+            self._mats_alive = parts if mats_key is not None else None        # keyed tensors stay alive (ids / blocks stay unique), as _static_key does
         v_raw = torch.cat([m._raw_positions() for m in meshes], dim=0)
         mv = mats[tp["vmesh"]]                                                     # [V,4,4]
         h = (mv[:, :3, :3] * v_raw.unsqueeze(1)).sum(-1) + mv[:, :3, 3]
@@ -1127,8 +1129,7 @@ class Scene(Object):
             tb.update(mt)
             self._version += 1
             tb["version"] = self._version
-            self._tables = tb
-            self._bvh_version = None
+            self._tables = tb           # _bvh_version stays: the tables keep their geo_version stamp, the tree on the handle is still theirs
             if o.log_level > 0:
                 self.log("Configured in %g seconds (material tables only)." % (time.perf_counter() - t_start))
             return

@@ -156,3 +156,107 @@ def test_large_table_is_built_on_the_device_by_default(tmp_path):
     assert (stri == b[1][:20000]).mean() > 0.999
     opt = _abi.make_opts(spp=4, bsdf_samples=1, light_samples=1)
     assert rel_l2(g.render_c(opt), gh.render_c(opt)) < 1e-4
+
+
+def scene_info(g):
+    return _abi.scene_stats(g.h)
+
+
+def test_scratch_growth_of_a_device_build_keeps_the_reverse_mode_buffers():
+    """lbvh_build's scratch-growth branch used to hipFree the reverse-mode / edge-list buffers of the handle without
+    forgetting them.  Reverse mode (all three terms: split secondary-edge list, primary-edge replicas, value-sweep record), then a
+    device build over a LARGER table on the same handle, then reverse mode again -- the gradients must be those of a fresh handle."""
+    from psdr_cuda.fixtures import make_interior_scene
+    sc, _ = load_scene("cbox_bunny", res=48, spp=4, sppe=4, sppse=4)
+    tb = sc.tables(0)
+    opt = _abi.make_opts(spp=4, sppe=4, sppse=4)
+    optp = _abi.make_opts(integrator=_abi.INTEGRATOR_PATH, max_depth=3, spp=4)
+    adj = np.random.default_rng(1).random((48 * 48, 3)).astype(np.float32)
+    with forced_build("device"):
+        g = GpuScene(tb)
+        g.render_d_rev(opt, adj, with_image=False)
+        g.render_d_rev(optp, adj, want=["tri_info", "texels"], with_image=False)
+        big = make_interior_scene(seed=1, n_objects=6, res=48, spp=4)          # ~30 k triangles: the LBVH scratch has to grow
+        big.opts.sppe = big.opts.sppse = 4
+        big.configure()
+        tb2 = big.tables(0)
+        assert tb2["tri_info"].shape[0] > 4 * tb["tri_info"].shape[0]
+        g.tb = {k: (v.detach().cuda() if isinstance(v, torch.Tensor) else v) for k, v in tb2.items()}
+        g.set_guide(None)
+        _abi.check(g.lib, g.lib.psdr_bvh_build(g.h, None))
+        assert bvh_stats(g)["builds"] == 2
+        fresh = GpuScene(tb2)
+        for o, want in ((opt, None), (optp, ["tri_info", "texels"])):
+            kw = {} if want is None else {"want": want}
+            _, a = g.render_d_rev(o, adj, with_image=False, **kw)
+            _, b = fresh.render_d_rev(o, adj, with_image=False, **kw)
+            for k in b:
+                assert np.isfinite(a[k]).all() and rel_l2(a[k], b[k]) < 1e-4, (k, rel_l2(a[k], b[k]))      # same tree, same samples: atomics order only
+        g.close(); fresh.close()                                                  # psdr_scene_destroy frees the four buffers (once)
+
+
+def _room_with_field(tmp_path, cells):
+    """A height field of 2 * cells^2 triangles listed BEFORE the Cornell-box walls: the walls' global triangle ids start behind it."""
+    import psdr_cuda
+    from psdr_cuda.fixtures import DATA_DIR
+    n = cells + 1
+    xs = np.linspace(-80.0, 80.0, n)
+    X, Z = np.meshgrid(xs, xs, indexing="ij")
+    Y = 40.0 + 12.0 * np.sin(X * 0.08) * np.cos(Z * 0.07)
+    idx = np.arange(n * n).reshape(n, n)
+    a, b, c, d = idx[:-1, :-1].ravel(), idx[1:, :-1].ravel(), idx[1:, 1:].ravel(), idx[:-1, 1:].ravel()
+    faces = np.concatenate([np.stack([a, c, b], 1), np.stack([a, d, c], 1)])
+    path = tmp_path / ("field%d.obj" % cells)
+    with open(path, "w") as f:
+        f.write("".join("v %.6f %.6f %.6f\n" % t for t in zip(X.ravel(), Y.ravel(), Z.ravel())))
+        f.write("".join("f %d %d %d\n" % tuple(r + 1) for r in faces))
+    base = psdr_cuda.Scene()
+    from psdr_cuda.fixtures import scene_path
+    base.load_file(scene_path("cbox"), False)
+    sc = psdr_cuda.Scene()
+    sc.opts.width = sc.opts.height = 48
+    sc.opts.spp, sc.opts.sppe, sc.opts.sppse, sc.opts.log_level = 4, 0, 0, 0
+    sc.add_sensor(base.m_sensors[0])
+    white = psdr_cuda.Diffuse([0.8, 0.8, 0.8]); white.id = "white"; sc.add_bsdf(white)
+    black = psdr_cuda.Diffuse([0.0, 0.0, 0.0]); black.id = "black"; sc.add_bsdf(black)
+    field = psdr_cuda.Mesh(); field.load(str(path)); field.enable_edges = False
+    sc.add_mesh(field, white, None)
+    light = psdr_cuda.Mesh(); light.load(os.path.join(DATA_DIR, "objects", "cbox", "emitter.obj"))
+    xf = np.eye(4); xf[:3, 3] = [50, 190, 0]
+    light._to_world_raw = torch.as_tensor(xf, dtype=torch.float32, device=light._to_world_raw.device)
+    light.use_face_normals = True
+    sc.add_mesh(light, black, [20.0, 20.0, 8.0])
+    for name in ("floor", "ceil", "wall_back", "wall_left", "wall_right"):
+        m = psdr_cuda.Mesh(); m.load(os.path.join(DATA_DIR, "objects", "cbox", name + ".obj")); m.use_face_normals = True
+        sc.add_mesh(m, white, None)
+    sc.finalize(); sc.configure()
+    return sc.tables(0)
+
+
+def test_inline_primitives_behind_65535_triangles_fall_back_to_one_tree(tmp_path):
+    """an inline primitive packs two GLOBAL triangle ids into 16 bits each.  A room whose large mesh is listed first (as in
+    cbox_bunny.xml) with >= 65535 triangles ahead of the walls must not take the two-level tree; a smaller one does, and both return the
+    oracle's hits and images."""
+    for cells, two_level in ((100, True), (182, False)):
+        tb = _room_with_field(tmp_path, cells)
+        T = tb["tri_info"].shape[0]
+        assert (T > 0xffff + 12) == (not two_level)
+        g = GpuScene(tb)
+        info = scene_info(g)
+        assert (info["n_blas"] > 0) == two_level, info
+        o, d = camera_rays(tb, 100_000, seed=11)
+        shape, tri, u, v = g.trace(o, d)
+        _, otri, ou, ov = oracle.trace(tb, o[:30000], d[:30000])
+        same = otri == tri[:30000]
+        assert same.mean() > 0.999, same.mean()
+        walls = tri >= T - 12
+        assert walls.sum() > 5000                                                  # the walls (ids behind the field) are hit and reported with THEIR ids
+        tm = tb["tri_mesh"].cpu().numpy() & ~0x40000000
+        assert np.array_equal(shape[tri >= 0], tm[tri[tri >= 0]])
+        rays = bounce_rays(tb, tri, u, v, 12)
+        _, tri2, _, _ = g.trace(*rays)
+        _, otri2, _, _ = oracle.trace(tb, rays[0][:20000], rays[1][:20000])
+        assert (otri2 == tri2[:20000]).mean() > 0.999
+        opt = _abi.make_opts(integrator=_abi.INTEGRATOR_PATH, max_depth=3, spp=4)
+        assert rel_l2(g.render_c(opt), oracle.render(tb, opt)) < 1e-4
+        g.close()
