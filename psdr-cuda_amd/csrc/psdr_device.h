@@ -38,6 +38,7 @@ struct SceneView {
     // n_lbtris leaf triangles and the first n_ltri TriangleInfo rows.
     int32_t n_lnodes, n_lbtris, n_ltri;
     int32_t off_lnodes, off_lbtris, off_ltri;
+    int32_t off_lprim;     // (ids, codeA, codeB, 0) of every kernel-argument primitive, 16 bytes each (resolve_tiny_hit)
     // Tiny scenes (<= kTinyTris triangles, e.g. the 12-triangle Cornell box): the leaf triangles travel IN THE
     // KERNEL ARGUMENTS and closest_hit tests all of them in order -- wave-uniform s_load from the kernarg
     // segment into SGPRs, no tree, no per-lane node fetches, no stack traffic, no divergence between lanes.
@@ -50,10 +51,18 @@ struct SceneView {
     // enters a box walks that tree.  In a room most rays never do (cbox_bunny: 7-14 % of the bounce rays).
     int32_t n_blas;
     float4 blas_lo[kMaxBlas], blas_hi[kMaxBlas];      // lo.w = root of the tree (encoded like a child)
+    // kSceneTiny launches: EVERY table a path vertex reads is staged in LDS (byte offsets into the dynamic LDS block; same layouts as the
+    // caller's tables) -- the per-vertex chain tri_mesh -> mesh_bsdf -> bsdf_rec -> texels and the emitter lookups are LDS reads (~64 clk)
+    // instead of dependent global loads (~300-500 clk each).  lt_tex < 0: the texel pool is too large and stays in global memory.
+    int32_t lt_trimesh, lt_meshbsdf, lt_meshemitter, lt_bsdf, lt_emf, lt_emi, lt_fcmf, lt_fpmf, lt_uv, lt_tex, lt_ecmf, lt_epmf;
+    int32_t lt_nfaces, lt_end;                          // entries of face_cmf / face_pmf staged; end of the block (bytes)
 };
 
 #if defined(__HIP_DEVICE_COMPILE__)
 extern __shared__ __attribute__((aligned(16))) unsigned char psdr_dyn_lds[];
+#define PSDR_LDS_TABLE(T, off) reinterpret_cast<const T *>(psdr_dyn_lds + (off))
+#else
+#define PSDR_LDS_TABLE(T, off) static_cast<const T *>(nullptr)
 #endif
 
 // K sets of forward-mode tangent tables (struct of K pointer groups).  FLAGS: compile-time properties of
@@ -66,14 +75,39 @@ extern __shared__ __attribute__((aligned(16))) unsigned char psdr_dyn_lds[];
 //   kSceneForest the scene has a two-level tree (SceneView::n_blas > 0): the box loop, the per-tree walks and the
 //                class-binned streams exist only in these instances (with a run-time switch instead the Cornell-box
 //                kernels spilled twice as many SGPRs: C2 renderC 1.41 -> 1.80 ms)
-constexpr int kSceneEnv = 1, kSceneRough = 2, kSceneAll = 3, kSceneForest = 4;
+//   kSceneTiny   ALL primitives of the scene travel in the kernel arguments (SceneView::n_tiny > 0, no tree at all -- the 12-triangle
+//                Cornell box of C1 / C2): the instance carries no tree walk, no traversal stack and no global-memory fallback of the
+//                LDS-staged TriangleInfo rows -- fewer registers (one more wave per SIMD), a third of the code
+constexpr int kSceneEnv = 1, kSceneRough = 2, kSceneAll = 3, kSceneForest = 4, kSceneTiny = 8;
+// closest_hit's FOREST argument of a flag set: 2 = kernel-argument primitives only, 1 = two-level, 0 = one tree (or a tiny scene served by a general instance)
+template <int FLAGS> constexpr int tree_mode() { return (FLAGS & kSceneTiny) ? 2 : ((FLAGS & kSceneForest) ? 1 : 0); }
 template <int K, int FLAGS = kSceneRough> struct TangentView {
-    static constexpr int flags = FLAGS;
-    static constexpr bool has_env = (FLAGS & kSceneEnv) != 0, has_rough = (FLAGS & kSceneRough) != 0, forest = (FLAGS & kSceneForest) != 0;
+    static constexpr int flags = FLAGS, k = K;
+    static constexpr bool has_env = (FLAGS & kSceneEnv) != 0, has_rough = (FLAGS & kSceneRough) != 0, forest = (FLAGS & kSceneForest) != 0, tiny = (FLAGS & kSceneTiny) != 0;
     psdr_tangents t[K > 0 ? K : 1];
 };
 
 struct Hit { int tri; float u, v, t; };
+
+// ------------------------------------------------------------------------ small-table access
+// The tables a path vertex looks up besides its TriangleInfo row.  Instances compiled for kSceneTiny read the LDS copies (the launch
+// staged all of them, make_ctx / setup_lds); every other instance reads the caller's tables in global memory.  FL = scene flag set.
+template <int FL> struct Tab {
+    static constexpr bool lds = (FL & kSceneTiny) != 0;
+    static PSDR_HD int tri_mesh(const SceneView &sc, int tri) { return lds ? PSDR_LDS_TABLE(int32_t, sc.lt_trimesh)[tri] : sc.d.tri_mesh[tri]; }
+    static PSDR_HD int mesh_bsdf(const SceneView &sc, int mesh) { return lds ? PSDR_LDS_TABLE(int32_t, sc.lt_meshbsdf)[mesh] : sc.d.mesh_bsdf[mesh]; }
+    static PSDR_HD int mesh_emitter(const SceneView &sc, int mesh) { return lds ? PSDR_LDS_TABLE(int32_t, sc.lt_meshemitter)[mesh] : sc.d.mesh_emitter[mesh]; }
+    static PSDR_HD const int32_t *bsdf_rec(const SceneView &sc, int id) {
+        return (lds ? PSDR_LDS_TABLE(int32_t, sc.lt_bsdf) : sc.d.bsdf_rec) + (size_t) (id < 0 ? 0 : id) * PSDR_BSDF_STRIDE;
+    }
+    static PSDR_HD const float *emitter_f(const SceneView &sc, int e) { return (lds ? PSDR_LDS_TABLE(float, sc.lt_emf) : sc.d.emitter_f) + (size_t) e * PSDR_EMITTER_F_STRIDE; }
+    static PSDR_HD const int32_t *emitter_i(const SceneView &sc, int e) { return (lds ? PSDR_LDS_TABLE(int32_t, sc.lt_emi) : sc.d.emitter_i) + (size_t) e * PSDR_EMITTER_I_STRIDE; }
+    static PSDR_HD const float *face_cmf(const SceneView &sc) { return lds ? PSDR_LDS_TABLE(float, sc.lt_fcmf) : sc.d.face_cmf; }
+    static PSDR_HD const float *face_pmf(const SceneView &sc) { return lds ? PSDR_LDS_TABLE(float, sc.lt_fpmf) : sc.d.face_pmf; }
+    static PSDR_HD const float *emitter_cmf(const SceneView &sc) { return lds ? PSDR_LDS_TABLE(float, sc.lt_ecmf) : sc.d.emitter_cmf; }
+    static PSDR_HD const float *emitter_pmf(const SceneView &sc) { return lds ? PSDR_LDS_TABLE(float, sc.lt_epmf) : sc.d.emitter_pmf; }
+    static PSDR_HD const float *tri_uv(const SceneView &sc, int tri) { return (lds ? PSDR_LDS_TABLE(float, sc.lt_uv) : sc.d.tri_uv) + (size_t) tri * PSDR_TRIUV_STRIDE; }
+};
 
 // Traversal stack: LDS on the device (one column per lane: conflict-free, no scratch traffic),
 // a plain array on the host (tests).
@@ -146,10 +180,14 @@ PSDR_HD void leaf_triangle_test(const float4 &a, const float4 &b, const float4 &
 // Replaces __raygen__/__closesthit__/__miss__ (cuda/psdr_cuda.cu:9-45): closest hit with
 // t in [RayEpsilon, tmax], both faces; (u,v) = barycentric weights of vertex 1 and 2.
 // One primitive of a tiny scene (psdr_bvh_build.h pack_tiny_prims): a triangle or a parallelogram of two triangles.
-// best.(u, v) hold the plane coordinates (s, t) of the primitive; (ids, code) remember the winning primitive's triangle
-// ids and barycentric map; resolve_tiny_hit turns them into (triangle, u, v) once per ray.
+// best.(u, v) hold the plane coordinates (s, t) of the primitive and best_i the index of the winning primitive; resolve_tiny_hit turns
+// them into (triangle, u, v) once per ray.  BRANCH-FREE on purpose: a triangle is the parallelogram test with the bound s + t <= 1
+// instead of <= 2 (a wave-uniform scalar select) and the hit update is four v_cndmask -- with `if (hit)` around it the ids / codes
+// were re-fetched by scalar loads INSIDE the divergent branch and every primitive waited for its own s_load (three basic blocks per
+// primitive: nothing could be scheduled across them); now the unrolled loop body is one block and the scalar loads of the following
+// primitives are in flight while one is tested.
 template <bool IGN = false>
-PSDR_HD void tiny_prim_test(const float4 &a, const float4 &b, const float4 &c, const Vec3f &o, const Vec3f &d, Hit &best, int &ids, int &codeA, int &codeB,
+PSDR_HD void tiny_prim_test(const float4 &a, const float4 &b, const float4 &c, int i, const Vec3f &o, const Vec3f &d, Hit &best, int &best_i,
                             int ig0 = -1, int ig1 = -1) {
     const Vec3f e1{b.x, b.y, b.z}, e2{c.x, c.y, c.z};
     const Vec3f h = cross(d, e2);
@@ -162,13 +200,21 @@ PSDR_HD void tiny_prim_test(const float4 &a, const float4 &b, const float4 &c, c
     const float t = f * dot(e2, q);
     const int id2 = __float_as_int_hd(a.w);                        // wave-uniform (kernel argument)
     const bool quad = ((uint32_t) id2 >> 16) != 0xffffu;
-    const bool inside = quad ? (u <= 1.f && v <= 1.f) : (u + v <= 1.f);
-    bool hit = u >= 0.f && v >= 0.f && inside && t >= kRayEpsilon && t < best.t;
-    if (IGN) { const int id = (quad && u + v > 1.f) ? (int) ((uint32_t) id2 >> 16) : (id2 & 0xffff); hit = hit && id != ig0 && id != ig1; }
-    if (hit) { best.t = t; best.u = u; best.v = v; ids = id2; codeA = __float_as_int_hd(b.w); codeB = __float_as_int_hd(c.w); }
+    const float lim = quad ? 2.f : 1.f;                            // u <= 1 and v <= 1 are implied for a triangle (u, v >= 0, u + v <= 1)
+    bool hit = (u >= 0.f) & (v >= 0.f) & (u <= 1.f) & (v <= 1.f) & (u + v <= lim) & (t >= kRayEpsilon) & (t < best.t);
+    if (IGN) { const int id = (quad && u + v > 1.f) ? (int) ((uint32_t) id2 >> 16) : (id2 & 0xffff); hit = hit & (id != ig0) & (id != ig1); }
+    best.t = hit ? t : best.t; best.u = hit ? u : best.u; best.v = hit ? v : best.v; best_i = hit ? i : best_i;
 }
-PSDR_HD void resolve_tiny_hit(Hit &best, int ids, int codeA, int codeB) {
-    if (ids == -1) return;                                          // no hit
+// (ids, codeA, codeB) of primitive i: from the LDS copy setup_lds made of the kernel-argument words (a per-lane index into the kernel
+// arguments would be a global load), on the host from the SceneView itself.
+PSDR_HD void resolve_tiny_hit(const SceneView &sc, Hit &best, int best_i) {
+    if (best_i < 0) return;                                         // no hit
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int32_t *m = PSDR_LDS_TABLE(int32_t, sc.off_lprim) + best_i * 4;
+    const int ids = m[0], codeA = m[1], codeB = m[2];
+#else
+    const int ids = __float_as_int_hd(sc.tiny[best_i * 3].w), codeA = __float_as_int_hd(sc.tiny[best_i * 3 + 1].w), codeB = __float_as_int_hd(sc.tiny[best_i * 3 + 2].w);
+#endif
     const bool second = ((uint32_t) ids >> 16) != 0xffffu && best.u + best.v > 1.f;
     const int code = second ? codeB : codeA;
     auto k = [&](int i) { return (float) (((code >> (3 * i)) & 7) - 2); };
@@ -233,22 +279,22 @@ PSDR_HD bool blas_box(const SceneView &sc, int k, const Vec3f &o, const Vec3f &i
     return slab(lo, hi, o, inv, tmax, t_entry);
 }
 
-// FOREST: 1 = the instance serves two-level scenes only, 0 = never (no box loop / per-tree walks in the code), -1 = decided at
-// run time (k_trace, host tests).
+// FOREST: 2 = the instance serves scenes WITHOUT a tree only (kSceneTiny: the walk below is not even compiled), 1 = two-level scenes only,
+// 0 = never two-level (no box loop / per-tree walks in the code), -1 = decided at run time (k_trace, host tests).
 template <bool IGN = false, int FOREST = -1>
 PSDR_HD Hit closest_hit(const SceneView &sc, TraversalStack &st, const Vec3f &o, const Vec3f &d, float tmax, int ig0 = -1, int ig1 = -1) {
     Hit best; best.tri = -1; best.u = best.v = -1.f;
     best.t = (tmax > 0.f && tmax < INFINITY) ? __int_as_float_hd(__float_as_int_hd(tmax) + 1) : tmax;   // accept t <= tmax
     const Vec3f inv{1.f / d.x, 1.f / d.y, 1.f / d.z};
     const bool forest = FOREST < 0 ? sc.n_blas > 0 : FOREST == 1;
-    if (sc.n_tiny > 0 || forest) {
+    if (FOREST == 2 || sc.n_tiny > 0 || forest) {
         // n_tiny PRIMITIVES (triangles, or parallelograms of two triangles: pack_tiny_prims), unrolled by 6 (the six
         // walls of the Cornell box): the scalar loads of the following primitives are in flight while one is tested
-        int ids = -1, codeA = 0, codeB = 0;
+        int best_i = -1;
 #pragma unroll 6
-        for (int i = 0; i < sc.n_tiny; ++i) tiny_prim_test<IGN>(sc.tiny[i * 3], sc.tiny[i * 3 + 1], sc.tiny[i * 3 + 2], o, d, best, ids, codeA, codeB, ig0, ig1);
-        resolve_tiny_hit(best, ids, codeA, codeB);
-        if (!forest) return best;
+        for (int i = 0; i < sc.n_tiny; ++i) tiny_prim_test<IGN>(sc.tiny[i * 3], sc.tiny[i * 3 + 1], sc.tiny[i * 3 + 2], i, o, d, best, best_i, ig0, ig1);
+        resolve_tiny_hit(sc, best, best_i);
+        if (FOREST == 2 || !forest) return best;
         // two-level tree: the trees whose box the segment [0, t_best] enters, NEAREST box first (a hit in a near object
         // prunes the far ones); every round re-tests the remaining boxes against the current t_best -- wave-uniform
         // loops over SGPR operands, 16 VALU instructions per box
@@ -314,7 +360,7 @@ template <class TVT> PSDR_HD TriRow<float> load_tri_f(const SceneView &sc, const
     TriRow<float> t;
     float4 r[6];
 #if defined(__HIP_DEVICE_COMPILE__)
-    if (id < sc.n_ltri) {
+    if (TVT::tiny || id < sc.n_ltri) {          // a kSceneTiny launch stages every row (make_ctx checks it)
         const float4 *q = reinterpret_cast<const float4 *>(psdr_dyn_lds + sc.off_ltri) + (size_t) id * 6;
 #pragma unroll
         for (int i = 0; i < 6; ++i) r[i] = q[i];
@@ -379,12 +425,12 @@ template <class R, class TVT> PSDR_HD Its<R> intersect(const SceneView &sc, cons
     its.valid = false; its.tri = its.mesh = -1; its.J = R(1.f); its.t = R(INFINITY);
     if (!active) return its;
     nrays++;
-    constexpr int F = TVT::forest ? 1 : 0;
+    constexpr int F = tree_mode<TVT::flags>();
     const Hit h = (ig0 >= 0 || ig1 >= 0) ? closest_hit<true, F>(sc, st, val(ray.o), val(ray.d), INFINITY, ig0, ig1)
                                          : closest_hit<false, F>(sc, st, val(ray.o), val(ray.d), INFINITY);
     if (h.tri < 0) return its;
     its.valid = true; its.tri = h.tri; its.hu = h.u; its.hv = h.v;
-    const int tm = sc.d.tri_mesh[h.tri];
+    const int tm = Tab<TVT::flags>::tri_mesh(sc, h.tri);
     its.mesh = tm & ~PSDR_TRI_FACE_NORMALS;
     const TriRow<R> T = load_tri<R>(sc, tv, h.tri);
     its.n = T.fn;
@@ -414,7 +460,7 @@ template <class R, class TVT> PSDR_HD Its<R> intersect(const SceneView &sc, cons
         its.wi = its.sh.to_local(-ray.d);
     }
     if (sc.d.tri_uv) {
-        const float *q = sc.d.tri_uv + (size_t) h.tri * PSDR_TRIUV_STRIDE;
+        const float *q = Tab<TVT::flags>::tri_uv(sc, h.tri);
         its.uvx = (q[2] - q[0]) * bu + ((q[4] - q[0]) * bv + q[0]);
         its.uvy = (q[3] - q[1]) * bu + ((q[5] - q[1]) * bv + q[1]);
     } else { its.uvx = R(0.f); its.uvy = R(0.f); }
@@ -426,7 +472,7 @@ template <class R, class TVT> PSDR_HD Its<R> intersect(const SceneView &sc, cons
 template <class TVT> PSDR_HD Its<float> path_vertex_from_record(const SceneView &sc, const TVT &tv, int tri, float hu, float hv, const Vec3f &dir) {
     Its<float> its;
     its.valid = true; its.tri = tri; its.hu = hu; its.hv = hv; its.J = 1.f; its.t = 0.f;
-    const int tm = sc.d.tri_mesh[tri];
+    const int tm = Tab<TVT::flags>::tri_mesh(sc, tri);
     its.mesh = tm & ~PSDR_TRI_FACE_NORMALS;
     const TriRow<float> T = load_tri_f(sc, tv, tri);
     its.n = T.fn;
@@ -435,17 +481,17 @@ template <class TVT> PSDR_HD Its<float> path_vertex_from_record(const SceneView 
     its.sh = Frame<float>(sh_n);
     its.wi = its.sh.to_local(-dir);
     if (sc.d.tri_uv) {
-        const float *q = sc.d.tri_uv + (size_t) tri * PSDR_TRIUV_STRIDE;
+        const float *q = Tab<TVT::flags>::tri_uv(sc, tri);
         its.uvx = (q[2] - q[0]) * hu + ((q[4] - q[0]) * hv + q[0]);
         its.uvy = (q[3] - q[1]) * hu + ((q[5] - q[1]) * hv + q[1]);
     } else { its.uvx = 0.f; its.uvy = 0.f; }
     return its;
 }
 
-template <class R> PSDR_HD int emitter_of(const SceneView &sc, const Its<R> &its) { return its.valid ? sc.d.mesh_emitter[its.mesh] : -1; }
+template <class R, class TVT> PSDR_HD int emitter_of(const SceneView &sc, const TVT &, const Its<R> &its) { return its.valid ? Tab<TVT::flags>::mesh_emitter(sc, its.mesh) : -1; }
 
 template <class M, class TVT> PSDR_HD Vec3<M> radiance(const SceneView &sc, const TVT &tv, int e) {
-    const float *f = sc.d.emitter_f + (size_t) e * PSDR_EMITTER_F_STRIDE;
+    const float *f = Tab<TVT::flags>::emitter_f(sc, e);
     Vec3<M> r = {M(f[0]), M(f[1]), M(f[2])};
     if constexpr (is_ad<M>()) {
 #pragma unroll
@@ -459,14 +505,27 @@ template <class M, class TVT> PSDR_HD Vec3<M> radiance(const SceneView &sc, cons
 // ------------------------------------------------------------------------------ BSDF
 // Bitmap<c>::eval (src/core/bitmap.cpp:41-89); 3-channel textures are stored interleaved RGB.
 // U = type of the texture coordinates (geometry), M = type of the texels.
-template <class M, int C, class U, class TVT>
-PSDR_HD void bitmap_eval(const SceneView &sc, const TVT &tv, const int32_t *slot, U u, U v, M *out, bool flip_v = true) {
+// One texel (value + tangents).  LDS = true: from the staged copy of the pool, [value pool | K tangent pools] (kSceneTiny launches
+// whose pool is small, SceneView::lt_tex >= 0; the kernel stages the tangent pools itself: stage_tangent_texels).
+template <class M, bool LDS, class TVT> PSDR_HD M texel(const SceneView &sc, const TVT &tv, size_t i) {
+    if constexpr (!LDS) return ldf<M>(sc.d.texels, tv, &psdr_tangents::d_texels, i);
+    else {
+        const float *lx = PSDR_LDS_TABLE(float, sc.lt_tex);
+        if constexpr (!is_ad<M>()) return lx[i];
+        else {
+            M r; r.v = lx[i];
+#pragma unroll
+            for (int k = 0; k < ad_traits<M>::K; ++k) r.d[k] = lx[(size_t) (k + 1) * sc.d.num_texels + i];
+            return r;
+        }
+    }
+}
+template <class M, int C, bool LDS, class U, class TVT>
+PSDR_HD void bitmap_eval_from(const SceneView &sc, const TVT &tv, const int32_t *slot, U u, U v, M *out, bool flip_v) {
     const int off = slot[0], w = slot[1], h = slot[2];
-    const float *tx = sc.d.texels;
-    constexpr auto m = &psdr_tangents::d_texels;
     if (w == 1 && h == 1) {
 #pragma unroll
-        for (int c = 0; c < C; ++c) out[c] = ldf<M>(tx, tv, m, off + c);
+        for (int c = 0; c < C; ++c) out[c] = texel<M, LDS>(sc, tv, off + c);
         return;
     }
     if (flip_v) v = -v;
@@ -479,10 +538,17 @@ PSDR_HD void bitmap_eval(const SceneView &sc, const TVT &tv, const int32_t *slot
     const size_t idx = (size_t) py * w + px;
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-        const M v00 = ldf<M>(tx, tv, m, off + idx * C + c), v10 = ldf<M>(tx, tv, m, off + (idx + 1) * C + c);
-        const M v01 = ldf<M>(tx, tv, m, off + (idx + w) * C + c), v11 = ldf<M>(tx, tv, m, off + (idx + w + 1) * C + c);
+        const M v00 = texel<M, LDS>(sc, tv, off + idx * C + c), v10 = texel<M, LDS>(sc, tv, off + (idx + 1) * C + c);
+        const M v01 = texel<M, LDS>(sc, tv, off + (idx + w) * C + c), v11 = texel<M, LDS>(sc, tv, off + (idx + w + 1) * C + c);
         out[c] = (v00 * w0x + v10 * w1x) * w0y + (v01 * w0x + v11 * w1x) * w1y;
     }
+}
+template <class M, int C, class U, class TVT>
+PSDR_HD void bitmap_eval(const SceneView &sc, const TVT &tv, const int32_t *slot, U u, U v, M *out, bool flip_v = true) {
+    if constexpr (TVT::tiny) {
+        if (sc.lt_tex >= 0) { bitmap_eval_from<M, C, true>(sc, tv, slot, u, v, out, flip_v); return; }
+    }
+    bitmap_eval_from<M, C, false>(sc, tv, slot, u, v, out, flip_v);
 }
 
 // ------------------------------------------------------------------- environment map
@@ -507,7 +573,7 @@ template <class M, class G, class TVT> PSDR_HD Vec3<M> env_eval_direction(const 
 }
 // Intersection::Le -> AreaLight::eval (src/emitter/area.cpp:20-29) / EnvironmentMap::eval (envmap.cpp:29-38)
 template <class M, class G, class TVT> PSDR_HD Vec3<M> Le(const SceneView &sc, const TVT &tv, const Its<G> &its, bool active) {
-    const int e = active ? emitter_of(sc, its) : -1;
+    const int e = active ? emitter_of(sc, tv, its) : -1;
     if (e < 0) return zero3<M>();
     if (TVT::has_env && e == sc.d.env_emitter) return env_eval_direction<M>(sc, tv, -its.sh.to_world(its.wi));
     if (!(val(its.wi.z) > 0.f)) return zero3<M>();
@@ -576,6 +642,7 @@ template <class G, class M> struct Bsdf {
     const int32_t *rec;
     const MatCache<M> *mc = nullptr;       // set: tex1 / tex3 answer from it
     PSDR_HD Bsdf(const SceneView &sc, int id) : rec(sc.d.bsdf_rec + (size_t) (id < 0 ? 0 : id) * PSDR_BSDF_STRIDE) {}
+    template <class TVT> PSDR_HD Bsdf(const SceneView &sc, const TVT &, int id) : rec(Tab<TVT::flags>::bsdf_rec(sc, id)) {}
     template <class TVT> PSDR_HD MatCache<M> fetch(const SceneView &sc, const TVT &tv, const Its<G> &its) const {
         MatCache<M> c;
         c.refl = tex3(sc, tv, PSDR_SLOT_REFLECTANCE, its);
@@ -718,16 +785,16 @@ template <class R, class TVT>
 PSDR_HD PosSample<R> sample_emitter_position(const SceneView &sc, const TVT &tv, const Vec3f &ref_p, float s0, float s1, bool with_J) {
     PosSample<R> ps;
     int e = 0; float epdf = 1.f;
-    if (sc.d.num_emitters > 1) e = sample_reuse(sc.d.emitter_cmf, sc.d.emitter_pmf, sc.d.emitter_sum, sc.d.num_emitters, s1, epdf);
+    if (sc.d.num_emitters > 1) e = sample_reuse(Tab<TVT::flags>::emitter_cmf(sc), Tab<TVT::flags>::emitter_pmf(sc), sc.d.emitter_sum, sc.d.num_emitters, s1, epdf);
     if (TVT::has_env && e == sc.d.env_emitter) {
         ps = env_sample_position<R>(sc, ref_p, s0, s1);
         ps.pdf *= epdf;
         return ps;
     }
-    const float *ef = sc.d.emitter_f + (size_t) e * PSDR_EMITTER_F_STRIDE;
-    const int32_t *ei = sc.d.emitter_i + (size_t) e * PSDR_EMITTER_I_STRIDE;
+    const float *ef = Tab<TVT::flags>::emitter_f(sc, e);
+    const int32_t *ei = Tab<TVT::flags>::emitter_i(sc, e);
     float fp;
-    const int f = sample_reuse(sc.d.face_cmf + ei[3], sc.d.face_pmf + ei[3], ef[5], ei[2], s0, fp);
+    const int f = sample_reuse(Tab<TVT::flags>::face_cmf(sc) + ei[3], Tab<TVT::flags>::face_pmf(sc) + ei[3], ef[5], ei[2], s0, fp);
     const float t = sqrtf(fmaxf(1.f - s0, 0.f));           // warp::square_to_uniform_triangle, warp.h:76-80
     const TriRow<R> T = load_tri<R>(sc, tv, ei[1] + f);
     ps.J = R(1.f);
@@ -739,11 +806,11 @@ PSDR_HD PosSample<R> sample_emitter_position(const SceneView &sc, const TVT &tv,
     return ps;
 }
 // Scene::emitter_position_pdf (scene.cpp:451-453) -> area.cpp:60-62 -> mesh.cpp:333-342, or envmap.cpp:124-143
-template <class R, class TVT> PSDR_HD float emitter_position_pdf(const SceneView &sc, const TVT &, const Vec3f &ref_p, const Its<R> &its) {
-    const int e = emitter_of(sc, its);
+template <class R, class TVT> PSDR_HD float emitter_position_pdf(const SceneView &sc, const TVT &tv, const Vec3f &ref_p, const Its<R> &its) {
+    const int e = emitter_of(sc, tv, its);
     if (e < 0) return 0.f;
     if (TVT::has_env && e == sc.d.env_emitter) return env_position_pdf(sc, ref_p, val(its.p), val(its.n));
-    const float *ef = sc.d.emitter_f + (size_t) e * PSDR_EMITTER_F_STRIDE;
+    const float *ef = Tab<TVT::flags>::emitter_f(sc, e);
     return ef[3] * ef[4];
 }
 
@@ -803,9 +870,9 @@ PSDR_HD Vec3<M> direct_step(const SceneView &sc, const TVT &tv, TraversalStack &
     constexpr bool ad = is_ad<M>();
     constexpr HitForm form = is_ad<G>() ? kPathSpace : kDetached;
     Vec3<M> result = zero3<M>();
-    int bsdf_id = active ? sc.d.mesh_bsdf[its.mesh] : 0;
+    int bsdf_id = active ? Tab<TVT::flags>::mesh_bsdf(sc, its.mesh) : 0;
     if (bsdf_id < 0) { active = false; bsdf_id = 0; }      // bounding mesh of the environment map, direct.cpp:54-57
-    const Bsdf<G, M> bsdf(sc, bsdf_id);
+    const Bsdf<G, M> bsdf(sc, tv, bsdf_id);
     for (int i = 0; i < nB; ++i) {
         const float s[3] = {rng.next(), rng.next(), rng.next()};
         if (!active) continue;
@@ -815,7 +882,7 @@ PSDR_HD Vec3<M> direct_step(const SceneView &sc, const TVT &tv, TraversalStack &
         const RayT<G> ray1{its.p, lift<G>(dir1)};
         const Its<G> its1 = intersect<G>(sc, tv, st, ray1, a1, form, nrays);
         const bool a_hit = a1 && its1.valid;
-        a1 = a_hit && emitter_of(sc, its1) >= 0;
+        a1 = a_hit && emitter_of(sc, tv, its1) >= 0;
         Vec3<M> bsdf_val = zero3<M>(); M pdf0(0.f);
         if (a_hit) {
             if constexpr (ad) {
@@ -847,7 +914,7 @@ PSDR_HD Vec3<M> direct_step(const SceneView &sc, const TVT &tv, TraversalStack &
         wo = wo / dist;
         const RayT<G> ray1{its.p, wo};
         const Its<G> its1 = intersect<G>(sc, tv, st, ray1, ps.valid, form, nrays);
-        if (!(its1.valid && val(its1.t) > val(dist) - kShadowEpsilon && emitter_of(sc, its1) >= 0)) continue;
+        if (!(its1.valid && val(its1.t) > val(dist) - kShadowEpsilon && emitter_of(sc, tv, its1) >= 0)) continue;
         const G Gv = abs_(dot(its1.n, -wo)) / d2;
         const Vec3<G> wl = its.sh.to_local(wo);
         const Vec3<M> bsdf_val = bsdf.eval(sc, tv, its, wl, true) * to_m<M>(Gv * ps.J / ps.pdf);
@@ -993,7 +1060,7 @@ PSDR_HD bool primary_edge_point_visible(const SceneView &sc, const TVT &tv0, Tra
     const RayT<float> ray = primary_ray<float>(sc, tv0, px, py);
     const float tmax = depth / dot(ray.d, cd) - 100.f * kShadowEpsilon;
     nrays++;
-    return closest_hit<true, TVT::forest ? 1 : 0>(sc, st, ray.o, ray.d, tmax, __float_as_int_hd(z[2]), __float_as_int_hd(z[3])).tri < 0;
+    return closest_hit<true, tree_mode<TVT::flags>()>(sc, st, ray.o, ray.d, tmax, __float_as_int_hd(z[2]), __float_as_int_hd(z[3])).tri < 0;
 }
 
 // One primary-edge slot: Integrator::render_primary_edges (integrator.cpp:98-119) +
@@ -1179,8 +1246,8 @@ PSDR_HD int secondary_edge_sample(const SceneView &sc, const TVT &tv, TraversalS
     if (!(sinphi > kEpsilon && sinphi2 > kEpsilon)) return -1;
     const Vec3f d0 = -val(camera_ray.d);
     const Vec3f d0_local = its1c.sh.to_local(d0);
-    if (sc.d.mesh_bsdf[its1c.mesh] < 0) return -1;          // bounding mesh: null BSDF evaluates to zero
-    const Bsdf<float, float> bsdf(sc, sc.d.mesh_bsdf[its1c.mesh]);
+    if (Tab<TVT::flags>::mesh_bsdf(sc, its1c.mesh) < 0) return -1;          // bounding mesh: null BSDF evaluates to zero
+    const Bsdf<float, float> bsdf(sc, tv0, Tab<TVT::flags>::mesh_bsdf(sc, its1c.mesh));
     Vec3f bsdf_val = bsdf.eval(sc, tv0, its1c, d0_local, true);
     const float correction = fabsf((its1c.wi.z * dot(d0, its1c.n)) / (d0_local.z * dot(dir, its1c.n)));
     bsdf_val = bsdf_val * correction;

@@ -144,15 +144,36 @@ int launch_blocks(const psdr_scene_s *h, long long n, int per_cu) {
 // LDS plan of one launch: stacks sized by the tree depth, the rest of a 40 KB budget (4 workgroups
 // per CU) filled with the top of the BVH, then the leaf triangles, then the TriangleInfo rows.
 constexpr int kLdsBudget = 40 * 1024;
+static bool tiny_only(const psdr_scene_s *h) { return h->n_tiny > 0 && h->n_blas == 0; }
+// entries of face_cmf / face_pmf the emitters reference (host copy of emitter_i, psdr_bvh_build)
+static int emitter_faces(const psdr_scene_s *h) {
+    int n = 0;
+    for (int e = 0; e < h->desc.num_emitters && (size_t) (e + 1) * PSDR_EMITTER_I_STRIDE <= h->emitter_i.size(); ++e)
+        n = std::max(n, h->emitter_i[(size_t) e * PSDR_EMITTER_I_STRIDE + 3] + h->emitter_i[(size_t) e * PSDR_EMITTER_I_STRIDE + 2]);
+    return n;
+}
+// A scene without a tree whose small tables fit the LDS block of the kSceneTiny kernel instances (a few KB): every launch on it stages
+// them (plan_lds) and variant_of picks those instances.  PSDR_TINY_VARIANTS=0: the general instances (A/B, tools).
+constexpr int kLdsTexels = 256, kLdsTexelTangents = 3;
+static bool tiny_tables_ok(const psdr_scene_s *h) {
+    static const bool enabled = !(std::getenv("PSDR_TINY_VARIANTS") && std::atoi(std::getenv("PSDR_TINY_VARIANTS")) == 0);
+    const psdr_scene_desc &d = h->desc;
+    return enabled && tiny_only(h) && d.env_emitter < 0 && d.num_meshes <= 64 && d.num_bsdfs <= 32 && d.num_emitters >= 0 && d.num_emitters <= 8 &&
+           (d.num_emitters == 0 || (d.face_cmf && d.face_pmf)) && emitter_faces(h) <= 64;
+}
+// traversal-stack entries per lane: none when no launch on this scene ever walks a tree
+static int stack_entries_of(const psdr_scene_s *h) { return tiny_only(h) ? 0 : std::min(kBvhStack, h->bvh_depth + 2); }
 int plan_lds(const psdr_scene_s *h, LaunchCtx &cx, int reserved) {
     // the plain diffuse variant runs renderC at 5 workgroups per CU: 28 KB each (C4 PathTracer(3) 40.0 -> 37.6 ms,
     // C3 3.26 -> 3.15 ms; 32 KB is already one workgroup less)
     static const int forced = std::getenv("PSDR_LDS_BUDGET") ? std::atoi(std::getenv("PSDR_LDS_BUDGET")) : 0;
     const bool lean = !h->has_rough && h->desc.env_emitter < 0;
     const int budget = forced ? forced : (lean ? 28 * 1024 : kLdsBudget);
-    const int stack_entries = std::min(kBvhStack, h->bvh_depth + 2);
-    const int stack_bytes = stack_entries * kBlock * 4;
+    const int stack_bytes = stack_entries_of(h) * kBlock * 4;
     int room = std::max(0, budget - reserved - stack_bytes);
+    // a scene without a tree (all primitives in the kernel arguments) ALWAYS stages its <= 16 TriangleInfo rows (1.5 KB): the kSceneTiny
+    // kernel instances have no global-memory fallback for them (psdr_device.h load_tri_f)
+    if (tiny_only(h)) room = std::max(room, h->num_nodes * 64 + h->num_btris * 48 + h->desc.num_tris * 96);
     SceneView &sc = cx.sc;
     int off = 0;
     sc.n_lnodes = std::min(h->num_nodes, room / 64); sc.off_lnodes = off; off += sc.n_lnodes * 64; room -= sc.n_lnodes * 64;
@@ -160,10 +181,27 @@ int plan_lds(const psdr_scene_s *h, LaunchCtx &cx, int reserved) {
     sc.off_lbtris = off; off += sc.n_lbtris * 48; room -= sc.n_lbtris * 48;
     sc.n_ltri = (sc.n_lbtris == h->num_btris) ? std::min(h->desc.num_tris, room / 96) : 0;
     sc.off_ltri = off; off += sc.n_ltri * 96;
+    sc.off_lprim = off; off += h->n_tiny * 16;          // ids / barycentric codes of the kernel-argument primitives (resolve_tiny_hit)
+    // the small tables of a scene without a tree (psdr_device.h Tab<FL>, staged by setup_lds): 16-byte aligned blocks
+    sc.lt_trimesh = sc.lt_meshbsdf = sc.lt_meshemitter = sc.lt_bsdf = sc.lt_emf = sc.lt_emi = sc.lt_fcmf = sc.lt_fpmf = sc.lt_uv = sc.lt_tex = sc.lt_ecmf = sc.lt_epmf = -1;
+    sc.lt_nfaces = 0;
+    if (tiny_tables_ok(h)) {
+        auto take = [&](int words) { const int o = off; off += (words * 4 + 15) / 16 * 16; return o; };
+        const psdr_scene_desc &d = h->desc;
+        sc.lt_nfaces = emitter_faces(h);
+        sc.lt_trimesh = take(d.num_tris); sc.lt_meshbsdf = take(d.num_meshes); sc.lt_meshemitter = take(d.num_meshes);
+        sc.lt_bsdf = take(std::max(d.num_bsdfs, 1) * PSDR_BSDF_STRIDE);
+        sc.lt_emf = take(d.num_emitters * PSDR_EMITTER_F_STRIDE); sc.lt_emi = take(d.num_emitters * PSDR_EMITTER_I_STRIDE);
+        sc.lt_fcmf = take(sc.lt_nfaces); sc.lt_fpmf = take(sc.lt_nfaces);
+        if (d.num_emitters > 1 && d.emitter_cmf && d.emitter_pmf) { sc.lt_ecmf = take(d.num_emitters); sc.lt_epmf = take(d.num_emitters); }
+        if (d.tri_uv) sc.lt_uv = take(d.num_tris * PSDR_TRIUV_STRIDE);
+        if (d.num_texels > 0 && d.num_texels <= kLdsTexels) sc.lt_tex = take(d.num_texels * (1 + kLdsTexelTangents));      // value pool + up to 3 tangent pools (forward mode)
+    }
+    sc.lt_end = off;
     cx.off_stack = off;
     return off + stack_bytes;
 }
-int lds_bytes(const LaunchCtx &cx, const psdr_scene_s *h) { return cx.off_stack + std::min(kBvhStack, h->bvh_depth + 2) * kBlock * 4; }
+int lds_bytes(const LaunchCtx &cx, const psdr_scene_s *h) { return cx.off_stack + stack_entries_of(h) * kBlock * 4; }
 
 // the part of the tree that travels in the kernel arguments (tiny scenes, two-level trees)
 void fill_top(const psdr_scene_s *h, SceneView &sc) {
@@ -416,13 +454,16 @@ int lbvh_build(psdr_scene_s *h, hipStream_t s, bool &fallback) {
 
 // kernel variant of the scene: bit 0 = environment map present, bit 1 = a rough conductor may be present
 const VariantOps *variant_of(const psdr_scene_s *h) {
-    const int fl = (h->desc.env_emitter >= 0 ? kSceneEnv : 0) | (h->has_rough ? kSceneRough : 0) | (h->n_blas > 0 ? kSceneForest : 0);
+    int fl = (h->desc.env_emitter >= 0 ? kSceneEnv : 0) | (h->has_rough ? kSceneRough : 0) | (h->n_blas > 0 ? kSceneForest : 0);
+    if (tiny_tables_ok(h)) fl |= kSceneTiny;
     switch (fl) {
         case 0: return variant_ops_0();
         case 1: return variant_ops_1();
         case 2: return variant_ops_2();
         case 3: return variant_ops_3();
         case 4: return variant_ops_4();
+        case 8: return variant_ops_8();
+        case 10: return variant_ops_10();
         default: return variant_ops_6();      // 6; psdr_bvh_build never builds a two-level tree under an environment map
     }
 }
@@ -504,6 +545,8 @@ int psdr_scene_set_tables(psdr_scene_t h, const psdr_scene_desc *desc) {
             return fail("psdr_scene_set_tables: inconsistent environment-map record");
     }
     if (h->have_tables && (d.tri_info != h->desc.tri_info || d.num_tris != h->desc.num_tris)) h->have_bvh = false;
+    // psdr_bvh_build keeps a host copy of emitter_i (hot gradient rows, the LDS table block of tiny scenes): new emitter tables need it again
+    if (h->have_tables && (d.emitter_i != h->desc.emitter_i || d.num_emitters != h->desc.num_emitters)) h->have_bvh = false;
     h->desc = d;
     // material_mask = 0: unknown -> serve every BSDF type
     h->has_rough = d.material_mask == 0 || (d.material_mask & (1u << PSDR_BSDF_ROUGHCONDUCTOR)) != 0;

@@ -40,10 +40,58 @@ __device__ __forceinline__ void setup_lds(const LaunchCtx &cx, TraversalStack &s
     for (int i = threadIdx.x; i < sc.n_lbtris * 3; i += kBlock) dst[sc.off_lbtris / 16 + i] = sc.btris[i];
     src = reinterpret_cast<const float4 *>(sc.d.tri_info);
     for (int i = threadIdx.x; i < sc.n_ltri * 6; i += kBlock) dst[sc.off_ltri / 16 + i] = src[i];
+    if (threadIdx.x == 0) {
+        int32_t *m = reinterpret_cast<int32_t *>(psdr_dyn_lds + sc.off_lprim);
+        for (int i = 0; i < sc.n_tiny; ++i) {            // uniform index: scalar loads from the kernel arguments
+            m[i * 4] = __float_as_int(sc.tiny[i * 3].w); m[i * 4 + 1] = __float_as_int(sc.tiny[i * 3 + 1].w); m[i * 4 + 2] = __float_as_int(sc.tiny[i * 3 + 2].w);
+            m[i * 4 + 3] = 0;
+        }
+    }
+    if (sc.lt_trimesh >= 0) {
+        // a scene without a tree: the small tables of a path vertex too (psdr_device.h Tab<FL>), same layouts as the caller's
+        auto stage = [&](int off, const void *table, int words) {
+            if (off < 0 || table == nullptr) return;
+            const uint32_t *g = static_cast<const uint32_t *>(table);
+            uint32_t *l = reinterpret_cast<uint32_t *>(psdr_dyn_lds + off);
+#pragma unroll 1
+            for (int i = threadIdx.x; i < words; i += kBlock) l[i] = g[i];
+        };
+        stage(sc.lt_trimesh, sc.d.tri_mesh, sc.d.num_tris);
+        stage(sc.lt_meshbsdf, sc.d.mesh_bsdf, sc.d.num_meshes);
+        stage(sc.lt_meshemitter, sc.d.mesh_emitter, sc.d.num_meshes);
+        stage(sc.lt_bsdf, sc.d.bsdf_rec, sc.d.num_bsdfs * PSDR_BSDF_STRIDE);
+        stage(sc.lt_emf, sc.d.emitter_f, sc.d.num_emitters * PSDR_EMITTER_F_STRIDE);
+        stage(sc.lt_emi, sc.d.emitter_i, sc.d.num_emitters * PSDR_EMITTER_I_STRIDE);
+        stage(sc.lt_ecmf, sc.d.emitter_cmf, sc.d.num_emitters);
+        stage(sc.lt_epmf, sc.d.emitter_pmf, sc.d.num_emitters);
+        stage(sc.lt_fcmf, sc.d.face_cmf, sc.lt_nfaces);
+        stage(sc.lt_fpmf, sc.d.face_pmf, sc.lt_nfaces);
+        stage(sc.lt_uv, sc.d.tri_uv, sc.d.num_tris * PSDR_TRIUV_STRIDE);
+        stage(sc.lt_tex, sc.d.texels, sc.d.num_texels);
+    }
     st.base = reinterpret_cast<int32_t *>(psdr_dyn_lds + cx.off_stack) + threadIdx.x;
     __syncthreads();
 #else
     (void) cx; (void) st;
+#endif
+}
+// Forward-mode kernels of the kSceneTiny instances: the K tangent texel pools behind the staged value pool (psdr_device.h texel<M, true>).
+template <class TVT> __device__ __forceinline__ void setup_lds(const LaunchCtx &cx, TraversalStack &st, const TVT &tv) {
+    setup_lds(cx, st);
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (TVT::tiny && TVT::k > 0) {
+        constexpr int K = TVT::k;
+        static_assert(K <= 3, "plan_lds reserves three tangent texel pools");
+        if (cx.sc.lt_tex >= 0) {
+            float *l = reinterpret_cast<float *>(psdr_dyn_lds + cx.sc.lt_tex);
+            const int nt = cx.sc.d.num_texels;
+            for (int k = 0; k < K; ++k) {
+                const float *g = tv.t[k].d_texels;
+                for (int i = threadIdx.x; i < nt; i += kBlock) l[(k + 1) * nt + i] = g ? g[i] : 0.f;
+            }
+            __syncthreads();
+        }
+    }
 #endif
 }
 
@@ -195,6 +243,8 @@ const VariantOps *variant_ops_2();
 const VariantOps *variant_ops_3();
 const VariantOps *variant_ops_4();      // two-level tree (kSceneForest), diffuse
 const VariantOps *variant_ops_6();      // two-level tree, rough conductor
+const VariantOps *variant_ops_8();      // no tree at all (kSceneTiny: every primitive in the kernel arguments), diffuse
+const VariantOps *variant_ops_10();     // no tree, rough conductor
 }  // namespace psdr_host
 
 #define HIP_TRY(expr)                                                                              \

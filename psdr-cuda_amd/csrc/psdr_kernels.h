@@ -111,7 +111,7 @@ __global__ __launch_bounds__(kBlock, (camera_waves<G, R, INTEG, FL, NOTREE>())) 
                                                    unsigned long long *counters) {
     constexpr int K = ad_traits<R>::K;
     constexpr int NV = 3 * (1 + K);
-    TraversalStack st; setup_lds(cx, st);
+    TraversalStack st; setup_lds(cx, st, tv);
     uint32_t nrays = 0;
     const long long nceil = (n + kBlock - 1) / kBlock * kBlock;
     for (long long j = (long long) blockIdx.x * kBlock + threadIdx.x; j < nceil; j += (long long) gridDim.x * kBlock) {
@@ -302,7 +302,7 @@ template <class M, int FL>
 __global__ __launch_bounds__(kBlock, (is_ad<M>() ? 2 : PSDR_WF_WAVES)) void k_wf_camera(LaunchCtx cx, TV<M, FL> tv, int spp, int s_begin, int nsp, long long j0, long long n,
                                                         float inv_spp, float *__restrict__ img, float *__restrict__ dimg, long long plane,
                                                         PathStream out, int want_next, unsigned long long *counters, RngJump jump_next) {
-    TraversalStack st; setup_lds(cx, st);
+    TraversalStack st; setup_lds(cx, st, tv);
     uint32_t nrays = 0;
     const long long nceil = (n + kBlock - 1) / kBlock * kBlock;
     for (long long jj = (long long) blockIdx.x * kBlock + threadIdx.x; jj < nceil; jj += (long long) gridDim.x * kBlock) {
@@ -402,7 +402,7 @@ template <class M, int FL>
 __global__ __launch_bounds__(kBlock, (is_ad<M>() ? 2 : PSDR_WF_WAVES)) void k_wf_bounce(LaunchCtx cx, TV<M, FL> tv, float inv_spp, float *__restrict__ img,
                                                         float *__restrict__ dimg, long long plane, PathStream in,
                                                         PathStream out, int want_next, unsigned long long *counters, RngJump jump_next) {
-    TraversalStack st; setup_lds(cx, st);
+    TraversalStack st; setup_lds(cx, st, tv);
     uint32_t nrays = 0;
     bool binned = false;
     if constexpr ((FL & kSceneForest) != 0) binned = in.binned != 0;
@@ -840,15 +840,11 @@ int run_camera(psdr_scene_s *h, const psdr_render_opts *o, const TV<R, FL> &tv, 
 #define PSDR_LAUNCH_CAMERA_T(INTEG, NOTREE)                                                                                        \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_camera<G, R, INTEG, FL, NOTREE>), dim3(launch_blocks(h, n, camera_blocks_per_cu(h, n))), dim3(kBlock), lds_bytes(cx, h), s, cx, tv, o->spp, \
                        o->spp_begin, nsp, n, 1.f / (float) o->spp, img, dimg, WH * 3, h->d_counters)
-#define PSDR_LAUNCH_CAMERA(INTEG) PSDR_LAUNCH_CAMERA_T(INTEG, false)
-    // a second instance of the kernel exists only where the occupancy choice differs between scenes with and without a tree
-    constexpr bool two = camera_waves<G, R, PSDR_INTEGRATOR_PATH, FL, true>() != camera_waves<G, R, PSDR_INTEGRATOR_PATH, FL, false>();
-    const bool notree = h->n_tiny > 0 && h->n_blas == 0;
+#define PSDR_LAUNCH_CAMERA(INTEG) PSDR_LAUNCH_CAMERA_T(INTEG, ((FL & kSceneTiny) != 0))
+    // scenes without a tree are served by their own flag sets (kSceneTiny): occupancy follows from FL alone
     switch (o->integrator) {
         case PSDR_INTEGRATOR_DIRECT: PSDR_LAUNCH_CAMERA(PSDR_INTEGRATOR_DIRECT); break;
-        case PSDR_INTEGRATOR_PATH:
-            if constexpr (two) { if (notree) { PSDR_LAUNCH_CAMERA_T(PSDR_INTEGRATOR_PATH, true); break; } }
-            PSDR_LAUNCH_CAMERA(PSDR_INTEGRATOR_PATH); break;
+        case PSDR_INTEGRATOR_PATH: PSDR_LAUNCH_CAMERA(PSDR_INTEGRATOR_PATH); break;
         case PSDR_INTEGRATOR_FIELD: PSDR_LAUNCH_CAMERA(PSDR_INTEGRATOR_FIELD); break;
         default: return fail("Unknown integrator");
     }

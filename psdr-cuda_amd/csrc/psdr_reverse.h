@@ -237,7 +237,7 @@ PSDR_HD GgxAdj ggx_geo_vjp(const Vec3f &wi, const Vec3f &wo, float au, float av,
 template <class Sink> struct BsdfRev {
     const SceneView &sc;
     Bsdf<float, float> b;
-    PSDR_HD BsdfRev(const SceneView &s, int id) : sc(s), b(s, id) {}
+    PSDR_HD BsdfRev(const SceneView &s, int id) : sc(s), b(s, TangentView<0, Sink::flags>{}, id) {}
 
     template <class TVT> PSDR_HD RcParams rc_params(const TVT &tv0, const Its<float> &its) const {
         RcParams p;
@@ -499,9 +499,9 @@ struct VertexOut {
     bool next_valid;
 };
 
-PSDR_HD Its<float> make_path_vertex(const SceneView &sc, const Vec3f &origin, int tri, float hu, float hv, const TriRow<float> &T) {
+template <int FL> PSDR_HD Its<float> make_path_vertex(const SceneView &sc, const Vec3f &origin, int tri, float hu, float hv, const TriRow<float> &T) {
     Its<float> n;
-    const int tm = sc.d.tri_mesh[tri];
+    const int tm = Tab<FL>::tri_mesh(sc, tri);
     n.valid = true; n.tri = tri; n.mesh = tm & ~PSDR_TRI_FACE_NORMALS; n.hu = hu; n.hv = hv;
     n.n = T.fn; n.J = 1.f;
     n.p = bary_point(T.p0, T.e1, T.e2, hu, hv);
@@ -511,7 +511,7 @@ PSDR_HD Its<float> make_path_vertex(const SceneView &sc, const Vec3f &origin, in
     const ShNormal sn = shading_normal(T, (tm & PSDR_TRI_FACE_NORMALS) != 0, hu, hv);
     n.sh = Frame<float>(sn.n);
     n.wi = n.sh.to_local(-dir);
-    const float *q = sc.d.tri_uv ? sc.d.tri_uv + (size_t) tri * PSDR_TRIUV_STRIDE : nullptr;
+    const float *q = sc.d.tri_uv ? Tab<FL>::tri_uv(sc, tri) : nullptr;
     n.uvx = q ? (q[2] - q[0]) * hu + ((q[4] - q[0]) * hv + q[0]) : 0.f;
     n.uvy = q ? (q[3] - q[1]) * hu + ((q[5] - q[1]) * hv + q[1]) : 0.f;
     return n;
@@ -532,9 +532,10 @@ PSDR_HD VertexOut vertex_eval(Sink &sink, const SceneView &sc, TraversalStack &s
     VertexOut out; out.c = Vec3f(0.f); out.f = Vec3f(0.f); out.next_valid = false;
     // the bounding mesh of the environment map has no BSDF (direct.cpp:54-57): nothing is gathered there and
     // the path ends (the caller stops on !next_valid, so the skipped random numbers are never missed)
-    if (sc.d.mesh_bsdf[its.mesh] < 0) return out;
+    const int bsdf_id = Tab<Sink::flags>::mesh_bsdf(sc, its.mesh);
+    if (bsdf_id < 0) return out;
     constexpr bool kEnv = Sink::has_env;
-    BsdfRev<Sink> brev(sc, sc.d.mesh_bsdf[its.mesh]);
+    BsdfRev<Sink> brev(sc, bsdf_id);
     const MatCache<float> mat = brev.b.fetch(sc, tv0, its);        // the vertex' material parameters, looked up once
     brev.b.mc = &mat;
     const Bsdf<float, float> &bsdf = brev.b;
@@ -549,11 +550,11 @@ PSDR_HD VertexOut vertex_eval(Sink &sink, const SceneView &sc, TraversalStack &s
         if (REPLAY && BACKWARD) h1.tri = rec.tri(k, 0);
         else {
             nrays++;
-            h1 = closest_hit<false, (Sink::flags & kSceneForest) ? 1 : 0>(sc, st, ray1.o, ray1.d, INFINITY);
+            h1 = closest_hit<false, tree_mode<Sink::flags>()>(sc, st, ray1.o, ray1.d, INFINITY);
             if (REPLAY) rec.put_tri(k, 0, h1.tri);
         }
         if (h1.tri < 0) continue;
-        const int tm = sc.d.tri_mesh[h1.tri], mesh1 = tm & ~PSDR_TRI_FACE_NORMALS;
+        const int tm = Tab<Sink::flags>::tri_mesh(sc, h1.tri), mesh1 = tm & ~PSDR_TRI_FACE_NORMALS;
         const TriRow<float> T1 = load_tri<float>(sc, tv0, h1.tri);
         if (REPLAY && BACKWARD) h1 = hit_on_triangle(h1.tri, T1.p0, T1.e1, T1.e2, ray1.o, ray1.d);
         const Vec3f p1 = bary_point(T1.p0, T1.e1, T1.e2, h1.u, h1.v);
@@ -567,7 +568,7 @@ PSDR_HD VertexOut vertex_eval(Sink &sink, const SceneView &sc, TraversalStack &s
         const float pdf0 = pdf_s * G;
         const float cfac = 1.f / pdf_s;                       // G * J / pdf0 with J = 1, pdf0 = pdf_s * G
         const Vec3f valv = f * cfac;
-        const int e1 = sc.d.mesh_emitter[mesh1];
+        const int e1 = Tab<Sink::flags>::mesh_emitter(sc, mesh1);
         Vec3f Le1(0.f);
         float w = 1.f / (float) nB, dw_dpdf0 = 0.f;
         const bool env1 = kEnv && e1 >= 0 && e1 == sc.d.env_emitter;
@@ -575,10 +576,10 @@ PSDR_HD VertexOut vertex_eval(Sink &sink, const SceneView &sc, TraversalStack &s
             if (env1) Le1 = env_eval_direction<float>(sc, tv0, wo);
             else {
                 const ShNormal sn1 = shading_normal(T1, (tm & PSDR_TRI_FACE_NORMALS) != 0, h1.u, h1.v);
-                if (-dot(wo, sn1.n) > 0.f) { const float *r = sc.d.emitter_f + (size_t) e1 * PSDR_EMITTER_F_STRIDE; Le1 = Vec3f{r[0], r[1], r[2]}; }
+                if (-dot(wo, sn1.n) > 0.f) { const float *r = Tab<Sink::flags>::emitter_f(sc, e1); Le1 = Vec3f{r[0], r[1], r[2]}; }
             }
             if (nL > 0) {
-                const float *ef = sc.d.emitter_f + (size_t) e1 * PSDR_EMITTER_F_STRIDE;
+                const float *ef = Tab<Sink::flags>::emitter_f(sc, e1);
                 const float pe = env1 ? env_position_pdf(sc, its.p, p1, T1.fn) : ef[3] * ef[4];
                 const float a2 = pdf0 * pdf0, b2 = pe * pe, den = a2 + b2;
                 w *= a2 / den;
@@ -586,7 +587,7 @@ PSDR_HD VertexOut vertex_eval(Sink &sink, const SceneView &sc, TraversalStack &s
             }
             out.c = out.c + Le1 * valv * w;
         }
-        if (i == 0) { out.f = valv; out.next = make_path_vertex(sc, its.p, h1.tri, h1.u, h1.v, T1); out.next_valid = true; }
+        if (i == 0) { out.f = valv; out.next = make_path_vertex<Sink::flags>(sc, its.p, h1.tri, h1.u, h1.v, T1); out.next_valid = true; }
         if (!BACKWARD) continue;
         Vec3f a_val = a_c * Le1 * w;
         const float a_w = dot(a_c, Le1 * valv);
@@ -630,17 +631,17 @@ PSDR_HD VertexOut vertex_eval(Sink &sink, const SceneView &sc, TraversalStack &s
         const float s0 = rng.next(), s1 = rng.next();
         float r0 = s0, r1 = s1;                                // mirrors sample_emitter_position
         int e = 0; float epdf = 1.f;
-        if (sc.d.num_emitters > 1) e = sample_reuse(sc.d.emitter_cmf, sc.d.emitter_pmf, sc.d.emitter_sum, sc.d.num_emitters, r1, epdf);
+        if (sc.d.num_emitters > 1) e = sample_reuse(Tab<Sink::flags>::emitter_cmf(sc), Tab<Sink::flags>::emitter_pmf(sc), sc.d.emitter_sum, sc.d.num_emitters, r1, epdf);
         const bool env_s = kEnv && e == sc.d.env_emitter;       // sampled from the environment map: detached, J = 1
         Vec3f psp; float pspdf, ba = 0.f, bb = 0.f, e_area = 1.f; int etri = -1;
         if (env_s) {
             const PosSample<float> pse = env_sample_position<float>(sc, its.p, r0, r1);
             psp = pse.p; pspdf = pse.pdf * epdf;
         } else {
-            const float *ef = sc.d.emitter_f + (size_t) e * PSDR_EMITTER_F_STRIDE;
-            const int32_t *ei = sc.d.emitter_i + (size_t) e * PSDR_EMITTER_I_STRIDE;
+            const float *ef = Tab<Sink::flags>::emitter_f(sc, e);
+            const int32_t *ei = Tab<Sink::flags>::emitter_i(sc, e);
             float fp;
-            const int fidx = sample_reuse(sc.d.face_cmf + ei[3], sc.d.face_pmf + ei[3], ef[5], ei[2], r0, fp);
+            const int fidx = sample_reuse(Tab<Sink::flags>::face_cmf(sc) + ei[3], Tab<Sink::flags>::face_pmf(sc) + ei[3], ef[5], ei[2], r0, fp);
             const float tt = sqrtf(fmaxf(1.f - r0, 0.f));
             ba = 1.f - tt; bb = tt * r1;
             etri = ei[1] + fidx;
@@ -656,12 +657,12 @@ PSDR_HD VertexOut vertex_eval(Sink &sink, const SceneView &sc, TraversalStack &s
         if (REPLAY && BACKWARD) h2.tri = rec.tri(k, 1);
         else {
             nrays++;
-            h2 = closest_hit<false, (Sink::flags & kSceneForest) ? 1 : 0>(sc, st, its.p, wo, INFINITY);
+            h2 = closest_hit<false, tree_mode<Sink::flags>()>(sc, st, its.p, wo, INFINITY);
             if (REPLAY) rec.put_tri(k, 1, h2.tri);
         }
         if (h2.tri < 0) continue;
-        const int tm2 = sc.d.tri_mesh[h2.tri], mesh2 = tm2 & ~PSDR_TRI_FACE_NORMALS;
-        const int e2 = sc.d.mesh_emitter[mesh2];
+        const int tm2 = Tab<Sink::flags>::tri_mesh(sc, h2.tri), mesh2 = tm2 & ~PSDR_TRI_FACE_NORMALS;
+        const int e2 = Tab<Sink::flags>::mesh_emitter(sc, mesh2);
         const TriRow<float> T2 = load_tri<float>(sc, tv0, h2.tri);
         if (REPLAY && BACKWARD) h2 = hit_on_triangle(h2.tri, T2.p0, T2.e1, T2.e2, its.p, wo);
         const Vec3f p2 = bary_point(T2.p0, T2.e1, T2.e2, h2.u, h2.v);
@@ -675,7 +676,7 @@ PSDR_HD VertexOut vertex_eval(Sink &sink, const SceneView &sc, TraversalStack &s
         else {
             const ShNormal sn2 = shading_normal(T2, (tm2 & PSDR_TRI_FACE_NORMALS) != 0, h2.u, h2.v);
             if (!(-dot((p2 - its.p) / t2, sn2.n) > 0.f)) continue;         // Le = 0 from behind
-            const float *rr = sc.d.emitter_f + (size_t) e2 * PSDR_EMITTER_F_STRIDE;
+            const float *rr = Tab<Sink::flags>::emitter_f(sc, e2);
             Le2 = Vec3f{rr[0], rr[1], rr[2]};
         }
         const float cosv = -dot(T2.fn, wo);
@@ -797,7 +798,7 @@ template <class RealSink> struct CameraSinkOf<false, RealSink> { using type = Ma
 template <class Sink> PSDR_HD Vec3f path_vertex_backward(Sink &sink, const SceneView &sc, const Its<float> &v, const Vec3f &prev_p, VertexAdj va, RowAdj &row) {
     const TangentView<0, Sink::flags> tv0{};
     const TriRow<float> T = load_tri<float>(sc, tv0, v.tri);
-    const bool face = (sc.d.tri_mesh[v.tri] & PSDR_TRI_FACE_NORMALS) != 0;
+    const bool face = (Tab<Sink::flags>::tri_mesh(sc, v.tri) & PSDR_TRI_FACE_NORMALS) != 0;
     const ShNormal sn = shading_normal(T, face, v.hu, v.hv);
     Vec3f dir = v.p - prev_p;
     const float t = norm(dir);
@@ -847,11 +848,11 @@ PSDR_HD Vec3f camera_sample_reverse(RealSink &real_sink, PrimaryGrad &pg, PathRe
         nv = disk.geti(1);
     } else {
         nrays++;
-        h0 = closest_hit<false, (RealSink::flags & kSceneForest) ? 1 : 0>(sc, st, ray.o, ray.d, INFINITY);
+        h0 = closest_hit<false, tree_mode<RealSink::flags>()>(sc, st, ray.o, ray.d, INFINITY);
         if (h0.tri < 0) { if constexpr (STAGE == 1) disk.puti(0, -1); return Vec3f(0.f); }
     }
     pg.tri = h0.tri;
-    const int tm0 = sc.d.tri_mesh[h0.tri];
+    const int tm0 = Tab<RealSink::flags>::tri_mesh(sc, h0.tri);
     const bool face0 = (tm0 & PSDR_TRI_FACE_NORMALS) != 0;
     const TriRow<float> T0 = load_tri<float>(sc, tv0, h0.tri);
     if constexpr (STAGE == 2) h0 = hit_on_triangle(h0.tri, T0.p0, T0.e1, T0.e2, ray.o, ray.d);       // the leaf test's arithmetic: the same (u, v)
@@ -871,7 +872,7 @@ PSDR_HD Vec3f camera_sample_reverse(RealSink &real_sink, PrimaryGrad &pg, PathRe
     const ShNormal sn0 = shading_normal(T0, face0, bu, bv);
     its.sh = Frame<float>(sn0.n);
     its.wi = its.sh.to_local(-ray.d);
-    const float *q = sc.d.tri_uv ? sc.d.tri_uv + (size_t) h0.tri * PSDR_TRIUV_STRIDE : nullptr;
+    const float *q = sc.d.tri_uv ? Tab<RealSink::flags>::tri_uv(sc, h0.tri) : nullptr;
     its.uvx = q ? (q[2] - q[0]) * bu + ((q[4] - q[0]) * bv + q[0]) : 0.f;
     its.uvy = q ? (q[3] - q[1]) * bu + ((q[5] - q[1]) * bv + q[1]) : 0.f;
 
@@ -908,10 +909,10 @@ PSDR_HD Vec3f camera_sample_reverse(RealSink &real_sink, PrimaryGrad &pg, PathRe
     // sweep 2 replays the hits of sweep 1 (always for the PathTracer; DirectIntegrator with <= 1 sample of each kind)
     const bool replay = STAGE != 0 || INTEG == PSDR_INTEGRATOR_PATH || (nB <= 1 && nL <= 1);      // a split launch is only made when the hits can be replayed
 
-    const int e0 = sc.d.mesh_emitter[its.mesh];
+    const int e0 = Tab<RealSink::flags>::mesh_emitter(sc, its.mesh);
     const bool env0 = Sink::has_env && !lp.hide_emitters && e0 >= 0 && e0 == sc.d.env_emitter;
     const bool le0 = !lp.hide_emitters && e0 >= 0 && !env0 && its.wi.z > 0.f;
-    if (le0) { const float *r = sc.d.emitter_f + (size_t) e0 * PSDR_EMITTER_F_STRIDE; result = Vec3f{r[0], r[1], r[2]}; }
+    if (le0) { const float *r = Tab<RealSink::flags>::emitter_f(sc, e0); result = Vec3f{r[0], r[1], r[2]}; }
     if (env0) result = env_eval_direction<float>(sc, tv0, ray.d);
 
     // ---- sweep 1 (values): record (c_k, f_k), build the suffix radiances T_k
@@ -1012,7 +1013,7 @@ PSDR_HD Vec3f camera_sample_reverse(RealSink &real_sink, PrimaryGrad &pg, PathRe
         moeller_trumbore(Tb.p0, Tb.e1, Tb.e2, ray_b, bu_b, bv_b, t_b);
         const ShNormal sn_b = shading_normal(Tb, face0, bu_b, bv_b);
         const Frame<float> sh_b(sn_b.n);
-        const float *qb = sc.d.tri_uv ? sc.d.tri_uv + (size_t) tri_b * PSDR_TRIUV_STRIDE : nullptr;
+        const float *qb = sc.d.tri_uv ? Tab<RealSink::flags>::tri_uv(sc, tri_b) : nullptr;
         Vec3f a_d = a_d_le0 - (sh_b.s * va0.wi.x + sh_b.t * va0.wi.y + sh_b.n * va0.wi.z);
         acc(va0.s, ray_b.d * (-va0.wi.x)); acc(va0.t, ray_b.d * (-va0.wi.y)); acc(va0.n, ray_b.d * (-va0.wi.z));
         const Vec3f a_shn = va0.n + frame_vjp(sn_b.n, va0.s, va0.t);
@@ -1113,7 +1114,7 @@ PSDR_HD void secondary_edge_reverse(Sink &sink, const SceneView &sc, TraversalSt
     const Vec3f dcam = camera_space_dir(sc, qx, qy);
     const RayT<float> cam = primary_ray<float>(sc, tv0, qx, qy);
     nrays++;
-    const Hit hc = closest_hit<false, (Sink::flags & kSceneForest) ? 1 : 0>(sc, st, cam.o, cam.d, INFINITY);
+    const Hit hc = closest_hit<false, tree_mode<Sink::flags>()>(sc, st, cam.o, cam.d, INFINITY);
     if (hc.tri < 0) return;
     const TriRow<float> Tc = load_tri<float>(sc, tv0, hc.tri);
     float cu, cv, ct;
@@ -1129,8 +1130,8 @@ PSDR_HD void secondary_edge_reverse(Sink &sink, const SceneView &sc, TraversalSt
     const float base_v = (its1c.t / dist) * (sinphi / sinphi2) * cos2;
     const Vec3f d0 = -cam.d;
     const Vec3f d0_local = its1c.sh.to_local(d0);
-    if (sc.d.mesh_bsdf[its1c.mesh] < 0) return;
-    const Bsdf<float, float> bsdf(sc, sc.d.mesh_bsdf[its1c.mesh]);
+    if (Tab<Sink::flags>::mesh_bsdf(sc, its1c.mesh) < 0) return;
+    const Bsdf<float, float> bsdf(sc, tv0, Tab<Sink::flags>::mesh_bsdf(sc, its1c.mesh));
     Vec3f bsdf_val = bsdf.eval(sc, tv0, its1c, d0_local, true);
     bsdf_val = bsdf_val * fabsf((its1c.wi.z * dot(d0, its1c.n)) / (d0_local.z * dot(dir, its1c.n)));
     Vec3f value0 = bsdf_val * Le<float>(sc, tv0, its2, true) * (base_v * sensor_val / bpdf);

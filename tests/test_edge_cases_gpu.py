@@ -146,9 +146,16 @@ def test_bvh_refit_between_configures_matches_a_rebuild():
         ref = oracle.render(tb, _abi.make_opts(spp=4, bsdf_samples=1, light_samples=1, rng_offset=(7 * (step + 1), 0, 0)))
         bad = (np.abs(img - ref).max(1) > 1e-3 * (1 + np.abs(ref).max(1))).mean()
         assert bad < 0.01
-    # blow the bunny up: the refitted boxes grow far beyond the build -> the next configure rebuilds
+    # blow the bunny up: the refitted boxes grow far beyond the build -> the next GEOMETRY configure rebuilds (the refit's area is read
+    # back one call later, without a stall); a material-only configure in between keeps the tree as it is (no psdr_bvh_build at all)
     mesh.set_transform(Matrix4fD.scale(Vector3fD([3.0, 3.0, 3.0])))
     sc.configure(); integ.renderC(sc)
+    lib.psdr_bvh_stats(sc._native, stats)
+    before = list(stats)[:2]
+    sc.configure(); integ.renderC(sc)
+    lib.psdr_bvh_stats(sc._native, stats)
+    assert list(stats)[:2] == before                                        # nothing but (unchanged) materials: neither rebuilt nor refitted
+    mesh.set_transform(Matrix4fD.scale(Vector3fD([3.0, 3.0, 3.01])))
     sc.configure(); integ.renderC(sc)
     lib.psdr_bvh_stats(sc._native, stats)
     assert stats[0] == 2
