@@ -90,6 +90,37 @@ inline void pack_tiny_prims(const std::vector<float4> &tris, std::vector<float4>
     }
 }
 
+// What the kernels receive (SceneView::tiny / tiny_meta): every primitive in PLANE FORM, computed here in double,
+//   row 0 = (n, c0)   unit normal and n . p0:            t = -(n . o - c0) / (n . d)
+//   row 1 = (a1, c1)  dual basis vector of e1, a1 . p0:  s = a1 . (o + t d) - c1
+//   row 2 = (a2, c2)  dual basis vector of e2, a2 . p0:  the second plane coordinate likewise
+// (a1 = e2 x n / |e1 x e2|, a2 = n x e1 / |e1 x e2| with the unit normal: a1 . e1 = a2 . e2 = 1, a1 . e2 = a2 . e1 = 0) -- 17 VALU
+// operations per test against Moeller-Trumbore's 31 (psdr_device.h tiny_prim_test), and meta = (ids, codeA, codeB, the bound on s + t as float bits: 2 for a parallelogram, 1 for a triangle).
+inline void tiny_plane_form(const std::vector<float4> &prims, float4 *rows, int32_t *meta) {
+    const int n = (int) prims.size() / 3;
+    for (int i = 0; i < n; ++i) {
+        const float4 &a = prims[(size_t) i * 3], &b = prims[(size_t) i * 3 + 1], &c = prims[(size_t) i * 3 + 2];
+        const double p0[3] = {a.x, a.y, a.z}, e1[3] = {b.x, b.y, b.z}, e2[3] = {c.x, c.y, c.z};
+        double nn[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+        const double len = std::sqrt(nn[0] * nn[0] + nn[1] * nn[1] + nn[2] * nn[2]);
+        double a1[3] = {0, 0, 0}, a2[3] = {0, 0, 0};
+        if (len > 0.0 && std::isfinite(len)) {
+            for (int k = 0; k < 3; ++k) nn[k] /= len;
+            const double x1[3] = {e2[1] * nn[2] - e2[2] * nn[1], e2[2] * nn[0] - e2[0] * nn[2], e2[0] * nn[1] - e2[1] * nn[0]};      // e2 x n
+            const double x2[3] = {nn[1] * e1[2] - nn[2] * e1[1], nn[2] * e1[0] - nn[0] * e1[2], nn[0] * e1[1] - nn[1] * e1[0]};      // n x e1
+            for (int k = 0; k < 3; ++k) { a1[k] = x1[k] / len; a2[k] = x2[k] / len; }
+        } else nn[0] = nn[1] = nn[2] = 0.0;                        // degenerate: n . d = 0 for every ray, never hit
+        auto dot3 = [](const double *x, const double *y) { return x[0] * y[0] + x[1] * y[1] + x[2] * y[2]; };
+        rows[i * 3] = float4{(float) nn[0], (float) nn[1], (float) nn[2], (float) dot3(nn, p0)};
+        rows[i * 3 + 1] = float4{(float) a1[0], (float) a1[1], (float) a1[2], (float) dot3(a1, p0)};
+        rows[i * 3 + 2] = float4{(float) a2[0], (float) a2[1], (float) a2[2], (float) dot3(a2, p0)};
+        int32_t ids, codeA, codeB;
+        std::memcpy(&ids, &a.w, 4); std::memcpy(&codeA, &b.w, 4); std::memcpy(&codeB, &c.w, 4);
+        meta[i * 4] = ids; meta[i * 4 + 1] = codeA; meta[i * 4 + 2] = codeB; const float lim = ((uint32_t) ids >> 16) != 0xffffu ? 2.f : 1.f;
+        std::memcpy(&meta[i * 4 + 3], &lim, 4);
+    }
+}
+
 // ---------------------------------------------------------------------------- BVH builder
 // Host binned-SAH builder (replaces the OptiX GAS build, include/psdr/scene/optix.h:277-340).
 // Scenes of this path are small (12 .. ~50k triangles) and the tree is rebuilt on every

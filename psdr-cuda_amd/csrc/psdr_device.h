@@ -43,7 +43,8 @@ struct SceneView {
     // KERNEL ARGUMENTS and closest_hit tests all of them in order -- wave-uniform s_load from the kernarg
     // segment into SGPRs, no tree, no per-lane node fetches, no stack traffic, no divergence between lanes.
     int32_t n_tiny;
-    float4 tiny[kTinyTris * 3];
+    float4 tiny[kTinyTris * 3];                 // plane form: (n | c0), (a1 | c1), (a2 | c2) per primitive (psdr_bvh_build.h tiny_plane_form)
+    int32_t tiny_meta[kTinyTris * 4];           // (ids, codeA, codeB, bound on s + t as float bits: 2 parallelogram / 1 triangle) per primitive
     // Two-level tree (psdr_bvh_build.h ForestBuilder; scenes of a few small meshes plus a few large ones -- a room with
     // objects): the triangles of the small meshes are the primitives above, every large mesh has its OWN tree in `nodes`,
     // and its box + root travel in the kernel arguments too.  A closest-hit query first tests the inline primitives
@@ -179,30 +180,28 @@ PSDR_HD void leaf_triangle_test(const float4 &a, const float4 &b, const float4 &
 
 // Replaces __raygen__/__closesthit__/__miss__ (cuda/psdr_cuda.cu:9-45): closest hit with
 // t in [RayEpsilon, tmax], both faces; (u,v) = barycentric weights of vertex 1 and 2.
-// One primitive of a tiny scene (psdr_bvh_build.h pack_tiny_prims): a triangle or a parallelogram of two triangles.
-// best.(u, v) hold the plane coordinates (s, t) of the primitive and best_i the index of the winning primitive; resolve_tiny_hit turns
-// them into (triangle, u, v) once per ray.  BRANCH-FREE on purpose: a triangle is the parallelogram test with the bound s + t <= 1
-// instead of <= 2 (a wave-uniform scalar select) and the hit update is four v_cndmask -- with `if (hit)` around it the ids / codes
-// were re-fetched by scalar loads INSIDE the divergent branch and every primitive waited for its own s_load (three basic blocks per
-// primitive: nothing could be scheduled across them); now the unrolled loop body is one block and the scalar loads of the following
-// primitives are in flight while one is tested.
+// One primitive of a tiny scene (psdr_bvh_build.h pack_tiny_prims): a triangle or a parallelogram of two triangles, in PLANE FORM
+// (tiny_plane_form): t from the plane equation, the plane coordinates (s, t) of the hit point from the dual basis of the two edges --
+// 17 VALU operations with the rows in SGPRs, against 31 for Moeller-Trumbore (the primitive tests are half of the C2 kernels'
+// arithmetic).  best.(u, v) hold the plane coordinates and best_i the index of the winning primitive; resolve_tiny_hit turns them into
+// (triangle, u, v) once per ray.  BRANCH-FREE on purpose: a triangle is the parallelogram test with the bound s + t <= 1 instead of
+// <= 2 (a wave-uniform select) and the hit update is four v_cndmask -- with `if (hit)` around it the ids / codes were re-fetched by
+// scalar loads INSIDE the divergent branch and every primitive waited for its own s_load (three basic blocks per primitive: nothing
+// could be scheduled across them); now the unrolled loop body is one block and the scalar loads of the following primitives are in
+// flight while one is tested.
 template <bool IGN = false>
-PSDR_HD void tiny_prim_test(const float4 &a, const float4 &b, const float4 &c, int i, const Vec3f &o, const Vec3f &d, Hit &best, int &best_i,
+PSDR_HD void tiny_prim_test(const float4 &r0, const float4 &r1, const float4 &r2, const int32_t *meta, int i, const Vec3f &o, const Vec3f &d, Hit &best, int &best_i,
                             int ig0 = -1, int ig1 = -1) {
-    const Vec3f e1{b.x, b.y, b.z}, e2{c.x, c.y, c.z};
-    const Vec3f h = cross(d, e2);
-    const float det = dot(e1, h);
-    const float f = 1.f / det;
-    const Vec3f s{o.x - a.x, o.y - a.y, o.z - a.z};
-    const float u = f * dot(s, h);
-    const Vec3f q = cross(s, e1);
-    const float v = f * dot(d, q);
-    const float t = f * dot(e2, q);
-    const int id2 = __float_as_int_hd(a.w);                        // wave-uniform (kernel argument)
-    const bool quad = ((uint32_t) id2 >> 16) != 0xffffu;
-    const float lim = quad ? 2.f : 1.f;                            // u <= 1 and v <= 1 are implied for a triangle (u, v >= 0, u + v <= 1)
+    const float dn = r0.x * d.x + (r0.y * d.y + r0.z * d.z);
+    const float on = r0.x * o.x + (r0.y * o.y + (r0.z * o.z - r0.w));
+    const float t = -on * (1.f / dn);
+    const Vec3f p{o.x + t * d.x, o.y + t * d.y, o.z + t * d.z};
+    const float u = r1.x * p.x + (r1.y * p.y + (r1.z * p.z - r1.w));
+    const float v = r2.x * p.x + (r2.y * p.y + (r2.z * p.z - r2.w));
+    const float lim = __int_as_float_hd(meta[3]);                  // wave-uniform (kernel argument): 2 for a parallelogram, 1 for a triangle (u, v <= 1 are then implied)
+    // a ray in the plane (dn = 0) gives t = +-inf or NaN, p and (u, v) NaN: every comparison fails
     bool hit = (u >= 0.f) & (v >= 0.f) & (u <= 1.f) & (v <= 1.f) & (u + v <= lim) & (t >= kRayEpsilon) & (t < best.t);
-    if (IGN) { const int id = (quad && u + v > 1.f) ? (int) ((uint32_t) id2 >> 16) : (id2 & 0xffff); hit = hit & (id != ig0) & (id != ig1); }
+    if (IGN) { const int id2 = meta[0]; const bool quad = lim > 1.5f; const int id = (quad && u + v > 1.f) ? (int) ((uint32_t) id2 >> 16) : (id2 & 0xffff); hit = hit & (id != ig0) & (id != ig1); }
     best.t = hit ? t : best.t; best.u = hit ? u : best.u; best.v = hit ? v : best.v; best_i = hit ? i : best_i;
 }
 // (ids, codeA, codeB) of primitive i: from the LDS copy setup_lds made of the kernel-argument words (a per-lane index into the kernel
@@ -211,10 +210,10 @@ PSDR_HD void resolve_tiny_hit(const SceneView &sc, Hit &best, int best_i) {
     if (best_i < 0) return;                                         // no hit
 #if defined(__HIP_DEVICE_COMPILE__)
     const int32_t *m = PSDR_LDS_TABLE(int32_t, sc.off_lprim) + best_i * 4;
-    const int ids = m[0], codeA = m[1], codeB = m[2];
 #else
-    const int ids = __float_as_int_hd(sc.tiny[best_i * 3].w), codeA = __float_as_int_hd(sc.tiny[best_i * 3 + 1].w), codeB = __float_as_int_hd(sc.tiny[best_i * 3 + 2].w);
+    const int32_t *m = sc.tiny_meta + best_i * 4;
 #endif
+    const int ids = m[0], codeA = m[1], codeB = m[2];
     const bool second = ((uint32_t) ids >> 16) != 0xffffu && best.u + best.v > 1.f;
     const int code = second ? codeB : codeA;
     auto k = [&](int i) { return (float) (((code >> (3 * i)) & 7) - 2); };
@@ -292,7 +291,7 @@ PSDR_HD Hit closest_hit(const SceneView &sc, TraversalStack &st, const Vec3f &o,
         // walls of the Cornell box): the scalar loads of the following primitives are in flight while one is tested
         int best_i = -1;
 #pragma unroll 6
-        for (int i = 0; i < sc.n_tiny; ++i) tiny_prim_test<IGN>(sc.tiny[i * 3], sc.tiny[i * 3 + 1], sc.tiny[i * 3 + 2], i, o, d, best, best_i, ig0, ig1);
+        for (int i = 0; i < sc.n_tiny; ++i) tiny_prim_test<IGN>(sc.tiny[i * 3], sc.tiny[i * 3 + 1], sc.tiny[i * 3 + 2], sc.tiny_meta + i * 4, i, o, d, best, best_i, ig0, ig1);
         resolve_tiny_hit(sc, best, best_i);
         if (FOREST == 2 || !forest) return best;
         // two-level tree: the trees whose box the segment [0, t_best] enters, NEAREST box first (a hit in a near object

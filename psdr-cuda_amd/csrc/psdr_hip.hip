@@ -207,6 +207,7 @@ int lds_bytes(const LaunchCtx &cx, const psdr_scene_s *h) { return cx.off_stack 
 void fill_top(const psdr_scene_s *h, SceneView &sc) {
     sc.n_tiny = h->n_tiny;
     std::memcpy(sc.tiny, h->tiny, sizeof(h->tiny));
+    std::memcpy(sc.tiny_meta, h->tiny_meta, sizeof(h->tiny_meta));
     sc.n_blas = h->n_blas;
     std::memcpy(sc.blas_lo, h->blas_lo, sizeof(h->blas_lo));
     std::memcpy(sc.blas_hi, h->blas_hi, sizeof(h->blas_hi));
@@ -597,7 +598,7 @@ int psdr_bvh_build(psdr_scene_t h, void *stream) {
                 refit_fits = (int) prims.size() / 3 <= kTinyTris;
                 if (refit_fits) {
                     h->n_tiny = (int) prims.size() / 3;
-                    if (!prims.empty()) std::memcpy(h->tiny, prims.data(), prims.size() * sizeof(float4));
+                    tiny_plane_form(prims, h->tiny, h->tiny_meta);
                     for (int k = 0; k < h->n_blas; ++k) {
                         const float w = h->blas_lo[k].w;
                         h->blas_lo[k] = top[kMaxInlineTris * 3 + k]; h->blas_lo[k].w = w;
@@ -692,7 +693,7 @@ int psdr_bvh_build(psdr_scene_t h, void *stream) {
     h->n_tiny = 0; h->n_blas = 0; h->n_inline = 0;
     if (forest) {
         h->n_tiny = (int) top_prims.size() / 3;
-        if (h->n_tiny) std::memcpy(h->tiny, top_prims.data(), top_prims.size() * sizeof(float4));
+        tiny_plane_form(top_prims, h->tiny, h->tiny_meta);
         h->n_inline = (int) fb.inline_ids.size();
         h->n_blas = (int) fb.roots.size();
         for (int k = 0; k < h->n_blas; ++k) {
@@ -708,7 +709,7 @@ int psdr_bvh_build(psdr_scene_t h, void *stream) {
         std::vector<float4> prims;
         pack_tiny_prims(b.btris, prims);           // walls as parallelograms: half the tests
         h->n_tiny = (int) prims.size() / 3;
-        std::memcpy(h->tiny, prims.data(), prims.size() * sizeof(float4));
+        tiny_plane_form(prims, h->tiny, h->tiny_meta);
     }
     // what the refit path needs: the levels of the breadth-first node order, the padding, the reference area
     h->tree_tris = T; h->refits_since_build = 0; h->num_builds++; h->bvh_pad = forest ? fb.pad : b.pad;

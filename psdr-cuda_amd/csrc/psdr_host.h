@@ -42,10 +42,7 @@ __device__ __forceinline__ void setup_lds(const LaunchCtx &cx, TraversalStack &s
     for (int i = threadIdx.x; i < sc.n_ltri * 6; i += kBlock) dst[sc.off_ltri / 16 + i] = src[i];
     if (threadIdx.x == 0) {
         int32_t *m = reinterpret_cast<int32_t *>(psdr_dyn_lds + sc.off_lprim);
-        for (int i = 0; i < sc.n_tiny; ++i) {            // uniform index: scalar loads from the kernel arguments
-            m[i * 4] = __float_as_int(sc.tiny[i * 3].w); m[i * 4 + 1] = __float_as_int(sc.tiny[i * 3 + 1].w); m[i * 4 + 2] = __float_as_int(sc.tiny[i * 3 + 2].w);
-            m[i * 4 + 3] = 0;
-        }
+        for (int i = 0; i < sc.n_tiny * 4; ++i) m[i] = sc.tiny_meta[i];            // uniform index: scalar loads from the kernel arguments
     }
     if (sc.lt_trimesh >= 0) {
         // a scene without a tree: the small tables of a path vertex too (psdr_device.h Tab<FL>), same layouts as the caller's
@@ -162,7 +159,8 @@ struct psdr_scene_s {
     // tiny scenes: the leaf triangles as they travel in the kernel arguments (SceneView::tiny)
     bool tiny_enabled = true;
     int n_tiny = 0;
-    float4 tiny[kTinyTris * 3] = {};
+    float4 tiny[kTinyTris * 3] = {};           // plane form (tiny_plane_form)
+    int32_t tiny_meta[kTinyTris * 4] = {};
     // two-level tree (psdr_bvh_build.h ForestBuilder): boxes + roots of the per-mesh trees, as they travel in the
     // kernel arguments; d_top / d_inline_ids serve the refresh after a device refit
     bool two_level_enabled = true, refit_ok = true, wf_binned = true;

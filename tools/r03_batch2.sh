@@ -2,7 +2,7 @@
 # round 3, batch 2: tiny-scene variants (LDS tables, no tree code) A/B against the general instances; full gpu test suite
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-O=$R/gpurun_out/r03b
+O=$R/gpurun_out/r03d
 mkdir -p $O
 cd $R
 tools/micro/bin/valu_rate > $O/valu_rate.txt 2>&1
