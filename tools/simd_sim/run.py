@@ -112,3 +112,52 @@ for R in (4,):
         x.reshape(-1, 2, 256, 3)[:, 0] = a.reshape(-1, 256, 3); x.reshape(-1, 2, 256, 3)[:, 1] = b.reshape(-1, 256, 3)
         return x
     sim("b1 bsdf+light", inter(p0, p0), inter(d1, l1), R); sim("b2 bsdf+light", inter(p1, p1), inter(d2, l2), R)
+
+# ---- ray sorting experiment (SORT=1): the same bounce rays, ordered by a key of (origin cell, direction) before they are cut into waves
+if os.environ.get("SORT"):
+    def morton3(x, y, z, bits):
+        k = np.zeros(len(x), np.uint64)
+        for b in range(bits):
+            k |= ((x >> b) & 1).astype(np.uint64) << np.uint64(3 * b) | ((y >> b) & 1).astype(np.uint64) << np.uint64(3 * b + 1) | ((z >> b) & 1).astype(np.uint64) << np.uint64(3 * b + 2)
+        return k
+    def sort_rays(o, d, ob, db, dir_first=False):
+        lo, hi = o.min(0), o.max(0)
+        q = np.minimum(((o - lo) / np.maximum(hi - lo, 1e-6) * (1 << ob)).astype(np.int64), (1 << ob) - 1)
+        ko = morton3(q[:, 0], q[:, 1], q[:, 2], ob)
+        qd = np.minimum(((d * 0.5 + 0.5) * (1 << db)).astype(np.int64), (1 << db) - 1)
+        kd = morton3(qd[:, 0], qd[:, 1], qd[:, 2], db)
+        key = (kd << np.uint64(3 * ob)) | ko if dir_first else (ko << np.uint64(3 * db)) | kd
+        idx = np.argsort(key, kind="stable")
+        return o[idx], d[idx]
+    for name, (oo, dd) in (("bounce1 bsdf", (p0, d1)), ("bounce2 bsdf", (p1, d2)), ("bounce2 light", (p1, l2))):
+        for ob, db, df in ((0, 0, False), (1, 1, False), (2, 1, False), (2, 2, False), (3, 1, False), (3, 2, False), (2, 1, True), (1, 2, True)):
+            if ob == 0:
+                sim(name + " unsorted", oo, dd, 4)
+            else:
+                so_, sd_ = sort_rays(oo, dd, ob, db, df)
+                sim("%s o%d d%d %s" % (name, ob, db, "dir-first" if df else "org-first"), so_, sd_, 4)
+
+# ---- the same within the EXPENSIVE class only (SORT2=1): rays that enter the box of the large mesh (what the class-binned wavefront already separates)
+if os.environ.get("SORT2"):
+    tm = tbc["tri_mesh"].numpy() & ~0x40000000
+    big = np.bincount(tm).argmax()
+    rows = info[tm == big]
+    vv = np.concatenate([rows[:, 0:3], rows[:, 0:3] + rows[:, 3:6], rows[:, 0:3] + rows[:, 6:9]])
+    blo, bhi = vv.min(0), vv.max(0)
+    def enters(o, d):
+        inv = 1.0 / np.where(d == 0, 1e-30, d)
+        t0, t1 = (blo - o) * inv, (bhi - o) * inv
+        tn, tf = np.minimum(t0, t1).max(1), np.maximum(t0, t1).min(1)
+        return (tf >= np.maximum(tn, 0))
+    for name, (oo, dd) in (("bounce1 bsdf", (p0, d1)), ("bounce2 bsdf", (p1, d2)), ("bounce2 light", (p1, l2))):
+        m = enters(oo, dd)
+        oo, dd = oo[m], dd[m]
+        n64 = len(oo) // 64 * 64
+        oo, dd = oo[:n64], dd[:n64]
+        print("%s: %d rays enter the box (%.1f %%)" % (name, n64, 100.0 * m.mean()))
+        for ob, db, df in ((0, 0, False), (1, 1, False), (2, 1, False), (2, 2, False), (3, 2, False), (4, 3, False), (1, 2, True), (2, 3, True)):
+            if ob == 0:
+                sim(name + " unsorted", oo, dd, 4)
+            else:
+                so_, sd_ = sort_rays(oo, dd, ob, db, df)
+                sim("%s o%d d%d %s" % (name, ob, db, "dir-first" if df else "org-first"), so_, sd_, 4)
