@@ -296,6 +296,65 @@ struct Builder {
 };
 
 
+// ------------------------------------------------------------------------ 4-wide tree (topology)
+// The kernels walk a 4-wide tree (psdr_device.h Bvh4Node) derived from the BVH2: every 4-wide node adopts grandchildren of its BVH2 node
+// until it has four children, always opening the inner child with the largest box (the greedy surface-area collapse).  Only the
+// TOPOLOGY is decided here; the quantised boxes are (re)computed on the device from the BVH2 nodes after every build and refit
+// (psdr_hip.hip k_bvh4_fill): child[i][c] = 4-wide node index / leaf code / kNoChild, src[i][c] = 2 * (BVH2 node holding the box) + side.
+// Nodes come out in level order across all roots (a prefix = the top of every tree: LDS staging).
+struct Bvh4Topology {
+    std::vector<int32_t> child, src;      // [n4][4]
+    std::vector<int32_t> roots;           // per BVH2 root: 4-wide root (encoded like a child)
+    int n4 = 0, stack_need = 0;           // traversal-stack entries a walk can need (worst case over all root-to-leaf paths) 
+};
+inline void collapse_bvh4(const std::vector<BvhNode> &nodes, const std::vector<int32_t> &roots2, Bvh4Topology &out) {
+    out.child.clear(); out.src.clear(); out.roots.clear(); out.n4 = 0; out.stack_need = 0;
+    std::vector<int32_t> queue;                       // BVH2 node of every 4-wide node, in creation (= level) order
+    std::vector<int32_t> id4(nodes.size(), -1);
+    auto make = [&](int32_t n2) { id4[(size_t) n2] = (int32_t) queue.size(); queue.push_back(n2); return id4[(size_t) n2]; };
+    for (int32_t r : roots2) out.roots.push_back(r >= 0 ? make(r) : r);
+    auto area_of = [&](int32_t s) {
+        const BvhNode &n = nodes[(size_t) (s >> 1)];
+        const float *lo = (s & 1) ? n.lo1 : n.lo0, *hi = (s & 1) ? n.hi1 : n.hi0;
+        const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        return dx * dy + dy * dz + dz * dx;
+    };
+    auto child_of = [&](int32_t s) { const BvhNode &n = nodes[(size_t) (s >> 1)]; return (s & 1) ? n.c1 : n.c0; };
+    for (size_t q = 0; q < queue.size(); ++q) {
+        const int32_t n2 = queue[q];
+        int32_t slots[4] = {2 * n2, 2 * n2 + 1, -1, -1};
+        int cnt = 2;
+        while (cnt < 4) {
+            int best = -1; float best_area = -1.f;
+            for (int i = 0; i < cnt; ++i)
+                if (child_of(slots[i]) >= 0 && area_of(slots[i]) > best_area) { best_area = area_of(slots[i]); best = i; }
+            if (best < 0) break;
+            const int32_t c = child_of(slots[best]);
+            slots[best] = 2 * c; slots[cnt++] = 2 * c + 1;
+        }
+        for (int i = 0; i < 4; ++i) {
+            if (i >= cnt) { out.child.push_back(kNoChild); out.src.push_back(-1); continue; }
+            const int32_t c = child_of(slots[i]);
+            out.child.push_back(c >= 0 ? make(c) : c);
+            out.src.push_back(slots[i]);
+        }
+    }
+    out.n4 = (int) queue.size();
+    // stack entries: a node with k children leaves k - 1 of them on the stack while the walk is below one of them
+    std::vector<int> need((size_t) out.n4, 0);
+    for (int i = out.n4 - 1; i >= 0; --i) {
+        int k = 0, deepest = 0;
+        for (int c = 0; c < 4; ++c) {
+            const int32_t ch = out.child[(size_t) i * 4 + c];
+            if (ch == kNoChild) continue;
+            ++k;
+            if (ch >= 0) deepest = std::max(deepest, need[(size_t) ch]);
+        }
+        need[(size_t) i] = std::max(k - 1, 0) + deepest;
+    }
+    for (int32_t r : out.roots) if (r >= 0) out.stack_need = std::max(out.stack_need, need[(size_t) r]);
+}
+
 // ------------------------------------------------------------------- two-level tree (forest)
 // Scenes made of a few small meshes (walls, lights) and a few large ones (objects): every mesh with at least
 // kMinBlasTris triangles gets its OWN tree; the triangles of the others stay "inline" (tested by every ray in a

@@ -22,6 +22,23 @@ struct __attribute__((aligned(16))) BvhNode {
 };
 static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
 
+// What the kernels WALK: a 4-wide tree with quantised child boxes, one 64-byte line per node (round 3).  The walk of incoherent rays
+// is bound by the rate at which a CU gathers distinct cache lines (tools/micro/gather_rate.hip: ~2.3-2.9 cycles per line, 186 cycles
+// for the 64 node fetches of a wave, whatever the occupancy) -- four times the VALU time of a BVH2 step -- so the lever is FEWER LINES
+// PER RAY: four children per line instead of two, half the node visits.  The BVH2 above stays the master structure (SAH build, LBVH
+// build, device refit); the 4-wide nodes are derived from it on the device (psdr_hip.hip k_bvh4_fill) after every build / refit.
+//   child box c on axis a:  [org[a] + qlo[a].byte(c) * 2^(exps.byte(a) - 127),  org[a] + qhi[a].byte(c) * 2^(exps.byte(a) - 127)]
+//   (lower planes rounded down, upper planes rounded up: the boxes only grow)
+struct __attribute__((aligned(16))) Bvh4Node {
+    float org[3];
+    uint32_t exps;
+    uint32_t qlo[3], qhi[3];
+    int32_t child[4];          // >= 0: Bvh4Node index; < 0: leaf, encoded as in BvhNode; kNoChild: empty slot
+    uint32_t pad[2];
+};
+static_assert(sizeof(Bvh4Node) == 64, "Bvh4Node must be 64 bytes");
+constexpr int32_t kNoChild = 0x7ffffffe;
+
 constexpr int kBvhStack = 40;     // builder guarantees depth <= kBvhStack - 2
 constexpr int kBlock = 256;
 
@@ -30,9 +47,11 @@ constexpr int kMaxBlas = 16;
 constexpr int kMinBlasTris = 64;      // meshes below this size stay inline in the top level
 struct SceneView {
     psdr_scene_desc d;
-    const BvhNode *nodes;
+    const BvhNode *nodes;  // BVH2 (master structure; walked by the host tests only)
     const float4 *btris;
     int32_t root;          // encoded like a child (negative = single leaf)
+    const Bvh4Node *nodes4; // the 4-wide tree the kernels walk
+    int32_t root4;         // its root (encoded like a child); the roots of a two-level scene's trees: blas_hi[k].w
     // LDS-staged prefix of the scene (device only; offsets in bytes into the dynamic LDS block):
     // the first n_lnodes BVH nodes (breadth-first order = the top of the tree), the first
     // n_lbtris leaf triangles and the first n_ltri TriangleInfo rows.
@@ -51,7 +70,7 @@ struct SceneView {
     // and the tree boxes in a wave-uniform loop (SGPR operands, no divergence); only a ray whose segment [0, t_best]
     // enters a box walks that tree.  In a room most rays never do (cbox_bunny: 7-14 % of the bounce rays).
     int32_t n_blas;
-    float4 blas_lo[kMaxBlas], blas_hi[kMaxBlas];      // lo.w = root of the tree (encoded like a child)
+    float4 blas_lo[kMaxBlas], blas_hi[kMaxBlas];      // lo.w = root of the tree (encoded like a child), hi.w = its root in the 4-wide tree
     // kSceneTiny launches: EVERY table a path vertex reads is staged in LDS (byte offsets into the dynamic LDS block; same layouts as the
     // caller's tables) -- the per-vertex chain tri_mesh -> mesh_bsdf -> bsdf_rec -> texels and the emitter lookups are LDS reads (~64 clk)
     // instead of dependent global loads (~300-500 clk each).  lt_tex < 0: the texel pool is too large and stays in global memory.
@@ -273,6 +292,90 @@ PSDR_HD void walk_tree(const SceneView &sc, TraversalStack &st, const Vec3f &o, 
     }
 }
 
+// PSDR_WIDE_TREE (per translation unit: psdr_variant.hip sets it from the flag set, psdr_hip.hip uses 2): 1 = the kernels walk the 4-wide
+// quantised tree, 0 = the BVH2, 2 = both walks in the kernel, chosen per scene (SceneView::nodes4 != nullptr)
+#ifndef PSDR_WIDE_TREE
+#define PSDR_WIDE_TREE 0
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+// The walk of the 4-wide tree (device).  Same while-while structure as walk_tree: inner nodes until the lane holds a leaf, then the leaf
+// triangles.  Per node: one 64-byte fetch (LDS for the staged top of the tree), the slab test of the four children on the quantised
+// planes -- t = q * (scale * inv) + (org - o) * inv: one v_cvt_f32_ubyteN and one v_fma per plane --, the hit children ordered by entry
+// distance with a 5-exchange network on keys (entry distance bits | slot), the nearest visited next, the others pushed far-to-near.
+template <bool IGN = false>
+__device__ __forceinline__ void walk_tree4(const SceneView &sc, TraversalStack &st, const Vec3f &o, const Vec3f &d, const Vec3f &inv, int32_t root, Hit &best, int ig0 = -1, int ig1 = -1) {
+    int sp = 0;
+    int32_t cur = root;
+    constexpr int32_t kDone = 0x7fffffff;
+    while (cur != kDone) {
+        while (cur >= 0 && cur != kDone) {
+            Bvh4Node n;
+            if (cur < sc.n_lnodes) n = reinterpret_cast<const Bvh4Node *>(psdr_dyn_lds + sc.off_lnodes)[cur];
+            else n = sc.nodes4[cur];
+            const float ax = __int_as_float_hd((int) ((n.exps & 0xffu) << 23)) * inv.x, ay = __int_as_float_hd((int) (((n.exps >> 8) & 0xffu) << 23)) * inv.y,
+                        az = __int_as_float_hd((int) (((n.exps >> 16) & 0xffu) << 23)) * inv.z;
+            const float bx = (n.org[0] - o.x) * inv.x, by = (n.org[1] - o.y) * inv.y, bz = (n.org[2] - o.z) * inv.z;
+            // the ray enters through the lower plane of an axis it travels up along, through the upper plane otherwise: near / far planes
+            // picked once per node (six selects on the packed plane words) instead of a min and a max per child and axis
+            const bool px = inv.x >= 0.f, py = inv.y >= 0.f, pz = inv.z >= 0.f;
+            const uint32_t nx = px ? n.qlo[0] : n.qhi[0], fx = px ? n.qhi[0] : n.qlo[0];
+            const uint32_t ny = py ? n.qlo[1] : n.qhi[1], fy = py ? n.qhi[1] : n.qlo[1];
+            const uint32_t nz = pz ? n.qlo[2] : n.qhi[2], fz = pz ? n.qhi[2] : n.qlo[2];
+            uint32_t key[4]; int32_t ch[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float tnx = (float) ((nx >> (8 * c)) & 0xffu) * ax + bx, tfx = (float) ((fx >> (8 * c)) & 0xffu) * ax + bx;
+                const float tny = (float) ((ny >> (8 * c)) & 0xffu) * ay + by, tfy = (float) ((fy >> (8 * c)) & 0xffu) * ay + by;
+                const float tnz = (float) ((nz >> (8 * c)) & 0xffu) * az + bz, tfz = (float) ((fz >> (8 * c)) & 0xffu) * az + bz;
+                // NaNs (0 * inf, inf - inf) drop out of fmin / fmax: that slab then does not cut -- conservative, as in slab()
+                const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.f));
+                const float tf = fminf(fminf(tfx, tfy), fminf(tfz, best.t));
+                const bool hit = tn <= tf && n.child[c] != kNoChild;
+                key[c] = hit ? (uint32_t) __float_as_int_hd(tn) : 0xffffffffu;        // tn >= 0: the bit pattern orders like the value
+                ch[c] = n.child[c];
+            }
+            // order the (entry distance, child) pairs: 5 exchanges
+            auto cx = [&](int i, int j) {
+                const bool sw = key[j] < key[i];
+                const uint32_t ki = sw ? key[j] : key[i], kj = sw ? key[i] : key[j]; const int32_t ci = sw ? ch[j] : ch[i], cj = sw ? ch[i] : ch[j];
+                key[i] = ki; key[j] = kj; ch[i] = ci; ch[j] = cj;
+            };
+            cx(0, 1); cx(2, 3); cx(0, 2); cx(1, 3); cx(1, 2);
+            if (key[3] != 0xffffffffu) st.put(sp++, ch[3]);
+            if (key[2] != 0xffffffffu) st.put(sp++, ch[2]);
+            if (key[1] != 0xffffffffu) st.put(sp++, ch[1]);
+            cur = key[0] != 0xffffffffu ? ch[0] : (sp > 0 ? st.get(--sp) : kDone);
+        }
+        if (cur == kDone) break;
+        {
+            const int enc = ~cur, first = enc >> 3, cnt = (enc & 7) + 1;
+            const bool staged = first + cnt <= sc.n_lbtris;
+            const float4 *lt = reinterpret_cast<const float4 *>(psdr_dyn_lds + sc.off_lbtris);
+            for (int i = 0; i < cnt; ++i) {
+                float4 a, b, c;
+                if (staged) { a = lt[(first + i) * 3]; b = lt[(first + i) * 3 + 1]; c = lt[(first + i) * 3 + 2]; }
+                else { a = sc.btris[(first + i) * 3]; b = sc.btris[(first + i) * 3 + 1]; c = sc.btris[(first + i) * 3 + 2]; }
+                leaf_triangle_test<IGN>(a, b, c, o, d, best, ig0, ig1);
+            }
+            cur = sp > 0 ? st.get(--sp) : kDone;
+        }
+    }
+}
+#endif
+// the tree walk of this build: the 4-wide tree on the device, the BVH2 on the host (tests/hostcheck, tools/simd_sim)
+template <bool IGN = false>
+PSDR_HD void walk(const SceneView &sc, TraversalStack &st, const Vec3f &o, const Vec3f &d, const Vec3f &inv, int32_t root2, int32_t root4, Hit &best, int ig0 = -1, int ig1 = -1) {
+#if defined(__HIP_DEVICE_COMPILE__) && PSDR_WIDE_TREE == 1
+    (void) root2; walk_tree4<IGN>(sc, st, o, d, inv, root4, best, ig0, ig1);
+#elif defined(__HIP_DEVICE_COMPILE__) && PSDR_WIDE_TREE == 2
+    // both walks in the kernel, chosen per scene (uniform): the 4-wide tree pays on large trees (50 k triangles: 5-8 %), not on a 5 k-triangle mesh
+    if (sc.nodes4 != nullptr) walk_tree4<IGN>(sc, st, o, d, inv, root4, best, ig0, ig1);
+    else walk_tree<IGN>(sc, st, o, d, inv, root2, best, ig0, ig1);
+#else
+    (void) root4; walk_tree<IGN>(sc, st, o, d, inv, root2, best, ig0, ig1);
+#endif
+}
+
 PSDR_HD bool blas_box(const SceneView &sc, int k, const Vec3f &o, const Vec3f &inv, float tmax, float &t_entry) {
     const float lo[3] = {sc.blas_lo[k].x, sc.blas_lo[k].y, sc.blas_lo[k].z}, hi[3] = {sc.blas_hi[k].x, sc.blas_hi[k].y, sc.blas_hi[k].z};
     return slab(lo, hi, o, inv, tmax, t_entry);
@@ -299,25 +402,25 @@ PSDR_HD Hit closest_hit(const SceneView &sc, TraversalStack &st, const Vec3f &o,
         // loops over SGPR operands, 16 VALU instructions per box
         if (sc.n_blas == 1) {
             float te;
-            if (blas_box(sc, 0, o, inv, best.t, te)) walk_tree<IGN>(sc, st, o, d, inv, __float_as_int_hd(sc.blas_lo[0].w), best, ig0, ig1);
+            if (blas_box(sc, 0, o, inv, best.t, te)) walk<IGN>(sc, st, o, d, inv, __float_as_int_hd(sc.blas_lo[0].w), __float_as_int_hd(sc.blas_hi[0].w), best, ig0, ig1);
             return best;
         }
         uint32_t cand = (1u << sc.n_blas) - 1u;
         while (cand) {
-            int32_t root = 0; float near_t = INFINITY; uint32_t pick = 0;
+            int32_t root = 0, root4 = 0; float near_t = INFINITY; uint32_t pick = 0;
             for (int k = 0; k < sc.n_blas; ++k) {
                 if (!((cand >> k) & 1u)) continue;
                 float te;
                 if (!blas_box(sc, k, o, inv, best.t, te)) cand &= ~(1u << k);
-                else if (te < near_t) { near_t = te; root = __float_as_int_hd(sc.blas_lo[k].w); pick = 1u << k; }
+                else if (te < near_t) { near_t = te; root = __float_as_int_hd(sc.blas_lo[k].w); root4 = __float_as_int_hd(sc.blas_hi[k].w); pick = 1u << k; }
             }
             if (!pick) break;
             cand &= ~pick;
-            walk_tree<IGN>(sc, st, o, d, inv, root, best, ig0, ig1);
+            walk<IGN>(sc, st, o, d, inv, root, root4, best, ig0, ig1);
         }
         return best;
     }
-    walk_tree<IGN>(sc, st, o, d, inv, sc.root, best, ig0, ig1);
+    walk<IGN>(sc, st, o, d, inv, sc.root, sc.root4, best, ig0, ig1);
     return best;
 }
 

@@ -1,6 +1,7 @@
 // psdr_hip.hip -- host side and C ABI of include/psdr_hip.h (+ k_trace).  The render kernels live in
 // psdr_kernels.h and are compiled per scene flag set in psdr_variant.hip; this file owns the scene
 // handle, the BVH build, the LDS plan and picks the kernel variant of the scene.
+#define PSDR_WIDE_TREE 2      // k_trace serves every scene: both walks, chosen by SceneView::nodes4
 #include "psdr_host.h"
 #include "psdr_bvh_build.h"
 
@@ -95,6 +96,54 @@ __global__ void k_gather_top(float4 *__restrict__ top, const BvhNode *__restrict
     }
 }
 
+// ------------------------------------------------------------------------ 4-wide tree (boxes)
+// One thread per 4-wide node: the boxes of its (up to) four children -- each stored in a BVH2 node (src = 2 * node + side) -- are
+// quantised to 8 bits per plane relative to their union: origin = lower corner, per-axis scale 2^e with 255 * 2^e >= extent, lower planes
+// rounded down, upper planes rounded up.  Runs after every build and refit of the BVH2 (a pure function of its boxes).
+__global__ __launch_bounds__(kBlock) void k_bvh4_fill(Bvh4Node *__restrict__ out, const BvhNode *__restrict__ nodes, const int32_t *__restrict__ child,
+                                                      const int32_t *__restrict__ src, int n4) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n4) return;
+    float lo[4][3], hi[4][3], org[3] = {INFINITY, INFINITY, INFINITY}, top[3] = {-INFINITY, -INFINITY, -INFINITY};
+    Bvh4Node n;
+    for (int c = 0; c < 4; ++c) {
+        n.child[c] = child[(size_t) i * 4 + c];
+        const int32_t s = src[(size_t) i * 4 + c];
+        if (s < 0) continue;
+        const BvhNode &b = nodes[s >> 1];
+        for (int a = 0; a < 3; ++a) {
+            lo[c][a] = (s & 1) ? b.lo1[a] : b.lo0[a]; hi[c][a] = (s & 1) ? b.hi1[a] : b.hi0[a];
+            org[a] = fminf(org[a], lo[c][a]); top[a] = fmaxf(top[a], hi[c][a]);
+        }
+    }
+    n.exps = 0; n.pad[0] = n.pad[1] = 0;
+    for (int a = 0; a < 3; ++a) {
+        n.org[a] = org[a];
+        n.qlo[a] = 0xffffffffu; n.qhi[a] = 0u;               // empty slots: lower plane above the upper one
+        const float ext = top[a] - org[a];
+        int e = 0;
+        (void) frexpf(ext * (1.f / 255.f), &e);               // ext / 255 = m * 2^e, m in [0.5, 1): 255 * 2^e >= ext
+        int E = min(max(e + 127, 1), 254);
+        for (;;) {
+            const float scale = __int_as_float(E << 23), inv = 1.f / scale;
+            uint32_t ql = 0, qh = 0; bool ok = true;
+            for (int c = 0; c < 4; ++c) {
+                if (src[(size_t) i * 4 + c] < 0) { ql |= 0xffu << (8 * c); continue; }
+                int l = (int) floorf((lo[c][a] - org[a]) * inv), u = (int) ceilf((hi[c][a] - org[a]) * inv);
+                l = max(min(l, 255), 0);
+                while (l > 0 && fmaf((float) l, scale, org[a]) > lo[c][a]) --l;                   // the dequantised plane must not cut into the box
+                while (u <= 255 && fmaf((float) u, scale, org[a]) < hi[c][a]) ++u;
+                if (u > 255) { ok = false; break; }
+                ql |= (uint32_t) l << (8 * c); qh |= (uint32_t) max(u, 0) << (8 * c);
+            }
+            if (ok || E >= 254) { n.qlo[a] = ql; n.qhi[a] = qh; break; }
+            ++E;
+        }
+        n.exps |= (uint32_t) E << (8 * a);
+    }
+    out[i] = n;
+}
+
 // --------------------------------------------------------------------- primary-edge slot order
 // A primary-edge slot draws a random silhouette edge, so consecutive slots land on unrelated pixels and
 // the two Li evaluations of a wave start from 64 unrelated camera rays.  The sample streams are stateless
@@ -129,6 +178,8 @@ thread_local std::string g_err;
 }  // namespace
 
 namespace psdr_host {
+int bvh4_refill(psdr_scene_s *h, hipStream_t s);
+int bvh4_build(psdr_scene_s *h, const std::vector<BvhNode> &nodes, const std::vector<int32_t> &roots2, bool forest, hipStream_t s);
 int fail(const std::string &m) { g_err = m; return 1; }
 
 // Grid of the grid-stride kernels: at most per_cu workgroups per CU (16 by default; the forward camera kernels
@@ -161,8 +212,18 @@ static bool tiny_tables_ok(const psdr_scene_s *h) {
     return enabled && tiny_only(h) && d.env_emitter < 0 && d.num_meshes <= 64 && d.num_bsdfs <= 32 && d.num_emitters >= 0 && d.num_emitters <= 8 &&
            (d.num_emitters == 0 || (d.face_cmf && d.face_pmf)) && emitter_faces(h) <= 64;
 }
+// Which tree the launches on this scene walk: the 4-wide quantised tree exactly where the scene's kernel variant is compiled for it (flag set 6:
+// rough conductor + two-level tree, psdr_variant.hip) -- measured 5-10 % ahead on the 50 k-triangle interior, level or behind elsewhere
+// (profiles/r03_bvh4_ab.txt).  k_trace (this unit) carries both walks and follows the scene.
+static bool use_wide_tree(const psdr_scene_s *h, bool forest) {
+    static const int forced = std::getenv("PSDR_WIDE") ? std::atoi(std::getenv("PSDR_WIDE")) : -1;      // 0: never (the variant-6 kernels then cannot run: tools only)
+    if (forced == 0) return false;
+    return forest && h->has_rough && h->desc.env_emitter < 0;
+}
+
 // traversal-stack entries per lane: none when no launch on this scene ever walks a tree
-static int stack_entries_of(const psdr_scene_s *h) { return tiny_only(h) ? 0 : std::min(kBvhStack, h->bvh_depth + 2); }
+static int stack_entries_of(const psdr_scene_s *h) { return tiny_only(h) ? 0 : (h->wide ? h->stack_need4 + 1 : std::min(kBvhStack, h->bvh_depth + 2)); }
+static int staged_nodes_of(const psdr_scene_s *h) { return h->wide ? h->num_nodes4 : h->num_nodes; }
 int plan_lds(const psdr_scene_s *h, LaunchCtx &cx, int reserved) {
     // the plain diffuse variant runs renderC at 5 workgroups per CU: 28 KB each (C4 PathTracer(3) 40.0 -> 37.6 ms,
     // C3 3.26 -> 3.15 ms; 32 KB is already one workgroup less)
@@ -173,11 +234,11 @@ int plan_lds(const psdr_scene_s *h, LaunchCtx &cx, int reserved) {
     int room = std::max(0, budget - reserved - stack_bytes);
     // a scene without a tree (all primitives in the kernel arguments) ALWAYS stages its <= 16 TriangleInfo rows (1.5 KB): the kSceneTiny
     // kernel instances have no global-memory fallback for them (psdr_device.h load_tri_f)
-    if (tiny_only(h)) room = std::max(room, h->num_nodes * 64 + h->num_btris * 48 + h->desc.num_tris * 96);
+    if (tiny_only(h)) room = std::max(room, staged_nodes_of(h) * 64 + h->num_btris * 48 + h->desc.num_tris * 96);
     SceneView &sc = cx.sc;
     int off = 0;
-    sc.n_lnodes = std::min(h->num_nodes, room / 64); sc.off_lnodes = off; off += sc.n_lnodes * 64; room -= sc.n_lnodes * 64;
-    sc.n_lbtris = (sc.n_lnodes == h->num_nodes) ? std::min(h->num_btris, room / 48) : 0;
+    sc.n_lnodes = std::min(staged_nodes_of(h), room / 64); sc.off_lnodes = off; off += sc.n_lnodes * 64; room -= sc.n_lnodes * 64;      // 4-wide nodes
+    sc.n_lbtris = (sc.n_lnodes == staged_nodes_of(h)) ? std::min(h->num_btris, room / 48) : 0;
     sc.off_lbtris = off; off += sc.n_lbtris * 48; room -= sc.n_lbtris * 48;
     sc.n_ltri = (sc.n_lbtris == h->num_btris) ? std::min(h->desc.num_tris, room / 96) : 0;
     sc.off_ltri = off; off += sc.n_ltri * 96;
@@ -211,6 +272,8 @@ void fill_top(const psdr_scene_s *h, SceneView &sc) {
     sc.n_blas = h->n_blas;
     std::memcpy(sc.blas_lo, h->blas_lo, sizeof(h->blas_lo));
     std::memcpy(sc.blas_hi, h->blas_hi, sizeof(h->blas_hi));
+    for (int k = 0; k < h->n_blas; ++k) std::memcpy(&sc.blas_hi[k].w, &h->blas_root4[k], 4);
+    sc.nodes4 = h->wide ? h->d_nodes4 : nullptr; sc.root4 = h->root4;
 }
 
 int make_ctx(psdr_scene_s *h, const psdr_render_opts *o, int sampler, LaunchCtx &cx) {
@@ -286,8 +349,24 @@ SinkLayout make_sink_layout(const psdr_scene_s *h, const psdr_grads *g) {
     return L;
 }
 
+// The tree kind follows the kernel variant, the variant follows material_mask -- which psdr_scene_set_tables can change without a rebuild (a
+// scene that gains or loses its rough conductors): bring the 4-wide tree in line before the launch (one read-back of the BVH2 nodes + the collapse).
+int ensure_tree_kind(psdr_scene_s *h, hipStream_t s) {
+    if (!h->have_bvh || h->num_nodes <= 0) return 0;
+    const bool forest = h->n_blas > 0;
+    if (use_wide_tree(h, forest) == h->wide) return 0;
+    std::vector<BvhNode> host_nodes((size_t) h->num_nodes);
+    HIP_TRY(hipMemcpyAsync(host_nodes.data(), h->d_nodes, host_nodes.size() * sizeof(BvhNode), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    std::vector<int32_t> roots;
+    if (forest) for (int k = 0; k < h->n_blas; ++k) { int32_t r; std::memcpy(&r, &h->blas_lo[k].w, 4); roots.push_back(r); }
+    else roots.push_back(h->root);
+    return bvh4_build(h, host_nodes, roots, forest, s);
+}
+
 int begin_call(psdr_scene_s *h, hipStream_t s) {
     h->last_stream = s;
+    if (int rc = ensure_tree_kind(h, s)) return rc;
     h->slots[0] = h->slots[1] = h->slots[2] = 0; h->last_path_depth = 0;
     HIP_TRY(hipMemsetAsync(h->d_counters, 0, sizeof(unsigned long long) * kRayCounters * kRayCounterStride, s));
     return 0;
@@ -447,9 +526,49 @@ int lbvh_build(psdr_scene_s *h, hipStream_t s, bool &fallback) {
     h->hot_rows = (int) tris.size();
     h->root = 0; h->bvh_depth = info.depth; h->num_nodes = T - 1; h->num_btris = T;
     h->n_tiny = 0; h->n_blas = 0; h->n_inline = 0;
+    {   // the 4-wide tree over the device-built BVH2: its topology is decided on the host (one read-back of the node array; the collapse is
+        // O(T)): 263 k triangles +~15 ms on top of the 2 ms device build -- still an order below the host SAH build
+        std::vector<BvhNode> host_nodes((size_t) T - 1);
+        HIP_TRY(hipMemcpyAsync(host_nodes.data(), h->d_nodes, host_nodes.size() * sizeof(BvhNode), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (int rc = bvh4_build(h, host_nodes, std::vector<int32_t>{0}, false, s)) return rc;
+    }
     h->tree_tris = T; h->refits_since_build = 0; h->num_builds++; h->bvh_pad = info.pad; h->built_area = area;
     h->level_start.clear();
     h->refit_ok = true; h->lbvh = true; h->have_bvh = true;
+    return 0;
+}
+
+// The 4-wide tree over the BVH2 now on the device (`nodes` = its host copy, `roots2` = its roots): collapse on the host, topology up,
+// boxes by k_bvh4_fill.  bvh4_refill: the boxes again after a refit of the BVH2.
+int bvh4_refill(psdr_scene_s *h, hipStream_t s) {
+    if (h->num_nodes4 <= 0) return 0;
+    hipLaunchKernelGGL(k_bvh4_fill, dim3((h->num_nodes4 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, h->d_nodes4, h->d_nodes, h->d_topo4,
+                       h->d_topo4 + (size_t) h->num_nodes4 * 4, h->num_nodes4);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+int bvh4_build(psdr_scene_s *h, const std::vector<BvhNode> &nodes, const std::vector<int32_t> &roots2, bool forest, hipStream_t s) {
+    h->wide = use_wide_tree(h, forest);
+    if (!h->wide) { h->num_nodes4 = 0; h->stack_need4 = 0; return 0; }
+    Bvh4Topology tp;
+    collapse_bvh4(nodes, roots2, tp);
+    h->num_nodes4 = tp.n4; h->stack_need4 = tp.stack_need;
+    h->root4 = roots2.size() == 1 ? tp.roots[0] : 0;
+    for (size_t k = 0; k < roots2.size() && k < (size_t) kMaxBlas; ++k) h->blas_root4[k] = tp.roots[k];
+    if (tp.n4 == 0) return 0;
+    if ((size_t) tp.n4 > h->cap_nodes4) {
+        if (h->d_nodes4) (void) hipFree(h->d_nodes4);
+        if (h->d_topo4) (void) hipFree(h->d_topo4);
+        h->d_nodes4 = nullptr; h->d_topo4 = nullptr;
+        h->cap_nodes4 = (size_t) tp.n4;
+        HIP_TRY(hipMalloc(&h->d_nodes4, h->cap_nodes4 * sizeof(Bvh4Node)));
+        HIP_TRY(hipMalloc(&h->d_topo4, h->cap_nodes4 * 8 * sizeof(int32_t)));
+    }
+    HIP_TRY(hipMemcpyAsync(h->d_topo4, tp.child.data(), (size_t) tp.n4 * 4 * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(h->d_topo4 + (size_t) tp.n4 * 4, tp.src.data(), (size_t) tp.n4 * 4 * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    if (int rc = bvh4_refill(h, s)) return rc;
+    HIP_TRY(hipStreamSynchronize(s));              // the topology vectors die at return
     return 0;
 }
 
@@ -514,6 +633,8 @@ int psdr_scene_destroy(psdr_scene_t h) {
     if (h->d_top) (void) hipFree(h->d_top);
     if (h->d_inline_ids) (void) hipFree(h->d_inline_ids);
     if (h->d_lbvh) (void) hipFree(h->d_lbvh);
+    if (h->d_nodes4) (void) hipFree(h->d_nodes4);
+    if (h->d_topo4) (void) hipFree(h->d_topo4);
     if (h->d_rev) (void) hipFree(h->d_rev);
     if (h->d_se_list) (void) hipFree(h->d_se_list);
     if (h->d_rev_deep) (void) hipFree(h->d_rev_deep);
@@ -570,6 +691,7 @@ int psdr_bvh_build(psdr_scene_t h, void *stream) {
         if (prev_area <= kRefitAreaGrowth * h->built_area && h->lbvh) {
             h->refit_stream = s;
             if (int rc = lbvh_refit(h, s)) return rc;
+            if (int rc = bvh4_refill(h, s)) return rc;
             h->refits_since_build++;
             h->num_refits++;
             h->have_bvh = true;
@@ -586,6 +708,7 @@ int psdr_bvh_build(psdr_scene_t h, void *stream) {
                                    h->d_refit_area);
             }
             HIP_TRY(hipGetLastError());
+            if (int rc = bvh4_refill(h, s)) return rc;          // the 4-wide nodes from the refitted boxes
             if (h->n_blas > 0) {          // the kernel arguments carry the inline primitives and the tree boxes: fetch the refitted ones
                 float4 top[kMaxInlineTris * 3 + 2 * kMaxBlas];
                 hipLaunchKernelGGL(k_gather_top, dim3(1), dim3(64), 0, s, h->d_top, h->d_nodes, h->desc.tri_info, h->d_inline_ids, h->n_inline, h->n_blas);
@@ -689,6 +812,7 @@ int psdr_bvh_build(psdr_scene_t h, void *stream) {
     }
     h->root = root;
     h->bvh_depth = forest ? fb.max_depth : b.max_depth; h->num_nodes = (int) nodes.size(); h->num_btris = (int) btris.size() / 3;
+    if (int rc = bvh4_build(h, nodes, forest ? fb.roots : std::vector<int32_t>{root}, forest, s)) return rc;
     h->have_bvh = true;
     h->n_tiny = 0; h->n_blas = 0; h->n_inline = 0;
     if (forest) {

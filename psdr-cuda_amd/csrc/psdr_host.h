@@ -35,7 +35,8 @@ __device__ __forceinline__ void setup_lds(const LaunchCtx &cx, TraversalStack &s
 #if defined(__HIP_DEVICE_COMPILE__)
     const SceneView &sc = cx.sc;
     float4 *dst = reinterpret_cast<float4 *>(psdr_dyn_lds);
-    const float4 *src = reinterpret_cast<const float4 *>(sc.nodes);
+    // the top of the tree this launch walks (level order): 4-wide nodes or BVH2 nodes, 64 bytes either way
+    const float4 *src = sc.nodes4 != nullptr ? reinterpret_cast<const float4 *>(sc.nodes4) : reinterpret_cast<const float4 *>(sc.nodes);
     for (int i = threadIdx.x; i < sc.n_lnodes * 4; i += kBlock) dst[sc.off_lnodes / 16 + i] = src[i];
     for (int i = threadIdx.x; i < sc.n_lbtris * 3; i += kBlock) dst[sc.off_lbtris / 16 + i] = sc.btris[i];
     src = reinterpret_cast<const float4 *>(sc.d.tri_info);
@@ -142,6 +143,13 @@ struct psdr_scene_s {
     int32_t root = 0;
     bool have_bvh = false;
     int bvh_depth = 0, num_nodes = 0, num_btris = 0;
+    // the 4-wide tree the kernels walk (psdr_device.h Bvh4Node): topology from the host collapse, boxes from k_bvh4_fill
+    Bvh4Node *d_nodes4 = nullptr;
+    int32_t *d_topo4 = nullptr;            // [n4][4] child, then [n4][4] src
+    size_t cap_nodes4 = 0;
+    int num_nodes4 = 0, stack_need4 = 0;
+    bool wide = false;                     // launches on this scene walk the 4-wide tree (psdr_hip.hip use_wide_tree)
+    int32_t root4 = 0, blas_root4[kMaxBlas] = {};
     // device refit of the tree between rebuilds (psdr_hip.hip k_refit_*)
     bool refit_enabled = true;
     int tree_tris = -1, refits_since_build = 0, num_builds = 0, num_refits = 0;
