@@ -300,16 +300,20 @@ int check_counts(const psdr_scene_s *h, const psdr_render_opts *o) {
     return 0;
 }
 
-// Strategy choice.  Measured on MI355X (tools/perf_cases.py): in a closed box almost every path
-// survives, compaction buys nothing and the fused kernel is 1.1-1.9x faster; in an open scene
-// (bunny_light: 2.5 of 7 possible rays per path) the wavefront is 1.35x faster.  The library keeps
-// the survival ratio of the previous PathTracer call on this handle and switches on it.
+// Strategy choice: a PURE FUNCTION of the scene and the options (round 3; it used to follow the survival ratio the previous PathTracer
+// call on the handle had measured, so the same call could run either strategy depending on the call history -- and the two agree only
+// to the rounding of separately compiled fp32 kernels, up to 1e-3 on a low-spp GGX scene where one firefly sample flips).
+// Measured on MI355X (tools/perf_cases.py): in a closed room almost every path survives every bounce, compaction buys nothing and the
+// fused kernel is 1.1-1.9x ahead; in an open scene (bunny_light: 2.5 of 7 possible rays per path) the wavefront is 1.35-1.5x ahead.
+// "Room" = what psdr_bvh_build recognised as one: all primitives in the kernel arguments (the Cornell box) or a two-level tree (>= 6 inline
+// wall triangles around the meshes); everything else (objects under a light, height fields, environment-lit scenes) counts as open.
+bool open_scene(const psdr_scene_s *h) { return !(h->n_blas > 0 || (h->n_tiny > 0 && h->n_blas == 0)); }
 bool use_wavefront(const psdr_scene_s *h, const psdr_render_opts *o) {
     if (o->integrator != PSDR_INTEGRATOR_PATH || o->max_depth > 250) return false;
     if (o->flags & PSDR_FLAG_FUSED) return false;
     if (o->flags & PSDR_FLAG_WAVEFRONT) return true;
-    if (o->max_depth < 2 || h->path_survival < 0.f) return false;
-    if (h->path_survival < 0.55f) return true;                      // open scene: most paths die early, compaction pays
+    if (o->max_depth < 2) return false;
+    if (open_scene(h)) return true;                                 // most paths die early, compaction pays
     // closed two-level scene (a room with objects), large launch: the class-binned wavefront (psdr_kernels.h) is ahead of
     // the fused kernel -- C4 shard (67 M slots) 27.5 against 29.6 ms; at 4 M slots its extra launches and stream traffic
     // cost more than they save (3.7 against 2.9 ms)
@@ -953,8 +957,6 @@ int psdr_get_counters(psdr_scene_t h, uint64_t out[4]) {
     HIP_TRY(hipStreamSynchronize(h->last_stream));
     for (int i = 0; i < kRayCounters; ++i) c[0] += all[i * kRayCounterStride];
     out[0] = c[0]; out[1] = h->slots[0]; out[2] = h->slots[1]; out[3] = h->slots[2];
-    if (h->last_path_depth > 0 && h->slots[0] > 0 && h->slots[1] == 0 && h->slots[2] == 0)
-        h->path_survival = (float) ((double) c[0] / ((double) h->slots[0] * (1.0 + 2.0 * h->last_path_depth)));
     return 0;
 }
 

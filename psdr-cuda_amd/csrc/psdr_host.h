@@ -183,7 +183,6 @@ struct psdr_scene_s {
     hipStream_t refit_stream = nullptr;    // stream of the last device refit
     uint64_t slots[3] = {0, 0, 0};
     int last_path_depth = 0;
-    float path_survival = -1.f;            // rays traced / rays of fully surviving paths (last PathTracer call)
 
     // reverse-mode gradient sink: triangle rows cached in LDS (chosen at build time)
     std::vector<int32_t> emitter_i;        // host copy of desc.emitter_i (the emitter meshes' rows are hot)

@@ -868,8 +868,7 @@ int run_camera_wavefront(psdr_scene_s *h, const psdr_render_opts *o, const TV<M,
     // class-binned streams pay where most paths survive every bounce (rooms); in an open scene the streams thin out quickly and the 64
     // sub-streams of mostly empty chunks cost more than the classes save (bunny_light PathTracer(3) 4.9 against 3.3 ms plain,
     // PathTracer(6) 8.7 against 3.6)
-    const bool open_scene = h->path_survival >= 0.f && h->path_survival < 0.55f;
-    const bool binned = (FL & kSceneForest) != 0 && h->n_blas > 0 && h->wf_binned && !open_scene;
+    const bool binned = (FL & kSceneForest) != 0 && h->n_blas > 0 && h->wf_binned;          // a two-level scene is a room (use_wavefront)
     const long long cap = std::min(n, binned ? kWfChunk / 2 : kWfChunk);
     const int depth = o->max_depth;
     const size_t words = 8 + 6 * (1 + K);

@@ -253,12 +253,10 @@ class Integrator(Object):
         return grads
 
     def _counters(self, lib, scene):
-        """The counters stay on the device until somebody looks (last_counters); the library's fused-vs-wavefront choice
-        for PathTracer calls feeds on them, so the first calls on a scene and every 64th fetch them."""
+        """The counters stay on the device until somebody looks (last_counters): no render call reads them back (the library's
+        fused-vs-wavefront choice is a function of the scene and the options, not of earlier calls)."""
         self._counters_src, self._counters_val = (lib, scene), None
         self._calls += 1
-        if self._kind == _abi.INTEGRATOR_PATH and (self._calls <= 2 or self._calls % 64 == 0):
-            _ = self.last_counters
 
     # ---- public API (src/psdr.cpp:282-285) -------------------------------------------
     def renderC(self, scene, sensor_id=0):

@@ -27,7 +27,7 @@ def test_c2_render_c_and_albedo_gradient_match_oracle(c2):
     o = _abi.make_opts(integrator=_abi.INTEGRATOR_PATH, max_depth=3, spp=SPP)
     img = g.render_c(o)
     ref = oracle.render(tb, o)
-    assert rel_l2(img, ref) < 2e-3, rel_l2(img, ref)
+    assert rel_l2(img, ref) < 1e-4, rel_l2(img, ref)
     assert abs(img.mean() - ref.mean()) < 1e-4 * ref.mean()
     # d image / d albedo(r,g,b) of BSDF[0] (white walls) in ONE K=3 pass; gradient of loss = sum(image)
     sets = []
@@ -106,5 +106,15 @@ def test_c4_one_gpu_share_of_1024x1024_spp512():
     tb3 = sc3.tables(0)
     o3 = _abi.make_opts(spp_range=(64, 128), **kw)
     a, b = GpuScene(tb3).render_c(o3), oracle.render(tb3, o3)
-    bad = (np.abs(a - b).max(1) > 1e-3 * (1 + np.abs(b).max(1))).mean()
-    assert bad < 0.01 and rel_l2(a, b) < 2e-2
+    bad = np.abs(a - b).max(1) > 1e-3 * (1 + np.abs(b).max(1))                       # pixels holding a sample that resolved a tie the other way
+    assert bad.mean() < 0.005 and rel_l2(a[~bad], b[~bad]) < 1e-3, (bad.mean(), rel_l2(a[~bad], b[~bad]))
+
+
+@pytest.mark.parametrize("res,spp", [(128, 1), (128, 4)])
+def test_c1_literal_size_direct_render_c(res, spp):
+    """BASELINE config C1 at its literal size: cbox 128x128, spp = 1, DirectIntegrator.renderC (the reference's CPU-runnable plumbing case)."""
+    sc, _ = load_scene("cbox", res=res, spp=spp)
+    tb = sc.tables(0)
+    o = _abi.make_opts(bsdf_samples=1, light_samples=1, spp=spp)
+    img, ref = GpuScene(tb).render_c(o), oracle.render(tb, o)
+    assert img.shape == (res * res, 3) and rel_l2(img, ref) < 1e-4, rel_l2(img, ref)
