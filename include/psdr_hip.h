@@ -164,6 +164,12 @@ typedef struct psdr_scene_desc {
    compaction of the live paths between bounces (renderC and material-only renderD). */
 #define PSDR_FLAG_FUSED     1
 #define PSDR_FLAG_WAVEFRONT 2
+/* Evaluate the three expressions the library replaces by fp32-robust equivalents in the reference's LITERAL
+   form instead: the solid-angle hit point as p = ray(t) (scene.cpp:368), the rays that start on a secondary edge without skipping
+   the adjacent faces (direct.cpp:246-254; as if sec_edge_faces were NULL), and "the camera sees p1" as the fp32 distance
+   |its1.p - p1| < ShadowEpsilon (direct.cpp:262).  psdr_render_c / psdr_render_d_fwd only (reverse mode has no literal-form adjoint):
+   makes the difference between the two forms measurable on the device against the oracle's reference_form. */
+#define PSDR_FLAG_LITERAL_FORMS 4
 
 /* One render call = Integrator::renderC / renderD on one shard of the sample
    slots (src/integrator/integrator.cpp:13-119, src/integrator/direct.cpp). */

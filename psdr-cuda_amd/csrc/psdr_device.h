@@ -76,6 +76,7 @@ struct SceneView {
     // instead of dependent global loads (~300-500 clk each).  lt_tex < 0: the texel pool is too large and stays in global memory.
     int32_t lt_trimesh, lt_meshbsdf, lt_meshemitter, lt_bsdf, lt_emf, lt_emi, lt_fcmf, lt_fpmf, lt_uv, lt_tex, lt_ecmf, lt_epmf;
     int32_t lt_nfaces, lt_end;                          // entries of face_cmf / face_pmf staged; end of the block (bytes)
+    int32_t literal_forms;                              // PSDR_FLAG_LITERAL_FORMS: the reference's literal fp32 expressions (psdr_hip.h)
 };
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -556,7 +557,7 @@ template <class R, class TVT> PSDR_HD Its<R> intersect(const SceneView &sc, cons
         // continuation ray that starts below it re-hits its own face above RayEpsilon = 1e-3 -- a one-sided loss of
         // ~2e-3 of the interior gradient in ANY fp32 evaluation of the literal form (fp32 against fp64,
         // tests/test_projections_gpu.py); with the point on the surface fp32 agrees with fp64 to ~1e-4.
-        its.p = bary_point(T.p0, T.e1, T.e2, bu, bv);
+        its.p = sc.literal_forms ? ray.o + ray.d * t : bary_point(T.p0, T.e1, T.e2, bu, bv);        // literal: scene.cpp:368
         its.t = t;
         its.sh = Frame<R>(sh_n);
         its.wi = its.sh.to_local(-ray.d);
@@ -1281,7 +1282,8 @@ PSDR_HD bool secondary_edge_survives(const SceneView &sc, TraversalStack &st, co
     const int sgn0 = d0n > kEdgeEpsilon ? 1 : (d0n < -kEdgeEpsilon ? -1 : 0), sgn1 = d1n > kEdgeEpsilon ? 1 : (d1n < -kEdgeEpsilon ? -1 : 0);
     bool valid = cosTheta > kEpsilon && (is_boundary ? sgn0 != 0 : sgn0 * sgn1 < 0);
     const Vec3f dir = normalize(p2 - p0);
-    const int f0 = sc.d.sec_edge_faces ? sc.d.sec_edge_faces[2 * k] : -1, f1 = sc.d.sec_edge_faces ? sc.d.sec_edge_faces[2 * k + 1] : -1;
+    const bool skip = sc.d.sec_edge_faces != nullptr && !sc.literal_forms;
+    const int f0 = skip ? sc.d.sec_edge_faces[2 * k] : -1, f1 = skip ? sc.d.sec_edge_faces[2 * k + 1] : -1;
     const Its<float> its2 = intersect<float>(sc, tv0, st, RayT<float>{p0, dir}, valid, kDetached, nrays, f0, f1);
     valid = valid && its2.valid && norm(its2.p - p2) < kShadowEpsilon;
     const Its<float> its1c = intersect<float>(sc, tv0, st, RayT<float>{p0, -dir}, valid, kDetached, nrays, f0, f1);
@@ -1320,7 +1322,8 @@ PSDR_HD int secondary_edge_sample(const SceneView &sc, const TVT &tv, TraversalS
     // -- eval_secondary_edge
     const Vec3f dir = normalize(p2 - p0);
     // the two rays that start ON the edge skip its adjacent faces when the caller supplies them (psdr_hip.h sec_edge_faces)
-    const int f0 = sc.d.sec_edge_faces ? sc.d.sec_edge_faces[2 * k] : -1, f1 = sc.d.sec_edge_faces ? sc.d.sec_edge_faces[2 * k + 1] : -1;
+    const bool skip = sc.d.sec_edge_faces != nullptr && !sc.literal_forms;
+    const int f0 = skip ? sc.d.sec_edge_faces[2 * k] : -1, f1 = skip ? sc.d.sec_edge_faces[2 * k + 1] : -1;
     uint32_t counted_before = 0;                 // split launch: secondary_edge_survives already traced (and counted) these two
     uint32_t &n12 = count_first ? nrays : counted_before;
     const Its<float> its2 = intersect<float>(sc, tv0, st, RayT<float>{p0, dir}, valid, kDetached, n12, f0, f1);
@@ -1338,7 +1341,9 @@ PSDR_HD int secondary_edge_sample(const SceneView &sc, const TVT &tv, TraversalS
     // other only to fp32 accuracy) carry the ray from p1 on a grazing surface 1000 units away -- of the order of
     // ShadowEpsilon itself.  In fp32 the decision flips for high-weight samples (5e-3 of the cbox_bunny boundary
     // term against an fp64 evaluation); camera_return_distance evaluates the same quantity in double.
-    if (!(its1.valid && camera_return_distance(sc, its1c.tri, its1c.hu, its1c.hv, its1.tri) < (double) kShadowEpsilon)) return -1;
+    if (!its1.valid) return -1;
+    if (sc.literal_forms) { if (!(norm(val(its1.p) - p1) < kShadowEpsilon)) return -1; }                 // direct.cpp:262 as written
+    else if (!(camera_return_distance(sc, its1c.tri, its1c.hu, its1c.hv, its1.tri) < (double) kShadowEpsilon)) return -1;
     const float dist = norm(p2 - p1), cos2 = fabsf(dot(bn, dir));
     const Vec3f ev = cross(edge, dir);
     const float sinphi = norm(ev);

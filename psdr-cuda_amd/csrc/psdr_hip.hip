@@ -285,6 +285,7 @@ int make_ctx(psdr_scene_s *h, const psdr_render_opts *o, int sampler, LaunchCtx 
     cx.sc.d = h->desc; cx.sc.nodes = h->d_nodes; cx.sc.btris = h->d_btris; cx.sc.root = h->root;
     fill_top(h, cx.sc);
     plan_lds(h, cx);
+    cx.sc.literal_forms = (o->flags & PSDR_FLAG_LITERAL_FORMS) ? 1 : 0;
     cx.lp = LiParams{o->integrator, o->bsdf_samples, o->light_samples, o->max_depth, o->hide_emitters, o->field};
     cx.jump = make_rng_jump(o->rng_offset[sampler]);
     return 0;
@@ -912,6 +913,7 @@ int psdr_render_d_rev(psdr_scene_t h, const psdr_render_opts *o, const float *ad
     if (!h || !o || !adj_img || !grads) return fail("psdr_render_d_rev: null argument");
     if (!h->have_tables) return fail("Scene not loaded yet!");
     if (int rc = check_counts(h, o)) return rc;
+    if (o->flags & PSDR_FLAG_LITERAL_FORMS) return fail("psdr_render_d_rev: PSDR_FLAG_LITERAL_FORMS is a forward-mode diagnostic (no literal-form adjoint)");
     if (o->integrator == PSDR_INTEGRATOR_PATH && o->max_depth > kMaxRevDepthDeep)
         return fail("psdr_render_d_rev: PathTracer max_depth > 250 is not supported in reverse mode");
     hipStream_t s = (hipStream_t) stream;

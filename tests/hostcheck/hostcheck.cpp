@@ -63,6 +63,7 @@ int hostcheck_render(const psdr_scene_desc *d, const psdr_render_opts *o, int mo
                      int nthreads) {
     HostScene hs;
     if (!setup(hs, d)) return 1;
+    hs.sc.literal_forms = (o->flags & PSDR_FLAG_LITERAL_FORMS) ? 1 : 0;
     const int W = d->width, H = d->height;
     const long long WH = (long long) W * H;
     const size_t n3 = (size_t) WH * 3;

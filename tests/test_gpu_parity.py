@@ -263,3 +263,40 @@ def test_wavefront_zeroes_whole_samples_like_the_fused_kernel():
         lost = (a[:, 0] < clean[:, 0] - 1e-4).mean()                     # samples zeroed in the red channel
         assert lost > 0.2, lost
         assert rel_l2(b, a) < 1e-5, (depth, rel_l2(b, a))
+
+
+@pytest.mark.parametrize("scene,mesh,res,spp", [("cbox_occluder", 1, 48, 8), ("cbox_bunny", 1, 64, 16), ("bunny_light", 0, 64, 16)])
+def test_literal_form_flag_on_the_gpu(scene, mesh, res, spp):
+    """PSDR_FLAG_LITERAL_FORMS makes the fp32-robust forms an A/B on the device.  With the flag the HIP
+    kernels match oracle.render(reference_form=True, precision=0) sample for sample; without it the robust-form oracle; and on the bunny
+    scenes the two forms are measurably apart in fp32 while fp64 holds them together (the reason the product evaluates the robust ones)."""
+    from helpers import tangents_wrt
+    sc, P = load_scene(scene, res=res, spp=spp, sppe=spp, sppse=spp, translate=(mesh, (1.0, 0.5, 0.0)))
+    tb = sc.tables(0)
+    tan = tangents_wrt(tb, P)
+    g = GpuScene(tb)
+    kw = dict(spp=spp, sppe=spp, sppse=spp, rng_offset=(0, 3, 7))
+    img_l, d_l = g.render_d_fwd(_abi.make_opts(flags=_abi.FLAG_LITERAL_FORMS, **kw), [tan])
+    img_r, d_r = g.render_d_fwd(_abi.make_opts(**kw), [tan])
+    o_l = oracle.render(tb, _abi.make_opts(**kw), mode=1, tangents=tan, precision=0, reference_form=True)
+    o_r = oracle.render(tb, _abi.make_opts(**kw), mode=1, tangents=tan, precision=0, reference_form=False)
+    o64 = oracle.render(tb, _abi.make_opts(**kw), mode=1, tangents=tan, precision=1, reference_form=True)
+    e_ll, e_rr, e_lr = rel_l2(d_l[0], o_l[1]), rel_l2(d_r[0], o_r[1]), rel_l2(d_l[0], d_r[0])
+    print("%s: literal vs oracle literal %.2e, robust vs oracle robust %.2e, literal vs robust (GPU) %.2e; against fp64 literal: GPU literal %.2e, GPU robust %.2e"
+          % (scene, e_ll, e_rr, e_lr, rel_l2(d_l[0], o64[1]), rel_l2(d_r[0], o64[1])))
+    def flips(a, b):
+        bad = np.abs(a - b).max(1) > 1e-3 * (1.0 + np.abs(b).max(1))
+        return bad.mean(), rel_l2(a[~bad], b[~bad])
+    for a, b in ((img_l, o_l[0]), (img_r, o_r[0])):
+        f, r = flips(a, b)
+        assert f < 0.01 and r < 1e-3, (f, r)                                     # the same estimator: all but isolated samples
+    if scene == "cbox_occluder":                                               # well-conditioned scene (distances ~ 100 units): sample for sample in both forms
+        assert rel_l2(img_l, o_l[0]) < 1e-4 and rel_l2(img_r, o_r[0]) < 1e-4 and e_ll < 1e-3 and e_rr < 1e-3
+    # the product's default (robust) forms are at least as close to the exact (fp64) value of the reference's estimator as the literal ones
+    # evaluated in fp32 (cbox_bunny at this size: 5.5e-3 against 4.5e-2 -- the literal tests flip high-weight boundary samples)
+    assert rel_l2(d_r[0], o64[1]) <= rel_l2(d_l[0], o64[1]) * 1.05 + 1e-4
+    lib = g.lib
+    import ctypes as C
+    adj = torch_adj = None
+    rc = lib.psdr_render_d_rev(g.h, C.byref(_abi.make_opts(flags=_abi.FLAG_LITERAL_FORMS, **kw)), C.c_void_p(8), None, C.byref(_abi.Grads()), None)
+    assert rc != 0 and b"LITERAL" in lib.psdr_last_error()                     # forward-mode diagnostic only

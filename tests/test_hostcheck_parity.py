@@ -134,3 +134,20 @@ def test_minimal_and_degenerate_scenes():
             o = _abi.make_opts(spp=4, **kw)
             a, b = host_render(tb, o), oracle.render(tb, o)
             assert np.isfinite(a).all() and rel_l2(a, b) < 2e-5
+
+
+@pytest.mark.parametrize("scene,mesh", [("cbox_occluder", 1), ("cbox", 0)])
+def test_literal_form_flag_matches_the_oracles_reference_form(scene, mesh):
+    """PSDR_FLAG_LITERAL_FORMS: the product evaluates p = ray(t), the edge rays without the adjacent-face skip and the fp32
+    |its1.p - p1| < ShadowEpsilon test as the reference writes them (scene.cpp:368, direct.cpp:246-262) -- sample for sample the oracle's
+    reference_form in fp32; without the flag it matches the oracle's robust forms (product code on the host)."""
+    sc, P = load_scene(scene, res=24, spp=8, sppe=8, sppse=8, translate=(mesh, (1.0, 0.5, 0.0)))
+    tb = sc.tables(0)
+    tan = tangents_wrt(tb, P)
+    kw = dict(spp=8, sppe=8, sppse=8, rng_offset=(0, 5, 9), **OPTS["direct11"])
+    lit = host_render(tb, _abi.make_opts(flags=_abi.FLAG_LITERAL_FORMS, **kw), mode=1, tangents=tan)
+    ref = oracle.render(tb, _abi.make_opts(**kw), mode=1, tangents=tan, precision=0, reference_form=True)
+    assert rel_l2(lit[0], ref[0]) < 2e-5 and rel_l2(lit[1], ref[1]) < 1e-4, (rel_l2(lit[0], ref[0]), rel_l2(lit[1], ref[1]))
+    rob = host_render(tb, _abi.make_opts(**kw), mode=1, tangents=tan)
+    ref_rob = oracle.render(tb, _abi.make_opts(**kw), mode=1, tangents=tan, precision=0, reference_form=False)
+    assert rel_l2(rob[1], ref_rob[1]) < 1e-4
