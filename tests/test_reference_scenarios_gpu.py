@@ -132,9 +132,10 @@ def test_emitter_radiance_gradient_with_two_emitters():
         assert np.abs(rd).max() > 0 and rel_l2(d[0], rd) < 1e-3, e
 
 
-def test_tree_scenario_secondary_edges_only_with_no_edge_meshes():
+@pytest.mark.parametrize("n_leaves", [600, 24118])            # 24 118 leaves + 12 trunk faces = the 24 130 faces of the reference's tree0.obj
+def test_tree_scenario_secondary_edges_only_with_no_edge_meshes(n_leaves):
     res, sppse = 64, 16
-    sc = make_tree_scene(seed=0, res=res, spp=0, sppe=0, sppse=sppse)
+    sc = make_tree_scene(seed=0, n_leaves=n_leaves, res=res, spp=0, sppe=0, sppse=sppse)
     assert [m.enable_edges for m in sc.m_meshes] == [False, True, False]
     P = FloatD(0.)
     ek.set_requires_gradient(P)
@@ -156,5 +157,9 @@ def test_tree_scenario_secondary_edges_only_with_no_edge_meshes():
     guide = integ._guide[0]
     o = _abi.make_opts(bsdf_samples=0, light_samples=2, spp=0, sppe=0, sppse=sppse)
     _, rd = oracle.render(tb, o, mode=1, tangents=tangents_wrt(tb, P), guide=guide)
-    print("tree: secondary-edge derivative image rel-L2 vs oracle %.2e" % rel_l2(d, rd))
-    assert rel_l2(d, rd) < 1e-3
+    print("tree (%d leaves): secondary-edge derivative image rel-L2 vs oracle %.2e" % (n_leaves, rel_l2(d, rd)))
+    if n_leaves <= 600:
+        assert rel_l2(d, rd) < 1e-3
+    else:       # 72 k boundary edges of 0.5-unit leaves: isolated boundary samples resolve an epsilon test the other way in the two fp32 evaluations
+        bad = np.abs(d - rd).max(1) > 1e-3 * (np.abs(rd).max() + np.abs(rd).max(1))
+        assert bad.mean() < 5e-3 and rel_l2(d[~bad], rd[~bad]) < 2e-3, (bad.mean(), rel_l2(d[~bad], rd[~bad]))
