@@ -281,6 +281,28 @@ int psdr_guide_build(psdr_scene_t h, const psdr_render_opts *opts,
                      const int32_t reso[4], int32_t nrounds,
                      float *out_mass, void *stream);
 
+/* ---- the differentiable table chain of Scene::configure as kernels (csrc/psdr_tables.hip) -------------------------------------
+   All pointers are device pointers; vertices [V][3], faces [T][3] int32 (global vertex ids), rows [T][row_stride >= 22] in the
+   TriangleInfo layout (PSDR_TRI_STRIDE words when written straight into tri_info), edges [E][5] int32 = v0, v1, face0, face1
+   (-1: boundary), opposite vertex of face0 (global ids; Mesh::m_edge_indices, mesh.cpp:154-196).  The *_rev entry points ADD the
+   adjoints into a_v / a_rows / a_w2s (the caller zeroes them). */
+/* process_mesh (src/shape/mesh.cpp:20-51): rows = p0 e1 e2 n0 n1 n2 face_normal face_area with area-weighted vertex normals;
+   vsum [V][3] = scratch kept for the adjoint (the un-normalised vertex normals). */
+int psdr_geo_tri_rows_fwd(int32_t V, int32_t T, const float *v, const int32_t *faces, float *vsum, float *rows, int32_t row_stride, void *stream);
+int psdr_geo_tri_rows_rev(int32_t V, int32_t T, const float *v, const int32_t *faces, const float *vsum, const float *a_rows, int32_t row_stride,
+                          float *a_vsum /* scratch [V][3] */, float *a_v, void *stream);
+/* SecondaryEdgeInfo of EVERY candidate edge (Mesh::configure, mesh.cpp:251-270): info [E][16] = p0 e1 n0 n1 p2 is_boundary, and
+   keep [E] = 1 where the coplanar filter of scene.cpp:219-244 keeps the edge (the caller compacts). */
+int psdr_geo_sec_edges_fwd(int32_t E, const int32_t *edges, const float *v, const float *rows, int32_t row_stride, float *info, uint8_t *keep, void *stream);
+int psdr_geo_sec_edges_rev(int32_t E, const int32_t *edges, const float *a_info, float *a_v, float *a_rows, int32_t row_stride, void *stream);
+/* PrimaryEdgeInfo of every candidate edge for one sensor (PerspectiveCamera::configure, src/sensor/perspective.cpp:39-111):
+   cam22 = world_to_sample (16, row-major), camera position (3), viewing direction (3); face_normals [E] = 1 where the edge's mesh uses
+   face normals; rows8 [E][PSDR_PEDGE_STRIDE], z4 [E][4] (psdr_scene_desc::prim_edge_z), keep [E] = the silhouette test. */
+int psdr_geo_prim_edges_fwd(int32_t E, const int32_t *edges, const uint8_t *face_normals, const float *v, const float *rows, int32_t row_stride,
+                            const float *cam22, float *rows8, float *z4, uint8_t *keep, void *stream);
+int psdr_geo_prim_edges_rev(int32_t E, const int32_t *edges, const float *v, const float *cam22, const float *a_rows8, float *a_v, float *a_w2s /* [16] */,
+                            void *stream);
+
 /* Counters of the last render call on this handle (host values):
    [0] rays traced, [1] camera slots, [2] primary-edge slots, [3] secondary-edge slots. */
 int psdr_get_counters(psdr_scene_t h, uint64_t out[4]);

@@ -16,6 +16,7 @@ import torch
 
 import enoki as ek
 from . import _abi
+from . import tables_native
 from .core import (Object, RenderOption, Bitmap1fD, Bitmap3fD, DiscreteDistribution, psdr_assert, PositionSampleC, PositionSampleD,
                    FloatC, FloatD, Vector2fD, Vector3fC, Vector3fD, Matrix4fD, IntC)
 
@@ -285,7 +286,22 @@ class PerspectiveCamera(Sensor):
             rows, zs = [], []
             bt = scene._batch
             ei = bt["tp"]["edges"]
-            if ei is not None:
+            if ei is not None and tables_native.available(bt["v_world"]):
+                # every candidate edge in ONE launch (csrc/psdr_tables.hip k_prim_edges): film records, 1 / depth rows, silhouette test
+                def film_records(v, m, edges):
+                    edges = edges.long()
+                    q0, q1 = transform_pos(m, v[edges[:, 0]])[:, :2], transform_pos(m, v[edges[:, 1]])[:, :2]
+                    e = (q1 - q0).detach()
+                    ln = torch.sqrt((e * e).sum(-1))
+                    e = e / ln.unsqueeze(-1)
+                    return torch.cat([q0, q1, torch.stack([-e[:, 1], e[:, 0]], dim=-1), ln.unsqueeze(-1), torch.zeros_like(ln).unsqueeze(-1)], dim=-1)
+                r8, z4, keep8 = tables_native.prim_edges(bt["v_world"], w2s, bt["tri_info"], bt["tp"]["edges_i32"], bt["tp"]["edge_face_normals_u8"],
+                                                        cam_pos, cam_dir, film_records)
+                keep = keep8.bool()
+                r8 = r8[keep]
+                if r8.shape[0] > 0:
+                    rows.append(r8); zs.append(z4[keep])
+            elif ei is not None:
                 tinfo, vpos, facen = bt["tri_info"], bt["v_world"], bt["tp"]["edge_face_normals"]
                 valid = ei[:, 3] >= 0
                 f1 = torch.where(valid, ei[:, 3], torch.zeros_like(ei[:, 3]))
@@ -981,6 +997,10 @@ class Scene(Object):
             "tri_mesh": torch.cat([torch.full((m.num_faces,), fl, dtype=torch.int32, device=d) for m, fl in zip(self.m_meshes, flags)]).contiguous(),
             "edges": torch.cat(edges) if edges else None, "edge_face_normals": torch.cat(eface) if eface else None,
         }
+        # what the native table chain reads (tables_native / csrc/psdr_tables.hip): int32 ids, uint8 flags
+        self._topo["faces_i32"] = self._topo["faces"].to(torch.int32).contiguous()
+        self._topo["edges_i32"] = self._topo["edges"].to(torch.int32).contiguous() if edges else None
+        self._topo["edge_face_normals_u8"] = self._topo["edge_face_normals"].to(torch.uint8).contiguous() if eface else None
         return self._topo
 
     def _configure_meshes(self):
@@ -1006,7 +1026,10 @@ class Scene(Object):
         h = (mv[:, :3, :3] * v_raw.unsqueeze(1)).sum(-1) + mv[:, :3, 3]
         w = (mv[:, 3, :3] * v_raw).sum(-1) + mv[:, 3, 3]
         v_world = h / w.unsqueeze(-1)                                              # transform_pos, transform.h:84-88
-        tri_info, _ = process_mesh(v_world, tp["faces"])
+        if tables_native.available(v_world):          # one forward (and one reverse) launch sequence on the HIP library
+            tri_info = tables_native.tri_rows(v_world, tp["faces_i32"], lambda v, f: process_mesh(v, f)[0])
+        else:
+            tri_info, _ = process_mesh(v_world, tp["faces"])
         areas = torch.zeros(len(meshes), device=v_world.device).index_add(0, tp["tmesh"], tri_info[:, 21].detach()).tolist()   # one sync
         for i, m in enumerate(meshes):
             m._vertex_positions = v_world[tp["v_off"][i]:tp["v_off"][i + 1]]
@@ -1028,15 +1051,26 @@ class Scene(Object):
         ei = tp["edges"]
         if ei is None:
             return None
-        is_b = ei[:, 3] < 0
-        p0 = v_world[ei[:, 0]]
-        e1 = v_world[ei[:, 1]] - p0
-        n0 = tri_info[ei[:, 2], 18:21]
-        n1 = tri_info[torch.where(is_b, torch.zeros_like(ei[:, 3]), ei[:, 3]), 18:21] * (~is_b).unsqueeze(-1).to(torch.float32)
-        p2 = v_world[ei[:, 4]]
-        keep = ((n0 * n1).sum(-1) < 1.0 - EdgeEpsilon).detach()
-        info = torch.cat([p0, e1, n0, n1, p2, is_b.to(torch.float32).unsqueeze(-1)], dim=-1)
-        self._sec_edge_faces = ei[keep][:, 2:4].to(torch.int32).contiguous()      # adjacent faces (global ids; -1 = none)
+
+        def records(v, rows, edges):
+            edges = edges.long()
+            is_b = edges[:, 3] < 0
+            p0 = v[edges[:, 0]]
+            e1 = v[edges[:, 1]] - p0
+            n0 = rows[edges[:, 2], 18:21]
+            n1 = rows[torch.where(is_b, torch.zeros_like(edges[:, 3]), edges[:, 3]), 18:21] * (~is_b).unsqueeze(-1).to(torch.float32)
+            p2 = v[edges[:, 4]]
+            return torch.cat([p0, e1, n0, n1, p2, is_b.to(torch.float32).unsqueeze(-1)], dim=-1)
+        if tables_native.available(v_world):
+            info, keep8 = tables_native.sec_edges(v_world, tri_info, tp["edges_i32"], records)
+            keep = keep8.bool()
+        else:
+            info = records(v_world, tri_info, ei)
+            is_b = ei[:, 3] < 0           # (the filter on the gathered normals themselves, as this chain always evaluated it: the rounding of the
+            n0 = tri_info[ei[:, 2], 18:21]     # reduction depends on the memory layout of its operand, and the committed fixtures follow these decisions)
+            n1 = tri_info[torch.where(is_b, torch.zeros_like(ei[:, 3]), ei[:, 3]), 18:21] * (~is_b).unsqueeze(-1).to(torch.float32)
+            keep = ((n0 * n1).sum(-1) < 1.0 - EdgeEpsilon).detach()
+        self._sec_edge_faces = tp["edges_i32"][keep][:, 2:4].contiguous()      # adjacent faces (global ids; -1 = none)
         return info[keep]
 
     def _material_tables(self, d):

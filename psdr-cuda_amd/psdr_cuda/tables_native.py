@@ -1,0 +1,155 @@
+"""The differentiable table chain of Scene::configure on the HIP library (csrc/psdr_tables.hip, include/psdr_hip.h psdr_geo_*): TriangleInfo
+rows (process_mesh, reference src/shape/mesh.cpp:20-51), secondary-edge records (mesh.cpp:251-270 + scene.cpp:219-244) and primary-edge
+records (perspective.cpp:39-111), each ONE forward and ONE reverse call wrapped in a torch.autograd.Function -- instead of ~150 eager torch
+launches per configure() and ~250 in its backward.
+
+Forward mode (enoki.forward) differentiates the chain by double backward (create_graph=True): a backward call whose incoming adjoint itself
+requires a gradient re-runs the torch formulation of the op (scene.py), which torch can differentiate again; plain reverse mode
+(enoki.backward, the optimisation loop) takes the kernels.  CPU tensors (no GPU: the host tests) always take the torch formulation."""
+import ctypes as C
+
+import torch
+
+from . import _abi
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+import os
+
+_enabled = os.environ.get("PSDR_NATIVE_TABLES", "1") != "0"          # 0: the eager torch chain everywhere (A/B, tools)
+
+
+def available(t):
+    return _enabled and t.is_cuda
+
+
+class torch_formulation:
+    """context manager: configure() inside it builds the tables with the eager torch chain (the formulation the committed fixtures were made with:
+    an edge whose faces are coplanar to within an ulp of the 1 - 1e-5 filter threshold can be kept by one formulation and dropped by the other,
+    and the sample streams of a fixture follow its edge list)"""
+
+    def __enter__(self):
+        global _enabled
+        self.old, _enabled = _enabled, False
+
+    def __exit__(self, *a):
+        global _enabled
+        _enabled = self.old
+
+
+class _TriRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, v, faces_i32, ref_fn):
+        lib = _abi.load_hip()
+        vc = v.detach().contiguous().float()
+        V, T = vc.shape[0], faces_i32.shape[0]
+        vsum = torch.empty(V, 3, dtype=torch.float32, device=v.device)
+        rows = torch.empty(T, 22, dtype=torch.float32, device=v.device)
+        _abi.check(lib, lib.psdr_geo_tri_rows_fwd(V, T, vc.data_ptr(), faces_i32.data_ptr(), vsum.data_ptr(), rows.data_ptr(), 22, _stream()))
+        ctx.save_for_backward(v, faces_i32, vsum)
+        ctx.ref_fn = ref_fn
+        return rows
+
+    @staticmethod
+    def backward(ctx, a_rows):
+        v, faces, vsum = ctx.saved_tensors
+        if a_rows.requires_grad:                         # double backward (forward-mode JVP): the torch formulation
+            with torch.enable_grad():
+                vv = v.detach().requires_grad_(True) if not v.requires_grad else v
+                rows = ctx.ref_fn(vv, faces)
+                g, = torch.autograd.grad(rows, vv, a_rows, create_graph=True)
+            return g, None, None
+        lib = _abi.load_hip()
+        V, T = v.shape[0], faces.shape[0]
+        a = a_rows.contiguous().float()
+        a_v = torch.zeros(V, 3, dtype=torch.float32, device=v.device)
+        a_vsum = torch.empty(V, 3, dtype=torch.float32, device=v.device)
+        _abi.check(lib, lib.psdr_geo_tri_rows_rev(V, T, v.detach().contiguous().data_ptr(), faces.data_ptr(), vsum.data_ptr(), a.data_ptr(), 22,
+                                                  a_vsum.data_ptr(), a_v.data_ptr(), _stream()))
+        return a_v, None, None
+
+
+def tri_rows(v_world, faces_i32, ref_fn):
+    """rows [T, 22] of process_mesh; ref_fn(v, faces) = the torch formulation (double backward, CPU)."""
+    return _TriRows.apply(v_world, faces_i32, ref_fn)
+
+
+class _SecEdges(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, v, rows, edges_i32, ref_fn):
+        lib = _abi.load_hip()
+        E = edges_i32.shape[0]
+        vc, rc = v.detach().contiguous().float(), rows.detach().contiguous().float()
+        info = torch.empty(E, 16, dtype=torch.float32, device=v.device)
+        keep = torch.empty(E, dtype=torch.uint8, device=v.device)
+        _abi.check(lib, lib.psdr_geo_sec_edges_fwd(E, edges_i32.data_ptr(), vc.data_ptr(), rc.data_ptr(), rc.shape[1], info.data_ptr(), keep.data_ptr(), _stream()))
+        ctx.save_for_backward(v, rows, edges_i32)
+        ctx.ref_fn = ref_fn
+        ctx.mark_non_differentiable(keep)
+        return info, keep
+
+    @staticmethod
+    def backward(ctx, a_info, _a_keep):
+        v, rows, edges = ctx.saved_tensors
+        if a_info.requires_grad:
+            with torch.enable_grad():
+                vv = v if v.requires_grad else v.detach().requires_grad_(True)
+                rr = rows if rows.requires_grad else rows.detach().requires_grad_(True)
+                info = ctx.ref_fn(vv, rr, edges)
+                gv, gr = torch.autograd.grad(info, (vv, rr), a_info, create_graph=True, allow_unused=True)
+            return gv, gr, None, None
+        lib = _abi.load_hip()
+        a = a_info.contiguous().float()
+        a_v = torch.zeros_like(v, dtype=torch.float32)
+        a_rows = torch.zeros(rows.shape, dtype=torch.float32, device=v.device)
+        _abi.check(lib, lib.psdr_geo_sec_edges_rev(edges.shape[0], edges.data_ptr(), a.data_ptr(), a_v.data_ptr(), a_rows.data_ptr(), a_rows.shape[1], _stream()))
+        return a_v, a_rows, None, None
+
+
+def sec_edges(v_world, rows, edges_i32, ref_fn):
+    """(info [E, 16], keep [E] uint8) for every candidate edge; ref_fn(v, rows, edges) -> info (torch formulation)."""
+    return _SecEdges.apply(v_world, rows, edges_i32, ref_fn)
+
+
+class _PrimEdges(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, v, w2s, rows, edges_i32, face_normals_u8, cam_pos, cam_dir, ref_fn):
+        lib = _abi.load_hip()
+        E = edges_i32.shape[0]
+        vc, rc = v.detach().contiguous().float(), rows.detach().contiguous().float()
+        cam22 = torch.cat([w2s.detach().reshape(-1), cam_pos.detach().reshape(-1), cam_dir.detach().reshape(-1)]).float().contiguous()
+        rows8 = torch.empty(E, 8, dtype=torch.float32, device=v.device)
+        z4 = torch.empty(E, 4, dtype=torch.float32, device=v.device)
+        keep = torch.empty(E, dtype=torch.uint8, device=v.device)
+        _abi.check(lib, lib.psdr_geo_prim_edges_fwd(E, edges_i32.data_ptr(), face_normals_u8.data_ptr(), vc.data_ptr(), rc.data_ptr(), rc.shape[1],
+                                                    cam22.data_ptr(), rows8.data_ptr(), z4.data_ptr(), keep.data_ptr(), _stream()))
+        ctx.save_for_backward(v, w2s, edges_i32, cam22)
+        ctx.ref_fn = ref_fn
+        ctx.mark_non_differentiable(z4, keep)
+        return rows8, z4, keep
+
+    @staticmethod
+    def backward(ctx, a_rows8, _a_z, _a_keep):
+        v, w2s, edges, cam22 = ctx.saved_tensors
+        if a_rows8.requires_grad:
+            with torch.enable_grad():
+                vv = v if v.requires_grad else v.detach().requires_grad_(True)
+                ww = w2s if w2s.requires_grad else w2s.detach().requires_grad_(True)
+                r8 = ctx.ref_fn(vv, ww, edges)
+                gv, gw = torch.autograd.grad(r8, (vv, ww), a_rows8, create_graph=True, allow_unused=True)
+            return gv, gw, None, None, None, None, None, None
+        lib = _abi.load_hip()
+        a = a_rows8.contiguous().float()
+        a_v = torch.zeros_like(v, dtype=torch.float32)
+        a_w = torch.zeros(16, dtype=torch.float32, device=v.device)
+        _abi.check(lib, lib.psdr_geo_prim_edges_rev(edges.shape[0], edges.data_ptr(), v.detach().contiguous().data_ptr(), cam22.data_ptr(), a.data_ptr(),
+                                                    a_v.data_ptr(), a_w.data_ptr(), _stream()))
+        return a_v, a_w.reshape(4, 4), None, None, None, None, None, None
+
+
+def prim_edges(v_world, w2s, rows, edges_i32, face_normals_u8, cam_pos, cam_dir, ref_fn):
+    """(rows8 [E, 8], z4 [E, 4], keep [E]) for every candidate edge of one sensor; ref_fn(v, w2s, edges) -> rows8 (torch formulation)."""
+    return _PrimEdges.apply(v_world, w2s, rows, edges_i32, face_normals_u8, cam_pos, cam_dir, ref_fn)

@@ -11,7 +11,7 @@ cd $ROOT/psdr-cuda_amd/csrc
 ALL="0 1 2 3 4 6 8 10"
 if [ -n "${ONLY:-}" ]; then cp $ROOT/psdr-cuda_amd/lib/obj/*.o $obj/; SET="$ONLY"; else SET="$ALL"; fi
 for v in $SET; do hipcc $FLAGS "$@" -DPSDR_VARIANT_FLAGS=$v -c psdr_variant.hip -o $obj/variant$v.o & done
-if [ -z "${ONLY:-}" ]; then hipcc $FLAGS "$@" -c psdr_hip.hip -o $obj/host.o & fi
+if [ -z "${ONLY:-}" ]; then hipcc $FLAGS "$@" -c psdr_hip.hip -o $obj/host.o & hipcc $FLAGS "$@" -c psdr_tables.hip -o $obj/tables.o & fi
 wait
 hipcc --offload-arch=gfx950 -shared -fPIC $obj/*.o -o $ROOT/variants/lib_$name.so
 echo built variants/lib_$name.so
