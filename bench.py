@@ -45,7 +45,10 @@ N_SIMD, CLOCK_HZ, HBM_BPS = 1024, 2.4e9, 8.0e12
 VALU_PEAK_WAVE_INSTS_PER_S = N_SIMD * CLOCK_HZ / 2.0          # 1.2288e12 wave-instructions / s
 # VALU lane-instructions one primitive test costs (Moeller-Trumbore with SGPR operands, csrc/psdr_device.h tiny_prim_test) and
 # the rest of a traced ray's share of its path vertex (hit reconstruction, sampling, shading): DESIGN.md section 3
-FLOOR_VALU_PER_PRIM_TEST, FLOOR_VALU_PER_RAY_REST = 27, 150
+FLOOR_VALU_PER_PRIM_TEST, FLOOR_VALU_PER_RAY_REST = 17, 150          # plane-form primitive test (round 3): 17 VALU with the rows in SGPRs
+# What a SIMD actually sustains (tools/micro/valu_rate.hip on MI355X, 8 waves per SIMD, clocks measured at 2.3-2.4 GHz;
+# profiles/r03_valu_rate.txt): wave64 VALU instructions per cycle per SIMD -- no stream reaches the 0.5 of the 2-cycle issue model
+MEASURED_VALU_PER_CYCLE = {"v_xor_b32 / v_mov_b32 (two operands)": 0.42, "v_fma_f32, dependent chain": 0.40, "v_fma_f32, 16 independent (three VGPR sources)": 0.265}
 
 
 def parse():
@@ -201,6 +204,49 @@ def pmc_passes(args):
     return out
 
 
+def pmc_passes_c4(args, res, spp):
+    """Stream-traffic accounting of the wavefront stages of --config c4 (the one place the north star's HBM roofline applies): one renderC of
+    the workload per rocprofv3 pass (--kernel-trace for the durations), FETCH_SIZE / WRITE_SIZE per kernel summed over its launches."""
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None
+    tmp = tempfile.mkdtemp(prefix="psdr_pmc4_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    cnt, dur, launches = {}, {}, {}
+    try:
+        for group in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, group)
+            cmd = [exe, "--pmc", group, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
+                   "--config", "c4", "--pmc-child", "--res", str(res), "--spp", str(spp), "--max-depth", str(args.max_depth)]
+            try:
+                subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=400, check=True)
+            except Exception:
+                return None
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    n = r.get("Kernel_Name", "")
+                    if "k_wf_" in n and r.get("Counter_Name") == group:
+                        k = "k_wf_camera" if "k_wf_camera" in n else "k_wf_bounce"
+                        cnt.setdefault(k, {}).setdefault(group, 0.0); cnt[k][group] += float(r["Counter_Value"])
+                        if group == "FETCH_SIZE":
+                            launches[k] = launches.get(k, 0) + 1
+            if group == "FETCH_SIZE":
+                for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+                    for r in csv.DictReader(open(f)):
+                        n = r.get("Kernel_Name", "")
+                        if "k_wf_" in n:
+                            k = "k_wf_camera" if "k_wf_camera" in n else "k_wf_bounce"
+                            dur[k] = dur.get(k, 0.0) + (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    out = {}
+    for k, c in cnt.items():
+        if "FETCH_SIZE" in c and "WRITE_SIZE" in c and dur.get(k):
+            b = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+            out[k] = {"launches": launches.get(k), "seconds": round(dur[k], 6), "hbm_bytes": b, "GBps": round(b / dur[k] / 1e9, 1), "hbm_measured_frac": round(b / dur[k] / HBM_BPS, 4)}
+    return out or None
+
+
 def relaunch_under_torchrun(args):
     """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run, one process per GPU (what the driver's own
     command line does for N > 1).  PSDR_BENCH_ONE_GPU=1 (developer switch) lets the N ranks share cuda:0 over gloo."""
@@ -244,6 +290,8 @@ def run_c4(args, world, rank, local_rank, dist, devices, rccl):
     from enoki.cuda_autodiff import Float32 as FloatD, Vector3f as Vector3fD
     from psdr_cuda.fixtures import scene_path
     res, spp = (args.res if args.res != 512 else 1024), (args.spp if args.spp != 64 else 512)
+    if args.pmc_child:
+        res, spp = args.res, args.spp
     sc = psdr_cuda.Scene()
     sc.load_file(scene_path("cbox_bunny"), False)
     sc.opts.width = sc.opts.height = res
@@ -254,6 +302,10 @@ def run_c4(args, world, rank, local_rank, dist, devices, rccl):
     mesh = sc.param_map["Mesh[1]"]                      # the bunny (cbox_bunny.xml)
     v0 = ek.detach(mesh.vertex_positions)
     sc.configure()
+    if args.pmc_child:                                  # one renderC of this rank's share under rocprofv3 (pmc_passes_c4)
+        integ.renderC(sc); integ.renderC(sc)
+        torch.cuda.synchronize()
+        return
 
     def step():
         img = integ.renderC(sc)
@@ -284,6 +336,9 @@ def run_c4(args, world, rank, local_rank, dist, devices, rccl):
         dt = float(tt.item())
     value = 2.0 * res * res * spp * args.steps / dt / 1e6
     T = int(sc.tables(0)["num_tris"])
+    # the wavefront stages' stream traffic against the HBM roofline: measured on one GPU's share of the 8-GPU job (64 spp: the launch size at
+    # which the library runs the class-binned wavefront), record size 44 + 12 K bytes + 3 (1 + K) accumulator words per live path and stage
+    wf = pmc_passes_c4(args, res, max(spp // 8, 1)) if (rank == 0 and world == 1 and not args.no_pmc) else None
     grad_words = T * 24 + int(sc.tables(0)["texels"].numel())
     if rank == 0:
         gv = out[1].numpy()
@@ -299,6 +354,8 @@ def run_c4(args, world, rank, local_rank, dist, devices, rccl):
                        "allreduce_bytes_per_step": 0 if world == 1 else int(2 * res * res * 3 * 4 + grad_words * 4),
                        "parallelism": "spp-shard x%d; all-reduces per step: [image] (renderC), [image] (renderD primal), [triangle-row || texel gradients]" % world},
             "grad_check": {"finite": bool(np.isfinite(gv).all()), "abs_max_vertex_grad": float(np.abs(gv).max())},
+            "wavefront_traffic": None if wf is None else {"workload": "renderC of one rank's share of the 8-GPU job (%d spp), two calls" % max(spp // 8, 1), "kernels": wf,
+                                                           "stream_record_bytes": 44 + 12, "note": "(2 * FETCH_SIZE + WRITE_SIZE) KiB per kernel summed over its launches / its summed duration / 8 TB/s (rocprofv3 --pmc, one pass per counter)"},
         }))
 
 
@@ -412,7 +469,9 @@ def main():
         "bound": "valu", "kernel": dom_name, "kernel_ms": round(dom_ms, 4),
         "achieved": None if achieved is None else round(achieved / 1e9, 3), "peak": round(VALU_PEAK_WAVE_INSTS_PER_S / 1e9, 3),
         "unit": "G wave-instructions/s", "frac": None if achieved is None else round(achieved / VALU_PEAK_WAVE_INSTS_PER_S, 4),
-        "peak_note": "1024 SIMD-32 units x 2.4 GHz / 2 cycles per wave64 VALU instruction (MI355X_MICROARCH.md; tools/micro/valu_rate.hip measures it)",
+        "peak_note": "1024 SIMD-32 units x 2.4 GHz / 2 cycles per wave64 VALU instruction (MI355X_MICROARCH.md)",
+        "measured_issue_ceiling": {"winst_per_cycle_per_simd": MEASURED_VALU_PER_CYCLE, "achieved_winst_per_cycle_per_simd": None if achieved is None else round(achieved / (N_SIMD * CLOCK_HZ), 4),
+                                   "note": "tools/micro/valu_rate.hip, profiles/r03_valu_rate.txt: what pure instruction streams sustain at 8 waves / SIMD; 0.5 = the 2-cycle model"},
         "valu_wave_insts_per_launch": valu, "algorithmic_floor_frac": None if valu is None else round(floor_lane_insts / (valu * 64.0), 4),
         "primitives_tested_per_ray": n_prims,
         "wait_any_frac": None if not wave_cycles or "SQ_WAIT_ANY" not in dpm else round(dpm["SQ_WAIT_ANY"] / wave_cycles, 4),
