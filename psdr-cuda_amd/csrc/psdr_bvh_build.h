@@ -92,7 +92,7 @@ inline void pack_tiny_prims(const std::vector<float4> &tris, std::vector<float4>
 
 // What the kernels receive (SceneView::tiny / tiny_meta): every primitive in PLANE FORM, computed here in double,
 //   row 0 = (n, c0)   unit normal and n . p0:            t = -(n . o - c0) / (n . d)
-//   row 1 = (a1, c1)  dual basis vector of e1, a1 . p0:  s = a1 . (o + t d) - c1
+//   row 1 = (a1, c1)  dual basis vector of e1, a1 . p0 + 1/2:  s - 1/2 = a1 . (o + t d) - c1
 //   row 2 = (a2, c2)  dual basis vector of e2, a2 . p0:  the second plane coordinate likewise
 // (a1 = e2 x n / |e1 x e2|, a2 = n x e1 / |e1 x e2| with the unit normal: a1 . e1 = a2 . e2 = 1, a1 . e2 = a2 . e1 = 0) -- 17 VALU
 // operations per test against Moeller-Trumbore's 31 (psdr_device.h tiny_prim_test), and meta = (ids, codeA, codeB, the bound on s + t as float bits: 2 for a parallelogram, 1 for a triangle).
@@ -112,11 +112,11 @@ inline void tiny_plane_form(const std::vector<float4> &prims, float4 *rows, int3
         } else nn[0] = nn[1] = nn[2] = 0.0;                        // degenerate: n . d = 0 for every ray, never hit
         auto dot3 = [](const double *x, const double *y) { return x[0] * y[0] + x[1] * y[1] + x[2] * y[2]; };
         rows[i * 3] = float4{(float) nn[0], (float) nn[1], (float) nn[2], (float) dot3(nn, p0)};
-        rows[i * 3 + 1] = float4{(float) a1[0], (float) a1[1], (float) a1[2], (float) dot3(a1, p0)};
-        rows[i * 3 + 2] = float4{(float) a2[0], (float) a2[1], (float) a2[2], (float) dot3(a2, p0)};
+        rows[i * 3 + 1] = float4{(float) a1[0], (float) a1[1], (float) a1[2], (float) (dot3(a1, p0) + 0.5)};      // the test works on s - 1/2, t - 1/2
+        rows[i * 3 + 2] = float4{(float) a2[0], (float) a2[1], (float) a2[2], (float) (dot3(a2, p0) + 0.5)};
         int32_t ids, codeA, codeB;
         std::memcpy(&ids, &a.w, 4); std::memcpy(&codeA, &b.w, 4); std::memcpy(&codeB, &c.w, 4);
-        meta[i * 4] = ids; meta[i * 4 + 1] = codeA; meta[i * 4 + 2] = codeB; const float lim = ((uint32_t) ids >> 16) != 0xffffu ? 2.f : 1.f;
+        meta[i * 4] = ids; meta[i * 4 + 1] = codeA; meta[i * 4 + 2] = codeB; const float lim = ((uint32_t) ids >> 16) != 0xffffu ? 1.f : 0.f;           // bound on (s - 1/2) + (t - 1/2)
         std::memcpy(&meta[i * 4 + 3], &lim, 4);
     }
 }

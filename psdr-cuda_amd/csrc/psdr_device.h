@@ -63,7 +63,7 @@ struct SceneView {
     // segment into SGPRs, no tree, no per-lane node fetches, no stack traffic, no divergence between lanes.
     int32_t n_tiny;
     float4 tiny[kTinyTris * 3];                 // plane form: (n | c0), (a1 | c1), (a2 | c2) per primitive (psdr_bvh_build.h tiny_plane_form)
-    int32_t tiny_meta[kTinyTris * 4];           // (ids, codeA, codeB, bound on s + t as float bits: 2 parallelogram / 1 triangle) per primitive
+    int32_t tiny_meta[kTinyTris * 4];           // (ids, codeA, codeB, bound on s + t - 1 as float bits: 1 parallelogram / 0 triangle) per primitive
     // Two-level tree (psdr_bvh_build.h ForestBuilder; scenes of a few small meshes plus a few large ones -- a room with
     // objects): the triangles of the small meshes are the primitives above, every large mesh has its OWN tree in `nodes`,
     // and its box + root travel in the kernel arguments too.  A closest-hit query first tests the inline primitives
@@ -216,12 +216,14 @@ PSDR_HD void tiny_prim_test(const float4 &r0, const float4 &r1, const float4 &r2
     const float on = r0.x * o.x + (r0.y * o.y + (r0.z * o.z - r0.w));
     const float t = -on * (1.f / dn);
     const Vec3f p{o.x + t * d.x, o.y + t * d.y, o.z + t * d.z};
+    // (u, v) = plane coordinates MINUS ONE HALF (the rows' constants carry the shift): 0 <= s <= 1 is |u| <= 1/2 -- one comparison with the free
+    // |.| source modifier instead of two
     const float u = r1.x * p.x + (r1.y * p.y + (r1.z * p.z - r1.w));
     const float v = r2.x * p.x + (r2.y * p.y + (r2.z * p.z - r2.w));
-    const float lim = __int_as_float_hd(meta[3]);                  // wave-uniform (kernel argument): 2 for a parallelogram, 1 for a triangle (u, v <= 1 are then implied)
+    const float lim = __int_as_float_hd(meta[3]);                  // wave-uniform (kernel argument): bound on u + v -- 1 for a parallelogram (s + t <= 2), 0 for a triangle
     // a ray in the plane (dn = 0) gives t = +-inf or NaN, p and (u, v) NaN: every comparison fails
-    bool hit = (u >= 0.f) & (v >= 0.f) & (u <= 1.f) & (v <= 1.f) & (u + v <= lim) & (t >= kRayEpsilon) & (t < best.t);
-    if (IGN) { const int id2 = meta[0]; const bool quad = lim > 1.5f; const int id = (quad && u + v > 1.f) ? (int) ((uint32_t) id2 >> 16) : (id2 & 0xffff); hit = hit & (id != ig0) & (id != ig1); }
+    bool hit = (fabsf(u) <= 0.5f) & (fabsf(v) <= 0.5f) & (u + v <= lim) & (t >= kRayEpsilon) & (t < best.t);
+    if (IGN) { const int id2 = meta[0]; const bool quad = lim > 0.5f; const int id = (quad && u + v > 0.f) ? (int) ((uint32_t) id2 >> 16) : (id2 & 0xffff); hit = hit & (id != ig0) & (id != ig1); }
     best.t = hit ? t : best.t; best.u = hit ? u : best.u; best.v = hit ? v : best.v; best_i = hit ? i : best_i;
 }
 // (ids, codeA, codeB) of primitive i: from the LDS copy setup_lds made of the kernel-argument words (a per-lane index into the kernel
@@ -234,10 +236,10 @@ PSDR_HD void resolve_tiny_hit(const SceneView &sc, Hit &best, int best_i) {
     const int32_t *m = sc.tiny_meta + best_i * 4;
 #endif
     const int ids = m[0], codeA = m[1], codeB = m[2];
-    const bool second = ((uint32_t) ids >> 16) != 0xffffu && best.u + best.v > 1.f;
+    const bool second = ((uint32_t) ids >> 16) != 0xffffu && best.u + best.v > 0.f;
     const int code = second ? codeB : codeA;
     auto k = [&](int i) { return (float) (((code >> (3 * i)) & 7) - 2); };
-    const float s = best.u, t = best.v;
+    const float s = best.u + 0.5f, t = best.v + 0.5f;               // tiny_prim_test keeps the plane coordinates shifted by one half
     best.tri = second ? (int) ((uint32_t) ids >> 16) : (ids & 0xffff);
     best.u = k(0) + (k(1) * s + k(2) * t);
     best.v = k(3) + (k(4) * s + k(5) * t);

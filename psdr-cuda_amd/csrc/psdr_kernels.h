@@ -20,8 +20,25 @@ __device__ __forceinline__ float wave_shfl_down(float v, int off) { return __shf
 // Segmented sum over a wave for NON-DECREASING integer keys (camera slots are pixel-major, so a
 // wave covers a few consecutive pixels).  After the loop the first lane of every key run holds
 // the run total.  All 64 lanes must call this.
+// Sum over all 64 lanes on the DPP path (no LDS round trips): an inclusive scan inside every row of 16 (row_shr 1, 2, 4, 8), then the row totals
+// carried into the following rows (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3): lane 63 holds the total.
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ float dpp_add(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true));
+}
+__device__ __forceinline__ float wave_total(float v) {
+    v = dpp_add<0x111, 0xf>(v); v = dpp_add<0x112, 0xf>(v); v = dpp_add<0x114, 0xf>(v); v = dpp_add<0x118, 0xf>(v);
+    v = dpp_add<0x142, 0xa>(v); v = dpp_add<0x143, 0xc>(v);
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
 template <int N> __device__ __forceinline__ bool wave_segmented_sum(int key, float (&v)[N]) {
     const int lane = threadIdx.x & 63;
+    // the common case of the camera kernels: spp is a multiple of 64 and the whole wave sits on ONE pixel -- six DPP adds per value instead of six
+    // ds_bpermute round trips (each an LDS instruction + its address arithmetic + the wait)
+    if (__ballot(key != __builtin_amdgcn_readfirstlane(key)) == 0ull) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] = wave_total(v[i]);
+        return lane == 0;
+    }
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
         const int okey = __shfl_down(key, off, 64);
