@@ -166,7 +166,7 @@ struct psdr_scene_s {
 
     // tiny scenes: the leaf triangles as they travel in the kernel arguments (SceneView::tiny)
     bool tiny_enabled = true;
-    int n_tiny = 0;
+    int n_tiny = 0, n_tiny_quads = 0;
     float4 tiny[kTinyTris * 3] = {};           // plane form (tiny_plane_form)
     int32_t tiny_meta[kTinyTris * 4] = {};
     // two-level tree (psdr_bvh_build.h ForestBuilder): boxes + roots of the per-mesh trees, as they travel in the

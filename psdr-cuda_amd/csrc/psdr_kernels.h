@@ -83,11 +83,21 @@ __device__ __forceinline__ void count_rays(unsigned long long *counters, uint32_
 
 // ------------------------------------------------------------------------------ k_camera
 // n = W*H*nsp slots of this shard, pixel-major: slot j -> pixel j / nsp, sample s_begin + j % nsp.
-// n <= INT_MAX (check_counts), so this is 32-bit unsigned arithmetic: a 64-bit division by the run-time
-// nsp costs ~170 VALU instructions per slot.
-__device__ __forceinline__ void slot_to_pixel(long long j, int nsp, int &pixel, int &s) {
-    const uint32_t ju = (uint32_t) j, q = ju / (uint32_t) nsp;
-    pixel = (int) q; s = (int) (ju - q * (uint32_t) nsp);
+// n <= INT_MAX (check_counts), so the division by the run-time nsp is a 32 x 32 -> 64 bit multiply by a host-computed
+// reciprocal and a shift (round-up method for 31-bit dividends: l = ceil(log2 d), m = floor(2^(31+l) / d) + 1 < 2^32,
+// q = (j * m) >> (31 + l), exact for every j < 2^31): 4 VALU instructions per slot where the expanded 32-bit division took ~30.
+struct SlotDiv {
+    uint32_t d, m; int sh;
+    SlotDiv() = default;
+    SlotDiv(int nsp) : d((uint32_t) nsp) {
+        int l = 0;
+        while ((1u << l) < d) ++l;
+        m = (uint32_t) ((1ull << (31 + l)) / d + 1ull); sh = 31 + l;
+    }
+};
+PSDR_HD void slot_to_pixel(long long j, const SlotDiv &nsp, int &pixel, int &s) {
+    const uint32_t ju = (uint32_t) j, q = (uint32_t) (((uint64_t) ju * nsp.m) >> nsp.sh);
+    pixel = (int) q; s = (int) (ju - q * nsp.d);
 }
 // Occupancy targets (waves per SIMD) of the camera kernel.  The kernel is latency/dependency bound
 // (rocprof r01: 43 % of wave cycles waiting at 2 waves/SIMD), so trading registers for resident
@@ -123,7 +133,7 @@ template <class G, class R, int INTEG, int FL, bool NOTREE = false> constexpr in
     return (lean && INTEG == PSDR_INTEGRATOR_PATH && ad_traits<R>::K == 1) ? PSDR_WAVES_DM + 1 : PSDR_WAVES_DM;
 }
 template <class G, class R, int INTEG, int FL, bool NOTREE = false>
-__global__ __launch_bounds__(kBlock, (camera_waves<G, R, INTEG, FL, NOTREE>())) void k_camera(LaunchCtx cx, TV<R, FL> tv, int spp, int s_begin, int nsp, long long n, float inv_spp,
+__global__ __launch_bounds__(kBlock, (camera_waves<G, R, INTEG, FL, NOTREE>())) void k_camera(LaunchCtx cx, TV<R, FL> tv, int spp, int s_begin, SlotDiv nsp, long long n, float inv_spp,
                                                    float *__restrict__ img, float *__restrict__ dimg, long long plane,
                                                    unsigned long long *counters) {
     constexpr int K = ad_traits<R>::K;
@@ -316,7 +326,7 @@ __device__ __forceinline__ void splat_runs(int pixel, bool valid, const Vec3<M> 
 #define PSDR_WF_WAVES 4
 #endif
 template <class M, int FL>
-__global__ __launch_bounds__(kBlock, (is_ad<M>() ? 2 : PSDR_WF_WAVES)) void k_wf_camera(LaunchCtx cx, TV<M, FL> tv, int spp, int s_begin, int nsp, long long j0, long long n,
+__global__ __launch_bounds__(kBlock, (is_ad<M>() ? 2 : PSDR_WF_WAVES)) void k_wf_camera(LaunchCtx cx, TV<M, FL> tv, int spp, int s_begin, SlotDiv nsp, long long j0, long long n,
                                                         float inv_spp, float *__restrict__ img, float *__restrict__ dimg, long long plane,
                                                         PathStream out, int want_next, unsigned long long *counters, RngJump jump_next) {
     TraversalStack st; setup_lds(cx, st, tv);
@@ -719,7 +729,7 @@ template <int FL, bool GEO, int INTEG> constexpr int rev_waves() {
 // workgroups per CU -- the tree walks are latency-bound and the adjoint code's registers hold the fused kernel at 2 -- writing a
 // record per path to `disk`; STAGE 2 = the adjoint sweep from that record: no traversal, no stacks in LDS.
 template <int FL, bool GEO, int INTEG, int STAGE = 0>
-__global__ __launch_bounds__(kBlock, (STAGE == 1 ? 3 : rev_waves<FL, GEO, INTEG>())) void k_camera_rev(LaunchCtx cx, DeviceSink<FL> sink, int spp, int s_begin, int nsp, long long j0,
+__global__ __launch_bounds__(kBlock, (STAGE == 1 ? 3 : rev_waves<FL, GEO, INTEG>())) void k_camera_rev(LaunchCtx cx, DeviceSink<FL> sink, int spp, int s_begin, SlotDiv nsp, long long j0,
                                                        long long n, float inv_spp, const float *__restrict__ adj_img, float *__restrict__ img,
                                                        unsigned long long *counters, float *__restrict__ disk, long long disk_stride, float *__restrict__ deep) {
     TraversalStack st; setup_lds(cx, st);
