@@ -88,19 +88,6 @@ inline void pack_tiny_prims(const std::vector<float4> &tris, std::vector<float4>
             prims.push_back(a); prims.push_back(b); prims.push_back(c);
         }
     }
-    // parallelograms first (closest_hit tests them in a loop of their own: no s + t bound to check)
-    std::vector<float4> q, t;
-    for (size_t i = 0; i < prims.size(); i += 3) {
-        int32_t ids; std::memcpy(&ids, &prims[i].w, 4);
-        std::vector<float4> &dst = ((uint32_t) ids >> 16) != 0xffffu ? q : t;
-        dst.push_back(prims[i]); dst.push_back(prims[i + 1]); dst.push_back(prims[i + 2]);
-    }
-    prims = q; prims.insert(prims.end(), t.begin(), t.end());
-}
-inline int count_tiny_quads(const std::vector<float4> &prims) {
-    int n = 0;
-    for (size_t i = 0; i < prims.size(); i += 3) { int32_t ids; std::memcpy(&ids, &prims[i].w, 4); n += ((uint32_t) ids >> 16) != 0xffffu ? 1 : 0; }
-    return n;
 }
 
 // What the kernels receive (SceneView::tiny / tiny_meta): every primitive in PLANE FORM, computed here in double,

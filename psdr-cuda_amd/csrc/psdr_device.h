@@ -61,7 +61,7 @@ struct SceneView {
     // Tiny scenes (<= kTinyTris triangles, e.g. the 12-triangle Cornell box): the leaf triangles travel IN THE
     // KERNEL ARGUMENTS and closest_hit tests all of them in order -- wave-uniform s_load from the kernarg
     // segment into SGPRs, no tree, no per-lane node fetches, no stack traffic, no divergence between lanes.
-    int32_t n_tiny, n_tiny_quads;               // primitives; the first n_tiny_quads are parallelograms (pack_tiny_prims orders them so)
+    int32_t n_tiny;
     float4 tiny[kTinyTris * 3];                 // plane form: (n | c0), (a1 | c1), (a2 | c2) per primitive (psdr_bvh_build.h tiny_plane_form)
     int32_t tiny_meta[kTinyTris * 4];           // (ids, codeA, codeB, bound on s + t - 1 as float bits: 1 parallelogram / 0 triangle) per primitive
     // Two-level tree (psdr_bvh_build.h ForestBuilder; scenes of a few small meshes plus a few large ones -- a room with
@@ -209,7 +209,7 @@ PSDR_HD void leaf_triangle_test(const float4 &a, const float4 &b, const float4 &
 // scalar loads INSIDE the divergent branch and every primitive waited for its own s_load (three basic blocks per primitive: nothing
 // could be scheduled across them); now the unrolled loop body is one block and the scalar loads of the following primitives are in
 // flight while one is tested.
-template <bool IGN = false, bool QUAD = false>
+template <bool IGN = false>
 PSDR_HD void tiny_prim_test(const float4 &r0, const float4 &r1, const float4 &r2, const int32_t *meta, int i, const Vec3f &o, const Vec3f &d, Hit &best, int &best_i,
                             int ig0 = -1, int ig1 = -1) {
     const float dn = r0.x * d.x + (r0.y * d.y + r0.z * d.z);
@@ -222,8 +222,7 @@ PSDR_HD void tiny_prim_test(const float4 &r0, const float4 &r1, const float4 &r2
     const float v = r2.x * p.x + (r2.y * p.y + (r2.z * p.z - r2.w));
     const float lim = __int_as_float_hd(meta[3]);                  // wave-uniform (kernel argument): bound on u + v -- 1 for a parallelogram (s + t <= 2), 0 for a triangle
     // a ray in the plane (dn = 0) gives t = +-inf or NaN, p and (u, v) NaN: every comparison fails
-    bool hit = (fabsf(u) <= 0.5f) & (fabsf(v) <= 0.5f) & (t >= kRayEpsilon) & (t < best.t);
-    if (!QUAD) hit = hit & (u + v <= lim);                         // a parallelogram (QUAD: the caller's first loop) has no bound on the sum
+    bool hit = (fabsf(u) <= 0.5f) & (fabsf(v) <= 0.5f) & (u + v <= lim) & (t >= kRayEpsilon) & (t < best.t);
     if (IGN) { const int id2 = meta[0]; const bool quad = lim > 0.5f; const int id = (quad && u + v > 0.f) ? (int) ((uint32_t) id2 >> 16) : (id2 & 0xffff); hit = hit & (id != ig0) & (id != ig1); }
     best.t = hit ? t : best.t; best.u = hit ? u : best.u; best.v = hit ? v : best.v; best_i = hit ? i : best_i;
 }
@@ -246,6 +245,14 @@ PSDR_HD void resolve_tiny_hit(const SceneView &sc, Hit &best, int best_i) {
     best.v = k(3) + (k(4) * s + k(5) * t);
 }
 
+// Byte stride of a staged 64-byte node in LDS.  Every lane reads ITS node as four 16-byte words; rows 64 bytes apart put word c of all rows
+// in two of the eight 16-byte bank groups (tools/micro/gather_rate.hip mode 4: 143 cycles per wave fetch), 80 bytes would spread them
+// uniformly -- measured level on every tree workload (profiles/r03_lds_stride_ab.txt: the walk does not wait on these reads), so the
+// rows stay packed and 25 % more of the tree fits.
+#ifndef PSDR_LDS_NODE_STRIDE
+#define PSDR_LDS_NODE_STRIDE 64
+#endif
+constexpr int kLdsNodeStride = PSDR_LDS_NODE_STRIDE;
 // Tree walk from `root` (encoded like a child), keeping the closer hit in `best` (strict: the first of equal hits wins).
 // "while-while" traversal: every lane first walks inner nodes until it holds a leaf (or is done), THEN
 // the wave tests leaf triangles together -- the two phases have very different lengths, and in one
@@ -259,7 +266,7 @@ PSDR_HD void walk_tree(const SceneView &sc, TraversalStack &st, const Vec3f &o, 
         while (cur >= 0 && cur != kDone) {
             BvhNode n;
 #if defined(__HIP_DEVICE_COMPILE__)
-            if (cur < sc.n_lnodes) n = reinterpret_cast<const BvhNode *>(psdr_dyn_lds + sc.off_lnodes)[cur];
+            if (cur < sc.n_lnodes) n = *reinterpret_cast<const BvhNode *>(psdr_dyn_lds + sc.off_lnodes + cur * kLdsNodeStride);
             else
 #endif
                 n = sc.nodes[cur];
@@ -314,7 +321,7 @@ __device__ __forceinline__ void walk_tree4(const SceneView &sc, TraversalStack &
     while (cur != kDone) {
         while (cur >= 0 && cur != kDone) {
             Bvh4Node n;
-            if (cur < sc.n_lnodes) n = reinterpret_cast<const Bvh4Node *>(psdr_dyn_lds + sc.off_lnodes)[cur];
+            if (cur < sc.n_lnodes) n = *reinterpret_cast<const Bvh4Node *>(psdr_dyn_lds + sc.off_lnodes + cur * kLdsNodeStride);
             else n = sc.nodes4[cur];
             const float ax = __int_as_float_hd((int) ((n.exps & 0xffu) << 23)) * inv.x, ay = __int_as_float_hd((int) (((n.exps >> 8) & 0xffu) << 23)) * inv.y,
                         az = __int_as_float_hd((int) (((n.exps >> 16) & 0xffu) << 23)) * inv.z;
@@ -397,10 +404,11 @@ PSDR_HD Hit closest_hit(const SceneView &sc, TraversalStack &st, const Vec3f &o,
         // n_tiny PRIMITIVES (triangles, or parallelograms of two triangles: pack_tiny_prims), unrolled by 6 (the six
         // walls of the Cornell box): the scalar loads of the following primitives are in flight while one is tested
         int best_i = -1;
+        // (one loop: a second loop over the triangles alone, starting at a run-time index, makes the compiler copy the primitive array from the
+        // kernel arguments to scratch in half of the kernels -- 2 KB per lane, C4 PathTracer(3) renderC 24 -> 54 ms -- and the two VALU
+        // instructions it saves per parallelogram bought no time on C2)
 #pragma unroll 6
-        for (int i = 0; i < sc.n_tiny_quads; ++i) tiny_prim_test<IGN, true>(sc.tiny[i * 3], sc.tiny[i * 3 + 1], sc.tiny[i * 3 + 2], sc.tiny_meta + i * 4, i, o, d, best, best_i, ig0, ig1);
-#pragma unroll 2
-        for (int i = sc.n_tiny_quads; i < sc.n_tiny; ++i) tiny_prim_test<IGN, false>(sc.tiny[i * 3], sc.tiny[i * 3 + 1], sc.tiny[i * 3 + 2], sc.tiny_meta + i * 4, i, o, d, best, best_i, ig0, ig1);
+        for (int i = 0; i < sc.n_tiny; ++i) tiny_prim_test<IGN>(sc.tiny[i * 3], sc.tiny[i * 3 + 1], sc.tiny[i * 3 + 2], sc.tiny_meta + i * 4, i, o, d, best, best_i, ig0, ig1);
         resolve_tiny_hit(sc, best, best_i);
         if (FOREST == 2 || !forest) return best;
         // two-level tree: the trees whose box the segment [0, t_best] enters, NEAREST box first (a hit in a near object

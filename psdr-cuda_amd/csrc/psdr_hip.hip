@@ -234,10 +234,10 @@ int plan_lds(const psdr_scene_s *h, LaunchCtx &cx, int reserved) {
     int room = std::max(0, budget - reserved - stack_bytes);
     // a scene without a tree (all primitives in the kernel arguments) ALWAYS stages its <= 16 TriangleInfo rows (1.5 KB): the kSceneTiny
     // kernel instances have no global-memory fallback for them (psdr_device.h load_tri_f)
-    if (tiny_only(h)) room = std::max(room, staged_nodes_of(h) * 64 + h->num_btris * 48 + h->desc.num_tris * 96);
+    if (tiny_only(h)) room = std::max(room, staged_nodes_of(h) * kLdsNodeStride + h->num_btris * 48 + h->desc.num_tris * 96);
     SceneView &sc = cx.sc;
     int off = 0;
-    sc.n_lnodes = std::min(staged_nodes_of(h), room / 64); sc.off_lnodes = off; off += sc.n_lnodes * 64; room -= sc.n_lnodes * 64;      // 4-wide nodes
+    sc.n_lnodes = std::min(staged_nodes_of(h), room / kLdsNodeStride); sc.off_lnodes = off; off += sc.n_lnodes * kLdsNodeStride; room -= sc.n_lnodes * kLdsNodeStride;
     sc.n_lbtris = (sc.n_lnodes == staged_nodes_of(h)) ? std::min(h->num_btris, room / 48) : 0;
     sc.off_lbtris = off; off += sc.n_lbtris * 48; room -= sc.n_lbtris * 48;
     sc.n_ltri = (sc.n_lbtris == h->num_btris) ? std::min(h->desc.num_tris, room / 96) : 0;
@@ -266,7 +266,7 @@ int lds_bytes(const LaunchCtx &cx, const psdr_scene_s *h) { return cx.off_stack 
 
 // the part of the tree that travels in the kernel arguments (tiny scenes, two-level trees)
 void fill_top(const psdr_scene_s *h, SceneView &sc) {
-    sc.n_tiny = h->n_tiny; sc.n_tiny_quads = h->n_tiny_quads;
+    sc.n_tiny = h->n_tiny;
     std::memcpy(sc.tiny, h->tiny, sizeof(h->tiny));
     std::memcpy(sc.tiny_meta, h->tiny_meta, sizeof(h->tiny_meta));
     sc.n_blas = h->n_blas;
@@ -530,7 +530,7 @@ int lbvh_build(psdr_scene_s *h, hipStream_t s, bool &fallback) {
     HIP_TRY(hipStreamSynchronize(s));            // `tris` dies at return
     h->hot_rows = (int) tris.size();
     h->root = 0; h->bvh_depth = info.depth; h->num_nodes = T - 1; h->num_btris = T;
-    h->n_tiny = 0; h->n_tiny_quads = 0; h->n_blas = 0; h->n_inline = 0;
+    h->n_tiny = 0; h->n_blas = 0; h->n_inline = 0;
     {   // the 4-wide tree over the device-built BVH2: its topology is decided on the host (one read-back of the node array; the collapse is
         // O(T)): 263 k triangles +~15 ms on top of the 2 ms device build -- still an order below the host SAH build
         std::vector<BvhNode> host_nodes((size_t) T - 1);
@@ -726,7 +726,7 @@ int psdr_bvh_build(psdr_scene_t h, void *stream) {
                 refit_fits = (int) prims.size() / 3 <= kTinyTris;
                 if (refit_fits) {
                     h->n_tiny = (int) prims.size() / 3;
-                    tiny_plane_form(prims, h->tiny, h->tiny_meta); h->n_tiny_quads = count_tiny_quads(prims);
+                    tiny_plane_form(prims, h->tiny, h->tiny_meta);
                     for (int k = 0; k < h->n_blas; ++k) {
                         const float w = h->blas_lo[k].w;
                         h->blas_lo[k] = top[kMaxInlineTris * 3 + k]; h->blas_lo[k].w = w;
@@ -819,10 +819,10 @@ int psdr_bvh_build(psdr_scene_t h, void *stream) {
     h->bvh_depth = forest ? fb.max_depth : b.max_depth; h->num_nodes = (int) nodes.size(); h->num_btris = (int) btris.size() / 3;
     if (int rc = bvh4_build(h, nodes, forest ? fb.roots : std::vector<int32_t>{root}, forest, s)) return rc;
     h->have_bvh = true;
-    h->n_tiny = 0; h->n_tiny_quads = 0; h->n_blas = 0; h->n_inline = 0;
+    h->n_tiny = 0; h->n_blas = 0; h->n_inline = 0;
     if (forest) {
         h->n_tiny = (int) top_prims.size() / 3;
-        tiny_plane_form(top_prims, h->tiny, h->tiny_meta); h->n_tiny_quads = count_tiny_quads(top_prims);
+        tiny_plane_form(top_prims, h->tiny, h->tiny_meta);
         h->n_inline = (int) fb.inline_ids.size();
         h->n_blas = (int) fb.roots.size();
         for (int k = 0; k < h->n_blas; ++k) {
@@ -838,7 +838,7 @@ int psdr_bvh_build(psdr_scene_t h, void *stream) {
         std::vector<float4> prims;
         pack_tiny_prims(b.btris, prims);           // walls as parallelograms: half the tests
         h->n_tiny = (int) prims.size() / 3;
-        tiny_plane_form(prims, h->tiny, h->tiny_meta); h->n_tiny_quads = count_tiny_quads(prims);
+        tiny_plane_form(prims, h->tiny, h->tiny_meta);
     }
     // what the refit path needs: the levels of the breadth-first node order, the padding, the reference area
     h->tree_tris = T; h->refits_since_build = 0; h->num_builds++; h->bvh_pad = forest ? fb.pad : b.pad;

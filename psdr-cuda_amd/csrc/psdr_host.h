@@ -37,7 +37,7 @@ __device__ __forceinline__ void setup_lds(const LaunchCtx &cx, TraversalStack &s
     float4 *dst = reinterpret_cast<float4 *>(psdr_dyn_lds);
     // the top of the tree this launch walks (level order): 4-wide nodes or BVH2 nodes, 64 bytes either way
     const float4 *src = sc.nodes4 != nullptr ? reinterpret_cast<const float4 *>(sc.nodes4) : reinterpret_cast<const float4 *>(sc.nodes);
-    for (int i = threadIdx.x; i < sc.n_lnodes * 4; i += kBlock) dst[sc.off_lnodes / 16 + i] = src[i];
+    for (int i = threadIdx.x; i < sc.n_lnodes * 4; i += kBlock) dst[sc.off_lnodes / 16 + (i >> 2) * (kLdsNodeStride / 16) + (i & 3)] = src[i];
     for (int i = threadIdx.x; i < sc.n_lbtris * 3; i += kBlock) dst[sc.off_lbtris / 16 + i] = sc.btris[i];
     src = reinterpret_cast<const float4 *>(sc.d.tri_info);
     for (int i = threadIdx.x; i < sc.n_ltri * 6; i += kBlock) dst[sc.off_ltri / 16 + i] = src[i];
@@ -166,7 +166,7 @@ struct psdr_scene_s {
 
     // tiny scenes: the leaf triangles as they travel in the kernel arguments (SceneView::tiny)
     bool tiny_enabled = true;
-    int n_tiny = 0, n_tiny_quads = 0;
+    int n_tiny = 0;
     float4 tiny[kTinyTris * 3] = {};           // plane form (tiny_plane_form)
     int32_t tiny_meta[kTinyTris * 4] = {};
     // two-level tree (psdr_bvh_build.h ForestBuilder): boxes + roots of the per-mesh trees, as they travel in the

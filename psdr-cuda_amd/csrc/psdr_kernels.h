@@ -1080,8 +1080,11 @@ int render_rev(psdr_scene_s *h, const psdr_render_opts *o, const float *adj_img,
         cx.off_pathrec = lds_bytes(cx, h);
         cx.off_sink = cx.off_pathrec + rec_bytes;
         cx2.off_pathrec = 0; cx2.off_sink = rec_bytes;
+        // a scene without a tree keeps its small tables in LDS (kSceneTiny instances: no global-memory fallback): the adjoint kernel stages them too
+        const bool no_tree = lds_bytes(cx, h) == cx.off_stack;
+        if (split && no_tree) cx2 = cx;
         const int dyn1 = cx.off_pathrec + rec_bytes;                   // value kernel of a split launch
-        const int dyn_bytes = split ? rec_bytes + cache_bytes : cx.off_sink + cache_bytes;
+        const int dyn_bytes = (split && !no_tree) ? rec_bytes + cache_bytes : cx.off_sink + cache_bytes;
         if (std::max(dyn_bytes, split ? dyn1 : 0) > h->lds_limit) return fail("psdr_render_d_rev: the launch needs " + std::to_string(dyn_bytes) + " bytes of LDS per workgroup (path record of " +
                                                   std::to_string(depth) + " levels + traversal stacks + gradient cache), the device offers " + std::to_string(h->lds_limit));
         // material-only gradients (no triangle / camera table wanted) run the variant without the geometric adjoints;

@@ -29,7 +29,7 @@ bool setup(HostScene &hs, const psdr_scene_desc *d) {
         std::vector<float4> prims;
         pack_tiny_prims(hs.b.btris, prims);
         hs.sc.n_tiny = (int32_t) (prims.size() / 3);
-        tiny_plane_form(prims, hs.sc.tiny, hs.sc.tiny_meta); hs.sc.n_tiny_quads = count_tiny_quads(prims);
+        tiny_plane_form(prims, hs.sc.tiny, hs.sc.tiny_meta);
     }
     return true;
 }

@@ -8,3 +8,5 @@ import json
 d=json.loads(open("$O/bench.json").read().strip().splitlines()[-1])
 print(d["value"], d["kernel_only"], {k:d["roofline"][k] for k in ("frac","valu_wave_insts_per_launch","wait_any_frac","algorithmic_floor_frac")}, d.get("grad_rel_l2"))
 PY
+# the tree workloads too (a change aimed at C2 once doubled C4's renderC unnoticed)
+timeout 900 python tools/perf_cases.py c4 c5 c3 2>&1 | grep "renderC\|rev\|fwd" > $O/perf_tree.txt; cat $O/perf_tree.txt
