@@ -57,7 +57,7 @@ struct SceneView {
     // n_lbtris leaf triangles and the first n_ltri TriangleInfo rows.
     int32_t n_lnodes, n_lbtris, n_ltri;
     int32_t off_lnodes, off_lbtris, off_ltri;
-    int32_t off_lprim;     // (ids, codeA, codeB, 0) of every kernel-argument primitive, 16 bytes each (resolve_tiny_hit)
+    int32_t off_lprim;     // the hit rows of the kernel-argument primitives, kTinyHitWords words each (resolve_tiny_hit)
     // Tiny scenes (<= kTinyTris triangles, e.g. the 12-triangle Cornell box): the leaf triangles travel IN THE
     // KERNEL ARGUMENTS and closest_hit tests all of them in order -- wave-uniform s_load from the kernarg
     // segment into SGPRs, no tree, no per-lane node fetches, no stack traffic, no divergence between lanes.
@@ -226,23 +226,39 @@ PSDR_HD void tiny_prim_test(const float4 &r0, const float4 &r1, const float4 &r2
     if (IGN) { const int id2 = meta[0]; const bool quad = lim > 0.5f; const int id = (quad && u + v > 0.f) ? (int) ((uint32_t) id2 >> 16) : (id2 & 0xffff); hit = hit & (id != ig0) & (id != ig1); }
     best.t = hit ? t : best.t; best.u = hit ? u : best.u; best.v = hit ? v : best.v; best_i = hit ? i : best_i;
 }
-// (ids, codeA, codeB) of primitive i: from the LDS copy setup_lds made of the kernel-argument words (a per-lane index into the kernel
-// arguments would be a global load), on the host from the SceneView itself.
+// The triangle and its barycentrics from the winning primitive's plane coordinates.  Per primitive and half (the second triangle of a
+// parallelogram is the half s + t > 1; a lone triangle fills both halves alike) eight words: the triangle id and the affine map
+// (u, v) = (k0, k3) + (k1, k2 | k4, k5) (s - 1/2, t - 1/2), coefficients small integers and halves (tiny_hit_row decodes them from the
+// 3-bit codes of pack_tiny_prims).  Device: the rows are staged in LDS by setup_lds, two 16-byte reads per ray (the decode itself was
+// ~35 VALU instructions per ray); host: decoded on the spot.
+constexpr int kTinyHitWords = 16;           // per primitive: two halves of (tri, k0, k1, k2, k3, k4, k5, -)
+PSDR_HD void tiny_hit_row(const int32_t *meta, int half, int32_t &tri, float k[6]) {
+    const int ids = meta[0];
+    const bool quad = ((uint32_t) ids >> 16) != 0xffffu, second = quad && half != 0;
+    const int code = second ? meta[2] : meta[1];
+    tri = second ? (int) ((uint32_t) ids >> 16) : (ids & 0xffff);
+    float c[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) c[i] = (float) (((code >> (3 * i)) & 7) - 2);
+    // tiny_prim_test keeps the plane coordinates shifted by one half: fold the shift into the constant
+    k[0] = c[0] + 0.5f * (c[1] + c[2]); k[1] = c[1]; k[2] = c[2];
+    k[3] = c[3] + 0.5f * (c[4] + c[5]); k[4] = c[4]; k[5] = c[5];
+}
 PSDR_HD void resolve_tiny_hit(const SceneView &sc, Hit &best, int best_i) {
     if (best_i < 0) return;                                         // no hit
+    const int half = best.u + best.v > 0.f ? 1 : 0;
+    float k[6];
 #if defined(__HIP_DEVICE_COMPILE__)
-    const int32_t *m = PSDR_LDS_TABLE(int32_t, sc.off_lprim) + best_i * 4;
+    const float4 *row = reinterpret_cast<const float4 *>(psdr_dyn_lds + sc.off_lprim) + best_i * (kTinyHitWords / 4) + half * 2;
+    const float4 a = row[0], b = row[1];
+    best.tri = __float_as_int_hd(a.x);
+    k[0] = a.y; k[1] = a.z; k[2] = a.w; k[3] = b.x; k[4] = b.y; k[5] = b.z;
 #else
-    const int32_t *m = sc.tiny_meta + best_i * 4;
+    tiny_hit_row(sc.tiny_meta + best_i * 4, half, best.tri, k);
 #endif
-    const int ids = m[0], codeA = m[1], codeB = m[2];
-    const bool second = ((uint32_t) ids >> 16) != 0xffffu && best.u + best.v > 0.f;
-    const int code = second ? codeB : codeA;
-    auto k = [&](int i) { return (float) (((code >> (3 * i)) & 7) - 2); };
-    const float s = best.u + 0.5f, t = best.v + 0.5f;               // tiny_prim_test keeps the plane coordinates shifted by one half
-    best.tri = second ? (int) ((uint32_t) ids >> 16) : (ids & 0xffff);
-    best.u = k(0) + (k(1) * s + k(2) * t);
-    best.v = k(3) + (k(4) * s + k(5) * t);
+    const float u = best.u, v = best.v;
+    best.u = k[0] + (k[1] * u + k[2] * v);
+    best.v = k[3] + (k[4] * u + k[5] * v);
 }
 
 // Byte stride of a staged 64-byte node in LDS.  Every lane reads ITS node as four 16-byte words; rows 64 bytes apart put word c of all rows

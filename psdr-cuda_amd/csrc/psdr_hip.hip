@@ -242,7 +242,7 @@ int plan_lds(const psdr_scene_s *h, LaunchCtx &cx, int reserved) {
     sc.off_lbtris = off; off += sc.n_lbtris * 48; room -= sc.n_lbtris * 48;
     sc.n_ltri = (sc.n_lbtris == h->num_btris) ? std::min(h->desc.num_tris, room / 96) : 0;
     sc.off_ltri = off; off += sc.n_ltri * 96;
-    sc.off_lprim = off; off += h->n_tiny * 16;          // ids / barycentric codes of the kernel-argument primitives (resolve_tiny_hit)
+    sc.off_lprim = off; off += h->n_tiny * kTinyHitWords * 4;          // hit rows of the kernel-argument primitives (resolve_tiny_hit)
     // the small tables of a scene without a tree (psdr_device.h Tab<FL>, staged by setup_lds): 16-byte aligned blocks
     sc.lt_trimesh = sc.lt_meshbsdf = sc.lt_meshemitter = sc.lt_bsdf = sc.lt_emf = sc.lt_emi = sc.lt_fcmf = sc.lt_fpmf = sc.lt_uv = sc.lt_tex = sc.lt_ecmf = sc.lt_epmf = -1;
     sc.lt_nfaces = 0;

@@ -41,9 +41,17 @@ __device__ __forceinline__ void setup_lds(const LaunchCtx &cx, TraversalStack &s
     for (int i = threadIdx.x; i < sc.n_lbtris * 3; i += kBlock) dst[sc.off_lbtris / 16 + i] = sc.btris[i];
     src = reinterpret_cast<const float4 *>(sc.d.tri_info);
     for (int i = threadIdx.x; i < sc.n_ltri * 6; i += kBlock) dst[sc.off_ltri / 16 + i] = src[i];
-    if (threadIdx.x == 0) {
-        int32_t *m = reinterpret_cast<int32_t *>(psdr_dyn_lds + sc.off_lprim);
-        for (int i = 0; i < sc.n_tiny * 4; ++i) m[i] = sc.tiny_meta[i];            // uniform index: scalar loads from the kernel arguments
+    {
+        // hit rows of the kernel-argument primitives (resolve_tiny_hit): the codes come by scalar loads (uniform index), 16 lanes decode one row
+        float *m = reinterpret_cast<float *>(psdr_dyn_lds + sc.off_lprim);
+#pragma unroll 1
+        for (int i = 0; i < sc.n_tiny; ++i) {
+            int32_t tri; float k[6];
+            const int w = threadIdx.x & 7;
+            tiny_hit_row(sc.tiny_meta + i * 4, (threadIdx.x >> 3) & 1, tri, k);
+            const float val = w == 0 ? __int_as_float(tri) : (w == 1 ? k[0] : w == 2 ? k[1] : w == 3 ? k[2] : w == 4 ? k[3] : w == 5 ? k[4] : w == 6 ? k[5] : 0.f);
+            if (threadIdx.x < kTinyHitWords) m[i * kTinyHitWords + threadIdx.x] = val;
+        }
     }
     if (sc.lt_trimesh >= 0) {
         // a scene without a tree: the small tables of a path vertex too (psdr_device.h Tab<FL>), same layouts as the caller's
