@@ -111,13 +111,14 @@ inline void tiny_plane_form(const std::vector<float4> &prims, float4 *rows, int3
             for (int k = 0; k < 3; ++k) { a1[k] = x1[k] / len; a2[k] = x2[k] / len; }
         } else nn[0] = nn[1] = nn[2] = 0.0;                        // degenerate: n . d = 0 for every ray, never hit
         auto dot3 = [](const double *x, const double *y) { return x[0] * y[0] + x[1] * y[1] + x[2] * y[2]; };
-        rows[i * 3] = float4{(float) nn[0], (float) nn[1], (float) nn[2], (float) dot3(nn, p0)};
-        rows[i * 3 + 1] = float4{(float) a1[0], (float) a1[1], (float) a1[2], (float) (dot3(a1, p0) + 0.5)};      // the test works on s - 1/2, t - 1/2
-        rows[i * 3 + 2] = float4{(float) a2[0], (float) a2[1], (float) a2[2], (float) (dot3(a2, p0) + 0.5)};
+        rows[i * 4] = float4{(float) nn[0], (float) nn[1], (float) nn[2], (float) dot3(nn, p0)};
+        rows[i * 4 + 1] = float4{(float) a1[0], (float) a1[1], (float) a1[2], (float) (dot3(a1, p0) + 0.5)};      // the test works on s - 1/2, t - 1/2
+        rows[i * 4 + 2] = float4{(float) a2[0], (float) a2[1], (float) a2[2], (float) (dot3(a2, p0) + 0.5)};
         int32_t ids, codeA, codeB;
         std::memcpy(&ids, &a.w, 4); std::memcpy(&codeA, &b.w, 4); std::memcpy(&codeB, &c.w, 4);
         meta[i * 4] = ids; meta[i * 4 + 1] = codeA; meta[i * 4 + 2] = codeB; const float lim = ((uint32_t) ids >> 16) != 0xffffu ? 1.f : 0.f;           // bound on (s - 1/2) + (t - 1/2)
         std::memcpy(&meta[i * 4 + 3], &lim, 4);
+        rows[i * 4 + 3] = float4{lim, 0.f, 0.f, 0.f}; std::memcpy(&rows[i * 4 + 3].y, &ids, 4);
     }
 }
 

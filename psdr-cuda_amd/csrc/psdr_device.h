@@ -62,7 +62,7 @@ struct SceneView {
     // KERNEL ARGUMENTS and closest_hit tests all of them in order -- wave-uniform s_load from the kernarg
     // segment into SGPRs, no tree, no per-lane node fetches, no stack traffic, no divergence between lanes.
     int32_t n_tiny;
-    float4 tiny[kTinyTris * 3];                 // plane form: (n | c0), (a1 | c1), (a2 | c2) per primitive (psdr_bvh_build.h tiny_plane_form)
+    float4 tiny[kTinyTris * 4];                 // plane form: (n | c0), (a1 | c1), (a2 | c2), (bound, ids, -, -) per primitive: 64 bytes, ONE scalar load (tiny_plane_form)
     int32_t tiny_meta[kTinyTris * 4];           // (ids, codeA, codeB, bound on s + t - 1 as float bits: 1 parallelogram / 0 triangle) per primitive
     // Two-level tree (psdr_bvh_build.h ForestBuilder; scenes of a few small meshes plus a few large ones -- a room with
     // objects): the triangles of the small meshes are the primitives above, every large mesh has its OWN tree in `nodes`,
@@ -198,6 +198,9 @@ PSDR_HD void leaf_triangle_test(const float4 &a, const float4 &b, const float4 &
     if (hit) { best.t = t; best.u = u; best.v = v; best.tri = __float_as_int_hd(a.w); }
 }
 
+#ifndef PSDR_TINY_UNROLL
+#define PSDR_TINY_UNROLL 6
+#endif
 // Replaces __raygen__/__closesthit__/__miss__ (cuda/psdr_cuda.cu:9-45): closest hit with
 // t in [RayEpsilon, tmax], both faces; (u,v) = barycentric weights of vertex 1 and 2.
 // One primitive of a tiny scene (psdr_bvh_build.h pack_tiny_prims): a triangle or a parallelogram of two triangles, in PLANE FORM
@@ -210,7 +213,7 @@ PSDR_HD void leaf_triangle_test(const float4 &a, const float4 &b, const float4 &
 // could be scheduled across them); now the unrolled loop body is one block and the scalar loads of the following primitives are in
 // flight while one is tested.
 template <bool IGN = false>
-PSDR_HD void tiny_prim_test(const float4 &r0, const float4 &r1, const float4 &r2, const int32_t *meta, int i, const Vec3f &o, const Vec3f &d, Hit &best, int &best_i,
+PSDR_HD void tiny_prim_test(const float4 &r0, const float4 &r1, const float4 &r2, const float4 &r3, int i, const Vec3f &o, const Vec3f &d, Hit &best, int &best_i,
                             int ig0 = -1, int ig1 = -1) {
     const float dn = r0.x * d.x + (r0.y * d.y + r0.z * d.z);
     const float on = r0.x * o.x + (r0.y * o.y + (r0.z * o.z - r0.w));
@@ -220,10 +223,10 @@ PSDR_HD void tiny_prim_test(const float4 &r0, const float4 &r1, const float4 &r2
     // |.| source modifier instead of two
     const float u = r1.x * p.x + (r1.y * p.y + (r1.z * p.z - r1.w));
     const float v = r2.x * p.x + (r2.y * p.y + (r2.z * p.z - r2.w));
-    const float lim = __int_as_float_hd(meta[3]);                  // wave-uniform (kernel argument): bound on u + v -- 1 for a parallelogram (s + t <= 2), 0 for a triangle
+    const float lim = r3.x;                                        // wave-uniform (kernel argument): bound on u + v -- 1 for a parallelogram (s + t <= 2), 0 for a triangle
     // a ray in the plane (dn = 0) gives t = +-inf or NaN, p and (u, v) NaN: every comparison fails
     bool hit = (fabsf(u) <= 0.5f) & (fabsf(v) <= 0.5f) & (u + v <= lim) & (t >= kRayEpsilon) & (t < best.t);
-    if (IGN) { const int id2 = meta[0]; const bool quad = lim > 0.5f; const int id = (quad && u + v > 0.f) ? (int) ((uint32_t) id2 >> 16) : (id2 & 0xffff); hit = hit & (id != ig0) & (id != ig1); }
+    if (IGN) { const int id2 = __float_as_int_hd(r3.y); const bool quad = lim > 0.5f; const int id = (quad && u + v > 0.f) ? (int) ((uint32_t) id2 >> 16) : (id2 & 0xffff); hit = hit & (id != ig0) & (id != ig1); }
     best.t = hit ? t : best.t; best.u = hit ? u : best.u; best.v = hit ? v : best.v; best_i = hit ? i : best_i;
 }
 // The triangle and its barycentrics from the winning primitive's plane coordinates.  Per primitive and half (the second triangle of a
@@ -423,8 +426,18 @@ PSDR_HD Hit closest_hit(const SceneView &sc, TraversalStack &st, const Vec3f &o,
         // (one loop: a second loop over the triangles alone, starting at a run-time index, makes the compiler copy the primitive array from the
         // kernel arguments to scratch in half of the kernels -- 2 KB per lane, C4 PathTracer(3) renderC 24 -> 54 ms -- and the two VALU
         // instructions it saves per parallelogram bought no time on C2)
-#pragma unroll 6
-        for (int i = 0; i < sc.n_tiny; ++i) tiny_prim_test<IGN>(sc.tiny[i * 3], sc.tiny[i * 3 + 1], sc.tiny[i * 3 + 2], sc.tiny_meta + i * 4, i, o, d, best, best_i, ig0, ig1);
+        // One s_load_dwordx16 per primitive, unrolled by 6 (the six walls of the Cornell box).  Device: the rows are read through
+        // the kernel-argument segment pointer itself -- SceneView is the first member of the first argument of every kernel that traces
+        // (static_assert in psdr_host.h) -- because an index into the by-value struct that the compiler cannot fold makes it copy the whole
+        // struct to scratch in some kernels (2 KB per lane; C4 PathTracer(3) renderC 24 -> 54 ms when a second loop did that).
+#if defined(__HIP_DEVICE_COMPILE__)
+        typedef __attribute__((address_space(4))) const float4 kernarg_float4;
+        const kernarg_float4 *rows = (kernarg_float4 *) ((__attribute__((address_space(4))) const char *) __builtin_amdgcn_kernarg_segment_ptr() + offsetof(SceneView, tiny));
+#else
+        const float4 *rows = sc.tiny;
+#endif
+#pragma unroll PSDR_TINY_UNROLL
+        for (int i = 0; i < sc.n_tiny; ++i) tiny_prim_test<IGN>(rows[i * 4], rows[i * 4 + 1], rows[i * 4 + 2], rows[i * 4 + 3], i, o, d, best, best_i, ig0, ig1);
         resolve_tiny_hit(sc, best, best_i);
         if (FOREST == 2 || !forest) return best;
         // two-level tree: the trees whose box the segment [0, t_best] enters, NEAREST box first (a hit in a near object

@@ -27,6 +27,8 @@ struct LaunchCtx {
     int32_t off_sink;           // reverse mode: the gradient cache of the workgroup (DeviceSink) behind those
 };
 
+static_assert(offsetof(LaunchCtx, sc) == 0, "closest_hit reads SceneView::tiny through the kernel-argument segment pointer: LaunchCtx (SceneView first) must be the first kernel argument");
+
 // Dynamic LDS block of every kernel:  [ staged BVH nodes | staged leaf triangles | staged
 // TriangleInfo rows | traversal stacks (stack_entries x 256 lanes) ].  The stacks are sized from the
 // depth of THIS scene's tree, so a 12-triangle scene uses 5 KB instead of 40 KB and the freed LDS
@@ -175,7 +177,7 @@ struct psdr_scene_s {
     // tiny scenes: the leaf triangles as they travel in the kernel arguments (SceneView::tiny)
     bool tiny_enabled = true;
     int n_tiny = 0;
-    float4 tiny[kTinyTris * 3] = {};           // plane form (tiny_plane_form)
+    float4 tiny[kTinyTris * 4] = {};           // plane form (tiny_plane_form)
     int32_t tiny_meta[kTinyTris * 4] = {};
     // two-level tree (psdr_bvh_build.h ForestBuilder): boxes + roots of the per-mesh trees, as they travel in the
     // kernel arguments; d_top / d_inline_ids serve the refresh after a device refit
