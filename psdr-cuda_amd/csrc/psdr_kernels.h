@@ -130,6 +130,9 @@ template <class G, class R, int INTEG, int FL, bool NOTREE = false> constexpr in
     // PathTracer material duals of the lean variant: K = 1 fits 4 waves / SIMD without spilling (C2 1.67 ms); K = 3 spills
     // 150 VGPRs there and runs faster at 3 (3.37 -> 2.99 ms)
     if (rough_path_notree && ad_traits<R>::K == 3) return 2;
+    // the instances of a scene without a tree (NOTREE, lean) take one more: PathTracer K = 1 at 5 waves (C2 1.215 -> 1.163 ms, no spills), K = 3 at 4
+    // (1.642 -> 1.624 ms)
+    if (lean && NOTREE && INTEG == PSDR_INTEGRATOR_PATH) return ad_traits<R>::K == 1 ? PSDR_WAVES_DM + 2 : PSDR_WAVES_DM + 1;
     return (lean && INTEG == PSDR_INTEGRATOR_PATH && ad_traits<R>::K == 1) ? PSDR_WAVES_DM + 1 : PSDR_WAVES_DM;
 }
 template <class G, class R, int INTEG, int FL, bool NOTREE = false>
@@ -850,6 +853,8 @@ __global__ __launch_bounds__(kBlock) void k_secondary_edge_rev(LaunchCtx cx, Dev
 // scene in LDS first: on a 4 M-slot launch of an open scene (bunny_light) 40 per CU is 9-15 % SLOWER.  So: 40 when
 // nothing is staged (tiny scene) or when a workgroup still makes >= 8 trips of its grid-stride loop, else 16.
 inline int camera_blocks_per_cu(const psdr_scene_s *h, long long n) {
+    static const int forced = std::getenv("PSDR_CAMERA_BLOCKS") ? std::atoi(std::getenv("PSDR_CAMERA_BLOCKS")) : 0;      // experiments (tools)
+    if (forced > 0) return forced;
     if (h->has_rough) return 16;
     if (h->n_tiny > 0 && h->n_blas == 0) return 40;
     const long long fit = n / ((long long) kBlock * h->num_cus * 8);
