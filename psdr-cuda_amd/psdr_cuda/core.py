@@ -238,12 +238,17 @@ class DiscreteDistribution:
         self.m_pmf = None
         self.m_cmf = None
 
-    def init(self, pmf):
+    def init(self, pmf, total=None):
+        """total: the sum of pmf when the caller already holds it on the host (Scene.configure reads every size and sum of a
+        configure back in one batch): no device-to-host read here."""
         t = pmf.t.detach() if isinstance(pmf, ek.ArrayBase) else torch.as_tensor(pmf).detach()
         t = t.to(torch.float32).reshape(-1)
         self.m_size = int(t.shape[0])
         self.m_pmf = t.contiguous()
-        self.m_sum = float(t.sum().item()) if self.m_size else 0.0
+        if total is not None:
+            self.m_sum = float(total)
+        else:
+            self.m_sum = float(t.sum().item()) if self.m_size else 0.0
         self.m_cmf = torch.cumsum(t, dim=0).contiguous()      # enoki::psum = inclusive prefix sum
 
     @property

@@ -120,11 +120,16 @@ class AreaLight(Emitter):
         self.m_sampling_weight = 1.0
         self.m_ready = False
 
-    def configure(self):
-        psdr_assert(self.m_mesh is not None and self.m_mesh.m_ready)
+    def _luminance_t(self):
         psdr_assert(ek.slices(self.radiance) == 1)
         r = self.radiance.t.detach().reshape(3)
-        lum = float((r[0] * .2126 + r[1] * .7152 + r[2] * .0722).item())
+        return (r[0] * .2126 + r[1] * .7152 + r[2] * .0722).reshape(1)
+
+    def configure(self, lum=None):
+        """lum: the luminance of the radiance when the caller read it back already (Scene.configure batches its reads)"""
+        psdr_assert(self.m_mesh is not None and self.m_mesh.m_ready)
+        if lum is None:
+            lum = float(self._luminance_t().item())
         self.m_sampling_weight = self.m_mesh.m_total_area * lum
         self.m_ready = True
 
@@ -230,6 +235,22 @@ def look_at(origin, target, up):
     return m
 
 
+def compact_indices(keep, count):
+    """Indices of the True entries of `keep`, in order, when their number is already known on the host: no device-to-host read
+    (a boolean-mask index reads the count back)."""
+    if count == 0:
+        return torch.zeros(0, dtype=torch.long, device=keep.device)
+    if hasattr(torch, "nonzero_static"):
+        try:
+            return torch.nonzero_static(keep, size=int(count)).reshape(-1)
+        except (RuntimeError, NotImplementedError):
+            pass
+    pos = torch.cumsum(keep.to(torch.long), dim=0) - 1
+    out = torch.empty(int(count) + 1, dtype=torch.long, device=keep.device)
+    out.scatter_(0, torch.where(keep, pos, torch.full_like(pos, int(count))), torch.arange(keep.shape[0], device=keep.device))
+    return out[:int(count)]
+
+
 class PerspectiveCamera(Sensor):
     """reference include/psdr/sensor/perspective.h, src/sensor/perspective.cpp"""
     _type_name = "PerspectiveCamera"
@@ -242,7 +263,17 @@ class PerspectiveCamera(Sensor):
         return "PerspectiveCamera"
 
     def configure(self, scene):
-        """perspective.cpp:11-112 -> dict of tensors for this sensor."""
+        """perspective.cpp:11-112 -> dict of tensors for this sensor (one call: reads the edge count and the distribution sum back itself;
+        Scene.configure uses configure_begin / configure_finish around its batched read-back)."""
+        st = self.configure_begin(scene)
+        count = int(st["count_t"].item()) if st["count_t"] is not None else 0
+        out = self.configure_finish(st, count)
+        if st.get("sum_t") is not None:
+            self.configure_sum(st, float(st["sum_t"].item()))
+        return out
+
+    def configure_begin(self, scene):
+        """Everything up to the silhouette mask of the primary-edge list, enqueued without a read-back.  count_t: number of kept edges (device)."""
         W, H = scene.opts.width, scene.opts.height
         aspect = float(W) / float(H)
         tw = self._to_world
@@ -282,8 +313,8 @@ class PerspectiveCamera(Sensor):
 
         # ---- primary-edge list, perspective.cpp:39-111
         self.m_enable_edges = False
+        st = {"out": out, "count_t": None, "sum_t": None, "vis": getattr(scene.opts, "primary_edge_vis_check", False)}
         if scene.opts.sppe > 0:
-            rows, zs = [], []
             bt = scene._batch
             ei = bt["tp"]["edges"]
             if ei is not None and tables_native.available(bt["v_world"]):
@@ -298,11 +329,9 @@ class PerspectiveCamera(Sensor):
                 r8, z4, keep8 = tables_native.prim_edges(bt["v_world"], w2s, bt["tri_info"], bt["tp"]["edges_i32"], bt["tp"]["edge_face_normals_u8"],
                                                         cam_pos, cam_dir, film_records)
                 keep = keep8.bool()
-                r8 = r8[keep]
-                if r8.shape[0] > 0:
-                    rows.append(r8); zs.append(z4[keep])
+                st.update(kind="native", r8=r8, z4=z4, keep=keep, count_t=keep.sum().reshape(1))
             elif ei is not None:
-                tinfo, vpos, facen = bt["tri_info"], bt["v_world"], bt["tp"]["edge_face_normals"]
+                tinfo, facen = bt["tri_info"], bt["tp"]["edge_face_normals"]
                 valid = ei[:, 3] >= 0
                 f1 = torch.where(valid, ei[:, 3], torch.zeros_like(ei[:, 3]))
                 f0 = ei[:, 2]
@@ -315,34 +344,54 @@ class PerspectiveCamera(Sensor):
                 d0, d1, dn = (e0 * n0).sum(-1), (e1 * n1).sum(-1), (n0 * n1).sum(-1)
                 keep_face = ~(valid & (((d0 < Epsilon) & (d1 < Epsilon)) | (dn > 1.0 - Epsilon)))      # face-normal meshes
                 keep_smooth = (~valid) | ((d0 > Epsilon) ^ (d1 > Epsilon))                             # smooth-shaded meshes
-                keep = torch.where(facen, keep_face, keep_smooth)
-                info = ei[keep.detach()]
-                if info.shape[0] > 0:
-                    p0 = vpos[info[:, 0]]
-                    p1 = vpos[info[:, 1]]
-                    q0f, q1f = transform_pos(w2s, p0), transform_pos(w2s, p1)
-                    q0, q1 = q0f[:, :2], q1f[:, :2]
-                    # PSDR_PRIMARY_EDGE_VIS_CHECK: (1 / camera-space depth of the two end points, the adjacent faces as int bits).
-                    # 1 / depth is affine along the film segment like the reference's sample-space z, but keeps fp32
-                    # precision (sample-space z = 1 - near / depth loses 3-4 digits at near = 0.1, depth = 500)
-                    cd = _normalize(cam_dir.detach())
-                    iz = [1.0 / ((pp.detach() - cam_pos.detach()) * cd).sum(-1) for pp in (p0, p1)]
-                    fb = [torch.where(info[:, 3] >= 0, info[:, c], info[:, 2]).to(torch.int32).view(torch.float32) for c in (2, 3)]
-                    zs.append(torch.stack(iz + fb, dim=-1))
-                    e = (q1 - q0).detach()
-                    ln = torch.sqrt((e * e).sum(-1))
-                    e = e / ln.unsqueeze(-1)
-                    nrm = torch.stack([-e[:, 1], e[:, 0]], dim=-1)
-                    rows.append(torch.cat([q0, q1, nrm, ln.unsqueeze(-1), torch.zeros_like(ln).unsqueeze(-1)], dim=-1))
-            if rows:
-                pe = torch.cat(rows, dim=0).contiguous()
-                d = DiscreteDistribution(); d.init(pe[:, 6].detach())
-                out.update(prim_edge=pe, prim_cmf=d.m_cmf, prim_pmf=d.m_pmf, prim_sum=d.m_sum,
-                           num_prim_edges=int(pe.shape[0]))
-                if getattr(scene.opts, "primary_edge_vis_check", False):
-                    out["prim_edge_z"] = torch.cat(zs, dim=0).contiguous()
-                self.m_enable_edges = True
+                keep = torch.where(facen, keep_face, keep_smooth).detach()
+                st.update(kind="torch", keep=keep, count_t=keep.sum().reshape(1), w2s=w2s, cam_pos=cam_pos, cam_dir=cam_dir, bt=bt)
+        return st
+
+    def configure_finish(self, st, count):
+        """The compacted primary-edge table from configure_begin's state and the number of kept edges.  st["sum_t"]: the sum of the edge
+        lengths on the device (configure_sum stores it once read back)."""
+        out = st["out"]
+        if st["count_t"] is None or count <= 0:
+            return out
+        bt_keep = st["keep"]
+        idx = compact_indices(bt_keep, count)
+        if st["kind"] == "native":
+            pe = st["r8"][idx].contiguous()
+            zs = st["z4"][idx]
+        else:
+            ei, vpos = st["bt"]["tp"]["edges"], st["bt"]["v_world"]
+            w2s, cam_pos, cam_dir = st["w2s"], st["cam_pos"], st["cam_dir"]
+            info = ei[idx]
+            p0 = vpos[info[:, 0]]
+            p1 = vpos[info[:, 1]]
+            q0f, q1f = transform_pos(w2s, p0), transform_pos(w2s, p1)
+            q0, q1 = q0f[:, :2], q1f[:, :2]
+            # PSDR_PRIMARY_EDGE_VIS_CHECK: (1 / camera-space depth of the two end points, the adjacent faces as int bits).
+            # 1 / depth is affine along the film segment like the reference's sample-space z, but keeps fp32
+            # precision (sample-space z = 1 - near / depth loses 3-4 digits at near = 0.1, depth = 500)
+            cd = _normalize(cam_dir.detach())
+            iz = [1.0 / ((pp.detach() - cam_pos.detach()) * cd).sum(-1) for pp in (p0, p1)]
+            fb = [torch.where(info[:, 3] >= 0, info[:, c], info[:, 2]).to(torch.int32).view(torch.float32) for c in (2, 3)]
+            zs = torch.stack(iz + fb, dim=-1)
+            e = (q1 - q0).detach()
+            ln = torch.sqrt((e * e).sum(-1))
+            e = e / ln.unsqueeze(-1)
+            nrm = torch.stack([-e[:, 1], e[:, 0]], dim=-1)
+            pe = torch.cat([q0, q1, nrm, ln.unsqueeze(-1), torch.zeros_like(ln).unsqueeze(-1)], dim=-1).contiguous()
+        pmf = pe[:, 6].detach().to(torch.float32).contiguous()
+        st["sum_t"] = pmf.sum().reshape(1)
+        d = DiscreteDistribution(); d.init(pmf, total=0.0)          # m_sum: configure_sum
+        st["distrb"] = d
+        out.update(prim_edge=pe, prim_cmf=d.m_cmf, prim_pmf=d.m_pmf, prim_sum=0.0, num_prim_edges=int(pe.shape[0]))
+        if st["vis"]:
+            out["prim_edge_z"] = zs.contiguous()
+        self.m_enable_edges = True
         return out
+
+    def configure_sum(self, st, total):
+        st["distrb"].m_sum = float(total)
+        st["out"]["prim_sum"] = float(total)
 
 
 PositionSample = PositionSampleD      # kept as an alias (older name of this build)
@@ -1030,13 +1079,12 @@ class Scene(Object):
             tri_info = tables_native.tri_rows(v_world, tp["faces_i32"], lambda v, f: process_mesh(v, f)[0])
         else:
             tri_info, _ = process_mesh(v_world, tp["faces"])
-        areas = torch.zeros(len(meshes), device=v_world.device).index_add(0, tp["tmesh"], tri_info[:, 21].detach()).tolist()   # one sync
+        # total areas: on the device until _mesh_areas_to_host (configure() reads every size and sum it needs back in ONE batch)
+        self._areas_t = torch.zeros(len(meshes), device=v_world.device).index_add(0, tp["tmesh"], tri_info[:, 21].detach())
         for i, m in enumerate(meshes):
             m._vertex_positions = v_world[tp["v_off"][i]:tp["v_off"][i + 1]]
             m._triangle_info = tri_info[tp["f_off"][i]:tp["f_off"][i + 1]]
             m._vertex_normals_raw = None
-            m.m_total_area = float(areas[i])
-            m.m_inv_total_area = 1.0 / m.m_total_area
             m._face_distrb = None
             m._sec_edge_info = None
             m._triangle_uv = None
@@ -1046,8 +1094,13 @@ class Scene(Object):
             m.m_ready = True
         return tp, v_world, tri_info
 
+    def _mesh_areas_to_host(self, areas):
+        for m, a in zip(self.m_meshes, areas):
+            m.m_total_area = float(np.float32(a))
+            m.m_inv_total_area = 1.0 / m.m_total_area
+
     def _secondary_edges(self, tp, v_world, tri_info):
-        """SecondaryEdgeInfo of every mesh with edges (mesh.cpp:251-270 + coplanar filter), one pass"""
+        """SecondaryEdgeInfo of every mesh with edges (mesh.cpp:251-270) and the coplanar filter's mask, one pass"""
         ei = tp["edges"]
         if ei is None:
             return None
@@ -1070,8 +1123,30 @@ class Scene(Object):
             n0 = tri_info[ei[:, 2], 18:21]     # reduction depends on the memory layout of its operand, and the committed fixtures follow these decisions)
             n1 = tri_info[torch.where(is_b, torch.zeros_like(ei[:, 3]), ei[:, 3]), 18:21] * (~is_b).unsqueeze(-1).to(torch.float32)
             keep = ((n0 * n1).sum(-1) < 1.0 - EdgeEpsilon).detach()
-        self._sec_edge_faces = tp["edges_i32"][keep][:, 2:4].contiguous()      # adjacent faces (global ids; -1 = none)
-        return info[keep]
+        return info, keep          # configure() compacts once it holds the count (no read-back here)
+
+    def _upload_small(self, arrays, d):
+        """Host float32 arrays -> device tensors through ONE staging buffer and one copy (pinned + asynchronous on a GPU: a pageable
+        host-to-device copy would wait for everything queued on the stream)."""
+        sizes = [int(a.size) for a in arrays]
+        flat = np.concatenate([np.ascontiguousarray(a, dtype=np.float32).reshape(-1) for a in arrays]) if arrays else np.zeros(0, np.float32)
+        if d.type == "cpu":
+            dev = torch.from_numpy(flat.copy())
+        else:
+            pin = getattr(self, "_pin", None)
+            # two staging buffers used alternately: the copy out of one is complete before it is written again (every configure() reads
+            # results back after queueing its copy)
+            if pin is None or pin[0].numel() < flat.size:
+                pin = [torch.empty(max(256, 2 * flat.size), dtype=torch.float32).pin_memory() for _ in range(2)]
+                self._pin, self._pin_turn = pin, 0
+            self._pin_turn ^= 1
+            buf = pin[self._pin_turn]
+            buf[:flat.size].copy_(torch.from_numpy(flat))
+            dev = buf[:flat.size].to(d, non_blocking=True)
+        out, o = [], 0
+        for n in sizes:
+            out.append(dev[o:o + n]); o += n
+        return out
 
     def _material_tables(self, d):
         """BSDF records + texel pool (+ the environment map's texels behind them): the part of the tables that a
@@ -1176,10 +1251,10 @@ class Scene(Object):
         self.m_lower = allv.min(dim=0)[0]
         self.m_upper = torch.clamp(allv.max(dim=0)[0], min=float(np.finfo(np.float32).tiny))
 
-        # sensors (+ camera positions into the AABB, scene.cpp:104-119)
-        self._sensor_tables = [s.configure(self) for s in self.m_sensors]
-        for st in self._sensor_tables:
-            cp = st["cam"][_abi.CAM_POS:_abi.CAM_POS + 3].detach()
+        # sensors (+ camera positions into the AABB, scene.cpp:104-119): everything up to the silhouette masks, no read-back yet
+        sensor_states = [s.configure_begin(self) for s in self.m_sensors]
+        for st in sensor_states:
+            cp = st["out"]["cam"][_abi.CAM_POS:_abi.CAM_POS + 3].detach()
             self.m_lower, self.m_upper = torch.minimum(self.m_lower, cp), torch.maximum(self.m_upper, cp)
 
         # environment lighting: bounding mesh added once, scene.cpp:135-180
@@ -1203,11 +1278,36 @@ class Scene(Object):
             self.m_has_bound_mesh = True
             tp, v_world, tri_info22 = self._configure_meshes()        # once: the mesh list just grew (no edges on the box)
             self._batch = {"tp": tp, "v_world": v_world, "tri_info": tri_info22}
+            for st in sensor_states:                                  # the edge states hold the batch they were made from (same edges: the box has none)
+                if "bt" in st:
+                    st["bt"] = self._batch
             if o.log_level > 0:
                 self.log("Bounding mesh added for environmental lighting.")
 
         face_offset = tp["f_off"]
         T = face_offset[-1]
+        # secondary edges, scene.cpp:219-244: records and the coplanar filter's mask (no read-back yet)
+        sec = self._secondary_edges(tp, v_world, tri_info22) if o.sppse > 0 else None
+
+        # ---- ONE read-back for every size and sum the host needs from here on: mesh areas, the luminance of the area lights, the
+        # sums of their face distributions, the numbers of kept secondary / primary edges
+        area_lights = [e for e in self.m_emitters if not isinstance(e, EnvironmentMap)]
+        parts = [self._areas_t.double()]
+        parts += [e._luminance_t().double() for e in area_lights]
+        parts += [e.m_mesh._triangle_info[:, 21].detach().to(torch.float32).sum().reshape(1).double() for e in area_lights]
+        parts.append(sec[1].sum().reshape(1).double() if sec is not None else torch.zeros(1, dtype=torch.float64, device=d))
+        parts += [(st["count_t"].double() if st["count_t"] is not None else torch.zeros(1, dtype=torch.float64, device=d)) for st in sensor_states]
+        stats = torch.cat(parts).tolist()
+        M, L = len(self.m_meshes), len(area_lights)
+        self._mesh_areas_to_host(stats[:M])
+        lum_of = {id(e): stats[M + i] for i, e in enumerate(area_lights)}
+        face_sum_of = {id(e): stats[M + L + i] for i, e in enumerate(area_lights)}
+        n_sec = int(round(stats[M + 2 * L]))
+        n_prim = [int(round(x)) for x in stats[M + 2 * L + 1:]]
+
+        # sensors: compacted primary-edge tables (their sums are read back with the secondary edges' at the end)
+        self._sensor_tables = [s.configure_finish(st, n) for s, st, n in zip(self.m_sensors, sensor_states, n_prim)]
+
         tri_info = torch.cat([tri_info22, torch.zeros(T, 2, device=d)], dim=-1).contiguous()
         tb = {"tri_info": tri_info, "tri_mesh": tp["tri_mesh"], "num_tris": T,
               "tri_uv": None, "face_offset": face_offset}
@@ -1219,38 +1319,53 @@ class Scene(Object):
         env_tex = mt.pop("env_tex")
         tb.update(mt)
 
-        # emitters, scene.cpp:183-196 + area.cpp:10-16
+        # emitters, scene.cpp:183-196 + area.cpp:10-16.  The small host-made tables travel in one pinned staging buffer (asynchronous copy:
+        # a pageable host-to-device copy waits for the stream)
         em_ids = {id(e): i for i, e in enumerate(self.m_emitters)}
-        tb["mesh_emitter"] = torch.tensor([em_ids.get(id(m.m_emitter), -1) for m in self.m_meshes], dtype=torch.int32, device=d)
+        mesh_emitter = [em_ids.get(id(m.m_emitter), -1) for m in self.m_meshes]
         Ne = len(self.m_emitters)
-        ef = torch.zeros(max(Ne, 1), _abi.EMITTER_F_STRIDE, device=d)
-        ei = torch.zeros(max(Ne, 1), _abi.EMITTER_I_STRIDE, dtype=torch.int32, device=d)
+        ef_h = np.zeros((max(Ne, 1), _abi.EMITTER_F_STRIDE), dtype=np.float32)
+        ei_h = np.zeros((max(Ne, 1), _abi.EMITTER_I_STRIDE), dtype=np.int32)
         rad = torch.zeros(max(Ne, 1), 3, device=d)
         cmfs, pmfs, coff = [], [], 0
+        ed_pmf = np.zeros(1, dtype=np.float32)
+        ed_sum = 0.0
         if Ne:
             weights = []
             for e in self.m_emitters:
-                e.configure()
+                if isinstance(e, EnvironmentMap):
+                    e.configure()
+                else:
+                    e.configure(lum_of[id(e)])
                 weights.append(e.m_sampling_weight)
-            ed = DiscreteDistribution(); ed.init(torch.tensor(weights, dtype=torch.float32, device=d))
-            inv_total = np.float32(1.0) / np.float32(ed.m_sum)
+            ed_pmf = np.asarray(weights, dtype=np.float32)
+            ed_sum = float(torch.from_numpy(ed_pmf).sum().item())           # host tensor: the float32 sum torch forms
+            inv_total = np.float32(1.0) / np.float32(ed_sum)
             rads = []
             for i, e in enumerate(self.m_emitters):
                 e.m_sampling_weight = float(np.float32(e.m_sampling_weight) * inv_total)
                 mi = self.m_meshes.index(e.m_mesh)
                 if isinstance(e, EnvironmentMap):
-                    ef[i, 3] = e.m_sampling_weight
-                    ei[i] = torch.tensor([mi, face_offset[mi], e.m_mesh.num_faces, 0], dtype=torch.int32)
+                    ef_h[i, 3] = e.m_sampling_weight
+                    ei_h[i] = [mi, face_offset[mi], e.m_mesh.num_faces, 0]
                     rads.append(torch.zeros(3, device=d))
                     continue
-                fd = e.m_mesh._face_distrb
-                ef[i, 3], ef[i, 4], ef[i, 5] = e.m_sampling_weight, e.m_mesh.m_inv_total_area, fd.m_sum
-                ei[i] = torch.tensor([mi, face_offset[mi], e.m_mesh.num_faces, coff], dtype=torch.int32)
+                fd = DiscreteDistribution(); fd.init(e.m_mesh._triangle_info[:, 21].detach(), total=face_sum_of[id(e)])
+                e.m_mesh._face_distrb = fd
+                ef_h[i, 3], ef_h[i, 4], ef_h[i, 5] = e.m_sampling_weight, e.m_mesh.m_inv_total_area, fd.m_sum
+                ei_h[i] = [mi, face_offset[mi], e.m_mesh.num_faces, coff]
                 cmfs.append(fd.m_cmf); pmfs.append(fd.m_pmf); coff += fd.m_size
                 rads.append(e.radiance.t.reshape(3))
             rad = torch.stack(rads)
+        ed_cmf = np.cumsum(ed_pmf, dtype=np.float32)
+        small = self._upload_small([np.asarray(mesh_emitter, dtype=np.int32).view(np.float32), ef_h.reshape(-1), ei_h.reshape(-1).view(np.float32),
+                                    ed_pmf, ed_cmf], d)
+        tb["mesh_emitter"] = small[0].view(torch.int32)
+        ef = small[1].reshape(max(Ne, 1), _abi.EMITTER_F_STRIDE)
+        ei = small[2].view(torch.int32).reshape(max(Ne, 1), _abi.EMITTER_I_STRIDE)
+        if Ne:
             ef = torch.cat([rad.detach(), ef[:, 3:]], dim=-1)
-            tb["emitter_cmf"], tb["emitter_pmf"], tb["emitter_sum"] = ed.m_cmf, ed.m_pmf, ed.m_sum
+            tb["emitter_cmf"], tb["emitter_pmf"], tb["emitter_sum"] = small[4], small[3], ed_sum
         else:
             z = torch.zeros(1, device=d)
             tb["emitter_cmf"], tb["emitter_pmf"], tb["emitter_sum"] = z, z, 0.0
@@ -1266,16 +1381,32 @@ class Scene(Object):
         else:
             tb.update(env_emitter=-1, env_tex=[0, 0, 0], env_reso=[0, 0], env_f=None, env_cmf=None, env_pmf=None, env_sum=0.0)
 
-        # secondary edges, scene.cpp:219-244
-        se_all = self._secondary_edges(tp, v_world, tri_info22) if o.sppse > 0 else None
-        if se_all is not None and se_all.shape[0] > 0:
-            se = se_all.contiguous()
+        # secondary edges: the kept records, their length distribution
+        sums = [st["sum_t"] for st in sensor_states if st.get("sum_t") is not None]
+        sd = None
+        if sec is not None and n_sec > 0:
+            idx = compact_indices(sec[1], n_sec)
+            se = sec[0][idx].contiguous()
+            self._sec_edge_faces = tp["edges_i32"][idx][:, 2:4].contiguous()      # adjacent faces (global ids; -1 = none)
             e1 = se[:, 3:6].detach()
-            sd = DiscreteDistribution(); sd.init(torch.sqrt((e1 * e1).sum(-1)))
-            tb.update(sec_edge=se, sec_cmf=sd.m_cmf, sec_pmf=sd.m_pmf, sec_sum=sd.m_sum, num_sec_edges=int(se.shape[0]),
+            ln = torch.sqrt((e1 * e1).sum(-1))
+            sd = DiscreteDistribution(); sd.init(ln, total=0.0)
+            sums.append(sd.m_pmf.sum().reshape(1))
+            tb.update(sec_edge=se, sec_cmf=sd.m_cmf, sec_pmf=sd.m_pmf, sec_sum=0.0, num_sec_edges=int(se.shape[0]),
                       sec_edge_faces=self._sec_edge_faces)
         else:
+            if sec is not None:
+                self._sec_edge_faces = tp["edges_i32"][:0, 2:4].contiguous()
             tb.update(sec_edge=None, sec_cmf=None, sec_pmf=None, sec_sum=0.0, num_sec_edges=0, sec_edge_faces=None)
+        # ---- second (and last) read-back: the sums of the edge distributions, formed over the compacted tables
+        if sums:
+            vals = torch.cat(sums).tolist()
+            k = 0
+            for s_, st in zip(self.m_sensors, sensor_states):
+                if st.get("sum_t") is not None:
+                    s_.configure_sum(st, vals[k]); k += 1
+            if sd is not None:
+                sd.m_sum = float(vals[k]); tb["sec_sum"] = sd.m_sum
         self._version += 1
         tb["version"] = self._version
         tb["geo_version"] = self._version      # stamps the geometry: the BVH on the native handle is tied to it (Integrator._prepare)
