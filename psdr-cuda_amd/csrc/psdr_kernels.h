@@ -725,7 +725,11 @@ template <int FL> struct DeviceSink {
 // diffuse DirectIntegrator instance needs 187 and runs faster at 3 (C2 direct all gradients 4.1 -> 3.4 ms), the
 // others lose 50-100 % there to spills
 template <int FL, bool GEO, int INTEG> constexpr int rev_waves() {
-    if (!GEO) return (FL & (kSceneEnv | kSceneRough)) == 0 ? PSDR_WAVES_REV_MAT + 1 : PSDR_WAVES_REV_MAT;   // plain diffuse variant: 130 VGPRs, C2 texel gradient 3.4 -> 2.8 ms
+    if (!GEO) {
+        if ((FL & (kSceneEnv | kSceneRough)) != 0) return PSDR_WAVES_REV_MAT;
+        // plain diffuse variant: 130 VGPRs, C2 texel gradient 3.4 -> 2.8 ms at 4; its instance for scenes without a tree (117 VGPRs) at 5: 2.17 -> 2.09 ms
+        return (FL & kSceneTiny) ? PSDR_WAVES_REV_MAT + 2 : PSDR_WAVES_REV_MAT + 1;
+    }
     return (INTEG == PSDR_INTEGRATOR_DIRECT && !(FL & kSceneRough)) ? 3 : PSDR_WAVES_REV;
 }
 // STAGE 0: value sweep + adjoint sweep per slot.  Split launch (tree scenes, render_rev): STAGE 1 = the value sweep alone at 3

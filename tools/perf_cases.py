@@ -21,7 +21,18 @@ def timeit(fn, reps=3):
     ts = []
     for _ in range(max(reps, 3)):
         t0 = time.perf_counter(); fn(); torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
-    return sorted(ts)[len(ts) // 2]
+    ms = sorted(ts)[len(ts) // 2]
+    if ms < 4.0:
+        # a short launch timed alone carries the launch latency and whatever clock the idle GPU had dropped to (the same call read 1.2 or
+        # 2.0 ms from run to run): batches of 8 back-to-back calls, best of 3
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            for _ in range(8):
+                fn()
+            torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) * 1e3 / 8)
+        ms = min(ts)
+    return ms
 
 
 def main():
