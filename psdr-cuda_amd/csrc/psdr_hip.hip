@@ -681,6 +681,12 @@ int psdr_scene_set_tables(psdr_scene_t h, const psdr_scene_desc *desc) {
     return 0;
 }
 
+// A copy between host and device buffers ON THE CALLER'S STREAM that is complete when the call returns (the host build reads the data /
+// the source vectors go out of scope) -- not hipMemcpy: the null stream would drag every other stream of the process into the wait.
+static hipError_t copy_on_stream(void *dst, const void *src, size_t bytes, hipMemcpyKind kind, hipStream_t s) {
+    if (hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, s)) return e;
+    return hipStreamSynchronize(s);
+}
 int psdr_bvh_build(psdr_scene_t h, void *stream) {
     if (!h || !h->have_tables) return fail("Scene not loaded yet!");
     hipStream_t s = (hipStream_t) stream;
@@ -754,13 +760,13 @@ int psdr_bvh_build(psdr_scene_t h, void *stream) {
     HIP_TRY(hipStreamSynchronize(s));
     h->emitter_i.assign((size_t) std::max(h->desc.num_emitters, 0) * PSDR_EMITTER_I_STRIDE, 0);
     if (h->desc.num_emitters > 0 && h->desc.emitter_i)
-        HIP_TRY(hipMemcpy(h->emitter_i.data(), h->desc.emitter_i, h->emitter_i.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+        HIP_TRY(copy_on_stream(h->emitter_i.data(), h->desc.emitter_i, h->emitter_i.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     // ---- which tree: two-level (a few small meshes + a few large ones) or one tree over everything
     std::vector<int32_t> tri_mesh;
     bool forest = false;
     if (h->two_level_enabled && h->tiny_enabled && T > kTinyTris && h->desc.num_meshes > 0 && h->desc.env_emitter < 0) {
         tri_mesh.resize((size_t) T);
-        HIP_TRY(hipMemcpy(tri_mesh.data(), h->desc.tri_mesh, tri_mesh.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+        HIP_TRY(copy_on_stream(tri_mesh.data(), h->desc.tri_mesh, tri_mesh.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
         forest = ForestBuilder::eligible(tri_mesh.data(), T, h->desc.num_meshes);
     }
     Builder b;
@@ -811,8 +817,8 @@ int psdr_bvh_build(psdr_scene_t h, void *stream) {
             HIP_TRY(hipMalloc(&h->d_hot_map, h->hot_cap * sizeof(int32_t)));
             HIP_TRY(hipMalloc(&h->d_hot_tris, kMaxHotRows * sizeof(int32_t)));
         }
-        HIP_TRY(hipMemcpy(h->d_hot_map, map.data(), map.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(h->d_hot_tris, tris.data(), tris.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIP_TRY(copy_on_stream(h->d_hot_map, map.data(), map.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+        HIP_TRY(copy_on_stream(h->d_hot_tris, tris.data(), tris.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
         h->hot_rows = (int) tris.size();
     }
     h->root = root;
@@ -833,7 +839,7 @@ int psdr_bvh_build(psdr_scene_t h, void *stream) {
         }
         if (!h->d_top) HIP_TRY(hipMalloc(&h->d_top, sizeof(float4) * (kMaxInlineTris * 3 + 2 * kMaxBlas)));
         if (!h->d_inline_ids) HIP_TRY(hipMalloc(&h->d_inline_ids, sizeof(int32_t) * kMaxInlineTris));
-        if (h->n_inline) HIP_TRY(hipMemcpy(h->d_inline_ids, fb.inline_ids.data(), sizeof(int32_t) * (size_t) h->n_inline, hipMemcpyHostToDevice));
+        if (h->n_inline) HIP_TRY(copy_on_stream(h->d_inline_ids, fb.inline_ids.data(), sizeof(int32_t) * (size_t) h->n_inline, hipMemcpyHostToDevice, s));
     } else if (tiny) {
         std::vector<float4> prims;
         pack_tiny_prims(b.btris, prims);           // walls as parallelograms: half the tests

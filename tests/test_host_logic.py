@@ -320,3 +320,46 @@ def test_material_only_configure_reuses_the_geometry_tables():
     a = sc.tables(0)["tri_info"]
     sc.configure()
     assert sc.tables(0)["tri_info"] is not a and sc.tables(0)["tri_info"].requires_grad
+
+
+def test_compact_indices_matches_a_boolean_mask_select():
+    """Scene.configure compacts its edge tables with counts it already holds (no read-back): same rows, same order as table[mask]"""
+    from psdr_cuda.scene import compact_indices
+    g = torch.Generator().manual_seed(3)
+    for n in (1, 7, 64, 1000):
+        keep = torch.rand(n, generator=g) < 0.4
+        idx = compact_indices(keep, int(keep.sum()))
+        assert torch.equal(idx, torch.nonzero(keep).reshape(-1))
+        # the scatter formulation behind it (used where nonzero_static is missing)
+        pos = torch.cumsum(keep.long(), 0) - 1
+        out = torch.empty(int(keep.sum()) + 1, dtype=torch.long)
+        out.scatter_(0, torch.where(keep, pos, torch.full_like(pos, int(keep.sum()))), torch.arange(n))
+        assert torch.equal(out[:int(keep.sum())], idx)
+    assert compact_indices(torch.zeros(5, dtype=torch.bool), 0).numel() == 0
+
+
+def test_batched_readback_configure_keeps_the_distribution_sums_and_areas():
+    """configure() reads sizes and sums back in two batches: what it stores equals what the one-by-one reads gave (areas, emitter weights,
+    face / edge distribution sums, edge counts), and a sensor configured on its own (its public configure()) agrees with the batched path"""
+    sc, _ = load_scene("cbox_bunny", res=32, spp=1, sppe=1, sppse=1)
+    tb = sc.tables(0)
+    for m in sc.m_meshes:
+        a = float(m._triangle_info[:, 21].sum())
+        assert abs(m.m_total_area - a) <= 1e-5 * a and abs(m.m_inv_total_area * m.m_total_area - 1.0) < 1e-12
+    assert tb["num_sec_edges"] == tb["sec_edge"].shape[0] == tb["sec_pmf"].shape[0] == tb["sec_edge_faces"].shape[0] > 0
+    assert abs(tb["sec_sum"] - float(tb["sec_pmf"].sum())) <= 1e-6 * tb["sec_sum"] and abs(float(tb["sec_cmf"][-1]) - tb["sec_sum"]) <= 1e-4 * tb["sec_sum"]
+    assert tb["num_prim_edges"] == tb["prim_edge"].shape[0] > 0 and abs(tb["prim_sum"] - float(tb["prim_pmf"].sum())) <= 1e-6 * tb["prim_sum"]
+    e = sc.m_emitters[0]
+    fd = e.m_mesh._face_distrb
+    assert abs(fd.m_sum - float(fd.m_pmf.sum())) <= 1e-6 * fd.m_sum and abs(tb["emitter_sum"] - float(tb["emitter_pmf"].sum())) < 1e-6 * tb["emitter_sum"]
+    assert abs(float(tb["emitter_f"][0, 4]) * e.m_mesh.m_total_area - 1.0) < 1e-6 and abs(float(tb["emitter_f"][0, 5]) - fd.m_sum) <= 1e-6 * fd.m_sum
+    alone = sc.m_sensors[0].configure(sc)                        # begin + its own reads + finish
+    assert alone["num_prim_edges"] == tb["num_prim_edges"] and torch.equal(alone["prim_edge"], tb["prim_edge"]) and alone["prim_sum"] == tb["prim_sum"]
+
+
+def test_discrete_distribution_takes_a_known_total():
+    d = psdr_cuda.DiscreteDistribution()
+    pmf = torch.tensor([0.5, 1.5, 2.0])
+    d.init(pmf, total=4.0)
+    e = psdr_cuda.DiscreteDistribution(); e.init(pmf)
+    assert d.m_sum == e.m_sum == 4.0 and torch.equal(d.m_cmf, e.m_cmf)
