@@ -198,6 +198,29 @@ PSDR_HD void leaf_triangle_test(const float4 &a, const float4 &b, const float4 &
     if (hit) { best.t = t; best.u = u; best.v = v; best.tri = __float_as_int_hd(a.w); }
 }
 
+// The triangles of a leaf that live in global memory (L2): TWO at a time -- the six loads of a pair are in flight together, so a leaf of four
+// costs two memory latencies instead of four (the loop over one triangle at a time waited for each in turn).  An odd end tests its last
+// triangle twice: the second test fails t < best.t, nothing changes.
+// Measured (profiles/r03_leaf_pair_ab.txt): the rough-conductor two-level kernels (flag set 6: C5) gain 2-10 %; the lean diffuse kernels at 5 waves
+// per SIMD LOSE 4-10 % to the twelve extra registers -- so the pairing is a per-translation-unit choice (psdr_variant.hip).
+#ifndef PSDR_LEAF_PAIR
+#define PSDR_LEAF_PAIR 0
+#endif
+template <bool IGN>
+PSDR_HD void leaf_from_memory(const float4 *bt, int cnt, const Vec3f &o, const Vec3f &d, Hit &best, int ig0, int ig1) {
+#if PSDR_LEAF_PAIR
+    for (int i = 0; i < cnt; i += 2) {
+        const int j = i + 1 < cnt ? i + 1 : i;
+        const float4 a0 = bt[i * 3], b0 = bt[i * 3 + 1], c0 = bt[i * 3 + 2];
+        const float4 a1 = bt[j * 3], b1 = bt[j * 3 + 1], c1 = bt[j * 3 + 2];
+        leaf_triangle_test<IGN>(a0, b0, c0, o, d, best, ig0, ig1);
+        leaf_triangle_test<IGN>(a1, b1, c1, o, d, best, ig0, ig1);
+    }
+#else
+    for (int i = 0; i < cnt; ++i) leaf_triangle_test<IGN>(bt[i * 3], bt[i * 3 + 1], bt[i * 3 + 2], o, d, best, ig0, ig1);
+#endif
+}
+
 #ifndef PSDR_TINY_UNROLL
 #define PSDR_TINY_UNROLL 6
 #endif
@@ -308,15 +331,12 @@ PSDR_HD void walk_tree(const SceneView &sc, TraversalStack &st, const Vec3f &o, 
             const bool staged = first + cnt <= sc.n_lbtris;
             const float4 *lt = reinterpret_cast<const float4 *>(psdr_dyn_lds + sc.off_lbtris);
 #endif
-            for (int i = 0; i < cnt; ++i) {
-                float4 a, b, c;
 #if defined(__HIP_DEVICE_COMPILE__)
-                if (staged) { a = lt[(first + i) * 3]; b = lt[(first + i) * 3 + 1]; c = lt[(first + i) * 3 + 2]; }
-                else
+            if (staged) {
+                for (int i = 0; i < cnt; ++i) leaf_triangle_test<IGN>(lt[(first + i) * 3], lt[(first + i) * 3 + 1], lt[(first + i) * 3 + 2], o, d, best, ig0, ig1);
+            } else
 #endif
-                { a = sc.btris[(first + i) * 3]; b = sc.btris[(first + i) * 3 + 1]; c = sc.btris[(first + i) * 3 + 2]; }
-                leaf_triangle_test<IGN>(a, b, c, o, d, best, ig0, ig1);
-            }
+                leaf_from_memory<IGN>(sc.btris + (size_t) first * 3, cnt, o, d, best, ig0, ig1);
             cur = sp > 0 ? st.get(--sp) : kDone;
         }
     }
@@ -381,12 +401,10 @@ __device__ __forceinline__ void walk_tree4(const SceneView &sc, TraversalStack &
             const int enc = ~cur, first = enc >> 3, cnt = (enc & 7) + 1;
             const bool staged = first + cnt <= sc.n_lbtris;
             const float4 *lt = reinterpret_cast<const float4 *>(psdr_dyn_lds + sc.off_lbtris);
-            for (int i = 0; i < cnt; ++i) {
-                float4 a, b, c;
-                if (staged) { a = lt[(first + i) * 3]; b = lt[(first + i) * 3 + 1]; c = lt[(first + i) * 3 + 2]; }
-                else { a = sc.btris[(first + i) * 3]; b = sc.btris[(first + i) * 3 + 1]; c = sc.btris[(first + i) * 3 + 2]; }
-                leaf_triangle_test<IGN>(a, b, c, o, d, best, ig0, ig1);
-            }
+            if (staged) {
+                for (int i = 0; i < cnt; ++i) leaf_triangle_test<IGN>(lt[(first + i) * 3], lt[(first + i) * 3 + 1], lt[(first + i) * 3 + 2], o, d, best, ig0, ig1);
+            } else
+                leaf_from_memory<IGN>(sc.btris + (size_t) first * 3, cnt, o, d, best, ig0, ig1);
             cur = sp > 0 ? st.get(--sp) : kDone;
         }
     }

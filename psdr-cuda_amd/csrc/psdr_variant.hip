@@ -12,6 +12,14 @@
 #define PSDR_WIDE_TREE 0
 #endif
 #endif
+// Leaf triangles fetched two at a time (psdr_device.h leaf_from_memory): same flag set, same reason (registers to spare).
+#ifndef PSDR_LEAF_PAIR
+#if PSDR_VARIANT_FLAGS == 6
+#define PSDR_LEAF_PAIR 1
+#else
+#define PSDR_LEAF_PAIR 0
+#endif
+#endif
 #include "psdr_kernels.h"
 
 #ifndef PSDR_VARIANT_FLAGS
