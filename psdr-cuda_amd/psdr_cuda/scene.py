@@ -1087,10 +1087,14 @@ class Scene(Object):
             m._vertex_normals_raw = None
             m._face_distrb = None
             m._sec_edge_info = None
-            m._triangle_uv = None
             if m.m_has_uv:
-                fu = m._face_uv_indices.long()
-                m._triangle_uv = torch.cat([m._vertex_uv[fu[:, 0]], m._vertex_uv[fu[:, 1]], m._vertex_uv[fu[:, 2]]], dim=-1)
+                uv_key = (id(m._face_uv_indices), m._face_uv_indices._version, id(m._vertex_uv), m._vertex_uv._version)
+                if getattr(m, "_triangle_uv_key", None) != uv_key or m._triangle_uv is None:        # the uv tables do not move with the vertices
+                    fu = m._face_uv_indices.long()
+                    m._triangle_uv = torch.cat([m._vertex_uv[fu[:, 0]], m._vertex_uv[fu[:, 1]], m._vertex_uv[fu[:, 2]]], dim=-1)
+                    m._triangle_uv_key = uv_key
+            else:
+                m._triangle_uv = None
             m.m_ready = True
         return tp, v_world, tri_info
 
@@ -1247,15 +1251,11 @@ class Scene(Object):
         self._batch = {"tp": tp, "v_world": v_world, "tri_info": tri_info22}       # the sensors' edge pass reads it
         # AABB over the meshes, scene.cpp:88-101 (m_upper starts at numeric_limits<float>::min(), the
         # smallest POSITIVE float: kept as is)
-        allv = v_world.detach()
-        self.m_lower = allv.min(dim=0)[0]
-        self.m_upper = torch.clamp(allv.max(dim=0)[0], min=float(np.finfo(np.float32).tiny))
-
         # sensors (+ camera positions into the AABB, scene.cpp:104-119): everything up to the silhouette masks, no read-back yet
         sensor_states = [s.configure_begin(self) for s in self.m_sensors]
-        for st in sensor_states:
-            cp = st["out"]["cam"][_abi.CAM_POS:_abi.CAM_POS + 3].detach()
-            self.m_lower, self.m_upper = torch.minimum(self.m_lower, cp), torch.maximum(self.m_upper, cp)
+        # the box itself is formed when somebody asks for it (m_lower / m_upper: the environment map's bounding mesh, the log line) -- seven launches
+        # per configure() that an optimisation loop never looks at
+        self._aabb_pending = (v_world.detach(), [st["out"]["cam"][_abi.CAM_POS:_abi.CAM_POS + 3].detach() for st in sensor_states])
 
         # environment lighting: bounding mesh added once, scene.cpp:135-180
         if self.m_emitter_env is not None and not self.m_has_bound_mesh:
@@ -1292,12 +1292,22 @@ class Scene(Object):
         # ---- ONE read-back for every size and sum the host needs from here on: mesh areas, the luminance of the area lights, the
         # sums of their face distributions, the numbers of kept secondary / primary edges
         area_lights = [e for e in self.m_emitters if not isinstance(e, EnvironmentMap)]
-        parts = [self._areas_t.double()]
-        parts += [e._luminance_t().double() for e in area_lights]
-        parts += [e.m_mesh._triangle_info[:, 21].detach().to(torch.float32).sum().reshape(1).double() for e in area_lights]
-        parts.append(sec[1].sum().reshape(1).double() if sec is not None else torch.zeros(1, dtype=torch.float64, device=d))
-        parts += [(st["count_t"].double() if st["count_t"] is not None else torch.zeros(1, dtype=torch.float64, device=d)) for st in sensor_states]
-        stats = torch.cat(parts).tolist()
+        parts = [self._areas_t]
+        parts += [e._luminance_t() for e in area_lights]
+        parts += [e.m_mesh._triangle_info[:, 21].detach().to(torch.float32).sum().reshape(1) for e in area_lights]
+        counts = [sec[1].sum().reshape(1)] if sec is not None else []
+        counts += [st["count_t"] for st in sensor_states if st["count_t"] is not None]
+        # floats and (bit-cast) 32-bit counts in one float32 buffer, one copy
+        buf = torch.cat(parts + [c.to(torch.int32).view(torch.float32) for c in counts]).cpu()
+        nf = buf.numel() - len(counts)
+        stats = buf[:nf].tolist() + [float(x) for x in buf[nf:].view(torch.int32).tolist()]
+        if sec is None:
+            stats.insert(nf, 0.0)
+        k = nf + 1
+        for st in sensor_states:                                   # a sensor without an edge pass reads as zero kept edges
+            if st["count_t"] is None:
+                stats.insert(k, 0.0)
+            k += 1
         M, L = len(self.m_meshes), len(area_lights)
         self._mesh_areas_to_host(stats[:M])
         lum_of = {id(e): stats[M + i] for i, e in enumerate(area_lights)}
@@ -1421,6 +1431,36 @@ class Scene(Object):
             if o.sppse > 0:
                 self.log("%d secondary edges initialized." % tb["num_sec_edges"])
             self.log("Configured in %g seconds." % (time.perf_counter() - t_start))
+
+    def _resolve_aabb(self):
+        pend = getattr(self, "_aabb_pending", None)
+        if pend is not None:
+            allv, cams = pend
+            lo = allv.min(dim=0)[0]
+            hi = torch.clamp(allv.max(dim=0)[0], min=float(np.finfo(np.float32).tiny))
+            for cp in cams:
+                lo, hi = torch.minimum(lo, cp), torch.maximum(hi, cp)
+            self._m_lower, self._m_upper, self._aabb_pending = lo, hi, None
+
+    @property
+    def m_lower(self):
+        self._resolve_aabb()
+        return getattr(self, "_m_lower", None)
+
+    @m_lower.setter
+    def m_lower(self, v):
+        self._resolve_aabb()
+        self._m_lower = v
+
+    @property
+    def m_upper(self):
+        self._resolve_aabb()
+        return getattr(self, "_m_upper", None)
+
+    @m_upper.setter
+    def m_upper(self, v):
+        self._resolve_aabb()
+        self._m_upper = v
 
     def is_ready(self):
         return self._configured and all(m.m_ready for m in self.m_meshes)
