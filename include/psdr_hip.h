@@ -286,6 +286,12 @@ int psdr_guide_build(psdr_scene_t h, const psdr_render_opts *opts,
    TriangleInfo layout (PSDR_TRI_STRIDE words when written straight into tri_info), edges [E][5] int32 = v0, v1, face0, face1
    (-1: boundary), opposite vertex of face0 (global ids; Mesh::m_edge_indices, mesh.cpp:154-196).  The *_rev entry points ADD the
    adjoints into a_v / a_rows / a_w2s (the caller zeroes them). */
+/* World positions (Mesh::configure, src/shape/mesh.cpp:226-232: transform_pos of include/psdr/core/transform.h:84-88 by the mesh's to_world):
+   v_raw [V][3] object-space positions, vmesh [V] int32 = the mesh of every vertex, mats [M][16] row-major to_world matrices.
+   The reverse entry point WRITES a_raw (adjoint of v_raw; the matrices carry no gradient on this path: the caller keeps the torch chain when they do). */
+int psdr_geo_world_vertices_fwd(int32_t V, const float *v_raw, const int32_t *vmesh, const float *mats, float *v_world, void *stream);
+int psdr_geo_world_vertices_rev(int32_t V, const float *v_raw, const int32_t *vmesh, const float *mats, const float *v_world, const float *a_world, float *a_raw,
+                                void *stream);
 /* process_mesh (src/shape/mesh.cpp:20-51): rows = p0 e1 e2 n0 n1 n2 face_normal face_area with area-weighted vertex normals;
    vsum [V][3] = scratch kept for the adjoint (the un-normalised vertex normals). */
 int psdr_geo_tri_rows_fwd(int32_t V, int32_t T, const float *v, const int32_t *faces, float *vsum, float *rows, int32_t row_stride, void *stream);

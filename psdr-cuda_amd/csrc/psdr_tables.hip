@@ -202,6 +202,41 @@ __global__ __launch_bounds__(kB) void k_prim_edges_rev(int E, const int32_t *__r
     }
 }
 
+// ------------------------------------------------------------------------------ world positions
+// transform_pos (include/psdr/core/transform.h:84-88) of every vertex by ITS mesh's to_world matrix: y = (A v + t) / (p . v + q).  Products and
+// sums as the eager torch chain forms them (three products, its reduction order, then the translation; no contraction): an edge whose
+// faces are coplanar to an ulp must see the same vertices either way.
+__global__ __launch_bounds__(kB) void k_world_vertices(int V, const float *__restrict__ v_raw, const int32_t *__restrict__ vmesh, const float *__restrict__ mats,
+                                                       float *__restrict__ out) {
+    const int i = blockIdx.x * kB + threadIdx.x;
+    if (i >= V) return;
+    const float *m = mats + 16 * (size_t) vmesh[i];
+    const V3 x = ld3(v_raw + 3 * (size_t) i);
+    float h[4];
+    {
+#pragma clang fp contract(off)
+        for (int r = 0; r < 4; ++r) {
+            const float s02 = m[4 * r] * x.x + m[4 * r + 2] * x.z;           // torch's reduction of three addends on this device: (a + c) + b
+            const float s012 = s02 + m[4 * r + 1] * x.y;
+            h[r] = s012 + m[4 * r + 3];
+        }
+    }
+    // an affine matrix (w = 1 exactly: every scene file of the reference) divides exactly; a projective one by this unit's approximate division
+    const float w = h[3];
+    st3(out + 3 * (size_t) i, w == 1.f ? V3{h[0], h[1], h[2]} : V3{h[0] / w, h[1] / w, h[2] / w});
+}
+// a_v = (A^T a - p (y . a)) / w
+__global__ __launch_bounds__(kB) void k_world_vertices_rev(int V, const float *__restrict__ v_raw, const int32_t *__restrict__ vmesh, const float *__restrict__ mats,
+                                                           const float *__restrict__ y, const float *__restrict__ a_y, float *__restrict__ a_raw) {
+    const int i = blockIdx.x * kB + threadIdx.x;
+    if (i >= V) return;
+    const float *m = mats + 16 * (size_t) vmesh[i];
+    const V3 x = ld3(v_raw + 3 * (size_t) i), yy = ld3(y + 3 * (size_t) i), a = ld3(a_y + 3 * (size_t) i);
+    const float w = m[12] * x.x + m[13] * x.y + m[14] * x.z + m[15], iw = 1.f / w, ya = dot(yy, a);
+    st3(a_raw + 3 * (size_t) i, V3{(m[0] * a.x + m[4] * a.y + m[8] * a.z - m[12] * ya) * iw, (m[1] * a.x + m[5] * a.y + m[9] * a.z - m[13] * ya) * iw,
+                                   (m[2] * a.x + m[6] * a.y + m[10] * a.z - m[14] * ya) * iw});
+}
+
 inline dim3 grid(int n) { return dim3((unsigned) ((n + kB - 1) / kB)); }
 }  // namespace
 
@@ -210,6 +245,19 @@ inline dim3 grid(int n) { return dim3((unsigned) ((n + kB - 1) / kB)); }
 
 extern "C" {
 
+int psdr_geo_world_vertices_fwd(int32_t V, const float *v_raw, const int32_t *vmesh, const float *mats, float *v_world, void *stream) {
+    if (V <= 0 || !v_raw || !vmesh || !mats || !v_world) return psdr_host::fail("psdr_geo_world_vertices_fwd: invalid argument");
+    hipLaunchKernelGGL(k_world_vertices, grid(V), dim3(kB), 0, (hipStream_t) stream, V, v_raw, vmesh, mats, v_world);
+    TAB_TRY(hipGetLastError());
+    return 0;
+}
+int psdr_geo_world_vertices_rev(int32_t V, const float *v_raw, const int32_t *vmesh, const float *mats, const float *v_world, const float *a_world, float *a_raw,
+                                void *stream) {
+    if (V <= 0 || !v_raw || !vmesh || !mats || !v_world || !a_world || !a_raw) return psdr_host::fail("psdr_geo_world_vertices_rev: invalid argument");
+    hipLaunchKernelGGL(k_world_vertices_rev, grid(V), dim3(kB), 0, (hipStream_t) stream, V, v_raw, vmesh, mats, v_world, a_world, a_raw);
+    TAB_TRY(hipGetLastError());
+    return 0;
+}
 int psdr_geo_tri_rows_fwd(int32_t V, int32_t T, const float *v, const int32_t *faces, float *vsum, float *rows, int32_t row_stride, void *stream) {
     if (V <= 0 || T <= 0 || !v || !faces || !vsum || !rows || row_stride < 22) return psdr_host::fail("psdr_geo_tri_rows_fwd: invalid argument");
     hipStream_t s = (hipStream_t) stream;

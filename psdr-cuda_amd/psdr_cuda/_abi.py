@@ -85,7 +85,7 @@ HIP_SYMBOLS = (
     "psdr_last_error", "psdr_version", "psdr_abi_struct_sizes", "psdr_scene_create", "psdr_scene_destroy", "psdr_scene_set_tables",
     "psdr_bvh_build", "psdr_bvh_stats", "psdr_scene_info", "psdr_trace", "psdr_render_c", "psdr_render_d_fwd", "psdr_render_d_rev",
     "psdr_guide_build", "psdr_get_counters",
-    "psdr_geo_tri_rows_fwd", "psdr_geo_tri_rows_rev", "psdr_geo_sec_edges_fwd", "psdr_geo_sec_edges_rev", "psdr_geo_prim_edges_fwd", "psdr_geo_prim_edges_rev",
+    "psdr_geo_world_vertices_fwd", "psdr_geo_world_vertices_rev", "psdr_geo_tri_rows_fwd", "psdr_geo_tri_rows_rev", "psdr_geo_sec_edges_fwd", "psdr_geo_sec_edges_rev", "psdr_geo_prim_edges_fwd", "psdr_geo_prim_edges_rev",
 )
 
 HIP_LIB_PATH = os.environ.get("PSDR_HIP_LIB") or os.path.join(PKG_ROOT, "lib", "libpsdr_hip.so")   # env override: kernel A/B experiments
@@ -116,6 +116,8 @@ def load_hip():
     lib.psdr_guide_build.argtypes = [vp, C.POINTER(RenderOpts), C.POINTER(i32), i32, vp, vp]
     lib.psdr_get_counters.argtypes = [vp, C.POINTER(C.c_uint64)]
     lib.psdr_scene_info.argtypes = [vp, C.POINTER(i32)]
+    lib.psdr_geo_world_vertices_fwd.argtypes = [i32, vp, vp, vp, vp, vp]
+    lib.psdr_geo_world_vertices_rev.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp]
     lib.psdr_geo_tri_rows_fwd.argtypes = [i32, i32, vp, vp, vp, vp, i32, vp]
     lib.psdr_geo_tri_rows_rev.argtypes = [i32, i32, vp, vp, vp, vp, i32, vp, vp, vp]
     lib.psdr_geo_sec_edges_fwd.argtypes = [i32, vp, vp, vp, i32, vp, vp, vp]

@@ -40,6 +40,39 @@ class torch_formulation:
         _enabled = self.old
 
 
+class _WorldVertices(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, v_raw, vmesh_i32, mats, ref_fn):
+        lib = _abi.load_hip()
+        vc, mc = v_raw.detach().contiguous().float(), mats.detach().contiguous().float()
+        out = torch.empty_like(vc)
+        _abi.check(lib, lib.psdr_geo_world_vertices_fwd(vc.shape[0], vc.data_ptr(), vmesh_i32.data_ptr(), mc.data_ptr(), out.data_ptr(), _stream()))
+        ctx.save_for_backward(v_raw, vmesh_i32, mc, out)
+        ctx.ref_fn = ref_fn
+        return out
+
+    @staticmethod
+    def backward(ctx, a_world):
+        v_raw, vmesh, mats, out = ctx.saved_tensors
+        if a_world.requires_grad:                        # double backward (forward-mode JVP): the torch formulation
+            with torch.enable_grad():
+                vv = v_raw if v_raw.requires_grad else v_raw.detach().requires_grad_(True)
+                g, = torch.autograd.grad(ctx.ref_fn(vv, mats), vv, a_world, create_graph=True)
+            return g, None, None, None
+        lib = _abi.load_hip()
+        a = a_world.contiguous().float()
+        a_raw = torch.empty_like(a)
+        _abi.check(lib, lib.psdr_geo_world_vertices_rev(a.shape[0], v_raw.detach().contiguous().float().data_ptr(), vmesh.data_ptr(), mats.data_ptr(), out.data_ptr(),
+                                                        a.data_ptr(), a_raw.data_ptr(), _stream()))
+        return a_raw, None, None, None
+
+
+def world_vertices(v_raw, vmesh_i32, mats, ref_fn):
+    """transform_pos of every vertex by its mesh's matrix (mats [M,4,4] WITHOUT a gradient: the caller keeps the torch chain when a transform is
+    being optimised); ref_fn(v_raw, mats) = the torch formulation."""
+    return _WorldVertices.apply(v_raw, vmesh_i32, mats, ref_fn)
+
+
 class _TriRows(torch.autograd.Function):
     @staticmethod
     def forward(ctx, v, faces_i32, ref_fn):

@@ -105,3 +105,45 @@ def test_forward_mode_still_works_through_the_native_chain():
             res[native] = {k: (None if t is None else t.detach().cpu().numpy()) for k, t in tangents_wrt(tb, P).items()}
     for k in ("tri_info", "sec_edge", "prim_edge"):
         assert np.abs(res[False][k]).max() > 0 and rel_l2(res[True][k], res[False][k]) < 1e-5, k
+
+
+def test_world_vertices_kernel_equals_the_torch_chain_bit_for_bit_and_in_its_adjoint():
+    """psdr_geo_world_vertices_*: the positions an affine to_world gives are THE SAME floats as the eager chain's (three products, left-to-right
+    sums, the translation, w = 1 divides exactly) -- an edge whose faces are coplanar to an ulp sees the same vertices; the adjoint to 1e-6"""
+    g = torch.Generator().manual_seed(5)
+    V, M = 5000, 4
+    v = (torch.rand(V, 3, generator=g) * 400 - 200).cuda().requires_grad_(True)
+    vmesh = torch.randint(0, M, (V,), generator=g).cuda()
+    mats = torch.eye(4).repeat(M, 1, 1)
+    for k in range(M):                                            # rotation * scale + translation per mesh
+        q, _ = torch.linalg.qr(torch.randn(3, 3, generator=g))
+        mats[k, :3, :3] = q * (0.5 + k)
+        mats[k, :3, 3] = torch.randn(3, generator=g) * 100
+    mats = mats.cuda()
+
+    def to_world(vv, mm):
+        mv = mm[vmesh]
+        h = (mv[:, :3, :3] * vv.unsqueeze(1)).sum(-1) + mv[:, :3, 3]
+        w = (mv[:, 3, :3] * vv).sum(-1) + mv[:, 3, 3]
+        return h / w.unsqueeze(-1)
+    ref = to_world(v, mats)
+    out = tables_native.world_vertices(v, vmesh.to(torch.int32), mats, to_world)
+    assert torch.equal(out, ref)
+    a = torch.randn(V, 3, generator=g).cuda()
+    g_ref, = torch.autograd.grad(ref, v, a)
+    g_out, = torch.autograd.grad(out, v, a)
+    assert rel_l2(g_out.cpu().numpy(), g_ref.cpu().numpy()) < 1e-6
+    # a projective matrix: the division is this unit's approximate one
+    mats2 = mats.clone(); mats2[:, 3, :3] = 1e-3; mats2[:, 3, 3] = 1.5
+    o2, r2 = tables_native.world_vertices(v, vmesh.to(torch.int32), mats2, to_world), to_world(v, mats2)
+    assert rel_l2(o2.detach().cpu().numpy(), r2.detach().cpu().numpy()) < 1e-6
+    ga, = torch.autograd.grad(o2, v, a); gb, = torch.autograd.grad(r2, v, a)
+    assert rel_l2(ga.cpu().numpy(), gb.cpu().numpy()) < 1e-5
+    # forward mode through the op (double backward falls back to the torch formulation)
+    u = torch.zeros(V, 3, device="cuda", requires_grad=True)
+    o3 = tables_native.world_vertices(v, vmesh.to(torch.int32), mats, to_world)
+    gv, = torch.autograd.grad(o3, v, u, create_graph=True)
+    t = torch.randn(V, 3, generator=g).cuda()
+    jvp, = torch.autograd.grad(gv, u, t)
+    jref = torch.autograd.functional.jvp(lambda x: to_world(x, mats), (v.detach(),), (t,))[1]
+    assert rel_l2(jvp.cpu().numpy(), jref.cpu().numpy()) < 1e-6
