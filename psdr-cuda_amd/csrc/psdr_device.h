@@ -111,22 +111,30 @@ template <int K, int FLAGS = kSceneRough> struct TangentView {
 struct Hit { int tri; float u, v, t; };
 
 // ------------------------------------------------------------------------ small-table access
-// The tables a path vertex looks up besides its TriangleInfo row.  Instances compiled for kSceneTiny read the LDS copies (the launch
-// staged all of them, make_ctx / setup_lds); every other instance reads the caller's tables in global memory.  FL = scene flag set.
+// The tables a path vertex looks up besides its TriangleInfo row.  Instances compiled for kSceneTiny read LDS copies of ALL of them (the launch
+// staged them, make_ctx / setup_lds); the two-level instances (kSceneForest: a room around a few large meshes) read LDS copies of the MESH-level
+// ones -- mesh -> bsdf / emitter, the BSDF and emitter records, the emitters' face distributions, a small texel pool -- and keep the
+// per-triangle tables (tri_mesh, tri_uv: one entry per triangle of the large meshes) in global memory; every other instance reads the caller's
+// tables.  A vertex' chain tri_mesh -> mesh_bsdf -> bsdf_rec -> texel is then ONE global load instead of four dependent ones -- what a
+// kernel at 2-3 waves per SIMD (the dual-number and adjoint instances) waits for most.  FL = scene flag set.
+#ifndef PSDR_FOREST_LDS_TABLES
+#define PSDR_FOREST_LDS_TABLES 1
+#endif
 template <int FL> struct Tab {
     static constexpr bool lds = (FL & kSceneTiny) != 0;
+    static constexpr bool lds_small = lds || (PSDR_FOREST_LDS_TABLES && (FL & kSceneForest) != 0);
     static PSDR_HD int tri_mesh(const SceneView &sc, int tri) { return lds ? PSDR_LDS_TABLE(int32_t, sc.lt_trimesh)[tri] : sc.d.tri_mesh[tri]; }
-    static PSDR_HD int mesh_bsdf(const SceneView &sc, int mesh) { return lds ? PSDR_LDS_TABLE(int32_t, sc.lt_meshbsdf)[mesh] : sc.d.mesh_bsdf[mesh]; }
-    static PSDR_HD int mesh_emitter(const SceneView &sc, int mesh) { return lds ? PSDR_LDS_TABLE(int32_t, sc.lt_meshemitter)[mesh] : sc.d.mesh_emitter[mesh]; }
+    static PSDR_HD int mesh_bsdf(const SceneView &sc, int mesh) { return lds_small ? PSDR_LDS_TABLE(int32_t, sc.lt_meshbsdf)[mesh] : sc.d.mesh_bsdf[mesh]; }
+    static PSDR_HD int mesh_emitter(const SceneView &sc, int mesh) { return lds_small ? PSDR_LDS_TABLE(int32_t, sc.lt_meshemitter)[mesh] : sc.d.mesh_emitter[mesh]; }
     static PSDR_HD const int32_t *bsdf_rec(const SceneView &sc, int id) {
-        return (lds ? PSDR_LDS_TABLE(int32_t, sc.lt_bsdf) : sc.d.bsdf_rec) + (size_t) (id < 0 ? 0 : id) * PSDR_BSDF_STRIDE;
+        return (lds_small ? PSDR_LDS_TABLE(int32_t, sc.lt_bsdf) : sc.d.bsdf_rec) + (size_t) (id < 0 ? 0 : id) * PSDR_BSDF_STRIDE;
     }
-    static PSDR_HD const float *emitter_f(const SceneView &sc, int e) { return (lds ? PSDR_LDS_TABLE(float, sc.lt_emf) : sc.d.emitter_f) + (size_t) e * PSDR_EMITTER_F_STRIDE; }
-    static PSDR_HD const int32_t *emitter_i(const SceneView &sc, int e) { return (lds ? PSDR_LDS_TABLE(int32_t, sc.lt_emi) : sc.d.emitter_i) + (size_t) e * PSDR_EMITTER_I_STRIDE; }
-    static PSDR_HD const float *face_cmf(const SceneView &sc) { return lds ? PSDR_LDS_TABLE(float, sc.lt_fcmf) : sc.d.face_cmf; }
-    static PSDR_HD const float *face_pmf(const SceneView &sc) { return lds ? PSDR_LDS_TABLE(float, sc.lt_fpmf) : sc.d.face_pmf; }
-    static PSDR_HD const float *emitter_cmf(const SceneView &sc) { return lds ? PSDR_LDS_TABLE(float, sc.lt_ecmf) : sc.d.emitter_cmf; }
-    static PSDR_HD const float *emitter_pmf(const SceneView &sc) { return lds ? PSDR_LDS_TABLE(float, sc.lt_epmf) : sc.d.emitter_pmf; }
+    static PSDR_HD const float *emitter_f(const SceneView &sc, int e) { return (lds_small ? PSDR_LDS_TABLE(float, sc.lt_emf) : sc.d.emitter_f) + (size_t) e * PSDR_EMITTER_F_STRIDE; }
+    static PSDR_HD const int32_t *emitter_i(const SceneView &sc, int e) { return (lds_small ? PSDR_LDS_TABLE(int32_t, sc.lt_emi) : sc.d.emitter_i) + (size_t) e * PSDR_EMITTER_I_STRIDE; }
+    static PSDR_HD const float *face_cmf(const SceneView &sc) { return lds_small ? PSDR_LDS_TABLE(float, sc.lt_fcmf) : sc.d.face_cmf; }
+    static PSDR_HD const float *face_pmf(const SceneView &sc) { return lds_small ? PSDR_LDS_TABLE(float, sc.lt_fpmf) : sc.d.face_pmf; }
+    static PSDR_HD const float *emitter_cmf(const SceneView &sc) { return lds_small ? PSDR_LDS_TABLE(float, sc.lt_ecmf) : sc.d.emitter_cmf; }
+    static PSDR_HD const float *emitter_pmf(const SceneView &sc) { return lds_small ? PSDR_LDS_TABLE(float, sc.lt_epmf) : sc.d.emitter_pmf; }
     static PSDR_HD const float *tri_uv(const SceneView &sc, int tri) { return (lds ? PSDR_LDS_TABLE(float, sc.lt_uv) : sc.d.tri_uv) + (size_t) tri * PSDR_TRIUV_STRIDE; }
 };
 
@@ -708,7 +716,7 @@ PSDR_HD void bitmap_eval_from(const SceneView &sc, const TVT &tv, const int32_t 
 }
 template <class M, int C, class U, class TVT>
 PSDR_HD void bitmap_eval(const SceneView &sc, const TVT &tv, const int32_t *slot, U u, U v, M *out, bool flip_v = true) {
-    if constexpr (TVT::tiny) {
+    if constexpr (Tab<TVT::flags>::lds_small) {
         if (sc.lt_tex >= 0) { bitmap_eval_from<M, C, true>(sc, tv, slot, u, v, out, flip_v); return; }
     }
     bitmap_eval_from<M, C, false>(sc, tv, slot, u, v, out, flip_v);

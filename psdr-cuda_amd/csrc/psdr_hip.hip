@@ -206,12 +206,19 @@ static int emitter_faces(const psdr_scene_s *h) {
 // A scene without a tree whose small tables fit the LDS block of the kSceneTiny kernel instances (a few KB): every launch on it stages
 // them (plan_lds) and variant_of picks those instances.  PSDR_TINY_VARIANTS=0: the general instances (A/B, tools).
 constexpr int kLdsTexels = 256, kLdsTexelTangents = 3;
-static bool tiny_tables_ok(const psdr_scene_s *h) {
-    static const bool enabled = !(std::getenv("PSDR_TINY_VARIANTS") && std::atoi(std::getenv("PSDR_TINY_VARIANTS")) == 0);
+// the mesh-level tables (mesh -> bsdf / emitter, BSDF and emitter records, the emitters' face distributions) fit the LDS block of the kernels
+static bool small_tables_fit(const psdr_scene_s *h) {
     const psdr_scene_desc &d = h->desc;
-    return enabled && tiny_only(h) && d.env_emitter < 0 && d.num_meshes <= 64 && d.num_bsdfs <= 32 && d.num_emitters >= 0 && d.num_emitters <= 8 &&
+    return d.env_emitter < 0 && d.num_meshes <= 64 && d.num_bsdfs <= 32 && d.num_emitters >= 0 && d.num_emitters <= 8 &&
            (d.num_emitters == 0 || (d.face_cmf && d.face_pmf)) && emitter_faces(h) <= 64;
 }
+static bool tiny_tables_ok(const psdr_scene_s *h) {
+    static const bool enabled = !(std::getenv("PSDR_TINY_VARIANTS") && std::atoi(std::getenv("PSDR_TINY_VARIANTS")) == 0);
+    return enabled && tiny_only(h) && small_tables_fit(h);
+}
+// The kernels of a two-level scene read the mesh-level tables from LDS and have no other path (psdr_device.h Tab<FL>::lds_small): such a tree
+// is only built, and only kept, while they fit (psdr_bvh_build, ensure_tree_kind).
+static bool forest_tables(const psdr_scene_s *h) { return PSDR_FOREST_LDS_TABLES && h->n_blas > 0; }
 // Which tree the launches on this scene walk: the 4-wide quantised tree exactly where the scene's kernel variant is compiled for it (flag set 6:
 // rough conductor + two-level tree, psdr_variant.hip) -- measured 5-10 % ahead on the 50 k-triangle interior, level or behind elsewhere
 // (profiles/r03_bvh4_ab.txt).  k_trace (this unit) carries both walks and follows the scene.
@@ -246,16 +253,18 @@ int plan_lds(const psdr_scene_s *h, LaunchCtx &cx, int reserved) {
     // the small tables of a scene without a tree (psdr_device.h Tab<FL>, staged by setup_lds): 16-byte aligned blocks
     sc.lt_trimesh = sc.lt_meshbsdf = sc.lt_meshemitter = sc.lt_bsdf = sc.lt_emf = sc.lt_emi = sc.lt_fcmf = sc.lt_fpmf = sc.lt_uv = sc.lt_tex = sc.lt_ecmf = sc.lt_epmf = -1;
     sc.lt_nfaces = 0;
-    if (tiny_tables_ok(h)) {
+    const bool all_tables = tiny_tables_ok(h);
+    if (all_tables || forest_tables(h)) {
         auto take = [&](int words) { const int o = off; off += (words * 4 + 15) / 16 * 16; return o; };
         const psdr_scene_desc &d = h->desc;
         sc.lt_nfaces = emitter_faces(h);
-        sc.lt_trimesh = take(d.num_tris); sc.lt_meshbsdf = take(d.num_meshes); sc.lt_meshemitter = take(d.num_meshes);
+        if (all_tables) sc.lt_trimesh = take(d.num_tris);          // per-triangle tables: only where every triangle is a kernel-argument primitive
+        sc.lt_meshbsdf = take(d.num_meshes); sc.lt_meshemitter = take(d.num_meshes);
         sc.lt_bsdf = take(std::max(d.num_bsdfs, 1) * PSDR_BSDF_STRIDE);
         sc.lt_emf = take(d.num_emitters * PSDR_EMITTER_F_STRIDE); sc.lt_emi = take(d.num_emitters * PSDR_EMITTER_I_STRIDE);
         sc.lt_fcmf = take(sc.lt_nfaces); sc.lt_fpmf = take(sc.lt_nfaces);
         if (d.num_emitters > 1 && d.emitter_cmf && d.emitter_pmf) { sc.lt_ecmf = take(d.num_emitters); sc.lt_epmf = take(d.num_emitters); }
-        if (d.tri_uv) sc.lt_uv = take(d.num_tris * PSDR_TRIUV_STRIDE);
+        if (all_tables && d.tri_uv) sc.lt_uv = take(d.num_tris * PSDR_TRIUV_STRIDE);
         if (d.num_texels > 0 && d.num_texels <= kLdsTexels) sc.lt_tex = take(d.num_texels * (1 + kLdsTexelTangents));      // value pool + up to 3 tangent pools (forward mode)
     }
     sc.lt_end = off;
@@ -358,6 +367,8 @@ SinkLayout make_sink_layout(const psdr_scene_s *h, const psdr_grads *g) {
 // scene that gains or loses its rough conductors): bring the 4-wide tree in line before the launch (one read-back of the BVH2 nodes + the collapse).
 int ensure_tree_kind(psdr_scene_s *h, hipStream_t s) {
     if (!h->have_bvh || h->num_nodes <= 0) return 0;
+    // a two-level tree stands only while the mesh-level tables fit the LDS block of its kernels (psdr_scene_set_tables may have grown them)
+    if (forest_tables(h) && !small_tables_fit(h)) return psdr_bvh_build(h, s);
     const bool forest = h->n_blas > 0;
     if (use_wide_tree(h, forest) == h->wide) return 0;
     std::vector<BvhNode> host_nodes((size_t) h->num_nodes);
@@ -693,7 +704,8 @@ int psdr_bvh_build(psdr_scene_t h, void *stream) {
     const int T = h->desc.num_tris;
     // ---- refit: same triangle count as the tree on the device and the tree has not degraded
     const bool tiny = h->tiny_enabled && T <= kTinyTris;        // the triangles travel in the kernel arguments: host copy needed
-    if (h->refit_enabled && !tiny && h->refit_ok && h->tree_tris == T && h->num_nodes > 0 && h->refits_since_build < kMaxRefits) {
+    const bool forest_stands = !(forest_tables(h) && !small_tables_fit(h));      // a two-level tree whose kernels could no longer stage the tables: rebuild as one tree
+    if (h->refit_enabled && !tiny && h->refit_ok && forest_stands && h->tree_tris == T && h->num_nodes > 0 && h->refits_since_build < kMaxRefits) {
         float prev_area = h->built_area;
         if (h->refits_since_build > 0) {        // of the PREVIOUS refit (done long ago), read on the stream that wrote it
             HIP_TRY(hipMemcpyAsync(&prev_area, h->d_refit_area, sizeof(float), hipMemcpyDeviceToHost, h->refit_stream));
@@ -767,7 +779,7 @@ int psdr_bvh_build(psdr_scene_t h, void *stream) {
     if (h->two_level_enabled && h->tiny_enabled && T > kTinyTris && h->desc.num_meshes > 0 && h->desc.env_emitter < 0) {
         tri_mesh.resize((size_t) T);
         HIP_TRY(copy_on_stream(tri_mesh.data(), h->desc.tri_mesh, tri_mesh.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-        forest = ForestBuilder::eligible(tri_mesh.data(), T, h->desc.num_meshes);
+        forest = ForestBuilder::eligible(tri_mesh.data(), T, h->desc.num_meshes) && (!PSDR_FOREST_LDS_TABLES || small_tables_fit(h));
     }
     Builder b;
     ForestBuilder fb;

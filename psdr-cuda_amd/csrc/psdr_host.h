@@ -55,7 +55,7 @@ __device__ __forceinline__ void setup_lds(const LaunchCtx &cx, TraversalStack &s
             if (threadIdx.x < kTinyHitWords) m[i * kTinyHitWords + threadIdx.x] = val;
         }
     }
-    if (sc.lt_trimesh >= 0) {
+    if (sc.lt_meshbsdf >= 0) {
         // a scene without a tree: the small tables of a path vertex too (psdr_device.h Tab<FL>), same layouts as the caller's
         auto stage = [&](int off, const void *table, int words) {
             if (off < 0 || table == nullptr) return;
@@ -87,7 +87,7 @@ __device__ __forceinline__ void setup_lds(const LaunchCtx &cx, TraversalStack &s
 template <class TVT> __device__ __forceinline__ void setup_lds(const LaunchCtx &cx, TraversalStack &st, const TVT &tv) {
     setup_lds(cx, st);
 #if defined(__HIP_DEVICE_COMPILE__)
-    if constexpr (TVT::tiny && TVT::k > 0) {
+    if constexpr (Tab<TVT::flags>::lds_small && TVT::k > 0) {
         constexpr int K = TVT::k;
         static_assert(K <= 3, "plan_lds reserves three tangent texel pools");
         if (cx.sc.lt_tex >= 0) {

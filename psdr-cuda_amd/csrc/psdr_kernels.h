@@ -1075,25 +1075,29 @@ int render_rev(psdr_scene_s *h, const psdr_render_opts *o, const float *adj_img,
         // large tree (3.8 -> 3.3 ms; bunny scenes 2.0 -> 2.4); the 12-triangle box neither way
         const bool worth = o->integrator == PSDR_INTEGRATOR_PATH ? o->max_depth >= 2 : h->num_nodes >= 16384;
         const bool split = geo && replayable && split_env != 0 && (split_env == 1 || (has_tree && worth && n >= (1ll << 20)));
-        LaunchCtx cx2 = cx;                                         // adjoint kernel of a split launch: nothing staged, no stacks
-        if (split) { cx2.sc.n_lnodes = cx2.sc.n_lbtris = cx2.sc.n_ltri = 0; cx2.off_stack = 0; }
+        // adjoint kernel of a split launch: nothing of the tree staged, no stacks -- only what plan_lds places without any room (the hit rows of
+        // the kernel-argument primitives and the small tables of the two-level / tiny instances, Tab<FL>::lds_small), then record and cache
+        LaunchCtx cx2 = cx;
+        plan_lds(h, cx2, 1 << 30);
+        const int base2 = cx2.off_stack;                           // bytes in front of where the stacks would start
+        cx2.sc.n_lnodes = cx2.sc.n_lbtris = cx2.sc.n_ltri = 0;
         // lane-private emitter rows (30 KB) only where they do not cost a resident workgroup (C5 PathTracer(3) fused: stacks 22 KB +
         // record 24 KB + cache 19 KB + 30 KB = one workgroup per CU instead of two, 11.5 -> 19.4 ms)
         {
             LaunchCtx probe = cx;
-            const int floor_bytes = (split ? 0 : plan_lds(h, probe, 1 << 30)) + rec_bytes;                      // stacks only + record
+            const int floor_bytes = (split ? base2 : plan_lds(h, probe, 1 << 30)) + rec_bytes;                  // (tables +) stacks only + record
             if (sink.L.priv_rows > 0 && floor_bytes + sink_bytes(sink.L) > h->lds_limit / wg_per_cu) { sink.L.priv_rows = 0; sink.L.priv_emitter = -1; }
         }
         const int cache_bytes = sink_bytes(sink.L);
         plan_lds(h, cx, split ? rec_bytes : rec_bytes + cache_bytes);   // stage less of the scene: the record (+ cache) live in LDS too
         cx.off_pathrec = lds_bytes(cx, h);
         cx.off_sink = cx.off_pathrec + rec_bytes;
-        cx2.off_pathrec = 0; cx2.off_sink = rec_bytes;
-        // a scene without a tree keeps its small tables in LDS (kSceneTiny instances: no global-memory fallback): the adjoint kernel stages them too
+        cx2.off_stack = base2; cx2.off_pathrec = base2; cx2.off_sink = base2 + rec_bytes;
+        // a scene without a tree runs both kernels of a (forced) split launch on the layout of the fused one
         const bool no_tree = lds_bytes(cx, h) == cx.off_stack;
         if (split && no_tree) cx2 = cx;
         const int dyn1 = cx.off_pathrec + rec_bytes;                   // value kernel of a split launch
-        const int dyn_bytes = (split && !no_tree) ? rec_bytes + cache_bytes : cx.off_sink + cache_bytes;
+        const int dyn_bytes = (split && !no_tree) ? cx2.off_sink + cache_bytes : cx.off_sink + cache_bytes;
         if (std::max(dyn_bytes, split ? dyn1 : 0) > h->lds_limit) return fail("psdr_render_d_rev: the launch needs " + std::to_string(dyn_bytes) + " bytes of LDS per workgroup (path record of " +
                                                   std::to_string(depth) + " levels + traversal stacks + gradient cache), the device offers " + std::to_string(h->lds_limit));
         // material-only gradients (no triangle / camera table wanted) run the variant without the geometric adjoints;
