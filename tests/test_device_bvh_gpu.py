@@ -264,3 +264,32 @@ def test_inline_primitives_behind_65535_triangles_fall_back_to_one_tree(tmp_path
         bad = (np.abs(img - ref).max(axis=1) > 1e-5 * (1.0 + np.abs(ref).max(axis=1)))
         assert bad.mean() < 5e-3 and rel_l2(img, ref) < 3e-3, (bad.mean(), rel_l2(img, ref))
         g.close()
+
+
+def test_two_level_tree_stands_only_while_the_mesh_level_tables_fit_its_kernels():
+    """The two-level kernel instances read the mesh-level tables from LDS and have no other path (psdr_device.h Tab<FL>::lds_small): a scene whose
+    tables outgrow that block is built as ONE tree, and a handle whose tables grow under a standing two-level tree (psdr_scene_set_tables
+    without a rebuild) changes its tree before the next launch.  Same image either way."""
+    sc, _ = load_scene("cbox_bunny", res=48, spp=4)
+    tb = dict(sc.tables(0))
+    o = _abi.make_opts(integrator=_abi.INTEGRATOR_PATH, max_depth=3, spp=4)
+    g = GpuScene(tb)
+    assert _abi.scene_stats(g.h)["n_blas"] > 0
+    ref = g.render_c(o)
+    # 40 BSDF records (the scene's own, then copies nobody points at): more than the LDS block of the two-level kernels takes
+    big = dict(tb)
+    big["bsdf_rec"] = torch.cat([tb["bsdf_rec"], tb["bsdf_rec"][:1].repeat(40 - tb["bsdf_rec"].shape[0], 1)]).contiguous()
+    big["num_bsdfs"] = 40
+    g2 = GpuScene(big)
+    assert _abi.scene_stats(g2.h)["n_blas"] == 0
+    assert rel_l2(g2.render_c(o), ref) < 1e-5
+    # the same growth on the standing handle: set_tables only, the launch brings the tree in line
+    g.tb = {k: (v.detach().cuda() if isinstance(v, torch.Tensor) else v) for k, v in big.items()}
+    g.set_guide(None)
+    img = g.render_c(o)
+    assert _abi.scene_stats(g.h)["n_blas"] == 0 and rel_l2(img, ref) < 1e-5
+    # and back to tables that fit (the refit of an unchanged triangle table keeps the tree it finds: one tree serves them as well)
+    g.tb = {k: (v.detach().cuda() if isinstance(v, torch.Tensor) else v) for k, v in tb.items()}
+    g.set_guide(None)
+    _abi.check(g.lib, g.lib.psdr_bvh_build(g.h, None))
+    assert rel_l2(g.render_c(o), ref) < 1e-5
