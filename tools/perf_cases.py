@@ -112,6 +112,11 @@ def extra(which):
             g.render_c(o); g.counters()          # as the psdr_cuda surface does on the first calls: the library learns the path survival ratio
             ms = timeit(lambda: g.render_c(o), reps=2); r = g.counters()[0] / n
             print("C4 shard %-9s renderC (67M slots) %8.2f ms  %7.0f Msamples/s  rays/slot %.2f" % (name, ms, n / ms / 1e3, r))
+            if name == "path3":
+                for fl, fn in ((_abi.FLAG_FUSED, "fused"), (_abi.FLAG_WAVEFRONT, "wavefront")):
+                    of = _abi.make_opts(spp=512, spp_range=(0, 64), flags=fl, **kw)
+                    ms = timeit(lambda: g.render_c(of), reps=2)
+                    print("C4 shard %-9s %-9s renderC (67M slots) %8.2f ms" % (name, fn, ms))
             # the renderD half of the shard: forward K = 1 (rigid translation of the bunny: geometry duals) and reverse (triangle rows + texels)
             adj = np.random.default_rng(0).random((1024 * 1024, 3)).astype(np.float32)
             tan = tangents_wrt(tb, P) if P is not None else None
