@@ -9,6 +9,7 @@
 #include "psdr_reverse.h"
 
 #include <algorithm>
+#include <type_traits>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -134,6 +135,7 @@ struct SinkLayout {
     // or two triangles of emitter 0 (an area-light quad) and its radiance.  kPrivWords words per lane behind the cache copies.
     int priv_off, priv_rows;                 // priv_rows = 0: off
     int priv_tri[2], priv_slot[2], priv_emitter;
+    int priv_regs;                           // 1: the kernel keeps these accumulators in REGISTERS (psdr_kernels.h RegPrivSink): no LDS block behind the cache
 };
 constexpr int kPrivRowWords = 13;            // position (p0, e1, e2: 9), face normal (3), area (1)
 constexpr int kPrivWords = 2 * kPrivRowWords + 3;
@@ -238,7 +240,7 @@ constexpr int kMaxInlineTris = 2 * kTinyTris;      // inline triangles of a two-
 int make_ctx(psdr_scene_s *h, const psdr_render_opts *o, int sampler, LaunchCtx &cx);
 bool use_wavefront(const psdr_scene_s *h, const psdr_render_opts *o);
 SinkLayout make_sink_layout(const psdr_scene_s *h, const psdr_grads *g);
-inline int sink_bytes(const SinkLayout &L) { return L.priv_rows > 0 ? (L.priv_off + kPrivWords * kBlock) * 4 : (L.rep * L.stride * 4 + 15) / 16 * 16; }
+inline int sink_bytes(const SinkLayout &L) { return (L.priv_rows > 0 && !L.priv_regs) ? (L.priv_off + kPrivWords * kBlock) * 4 : (L.rep * L.stride * 4 + 15) / 16 * 16; }
 int check_counts(const psdr_scene_s *h, const psdr_render_opts *o);
 int begin_call(psdr_scene_s *h, hipStream_t s);
 int primary_edge_order(psdr_scene_s *h, const LaunchCtx &cx, long long i0, long long n, const uint32_t **order, hipStream_t s);

@@ -662,7 +662,7 @@ template <int FL> struct DeviceSink {
         lds = lds0 + (threadIdx.x & (L.rep - 1)) * L.stride;
         for (int i = threadIdx.x; i < L.rep * L.stride; i += kBlock) lds0[i] = 0.f;
         priv = lds0 + L.priv_off + threadIdx.x;
-        if (L.priv_rows > 0) {
+        if (L.priv_rows > 0 && !L.priv_regs) {
 #pragma unroll 1
             for (int i = 0; i < kPrivWords; ++i) priv[i * kBlock] = 0.f;
         }
@@ -683,7 +683,7 @@ template <int FL> struct DeviceSink {
                 if ((threadIdx.x & 63) == 0 && v != 0.f) lds_add(lds0 + L.cam_off + i, v);
             }
         }
-        if (L.priv_rows > 0) {
+        if (L.priv_rows > 0 && !L.priv_regs) {
             // private columns -> the cache words they stand for: thread t sums word (t & 31) over 32 of the 256 lanes
             __syncthreads();
             const int w = threadIdx.x & 31, part = threadIdx.x >> 5;
@@ -715,6 +715,63 @@ template <int FL> struct DeviceSink {
     }
 };
 
+// The same sink with the lane-private accumulators in REGISTERS (SinkLayout::priv_regs; the PathTracer's geometry-adjoint kernel: 2 waves per SIMD,
+// ~40 of its 256 VGPRs free).  The LDS version costs a read and a write per word and light sample -- 78 LDS round trips per slot whose latency a
+// kernel at 2 waves per SIMD cannot hide -- and 30 KB of LDS that tree scenes could not spare at all (they fell back to LDS atomics).  Here a row
+// adjoint is 26 selects + adds, the totals leave through six DPP adds per word at kernel end.
+#ifndef PSDR_SINK_REG_PRIV
+#define PSDR_SINK_REG_PRIV 1
+#endif
+template <int FL> struct RegPrivSink : DeviceSink<FL> {
+    typedef DeviceSink<FL> Base;
+    float pacc[kPrivWords];
+    __device__ __forceinline__ explicit RegPrivSink(const Base &b) : Base(b) {}
+    __device__ __forceinline__ bool add_row(int tri, float u, float v, const Vec3f &ap, const Vec3f &afn, float aarea) {
+        if (this->L.priv_rows == 0 || this->g.g_tri_info == nullptr) return false;
+        const bool r0 = tri == this->L.priv_tri[0], r1 = tri == this->L.priv_tri[1];
+        if (!(r0 || r1)) return false;
+        const Vec3f a{Base::finite(ap.x), Base::finite(ap.y), Base::finite(ap.z)};
+        const float w[kPrivRowWords] = {a.x, a.y, a.z, u * a.x, u * a.y, u * a.z, v * a.x, v * a.y, v * a.z, Base::finite(afn.x), Base::finite(afn.y), Base::finite(afn.z),
+                                        Base::finite(aarea)};
+#pragma unroll
+        for (int i = 0; i < kPrivRowWords; ++i) { pacc[i] += r0 ? w[i] : 0.f; pacc[kPrivRowWords + i] += r1 ? w[i] : 0.f; }
+        return true;
+    }
+    __device__ __forceinline__ void add_rad(int e, int c, float v) {
+        if (this->g.g_emitter_rad == nullptr || !Base::ok(v)) return;
+        if (e == this->L.priv_emitter) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) pacc[2 * kPrivRowWords + k] += c == k ? v : 0.f;
+            return;
+        }
+        Base::add_rad(e, c, v);
+    }
+    __device__ __forceinline__ void begin(float *cache) {
+        Base::begin(cache);
+#pragma unroll
+        for (int i = 0; i < kPrivWords; ++i) pacc[i] = 0.f;
+    }
+    __device__ __forceinline__ void end() {
+        if (this->L.priv_rows > 0) {
+#pragma unroll
+            for (int w = 0; w < kPrivWords; ++w) {
+                const float sum = wave_total(pacc[w]);             // every lane of the workgroup is here
+                if ((threadIdx.x & 63) == 0 && sum != 0.f) {
+                    if (w < 2 * kPrivRowWords) {
+                        const int r = w / kPrivRowWords, c = w % kPrivRowWords;
+                        const int word = c < 9 ? c : c + 9;                                    // 9..11 -> face normal (18..20), 12 -> area (21)
+                        if (r < this->L.priv_rows) Base::lds_add(this->lds0 + this->L.hot_off + this->L.priv_slot[r] * PSDR_TRI_STRIDE + word, sum);
+                    } else if (this->L.priv_emitter >= 0) Base::lds_add(this->lds0 + this->L.rad_off + this->L.priv_emitter * 3 + (w - 2 * kPrivRowWords), sum);
+                }
+            }
+        }
+        Base::end();
+    }
+};
+// which kernels keep them in registers: the host (render_rev) sets SinkLayout::priv_regs by the same rule
+// (not the rough-conductor instances: their adjoint kernel already fills 256 VGPRs and spilled 180 more with the accumulators: C5 7.75 -> 8.27 ms)
+template <int FL, bool GEO, int INTEG> constexpr bool reg_priv_kernel() { return PSDR_SINK_REG_PRIV && GEO && INTEG == PSDR_INTEGRATOR_PATH && (FL & kSceneRough) == 0; }
+
 #ifndef PSDR_WAVES_REV
 #define PSDR_WAVES_REV 2
 #endif
@@ -736,10 +793,11 @@ template <int FL, bool GEO, int INTEG> constexpr int rev_waves() {
 // workgroups per CU -- the tree walks are latency-bound and the adjoint code's registers hold the fused kernel at 2 -- writing a
 // record per path to `disk`; STAGE 2 = the adjoint sweep from that record: no traversal, no stacks in LDS.
 template <int FL, bool GEO, int INTEG, int STAGE = 0>
-__global__ __launch_bounds__(kBlock, (STAGE == 1 ? 3 : rev_waves<FL, GEO, INTEG>())) void k_camera_rev(LaunchCtx cx, DeviceSink<FL> sink, int spp, int s_begin, SlotDiv nsp, long long j0,
+__global__ __launch_bounds__(kBlock, (STAGE == 1 ? 3 : rev_waves<FL, GEO, INTEG>())) void k_camera_rev(LaunchCtx cx, DeviceSink<FL> sink_arg, int spp, int s_begin, SlotDiv nsp, long long j0,
                                                        long long n, float inv_spp, const float *__restrict__ adj_img, float *__restrict__ img,
                                                        unsigned long long *counters, float *__restrict__ disk, long long disk_stride, float *__restrict__ deep) {
     TraversalStack st; setup_lds(cx, st);
+    typename std::conditional<reg_priv_kernel<FL, GEO, INTEG>() && STAGE != 1, RegPrivSink<FL>, DeviceSink<FL> &>::type sink(sink_arg);
     if (STAGE != 1) sink.begin(dyn_lds_floats(cx.off_sink));
     uint32_t nrays = 0;
     const long long nceil = (n + kBlock - 1) / kBlock * kBlock;
@@ -1080,6 +1138,8 @@ int render_rev(psdr_scene_s *h, const psdr_render_opts *o, const float *adj_img,
         const bool split = geo && replayable && split_env != 0 && (split_env == 1 || (has_tree && worth && n >= (1ll << 20)));
         // adjoint kernel of a split launch: nothing of the tree staged, no stacks -- only what plan_lds places without any room (the hit rows of
         // the kernel-argument primitives and the small tables of the two-level / tiny instances, Tab<FL>::lds_small), then record and cache
+        // the PathTracer's geometry-adjoint kernels keep the lane-private emitter accumulators in registers (RegPrivSink): no LDS block, never switched off
+        sink.L.priv_regs = (geo && o->integrator == PSDR_INTEGRATOR_PATH && reg_priv_kernel<FL, true, PSDR_INTEGRATOR_PATH>()) ? 1 : 0;
         LaunchCtx cx2 = cx;
         plan_lds(h, cx2, 1 << 30);
         const int base2 = cx2.off_stack;                           // bytes in front of where the stacks would start
@@ -1089,7 +1149,7 @@ int render_rev(psdr_scene_s *h, const psdr_render_opts *o, const float *adj_img,
         {
             LaunchCtx probe = cx;
             const int floor_bytes = (split ? base2 : plan_lds(h, probe, 1 << 30)) + rec_bytes;                  // (tables +) stacks only + record
-            if (sink.L.priv_rows > 0 && floor_bytes + sink_bytes(sink.L) > h->lds_limit / wg_per_cu) { sink.L.priv_rows = 0; sink.L.priv_emitter = -1; }
+            if (!sink.L.priv_regs && sink.L.priv_rows > 0 && floor_bytes + sink_bytes(sink.L) > h->lds_limit / wg_per_cu) { sink.L.priv_rows = 0; sink.L.priv_emitter = -1; }
         }
         const int cache_bytes = sink_bytes(sink.L);
         plan_lds(h, cx, split ? rec_bytes : rec_bytes + cache_bytes);   // stage less of the scene: the record (+ cache) live in LDS too
