@@ -252,7 +252,7 @@ template <class TVT>
 __device__ __forceinline__ int classify_next(const SceneView &sc, const TVT &, const RngJump &jump_next, uint32_t slot, const Its<float> &next, const Vec3f &) {
     const TangentView<0, TVT::flags> tv0{};
     const Its<float> &its = next;
-    const int bsdf_id = sc.d.mesh_bsdf[its.mesh];
+    const int bsdf_id = Tab<TVT::flags>::mesh_bsdf(sc, its.mesh);          // the staged copies (two-level instances), as every estimator reads them
     if (bsdf_id < 0) return 0;
     auto enters = [&](const Vec3f &o, const Vec3f &d, float tmax) {
         const Vec3f inv{1.f / d.x, 1.f / d.y, 1.f / d.z};
@@ -264,7 +264,7 @@ __device__ __forceinline__ int classify_next(const SceneView &sc, const TVT &, c
     const float s[3] = {rng.next(), rng.next(), rng.next()};
     const float s0 = rng.next(), s1 = rng.next();
     int cls = 0;
-    const Bsdf<float, float> bsdf(sc, bsdf_id);
+    const Bsdf<float, float> bsdf(sc, tv0, bsdf_id);
     Vec3f wo_s; float pdf_s;
     if (bsdf.sample(sc, tv0, its, s, true, wo_s, pdf_s)) {
         const Vec3f d1 = its.sh.s * wo_s.x + its.sh.t * wo_s.y + its.sh.n * wo_s.z;
