@@ -123,6 +123,11 @@ def extra(which):
             if tan is not None:
                 ms = timeit(lambda: g.render_d_fwd(o, [tan]), reps=2)
                 print("C4 shard %-9s renderD fwd K=1 geo (67M slots) %8.2f ms  %7.0f Msamples/s" % (name, ms, n / ms / 1e3))
+                if name == "path3":
+                    for fl, fn in ((_abi.FLAG_FUSED, "fused"), (_abi.FLAG_WAVEFRONT, "wavefront")):
+                        of = _abi.make_opts(spp=512, spp_range=(0, 64), flags=fl, **kw)
+                        ms = timeit(lambda: g.render_d_fwd(of, [tan]), reps=2)
+                        print("C4 shard %-9s %-9s renderD fwd K=1 geo (67M slots) %8.2f ms" % (name, fn, ms))
             ms = timeit(lambda: g.render_d_rev(o, adj, want=["tri_info", "texels"], with_image=False), reps=2)
             print("C4 shard %-9s renderD rev tri+texels (67M slots) %8.2f ms  %7.0f Msamples/s" % (name, ms, n / ms / 1e3))
     if "c5" in which:
