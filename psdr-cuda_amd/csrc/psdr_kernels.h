@@ -775,6 +775,9 @@ template <int FL, bool GEO, int INTEG> constexpr bool reg_priv_kernel() { return
 #ifndef PSDR_WAVES_REV
 #define PSDR_WAVES_REV 2
 #endif
+#ifndef PSDR_WAVES_REV_VALUE
+#define PSDR_WAVES_REV_VALUE 3          // value kernel of a split reverse launch
+#endif
 #ifndef PSDR_WAVES_REV_MAT
 #define PSDR_WAVES_REV_MAT 3
 #endif
@@ -793,7 +796,7 @@ template <int FL, bool GEO, int INTEG> constexpr int rev_waves() {
 // workgroups per CU -- the tree walks are latency-bound and the adjoint code's registers hold the fused kernel at 2 -- writing a
 // record per path to `disk`; STAGE 2 = the adjoint sweep from that record: no traversal, no stacks in LDS.
 template <int FL, bool GEO, int INTEG, int STAGE = 0>
-__global__ __launch_bounds__(kBlock, (STAGE == 1 ? 3 : rev_waves<FL, GEO, INTEG>())) void k_camera_rev(LaunchCtx cx, DeviceSink<FL> sink_arg, int spp, int s_begin, SlotDiv nsp, long long j0,
+__global__ __launch_bounds__(kBlock, (STAGE == 1 ? PSDR_WAVES_REV_VALUE : rev_waves<FL, GEO, INTEG>())) void k_camera_rev(LaunchCtx cx, DeviceSink<FL> sink_arg, int spp, int s_begin, SlotDiv nsp, long long j0,
                                                        long long n, float inv_spp, const float *__restrict__ adj_img, float *__restrict__ img,
                                                        unsigned long long *counters, float *__restrict__ disk, long long disk_stride, float *__restrict__ deep) {
     TraversalStack st; setup_lds(cx, st);
