@@ -30,11 +30,13 @@ __device__ __forceinline__ float wave_total(float v) {
     v = dpp_add<0x142, 0xa>(v); v = dpp_add<0x143, 0xc>(v);
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
-template <int N> __device__ __forceinline__ bool wave_segmented_sum(int key, float (&v)[N]) {
+template <int N, bool DPP = (N <= 6)> __device__ __forceinline__ bool wave_segmented_sum(int key, float (&v)[N]) {
     const int lane = threadIdx.x & 63;
     // the common case of the camera kernels: spp is a multiple of 64 and the whole wave sits on ONE pixel -- six DPP adds per value instead of six
     // ds_bpermute round trips (each an LDS instruction + its address arithmetic + the wait)
-    if (__ballot(key != __builtin_amdgcn_readfirstlane(key)) == 0ull) {
+    // (DPP: by default only for few values -- the K = 3 dual kernels spill hundreds of registers, and a DPP sequence in a heavily spilled kernel once
+    // returned stale registers, DESIGN.md round 3 -- or where the caller knows its kernel: the diffuse adjoint instances)
+    if (DPP && __ballot(key != __builtin_amdgcn_readfirstlane(key)) == 0ull) {
 #pragma unroll
         for (int i = 0; i < N; ++i) v[i] = wave_total(v[i]);
         return lane == 0;
@@ -55,13 +57,13 @@ template <int N> __device__ __forceinline__ bool wave_segmented_sum(int key, flo
 
 // Sum of v over runs of ADJACENT lanes holding the same key (keys in any order); the first lane of
 // each run gets the total.
-template <int N> __device__ __forceinline__ bool wave_run_sum(int key, float (&v)[N]) {
+template <int N, bool DPP = (N <= 6)> __device__ __forceinline__ bool wave_run_sum(int key, float (&v)[N]) {
     const int lane = threadIdx.x & 63;
     const int prev = __shfl_up(key, 1, 64);
     const bool head = lane == 0 || prev != key;
     const unsigned long long heads = __ballot(head);
     const int seg = __popcll(heads & (~0ull >> (63 - lane)));       // run index: non-decreasing
-    wave_segmented_sum<N>(seg, v);
+    wave_segmented_sum<N, DPP>(seg, v);
     return head;
 }
 
@@ -826,7 +828,7 @@ __global__ __launch_bounds__(kBlock, (STAGE == 1 ? PSDR_WAVES_REV_VALUE : rev_wa
         }
         // primary-triangle row: one add per run of lanes that hit the same triangle
         if (STAGE != 1 && GEO && sink.g.g_tri_info != nullptr) {
-            const bool head = wave_run_sum<kPrimaryWords>(pg.tri, pg.w);
+            const bool head = wave_run_sum<kPrimaryWords, (FL & kSceneRough) == 0>(pg.tri, pg.w);
             if (head && pg.tri >= 0) {
 #pragma unroll
                 for (int w = 0; w < kPrimaryWords; ++w) sink.add_tri(pg.tri, w, pg.w[w]);
