@@ -294,7 +294,9 @@ class PerspectiveCamera(Sensor):
             self._lens_key = lens_key
             self._lens = (c2s, s2c, torch.as_tensor(c2s, dtype=torch.float32, device=tw.device), torch.as_tensor(s2c, dtype=torch.float32, device=tw.device))
         c2s, s2c, c2s_t, s2c_t = self._lens
-        w2s = c2s_t @ (self._pose_inv if self._pose_inv is not None else torch.linalg.inv(tw))
+        # (inv_ex: torch.linalg.inv reads its error flag back -- a device-to-host read per configure() when the pose carries a gradient; the
+        # pose was checked when it changed: the determinant test above)
+        w2s = c2s_t @ (self._pose_inv if self._pose_inv is not None else torch.linalg.inv_ex(tw)[0])
         cam_pos = tw[:3, 3] / tw[3, 3]            # transform_pos(to_world, origin)
         cam_dir = tw[:3, 2]                       # transform_dir(to_world, (0, 0, 1))
 

@@ -147,3 +147,26 @@ def test_world_vertices_kernel_equals_the_torch_chain_bit_for_bit_and_in_its_adj
     jvp, = torch.autograd.grad(gv, u, t)
     jref = torch.autograd.functional.jvp(lambda x: to_world(x, mats), (v.detach(),), (t,))[1]
     assert rel_l2(jvp.cpu().numpy(), jref.cpu().numpy()) < 1e-6
+
+
+def test_configure_reads_back_in_two_batches():
+    """Scene.configure with vertex gradients synchronises with the device twice (sizes and sums, then the edge-distribution sums) -- it used to read
+    seventeen values back one by one; torch's sync debug mode counts the synchronising calls"""
+    import warnings
+    sc, v, _ = build("cbox_bunny", True, True)
+    mesh = sc.param_map["Mesh[1]"]
+    for _ in range(2):                                            # steady state: caches of the first configure() in place
+        vv = Vector3fD(ek.detach(mesh.vertex_positions)); ek.set_requires_gradient(vv); mesh.vertex_positions = vv
+        sc.configure()
+    vv = Vector3fD(ek.detach(mesh.vertex_positions)); ek.set_requires_gradient(vv); mesh.vertex_positions = vv
+    torch.cuda.synchronize()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        torch.cuda.set_sync_debug_mode("warn")
+        try:
+            sc.configure()
+        finally:
+            torch.cuda.set_sync_debug_mode("default")
+    syncs = [x for x in w if "called a synchronizing" in str(x.message)]
+    assert len(syncs) <= 2, [str(x.message)[:80] for x in syncs]
+    assert sc.tables(0)["num_sec_edges"] > 0 and sc.tables(0)["num_prim_edges"] > 0
