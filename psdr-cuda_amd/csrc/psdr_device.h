@@ -99,9 +99,12 @@ extern __shared__ __attribute__((aligned(16))) unsigned char psdr_dyn_lds[];
 //   kSceneTiny   ALL primitives of the scene travel in the kernel arguments (SceneView::n_tiny > 0, no tree at all -- the 12-triangle
 //                Cornell box of C1 / C2): the instance carries no tree walk, no traversal stack and no global-memory fallback of the
 //                LDS-staged TriangleInfo rows -- fewer registers (one more wave per SIMD), a third of the code
-constexpr int kSceneEnv = 1, kSceneRough = 2, kSceneAll = 3, kSceneForest = 4, kSceneTiny = 8;
-// closest_hit's FOREST argument of a flag set: 2 = kernel-argument primitives only, 1 = two-level, 0 = one tree (or a tiny scene served by a general instance)
-template <int FLAGS> constexpr int tree_mode() { return (FLAGS & kSceneTiny) ? 2 : ((FLAGS & kSceneForest) ? 1 : 0); }
+//   kScenePre    (kernel instances only, never a scene's flag set) the tree walks of this kernel's rays were done beforehand by the dense trace kernel
+//                (psdr_hip.hip k_wf_trace): closest_hit tests the kernel-argument primitives and merges the tree hit it finds in TraversalStack::pre
+constexpr int kSceneEnv = 1, kSceneRough = 2, kSceneAll = 3, kSceneForest = 4, kSceneTiny = 8, kScenePre = 16;
+// closest_hit's FOREST argument of a flag set: 3 = two-level with the tree hits traced beforehand, 2 = kernel-argument primitives only, 1 = two-level,
+// 0 = one tree (or a tiny scene served by a general instance)
+template <int FLAGS> constexpr int tree_mode() { return (FLAGS & kSceneTiny) ? 2 : ((FLAGS & kSceneForest) ? ((FLAGS & kScenePre) ? 3 : 1) : 0); }
 template <int K, int FLAGS = kSceneRough> struct TangentView {
     static constexpr int flags = FLAGS, k = K;
     static constexpr bool has_env = (FLAGS & kSceneEnv) != 0, has_rough = (FLAGS & kSceneRough) != 0, forest = (FLAGS & kSceneForest) != 0, tiny = (FLAGS & kSceneTiny) != 0;
@@ -109,6 +112,7 @@ template <int K, int FLAGS = kSceneRough> struct TangentView {
 };
 
 struct Hit { int tri; float u, v, t; };
+constexpr int kPreBsdfRay = 0, kPreLightRay = 1;     // TraversalStack::pre slots of the two rays of a path vertex (direct_step)
 
 // ------------------------------------------------------------------------ small-table access
 // The tables a path vertex looks up besides its TriangleInfo row.  Instances compiled for kSceneTiny read LDS copies of ALL of them (the launch
@@ -141,6 +145,8 @@ template <int FL> struct Tab {
 // Traversal stack: LDS on the device (one column per lane: conflict-free, no scratch traffic),
 // a plain array on the host (tests).
 struct TraversalStack {
+    // kScenePre instances: the closest TREE hits of the vertex' two rays (tri < 0: none), found beforehand by the dense trace kernel
+    Hit pre[2];
 #if defined(__HIP_DEVICE_COMPILE__)
     int32_t *base;   // &lds[threadIdx.x], stride kBlock
     __device__ __forceinline__ void put(int i, int32_t v) { base[i * kBlock] = v; }
@@ -440,12 +446,12 @@ PSDR_HD bool blas_box(const SceneView &sc, int k, const Vec3f &o, const Vec3f &i
 // FOREST: 2 = the instance serves scenes WITHOUT a tree only (kSceneTiny: the walk below is not even compiled), 1 = two-level scenes only,
 // 0 = never two-level (no box loop / per-tree walks in the code), -1 = decided at run time (k_trace, host tests).
 template <bool IGN = false, int FOREST = -1>
-PSDR_HD Hit closest_hit(const SceneView &sc, TraversalStack &st, const Vec3f &o, const Vec3f &d, float tmax, int ig0 = -1, int ig1 = -1) {
+PSDR_HD Hit closest_hit(const SceneView &sc, TraversalStack &st, const Vec3f &o, const Vec3f &d, float tmax, int ig0 = -1, int ig1 = -1, int pre_slot = 0) {
     Hit best; best.tri = -1; best.u = best.v = -1.f;
     best.t = (tmax > 0.f && tmax < INFINITY) ? __int_as_float_hd(__float_as_int_hd(tmax) + 1) : tmax;   // accept t <= tmax
     const Vec3f inv{1.f / d.x, 1.f / d.y, 1.f / d.z};
     const bool forest = FOREST < 0 ? sc.n_blas > 0 : FOREST == 1;
-    if (FOREST == 2 || sc.n_tiny > 0 || forest) {
+    if (FOREST == 3 || FOREST == 2 || sc.n_tiny > 0 || forest) {
         // n_tiny PRIMITIVES (triangles, or parallelograms of two triangles: pack_tiny_prims), unrolled by 6 (the six
         // walls of the Cornell box): the scalar loads of the following primitives are in flight while one is tested
         int best_i = -1;
@@ -465,6 +471,13 @@ PSDR_HD Hit closest_hit(const SceneView &sc, TraversalStack &st, const Vec3f &o,
 #pragma unroll PSDR_TINY_UNROLL
         for (int i = 0; i < sc.n_tiny; ++i) tiny_prim_test<IGN>(rows[i * 4], rows[i * 4 + 1], rows[i * 4 + 2], rows[i * 4 + 3], i, o, d, best, best_i, ig0, ig1);
         resolve_tiny_hit(sc, best, best_i);
+        if (FOREST == 3) {
+            // the trees were walked beforehand (same leaf test, tmax = infinity): the closest tree hit replaces the primitive hit exactly where the
+            // walk below would have -- strictly closer
+            const Hit ph = st.pre[pre_slot];
+            if (ph.tri >= 0 && ph.t < best.t) best = ph;
+            return best;
+        }
         if (FOREST == 2 || !forest) return best;
         // two-level tree: the trees whose box the segment [0, t_best] enters, NEAREST box first (a hit in a near object
         // prunes the far ones); every round re-tests the remaining boxes against the current t_best -- wave-uniform
@@ -591,14 +604,14 @@ enum HitForm { kDetached = 0, kPathSpace = 1, kSolidAngle = 2 };
 //   kSolidAngle: D types, differentiable Moeller-Trumbore on the chosen triangle, J = 1
 // ig0 / ig1 >= 0: triangles the ray must not hit (rays that start on a secondary edge, psdr_scene_desc::sec_edge_faces).
 template <class R, class TVT> PSDR_HD Its<R> intersect(const SceneView &sc, const TVT &tv, TraversalStack &st, const RayT<R> &ray,
-                                                       bool active, HitForm form, uint32_t &nrays, int ig0 = -1, int ig1 = -1) {
+                                                       bool active, HitForm form, uint32_t &nrays, int ig0 = -1, int ig1 = -1, int pre_slot = 0) {
     Its<R> its;
     its.valid = false; its.tri = its.mesh = -1; its.J = R(1.f); its.t = R(INFINITY);
     if (!active) return its;
     nrays++;
     constexpr int F = tree_mode<TVT::flags>();
-    const Hit h = (ig0 >= 0 || ig1 >= 0) ? closest_hit<true, F>(sc, st, val(ray.o), val(ray.d), INFINITY, ig0, ig1)
-                                         : closest_hit<false, F>(sc, st, val(ray.o), val(ray.d), INFINITY);
+    const Hit h = (ig0 >= 0 || ig1 >= 0) ? closest_hit<true, F>(sc, st, val(ray.o), val(ray.d), INFINITY, ig0, ig1, pre_slot)
+                                         : closest_hit<false, F>(sc, st, val(ray.o), val(ray.d), INFINITY, -1, -1, pre_slot);
     if (h.tri < 0) return its;
     its.valid = true; its.tri = h.tri; its.hu = h.u; its.hv = h.v;
     const int tm = Tab<TVT::flags>::tri_mesh(sc, h.tri);
@@ -1051,7 +1064,7 @@ PSDR_HD Vec3<M> direct_step(const SceneView &sc, const TVT &tv, TraversalStack &
         bool a1 = bsdf.sample(sc, tv, its, s, active, wo_s, pdf_s);
         const Vec3f dir1 = val(its.sh.s) * wo_s.x + val(its.sh.t) * wo_s.y + val(its.sh.n) * wo_s.z;
         const RayT<G> ray1{its.p, lift<G>(dir1)};
-        const Its<G> its1 = intersect<G>(sc, tv, st, ray1, a1, form, nrays);
+        const Its<G> its1 = intersect<G>(sc, tv, st, ray1, a1, form, nrays, -1, -1, kPreBsdfRay);
         const bool a_hit = a1 && its1.valid;
         a1 = a_hit && emitter_of(sc, tv, its1) >= 0;
         Vec3<M> bsdf_val = zero3<M>(); M pdf0(0.f);
@@ -1084,7 +1097,7 @@ PSDR_HD Vec3<M> direct_step(const SceneView &sc, const TVT &tv, TraversalStack &
         const G d2 = dot(wo, wo), dist = safe_sqrt(d2);
         wo = wo / dist;
         const RayT<G> ray1{its.p, wo};
-        const Its<G> its1 = intersect<G>(sc, tv, st, ray1, ps.valid, form, nrays);
+        const Its<G> its1 = intersect<G>(sc, tv, st, ray1, ps.valid, form, nrays, -1, -1, kPreLightRay);
         if (!(its1.valid && val(its1.t) > val(dist) - kShadowEpsilon && emitter_of(sc, tv, its1) >= 0)) continue;
         const G Gv = abs_(dot(its1.n, -wo)) / d2;
         const Vec3<G> wl = its.sh.to_local(wo);

@@ -26,6 +26,186 @@ __global__ __launch_bounds__(kBlock) void k_trace(LaunchCtx cx, int m, const flo
 }
 
 
+// ------------------------------------------------------------------------------- k_wf_trace
+// The DENSE trace kernel of the traced wavefront (psdr_kernels.h run_camera_wavefront; replaces optixLaunch + the closest-hit programs,
+// src/scene/scene_optix.cpp:81-126, cuda/psdr_cuda.cu:9-45, for the rays that enter a tree box).  In a room only a fifth of the rays meet an
+// object, and inside the render kernels a wave pays for its slowest lane at every closest_hit: on the 50 k-triangle interior the fused
+// PathTracer spent two thirds of its instructions walking trees with one or two lanes busy (tools/walk_stats: 18 % of the bounce rays enter a
+// tree and visit 8.6 nodes, a wave of 64 almost always holds one).  Here the walk is a kernel of its own:
+//   * input: a queue of ray requests (o | dest), (d | -) -- only rays that enter a box, written by the stage that sampled them;
+//   * one persistent workgroup of 1024 threads per CU with the 4-wide tree in its 160 KB of LDS (the whole tree of a 5 k-triangle mesh, the
+//     top levels of a larger forest; 80-byte rows: the 16-byte words of 16 random rows then spread over all bank groups) and the
+//     traversal stacks (one column per lane) behind it;
+//   * LANE REFILL: a lane whose ray is done writes its hit row and takes the next request at the following leaf boundary -- the wave
+//     keeps a block of 64 requests in registers and hands them out by rank (ds_bpermute), so every node step runs with (nearly) all lanes busy;
+//   * output: hit[dest] = (tri, u, v, t) of the closest TREE hit (tri < 0: none), the same leaf test as every other walk of the library.
+constexpr int kTraceBlock = 1024, kTraceNodeStride = 80, kTraceStackMax = 16;
+struct TraceArgs {
+    // boxes first: read through the kernel-argument segment pointer with a run-time index (an index into the by-value struct sends it to scratch)
+    float4 blas_lo[kMaxBlas], blas_hi[kMaxBlas];      // hi.w = root of the tree in the 4-wide node array
+    const Bvh4Node *nodes4; const float4 *btris;
+    const float4 *req; const int32_t *count; float4 *hit; int32_t *ovf;
+    long long sub_cap;
+    int32_t n_blas, n_lnodes, off_stack, stack_entries, ovf_stride;
+};
+static_assert(offsetof(TraceArgs, blas_lo) == 0, "k_wf_trace reads the boxes through the kernel-argument segment pointer");
+
+// MULTI: more than one tree (nearest box first, the remaining boxes re-tested against the current hit after every walk, as closest_hit does);
+// OVF: the worst-case stack of the forest is deeper than the LDS columns -- entries beyond them live in a per-lane global column (rare: the deepest
+// stack of a ray on the bunny / the interior is 11 of 24 / 22 possible entries).
+template <bool MULTI, bool OVF>
+__global__ __launch_bounds__(kTraceBlock) void k_wf_trace(TraceArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int32_t kDone = 0x7fffffff;
+    {
+        float4 *dst = reinterpret_cast<float4 *>(psdr_dyn_lds);
+        const float4 *src = reinterpret_cast<const float4 *>(a.nodes4);
+        for (int i = threadIdx.x; i < a.n_lnodes * 4; i += kTraceBlock) dst[(i >> 2) * (kTraceNodeStride / 16) + (i & 3)] = src[i];
+    }
+    // the 64 request sub-queues as one list of 64-request blocks; wave w of the grid takes blocks w, w + W, ...
+    __shared__ int s_pref[kWfSub + 1];
+    if (threadIdx.x < kWfSub) {
+        int c = (a.count[threadIdx.x * kWfCountStride] + 63) / 64;
+#pragma unroll
+        for (int off = 1; off < kWfSub; off <<= 1) { const int o = __shfl_up(c, off, 64); if ((int) threadIdx.x >= off) c += o; }
+        s_pref[threadIdx.x + 1] = c;
+        if (threadIdx.x == 0) s_pref[0] = 0;
+    }
+    __syncthreads();
+    const int total = s_pref[kWfSub];
+    const int lane = threadIdx.x & 63;
+    const int W = (int) gridDim.x * (kTraceBlock / 64);
+    int next_b = __builtin_amdgcn_readfirstlane((int) blockIdx.x * (kTraceBlock / 64) + (int) (threadIdx.x >> 6));
+    int32_t *stack = reinterpret_cast<int32_t *>(psdr_dyn_lds + a.off_stack) + threadIdx.x;
+    const int S = a.stack_entries;
+    int32_t *ovf = OVF ? a.ovf + ((size_t) blockIdx.x * kTraceBlock + threadIdx.x) : nullptr;
+    typedef __attribute__((address_space(4))) const float4 kernarg_float4;
+    const kernarg_float4 *boxes = (kernarg_float4 *) __builtin_amdgcn_kernarg_segment_ptr();
+
+    bool active = false;
+    Vec3f o(0.f), d(0.f), inv(0.f);
+    Hit best; best.tri = -1; best.u = best.v = -1.f; best.t = INFINITY;
+    uint32_t dest = 0, cand = 0;
+    int32_t cur = kDone;
+    int sp = 0;
+    float4 ra{0.f, 0.f, 0.f, 0.f}, rb{0.f, 0.f, 0.f, 0.f};        // this lane's request of the wave's current block
+    int blk_n = 0, consumed = 0;
+    for (;;) {
+        // ---- a ray whose walk is over: its hit row
+        if (active && cur == kDone && (!MULTI || cand == 0u)) {
+            a.hit[dest] = float4{__int_as_float(best.tri), best.u, best.v, best.t};
+            active = false;
+        }
+        // ---- refill the idle lanes from the wave's block of requests
+        unsigned long long idle = __ballot(!active);
+        while (idle != 0ull) {
+            if (consumed >= blk_n) {
+                if (next_b >= total) break;
+                int lo = 0, hi = kWfSub - 1;
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_pref[mid + 1] <= next_b) lo = mid + 1; else hi = mid; }
+                const int off = (next_b - s_pref[lo]) * 64;
+                blk_n = min(64, a.count[lo * kWfCountStride] - off);
+                const float4 *r = a.req + 2 * ((size_t) lo * a.sub_cap + off + lane);
+                if (lane < blk_n) { ra = r[0]; rb = r[1]; }
+                consumed = 0; next_b += W;
+            }
+            const int take = min((int) __popcll(idle), blk_n - consumed);
+            const int rank = (int) __popcll(idle & ((1ull << lane) - 1ull));
+            const int from = (consumed + rank) & 63;
+            const float ox = __shfl(ra.x, from, 64), oy = __shfl(ra.y, from, 64), oz = __shfl(ra.z, from, 64), dw = __shfl(ra.w, from, 64);
+            const float dx = __shfl(rb.x, from, 64), dy = __shfl(rb.y, from, 64), dz = __shfl(rb.z, from, 64);
+            if (!active && rank < take) {
+                o = Vec3f{ox, oy, oz}; d = Vec3f{dx, dy, dz}; inv = Vec3f{1.f / dx, 1.f / dy, 1.f / dz};
+                dest = (uint32_t) __float_as_int(dw);
+                best.tri = -1; best.u = best.v = -1.f; best.t = INFINITY;
+                sp = 0; active = true;
+                if (MULTI) { cur = kDone; cand = (1u << a.n_blas) - 1u; }
+                else { cur = __float_as_int(boxes[kMaxBlas].w); cand = 0u; }
+            }
+            consumed += take;
+            idle = __ballot(!active);
+        }
+        if (__ballot(active) == 0ull) break;
+        // ---- the next tree of a ray between two walks: the nearest box its segment [0, t_best] still enters (wave-uniform loop, boxes in SGPRs)
+        if (MULTI) {
+            const bool need = active && cur == kDone && cand != 0u;
+            if (__ballot(need) != 0ull) {
+                float near_t = INFINITY; int32_t root = kDone; uint32_t pick = 0u;
+                for (int k = 0; k < a.n_blas; ++k) {
+                    const float4 blo = boxes[k], bhi = boxes[kMaxBlas + k];
+                    const float lo3[3] = {blo.x, blo.y, blo.z}, hi3[3] = {bhi.x, bhi.y, bhi.z};
+                    float te;
+                    const bool h = slab(lo3, hi3, o, inv, best.t, te);
+                    const bool c = need && ((cand >> k) & 1u) != 0u;
+                    if (c && !h) cand &= ~(1u << k);
+                    else if (c && te < near_t) { near_t = te; root = __float_as_int(bhi.w); pick = 1u << k; }
+                }
+                if (need) { cand &= ~pick; cur = pick ? root : kDone; if (!pick) cand = 0u; }
+            }
+        }
+        // ---- inner nodes until every lane holds a leaf (or is done)
+        while (cur >= 0 && cur != kDone) {
+            Bvh4Node n;
+            if (cur < a.n_lnodes) n = *reinterpret_cast<const Bvh4Node *>(psdr_dyn_lds + cur * kTraceNodeStride);
+            else n = a.nodes4[cur];
+            const float ax = __int_as_float((int) ((n.exps & 0xffu) << 23)) * inv.x, ay = __int_as_float((int) (((n.exps >> 8) & 0xffu) << 23)) * inv.y,
+                        az = __int_as_float((int) (((n.exps >> 16) & 0xffu) << 23)) * inv.z;
+            const float bx = (n.org[0] - o.x) * inv.x, by = (n.org[1] - o.y) * inv.y, bz = (n.org[2] - o.z) * inv.z;
+            const bool px = inv.x >= 0.f, py = inv.y >= 0.f, pz = inv.z >= 0.f;
+            const uint32_t nx = px ? n.qlo[0] : n.qhi[0], fx = px ? n.qhi[0] : n.qlo[0];
+            const uint32_t ny = py ? n.qlo[1] : n.qhi[1], fy = py ? n.qhi[1] : n.qlo[1];
+            const uint32_t nz = pz ? n.qlo[2] : n.qhi[2], fz = pz ? n.qhi[2] : n.qlo[2];
+            uint32_t key[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float tnx = (float) ((nx >> (8 * c)) & 0xffu) * ax + bx, tfx = (float) ((fx >> (8 * c)) & 0xffu) * ax + bx;
+                const float tny = (float) ((ny >> (8 * c)) & 0xffu) * ay + by, tfy = (float) ((fy >> (8 * c)) & 0xffu) * ay + by;
+                const float tnz = (float) ((nz >> (8 * c)) & 0xffu) * az + bz, tfz = (float) ((fz >> (8 * c)) & 0xffu) * az + bz;
+                const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.f));
+                const float tf = fminf(fminf(tfx, tfy), fminf(tfz, best.t));
+                const bool hit = tn <= tf && n.child[c] != kNoChild;
+                // tn >= 0: its bit pattern orders like the value; the two low mantissa bits carry the slot (the nearest child is visited first,
+                // the others are pushed in slot order: a full sort saves 1.5 % of the node visits, tools/walk_stats, and costs 25 instructions)
+                key[c] = hit ? (((uint32_t) __float_as_int(tn) & ~3u) | (uint32_t) c) : 0xffffffffu;
+            }
+            const uint32_t kmin = min(min(key[0], key[1]), min(key[2], key[3]));
+            const int slot = (int) (kmin & 3u);
+            if (OVF && __ballot(sp + 3 > S) != 0ull) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (key[c] != 0xffffffffu && c != slot) {
+                        if (sp < S) stack[sp * kTraceBlock] = n.child[c]; else ovf[(size_t) (sp - S) * a.ovf_stride] = n.child[c];
+                        ++sp;
+                    }
+            } else {
+                // room for three more everywhere in the wave: unconditional stores, the stack pointer moves where the child counts
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { stack[sp * kTraceBlock] = n.child[c]; sp += (key[c] != 0xffffffffu && c != slot) ? 1 : 0; }
+            }
+            if (kmin != 0xffffffffu) cur = slot == 0 ? n.child[0] : slot == 1 ? n.child[1] : slot == 2 ? n.child[2] : n.child[3];
+            else if (sp > 0) { --sp; cur = (!OVF || sp < S) ? stack[sp * kTraceBlock] : ovf[(size_t) (sp - S) * a.ovf_stride]; }
+            else cur = kDone;
+        }
+        // ---- the leaf triangles, two at a time (six loads in flight)
+        if (cur != kDone) {
+            const int enc = ~cur, first = enc >> 3, cnt = (enc & 7) + 1;
+            const float4 *bt = a.btris + (size_t) first * 3;
+            for (int i = 0; i < cnt; i += 2) {
+                const int j = i + 1 < cnt ? i + 1 : i;
+                const float4 a0 = bt[i * 3], b0 = bt[i * 3 + 1], c0 = bt[i * 3 + 2];
+                const float4 a1 = bt[j * 3], b1 = bt[j * 3 + 1], c1 = bt[j * 3 + 2];
+                leaf_triangle_test<false>(a0, b0, c0, o, d, best);
+                leaf_triangle_test<false>(a1, b1, c1, o, d, best);
+            }
+            if (sp > 0) { --sp; cur = (!OVF || sp < S) ? stack[sp * kTraceBlock] : ovf[(size_t) (sp - S) * a.ovf_stride]; }
+            else cur = kDone;
+        }
+    }
+#else
+    (void) a;
+#endif
+}
+
 // ------------------------------------------------------------------------------- BVH refit
 // Between two Scene::configure() calls of an optimisation loop the topology stays and the vertices move a
 // little: instead of the host rebuild (D2H of the triangle table, SAH build, H2D: ~2.5 ms for 5 k
@@ -542,13 +722,14 @@ int lbvh_build(psdr_scene_s *h, hipStream_t s, bool &fallback) {
     h->hot_rows = (int) tris.size();
     h->root = 0; h->bvh_depth = info.depth; h->num_nodes = T - 1; h->num_btris = T;
     h->n_tiny = 0; h->n_blas = 0; h->n_inline = 0;
-    {   // the 4-wide tree over the device-built BVH2: its topology is decided on the host (one read-back of the node array; the collapse is
-        // O(T)): 263 k triangles +~15 ms on top of the 2 ms device build -- still an order below the host SAH build
+    if (use_wide_tree(h, false)) {
+        // the 4-wide tree over the device-built BVH2: its topology is decided on the host (one read-back of the node array; the collapse is
+        // O(T)): 263 k triangles +~15 ms on top of the 2 ms device build -- only where a launch would walk it
         std::vector<BvhNode> host_nodes((size_t) T - 1);
         HIP_TRY(hipMemcpyAsync(host_nodes.data(), h->d_nodes, host_nodes.size() * sizeof(BvhNode), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         if (int rc = bvh4_build(h, host_nodes, std::vector<int32_t>{0}, false, s)) return rc;
-    }
+    } else { h->wide = false; h->num_nodes4 = 0; h->stack_need4 = 0; }
     h->tree_tris = T; h->refits_since_build = 0; h->num_builds++; h->bvh_pad = info.pad; h->built_area = area;
     h->level_start.clear();
     h->refit_ok = true; h->lbvh = true; h->have_bvh = true;
@@ -566,7 +747,8 @@ int bvh4_refill(psdr_scene_s *h, hipStream_t s) {
 }
 int bvh4_build(psdr_scene_s *h, const std::vector<BvhNode> &nodes, const std::vector<int32_t> &roots2, bool forest, hipStream_t s) {
     h->wide = use_wide_tree(h, forest);
-    if (!h->wide) { h->num_nodes4 = 0; h->stack_need4 = 0; return 0; }
+    // the dense trace kernel of the traced wavefront walks the 4-wide forest of every two-level scene, whatever its render kernels walk
+    if (!h->wide && !forest) { h->num_nodes4 = 0; h->stack_need4 = 0; return 0; }
     Bvh4Topology tp;
     collapse_bvh4(nodes, roots2, tp);
     h->num_nodes4 = tp.n4; h->stack_need4 = tp.stack_need;
@@ -585,6 +767,46 @@ int bvh4_build(psdr_scene_s *h, const std::vector<BvhNode> &nodes, const std::ve
     HIP_TRY(hipMemcpyAsync(h->d_topo4 + (size_t) tp.n4 * 4, tp.src.data(), (size_t) tp.n4 * 4 * sizeof(int32_t), hipMemcpyHostToDevice, s));
     if (int rc = bvh4_refill(h, s)) return rc;
     HIP_TRY(hipStreamSynchronize(s));              // the topology vectors die at return
+    return 0;
+}
+
+// ---- the dense trace kernel of the traced wavefront
+bool traced_wavefront(const psdr_scene_s *h) { return h->traced_enabled && h->n_blas > 0 && h->num_nodes4 > 0 && h->d_nodes4 != nullptr; }
+int launch_wf_trace(psdr_scene_s *h, const float4 *req, const int32_t *count, long long sub_cap, float4 *hit, hipStream_t s) {
+    TraceArgs a{};
+    std::memcpy(a.blas_lo, h->blas_lo, sizeof(a.blas_lo));
+    std::memcpy(a.blas_hi, h->blas_hi, sizeof(a.blas_hi));
+    for (int k = 0; k < h->n_blas; ++k) std::memcpy(&a.blas_hi[k].w, &h->blas_root4[k], 4);
+    a.nodes4 = h->d_nodes4; a.btris = h->d_btris; a.req = req; a.count = count; a.hit = hit; a.sub_cap = sub_cap; a.n_blas = h->n_blas;
+    // LDS: stacks first in the budget (S + 1 columns: the unconditional stores of a node step may touch the entry above the top), the tree in the rest
+    const int S = std::min(h->stack_need4, kTraceStackMax);
+    const bool ovf = h->stack_need4 > S;
+    const int stack_bytes = (S + 1) * kTraceBlock * 4;
+    const int room = h->lds_limit - 1024 - stack_bytes;                 // 1 KB: the kernel's static LDS
+    a.n_lnodes = std::max(0, std::min(h->num_nodes4, room / kTraceNodeStride));
+    a.off_stack = a.n_lnodes * kTraceNodeStride;
+    a.stack_entries = S;
+    const int grid = h->num_cus;
+    if (ovf) {
+        a.ovf_stride = grid * kTraceBlock;
+        const size_t need = (size_t) a.ovf_stride * (size_t) (h->stack_need4 - S) * sizeof(int32_t);
+        if (need > h->trace_ovf_bytes) {
+            if (h->d_trace_ovf) (void) hipFree(h->d_trace_ovf);
+            h->d_trace_ovf = nullptr; h->trace_ovf_bytes = 0;
+            HIP_TRY(hipMalloc(&h->d_trace_ovf, need));
+            h->trace_ovf_bytes = need;
+        }
+        a.ovf = h->d_trace_ovf;
+    }
+    const int dyn = a.off_stack + stack_bytes;
+#define PSDR_LAUNCH_TRACE(MULTI, OVF)                                                                                                                       \
+    do { static bool attr_set = false;                                                                                                                      \
+         if (!attr_set) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wf_trace<MULTI, OVF>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024)); attr_set = true; } \
+         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wf_trace<MULTI, OVF>), dim3(grid), dim3(kTraceBlock), dyn, s, a); } while (0)
+    if (h->n_blas > 1) { if (ovf) PSDR_LAUNCH_TRACE(true, true); else PSDR_LAUNCH_TRACE(true, false); }
+    else { if (ovf) PSDR_LAUNCH_TRACE(false, true); else PSDR_LAUNCH_TRACE(false, false); }
+#undef PSDR_LAUNCH_TRACE
+    HIP_TRY(hipGetLastError());
     return 0;
 }
 
@@ -630,6 +852,7 @@ int psdr_scene_create(psdr_scene_t *out) {
     if (const char *e4 = std::getenv("PSDR_TINY_SCENE")) h->tiny_enabled = std::atoi(e4) != 0;      // 0: walk the tree even for <= 16 triangles
     if (const char *e5 = std::getenv("PSDR_TWO_LEVEL")) h->two_level_enabled = std::atoi(e5) != 0;  // 0: one tree over all triangles
     if (const char *e7 = std::getenv("PSDR_WF_BINNED")) h->wf_binned = std::atoi(e7) != 0;          // 0: wavefront streams not binned by cost class
+    if (const char *e9 = std::getenv("PSDR_WF_TRACED")) h->traced_enabled = std::atoi(e9) != 0;     // 0: no dense trace kernel between the wavefront stages
     if (const char *e8 = std::getenv("PSDR_BVH_BUILD")) h->bvh_device_mode = std::string(e8) == "device" ? 1 : (std::string(e8) == "host" ? 0 : -1);
     if (const char *e3 = std::getenv("PSDR_SORT_EDGES")) h->sort_edges = std::atoi(e3) != 0;        // 0: primary-edge slots in natural order
     *out = h;
@@ -655,6 +878,7 @@ int psdr_scene_destroy(psdr_scene_t h) {
     if (h->d_se_list) (void) hipFree(h->d_se_list);
     if (h->d_rev_deep) (void) hipFree(h->d_rev_deep);
     if (h->d_pe_rep) (void) hipFree(h->d_pe_rep);
+    if (h->d_trace_ovf) (void) hipFree(h->d_trace_ovf);
     delete h;
     return 0;
 }

@@ -160,7 +160,11 @@ struct psdr_scene_s {
     int32_t *d_topo4 = nullptr;            // [n4][4] child, then [n4][4] src
     size_t cap_nodes4 = 0;
     int num_nodes4 = 0, stack_need4 = 0;
-    bool wide = false;                     // launches on this scene walk the 4-wide tree (psdr_hip.hip use_wide_tree)
+    bool wide = false;                     // the render kernels of this scene walk the 4-wide tree (psdr_hip.hip use_wide_tree); the dense trace kernel
+                                           // always does -- the 4-wide forest of a two-level scene exists whenever num_nodes4 > 0
+    int32_t *d_trace_ovf = nullptr;        // k_wf_trace: stack entries beyond the LDS columns
+    size_t trace_ovf_bytes = 0;
+    bool traced_enabled = true;
     int32_t root4 = 0, blas_root4[kMaxBlas] = {};
     // device refit of the tree between rebuilds (psdr_hip.hip k_refit_*)
     bool refit_enabled = true;
@@ -229,6 +233,8 @@ struct psdr_scene_s {
 };
 
 constexpr int kRayCounters = 64, kRayCounterStride = 16;     // d_counters: 64 counters, 128 bytes apart
+// wavefront streams and trace-request queues: 64 sub-streams / sub-queues, their counters on their own 128-byte lines (psdr_kernels.h)
+constexpr int kWfSub = 64, kWfCountStride = 32;
 
 namespace psdr_host {
 int fail(const std::string &m);
@@ -239,6 +245,9 @@ void fill_top(const psdr_scene_s *h, SceneView &sc);
 constexpr int kMaxInlineTris = 2 * kTinyTris;      // inline triangles of a two-level tree before pairing
 int make_ctx(psdr_scene_s *h, const psdr_render_opts *o, int sampler, LaunchCtx &cx);
 bool use_wavefront(const psdr_scene_s *h, const psdr_render_opts *o);
+// traced wavefront (psdr_hip.hip k_wf_trace): the scene has a two-level tree whose 4-wide forest is on the device
+bool traced_wavefront(const psdr_scene_s *h);
+int launch_wf_trace(psdr_scene_s *h, const float4 *req, const int32_t *count, long long sub_cap, float4 *hit, hipStream_t s);
 SinkLayout make_sink_layout(const psdr_scene_s *h, const psdr_grads *g);
 inline int sink_bytes(const SinkLayout &L) { return (L.priv_rows > 0 && !L.priv_regs) ? (L.priv_off + kPrivWords * kBlock) * 4 : (L.rep * L.stride * 4 + 15) / 16 * 16; }
 int check_counts(const psdr_scene_s *h, const psdr_render_opts *o);

@@ -192,7 +192,6 @@ __global__ __launch_bounds__(kBlock, (camera_waves<G, R, INTEG, FL, NOTREE>())) 
 // C2 stage serialised on a single L2 atomic (3-5 ns each: ~1 ms per stage, C2 PathTracer(3) 6.6 ms);
 // wave-private segments without any atomic were measured too: as fast on C2 (3.0 ms) but 10 % slower on
 // open scenes, where the waves' survivor counts differ and the next stage inherits the imbalance.
-constexpr int kWfSub = 64, kWfCountStride = 32;
 // Two-level scenes (SceneView::n_blas > 0) run the wavefront BINNED BY COST CLASS: in a room most bounce rays only meet
 // the walls (uniform, ~200 VALU) while the few that enter an object's box walk its tree (1 500 - 4 000), and a wave
 // pays for its most expensive lane -- SIMD efficiency 16-23 % on the bounce rays of cbox_bunny (tools/simd_sim).  The
@@ -211,13 +210,26 @@ struct PathStream {
     int32_t *count;       // [kWfSub * kWfCountStride] records in each sub-stream (+ the grab counter behind them)
     long long sub_cap;    // records per sub-stream
     int32_t binned;       // 1: sub-stream = (3 - class) * kWfGroups + chunk % kWfGroups, consumed by dynamic chunk grabs
+    // traced wavefront (kScenePre instances): hit[2 * i + ray] = closest TREE hit (tri, u, v, t) of ray 0 (BSDF-sampled) / 1 (light) of record i,
+    // written by the dense trace kernel (psdr_hip.hip k_wf_trace) between the stage that pushed the record and the stage that consumes it;
+    // bits 29-30 of tri[i] tell which of the two rays have one
+    float4 *hit;
+};
+constexpr int kWfClsShift = 29;
+constexpr int32_t kWfTriMask = (1 << kWfClsShift) - 1;
+// Requests of the dense trace kernel: the rays of the NEXT stage that enter a tree box, as (o | dest), (d | -) rows in kWfSub sub-queues
+// (block b appends to queue b % kWfSub, one atomic per wave); dest = 2 * record + ray addresses PathStream::hit of the stream the record went to.
+struct TraceQueue {
+    float4 *req;          // [2 * kWfSub * sub_cap]
+    int32_t *count;       // [kWfSub * kWfCountStride]
+    long long sub_cap;    // requests per sub-queue
 };
 
 template <class M>
 __device__ __forceinline__ void stream_write(const PathStream &out, long long i, int pixel, uint32_t slot, const Its<float> &next, const Vec3f &dir, const Vec3<M> &beta,
-                                             const Vec3<M> &acc) {
+                                             const Vec3<M> &acc, int cls = 0) {
     constexpr int K = ad_traits<M>::K;
-    out.pixel[i] = pixel; out.slot[i] = slot; out.tri[i] = next.tri; out.hu[i] = next.hu; out.hv[i] = next.hv;
+    out.pixel[i] = pixel; out.slot[i] = slot; out.tri[i] = next.tri | (cls << kWfClsShift); out.hu[i] = next.hu; out.hv[i] = next.hv;
     out.dir[i] = dir.x; out.dir[out.cap + i] = dir.y; out.dir[2 * out.cap + i] = dir.z;
     out.beta[i] = val(beta.x); out.beta[out.cap + i] = val(beta.y); out.beta[2 * out.cap + i] = val(beta.z);
     out.acc[i] = val(acc.x); out.acc[out.cap + i] = val(acc.y); out.acc[2 * out.cap + i] = val(acc.z);
@@ -250,8 +262,11 @@ __device__ __forceinline__ void stream_push(const PathStream &out, bool alive, i
 // test ignores t_best (conservative: class 0 NEVER walks a tree).
 // `next` is the complete vertex the current stage just produced (position, frame, wi): no need to rebuild it from the record as the
 // next stage will -- a direction one ulp apart can at worst put a record into a cheaper class than its walk turns out to be.
-template <class TVT>
-__device__ __forceinline__ int classify_next(const SceneView &sc, const TVT &, const RngJump &jump_next, uint32_t slot, const Its<float> &next, const Vec3f &) {
+// TRACED (the traced wavefront): the two directions are handed back -- they become the trace requests -- and the light ray is tested against the
+// boxes without its length too: closest_hit looks for the closest hit along the whole ray, and so does the trace kernel.
+template <bool TRACED = false, class TVT>
+__device__ __forceinline__ int classify_next(const SceneView &sc, const TVT &, const RngJump &jump_next, uint32_t slot, const Its<float> &next, const Vec3f &,
+                                             Vec3f *d_bsdf = nullptr, Vec3f *d_light = nullptr) {
     const TangentView<0, TVT::flags> tv0{};
     const Its<float> &its = next;
     const int bsdf_id = Tab<TVT::flags>::mesh_bsdf(sc, its.mesh);          // the staged copies (two-level instances), as every estimator reads them
@@ -271,13 +286,15 @@ __device__ __forceinline__ int classify_next(const SceneView &sc, const TVT &, c
     if (bsdf.sample(sc, tv0, its, s, true, wo_s, pdf_s)) {
         const Vec3f d1 = its.sh.s * wo_s.x + its.sh.t * wo_s.y + its.sh.n * wo_s.z;
         if (enters(its.p, d1, INFINITY)) cls |= 1;
+        if (TRACED) *d_bsdf = d1;
     }
     const PosSample<float> ps = sample_emitter_position<float>(sc, tv0, its.p, s0, s1, false);
     if (ps.valid) {
         Vec3f wo = ps.p - its.p;
         const float dist = sqrtf(fmaxf(dot(wo, wo), 0.f));
         wo = wo / dist;
-        if (enters(its.p, wo, dist)) cls |= 2;
+        if (enters(its.p, wo, TRACED ? INFINITY : dist)) cls |= 2;
+        if (TRACED) *d_light = wo;
     }
     return cls;
 }
@@ -298,6 +315,37 @@ __device__ __forceinline__ void stream_push_binned(const PathStream &out, bool a
         if (lane == __ffsll((long long) mask) - 1) base = atomicAdd(out.count + sub * kWfCountStride, (int) __popcll(mask));
         base = __shfl(base, __ffsll((long long) mask) - 1, 64);
         if (mine) stream_write<M>(out, (long long) sub * out.sub_cap + base + __popcll(mask & ((1ull << lane) - 1ull)), pixel, slot, next, dir, beta, acc);
+    }
+}
+
+// Traced wavefront: plain sub-streams (block b -> sub-stream b % kWfSub, like stream_push) + the trace requests of the record's two rays.
+template <class M>
+__device__ __forceinline__ void stream_push_traced(const PathStream &out, const TraceQueue &q, bool alive, int cls, int pixel, uint32_t slot, const Its<float> &next,
+                                                   const Vec3f &dir, const Vec3<M> &beta, const Vec3<M> &acc, const Vec3f &d_bsdf, const Vec3f &d_light) {
+    const unsigned long long mask = __ballot(alive);
+    if (mask == 0ull) return;
+    const int lane = threadIdx.x & 63, sub = blockIdx.x % kWfSub, leader = __ffsll((long long) mask) - 1;
+    const unsigned long long m1 = __ballot(alive && (cls & 1)), m2 = __ballot(alive && (cls & 2));
+    const int n1 = (int) __popcll(m1), n2 = (int) __popcll(m2);
+    int base = 0, rbase = 0;
+    if (lane == leader) {
+        base = atomicAdd(out.count + sub * kWfCountStride, (int) __popcll(mask));
+        if (n1 + n2 > 0) rbase = atomicAdd(q.count + sub * kWfCountStride, n1 + n2);
+    }
+    base = __shfl(base, leader, 64); rbase = __shfl(rbase, leader, 64);
+    if (!alive) return;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const long long i = (long long) sub * out.sub_cap + base + __popcll(mask & below);
+    stream_write<M>(out, i, pixel, slot, next, dir, beta, acc, cls);
+    if (cls & 1) {
+        const long long r = (long long) sub * q.sub_cap + rbase + __popcll(m1 & below);
+        q.req[2 * r] = float4{next.p.x, next.p.y, next.p.z, __int_as_float((int) (2 * i))};
+        q.req[2 * r + 1] = float4{d_bsdf.x, d_bsdf.y, d_bsdf.z, 0.f};
+    }
+    if (cls & 2) {
+        const long long r = (long long) sub * q.sub_cap + rbase + n1 + __popcll(m2 & below);
+        q.req[2 * r] = float4{next.p.x, next.p.y, next.p.z, __int_as_float((int) (2 * i + 1))};
+        q.req[2 * r + 1] = float4{d_light.x, d_light.y, d_light.z, 0.f};
     }
 }
 
@@ -330,10 +378,12 @@ __device__ __forceinline__ void splat_runs(int pixel, bool valid, const Vec3<M> 
 #ifndef PSDR_WF_WAVES
 #define PSDR_WF_WAVES 4
 #endif
-template <class M, int FL>
+// TRACED (two-level scenes, run_camera_wavefront): the stage stops at the primary hit like the binned one, the records go to plain sub-streams and the
+// two rays of bounce stage 0 that enter a tree box become requests of the dense trace kernel (stream_push_traced).
+template <class M, int FL, bool TRACED = false>
 __global__ __launch_bounds__(kBlock, (is_ad<M>() ? 2 : PSDR_WF_WAVES)) void k_wf_camera(LaunchCtx cx, TV<M, FL> tv, int spp, int s_begin, SlotDiv nsp, long long j0, long long n,
                                                         float inv_spp, float *__restrict__ img, float *__restrict__ dimg, long long plane,
-                                                        PathStream out, int want_next, unsigned long long *counters, RngJump jump_next) {
+                                                        PathStream out, int want_next, unsigned long long *counters, RngJump jump_next, TraceQueue tq) {
     TraversalStack st; setup_lds(cx, st, tv);
     uint32_t nrays = 0;
     const long long nceil = (n + kBlock - 1) / kBlock * kBlock;
@@ -348,7 +398,8 @@ __global__ __launch_bounds__(kBlock, (is_ad<M>() ? 2 : PSDR_WF_WAVES)) void k_wf
         bool alive = false;
         uint32_t slot = 0;
         bool primary_only = false;
-        if constexpr ((FL & kSceneForest) != 0) primary_only = out.binned != 0 && want_next;
+        if constexpr (TRACED) primary_only = want_next != 0;
+        else if constexpr ((FL & kSceneForest) != 0) primary_only = out.binned != 0 && want_next;
         if (in) {
             slot = (uint32_t) ((uint64_t) pixel * (uint64_t) spp + (uint64_t) (s_begin + s_in));
             if (primary_only) {
@@ -363,7 +414,11 @@ __global__ __launch_bounds__(kBlock, (is_ad<M>() ? 2 : PSDR_WF_WAVES)) void k_wf
         const bool goes_on = want_next && alive;
         splat_runs<M>(pixel, in && !goes_on, zero_nonfinite(r), inv_spp, img, dimg, plane);
         if (want_next) {
-            if constexpr ((FL & kSceneForest) != 0) {
+            if constexpr (TRACED) {
+                Vec3f d_bsdf(0.f), d_light(0.f);
+                const int cls = alive ? classify_next<true>(cx.sc, tv, jump_next, slot, next, dir, &d_bsdf, &d_light) : 0;
+                stream_push_traced<M>(out, tq, alive, cls, pixel, slot, next, dir, beta, r, d_bsdf, d_light);
+            } else if constexpr ((FL & kSceneForest) != 0) {
                 if (out.binned) stream_push_binned<M>(out, alive, alive ? classify_next(cx.sc, tv, jump_next, slot, next, dir) : 0, jj / kBlock, pixel, slot, next, dir, beta, r);
                 else stream_push<M>(out, alive, pixel, slot, next, dir, beta, r);
             } else stream_push<M>(out, alive, pixel, slot, next, dir, beta, r);
@@ -375,10 +430,10 @@ __global__ __launch_bounds__(kBlock, (is_ad<M>() ? 2 : PSDR_WF_WAVES)) void k_wf
 // One bounce: block b consumes its share of sub-stream b % kWfSub (grid-stride over the blocks of that
 // sub-stream; gridDim.x is a multiple of kWfSub) and appends the surviving paths to the same sub-stream of `out`.
 // One record of a bounce stage: rebuild the vertex, direct step, splat, push the continuation.
-template <class M, int FL>
+template <class M, int FL, bool TRACED = false>
 __device__ __forceinline__ void wf_bounce_record(const LaunchCtx &cx, const TV<M, FL> &tv, TraversalStack &st, float inv_spp, float *__restrict__ img,
                                                  float *__restrict__ dimg, long long plane, const PathStream &in, const PathStream &out, int want_next,
-                                                 const RngJump &jump_next, bool live, long long j, long long chunk, uint32_t &nrays) {
+                                                 const RngJump &jump_next, bool live, long long j, long long chunk, uint32_t &nrays, const TraceQueue &tq) {
     constexpr int K = ad_traits<M>::K;
     int pixel = -1; uint32_t slot = 0;
     Vec3<M> r = zero3<M>(), beta = zero3<M>();
@@ -405,9 +460,23 @@ __device__ __forceinline__ void wf_bounce_record(const LaunchCtx &cx, const TV<M
                 acc.z.d[k] = in.acc[(5 + 3 * k) * in.cap + j];
             }
         }
-        const Its<float> its = path_vertex_from_record(cx.sc, tv, in.tri[j], in.hu[j], in.hv[j], din);
-        Vec3<M> f;
-        const Vec3<M> c = wavefront_bounce_vertex<M>(cx.sc, tv, st, cx.jump, (uint64_t) slot, its, nrays, next, f, alive);
+        int tri_word = in.tri[j];
+        Vec3<M> f, c;
+        if constexpr (TRACED) {
+            // the tree hits of this vertex' two rays, traced since the record was pushed (none where its class bit is clear: the ray enters no box)
+            const int cls = (tri_word >> kWfClsShift) & 3;
+            tri_word &= kWfTriMask;
+            st.pre[kPreBsdfRay].tri = st.pre[kPreLightRay].tri = -1;
+            if (cls & 1) { const float4 h = in.hit[2 * j]; st.pre[kPreBsdfRay] = Hit{__float_as_int(h.x), h.y, h.z, h.w}; }
+            if (cls & 2) { const float4 h = in.hit[2 * j + 1]; st.pre[kPreLightRay] = Hit{__float_as_int(h.x), h.y, h.z, h.w}; }
+        }
+        const Its<float> its = path_vertex_from_record(cx.sc, tv, tri_word, in.hu[j], in.hv[j], din);
+        if constexpr (TRACED) {
+            TV<M, FL | kScenePre> tvp;
+#pragma unroll
+            for (int k = 0; k < (K > 0 ? K : 1); ++k) tvp.t[k] = tv.t[k];
+            c = wavefront_bounce_vertex<M>(cx.sc, tvp, st, cx.jump, (uint64_t) slot, its, nrays, next, f, alive);
+        } else c = wavefront_bounce_vertex<M>(cx.sc, tv, st, cx.jump, (uint64_t) slot, its, nrays, next, f, alive);
         r = acc + beta * c;
         if (alive) {
             beta = beta * f;
@@ -419,7 +488,11 @@ __device__ __forceinline__ void wf_bounce_record(const LaunchCtx &cx, const TV<M
     const bool goes_on = want_next && alive;
     splat_runs<M>(pixel, live && !goes_on, zero_nonfinite(r), inv_spp, img, dimg, plane);
     if (want_next) {
-        if constexpr ((FL & kSceneForest) != 0) {
+        if constexpr (TRACED) {
+            Vec3f d_bsdf(0.f), d_light(0.f);
+            const int cls = alive ? classify_next<true>(cx.sc, tv, jump_next, slot, next, dir, &d_bsdf, &d_light) : 0;
+            stream_push_traced<M>(out, tq, alive, cls, pixel, slot, next, dir, beta, r, d_bsdf, d_light);
+        } else if constexpr ((FL & kSceneForest) != 0) {
             if (out.binned) stream_push_binned<M>(out, alive, alive ? classify_next(cx.sc, tv, jump_next, slot, next, dir) : 0, chunk, pixel, slot, next, dir, beta, r);
             else stream_push<M>(out, alive, pixel, slot, next, dir, beta, r);
         } else stream_push<M>(out, alive, pixel, slot, next, dir, beta, r);
@@ -430,14 +503,14 @@ __device__ __forceinline__ void wf_bounce_record(const LaunchCtx &cx, const TV<M
 // sub-stream; gridDim.x is a multiple of kWfSub) and appends the surviving paths to the same sub-stream of `out`.
 // Binned streams: the 64 sub-streams form one list of 256-record chunks (expensive classes first) that the workgroups
 // grab kWfGrab at a time from one counter.
-template <class M, int FL>
+template <class M, int FL, bool TRACED = false>
 __global__ __launch_bounds__(kBlock, (is_ad<M>() ? 2 : PSDR_WF_WAVES)) void k_wf_bounce(LaunchCtx cx, TV<M, FL> tv, float inv_spp, float *__restrict__ img,
                                                         float *__restrict__ dimg, long long plane, PathStream in,
-                                                        PathStream out, int want_next, unsigned long long *counters, RngJump jump_next) {
+                                                        PathStream out, int want_next, unsigned long long *counters, RngJump jump_next, TraceQueue tq) {
     TraversalStack st; setup_lds(cx, st, tv);
     uint32_t nrays = 0;
     bool binned = false;
-    if constexpr ((FL & kSceneForest) != 0) binned = in.binned != 0;
+    if constexpr ((FL & kSceneForest) != 0 && !TRACED) binned = in.binned != 0;
     if (binned) {
         __shared__ int s_pref[kWfSub + 1];
         __shared__ int s_grab;
@@ -462,7 +535,7 @@ __global__ __launch_bounds__(kBlock, (is_ad<M>() ? 2 : PSDR_WF_WAVES)) void k_wf
                 while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_pref[mid + 1] <= c) lo = mid + 1; else hi = mid; }
                 const int off = (c - s_pref[lo]) * kBlock + (int) threadIdx.x;
                 const bool live = off < in.count[lo * kWfCountStride];
-                wf_bounce_record<M, FL>(cx, tv, st, inv_spp, img, dimg, plane, in, out, want_next, jump_next, live, (long long) lo * in.sub_cap + off, c, nrays);
+                wf_bounce_record<M, FL, false>(cx, tv, st, inv_spp, img, dimg, plane, in, out, want_next, jump_next, live, (long long) lo * in.sub_cap + off, c, nrays, tq);
             }
         }
     } else {
@@ -470,8 +543,8 @@ __global__ __launch_bounds__(kBlock, (is_ad<M>() ? 2 : PSDR_WF_WAVES)) void k_wf
         const long long in_base = (long long) sub * in.sub_cap;
         const int n = in.count[sub * kWfCountStride];
         for (int base = (blockIdx.x / kWfSub) * kBlock; base < n; base += per * kBlock)
-            wf_bounce_record<M, FL>(cx, tv, st, inv_spp, img, dimg, plane, in, out, want_next, jump_next, base + (int) threadIdx.x < n, in_base + base + threadIdx.x,
-                                    base / kBlock, nrays);
+            wf_bounce_record<M, FL, TRACED>(cx, tv, st, inv_spp, img, dimg, plane, in, out, want_next, jump_next, base + (int) threadIdx.x < n, in_base + base + threadIdx.x,
+                                            base / kBlock, nrays, tq);
     }
     count_rays(counters, nrays);
 }
@@ -970,17 +1043,23 @@ int run_camera_wavefront(psdr_scene_s *h, const psdr_render_opts *o, const TV<M,
     // class-binned streams pay where most paths survive every bounce (rooms); in an open scene the streams thin out quickly and the 64
     // sub-streams of mostly empty chunks cost more than the classes save (bunny_light PathTracer(3) 4.9 against 3.3 ms plain,
     // PathTracer(6) 8.7 against 3.6)
-    const bool binned = (FL & kSceneForest) != 0 && h->n_blas > 0 && h->wf_binned;          // a two-level scene is a room (use_wavefront)
+    // two-level scenes: the TRACED wavefront -- tree walks in the dense trace kernel between the stages (psdr_hip.hip k_wf_trace), plain streams;
+    // PSDR_WF_TRACED=0 (psdr_scene_create) falls back to the class-binned streams of round 2
+    bool traced = false;
+    if constexpr ((FL & kSceneForest) != 0) traced = traced_wavefront(h);
+    const bool binned = !traced && (FL & kSceneForest) != 0 && h->n_blas > 0 && h->wf_binned;          // a two-level scene is a room (use_wavefront)
     const long long cap = std::min(n, binned ? kWfChunk / 2 : kWfChunk);
     const int depth = o->max_depth;
-    const size_t words = 8 + 6 * (1 + K);
+    const size_t words = 8 + 6 * (1 + K) + (traced ? 8 : 0);          // traced: + the two hit rows of a record
     // plain: block b appends to sub-stream b % kWfSub, at most ceil(blocks / kWfSub) * trips * kBlock records each.
     // binned: the records of chunk c go to group c % kWfGroups of their class; a class can take all of a group
     const long long max_blocks = ((long long) launch_blocks(h, cap) + kWfSub - 1) / kWfSub * kWfSub;   // >= the grid of any chunk
     const long long binned_sub_cap = (((cap + kBlock - 1) / kBlock + kWfSub) / kWfGroups + 2) * kBlock;
-    const long long cap_alloc = binned ? binned_sub_cap * kWfSub : cap + max_blocks * kBlock;
-    const size_t cnt_bytes = (size_t) (kWfMaxDepth + 1) * kWfStageInts * sizeof(int32_t);
-    const size_t need = 2 * words * 4 * (size_t) cap_alloc + cnt_bytes;
+    const long long cap_alloc = ((binned ? binned_sub_cap * kWfSub : cap + max_blocks * kBlock) + 63) / 64 * 64;      // the hit rows are float4
+    const size_t cnt_ints = (size_t) (kWfMaxDepth + 1) * kWfStageInts + (traced ? (size_t) (kWfMaxDepth + 1) * kWfSub * kWfCountStride : 0);
+    const size_t cnt_bytes = cnt_ints * sizeof(int32_t);
+    const size_t req_bytes = traced ? (size_t) 2 * cap_alloc * 2 * sizeof(float4) : 0;      // at most two requests per record, two rows each
+    const size_t need = 2 * words * 4 * (size_t) cap_alloc + cnt_bytes + req_bytes;
     if (need > h->ws_bytes) {
         if (h->d_ws) (void) hipFree(h->d_ws);
         h->d_ws = nullptr; h->ws_bytes = 0;
@@ -988,6 +1067,7 @@ int run_camera_wavefront(psdr_scene_s *h, const psdr_render_opts *o, const TV<M,
         h->ws_bytes = need;
     }
     int32_t *cnt = reinterpret_cast<int32_t *>(h->d_ws);
+    int32_t *req_cnt = cnt + (size_t) (kWfMaxDepth + 1) * kWfStageInts;
     PathStream st[2];
     for (int i = 0; i < 2; ++i) {
         float *b = reinterpret_cast<float *>(reinterpret_cast<char *>(h->d_ws) + cnt_bytes) + (size_t) i * words * cap_alloc;
@@ -995,8 +1075,11 @@ int run_camera_wavefront(psdr_scene_s *h, const psdr_render_opts *o, const TV<M,
         st[i].cap = c;
         st[i].pixel = reinterpret_cast<int32_t *>(b); st[i].slot = reinterpret_cast<uint32_t *>(b + c); st[i].tri = reinterpret_cast<int32_t *>(b + 2 * c);
         st[i].hu = b + 3 * c; st[i].hv = b + 4 * c; st[i].dir = b + 5 * c; st[i].beta = b + 8 * c; st[i].acc = b + (8 + 3 * (1 + K)) * c;
+        st[i].hit = traced ? reinterpret_cast<float4 *>(b + (8 + 6 * (1 + K)) * c) : nullptr;
         st[i].binned = binned ? 1 : 0;
     }
+    TraceQueue tq{};
+    tq.req = traced ? reinterpret_cast<float4 *>(reinterpret_cast<char *>(h->d_ws) + cnt_bytes + 2 * words * 4 * (size_t) cap_alloc) : nullptr;
     h->slots[0] += (uint64_t) n;
     const float inv_spp = 1.f / (float) o->spp;
     for (long long j0 = 0; j0 < n; j0 += cap) {
@@ -1004,33 +1087,60 @@ int run_camera_wavefront(psdr_scene_s *h, const psdr_render_opts *o, const TV<M,
         LaunchCtx cx;
         if (int rc = make_ctx(h, o, 0, cx)) return rc;
         HIP_TRY(hipMemsetAsync(cnt, 0, (size_t) (std::min(depth, kWfMaxDepth) + 1) * kWfStageInts * sizeof(int32_t), s));
+        if (traced) HIP_TRY(hipMemsetAsync(req_cnt, 0, (size_t) (std::min(depth, kWfMaxDepth) + 1) * kWfSub * kWfCountStride * sizeof(int32_t), s));
         const int blocks = (launch_blocks(h, cn) + kWfSub - 1) / kWfSub * kWfSub;
         const long long trips = (cn + (long long) blocks * kBlock - 1) / ((long long) blocks * kBlock);
         st[0].sub_cap = st[1].sub_cap = binned ? binned_sub_cap : (blocks / kWfSub) * trips * kBlock;
         st[0].count = cnt;
+        if constexpr ((FL & kSceneForest) != 0) {
+            if (traced) {
+                // camera stage = primary hit (its walk stays in the kernel: camera rays are coherent) + the requests of bounce stage 0; then per
+                // bounce: trace kernel (requests -> hit rows of the stream they belong to), bounce stage on the records + their hit rows
+                tq.sub_cap = 2 * st[0].sub_cap;
+                tq.count = req_cnt;
+                // the bounce stages walk no tree: nothing of it staged, no stacks -- the hit rows of the kernel-argument primitives and the small tables only
+                LaunchCtx cxp = cx;
+                plan_lds(h, cxp, 1 << 30);
+                cxp.sc.n_lnodes = cxp.sc.n_lbtris = cxp.sc.n_ltri = 0;
+                const int dyn_p = cxp.off_stack;
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wf_camera<M, FL, true>), dim3(blocks), dim3(kBlock), lds_bytes(cx, h), s, cx, tv, o->spp, o->spp_begin, nsp, j0, cn,
+                                   inv_spp, img, dimg, WH * 3, st[0], 1, h->d_counters, make_rng_jump(o->rng_offset[0] + 2), tq);
+                HIP_TRY(hipGetLastError());
+                for (int k = 0; k < depth; ++k) {
+                    if (int rc = launch_wf_trace(h, tq.req, tq.count, tq.sub_cap, st[k & 1].hit, s)) return rc;
+                    st[(k + 1) & 1].count = cnt + (size_t) (k + 1) * kWfStageInts;
+                    tq.count = req_cnt + (size_t) (k + 1) * kWfSub * kWfCountStride;
+                    cxp.jump = make_rng_jump(o->rng_offset[0] + 2 + 5 * (uint64_t) k);
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wf_bounce<M, FL, true>), dim3(blocks), dim3(kBlock), dyn_p, s, cxp, tv, inv_spp, img, dimg, WH * 3,
+                                       st[k & 1], st[(k + 1) & 1], k + 1 < depth ? 1 : 0, h->d_counters, make_rng_jump(o->rng_offset[0] + 2 + 5 * (uint64_t) (k + 1)), tq);
+                    HIP_TRY(hipGetLastError());
+                }
+                continue;
+            }
+        }
         if (binned) {
             // camera stage = primary hit only; the direct step at the primary vertex is bounce stage 0 (binned like the rest):
             // stage k reads stream k & 1 (counter set k) and appends to stream (k + 1) & 1 (set k + 1)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wf_camera<M, FL>), dim3(blocks), dim3(kBlock), lds_bytes(cx, h), s, cx, tv, o->spp, o->spp_begin, nsp, j0, cn,
-                               inv_spp, img, dimg, WH * 3, st[0], 1, h->d_counters, make_rng_jump(o->rng_offset[0] + 2));
+                               inv_spp, img, dimg, WH * 3, st[0], 1, h->d_counters, make_rng_jump(o->rng_offset[0] + 2), tq);
             HIP_TRY(hipGetLastError());
             for (int k = 0; k < depth; ++k) {
                 st[(k + 1) & 1].count = cnt + (size_t) (k + 1) * kWfStageInts;
                 cx.jump = make_rng_jump(o->rng_offset[0] + 2 + 5 * (uint64_t) k);
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wf_bounce<M, FL>), dim3(blocks), dim3(kBlock), lds_bytes(cx, h), s, cx, tv, inv_spp, img, dimg, WH * 3,
-                                   st[k & 1], st[(k + 1) & 1], k + 1 < depth ? 1 : 0, h->d_counters, make_rng_jump(o->rng_offset[0] + 2 + 5 * (uint64_t) (k + 1)));
+                                   st[k & 1], st[(k + 1) & 1], k + 1 < depth ? 1 : 0, h->d_counters, make_rng_jump(o->rng_offset[0] + 2 + 5 * (uint64_t) (k + 1)), tq);
                 HIP_TRY(hipGetLastError());
             }
             continue;
         }
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wf_camera<M, FL>), dim3(blocks), dim3(kBlock), lds_bytes(cx, h), s, cx, tv, o->spp, o->spp_begin, nsp, j0, cn,
-                           inv_spp, img, dimg, WH * 3, st[0], depth > 1 ? 1 : 0, h->d_counters, make_rng_jump(o->rng_offset[0] + 2 + 5));
+                           inv_spp, img, dimg, WH * 3, st[0], depth > 1 ? 1 : 0, h->d_counters, make_rng_jump(o->rng_offset[0] + 2 + 5), tq);
         HIP_TRY(hipGetLastError());
         for (int k = 1; k < depth; ++k) {
             st[k & 1].count = cnt + (size_t) k * kWfStageInts;      // a fresh (zeroed) counter set per stage
             cx.jump = make_rng_jump(o->rng_offset[0] + 2 + 5 * (uint64_t) k);
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wf_bounce<M, FL>), dim3(blocks), dim3(kBlock), lds_bytes(cx, h), s, cx, tv, inv_spp, img, dimg, WH * 3,
-                               st[(k - 1) & 1], st[k & 1], k + 1 < depth ? 1 : 0, h->d_counters, make_rng_jump(o->rng_offset[0] + 2 + 5 * (uint64_t) (k + 1)));
+                               st[(k - 1) & 1], st[k & 1], k + 1 < depth ? 1 : 0, h->d_counters, make_rng_jump(o->rng_offset[0] + 2 + 5 * (uint64_t) (k + 1)), tq);
             HIP_TRY(hipGetLastError());
         }
     }
