@@ -40,6 +40,16 @@ __global__ __launch_bounds__(kBlock) void k_trace(LaunchCtx cx, int m, const flo
 //     keeps a block of 64 requests in registers and hands them out by rank (ds_bpermute), so every node step runs with (nearly) all lanes busy;
 //   * output: hit[dest] = (tri, u, v, t) of the closest TREE hit (tri < 0: none), the same leaf test as every other walk of the library.
 constexpr int kTraceBlock = 1024, kTraceNodeStride = 80, kTraceStackMax = 16;
+#ifndef PSDR_TRACE_SERVICE_MIN
+#define PSDR_TRACE_SERVICE_MIN 16
+#endif
+#ifndef PSDR_TRACE_VOTE_NODE
+#define PSDR_TRACE_VOTE_NODE 1
+#endif
+#ifndef PSDR_TRACE_VOTE_LEAF
+#define PSDR_TRACE_VOTE_LEAF 1
+#endif
+constexpr int kTraceServiceMin = PSDR_TRACE_SERVICE_MIN, kTraceVoteNode = PSDR_TRACE_VOTE_NODE, kTraceVoteLeaf = PSDR_TRACE_VOTE_LEAF;
 struct TraceArgs {
     // boxes first: read through the kernel-argument segment pointer with a run-time index (an index into the by-value struct sends it to scratch)
     float4 blas_lo[kMaxBlas], blas_hi[kMaxBlas];      // hi.w = root of the tree in the 4-wide node array
@@ -86,119 +96,140 @@ __global__ __launch_bounds__(kTraceBlock) void k_wf_trace(TraceArgs a) {
     Vec3f o(0.f), d(0.f), inv(0.f);
     Hit best; best.tri = -1; best.u = best.v = -1.f; best.t = INFINITY;
     uint32_t dest = 0, cand = 0;
-    int32_t cur = kDone;
-    int sp = 0;
+    int32_t cur = kDone;                                           // >= 0: inner node, < 0: leaf, kDone: between trees / finished / idle
+    int sp = 0, li = 0;                                            // li: next triangle of the leaf in `cur`
     float4 ra{0.f, 0.f, 0.f, 0.f}, rb{0.f, 0.f, 0.f, 0.f};        // this lane's request of the wave's current block
     int blk_n = 0, consumed = 0;
+    bool exhausted = false;                                        // wave-uniform: no request left for this wave
+    auto pop = [&]() {
+        if (sp > 0) { --sp; cur = (!OVF || sp < S) ? stack[sp * kTraceBlock] : ovf[(size_t) (sp - S) * a.ovf_stride]; }
+        else cur = kDone;
+    };
+    // VOTE scheduling: every iteration the wave runs ONE step of the phase more of its lanes wait for -- a node step (lanes at an inner node)
+    // or a leaf step (two triangles, lanes at a leaf) -- instead of walking inner nodes until the last lane has reached a leaf
+    // (tools/simd_sim: 1.25x fewer wave steps than while-while on the rays that enter the bunny's box, both with refill); finished rays are
+    // written out and idle lanes refilled when kTraceServiceMin lanes wait for it (or nothing else is left to do).
     for (;;) {
-        // ---- a ray whose walk is over: its hit row
-        if (active && cur == kDone && (!MULTI || cand == 0u)) {
-            a.hit[dest] = float4{__int_as_float(best.tri), best.u, best.v, best.t};
-            active = false;
-        }
-        // ---- refill the idle lanes from the wave's block of requests
-        unsigned long long idle = __ballot(!active);
-        while (idle != 0ull) {
-            if (consumed >= blk_n) {
-                if (next_b >= total) break;
-                int lo = 0, hi = kWfSub - 1;
-                while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_pref[mid + 1] <= next_b) lo = mid + 1; else hi = mid; }
-                const int off = (next_b - s_pref[lo]) * 64;
-                blk_n = min(64, a.count[lo * kWfCountStride] - off);
-                const float4 *r = a.req + 2 * ((size_t) lo * a.sub_cap + off + lane);
-                if (lane < blk_n) { ra = r[0]; rb = r[1]; }
-                consumed = 0; next_b += W;
+        const bool inner = cur >= 0 && cur != kDone, leaf = cur < 0;
+        const bool ended = active && cur == kDone;                  // finished, or between two trees
+        const unsigned long long m_inner = __ballot(inner), m_leaf = __ballot(leaf);
+        const int n_inner = (int) __popcll(m_inner), n_leaf = (int) __popcll(m_leaf);
+        const int n_service = (int) __popcll(__ballot(ended || (!active && !exhausted)));
+        if (n_service >= kTraceServiceMin || (n_inner + n_leaf == 0)) {
+            // ---- a ray whose walk is over: its hit row
+            if (ended && (!MULTI || cand == 0u)) {
+                a.hit[dest] = float4{__int_as_float(best.tri), best.u, best.v, best.t};
+                active = false;
             }
-            const int take = min((int) __popcll(idle), blk_n - consumed);
-            const int rank = (int) __popcll(idle & ((1ull << lane) - 1ull));
-            const int from = (consumed + rank) & 63;
-            const float ox = __shfl(ra.x, from, 64), oy = __shfl(ra.y, from, 64), oz = __shfl(ra.z, from, 64), dw = __shfl(ra.w, from, 64);
-            const float dx = __shfl(rb.x, from, 64), dy = __shfl(rb.y, from, 64), dz = __shfl(rb.z, from, 64);
-            if (!active && rank < take) {
-                o = Vec3f{ox, oy, oz}; d = Vec3f{dx, dy, dz}; inv = Vec3f{1.f / dx, 1.f / dy, 1.f / dz};
-                dest = (uint32_t) __float_as_int(dw);
-                best.tri = -1; best.u = best.v = -1.f; best.t = INFINITY;
-                sp = 0; active = true;
-                if (MULTI) { cur = kDone; cand = (1u << a.n_blas) - 1u; }
-                else { cur = __float_as_int(boxes[kMaxBlas].w); cand = 0u; }
-            }
-            consumed += take;
-            idle = __ballot(!active);
-        }
-        if (__ballot(active) == 0ull) break;
-        // ---- the next tree of a ray between two walks: the nearest box its segment [0, t_best] still enters (wave-uniform loop, boxes in SGPRs)
-        if (MULTI) {
-            const bool need = active && cur == kDone && cand != 0u;
-            if (__ballot(need) != 0ull) {
-                float near_t = INFINITY; int32_t root = kDone; uint32_t pick = 0u;
-                for (int k = 0; k < a.n_blas; ++k) {
-                    const float4 blo = boxes[k], bhi = boxes[kMaxBlas + k];
-                    const float lo3[3] = {blo.x, blo.y, blo.z}, hi3[3] = {bhi.x, bhi.y, bhi.z};
-                    float te;
-                    const bool h = slab(lo3, hi3, o, inv, best.t, te);
-                    const bool c = need && ((cand >> k) & 1u) != 0u;
-                    if (c && !h) cand &= ~(1u << k);
-                    else if (c && te < near_t) { near_t = te; root = __float_as_int(bhi.w); pick = 1u << k; }
+            // ---- refill the idle lanes from the wave's block of requests
+            unsigned long long idle = __ballot(!active);
+            while (idle != 0ull) {
+                if (consumed >= blk_n) {
+                    if (next_b >= total) { exhausted = true; break; }
+                    int lo = 0, hi = kWfSub - 1;
+                    while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_pref[mid + 1] <= next_b) lo = mid + 1; else hi = mid; }
+                    const int off = (next_b - s_pref[lo]) * 64;
+                    blk_n = min(64, a.count[lo * kWfCountStride] - off);
+                    const float4 *r = a.req + 2 * ((size_t) lo * a.sub_cap + off + lane);
+                    if (lane < blk_n) { ra = r[0]; rb = r[1]; }
+                    consumed = 0; next_b += W;
                 }
-                if (need) { cand &= ~pick; cur = pick ? root : kDone; if (!pick) cand = 0u; }
+                const int take = min((int) __popcll(idle), blk_n - consumed);
+                const int rank = (int) __popcll(idle & ((1ull << lane) - 1ull));
+                const int from = (consumed + rank) & 63;
+                const float ox = __shfl(ra.x, from, 64), oy = __shfl(ra.y, from, 64), oz = __shfl(ra.z, from, 64), dw = __shfl(ra.w, from, 64);
+                const float dx = __shfl(rb.x, from, 64), dy = __shfl(rb.y, from, 64), dz = __shfl(rb.z, from, 64);
+                if (!active && rank < take) {
+                    o = Vec3f{ox, oy, oz}; d = Vec3f{dx, dy, dz}; inv = Vec3f{1.f / dx, 1.f / dy, 1.f / dz};
+                    dest = (uint32_t) __float_as_int(dw);
+                    best.tri = -1; best.u = best.v = -1.f; best.t = INFINITY;
+                    sp = 0; li = 0; active = true;
+                    if (MULTI) { cur = kDone; cand = (1u << a.n_blas) - 1u; }
+                    else { cur = __float_as_int(boxes[kMaxBlas].w); cand = 0u; }
+                }
+                consumed += take;
+                idle = __ballot(!active);
             }
-        }
-        // ---- inner nodes until every lane holds a leaf (or is done)
-        while (cur >= 0 && cur != kDone) {
-            Bvh4Node n;
-            if (cur < a.n_lnodes) n = *reinterpret_cast<const Bvh4Node *>(psdr_dyn_lds + cur * kTraceNodeStride);
-            else n = a.nodes4[cur];
-            const float ax = __int_as_float((int) ((n.exps & 0xffu) << 23)) * inv.x, ay = __int_as_float((int) (((n.exps >> 8) & 0xffu) << 23)) * inv.y,
-                        az = __int_as_float((int) (((n.exps >> 16) & 0xffu) << 23)) * inv.z;
-            const float bx = (n.org[0] - o.x) * inv.x, by = (n.org[1] - o.y) * inv.y, bz = (n.org[2] - o.z) * inv.z;
-            const bool px = inv.x >= 0.f, py = inv.y >= 0.f, pz = inv.z >= 0.f;
-            const uint32_t nx = px ? n.qlo[0] : n.qhi[0], fx = px ? n.qhi[0] : n.qlo[0];
-            const uint32_t ny = py ? n.qlo[1] : n.qhi[1], fy = py ? n.qhi[1] : n.qlo[1];
-            const uint32_t nz = pz ? n.qlo[2] : n.qhi[2], fz = pz ? n.qhi[2] : n.qlo[2];
-            uint32_t key[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float tnx = (float) ((nx >> (8 * c)) & 0xffu) * ax + bx, tfx = (float) ((fx >> (8 * c)) & 0xffu) * ax + bx;
-                const float tny = (float) ((ny >> (8 * c)) & 0xffu) * ay + by, tfy = (float) ((fy >> (8 * c)) & 0xffu) * ay + by;
-                const float tnz = (float) ((nz >> (8 * c)) & 0xffu) * az + bz, tfz = (float) ((fz >> (8 * c)) & 0xffu) * az + bz;
-                const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.f));
-                const float tf = fminf(fminf(tfx, tfy), fminf(tfz, best.t));
-                const bool hit = tn <= tf && n.child[c] != kNoChild;
-                // tn >= 0: its bit pattern orders like the value; the two low mantissa bits carry the slot (the nearest child is visited first,
-                // the others are pushed in slot order: a full sort saves 1.5 % of the node visits, tools/walk_stats, and costs 25 instructions)
-                key[c] = hit ? (((uint32_t) __float_as_int(tn) & ~3u) | (uint32_t) c) : 0xffffffffu;
-            }
-            const uint32_t kmin = min(min(key[0], key[1]), min(key[2], key[3]));
-            const int slot = (int) (kmin & 3u);
-            if (OVF && __ballot(sp + 3 > S) != 0ull) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    if (key[c] != 0xffffffffu && c != slot) {
-                        if (sp < S) stack[sp * kTraceBlock] = n.child[c]; else ovf[(size_t) (sp - S) * a.ovf_stride] = n.child[c];
-                        ++sp;
+            if (__ballot(active) == 0ull) break;
+            // ---- the next tree of a ray between two walks: the nearest box its segment [0, t_best] still enters (wave-uniform loop, boxes in SGPRs)
+            if (MULTI) {
+                const bool need = active && cur == kDone && cand != 0u;
+                if (__ballot(need) != 0ull) {
+                    float near_t = INFINITY; int32_t root = kDone; uint32_t pick = 0u;
+                    for (int k = 0; k < a.n_blas; ++k) {
+                        const float4 blo = boxes[k], bhi = boxes[kMaxBlas + k];
+                        const float lo3[3] = {blo.x, blo.y, blo.z}, hi3[3] = {bhi.x, bhi.y, bhi.z};
+                        float te;
+                        const bool h = slab(lo3, hi3, o, inv, best.t, te);
+                        const bool c = need && ((cand >> k) & 1u) != 0u;
+                        if (c && !h) cand &= ~(1u << k);
+                        else if (c && te < near_t) { near_t = te; root = __float_as_int(bhi.w); pick = 1u << k; }
                     }
-            } else {
-                // room for three more everywhere in the wave: unconditional stores, the stack pointer moves where the child counts
-#pragma unroll
-                for (int c = 0; c < 4; ++c) { stack[sp * kTraceBlock] = n.child[c]; sp += (key[c] != 0xffffffffu && c != slot) ? 1 : 0; }
+                    if (need) { cand &= ~pick; cur = pick ? root : kDone; li = 0; if (!pick) cand = 0u; }
+                }
             }
-            if (kmin != 0xffffffffu) cur = slot == 0 ? n.child[0] : slot == 1 ? n.child[1] : slot == 2 ? n.child[2] : n.child[3];
-            else if (sp > 0) { --sp; cur = (!OVF || sp < S) ? stack[sp * kTraceBlock] : ovf[(size_t) (sp - S) * a.ovf_stride]; }
-            else cur = kDone;
+            continue;
         }
-        // ---- the leaf triangles, two at a time (six loads in flight)
-        if (cur != kDone) {
-            const int enc = ~cur, first = enc >> 3, cnt = (enc & 7) + 1;
-            const float4 *bt = a.btris + (size_t) first * 3;
-            for (int i = 0; i < cnt; i += 2) {
-                const int j = i + 1 < cnt ? i + 1 : i;
-                const float4 a0 = bt[i * 3], b0 = bt[i * 3 + 1], c0 = bt[i * 3 + 2];
-                const float4 a1 = bt[j * 3], b1 = bt[j * 3 + 1], c1 = bt[j * 3 + 2];
+        if (n_inner * kTraceVoteNode >= n_leaf * kTraceVoteLeaf) {
+            // ---- one node step of the lanes at an inner node
+            if (inner) {
+                Bvh4Node n;
+                if (cur < a.n_lnodes) n = *reinterpret_cast<const Bvh4Node *>(psdr_dyn_lds + __umul24((uint32_t) cur, (uint32_t) kTraceNodeStride));
+                else n = a.nodes4[cur];
+                const float ax = __int_as_float((int) ((n.exps & 0xffu) << 23)) * inv.x, ay = __int_as_float((int) (((n.exps >> 8) & 0xffu) << 23)) * inv.y,
+                            az = __int_as_float((int) (((n.exps >> 16) & 0xffu) << 23)) * inv.z;
+                const float bx = (n.org[0] - o.x) * inv.x, by = (n.org[1] - o.y) * inv.y, bz = (n.org[2] - o.z) * inv.z;
+                const bool px = inv.x >= 0.f, py = inv.y >= 0.f, pz = inv.z >= 0.f;
+                const uint32_t nx = px ? n.qlo[0] : n.qhi[0], fx = px ? n.qhi[0] : n.qlo[0];
+                const uint32_t ny = py ? n.qlo[1] : n.qhi[1], fy = py ? n.qhi[1] : n.qlo[1];
+                const uint32_t nz = pz ? n.qlo[2] : n.qhi[2], fz = pz ? n.qhi[2] : n.qlo[2];
+                uint32_t key[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float tnx = (float) ((nx >> (8 * c)) & 0xffu) * ax + bx, tfx = (float) ((fx >> (8 * c)) & 0xffu) * ax + bx;
+                    const float tny = (float) ((ny >> (8 * c)) & 0xffu) * ay + by, tfy = (float) ((fy >> (8 * c)) & 0xffu) * ay + by;
+                    const float tnz = (float) ((nz >> (8 * c)) & 0xffu) * az + bz, tfz = (float) ((fz >> (8 * c)) & 0xffu) * az + bz;
+                    const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.f));
+                    const float tf = fminf(fminf(tfx, tfy), fminf(tfz, best.t));
+                    // tn >= 0: its bit pattern orders like the value; the two low mantissa bits carry the slot (the nearest child is visited first,
+                    // the others are pushed in slot order: a full sort saves 1.5 % of the node visits, tools/walk_stats, and costs 25 instructions)
+                    const uint32_t k = ((uint32_t) __float_as_int(tn) & ~3u) | (uint32_t) c;
+                    const bool hit = (tn <= tf) & (n.child[c] != kNoChild);
+                    key[c] = hit ? k : 0xffffffffu;
+                }
+                const uint32_t kmin = min(min(key[0], key[1]), min(key[2], key[3]));
+                const int slot = (int) (kmin & 3u);
+                if (OVF && __ballot(sp + 3 > S) != 0ull) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (key[c] != 0xffffffffu && c != slot) {
+                            if (sp < S) stack[sp * kTraceBlock] = n.child[c]; else ovf[(size_t) (sp - S) * a.ovf_stride] = n.child[c];
+                            ++sp;
+                        }
+                } else {
+                    // room for three more everywhere in the wave: unconditional stores, the stack pointer moves where the child counts
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { stack[sp * kTraceBlock] = n.child[c]; sp += (key[c] != 0xffffffffu && c != slot) ? 1 : 0; }
+                }
+                const int32_t c01 = (slot & 1) ? n.child[1] : n.child[0], c23 = (slot & 1) ? n.child[3] : n.child[2];
+                if (kmin != 0xffffffffu) cur = (slot & 2) ? c23 : c01;
+                else pop();
+                li = 0;
+            }
+        } else {
+            // ---- one leaf step of the lanes at a leaf: two triangles (six loads in flight; an odd end tests its last triangle twice -- the second test
+            // fails t < t_best)
+            if (leaf) {
+                const int enc = ~cur, first = enc >> 3, cnt = (enc & 7) + 1;
+                const int j = li + 1 < cnt ? li + 1 : li;
+                const float4 *bt = a.btris + (size_t) (first + li) * 3, *bu = a.btris + (size_t) (first + j) * 3;
+                const float4 a0 = bt[0], b0 = bt[1], c0 = bt[2];
+                const float4 a1 = bu[0], b1 = bu[1], c1 = bu[2];
                 leaf_triangle_test<false>(a0, b0, c0, o, d, best);
                 leaf_triangle_test<false>(a1, b1, c1, o, d, best);
+                li += 2;
+                if (li >= cnt) { pop(); li = 0; }
             }
-            if (sp > 0) { --sp; cur = (!OVF || sp < S) ? stack[sp * kTraceBlock] : ovf[(size_t) (sp - S) * a.ovf_stride]; }
-            else cur = kDone;
         }
     }
 #else
@@ -500,14 +531,19 @@ int check_counts(const psdr_scene_s *h, const psdr_render_opts *o) {
 bool open_scene(const psdr_scene_s *h) { return !(h->n_blas > 0 || (h->n_tiny > 0 && h->n_blas == 0)); }
 bool use_wavefront(const psdr_scene_s *h, const psdr_render_opts *o) {
     if (o->integrator != PSDR_INTEGRATOR_PATH || o->max_depth > 250) return false;
+    if (h->desc.num_tris >= (1 << 29)) return false;                // a stream record keeps its triangle in 29 bits (psdr_kernels.h kWfTriMask)
     if (o->flags & PSDR_FLAG_FUSED) return false;
     if (o->flags & PSDR_FLAG_WAVEFRONT) return true;
     if (o->max_depth < 2) return false;
     if (open_scene(h)) return true;                                 // most paths die early, compaction pays
-    // closed two-level scene (a room with objects), large launch: the class-binned wavefront (psdr_kernels.h) is ahead of
-    // the fused kernel -- C4 shard (67 M slots) 27.5 against 29.6 ms; at 4 M slots its extra launches and stream traffic
-    // cost more than they save (3.7 against 2.9 ms)
     const long long n = (long long) h->desc.width * h->desc.height * (o->spp_end - o->spp_begin);
+    // two-level scene (a room with objects): the TRACED wavefront -- in the fused kernel a wave pays the slowest lane's tree walk at every
+    // closest_hit although only a fifth of the rays enter a tree; with the walks in the dense trace kernel between the stages C4's shard takes
+    // 18.2 ms against 25.8 fused (21.8 class-binned), the 50 k-triangle interior 2.8 against 4.6, cbox_bunny at 4 M slots 1.6 against 2.1
+    // (profiles/r04_traced_first.txt); below 2^16 slots the seven launches cost more than the walks
+    if (traced_wavefront(h)) return n >= (1ll << 16);
+    // without the trace kernel (PSDR_WF_TRACED=0): the class-binned streams (psdr_kernels.h) are ahead of the fused kernel on large launches only --
+    // C4 shard (67 M slots) 27.5 against 29.6 ms; at 4 M slots their extra launches and stream traffic cost more than they save (3.7 against 2.9 ms)
     return h->n_blas > 0 && h->wf_binned && n >= (1ll << 25);
 }
 

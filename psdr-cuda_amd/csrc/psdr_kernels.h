@@ -378,6 +378,9 @@ __device__ __forceinline__ void splat_runs(int pixel, bool valid, const Vec3<M> 
 #ifndef PSDR_WF_WAVES
 #define PSDR_WF_WAVES 4
 #endif
+#ifndef PSDR_WF_WAVES_T
+#define PSDR_WF_WAVES_T 4          // bounce stages of the traced wavefront (no tree walk in the kernel)
+#endif
 // TRACED (two-level scenes, run_camera_wavefront): the stage stops at the primary hit like the binned one, the records go to plain sub-streams and the
 // two rays of bounce stage 0 that enter a tree box become requests of the dense trace kernel (stream_push_traced).
 template <class M, int FL, bool TRACED = false>
@@ -465,12 +468,11 @@ __device__ __forceinline__ void wf_bounce_record(const LaunchCtx &cx, const TV<M
         if constexpr (TRACED) {
             // the tree hits of this vertex' two rays, traced since the record was pushed (none where its class bit is clear: the ray enters no box)
             const int cls = (tri_word >> kWfClsShift) & 3;
-            tri_word &= kWfTriMask;
             st.pre[kPreBsdfRay].tri = st.pre[kPreLightRay].tri = -1;
             if (cls & 1) { const float4 h = in.hit[2 * j]; st.pre[kPreBsdfRay] = Hit{__float_as_int(h.x), h.y, h.z, h.w}; }
             if (cls & 2) { const float4 h = in.hit[2 * j + 1]; st.pre[kPreLightRay] = Hit{__float_as_int(h.x), h.y, h.z, h.w}; }
         }
-        const Its<float> its = path_vertex_from_record(cx.sc, tv, tri_word, in.hu[j], in.hv[j], din);
+        const Its<float> its = path_vertex_from_record(cx.sc, tv, tri_word & kWfTriMask, in.hu[j], in.hv[j], din);
         if constexpr (TRACED) {
             TV<M, FL | kScenePre> tvp;
 #pragma unroll
@@ -504,7 +506,7 @@ __device__ __forceinline__ void wf_bounce_record(const LaunchCtx &cx, const TV<M
 // Binned streams: the 64 sub-streams form one list of 256-record chunks (expensive classes first) that the workgroups
 // grab kWfGrab at a time from one counter.
 template <class M, int FL, bool TRACED = false>
-__global__ __launch_bounds__(kBlock, (is_ad<M>() ? 2 : PSDR_WF_WAVES)) void k_wf_bounce(LaunchCtx cx, TV<M, FL> tv, float inv_spp, float *__restrict__ img,
+__global__ __launch_bounds__(kBlock, (is_ad<M>() ? 2 : (TRACED ? PSDR_WF_WAVES_T : PSDR_WF_WAVES))) void k_wf_bounce(LaunchCtx cx, TV<M, FL> tv, float inv_spp, float *__restrict__ img,
                                                         float *__restrict__ dimg, long long plane, PathStream in,
                                                         PathStream out, int want_next, unsigned long long *counters, RngJump jump_next, TraceQueue tq) {
     TraversalStack st; setup_lds(cx, st, tv);

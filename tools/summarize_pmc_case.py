@@ -41,4 +41,5 @@ for k, c in cnt.items():
           "WAIT_ANY %.3f WAIT_INST_ANY %.3f ACTIVE_VALU %.3f of wave cycles | L2 hit %.3f | HBM %.4g B/call = %.1f GB/s (%.4f of 8 TB/s)"
           % (short, nl[k] / calls, ns / 1e6, valu, valu / (ns * 1e-9) / 1228.8e9 if ns else 0, g("SQ_INSTS_SALU"), g("SQ_INSTS_LDS"), g("SQ_INSTS_SMEM"), g("SQ_INSTS_VMEM_RD"),
              g("SQ_INSTS_VMEM_WR"), g("SQ_WAIT_ANY") / wc, g("SQ_WAIT_INST_ANY") / wc, g("SQ_ACTIVE_INST_VALU") / wc, hit / (hit + miss), hbm,
-             hbm / (ns * 1e-9) / 1e9 if ns else 0, hbm / (ns * 1e-9) / 8e12 if ns else 0))
+             hbm / (ns * 1e-9) / 1e9 if ns else 0, hbm / (ns * 1e-9) / 8e12 if ns else 0)
+          + (" | LDS_IDX_ACTIVE %.3g BANK_CONFLICT %.3g cycles/call, busy cycles %.4g" % (g("SQ_LDS_IDX_ACTIVE"), g("SQ_LDS_BANK_CONFLICT"), g("SQ_BUSY_CYCLES")) if "SQ_LDS_IDX_ACTIVE" in c else ""))
