@@ -45,7 +45,7 @@ N_SIMD, CLOCK_HZ, HBM_BPS = 1024, 2.4e9, 8.0e12
 VALU_PEAK_WAVE_INSTS_PER_S = N_SIMD * CLOCK_HZ / 2.0          # 1.2288e12 wave-instructions / s
 # VALU lane-instructions one primitive test costs (Moeller-Trumbore with SGPR operands, csrc/psdr_device.h tiny_prim_test) and
 # the rest of a traced ray's share of its path vertex (hit reconstruction, sampling, shading): DESIGN.md section 3
-FLOOR_VALU_PER_PRIM_TEST, FLOOR_VALU_PER_RAY_REST = 17, 150          # plane-form primitive test (round 3): 17 VALU with the rows in SGPRs
+FLOOR_VALU_PER_PRIM_TEST, FLOOR_VALU_PER_RAY_REST = 31, 150          # plane-form primitive test as the ISA issues it: 20 arithmetic + 6 compare + 5 select
 # What a SIMD actually sustains (tools/micro/valu_rate.hip on MI355X, 8 waves per SIMD, clocks measured at 2.3-2.4 GHz;
 # profiles/r03_valu_rate.txt): wave64 VALU instructions per cycle per SIMD -- no stream reaches the 0.5 of the 2-cycle issue model
 MEASURED_VALU_PER_CYCLE = {"v_xor_b32 / v_mov_b32 (two operands)": 0.42, "v_fma_f32, dependent chain": 0.40, "v_fma_f32, 16 independent (three VGPR sources)": 0.265}
@@ -67,6 +67,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-tree-scenes", action="store_true", help="skip the tree_scenes block (BASELINE configs 3-5 at one GPU's share)")
+    ap.add_argument("--tree-child", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
@@ -273,6 +275,134 @@ def pmc_passes_c4(args, res, spp):
     return out or None
 
 
+# ---------------------------------------------------------------------------------------------------------------- tree scenes
+# BASELINE configs 3-5 (the scenes WITH a tree) at one GPU's share, through the same C-ABI entry points as the headline's kernel_only block:
+#   c4_shard_path3_renderC      cbox_bunny 1024^2, 64 of the 512 spp (one of eight GPUs), PathTracer(3) renderC
+#   c4_shard_direct_rev3        the same shard, DirectIntegrator(1,1) renderD + backward with all three terms (spp = sppe = sppse share), triangle rows + texels
+#   c5_path3_renderC            50 k-triangle interior with rough conductors, 512^2 spp 16, PathTracer(3) renderC
+#   c3_direct_fwd3              cbox_bunny 512^2 spp = sppe = sppse = 16, renderD forward (K = 1: a translation of the bunny), three terms
+class TreeScenes:
+    def __init__(self):
+        import psdr_cuda
+        from psdr_cuda import _abi
+        from psdr_cuda.fixtures import make_interior_scene, scene_path
+        self._abi = _abi
+        self.integ = psdr_cuda.DirectIntegrator(1, 1)          # only its native plumbing is used: the options below name the integrator
+        self.cases = []
+
+        def bunny(res, spp, sppe, sppse):
+            sc = psdr_cuda.Scene()
+            sc.load_file(scene_path("cbox_bunny"), False)
+            sc.opts.width = sc.opts.height = res
+            sc.opts.spp, sc.opts.sppe, sc.opts.sppse, sc.opts.log_level = spp, sppe, sppse, 0
+            sc.configure()
+            return sc
+        sc4 = bunny(1024, 512, 512, 512)
+        tb4 = sc4.tables(0)
+        n4 = 1024 * 1024 * 64
+        o = _abi.make_opts(integrator=_abi.INTEGRATOR_PATH, max_depth=3, spp=512, spp_range=(0, 64))
+        self.cases.append(("c4_shard_path3_renderC", n4, lambda sc=sc4, tb=tb4, o=o: self.integ._render_c(sc, tb, o, None), sc4))
+        od = _abi.make_opts(spp=512, sppe=512, sppse=512, spp_range=(0, 64), sppe_range=(0, 64), sppse_range=(0, 64))
+        adj4 = torch.ones(1024 * 1024 * 3, device="cuda")
+        tb4g = dict(tb4)
+        for k in ("tri_info", "texels", "prim_edge", "sec_edge"):
+            if tb4g.get(k) is not None:
+                tb4g[k] = tb4g[k].detach().requires_grad_(True)
+        self.cases.append(("c4_shard_direct_rev3", 3 * n4, lambda sc=sc4, tb=tb4g, o=od, a=adj4: self.integ._render_rev(sc, tb, o, None, a), sc4))
+        sc5 = make_interior_scene(seed=0, n_objects=10, res=512, spp=16)
+        sc5.configure()
+        tb5 = sc5.tables(0)
+        o5 = _abi.make_opts(integrator=_abi.INTEGRATOR_PATH, max_depth=3, spp=16)
+        self.cases.append(("c5_path3_renderC", 512 * 512 * 16, lambda sc=sc5, tb=tb5, o=o5: self.integ._render_c(sc, tb, o, None), sc5))
+        # C3: forward mode, the tangent tables of a unit translation of the bunny along x (every table row that moves with the mesh)
+        sc3 = bunny(512, 16, 16, 16)
+        tb3 = sc3.tables(0)
+        o3 = _abi.make_opts(spp=16, sppe=16, sppse=16)
+        tan3 = self._translation_tangents(sc3, tb3)
+        tb3 = sc3.tables(0)                                     # the tables of the configure() that carries P (same values)
+        self.cases.append(("c3_direct_fwd3", 3 * 512 * 512 * 16, lambda sc=sc3, tb=tb3, o=o3, t=tan3: self.integ._render_fwd(sc, tb, o, None, [t]), sc3))
+
+    def _translation_tangents(self, sc, tb):
+        """d table / d P for Mesh[1] (the bunny) translated by P along x: JVP of the table chain through a second configure."""
+        import enoki as ek
+        from enoki.cuda_autodiff import Float32 as FloatD, Vector3f as Vector3fD, Matrix4f as Matrix4fD
+        P = FloatD(0.)
+        ek.set_requires_gradient(P)
+        sc.param_map["Mesh[1]"].set_transform(Matrix4fD.translate(Vector3fD([1.0, 0.0, 0.0]) * P))
+        sc.configure()
+        tbd = sc.tables(0)
+        from enoki._array import _jvp_wrt
+        from psdr_cuda import _abi
+        return [None if t is None else t.detach() for t in _jvp_wrt([tbd.get(k) for k in _abi.TANGENT_FIELDS], P.t)]
+
+    def run(self, name, fn, scene):
+        fn(); torch.cuda.synchronize()
+        ms = []
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+            ms.append(e0.elapsed_time(e1))
+        return sorted(ms)[1], int(self.integ.last_counters[0])
+
+
+def tree_child():
+    """--tree-child (under rocprofv3 --pmc SQ_INSTS_VALU --kernel-trace): every workload once, a spin kernel between them as a separator."""
+    ts = TreeScenes()
+    for name, slots, fn, sc in ts.cases:
+        fn(); torch.cuda.synchronize()
+    torch.cuda._sleep(1000); torch.cuda.synchronize()
+    for name, slots, fn, sc in ts.cases:
+        fn(); torch.cuda.synchronize()
+        torch.cuda._sleep(1000); torch.cuda.synchronize()
+
+
+def tree_scenes(args):
+    ts = TreeScenes()
+    out = {}
+    for name, slots, fn, sc in ts.cases:
+        ms, rays = ts.run(name, fn, sc)
+        out[name] = {"ms": round(ms, 3), "slots": slots, "rays": rays, "Grays_per_s": round(rays / ms / 1e6, 2), "Mslots_per_s": round(slots / ms / 1e3, 1)}
+    exe = shutil.which("rocprofv3")
+    if exe and not args.no_pmc:
+        tmp = tempfile.mkdtemp(prefix="psdr_tree_", dir="/tmp")
+        try:
+            cmd = [exe, "--pmc", "SQ_INSTS_VALU", "--kernel-trace", "--output-format", "csv", "-d", tmp, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--tree-child"]
+            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300, check=True)
+            disp = {}
+            for f in glob.glob(os.path.join(tmp, "**", "*kernel_trace.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    disp[r["Dispatch_Id"]] = [r["Kernel_Name"], int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), 0.0]
+            for f in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if r.get("Counter_Name") == "SQ_INSTS_VALU" and r["Dispatch_Id"] in disp:
+                        disp[r["Dispatch_Id"]][3] += float(r["Counter_Value"])
+            rows = sorted(disp.values(), key=lambda x: x[1])
+            seg, segs = [], []
+            for r in rows:
+                if "spin_kernel" in r[0]:
+                    segs.append(seg); seg = []
+                else:
+                    seg.append(r)
+            segs = segs[1:]                                     # [0] = the warm-up calls in front of the first separator
+            for (name, _, _, _), sg in zip(ts.cases, segs):
+                agg = {}
+                for kn, _, d, v in sg:
+                    if "k_" in kn and "at::native" not in kn and "rocprim" not in kn:
+                        a = agg.setdefault(kn, [0.0, 0.0, 0]); a[0] += d; a[1] += v; a[2] += 1
+                if agg:
+                    kn, (d, v, c) = max(agg.items(), key=lambda kv: kv[1][0])
+                    short = kn.replace("void (anonymous namespace)::", "").split("(")[0]
+                    out[name]["dominant_kernel"] = {"name": short, "launches": c, "ms_under_profiler": round(d / 1e6, 3), "valu_wave_insts": v,
+                                                    "valu_issue_frac": round(v / (d * 1e-9) / VALU_PEAK_WAVE_INSTS_PER_S, 4) if d else None}
+        except Exception as e:
+            out["pmc_error"] = repr(e)
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    out["note"] = ("C-ABI launches on ONE GPU, median of 3 (HIP events); Grays_per_s = rays traced / time; dominant_kernel = the kernel with the largest summed duration of "
+                   "the workload, its SQ_INSTS_VALU over its duration against 1228.8 G wave-instructions/s (rocprofv3 --pmc pass of this script)")
+    return out
+
+
 def relaunch_under_torchrun(args):
     """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run, one process per GPU (what the driver's own
     command line does for N > 1).  PSDR_BENCH_ONE_GPU=1 (developer switch) lets the N ranks share cuda:0 over gloo."""
@@ -321,8 +451,11 @@ def run_c4(args, world, rank, local_rank, dist, devices, rccl):
     sc = psdr_cuda.Scene()
     sc.load_file(scene_path("cbox_bunny"), False)
     sc.opts.width = sc.opts.height = res
-    sc.opts.spp, sc.opts.sppe, sc.opts.sppse, sc.opts.log_level = spp, 0, 0, 0
+    # geometry gradients with all three terms (interior + primary-edge + secondary-edge boundary integrals) come from the DirectIntegrator, the
+    # reference's own configuration for them (the PathTracer has no secondary-edge term); renderC is the PathTracer
+    sc.opts.spp, sc.opts.sppe, sc.opts.sppse, sc.opts.log_level = spp, spp, spp, 0
     integ = psdr_cuda.PathTracer(max_depth=args.max_depth)
+    integ_d = psdr_cuda.DirectIntegrator(1, 1)
     refl = sc.param_map["BSDF[0]"].reflectance
     base = ek.detach(refl.data)
     mesh = sc.param_map["Mesh[1]"]                      # the bunny (cbox_bunny.xml)
@@ -338,7 +471,7 @@ def run_c4(args, world, rank, local_rank, dist, devices, rccl):
         r = Vector3fD(base); ek.set_requires_gradient(r); refl.data = r
         v = Vector3fD(v0); ek.set_requires_gradient(v); mesh.vertex_positions = v
         sc.configure()
-        imgD = integ.renderD(sc)
+        imgD = integ_d.renderD(sc)
         ek.backward(FloatD._wrap(imgD.t.sum().reshape(1)))
         return img, ek.gradient(v), ek.gradient(r)
 
@@ -373,11 +506,12 @@ def run_c4(args, world, rank, local_rank, dist, devices, rccl):
             "value": round(value, 3), "unit": "Mpath-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "cbox_bunny %dx%d GLOBAL spp=%d (%d per GPU) PathTracer(max_depth=%d): renderC + configure + renderD + enoki.backward "
-                                   "w.r.t. the bunny's vertex positions and the albedo texels, through the psdr_cuda surface"
+            "config": {"workload": "cbox_bunny %dx%d GLOBAL spp = sppe = sppse = %d (%d per GPU): PathTracer(max_depth=%d).renderC + configure + DirectIntegrator(1,1).renderD "
+                                   "(interior + primary-edge + secondary-edge terms) + enoki.backward w.r.t. the bunny's vertex positions and the albedo texels, through the psdr_cuda surface"
                                    % (res, res, spp, spp // world, args.max_depth),
                        "triangles": T, "global_spp": spp, "world_size": world, "devices": devices, "rccl_version": rccl,
-                       "allreduce_bytes_per_step": 0 if world == 1 else int(2 * res * res * 3 * 4 + grad_words * 4),
+                       "collectives_forced": bool(dist is not None and world == 1),
+                       "allreduce_bytes_per_step": 0 if (world == 1 and dist is None) else int(2 * res * res * 3 * 4 + grad_words * 4),
                        "parallelism": "spp-shard x%d; all-reduces per step: [image] (renderC), [image] (renderD primal), [triangle-row || texel gradients]" % world},
             "grad_check": {"finite": bool(np.isfinite(gv).all()), "abs_max_vertex_grad": float(np.abs(gv).max())},
             "wavefront_traffic": None if wf is None else {"workload": "renderC of one rank's share of the 8-GPU job (%d spp), two calls" % max(spp // 8, 1), "kernels": wf,
@@ -387,6 +521,12 @@ def run_c4(args, world, rank, local_rank, dist, devices, rccl):
 
 def main():
     args = parse()
+    if args.tree_child:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU")
+        torch.cuda.set_device(0)
+        tree_child()
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.pmc_child:
         relaunch_under_torchrun(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -401,12 +541,22 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
+    # PSDR_FORCE_COLLECTIVES=1 (developer switch): a one-rank job builds its nccl (= RCCL) process group as well and every collective of the
+    # render calls EXECUTES (psdr_cuda/integrator.py _dist) -- the RCCL path on a one-GPU box (tests/test_rccl_single_rank_gpu.py)
+    forced = world == 1 and os.environ.get("PSDR_FORCE_COLLECTIVES") == "1" and not args.pmc_child
     if world > 1:
         import torch.distributed as dist
         if one_gpu:
             dist.init_process_group(backend="gloo")
         else:
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    elif forced:
+        import socket
+        import torch.distributed as dist
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
 
     devices, rccl = rank_devices(dist, local_rank)
     if args.config == "c4":
@@ -573,6 +723,12 @@ def main():
                 "check": "d image / d albedo(r,g,b), %s %dx%d spp=%d PathTracer(max_depth=%d), HIP vs CPU oracle on the same sample streams; rel_l2 = against "
                          "fp64 in the reference's literal forms" % (args.scene, gres, gres, gspp, args.max_depth)}
 
+    trees = None
+    if rank == 0 and world == 1 and not args.no_tree_scenes:
+        try:
+            trees = tree_scenes(args)
+        except Exception as e:                                  # reported as missing, never as a number
+            trees = {"error": repr(e)}
     if rank == 0:
         out = {
             "metric": "Mpath-samples/s renderC+renderD, cbox 512x512 spp=64; grad rel-L2 vs ref",
@@ -586,7 +742,7 @@ def main():
                        "allreduce_bytes_per_step": 0 if world == 1 else int(args.res * args.res * 3 * 4 * 3),
                        "parallelism": "spp-shard x%d, one all-reduce per render call ([image] for renderC, [image || derivative image] for renderD)" % world},
             "surface": surface, "kernel_only": kernel_only,
-            "roofline": roofline, "cpu_baseline": cpu, "grad_rel_l2": grad,
+            "roofline": roofline, "cpu_baseline": cpu, "grad_rel_l2": grad, "tree_scenes": trees,
         }
         print(json.dumps(out))
     if dist:

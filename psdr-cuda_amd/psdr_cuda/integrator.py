@@ -23,8 +23,11 @@ _AD_KEYS = _abi.TANGENT_FIELDS
 
 
 def _dist():
+    """torch.distributed when the job has more than one rank.  PSDR_FORCE_COLLECTIVES=1 returns it at world size 1 too: every collective of a
+    render call then EXECUTES (over RCCL when the group's backend is nccl) on a one-GPU box -- tests/test_rccl_single_rank_gpu.py."""
+    import os
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("PSDR_FORCE_COLLECTIVES") == "1"):
         return dist
     return None
 
