@@ -123,6 +123,7 @@ def oracle_projections(case, ntan=None, precision=1, verbose=True, reference_for
             holder["v"] = tangent_fields(V0, ntan)[i].to(V0.device)
             return V0 + holder["v"] * P
         sc, tb, V0 = build_scene(case, "cpu", param)
+        n_edges = int(tb["num_sec_edges"])
         tan = dict(zip(AD_KEYS, _jvp_wrt([tb.get(k) for k in AD_KEYS], P)))
         t0 = time.time()
         img, dimg = oracle.render(tb, o, mode=1, tangents=tan, precision=precision, reference_form=reference_form)
@@ -131,15 +132,17 @@ def oracle_projections(case, ntan=None, precision=1, verbose=True, reference_for
         scale.append(float(np.abs(adj * d).sum()))
         if verbose:
             print("%s tangent %2d: <A, dI> = %+.9e   sum|A dI| = %.3e   (%.1f s)" % (case, i, out[-1], scale[-1], time.time() - t0), flush=True)
-    return np.array(out), np.array(scale), float(img.astype(np.float64).mean())
+    return np.array(out), np.array(scale), float(img.astype(np.float64).mean()), n_edges
 
 
 def main():
     for case in sys.argv[1:] or list(CASES):
-        b, s, mean = oracle_projections(case)
+        b, s, mean, n_edges = oracle_projections(case)
         c = CASES[case]
+        # num_sec_edges: the secondary-edge list the sample streams follow (the native table chain decides every borderline coplanar edge
+        # deterministically; the test asserts that its tables hold the same list)
         np.savez(os.path.join(GOLD, "proj_%s.npz" % case), b=b, scale=s, image_mean=mean, ntan=len(b), res=c["res"], spp=c["spp"],
-                 sppe=c["sppe"], sppse=c["sppse"])
+                 sppe=c["sppe"], sppse=c["sppse"], num_sec_edges=n_edges)
         print("wrote proj_%s.npz" % case)
 
 
