@@ -30,12 +30,17 @@ __device__ __forceinline__ float wave_total(float v) {
     v = dpp_add<0x142, 0xa>(v); v = dpp_add<0x143, 0xc>(v);
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
-template <int N, bool DPP = (N <= 6)> __device__ __forceinline__ bool wave_segmented_sum(int key, float (&v)[N]) {
+#ifndef PSDR_DPP_ALWAYS
+#define PSDR_DPP_ALWAYS 0                   // test builds (variants/): the DPP totals in every instance
+#endif
+template <int N, bool DPP = (N <= 6 || PSDR_DPP_ALWAYS)> __device__ __forceinline__ bool wave_segmented_sum(int key, float (&v)[N]) {
     const int lane = threadIdx.x & 63;
     // the common case of the camera kernels: spp is a multiple of 64 and the whole wave sits on ONE pixel -- six DPP adds per value instead of six
     // ds_bpermute round trips (each an LDS instruction + its address arithmetic + the wait)
-    // (DPP: by default only for few values -- the K = 3 dual kernels spill hundreds of registers, and a DPP sequence in a heavily spilled kernel once
-    // returned stale registers, DESIGN.md round 3 -- or where the caller knows its kernel: the diffuse adjoint instances)
+    // (DPP by default only for few values: a PERFORMANCE choice -- the K = 3 dual kernels spill hundreds of registers and gain nothing from 12 more
+    // live values at the splat.  Round 3 read a wrong gradient of a build with more DPP totals as "DPP returns stale registers in a spilled kernel";
+    // round 4 found the cause elsewhere: a spill-placement defect of the compiler that any change of register pressure can expose -- DESIGN.md
+    // "the order-dependent gradient", guarded at build time by tools/check_spill_exec.py, not by this flag)
     if (DPP && __ballot(key != __builtin_amdgcn_readfirstlane(key)) == 0ull) {
 #pragma unroll
         for (int i = 0; i < N; ++i) v[i] = wave_total(v[i]);
@@ -57,7 +62,7 @@ template <int N, bool DPP = (N <= 6)> __device__ __forceinline__ bool wave_segme
 
 // Sum of v over runs of ADJACENT lanes holding the same key (keys in any order); the first lane of
 // each run gets the total.
-template <int N, bool DPP = (N <= 6)> __device__ __forceinline__ bool wave_run_sum(int key, float (&v)[N]) {
+template <int N, bool DPP = (N <= 6 || PSDR_DPP_ALWAYS)> __device__ __forceinline__ bool wave_run_sum(int key, float (&v)[N]) {
     const int lane = threadIdx.x & 63;
     const int prev = __shfl_up(key, 1, 64);
     const bool head = lane == 0 || prev != key;
@@ -846,8 +851,12 @@ template <int FL> struct RegPrivSink : DeviceSink<FL> {
     }
 };
 // which kernels keep them in registers: the host (render_rev) sets SinkLayout::priv_regs by the same rule
-// (not the rough-conductor instances: their adjoint kernel already fills 256 VGPRs and spilled 180 more with the accumulators: C5 7.75 -> 8.27 ms)
-template <int FL, bool GEO, int INTEG> constexpr bool reg_priv_kernel() { return PSDR_SINK_REG_PRIV && GEO && INTEG == PSDR_INTEGRATOR_PATH && (FL & kSceneRough) == 0; }
+// (not the rough-conductor instances: their adjoint kernel already fills 256 VGPRs and spilled 180 more with the accumulators: C5 7.75 -> 8.27 ms.
+// The wrong camera gradient round 3 saw in that configuration was the compiler's spill-placement defect, DESIGN.md "the order-dependent gradient")
+#ifndef PSDR_SINK_REG_PRIV_ROUGH
+#define PSDR_SINK_REG_PRIV_ROUGH 0          // test builds (variants/): the register accumulators in the rough-conductor instances too
+#endif
+template <int FL, bool GEO, int INTEG> constexpr bool reg_priv_kernel() { return PSDR_SINK_REG_PRIV && GEO && INTEG == PSDR_INTEGRATOR_PATH && ((FL & kSceneRough) == 0 || PSDR_SINK_REG_PRIV_ROUGH); }
 
 #ifndef PSDR_WAVES_REV
 #define PSDR_WAVES_REV 2
@@ -903,7 +912,7 @@ __global__ __launch_bounds__(kBlock, (STAGE == 1 ? PSDR_WAVES_REV_VALUE : rev_wa
         }
         // primary-triangle row: one add per run of lanes that hit the same triangle
         if (STAGE != 1 && GEO && sink.g.g_tri_info != nullptr) {
-            const bool head = wave_run_sum<kPrimaryWords, (FL & kSceneRough) == 0>(pg.tri, pg.w);
+            const bool head = wave_run_sum<kPrimaryWords, (FL & kSceneRough) == 0 || PSDR_DPP_ALWAYS>(pg.tri, pg.w);
             if (head && pg.tri >= 0) {
 #pragma unroll
                 for (int w = 0; w < kPrimaryWords; ++w) sink.add_tri(pg.tri, w, pg.w[w]);

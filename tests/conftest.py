@@ -20,6 +20,19 @@ def pytest_configure(config):
         __graft_entry__.build()
 
 
+@pytest.fixture(autouse=True)
+def _poison_scratch(request):
+    """PSDR_TEST_POISON=<hex pattern> (developer switch): before every GPU test the scratch arena of the queue is filled with the pattern
+    (tests/poison/poison.hip) -- a kernel that reloads a spill slot it never stored for some lane then computes with the pattern instead of
+    with whatever an earlier kernel left there (the order-dependent gradient).  tests/test_rough_rev_order_gpu.py does this
+    for the kernels the defect was found in, whatever the environment says."""
+    pat = os.environ.get("PSDR_TEST_POISON")
+    if pat and "gpu" in request.keywords:
+        from helpers import poison_gpu
+        poison_gpu(int(pat, 16), 1)
+    yield
+
+
 def pytest_collection_modifyitems(config, items):
     import torch
     if torch.cuda.is_available():

@@ -43,6 +43,23 @@ def tangents_wrt(tb, P):
     return dict(zip(AD_KEYS, _jvp_wrt([tb.get(k) for k in AD_KEYS], P.t)))
 
 
+# ---------------------------------------------------------------- scratch / LDS / VGPR poison (tests/poison/poison.hip)
+_poison = None
+
+
+def poison_gpu(pattern, what=1):
+    """Fill the queue's scratch arena (what & 1), the LDS of every CU (& 2), the VGPRs later waves inherit (& 4) with a bit pattern."""
+    global _poison
+    if _poison is None:
+        d = os.path.join(ROOT, "tests", "poison")
+        so, src = os.path.join(d, "libpoison.so"), os.path.join(d, "poison.hip")
+        if not os.path.exists(so) or os.path.getmtime(src) > os.path.getmtime(so):
+            subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O1", "-fPIC", "-shared", src, "-o", so])
+        _poison = C.CDLL(so)
+    rc = _poison.poison_gpu(C.c_uint32(pattern), int(what))
+    assert rc == 0, "poison_gpu failed (%d)" % rc
+
+
 # ---------------------------------------------------------------- hostcheck (product code on the CPU)
 _hostcheck = None
 
