@@ -138,10 +138,6 @@ struct Builder {
     int kMaxLeaf = 4;                  // leaf encoding holds 1..8
     float kTraversalCost = 2.0f;       // node visit / triangle test: a visit is two slab tests, a stack access and two dependent loads --
                                        // measured (tools/bvh_param_sweep.py): 2.0 is 4-5 % ahead of 1.0 on cbox_bunny and the 50 k-triangle interior, 3.0 no better
-    Builder() {                        // experiment knobs (tools only): PSDR_BVH_MAXLEAF, PSDR_BVH_TCOST
-        if (const char *e = std::getenv("PSDR_BVH_MAXLEAF")) kMaxLeaf = std::max(1, std::min(8, std::atoi(e)));
-        if (const char *e = std::getenv("PSDR_BVH_TCOST")) kTraversalCost = (float) std::atof(e);
-    }
 
     static float area(const float *lo, const float *hi) {
         const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
@@ -372,6 +368,7 @@ struct ForestBuilder {
     std::vector<int> level_start;
     int max_depth = 0;
     float pad = 0.f;
+    int max_leaf = 4; float traversal_cost = 2.0f;      // Builder::kMaxLeaf / kTraversalCost of the per-mesh trees
 
     static bool eligible(const int32_t *tri_mesh, int T, int num_meshes) {
         std::vector<int> cnt((size_t) std::max(num_meshes, 1), 0);
@@ -421,6 +418,7 @@ struct ForestBuilder {
             sub.resize(id.size() * PSDR_TRI_STRIDE);
             for (size_t i = 0; i < id.size(); ++i) std::memcpy(&sub[i * PSDR_TRI_STRIDE], rows + (size_t) id[i] * PSDR_TRI_STRIDE, PSDR_TRI_STRIDE * sizeof(float));
             Builder b;
+            b.kMaxLeaf = max_leaf; b.kTraversalCost = traversal_cost;
             int32_t root = 0;
             if (const char *err = b.run(sub.data(), (int) id.size(), root)) return err;
             // Builder padded its boxes with ITS pad; re-pad consistently is unnecessary (boxes only need to contain

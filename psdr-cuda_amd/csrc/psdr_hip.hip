@@ -397,7 +397,7 @@ int fail(const std::string &m) { g_err = m; return 1; }
 // choose theirs, psdr_kernels.h camera_blocks_per_cu; the reverse kernels zero and flush a gradient cache per
 // workgroup and are flat between 8 and 24).
 int launch_blocks(const psdr_scene_s *h, long long n, int per_cu) {
-    static const int forced = std::getenv("PSDR_BLOCKS_PER_CU") ? std::atoi(std::getenv("PSDR_BLOCKS_PER_CU")) : 0;
+    const int forced = h->opt.blocks_per_cu;
     const long long need = (n + kBlock - 1) / kBlock;
     const long long cap = (long long) h->num_cus * (forced ? forced : per_cu);
     return (int) std::max(1LL, std::min(need, cap));
@@ -424,8 +424,7 @@ static bool small_tables_fit(const psdr_scene_s *h) {
            (d.num_emitters == 0 || (d.face_cmf && d.face_pmf)) && emitter_faces(h) <= 64;
 }
 static bool tiny_tables_ok(const psdr_scene_s *h) {
-    static const bool enabled = !(std::getenv("PSDR_TINY_VARIANTS") && std::atoi(std::getenv("PSDR_TINY_VARIANTS")) == 0);
-    return enabled && tiny_only(h) && small_tables_fit(h);
+    return h->opt.tiny_variants != 0 && tiny_only(h) && small_tables_fit(h);
 }
 // The kernels of a two-level scene read the mesh-level tables from LDS and have no other path (psdr_device.h Tab<FL>::lds_small): such a tree
 // is only built, and only kept, while they fit (psdr_bvh_build, ensure_tree_kind).
@@ -434,8 +433,7 @@ static bool forest_tables(const psdr_scene_s *h) { return PSDR_FOREST_LDS_TABLES
 // rough conductor + two-level tree, psdr_variant.hip) -- measured 5-10 % ahead on the 50 k-triangle interior, level or behind elsewhere
 // (profiles/r03_bvh4_ab.txt).  k_trace (this unit) carries both walks and follows the scene.
 static bool use_wide_tree(const psdr_scene_s *h, bool forest) {
-    static const int forced = std::getenv("PSDR_WIDE") ? std::atoi(std::getenv("PSDR_WIDE")) : -1;      // 0: never (the variant-6 kernels then cannot run: tools only)
-    if (forced == 0) return false;
+    if (h->opt.wide == 0) return false;                 // never (the variant-6 kernels then cannot run: tools only)
     return forest && h->has_rough && h->desc.env_emitter < 0;
 }
 
@@ -445,7 +443,7 @@ static int staged_nodes_of(const psdr_scene_s *h) { return h->wide ? h->num_node
 int plan_lds(const psdr_scene_s *h, LaunchCtx &cx, int reserved) {
     // the plain diffuse variant runs renderC at 5 workgroups per CU: 28 KB each (C4 PathTracer(3) 40.0 -> 37.6 ms,
     // C3 3.26 -> 3.15 ms; 32 KB is already one workgroup less)
-    static const int forced = std::getenv("PSDR_LDS_BUDGET") ? std::atoi(std::getenv("PSDR_LDS_BUDGET")) : 0;
+    const int forced = h->opt.lds_budget;
     const bool lean = !h->has_rough && h->desc.env_emitter < 0;
     const int budget = forced ? forced : (lean ? 28 * 1024 : kLdsBudget);
     const int stack_bytes = stack_entries_of(h) * kBlock * 4;
@@ -564,10 +562,10 @@ SinkLayout make_sink_layout(const psdr_scene_s *h, const psdr_grads *g) {
     L.stride = off | 1;
     L.rep = 1;
     // 2 copies bought 6 % on C2, more nothing: 4 at most, so that a small scene's cache stays a few KB of LDS
-    static const int max_rep = std::getenv("PSDR_SINK_REP") ? std::atoi(std::getenv("PSDR_SINK_REP")) : 4;
+    const int max_rep = h->opt.sink_rep;
     while (L.rep * 2 <= max_rep && L.rep * 2 * L.stride <= kSinkCacheWords) L.rep *= 2;
     // lane-private rows: the leading hot slots are emitter 0's triangles (build_bvh)
-    static const bool priv_on = !(std::getenv("PSDR_SINK_PRIVATE") && std::atoi(std::getenv("PSDR_SINK_PRIVATE")) == 0);
+    const bool priv_on = h->opt.sink_private != 0;
     L.priv_tri[0] = L.priv_tri[1] = -1; L.priv_slot[0] = L.priv_slot[1] = 0; L.priv_emitter = -1;
     if (priv_on && L.hot_rows > 0 && h->desc.num_emitters > 0 && h->desc.env_emitter != 0) {
         const int32_t *ei = h->emitter_i.data();
@@ -884,14 +882,35 @@ int psdr_scene_create(psdr_scene_t *out) {
         h->num_cus = prop.multiProcessorCount;
         h->lds_limit = (int) std::min<size_t>(prop.sharedMemPerBlock, 160 * 1024);
     }
-    if (const char *e2 = std::getenv("PSDR_BVH_REFIT")) h->refit_enabled = std::atoi(e2) != 0;      // 0: always rebuild on the host
-    if (const char *e4 = std::getenv("PSDR_TINY_SCENE")) h->tiny_enabled = std::atoi(e4) != 0;      // 0: walk the tree even for <= 16 triangles
-    if (const char *e5 = std::getenv("PSDR_TWO_LEVEL")) h->two_level_enabled = std::atoi(e5) != 0;  // 0: one tree over all triangles
-    if (const char *e7 = std::getenv("PSDR_WF_BINNED")) h->wf_binned = std::atoi(e7) != 0;          // 0: wavefront streams not binned by cost class
-    if (const char *e9 = std::getenv("PSDR_WF_TRACED")) h->traced_enabled = std::atoi(e9) != 0;     // 0: no dense trace kernel between the wavefront stages
-    if (const char *e8 = std::getenv("PSDR_BVH_BUILD")) h->bvh_device_mode = std::string(e8) == "device" ? 1 : (std::string(e8) == "host" ? 0 : -1);
-    if (const char *e3 = std::getenv("PSDR_SORT_EDGES")) h->sort_edges = std::atoi(e3) != 0;        // 0: primary-edge slots in natural order
     *out = h;
+    return 0;
+}
+
+// Developer options (A/B switches of tools and tests; DESIGN.md names the default of each).  Takes effect at the next psdr_bvh_build / render call.
+int psdr_scene_set_option(psdr_scene_t h, const char *name, double value) {
+    if (!h || !name) return fail("psdr_scene_set_option: null argument");
+    const std::string n(name);
+    const int iv = (int) value;
+    if (n == "bvh_refit") h->refit_enabled = iv != 0;                   // 0: rebuild the tree on the host at every psdr_bvh_build
+    else if (n == "tiny_scene") h->tiny_enabled = iv != 0;              // 0: walk a tree even for <= 16 triangles
+    else if (n == "two_level") h->two_level_enabled = iv != 0;          // 0: one tree over all triangles
+    else if (n == "wf_binned") h->wf_binned = iv != 0;                  // 0: wavefront streams not binned by cost class (only without the trace kernel)
+    else if (n == "wf_traced") h->traced_enabled = iv != 0;             // 0: no dense trace kernel between the wavefront stages
+    else if (n == "bvh_build") h->bvh_device_mode = iv;                 // 1: always on the device, 0: always on the host, -1: by size
+    else if (n == "sort_edges") h->sort_edges = iv != 0;                // 0: primary-edge slots in natural order
+    else if (n == "blocks_per_cu") h->opt.blocks_per_cu = iv;
+    else if (n == "camera_blocks") h->opt.camera_blocks = iv;
+    else if (n == "tiny_variants") h->opt.tiny_variants = iv;
+    else if (n == "wide") h->opt.wide = iv;
+    else if (n == "lds_budget") h->opt.lds_budget = iv;
+    else if (n == "sink_rep") h->opt.sink_rep = std::max(1, std::min(16, iv));
+    else if (n == "sink_private") h->opt.sink_private = iv;
+    else if (n == "rev_split") h->opt.rev_split = iv;
+    else if (n == "sedge_split") h->opt.sedge_split = iv;
+    else if (n == "bvh_maxleaf") h->opt.bvh_maxleaf = std::max(1, std::min(8, iv));
+    else if (n == "bvh_tcost") h->opt.bvh_tcost = (float) value;
+    else return fail("psdr_scene_set_option: unknown option '" + n + "'");
+    if (n == "tiny_scene" || n == "two_level" || n == "bvh_build" || n == "wide" || n == "bvh_maxleaf" || n == "bvh_tcost" || n == "tiny_variants") h->have_bvh = false;
     return 0;
 }
 
@@ -1043,6 +1062,7 @@ int psdr_bvh_build(psdr_scene_t h, void *stream) {
     }
     Builder b;
     ForestBuilder fb;
+    b.kMaxLeaf = fb.max_leaf = h->opt.bvh_maxleaf; b.kTraversalCost = fb.traversal_cost = h->opt.bvh_tcost;
     std::vector<float4> top_prims;
     int32_t root = 0;
     if (forest) {

@@ -141,7 +141,24 @@ constexpr int kPrivRowWords = 13;            // position (p0, e1, e2: 9), face n
 constexpr int kPrivWords = 2 * kPrivRowWords + 3;
 
 // The scene handle behind psdr_scene_t: the caller's tables, the BVH on the device and per-handle scratch.
+// Developer options of a handle (psdr_scene_set_option; the library reads no environment variable): A/B switches of the strategies below, for
+// tools and tests.  The defaults are what every measurement in DESIGN.md refers to.
+struct psdr_scene_options {
+    int blocks_per_cu = 0;                 // cap of the grid-stride grids (0: per kernel)
+    int camera_blocks = 0;                 // workgroups per CU of the forward camera kernels (0: camera_blocks_per_cu)
+    int tiny_variants = 1;                 // scenes without a tree run the kSceneTiny kernel instances
+    int wide = -1;                         // 0: never derive the 4-wide tree for the render kernels (-1: by scene)
+    int lds_budget = 0;                    // LDS per workgroup for stacks + staged scene (0: 28 KB / 40 KB by variant)
+    int sink_rep = 4;                      // copies of the LDS gradient cache at most
+    int sink_private = 1;                  // lane-private accumulators for the emitter's rows
+    int rev_split = -1;                    // reverse mode as value kernel + adjoint kernel: 1 / 0 force, -1 by scene and launch size
+    int sedge_split = -1;                  // secondary-edge term as filter + survivor kernel: 1 / 0 force, -1 from 2^18 slots
+    int bvh_maxleaf = 4;                   // host SAH builder: leaf size limit (1..8)
+    float bvh_tcost = 2.0f;                //                   cost of a node visit in triangle tests
+};
+
 struct psdr_scene_s {
+    psdr_scene_options opt;
     psdr_scene_desc desc{};                // caller-owned device tables (psdr_scene_set_tables)
     bool have_tables = false;
     bool has_rough = true;                 // a RoughConductor may be present (desc.material_mask)

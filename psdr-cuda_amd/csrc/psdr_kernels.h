@@ -1004,8 +1004,7 @@ __global__ __launch_bounds__(kBlock) void k_secondary_edge_rev(LaunchCtx cx, Dev
 // scene in LDS first: on a 4 M-slot launch of an open scene (bunny_light) 40 per CU is 9-15 % SLOWER.  So: 40 when
 // nothing is staged (tiny scene) or when a workgroup still makes >= 8 trips of its grid-stride loop, else 16.
 inline int camera_blocks_per_cu(const psdr_scene_s *h, long long n) {
-    static const int forced = std::getenv("PSDR_CAMERA_BLOCKS") ? std::atoi(std::getenv("PSDR_CAMERA_BLOCKS")) : 0;      // experiments (tools)
-    if (forced > 0) return forced;
+    if (h->opt.camera_blocks > 0) return h->opt.camera_blocks;          // experiments (psdr_scene_set_option)
     if (h->has_rough) return 16;
     if (h->n_tiny > 0 && h->n_blas == 0) return 40;
     // tree scenes (lean variants): pixels on a mesh cost several times a wall pixel and neighbouring pixels share a workgroup, so the hardware's
@@ -1162,7 +1161,7 @@ int run_camera_wavefront(psdr_scene_s *h, const psdr_render_opts *o, const TV<M,
 template <int FL>
 int secondary_edge_filter(psdr_scene_s *h, const LaunchCtx &cx, long long i0, long long n, const uint32_t **list, const int **list_n, hipStream_t s) {
     *list = nullptr; *list_n = nullptr;
-    const int split_env = std::getenv("PSDR_SEDGE_SPLIT") ? std::atoi(std::getenv("PSDR_SEDGE_SPLIT")) : -1;
+    const int split_env = h->opt.sedge_split;
     if (split_env == 0 || (split_env < 0 && n < (1ll << 18)) || n > 0x7fffffffLL) return 0;
     const size_t need = 256 + (size_t) n * sizeof(uint32_t);
     if (need > h->se_list_bytes) {
@@ -1254,7 +1253,7 @@ int render_rev(psdr_scene_s *h, const psdr_render_opts *o, const float *adj_img,
         const bool geo = grads->g_tri_info != nullptr || grads->g_cam_to_world != nullptr;
         const int wg_per_cu = (o->integrator == PSDR_INTEGRATOR_DIRECT && !(FL & kSceneRough)) ? 3 : 2;       // rev_waves<FL, true, INTEG>
         // Split launch: a scene with a tree to walk, geometry gradients (the register-heavy kernel), hits replayable.
-        const int split_env = std::getenv("PSDR_REV_SPLIT") ? std::atoi(std::getenv("PSDR_REV_SPLIT")) : -1;
+        const int split_env = h->opt.rev_split;
         const bool replayable = o->integrator == PSDR_INTEGRATOR_PATH || (o->integrator == PSDR_INTEGRATOR_DIRECT && o->bsdf_samples <= 1 && o->light_samples <= 1);
         const bool has_tree = h->num_nodes > 0 && (h->n_tiny == 0 || h->n_blas > 0);
         // measured (tools/rev_split_probe.py, 4 M slots): PathTracer(3) cbox_bunny 6.8 -> 4.8 ms, bunny_light 5.6 -> 3.9, 50 k-triangle interior

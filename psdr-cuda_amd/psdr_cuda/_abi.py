@@ -82,7 +82,7 @@ TANGENT_FIELDS = ("tri_info", "texels", "emitter_rad", "cam_to_world", "sec_edge
 
 # every symbol include/psdr_hip.h declares (checked by tests/test_abi.py)
 HIP_SYMBOLS = (
-    "psdr_last_error", "psdr_version", "psdr_abi_struct_sizes", "psdr_scene_create", "psdr_scene_destroy", "psdr_scene_set_tables",
+    "psdr_last_error", "psdr_version", "psdr_abi_struct_sizes", "psdr_scene_create", "psdr_scene_destroy", "psdr_scene_set_option", "psdr_scene_set_tables",
     "psdr_bvh_build", "psdr_bvh_stats", "psdr_scene_info", "psdr_trace", "psdr_render_c", "psdr_render_d_fwd", "psdr_render_d_rev",
     "psdr_guide_build", "psdr_get_counters",
     "psdr_geo_world_vertices_fwd", "psdr_geo_world_vertices_rev", "psdr_geo_tri_rows_fwd", "psdr_geo_tri_rows_rev", "psdr_geo_sec_edges_fwd", "psdr_geo_sec_edges_rev", "psdr_geo_prim_edges_fwd", "psdr_geo_prim_edges_rev",
@@ -107,6 +107,7 @@ def load_hip():
     vp, i32 = C.c_void_p, C.c_int32
     lib.psdr_scene_create.argtypes = [C.POINTER(vp)]
     lib.psdr_scene_destroy.argtypes = [vp]
+    lib.psdr_scene_set_option.argtypes = [vp, C.c_char_p, C.c_double]
     lib.psdr_scene_set_tables.argtypes = [vp, C.POINTER(SceneDesc)]
     lib.psdr_bvh_build.argtypes = [vp, vp]
     lib.psdr_trace.argtypes = [vp, i32] + [vp] * 7 + [vp] * 4 + [vp]

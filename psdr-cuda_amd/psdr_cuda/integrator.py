@@ -190,6 +190,8 @@ class Integrator(Object):
             h = C.c_void_p()
             _abi.check(lib, lib.psdr_scene_create(C.byref(h)))
             scene._native = h
+            for name, value in getattr(scene, "native_options", {}).items():
+                _abi.check(lib, lib.psdr_scene_set_option(h, name.encode(), float(value)))
         desc, keep = make_desc(tb, guide)
         _abi.check(lib, lib.psdr_scene_set_tables(scene._native, C.byref(desc)))
         # the tree on the handle belongs to ONE set of tables: rebuild / refit whenever the tables submitted now are

@@ -843,6 +843,7 @@ class Scene(Object):
         self._tables = None
         self._sensor_tables = []
         self._native = None            # psdr_scene_t
+        self.native_options = {}       # developer options applied to the handle when it is created (psdr_scene_set_option: name -> value)
         self._sample_count = [0, 0, 0]
         self._rng_offset = [0, 0, 0]
         self._configured = False

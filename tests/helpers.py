@@ -143,13 +143,24 @@ def dot_tables(grads, tangents):
 class GpuScene:
     """Thin ctypes driver of libpsdr_hip.so (exactly what a foreign-language binding would do)."""
 
-    def __init__(self, tb, guide=None):
+    def __init__(self, tb, guide=None, options=None):
         self.lib = _abi.load_hip()
         self.h = C.c_void_p()
         _abi.check(self.lib, self.lib.psdr_scene_create(C.byref(self.h)))
+        # developer options of the handle (psdr_scene_set_option): the `options` dict of this call, then PSDR_OPTIONS="name=value,..." of
+        # the environment (tools: A/B runs without touching the scripts) -- read HERE, in the test driver, never by the library
+        opts = dict(options or {})
+        for kv in filter(None, os.environ.get("PSDR_OPTIONS", "").split(",")):
+            k, v = kv.split("=")
+            opts.setdefault(k.strip(), float(v))
+        for k, v in opts.items():
+            self.set_option(k, v)
         self.tb = {k: (v.detach().cuda() if isinstance(v, torch.Tensor) else v) for k, v in tb.items()}
         self.set_guide(guide)
         _abi.check(self.lib, self.lib.psdr_bvh_build(self.h, None))
+
+    def set_option(self, name, value):
+        _abi.check(self.lib, self.lib.psdr_scene_set_option(self.h, name.encode(), float(value)))
 
     def set_guide(self, guide):
         if guide is not None:

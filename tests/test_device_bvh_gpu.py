@@ -1,7 +1,7 @@
 """The tree built ON THE DEVICE (csrc/psdr_lbvh.h: Morton codes, rocPRIM sort, Karras radix tree, bottom-up fit) -- what the
 reference's OptiX GAS build does at every configure() (include/psdr/scene/optix.h:277-340, scene.cpp:247-248).  The closest
 hit does not depend on the tree: a device-built tree must return the host-built tree's hits, the oracle's images, and survive a
-refit.  PSDR_BVH_BUILD=device forces it (by default only tables of >= 2^18 triangles take it)."""
+refit.  psdr_scene_set_option("bvh_build", 1) forces it (by default only tables of >= 2^18 triangles take it)."""
 import os
 import time
 
@@ -17,18 +17,20 @@ pytestmark = pytest.mark.gpu
 
 
 class forced_build:
+    """Handles created inside get psdr_scene_set_option("bvh_build", 1 = device / 0 = host): tests/helpers.py GpuScene reads PSDR_OPTIONS
+    (the library itself reads no environment variable)."""
     def __init__(self, mode):
         self.mode = mode
 
     def __enter__(self):
-        self.old = os.environ.get("PSDR_BVH_BUILD")
-        os.environ["PSDR_BVH_BUILD"] = self.mode
+        self.old = os.environ.get("PSDR_OPTIONS")
+        os.environ["PSDR_OPTIONS"] = "bvh_build=%d" % (1 if self.mode == "device" else 0)
 
     def __exit__(self, *a):
         if self.old is None:
-            del os.environ["PSDR_BVH_BUILD"]
+            del os.environ["PSDR_OPTIONS"]
         else:
-            os.environ["PSDR_BVH_BUILD"] = self.old
+            os.environ["PSDR_OPTIONS"] = self.old
 
 
 def bvh_stats(g):

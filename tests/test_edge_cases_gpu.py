@@ -196,7 +196,7 @@ def test_trace_fuzz_random_triangle_soups(n_tris, seed):
 def test_tiny_scene_all_triangles_path_equals_the_tree_walk(monkeypatch):
     """<= 16 triangles: the geometry travels in the kernel arguments and closest_hit tests all of it (SceneView::tiny),
     two triangles of a wall as ONE parallelogram whose plane coordinates are mapped to the hit triangle's barycentrics
-    (pack_tiny_prims); PSDR_TINY_SCENE=0 walks the tree instead -- same triangles, barycentrics equal to rounding, same
+    (pack_tiny_prims); psdr_scene_set_option("tiny_scene", 0) walks the tree instead -- same triangles, barycentrics equal to rounding, same
     image, same gradients; a 17-triangle scene takes the tree"""
     from helpers import camera_rays
     sc, _ = load_scene("cbox", res=48, spp=8)
@@ -207,8 +207,7 @@ def test_tiny_scene_all_triangles_path_equals_the_tree_walk(monkeypatch):
     adj = np.random.default_rng(0).random((48 * 48, 3)).astype(np.float32)
     out = {}
     for mode in ("1", "0"):
-        monkeypatch.setenv("PSDR_TINY_SCENE", mode)       # read when the handle is created
-        g = GpuScene(tb)
+        g = GpuScene(tb, options={"tiny_scene": int(mode)})
         out[mode] = (g.trace(o_, d_), g.render_c(opts), g.render_d_rev(opts, adj, want=["tri_info", "texels"], with_image=False)[1])
     (sa, ta, ua, va), (sb, tb_, ub, vb) = out["1"][0], out["0"][0]
     same = ta == tb_
@@ -241,20 +240,13 @@ def test_deep_paths_reverse_on_the_large_scene():
     # the two homes of the record give the same gradient: depth 8 (LDS) against depth 9 with an albedo so dark that a ninth vertex adds < 1e-6
     import os
     o8, o12 = (_abi.make_opts(spp=4, integrator=_abi.INTEGRATOR_PATH, max_depth=d) for d in (8, 12))
-    old = os.environ.get("PSDR_REV_SPLIT")
-    try:
-        for mode in ("0", "1"):                      # one kernel / value kernel + adjoint kernel: both read the HBM record
-            os.environ["PSDR_REV_SPLIT"] = mode
-            _, g12 = g.render_d_rev(o12, adj, want=["texels"], with_image=False)
-            tan = random_tangents(tb, ["texels"], seed=3)
-            _, d12 = g.render_d_fwd(o12, [tan])
-            lhs, rhs = float((adj.astype(np.float64) * d12[0]).sum()), dot_tables(g12, tan)
-            assert abs(lhs - rhs) < 3e-3 * np.abs(adj * d12[0]).sum(), (mode, lhs, rhs)
-    finally:
-        if old is None:
-            os.environ.pop("PSDR_REV_SPLIT", None)
-        else:
-            os.environ["PSDR_REV_SPLIT"] = old
+    for mode in (0, 1):                              # one kernel / value kernel + adjoint kernel: both read the HBM record
+        g.set_option("rev_split", mode)
+        _, g12 = g.render_d_rev(o12, adj, want=["texels"], with_image=False)
+        tan = random_tangents(tb, ["texels"], seed=3)
+        _, d12 = g.render_d_fwd(o12, [tan])
+        lhs, rhs = float((adj.astype(np.float64) * d12[0]).sum()), dot_tables(g12, tan)
+        assert abs(lhs - rhs) < 3e-3 * np.abs(adj * d12[0]).sum(), (mode, lhs, rhs)
 
 
 @pytest.mark.parametrize("scene", ["cbox", "cbox_bunny"])

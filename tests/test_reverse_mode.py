@@ -108,7 +108,7 @@ def test_split_reverse_launch_equals_the_fused_kernel(kind):
     """Tree scenes run reverse mode as two kernels -- the value sweep at the occupancy of a forward kernel, leaving a record per
     path (primary triangle, vertex count, suffix radiances, the triangles the rays arrived at), then the adjoint sweep from the
     record, without traversal (csrc/psdr_kernels.h render_rev).  Same samples, same arithmetic: the gradients of the one-kernel
-    launch up to the order of the float adds.  PSDR_REV_SPLIT = 1 / 0 forces either (default: by scene and launch size)."""
+    launch up to the order of the float adds.  psdr_scene_set_option("rev_split", 1 / 0) forces either (default: by scene and launch size)."""
     import os
     import numpy as np
     from helpers import GpuScene, load_scene, rel_l2
@@ -120,17 +120,10 @@ def test_split_reverse_launch_equals_the_fused_kernel(kind):
     o = _abi.make_opts(spp=8, **kw)
     adj = np.random.default_rng(3).random((96 * 96, 3)).astype(np.float32)
     out = {}
-    old = os.environ.get("PSDR_REV_SPLIT")
-    try:
-        for mode in ("0", "1"):
-            os.environ["PSDR_REV_SPLIT"] = mode
-            img, grads = g.render_d_rev(o, adj, want=["tri_info", "texels", "emitter_rad", "cam_to_world"])
-            out[mode] = (img, grads, g.counters()[0])
-    finally:
-        if old is None:
-            del os.environ["PSDR_REV_SPLIT"]
-        else:
-            os.environ["PSDR_REV_SPLIT"] = old
+    for mode in ("0", "1"):
+        g.set_option("rev_split", int(mode))
+        img, grads = g.render_d_rev(o, adj, want=["tri_info", "texels", "emitter_rad", "cam_to_world"])
+        out[mode] = (img, grads, g.counters()[0])
     assert out["0"][2] == out["1"][2]                                       # the same rays traced
     assert rel_l2(out["1"][0], out["0"][0]) < 1e-6
     for k in ("tri_info", "texels", "emitter_rad", "cam_to_world"):
@@ -152,18 +145,11 @@ def test_secondary_edge_split_launch_equals_one_kernel():
     tan = tangents_wrt(tb, P)
     adj = np.random.default_rng(4).random((64 * 64, 3)).astype(np.float32)
     out = {}
-    old = os.environ.get("PSDR_SEDGE_SPLIT")
-    try:
-        for mode in ("0", "1"):
-            os.environ["PSDR_SEDGE_SPLIT"] = mode
-            _, d = g.render_d_fwd(o, [tan]); rays_f = g.counters()[0]
-            _, grads = g.render_d_rev(o, adj, want=["tri_info", "sec_edge", "cam_to_world"], with_image=False); rays_r = g.counters()[0]
-            out[mode] = (d[0], grads, rays_f, rays_r)
-    finally:
-        if old is None:
-            os.environ.pop("PSDR_SEDGE_SPLIT", None)
-        else:
-            os.environ["PSDR_SEDGE_SPLIT"] = old
+    for mode in ("0", "1"):
+        g.set_option("sedge_split", int(mode))
+        _, d = g.render_d_fwd(o, [tan]); rays_f = g.counters()[0]
+        _, grads = g.render_d_rev(o, adj, want=["tri_info", "sec_edge", "cam_to_world"], with_image=False); rays_r = g.counters()[0]
+        out[mode] = (d[0], grads, rays_f, rays_r)
     assert out["0"][2] == out["1"][2] and out["0"][3] == out["1"][3]
     assert np.abs(out["0"][0]).max() > 0 and rel_l2(out["1"][0], out["0"][0]) < 1e-5
     for k in ("tri_info", "sec_edge", "cam_to_world"):

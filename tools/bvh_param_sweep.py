@@ -24,11 +24,11 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
         g = GpuScene(tb)
         o = _abi.make_opts(spp=16, integrator=_abi.INTEGRATOR_PATH, max_depth=3, flags=_abi.FLAG_FUSED)
         out.append("%s %.2f" % (name, timeit(lambda: g.render_c(o))))
-    print("leaf=%s tcost=%s  " % (os.environ.get("PSDR_BVH_MAXLEAF", "4"), os.environ.get("PSDR_BVH_TCOST", "1.0")) + "  ".join(out))
+    print("leaf=%s tcost=%s  " % (os.environ.get("PSDR_OPTIONS", ""), "") + "  ".join(out))
 else:
     combos = [tuple(a.split(":")) for a in sys.argv[1:]] or [(l, t) for l in ("2", "4", "6", "8") for t in ("0.5", "1.0", "2.0")]
     for leaf, tc in combos:
         if True:
-            env = dict(os.environ, PSDR_BVH_MAXLEAF=leaf, PSDR_BVH_TCOST=tc)
+            env = dict(os.environ, PSDR_OPTIONS="bvh_maxleaf=%s,bvh_tcost=%s" % (leaf, tc))
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=env, capture_output=True, text=True)
             print(r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-300:], flush=True)

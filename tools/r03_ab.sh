@@ -5,7 +5,7 @@ for L in base $2 base $2; do
   echo "== $L" >> $O/ab.txt
   if [ $L = base ]; then unset PSDR_HIP_LIB; else export PSDR_HIP_LIB=$R/variants/lib_$L.so; fi
   timeout 600 python tools/perf_cases.py c4 c5 c3 open 2>&1 | grep "renderC\|rev\|fwd" >> $O/ab.txt
-  PSDR_TWO_LEVEL=0 timeout 600 python tools/perf_cases.py c4 skipmain 2>&1 | grep "renderC" | sed 's/^/one-tree /' >> $O/ab.txt
+  PSDR_OPTIONS=two_level=0 timeout 600 python tools/perf_cases.py c4 skipmain 2>&1 | grep "renderC" | sed 's/^/one-tree /' >> $O/ab.txt
 done
 python - <<PY
 import re, collections

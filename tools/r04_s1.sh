@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "wavefront or trace_matches" > $O/parity.log 2>&1; echo "pytest rc=$?" >> $O/parity.log; tail -5 $O/parity.log
 for c in c4 c5 c3b; do
   for m in fused wavefront default; do
-    PSDR_WF_TRACED=0 timeout 300 python tools/wf_case.py $c $m 3 2>&1 | tail -1 | sed 's/^/traced=0 /'
+    PSDR_OPTIONS=wf_traced=0 timeout 300 python tools/wf_case.py $c $m 3 2>&1 | tail -1 | sed 's/^/traced=0 /'
     timeout 300 python tools/wf_case.py $c $m 3 2>&1 | tail -1 | sed 's/^/traced=1 /'
   done
 done | tee $O/cases.txt

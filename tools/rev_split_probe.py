@@ -32,6 +32,6 @@ for name in sys.argv[1:] or ["cbox_bunny", "bunny_light", "interior", "cbox"]:
         o = _abi.make_opts(spp=spp, **kw)
         t = {}
         for mode in ("0", "1"):
-            os.environ["PSDR_REV_SPLIT"] = mode
+            os.environ["PSDR_OPTIONS"] = "rev_split=%s" % mode
             t[mode] = timeit(lambda: g.render_d_rev(o, adj, want=["tri_info", "texels"], with_image=False))
         print("%-12s %-8s one kernel %6.2f ms   split %6.2f ms" % (name, kind, t["0"], t["1"]))

@@ -14,12 +14,12 @@ history = sys.argv[1] if len(sys.argv) > 1 else "none"
 pattern = int(sys.argv[2], 16) if len(sys.argv) > 2 else None
 what = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 if history == "bvh":
-    os.environ["PSDR_BVH_BUILD"] = "device"
+    os.environ["PSDR_OPTIONS"] = "bvh_build=1"
     sc, _ = load_scene("cbox_bunny", res=64)
     g = GpuScene(sc.tables(0))
     o, d = camera_rays(sc.tables(0), 100000, seed=1)
     g.trace(o, d)
-    os.environ.pop("PSDR_BVH_BUILD")
+    os.environ.pop("PSDR_OPTIONS")
 elif history == "big":
     from psdr_cuda.fixtures import make_interior_scene
     sc = make_interior_scene(seed=0, n_objects=4, res=64, spp=4); sc.configure()
