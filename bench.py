@@ -46,9 +46,7 @@ VALU_PEAK_WAVE_INSTS_PER_S = N_SIMD * CLOCK_HZ / 2.0          # 1.2288e12 wave-i
 # VALU lane-instructions one primitive test costs (Moeller-Trumbore with SGPR operands, csrc/psdr_device.h tiny_prim_test) and
 # the rest of a traced ray's share of its path vertex (hit reconstruction, sampling, shading): DESIGN.md section 3
 FLOOR_VALU_PER_PRIM_TEST, FLOOR_VALU_PER_RAY_REST = 31, 150          # plane-form primitive test as the ISA issues it: 20 arithmetic + 6 compare + 5 select
-# What a SIMD actually sustains (tools/micro/valu_rate.hip on MI355X, 8 waves per SIMD, clocks measured at 2.3-2.4 GHz;
-# profiles/r03_valu_rate.txt): wave64 VALU instructions per cycle per SIMD -- no stream reaches the 0.5 of the 2-cycle issue model
-MEASURED_VALU_PER_CYCLE = {"v_xor_b32 / v_mov_b32 (two operands)": 0.42, "v_fma_f32, dependent chain": 0.40, "v_fma_f32, 16 independent (three VGPR sources)": 0.265}
+
 
 
 def parse():
@@ -279,6 +277,7 @@ def pmc_passes_c4(args, res, spp):
 # BASELINE configs 3-5 (the scenes WITH a tree) at one GPU's share, through the same C-ABI entry points as the headline's kernel_only block:
 #   c4_shard_path3_renderC      cbox_bunny 1024^2, 64 of the 512 spp (one of eight GPUs), PathTracer(3) renderC
 #   c4_shard_direct_rev3        the same shard, DirectIntegrator(1,1) renderD + backward with all three terms (spp = sppe = sppse share), triangle rows + texels
+#   c4_shard_path3_rev          the same shard, PathTracer(3) renderD + backward (interior term), triangle rows + texels
 #   c5_path3_renderC            50 k-triangle interior with rough conductors, 512^2 spp 16, PathTracer(3) renderC
 #   c3_direct_fwd3              cbox_bunny 512^2 spp = sppe = sppse = 16, renderD forward (K = 1: a translation of the bunny), three terms
 class TreeScenes:
@@ -309,6 +308,10 @@ class TreeScenes:
             if tb4g.get(k) is not None:
                 tb4g[k] = tb4g[k].detach().requires_grad_(True)
         self.cases.append(("c4_shard_direct_rev3", 3 * n4, lambda sc=sc4, tb=tb4g, o=od, a=adj4: self.integ._render_rev(sc, tb, o, None, a), sc4))
+        tb4p = dict(tb4)
+        for k in ("tri_info", "texels"):
+            tb4p[k] = tb4p[k].detach().requires_grad_(True)
+        self.cases.append(("c4_shard_path3_rev", n4, lambda sc=sc4, tb=tb4p, o=o, a=adj4: self.integ._render_rev(sc, tb, o, None, a), sc4))
         sc5 = make_interior_scene(seed=0, n_objects=10, res=512, spp=16)
         sc5.configure()
         tb5 = sc5.tables(0)
@@ -653,8 +656,6 @@ def main():
         "achieved": None if achieved is None else round(achieved / 1e9, 3), "peak": round(VALU_PEAK_WAVE_INSTS_PER_S / 1e9, 3),
         "unit": "G wave-instructions/s", "frac": None if achieved is None else round(achieved / VALU_PEAK_WAVE_INSTS_PER_S, 4),
         "peak_note": "1024 SIMD-32 units x 2.4 GHz / 2 cycles per wave64 VALU instruction (MI355X_MICROARCH.md)",
-        "measured_issue_ceiling": {"winst_per_cycle_per_simd": MEASURED_VALU_PER_CYCLE, "achieved_winst_per_cycle_per_simd": None if achieved is None else round(achieved / (N_SIMD * CLOCK_HZ), 4),
-                                   "note": "tools/micro/valu_rate.hip, profiles/r03_valu_rate.txt: what pure instruction streams sustain at 8 waves / SIMD; 0.5 = the 2-cycle model"},
         "valu_wave_insts_per_launch": valu, "algorithmic_floor_frac": None if valu is None else round(floor_lane_insts / (valu * 64.0), 4),
         "primitives_tested_per_ray": n_prims,
         "wait_any_frac": None if not wave_cycles or "SQ_WAIT_ANY" not in dpm else round(dpm["SQ_WAIT_ANY"] / wave_cycles, 4),

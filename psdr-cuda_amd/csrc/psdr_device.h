@@ -1050,7 +1050,7 @@ struct LiParams {                 // uniform per launch
 // points, detached G in the pdfs) are used whenever the result type M carries tangents.
 template <class G, class M, class TVT>
 PSDR_HD Vec3<M> direct_step(const SceneView &sc, const TVT &tv, TraversalStack &st, Rng &rng, const Its<G> &its, bool active, int nB,
-                            int nL, uint32_t &nrays, Its<G> *next_its, Vec3<M> *next_f, bool *next_valid) {
+                            int nL, uint32_t &nrays, Its<G> *next_its, Vec3<M> *next_f, bool *next_valid, int *light_tri = nullptr) {
     constexpr bool ad = is_ad<M>();
     constexpr HitForm form = is_ad<G>() ? kPathSpace : kDetached;
     Vec3<M> result = zero3<M>();
@@ -1098,6 +1098,7 @@ PSDR_HD Vec3<M> direct_step(const SceneView &sc, const TVT &tv, TraversalStack &
         wo = wo / dist;
         const RayT<G> ray1{its.p, wo};
         const Its<G> its1 = intersect<G>(sc, tv, st, ray1, ps.valid, form, nrays, -1, -1, kPreLightRay);
+        if (light_tri && i == 0) *light_tri = its1.valid ? its1.tri : -1;          // the value sweep of a split reverse launch records it (psdr_reverse.h RevDisk)
         if (!(its1.valid && val(its1.t) > val(dist) - kShadowEpsilon && emitter_of(sc, tv, its1) >= 0)) continue;
         const G Gv = abs_(dot(its1.n, -wo)) / d2;
         const Vec3<G> wl = its.sh.to_local(wo);
@@ -1209,10 +1210,11 @@ PSDR_HD Vec3<M> wavefront_primary_vertex(const SceneView &sc, const TVT &tv, Tra
 // Wavefront mode, stage k >= 1: the direct step at a path vertex read back from the stream.
 template <class M, class TVT>
 PSDR_HD Vec3<M> wavefront_bounce_vertex(const SceneView &sc, const TVT &tv, TraversalStack &st, const RngJump &jump_k, uint64_t slot,
-                                        const Its<float> &its, uint32_t &nrays, Its<float> &next, Vec3<M> &f, bool &alive) {
+                                        const Its<float> &its, uint32_t &nrays, Its<float> &next, Vec3<M> &f, bool &alive, int *light_tri = nullptr) {
     Rng rng; rng.init(slot, jump_k);
     bool nvalid = false;
-    const Vec3<M> c = direct_step<float, M>(sc, tv, st, rng, its, true, 1, 1, nrays, &next, &f, &nvalid);
+    if (light_tri) *light_tri = -1;
+    const Vec3<M> c = direct_step<float, M>(sc, tv, st, rng, its, true, 1, 1, nrays, &next, &f, &nvalid, light_tri);
     alive = nvalid;
     return c;
 }

@@ -229,6 +229,18 @@ struct TraceQueue {
     int32_t *count;       // [kWfSub * kWfCountStride]
     long long sub_cap;    // requests per sub-queue
 };
+// REC instances of the traced wavefront = the VALUE SWEEP of a split reverse launch (render_rev): every stage leaves, in the per-path record
+// the adjoint kernel reads (psdr_reverse.h RevDisk, cf format), what it evaluated -- the camera stage the primary triangle, bounce stage k
+// (c_k, f_k) and the triangles the vertex' two rays arrived at, the stage a path ends in its vertex count (or -1: a non-finite sample has no
+// gradient, integrator.cpp:87).  Column of a path = its slot index inside the chunk of slots the launch serves.
+struct WfRec {
+    float *disk; long long stride;      // word w of column c at disk[w * stride + c]
+    int spp, s_begin, nsp; long long j0;
+    int stage;                          // vertex this bounce stage evaluates
+    __device__ __forceinline__ long long column(int pixel, uint32_t slot) const {
+        return (long long) pixel * nsp + (long long) (slot - (uint32_t) pixel * (uint32_t) spp - (uint32_t) s_begin) - j0;
+    }
+};
 
 template <class M>
 __device__ __forceinline__ void stream_write(const PathStream &out, long long i, int pixel, uint32_t slot, const Its<float> &next, const Vec3f &dir, const Vec3<M> &beta,
@@ -366,6 +378,7 @@ __device__ __forceinline__ void splat_runs(int pixel, bool valid, const Vec3<M> 
 #pragma unroll
         for (int i = 0; i < NV; ++i) v[i] = 0.f;
     }
+    if (img == nullptr) return;                                     // a reverse launch that does not want the primal image (uniform)
     const bool head = wave_run_sum<NV>(valid ? pixel : -1, v);
     if (head && valid) {
         float *p = img + (size_t) pixel * 3;
@@ -388,10 +401,10 @@ __device__ __forceinline__ void splat_runs(int pixel, bool valid, const Vec3<M> 
 #endif
 // TRACED (two-level scenes, run_camera_wavefront): the stage stops at the primary hit like the binned one, the records go to plain sub-streams and the
 // two rays of bounce stage 0 that enter a tree box become requests of the dense trace kernel (stream_push_traced).
-template <class M, int FL, bool TRACED = false>
+template <class M, int FL, bool TRACED = false, bool REC = false>
 __global__ __launch_bounds__(kBlock, (is_ad<M>() ? 2 : PSDR_WF_WAVES)) void k_wf_camera(LaunchCtx cx, TV<M, FL> tv, int spp, int s_begin, SlotDiv nsp, long long j0, long long n,
                                                         float inv_spp, float *__restrict__ img, float *__restrict__ dimg, long long plane,
-                                                        PathStream out, int want_next, unsigned long long *counters, RngJump jump_next, TraceQueue tq) {
+                                                        PathStream out, int want_next, unsigned long long *counters, RngJump jump_next, TraceQueue tq, WfRec wr) {
     TraversalStack st; setup_lds(cx, st, tv);
     uint32_t nrays = 0;
     const long long nceil = (n + kBlock - 1) / kBlock * kBlock;
@@ -420,6 +433,7 @@ __global__ __launch_bounds__(kBlock, (is_ad<M>() ? 2 : PSDR_WF_WAVES)) void k_wf
         }
         // a path that goes on carries its radiance along; one that ends here is splatted now
         const bool goes_on = want_next && alive;
+        if constexpr (REC) { if (in) wr.disk[jj] = __int_as_float(alive ? next.tri : -1); }          // head word 0: the primary triangle (-1: no gradient)
         splat_runs<M>(pixel, in && !goes_on, zero_nonfinite(r), inv_spp, img, dimg, plane);
         if (want_next) {
             if constexpr (TRACED) {
@@ -438,10 +452,11 @@ __global__ __launch_bounds__(kBlock, (is_ad<M>() ? 2 : PSDR_WF_WAVES)) void k_wf
 // One bounce: block b consumes its share of sub-stream b % kWfSub (grid-stride over the blocks of that
 // sub-stream; gridDim.x is a multiple of kWfSub) and appends the surviving paths to the same sub-stream of `out`.
 // One record of a bounce stage: rebuild the vertex, direct step, splat, push the continuation.
-template <class M, int FL, bool TRACED = false>
+template <class M, int FL, bool TRACED = false, bool REC = false>
 __device__ __forceinline__ void wf_bounce_record(const LaunchCtx &cx, const TV<M, FL> &tv, TraversalStack &st, float inv_spp, float *__restrict__ img,
                                                  float *__restrict__ dimg, long long plane, const PathStream &in, const PathStream &out, int want_next,
-                                                 const RngJump &jump_next, bool live, long long j, long long chunk, uint32_t &nrays, const TraceQueue &tq) {
+                                                 const RngJump &jump_next, bool live, long long j, long long chunk, uint32_t &nrays, const TraceQueue &tq,
+                                                 const WfRec &wr) {
     constexpr int K = ad_traits<M>::K;
     int pixel = -1; uint32_t slot = 0;
     Vec3<M> r = zero3<M>(), beta = zero3<M>();
@@ -482,7 +497,16 @@ __device__ __forceinline__ void wf_bounce_record(const LaunchCtx &cx, const TV<M
             TV<M, FL | kScenePre> tvp;
 #pragma unroll
             for (int k = 0; k < (K > 0 ? K : 1); ++k) tvp.t[k] = tv.t[k];
-            c = wavefront_bounce_vertex<M>(cx.sc, tvp, st, cx.jump, (uint64_t) slot, its, nrays, next, f, alive);
+            int light_tri = -1;
+            c = wavefront_bounce_vertex<M>(cx.sc, tvp, st, cx.jump, (uint64_t) slot, its, nrays, next, f, alive, REC ? &light_tri : nullptr);
+            if constexpr (REC) {
+                // vertex `stage` of this path: (c_k, f_k) and the triangles its two rays arrived at (the adjoint kernel re-intersects those)
+                float *col = wr.disk + wr.column(pixel, slot) + (long long) (kRevDiskHead + wr.stage * kRevDiskPerVertexCf) * wr.stride;
+                const Vec3f cv = val(c), fv = alive ? val(f) : Vec3f(0.f);
+                col[0] = cv.x; col[wr.stride] = cv.y; col[2 * wr.stride] = cv.z;
+                col[3 * wr.stride] = fv.x; col[4 * wr.stride] = fv.y; col[5 * wr.stride] = fv.z;
+                col[6 * wr.stride] = __int_as_float(alive ? next.tri : -1); col[7 * wr.stride] = __int_as_float(light_tri);
+            }
         } else c = wavefront_bounce_vertex<M>(cx.sc, tv, st, cx.jump, (uint64_t) slot, its, nrays, next, f, alive);
         r = acc + beta * c;
         if (alive) {
@@ -493,6 +517,15 @@ __device__ __forceinline__ void wf_bounce_record(const LaunchCtx &cx, const TV<M
         }
     }
     const bool goes_on = want_next && alive;
+    if constexpr (REC) {
+        if (live && !goes_on) {
+            // the path ends at this vertex: its vertex count; a non-finite sample is zeroed as a whole and has no gradient
+            const Vec3f rv = val(r);
+            float *col = wr.disk + wr.column(pixel, slot);
+            if (isfinite(rv.x) && isfinite(rv.y) && isfinite(rv.z)) col[wr.stride] = __int_as_float(wr.stage + 1);
+            else col[0] = __int_as_float(-1);
+        }
+    }
     splat_runs<M>(pixel, live && !goes_on, zero_nonfinite(r), inv_spp, img, dimg, plane);
     if (want_next) {
         if constexpr (TRACED) {
@@ -510,10 +543,10 @@ __device__ __forceinline__ void wf_bounce_record(const LaunchCtx &cx, const TV<M
 // sub-stream; gridDim.x is a multiple of kWfSub) and appends the surviving paths to the same sub-stream of `out`.
 // Binned streams: the 64 sub-streams form one list of 256-record chunks (expensive classes first) that the workgroups
 // grab kWfGrab at a time from one counter.
-template <class M, int FL, bool TRACED = false>
+template <class M, int FL, bool TRACED = false, bool REC = false>
 __global__ __launch_bounds__(kBlock, (is_ad<M>() ? 2 : (TRACED ? PSDR_WF_WAVES_T : PSDR_WF_WAVES))) void k_wf_bounce(LaunchCtx cx, TV<M, FL> tv, float inv_spp, float *__restrict__ img,
                                                         float *__restrict__ dimg, long long plane, PathStream in,
-                                                        PathStream out, int want_next, unsigned long long *counters, RngJump jump_next, TraceQueue tq) {
+                                                        PathStream out, int want_next, unsigned long long *counters, RngJump jump_next, TraceQueue tq, WfRec wr) {
     TraversalStack st; setup_lds(cx, st, tv);
     uint32_t nrays = 0;
     bool binned = false;
@@ -542,7 +575,7 @@ __global__ __launch_bounds__(kBlock, (is_ad<M>() ? 2 : (TRACED ? PSDR_WF_WAVES_T
                 while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_pref[mid + 1] <= c) lo = mid + 1; else hi = mid; }
                 const int off = (c - s_pref[lo]) * kBlock + (int) threadIdx.x;
                 const bool live = off < in.count[lo * kWfCountStride];
-                wf_bounce_record<M, FL, false>(cx, tv, st, inv_spp, img, dimg, plane, in, out, want_next, jump_next, live, (long long) lo * in.sub_cap + off, c, nrays, tq);
+                wf_bounce_record<M, FL, false, false>(cx, tv, st, inv_spp, img, dimg, plane, in, out, want_next, jump_next, live, (long long) lo * in.sub_cap + off, c, nrays, tq, wr);
             }
         }
     } else {
@@ -550,8 +583,8 @@ __global__ __launch_bounds__(kBlock, (is_ad<M>() ? 2 : (TRACED ? PSDR_WF_WAVES_T
         const long long in_base = (long long) sub * in.sub_cap;
         const int n = in.count[sub * kWfCountStride];
         for (int base = (blockIdx.x / kWfSub) * kBlock; base < n; base += per * kBlock)
-            wf_bounce_record<M, FL, TRACED>(cx, tv, st, inv_spp, img, dimg, plane, in, out, want_next, jump_next, base + (int) threadIdx.x < n, in_base + base + threadIdx.x,
-                                            base / kBlock, nrays, tq);
+            wf_bounce_record<M, FL, TRACED, REC>(cx, tv, st, inv_spp, img, dimg, plane, in, out, want_next, jump_next, base + (int) threadIdx.x < n, in_base + base + threadIdx.x,
+                                                 base / kBlock, nrays, tq, wr);
     }
     count_rays(counters, nrays);
 }
@@ -884,7 +917,7 @@ template <int FL, bool GEO, int INTEG> constexpr int rev_waves() {
 template <int FL, bool GEO, int INTEG, int STAGE = 0>
 __global__ __launch_bounds__(kBlock, (STAGE == 1 ? PSDR_WAVES_REV_VALUE : rev_waves<FL, GEO, INTEG>())) void k_camera_rev(LaunchCtx cx, DeviceSink<FL> sink_arg, int spp, int s_begin, SlotDiv nsp, long long j0,
                                                        long long n, float inv_spp, const float *__restrict__ adj_img, float *__restrict__ img,
-                                                       unsigned long long *counters, float *__restrict__ disk, long long disk_stride, float *__restrict__ deep) {
+                                                       unsigned long long *counters, float *__restrict__ disk, long long disk_stride, float *__restrict__ deep, int disk_cf) {
     TraversalStack st; setup_lds(cx, st);
     typename std::conditional<reg_priv_kernel<FL, GEO, INTEG>() && STAGE != 1, RegPrivSink<FL>, DeviceSink<FL> &>::type sink(sink_arg);
     if (STAGE != 1) sink.begin(dyn_lds_floats(cx.off_sink));
@@ -906,7 +939,7 @@ __global__ __launch_bounds__(kBlock, (STAGE == 1 ? PSDR_WAVES_REV_VALUE : rev_wa
             const uint64_t slot = (uint64_t) pixel * (uint64_t) spp + (uint64_t) s;
             const float *a = adj_img + (size_t) pixel * 3;
             const Vec3f adj{a[0] * inv_spp, a[1] * inv_spp, a[2] * inv_spp};
-            const RevDisk dk{disk + jj, disk_stride};
+            const RevDisk dk{disk + jj, disk_stride, disk_cf};
             const Vec3f r = camera_sample_reverse<GEO, INTEG, STAGE>(sink, pg, rec, cx.sc, st, cx.lp, cx.jump, pixel, slot, adj, nrays, dk);
             v[0] = r.x * inv_spp; v[1] = r.y * inv_spp; v[2] = r.z * inv_spp;
         }
@@ -1043,13 +1076,17 @@ int run_camera(psdr_scene_s *h, const psdr_render_opts *o, const TV<R, FL> &tv, 
 // with plain-fp32 geometry.
 constexpr long long kWfChunk = 1ll << 25;
 constexpr int kWfMaxDepth = 256;         // counter sets (use_wavefront: max_depth <= 250)
+// rec != nullptr: the launch is the VALUE SWEEP of a split reverse launch over the slots [rec->c0, rec->c0 + rec->nc) of the shard -- the traced
+// wavefront with REC kernels that leave the per-path records the adjoint kernel reads (WfRec); float only, two-level scenes only.
+struct WfRecArgs { float *disk; long long stride, c0, nc; };
 template <class M, int FL>
-int run_camera_wavefront(psdr_scene_s *h, const psdr_render_opts *o, const TV<M, FL> &tv, float *img, float *dimg, hipStream_t s) {
+int run_camera_wavefront(psdr_scene_s *h, const psdr_render_opts *o, const TV<M, FL> &tv, float *img, float *dimg, hipStream_t s, const WfRecArgs *rec = nullptr) {
     constexpr int K = ad_traits<M>::K;
     const long long WH = (long long) h->desc.width * h->desc.height;
     const int nsp = o->spp_end - o->spp_begin;
     if (o->spp <= 0 || nsp <= 0) return 0;
-    const long long n = WH * nsp;
+    const long long n_all = WH * nsp;
+    const long long n = rec ? rec->nc : n_all;
     // class-binned streams pay where most paths survive every bounce (rooms); in an open scene the streams thin out quickly and the 64
     // sub-streams of mostly empty chunks cost more than the classes save (bunny_light PathTracer(3) 4.9 against 3.3 ms plain,
     // PathTracer(6) 8.7 against 3.6)
@@ -1090,10 +1127,11 @@ int run_camera_wavefront(psdr_scene_s *h, const psdr_render_opts *o, const TV<M,
     }
     TraceQueue tq{};
     tq.req = traced ? reinterpret_cast<float4 *>(reinterpret_cast<char *>(h->d_ws) + cnt_bytes + 2 * words * 4 * (size_t) cap_alloc) : nullptr;
-    h->slots[0] += (uint64_t) n;
+    if (!rec) h->slots[0] += (uint64_t) n;
     const float inv_spp = 1.f / (float) o->spp;
-    for (long long j0 = 0; j0 < n; j0 += cap) {
-        const long long cn = std::min(cap, n - j0);
+    const long long j_first = rec ? rec->c0 : 0;
+    for (long long j0 = j_first; j0 < j_first + n; j0 += cap) {
+        const long long cn = std::min(cap, j_first + n - j0);
         LaunchCtx cx;
         if (int rc = make_ctx(h, o, 0, cx)) return rc;
         HIP_TRY(hipMemsetAsync(cnt, 0, (size_t) (std::min(depth, kWfMaxDepth) + 1) * kWfStageInts * sizeof(int32_t), s));
@@ -1113,16 +1151,32 @@ int run_camera_wavefront(psdr_scene_s *h, const psdr_render_opts *o, const TV<M,
                 plan_lds(h, cxp, 1 << 30);
                 cxp.sc.n_lnodes = cxp.sc.n_lbtris = cxp.sc.n_ltri = 0;
                 const int dyn_p = cxp.off_stack;
+                WfRec wr{};
+                bool recording = false;
+                if constexpr (K == 0) {
+                    if (rec) { recording = true; wr = WfRec{rec->disk + (j0 - rec->c0), rec->stride, o->spp, o->spp_begin, nsp, j0, 0}; }
+                }
+                if (recording) {
+                    if constexpr (K == 0)
+                        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wf_camera<M, FL, true, true>), dim3(blocks), dim3(kBlock), lds_bytes(cx, h), s, cx, tv, o->spp, o->spp_begin, nsp, j0, cn,
+                                           inv_spp, img, dimg, WH * 3, st[0], 1, h->d_counters, make_rng_jump(o->rng_offset[0] + 2), tq, wr);
+                } else
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wf_camera<M, FL, true>), dim3(blocks), dim3(kBlock), lds_bytes(cx, h), s, cx, tv, o->spp, o->spp_begin, nsp, j0, cn,
-                                   inv_spp, img, dimg, WH * 3, st[0], 1, h->d_counters, make_rng_jump(o->rng_offset[0] + 2), tq);
+                                   inv_spp, img, dimg, WH * 3, st[0], 1, h->d_counters, make_rng_jump(o->rng_offset[0] + 2), tq, wr);
                 HIP_TRY(hipGetLastError());
                 for (int k = 0; k < depth; ++k) {
                     if (int rc = launch_wf_trace(h, tq.req, tq.count, tq.sub_cap, st[k & 1].hit, s)) return rc;
                     st[(k + 1) & 1].count = cnt + (size_t) (k + 1) * kWfStageInts;
                     tq.count = req_cnt + (size_t) (k + 1) * kWfSub * kWfCountStride;
                     cxp.jump = make_rng_jump(o->rng_offset[0] + 2 + 5 * (uint64_t) k);
+                    wr.stage = k;
+                    if (recording) {
+                        if constexpr (K == 0)
+                            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wf_bounce<M, FL, true, true>), dim3(blocks), dim3(kBlock), dyn_p, s, cxp, tv, inv_spp, img, dimg, WH * 3,
+                                               st[k & 1], st[(k + 1) & 1], k + 1 < depth ? 1 : 0, h->d_counters, make_rng_jump(o->rng_offset[0] + 2 + 5 * (uint64_t) (k + 1)), tq, wr);
+                    } else
                     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wf_bounce<M, FL, true>), dim3(blocks), dim3(kBlock), dyn_p, s, cxp, tv, inv_spp, img, dimg, WH * 3,
-                                       st[k & 1], st[(k + 1) & 1], k + 1 < depth ? 1 : 0, h->d_counters, make_rng_jump(o->rng_offset[0] + 2 + 5 * (uint64_t) (k + 1)), tq);
+                                       st[k & 1], st[(k + 1) & 1], k + 1 < depth ? 1 : 0, h->d_counters, make_rng_jump(o->rng_offset[0] + 2 + 5 * (uint64_t) (k + 1)), tq, wr);
                     HIP_TRY(hipGetLastError());
                 }
                 continue;
@@ -1132,25 +1186,25 @@ int run_camera_wavefront(psdr_scene_s *h, const psdr_render_opts *o, const TV<M,
             // camera stage = primary hit only; the direct step at the primary vertex is bounce stage 0 (binned like the rest):
             // stage k reads stream k & 1 (counter set k) and appends to stream (k + 1) & 1 (set k + 1)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wf_camera<M, FL>), dim3(blocks), dim3(kBlock), lds_bytes(cx, h), s, cx, tv, o->spp, o->spp_begin, nsp, j0, cn,
-                               inv_spp, img, dimg, WH * 3, st[0], 1, h->d_counters, make_rng_jump(o->rng_offset[0] + 2), tq);
+                               inv_spp, img, dimg, WH * 3, st[0], 1, h->d_counters, make_rng_jump(o->rng_offset[0] + 2), tq, WfRec{});
             HIP_TRY(hipGetLastError());
             for (int k = 0; k < depth; ++k) {
                 st[(k + 1) & 1].count = cnt + (size_t) (k + 1) * kWfStageInts;
                 cx.jump = make_rng_jump(o->rng_offset[0] + 2 + 5 * (uint64_t) k);
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wf_bounce<M, FL>), dim3(blocks), dim3(kBlock), lds_bytes(cx, h), s, cx, tv, inv_spp, img, dimg, WH * 3,
-                                   st[k & 1], st[(k + 1) & 1], k + 1 < depth ? 1 : 0, h->d_counters, make_rng_jump(o->rng_offset[0] + 2 + 5 * (uint64_t) (k + 1)), tq);
+                                   st[k & 1], st[(k + 1) & 1], k + 1 < depth ? 1 : 0, h->d_counters, make_rng_jump(o->rng_offset[0] + 2 + 5 * (uint64_t) (k + 1)), tq, WfRec{});
                 HIP_TRY(hipGetLastError());
             }
             continue;
         }
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wf_camera<M, FL>), dim3(blocks), dim3(kBlock), lds_bytes(cx, h), s, cx, tv, o->spp, o->spp_begin, nsp, j0, cn,
-                           inv_spp, img, dimg, WH * 3, st[0], depth > 1 ? 1 : 0, h->d_counters, make_rng_jump(o->rng_offset[0] + 2 + 5), tq);
+                           inv_spp, img, dimg, WH * 3, st[0], depth > 1 ? 1 : 0, h->d_counters, make_rng_jump(o->rng_offset[0] + 2 + 5), tq, WfRec{});
         HIP_TRY(hipGetLastError());
         for (int k = 1; k < depth; ++k) {
             st[k & 1].count = cnt + (size_t) k * kWfStageInts;      // a fresh (zeroed) counter set per stage
             cx.jump = make_rng_jump(o->rng_offset[0] + 2 + 5 * (uint64_t) k);
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wf_bounce<M, FL>), dim3(blocks), dim3(kBlock), lds_bytes(cx, h), s, cx, tv, inv_spp, img, dimg, WH * 3,
-                               st[(k - 1) & 1], st[k & 1], k + 1 < depth ? 1 : 0, h->d_counters, make_rng_jump(o->rng_offset[0] + 2 + 5 * (uint64_t) (k + 1)), tq);
+                               st[(k - 1) & 1], st[k & 1], k + 1 < depth ? 1 : 0, h->d_counters, make_rng_jump(o->rng_offset[0] + 2 + 5 * (uint64_t) (k + 1)), tq, WfRec{});
             HIP_TRY(hipGetLastError());
         }
     }
@@ -1293,11 +1347,17 @@ int render_rev(psdr_scene_s *h, const psdr_render_opts *o, const float *adj_img,
 #define PSDR_LAUNCH_REV_K(GEO, INTEG, STAGE, CX, BYTES, J0, N, IMG, DISK, STRIDE)                                                    \
         do { if ((BYTES) > 48 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_camera_rev<FL, GEO, INTEG, STAGE>), hipFuncAttributeMaxDynamicSharedMemorySize, (BYTES))); \
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_camera_rev<FL, GEO, INTEG, STAGE>), dim3(launch_blocks(h, (N))), dim3(kBlock), (BYTES), s, CX, sink, \
-                           o->spp, o->spp_begin, nsp, (long long) (J0), (long long) (N), 1.f / (float) o->spp, adj_img, IMG, h->d_counters, DISK, (long long) (STRIDE), deep); } while (0)
+                           o->spp, o->spp_begin, nsp, (long long) (J0), (long long) (N), 1.f / (float) o->spp, adj_img, IMG, h->d_counters, DISK, (long long) (STRIDE), deep, disk_cf); } while (0)
 #define PSDR_LAUNCH_REV(GEO, INTEG) PSDR_LAUNCH_REV_K(GEO, INTEG, 0, cx, dyn_bytes, 0, n, out_img, (float *) nullptr, 0)
+        // the value sweep of a split PathTracer launch on a two-level scene runs as the TRACED WAVEFRONT (dense trace kernel between the stages):
+        // in the fused value kernel a wave pays its slowest lane's tree walk at every closest_hit (C4 shard: 29 ms of the 57; renderC by the
+        // wavefront: 16 ms)
+        bool wf_value = false;
+        if constexpr ((FL & kSceneForest) != 0) wf_value = split && !no_tree && o->integrator == PSDR_INTEGRATOR_PATH && !deep_rec && traced_wavefront(h) && use_wavefront(h, o);
+        const int disk_cf = wf_value ? 1 : 0;
         if (split) {
-            // records of one chunk of slots live in a scratch buffer (2 + 5 depth words per slot); chunks bound its size
-            const int words = kRevDiskHead + kRevDiskPerVertex * depth;
+            // records of one chunk of slots live in a scratch buffer (2 + 5 depth words per slot; 2 + 8 depth from the wavefront); chunks bound its size
+            const int words = kRevDiskHead + (wf_value ? kRevDiskPerVertexCf : kRevDiskPerVertex) * depth;
             const long long chunk = std::min<long long>(n, 1ll << 24);
             const size_t need = (size_t) chunk * words * sizeof(float);
             if (need > h->rev_bytes) {
@@ -1310,6 +1370,13 @@ int render_rev(psdr_scene_s *h, const psdr_render_opts *o, const float *adj_img,
             for (long long c0 = 0; c0 < n; c0 += chunk) {
                 const long long nc = std::min(chunk, n - c0);
                 if (o->integrator == PSDR_INTEGRATOR_PATH) {
+                    if (wf_value) {
+                        if constexpr ((FL & kSceneForest) != 0) {
+                            const TangentView<0, FL> tv0{};
+                            const WfRecArgs ra{disk, chunk, c0, nc};
+                            if (int rc = run_camera_wavefront<float, FL>(h, o, tv0, out_img, nullptr, s, &ra)) return rc;
+                        }
+                    } else
                     PSDR_LAUNCH_REV_K(true, PSDR_INTEGRATOR_PATH, 1, cx, dyn1, c0, nc, out_img, disk, chunk);
                     PSDR_LAUNCH_REV_K(true, PSDR_INTEGRATOR_PATH, 2, cx2, dyn_bytes, c0, nc, (float *) nullptr, disk, chunk);
                 } else {

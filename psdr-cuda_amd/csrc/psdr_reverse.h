@@ -482,9 +482,11 @@ struct PathRec {
 // Split reverse launch (tree scenes): the value sweep runs as its own kernel at the occupancy of a forward kernel and leaves,
 // per path, what the adjoint kernel needs instead of tracing again -- the primary triangle, the number of vertices, and per
 // vertex the suffix radiance T_{k+1} and the two triangles its rays arrived at.  One column per path, word w at p[w * stride].
-constexpr int kRevDiskHead = 2, kRevDiskPerVertex = 5;
+// cf = 1 (the value sweep ran as the TRACED WAVEFRONT, psdr_kernels.h): per vertex (c_k, f_k, tri, tri) as the stage that evaluated the vertex
+// left them; the adjoint kernel forms the suffix radiances itself.
+constexpr int kRevDiskHead = 2, kRevDiskPerVertex = 5, kRevDiskPerVertexCf = 8;
 struct RevDisk {
-    float *p; long long stride;
+    float *p; long long stride; int cf = 0;
     PSDR_HD void put(int w, float v) const { p[(long long) w * stride] = v; }
     PSDR_HD float get(int w) const { return p[(long long) w * stride]; }
     PSDR_HD void puti(int w, int v) const { put(w, __int_as_float_hd(v)); }
@@ -958,6 +960,17 @@ PSDR_HD Vec3f camera_sample_reverse(RealSink &real_sink, PrimaryGrad &pg, PathRe
         return result;
     }
     if constexpr (STAGE == 2) {
+        if (disk.cf) {
+            // records of the wavefront value sweep: (c_k, f_k) per vertex -> suffix radiances T_{k+1} in place of c_k, as sweep 1 leaves them
+            Vec3f T(0.f);
+            for (int k = nv - 1; k >= 0; --k) {
+                const int w = kRevDiskHead + k * kRevDiskPerVertexCf;
+                const Vec3f ck{disk.get(w), disk.get(w + 1), disk.get(w + 2)}, fk{disk.get(w + 3), disk.get(w + 4), disk.get(w + 5)};
+                rec.put(k, 0, T.x); rec.put(k, 1, T.y); rec.put(k, 2, T.z);
+                rec.put_tri(k, 0, disk.geti(w + 6)); rec.put_tri(k, 1, disk.geti(w + 7));
+                T = ck + fk * T;
+            }
+        } else
         for (int k = 0; k < nv; ++k) {
             const int w = kRevDiskHead + k * kRevDiskPerVertex;
             rec.put(k, 0, disk.get(w)); rec.put(k, 1, disk.get(w + 1)); rec.put(k, 2, disk.get(w + 2));
