@@ -112,7 +112,7 @@ template <int K, int FLAGS = kSceneRough> struct TangentView {
 };
 
 struct Hit { int tri; float u, v, t; };
-constexpr int kPreBsdfRay = 0, kPreLightRay = 1;     // TraversalStack::pre slots of the two rays of a path vertex (direct_step)
+constexpr int kPreBsdfRay = 0, kPreLightRay = 1, kPrePrimaryRay = 2;     // TraversalStack::pre slots: the two rays of a path vertex (direct_step), the ray that found the vertex (Li)
 
 // ------------------------------------------------------------------------ small-table access
 // The tables a path vertex looks up besides its TriangleInfo row.  Instances compiled for kSceneTiny read LDS copies of ALL of them (the launch
@@ -146,7 +146,7 @@ template <int FL> struct Tab {
 // a plain array on the host (tests).
 struct TraversalStack {
     // kScenePre instances: the closest TREE hits of the vertex' two rays (tri < 0: none), found beforehand by the dense trace kernel
-    Hit pre[2];
+    Hit pre[3];
 #if defined(__HIP_DEVICE_COMPILE__)
     int32_t *base;   // &lds[threadIdx.x], stride kBlock
     __device__ __forceinline__ void put(int i, int32_t v) { base[i * kBlock] = v; }
@@ -1367,10 +1367,35 @@ PSDR_HD bool secondary_edge_survives(const SceneView &sc, TraversalStack &st, co
     const Vec3f dir = normalize(p2 - p0);
     const bool skip = sc.d.sec_edge_faces != nullptr && !sc.literal_forms;
     const int f0 = skip ? sc.d.sec_edge_faces[2 * k] : -1, f1 = skip ? sc.d.sec_edge_faces[2 * k + 1] : -1;
-    const Its<float> its2 = intersect<float>(sc, tv0, st, RayT<float>{p0, dir}, valid, kDetached, nrays, f0, f1);
+    const Its<float> its2 = intersect<float>(sc, tv0, st, RayT<float>{p0, dir}, valid, kDetached, nrays, f0, f1, 0);
     valid = valid && its2.valid && norm(its2.p - p2) < kShadowEpsilon;
-    const Its<float> its1c = intersect<float>(sc, tv0, st, RayT<float>{p0, -dir}, valid, kDetached, nrays, f0, f1);
+    const Its<float> its1c = intersect<float>(sc, tv0, st, RayT<float>{p0, -dir}, valid, kDetached, nrays, f0, f1, 1);
     return valid && its1c.valid;
+}
+
+// What the dense trace kernel needs of a secondary-edge slot BEFORE that test (the probe pass of a traced launch, psdr_kernels.h k_se_probe): the
+// geometric part of the decision, the edge point, the direction towards the emitter sample and the edge (its adjacent faces are skipped by
+// both rays).  The same draws and the same arithmetic as secondary_edge_survives.
+template <int FL>
+PSDR_HD bool secondary_edge_rays(const SceneView &sc, const float s3[3], Vec3f &p0, Vec3f &dir, int &edge) {
+    const TangentView<0, FL> tv0{};
+    float s1 = s3[0], pdf0;
+    const int k = sample_reuse(sc.d.sec_cmf, sc.d.sec_pmf, sc.d.sec_sum, sc.d.num_sec_edges, s1, pdf0);
+    const float *se = sc.d.sec_edge + (size_t) k * PSDR_SEDGE_STRIDE;
+    const Vec3f ep0{se[0], se[1], se[2]}, ee1{se[3], se[4], se[5]}, n0{se[6], se[7], se[8]}, n1{se[9], se[10], se[11]};
+    const bool is_boundary = se[15] != 0.f;
+    p0 = ee1 * s1 + ep0;
+    const PosSample<float> ps2 = sample_emitter_position<float>(sc, tv0, p0, s3[1], s3[2], false);
+    const Vec3f p2 = ps2.p, bn = ps2.n;
+    Vec3f e = p2 - p0;
+    const float distSqr = dot(e, e);
+    e = e / sqrtf(fmaxf(distSqr, 0.f));
+    const float cosTheta = -dot(bn, e);
+    const float d0n = dot(n0, e), d1n = dot(n1, e);
+    const int sgn0 = d0n > kEdgeEpsilon ? 1 : (d0n < -kEdgeEpsilon ? -1 : 0), sgn1 = d1n > kEdgeEpsilon ? 1 : (d1n < -kEdgeEpsilon ? -1 : 0);
+    dir = normalize(p2 - p0);
+    edge = (sc.d.sec_edge_faces != nullptr && !sc.literal_forms) ? k : -1;
+    return cosTheta > kEpsilon && (is_boundary ? sgn0 != 0 : sgn0 * sgn1 < 0);
 }
 
 template <class R, class TVT>

@@ -55,6 +55,7 @@ struct TraceArgs {
     float4 blas_lo[kMaxBlas], blas_hi[kMaxBlas];      // hi.w = root of the tree in the 4-wide node array
     const Bvh4Node *nodes4; const float4 *btris;
     const float4 *req; const int32_t *count; float4 *hit; int32_t *ovf;
+    const int32_t *sec_edge_faces;     // IGN instances: a request whose second row carries a secondary-edge index skips that edge's two faces
     long long sub_cap;
     int32_t n_blas, n_lnodes, off_stack, stack_entries, ovf_stride;
 };
@@ -63,7 +64,8 @@ static_assert(offsetof(TraceArgs, blas_lo) == 0, "k_wf_trace reads the boxes thr
 // MULTI: more than one tree (nearest box first, the remaining boxes re-tested against the current hit after every walk, as closest_hit does);
 // OVF: the worst-case stack of the forest is deeper than the LDS columns -- entries beyond them live in a per-lane global column (rare: the deepest
 // stack of a ray on the bunny / the interior is 11 of 24 / 22 possible entries).
-template <bool MULTI, bool OVF>
+// IGN: rays that start ON a secondary edge (the probe pass of a traced secondary-edge launch): rb.w = the edge, its adjacent faces are not hit.
+template <bool MULTI, bool OVF, bool IGN = false>
 __global__ __launch_bounds__(kTraceBlock) void k_wf_trace(TraceArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int32_t kDone = 0x7fffffff;
@@ -96,6 +98,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_wf_trace(TraceArgs a) {
     Vec3f o(0.f), d(0.f), inv(0.f);
     Hit best; best.tri = -1; best.u = best.v = -1.f; best.t = INFINITY;
     uint32_t dest = 0, cand = 0;
+    int ig0 = -1, ig1 = -1;
     int32_t cur = kDone;                                           // >= 0: inner node, < 0: leaf, kDone: between trees / finished / idle
     int sp = 0, li = 0;                                            // li: next triangle of the leaf in `cur`
     float4 ra{0.f, 0.f, 0.f, 0.f}, rb{0.f, 0.f, 0.f, 0.f};        // this lane's request of the wave's current block
@@ -139,7 +142,10 @@ __global__ __launch_bounds__(kTraceBlock) void k_wf_trace(TraceArgs a) {
                 const int from = (consumed + rank) & 63;
                 const float ox = __shfl(ra.x, from, 64), oy = __shfl(ra.y, from, 64), oz = __shfl(ra.z, from, 64), dw = __shfl(ra.w, from, 64);
                 const float dx = __shfl(rb.x, from, 64), dy = __shfl(rb.y, from, 64), dz = __shfl(rb.z, from, 64);
+                int edge = -1;
+                if (IGN) edge = __float_as_int(__shfl(rb.w, from, 64));
                 if (!active && rank < take) {
+                    if (IGN) { ig0 = ig1 = -1; if (edge >= 0) { ig0 = a.sec_edge_faces[2 * edge]; ig1 = a.sec_edge_faces[2 * edge + 1]; } }
                     o = Vec3f{ox, oy, oz}; d = Vec3f{dx, dy, dz}; inv = Vec3f{1.f / dx, 1.f / dy, 1.f / dz};
                     dest = (uint32_t) __float_as_int(dw);
                     best.tri = -1; best.u = best.v = -1.f; best.t = INFINITY;
@@ -225,8 +231,8 @@ __global__ __launch_bounds__(kTraceBlock) void k_wf_trace(TraceArgs a) {
                 const float4 *bt = a.btris + (size_t) (first + li) * 3, *bu = a.btris + (size_t) (first + j) * 3;
                 const float4 a0 = bt[0], b0 = bt[1], c0 = bt[2];
                 const float4 a1 = bu[0], b1 = bu[1], c1 = bu[2];
-                leaf_triangle_test<false>(a0, b0, c0, o, d, best);
-                leaf_triangle_test<false>(a1, b1, c1, o, d, best);
+                leaf_triangle_test<IGN>(a0, b0, c0, o, d, best, ig0, ig1);
+                leaf_triangle_test<IGN>(a1, b1, c1, o, d, best, ig0, ig1);
                 li += 2;
                 if (li >= cnt) { pop(); li = 0; }
             }
@@ -806,8 +812,10 @@ int bvh4_build(psdr_scene_s *h, const std::vector<BvhNode> &nodes, const std::ve
 
 // ---- the dense trace kernel of the traced wavefront
 bool traced_wavefront(const psdr_scene_s *h) { return h->traced_enabled && h->n_blas > 0 && h->num_nodes4 > 0 && h->d_nodes4 != nullptr; }
-int launch_wf_trace(psdr_scene_s *h, const float4 *req, const int32_t *count, long long sub_cap, float4 *hit, hipStream_t s) {
+int launch_wf_trace(psdr_scene_s *h, const float4 *req, const int32_t *count, long long sub_cap, float4 *hit, hipStream_t s, bool ign) {
     TraceArgs a{};
+    a.sec_edge_faces = h->desc.sec_edge_faces;
+    if (ign && !a.sec_edge_faces) ign = false;
     std::memcpy(a.blas_lo, h->blas_lo, sizeof(a.blas_lo));
     std::memcpy(a.blas_hi, h->blas_hi, sizeof(a.blas_hi));
     for (int k = 0; k < h->n_blas; ++k) std::memcpy(&a.blas_hi[k].w, &h->blas_root4[k], 4);
@@ -833,14 +841,39 @@ int launch_wf_trace(psdr_scene_s *h, const float4 *req, const int32_t *count, lo
         a.ovf = h->d_trace_ovf;
     }
     const int dyn = a.off_stack + stack_bytes;
-#define PSDR_LAUNCH_TRACE(MULTI, OVF)                                                                                                                       \
+#define PSDR_LAUNCH_TRACE_I(MULTI, OVF, IGN)                                                                                                                \
     do { static bool attr_set = false;                                                                                                                      \
-         if (!attr_set) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wf_trace<MULTI, OVF>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024)); attr_set = true; } \
-         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wf_trace<MULTI, OVF>), dim3(grid), dim3(kTraceBlock), dyn, s, a); } while (0)
+         if (!attr_set) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wf_trace<MULTI, OVF, IGN>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024)); attr_set = true; } \
+         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wf_trace<MULTI, OVF, IGN>), dim3(grid), dim3(kTraceBlock), dyn, s, a); } while (0)
+#define PSDR_LAUNCH_TRACE(MULTI, OVF) do { if (ign) PSDR_LAUNCH_TRACE_I(MULTI, OVF, true); else PSDR_LAUNCH_TRACE_I(MULTI, OVF, false); } while (0)
     if (h->n_blas > 1) { if (ovf) PSDR_LAUNCH_TRACE(true, true); else PSDR_LAUNCH_TRACE(true, false); }
     else { if (ovf) PSDR_LAUNCH_TRACE(false, true); else PSDR_LAUNCH_TRACE(false, false); }
+#undef PSDR_LAUNCH_TRACE_I
 #undef PSDR_LAUNCH_TRACE
     HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// hit rows [slots * rays_per_slot], one mask word per slot, the request queue (64 sub-queues, every ray can be a request) and its counters (zeroed here)
+int probe_buffers(psdr_scene_s *h, long long slots, int rays_per_slot, ProbeBuffers &pb, hipStream_t s) {
+    const long long rays = slots * rays_per_slot;
+    const long long blocks = ((long long) launch_blocks(h, slots) + kWfSub - 1) / kWfSub * kWfSub;
+    const long long trips = (slots + blocks * kBlock - 1) / (blocks * kBlock);
+    pb.sub_cap = (blocks / kWfSub) * trips * kBlock * rays_per_slot;          // block b appends to queue b % kWfSub
+    const size_t cnt_bytes = (size_t) kWfSub * kWfCountStride * sizeof(int32_t);
+    const size_t need = cnt_bytes + (size_t) rays * sizeof(float4) + (((size_t) slots * 4 + 255) & ~(size_t) 255) + (size_t) 2 * pb.sub_cap * kWfSub * sizeof(float4);
+    if (need > h->probe_bytes) {
+        if (h->d_probe) (void) hipFree(h->d_probe);
+        h->d_probe = nullptr; h->probe_bytes = 0;
+        HIP_TRY(hipMalloc(&h->d_probe, need));
+        h->probe_bytes = need;
+    }
+    char *p = reinterpret_cast<char *>(h->d_probe);
+    pb.count = reinterpret_cast<int32_t *>(p); p += cnt_bytes;
+    pb.hit = reinterpret_cast<float4 *>(p); p += (size_t) rays * sizeof(float4);
+    pb.mask = reinterpret_cast<uint32_t *>(p); p += ((size_t) slots * 4 + 255) & ~(size_t) 255;
+    pb.req = reinterpret_cast<float4 *>(p);
+    HIP_TRY(hipMemsetAsync(pb.count, 0, cnt_bytes, s));
     return 0;
 }
 
@@ -907,6 +940,7 @@ int psdr_scene_set_option(psdr_scene_t h, const char *name, double value) {
     else if (n == "sink_private") h->opt.sink_private = iv;
     else if (n == "rev_split") h->opt.rev_split = iv;
     else if (n == "sedge_split") h->opt.sedge_split = iv;
+    else if (n == "probe") h->opt.probe = iv;
     else if (n == "bvh_maxleaf") h->opt.bvh_maxleaf = std::max(1, std::min(8, iv));
     else if (n == "bvh_tcost") h->opt.bvh_tcost = (float) value;
     else return fail("psdr_scene_set_option: unknown option '" + n + "'");
@@ -934,6 +968,7 @@ int psdr_scene_destroy(psdr_scene_t h) {
     if (h->d_rev_deep) (void) hipFree(h->d_rev_deep);
     if (h->d_pe_rep) (void) hipFree(h->d_pe_rep);
     if (h->d_trace_ovf) (void) hipFree(h->d_trace_ovf);
+    if (h->d_probe) (void) hipFree(h->d_probe);
     delete h;
     return 0;
 }

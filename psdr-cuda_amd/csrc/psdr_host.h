@@ -153,6 +153,7 @@ struct psdr_scene_options {
     int sink_private = 1;                  // lane-private accumulators for the emitter's rows
     int rev_split = -1;                    // reverse mode as value kernel + adjoint kernel: 1 / 0 force, -1 by scene and launch size
     int sedge_split = -1;                  // secondary-edge term as filter + survivor kernel: 1 / 0 force, -1 from 2^18 slots
+    int probe = 1;                         // two-level scenes: fused kernels as probe pass + dense trace kernel + final pass where that is built (0: one kernel)
     int bvh_maxleaf = 4;                   // host SAH builder: leaf size limit (1..8)
     float bvh_tcost = 2.0f;                //                   cost of a node visit in triangle tests
 };
@@ -247,6 +248,9 @@ struct psdr_scene_s {
     // wavefront PathTracer: path-state streams + stream counters
     void *d_ws = nullptr;
     size_t ws_bytes = 0;
+    // probe / final launches: hit rows, masks, trace requests
+    void *d_probe = nullptr;
+    size_t probe_bytes = 0;
 };
 
 constexpr int kRayCounters = 64, kRayCounterStride = 16;     // d_counters: 64 counters, 128 bytes apart
@@ -264,7 +268,10 @@ int make_ctx(psdr_scene_s *h, const psdr_render_opts *o, int sampler, LaunchCtx 
 bool use_wavefront(const psdr_scene_s *h, const psdr_render_opts *o);
 // traced wavefront (psdr_hip.hip k_wf_trace): the scene has a two-level tree whose 4-wide forest is on the device
 bool traced_wavefront(const psdr_scene_s *h);
-int launch_wf_trace(psdr_scene_s *h, const float4 *req, const int32_t *count, long long sub_cap, float4 *hit, hipStream_t s);
+int launch_wf_trace(psdr_scene_s *h, const float4 *req, const int32_t *count, long long sub_cap, float4 *hit, hipStream_t s, bool ign = false);
+// Probe / final launches of the fused kernels on two-level scenes (psdr_kernels.h): the buffers between the probe pass, the trace kernel and the final pass
+struct ProbeBuffers { float4 *hit; uint32_t *mask; float4 *req; int32_t *count; long long sub_cap; };
+int probe_buffers(psdr_scene_s *h, long long slots, int rays_per_slot, ProbeBuffers &pb, hipStream_t s);
 SinkLayout make_sink_layout(const psdr_scene_s *h, const psdr_grads *g);
 inline int sink_bytes(const SinkLayout &L) { return (L.priv_rows > 0 && !L.priv_regs) ? (L.priv_off + kPrivWords * kBlock) * 4 : (L.rep * L.stride * 4 + 15) / 16 * 16; }
 int check_counts(const psdr_scene_s *h, const psdr_render_opts *o);

@@ -357,12 +357,12 @@ __device__ __forceinline__ void stream_push_traced(const PathStream &out, const 
     if (cls & 1) {
         const long long r = (long long) sub * q.sub_cap + rbase + __popcll(m1 & below);
         q.req[2 * r] = float4{next.p.x, next.p.y, next.p.z, __int_as_float((int) (2 * i))};
-        q.req[2 * r + 1] = float4{d_bsdf.x, d_bsdf.y, d_bsdf.z, 0.f};
+        q.req[2 * r + 1] = float4{d_bsdf.x, d_bsdf.y, d_bsdf.z, __int_as_float(-1)};
     }
     if (cls & 2) {
         const long long r = (long long) sub * q.sub_cap + rbase + n1 + __popcll(m2 & below);
         q.req[2 * r] = float4{next.p.x, next.p.y, next.p.z, __int_as_float((int) (2 * i + 1))};
-        q.req[2 * r + 1] = float4{d_light.x, d_light.y, d_light.z, 0.f};
+        q.req[2 * r + 1] = float4{d_light.x, d_light.y, d_light.z, __int_as_float(-1)};
     }
 }
 
@@ -399,6 +399,7 @@ __device__ __forceinline__ void splat_runs(int pixel, bool valid, const Vec3<M> 
 #ifndef PSDR_WF_WAVES_T
 #define PSDR_WF_WAVES_T 4          // bounce stages of the traced wavefront (no tree walk in the kernel)
 #endif
+
 // TRACED (two-level scenes, run_camera_wavefront): the stage stops at the primary hit like the binned one, the records go to plain sub-streams and the
 // two rays of bounce stage 0 that enter a tree box become requests of the dense trace kernel (stream_push_traced).
 template <class M, int FL, bool TRACED = false, bool REC = false>
@@ -452,11 +453,23 @@ __global__ __launch_bounds__(kBlock, (is_ad<M>() ? 2 : PSDR_WF_WAVES)) void k_wf
 // One bounce: block b consumes its share of sub-stream b % kWfSub (grid-stride over the blocks of that
 // sub-stream; gridDim.x is a multiple of kWfSub) and appends the surviving paths to the same sub-stream of `out`.
 // One record of a bounce stage: rebuild the vertex, direct step, splat, push the continuation.
+// The value words of a stream record (14 coalesced loads).
+struct WfRaw { int pixel; uint32_t slot; int tri; float hu, hv, dx, dy, dz, bx, by, bz, ax, ay, az; };
+__device__ __forceinline__ WfRaw wf_load_raw(const PathStream &in, long long j, bool live) {
+    WfRaw w{-1, 0u, 0, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (live) {
+        w.pixel = in.pixel[j]; w.slot = in.slot[j]; w.tri = in.tri[j]; w.hu = in.hu[j]; w.hv = in.hv[j];
+        w.dx = in.dir[j]; w.dy = in.dir[in.cap + j]; w.dz = in.dir[2 * in.cap + j];
+        w.bx = in.beta[j]; w.by = in.beta[in.cap + j]; w.bz = in.beta[2 * in.cap + j];
+        w.ax = in.acc[j]; w.ay = in.acc[in.cap + j]; w.az = in.acc[2 * in.cap + j];
+    }
+    return w;
+}
 template <class M, int FL, bool TRACED = false, bool REC = false>
 __device__ __forceinline__ void wf_bounce_record(const LaunchCtx &cx, const TV<M, FL> &tv, TraversalStack &st, float inv_spp, float *__restrict__ img,
                                                  float *__restrict__ dimg, long long plane, const PathStream &in, const PathStream &out, int want_next,
                                                  const RngJump &jump_next, bool live, long long j, long long chunk, uint32_t &nrays, const TraceQueue &tq,
-                                                 const WfRec &wr) {
+                                                 const WfRec &wr, const WfRaw &raw) {
     constexpr int K = ad_traits<M>::K;
     int pixel = -1; uint32_t slot = 0;
     Vec3<M> r = zero3<M>(), beta = zero3<M>();
@@ -464,9 +477,9 @@ __device__ __forceinline__ void wf_bounce_record(const LaunchCtx &cx, const TV<M
     Vec3f dir(0.f);
     bool alive = false;
     if (live) {
-        pixel = in.pixel[j]; slot = in.slot[j];
-        const Vec3f din{in.dir[j], in.dir[in.cap + j], in.dir[2 * in.cap + j]};
-        beta.x = M(in.beta[j]); beta.y = M(in.beta[in.cap + j]); beta.z = M(in.beta[2 * in.cap + j]);
+        pixel = raw.pixel; slot = raw.slot;
+        const Vec3f din{raw.dx, raw.dy, raw.dz};
+        beta.x = M(raw.bx); beta.y = M(raw.by); beta.z = M(raw.bz);
         if constexpr (K > 0) {
 #pragma unroll
             for (int k = 0; k < K; ++k) {
@@ -475,7 +488,7 @@ __device__ __forceinline__ void wf_bounce_record(const LaunchCtx &cx, const TV<M
             }
         }
         Vec3<M> acc;
-        acc.x = M(in.acc[j]); acc.y = M(in.acc[in.cap + j]); acc.z = M(in.acc[2 * in.cap + j]);
+        acc.x = M(raw.ax); acc.y = M(raw.ay); acc.z = M(raw.az);
         if constexpr (K > 0) {
 #pragma unroll
             for (int k = 0; k < K; ++k) {
@@ -483,7 +496,7 @@ __device__ __forceinline__ void wf_bounce_record(const LaunchCtx &cx, const TV<M
                 acc.z.d[k] = in.acc[(5 + 3 * k) * in.cap + j];
             }
         }
-        int tri_word = in.tri[j];
+        int tri_word = raw.tri;
         Vec3<M> f, c;
         if constexpr (TRACED) {
             // the tree hits of this vertex' two rays, traced since the record was pushed (none where its class bit is clear: the ray enters no box)
@@ -492,7 +505,7 @@ __device__ __forceinline__ void wf_bounce_record(const LaunchCtx &cx, const TV<M
             if (cls & 1) { const float4 h = in.hit[2 * j]; st.pre[kPreBsdfRay] = Hit{__float_as_int(h.x), h.y, h.z, h.w}; }
             if (cls & 2) { const float4 h = in.hit[2 * j + 1]; st.pre[kPreLightRay] = Hit{__float_as_int(h.x), h.y, h.z, h.w}; }
         }
-        const Its<float> its = path_vertex_from_record(cx.sc, tv, tri_word & kWfTriMask, in.hu[j], in.hv[j], din);
+        const Its<float> its = path_vertex_from_record(cx.sc, tv, tri_word & kWfTriMask, raw.hu, raw.hv, din);
         if constexpr (TRACED) {
             TV<M, FL | kScenePre> tvp;
 #pragma unroll
@@ -575,16 +588,19 @@ __global__ __launch_bounds__(kBlock, (is_ad<M>() ? 2 : (TRACED ? PSDR_WF_WAVES_T
                 while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_pref[mid + 1] <= c) lo = mid + 1; else hi = mid; }
                 const int off = (c - s_pref[lo]) * kBlock + (int) threadIdx.x;
                 const bool live = off < in.count[lo * kWfCountStride];
-                wf_bounce_record<M, FL, false, false>(cx, tv, st, inv_spp, img, dimg, plane, in, out, want_next, jump_next, live, (long long) lo * in.sub_cap + off, c, nrays, tq, wr);
+                wf_bounce_record<M, FL, false, false>(cx, tv, st, inv_spp, img, dimg, plane, in, out, want_next, jump_next, live, (long long) lo * in.sub_cap + off, c, nrays, tq, wr,
+                                                      wf_load_raw(in, (long long) lo * in.sub_cap + off, live));
             }
         }
     } else {
         const int sub = blockIdx.x % kWfSub, per = gridDim.x / kWfSub;
         const long long in_base = (long long) sub * in.sub_cap;
         const int n = in.count[sub * kWfCountStride];
+        // (measured and dropped: fetching the NEXT trip's record while the current one is processed -- 1 571 against 1 548 us per C4 stage: the stage does
+        // not wait for its record)
         for (int base = (blockIdx.x / kWfSub) * kBlock; base < n; base += per * kBlock)
             wf_bounce_record<M, FL, TRACED, REC>(cx, tv, st, inv_spp, img, dimg, plane, in, out, want_next, jump_next, base + (int) threadIdx.x < n, in_base + base + threadIdx.x,
-                                                 base / kBlock, nrays, tq, wr);
+                                                 base / kBlock, nrays, tq, wr, wf_load_raw(in, in_base + base + threadIdx.x, base + (int) threadIdx.x < n));
     }
     count_rays(counters, nrays);
 }
@@ -619,30 +635,120 @@ __global__ __launch_bounds__(kBlock, PSDR_WAVES_PE) void k_primary_edge(LaunchCt
 // dual-number / adjoint code that the survivors need holds the full kernels at 2 waves/SIMD while all of them walk the tree.  The filter
 // traces those two rays for every slot at the occupancy of a plain kernel and compacts the survivors' slot numbers (one atomic per
 // wave); the full kernel then runs over that list.
+// ---- probe / final launches (two-level scenes).  A fused kernel pays its slowest lane's tree walk at every closest_hit although few of its rays
+// enter a tree box; where the rays of a slot are known before any of them is traced, the launch becomes PROBE pass (the rays that enter a box
+// become requests of the dense trace kernel, psdr_hip.hip k_wf_trace; one mask word per slot says which) -> trace kernel -> FINAL pass = the same
+// kernel compiled with kScenePre: closest_hit tests the kernel-argument primitives and merges the hit row of the ray (TraversalStack::pre).
+struct ProbeView { const float4 *hit; const uint32_t *mask; };
+// The requests of one lane's rays: `want` bit r set = ray r (direction d[r], common origin o) becomes request dest0 + r; block b appends to
+// sub-queue b % kWfSub with one atomic per wave.  `edge` >= 0: a secondary edge whose adjacent faces both rays skip.
+template <int NR>
+__device__ __forceinline__ void probe_push(const TraceQueue &q, uint32_t want, const Vec3f &o, const Vec3f (&d)[NR], uint32_t dest0, int edge) {
+    const int lane = threadIdx.x & 63, sub = blockIdx.x % kWfSub;
+    unsigned long long m[NR]; int total = 0;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) { m[r] = __ballot((want >> r) & 1u); total += (int) __popcll(m[r]); }
+    if (total == 0) return;
+    int base = 0;
+    if (lane == 0) base = atomicAdd(q.count + sub * kWfCountStride, total);
+    base = __shfl(base, 0, 64);
+    const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        if ((want >> r) & 1u) {
+            const long long i = (long long) sub * q.sub_cap + base + __popcll(m[r] & below);
+            q.req[2 * i] = float4{o.x, o.y, o.z, __int_as_float((int) (dest0 + (uint32_t) r))};
+            q.req[2 * i + 1] = float4{d[r].x, d[r].y, d[r].z, __int_as_float(edge)};
+        }
+        base += (int) __popcll(m[r]);
+    }
+}
+template <int NR>
+__device__ __forceinline__ void probe_load(TraversalStack &st, const ProbeView &pv, long long slot, uint32_t m) {
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        st.pre[r].tri = -1;
+        if ((m >> r) & 1u) { const float4 h = pv.hit[slot * NR + r]; st.pre[r] = Hit{__float_as_int(h.x), h.y, h.z, h.w}; }
+    }
+}
+__device__ __forceinline__ bool enters_any_box(const SceneView &sc, const Vec3f &o, const Vec3f &d) {
+    const Vec3f inv{1.f / d.x, 1.f / d.y, 1.f / d.z};
+    bool any = false;
+    for (int k = 0; k < sc.n_blas; ++k) { float te; any = any || blas_box(sc, k, o, inv, INFINITY, te); }
+    return any;
+}
+
+// Probe pass of the secondary-edge filter: mask bit 2 = the slot passes the geometric part of the test (everything else never traces), bits 0 / 1 =
+// its ray towards the emitter sample / away from it enters a tree box.
+template <int FL>
+__global__ __launch_bounds__(kBlock, 6) void k_se_probe(LaunchCtx cx, long long i0, long long n, TraceQueue tq, uint32_t *__restrict__ mask) {
+    TraversalStack st; setup_lds(cx, st);
+    const bool guided = cx.sc.d.guide_cmf != nullptr && cx.sc.d.num_guide_cells > 0;
+    const long long nceil = (n + kBlock - 1) / kBlock * kBlock;
+    for (long long j = (long long) blockIdx.x * kBlock + threadIdx.x; j < nceil; j += (long long) gridDim.x * kBlock) {
+        uint32_t m = 0; Vec3f p0(0.f), d[2] = {Vec3f(0.f), Vec3f(0.f)}; int edge = -1;
+        if (j < n) {
+            Rng rng; rng.init((uint64_t) (i0 + j), cx.jump);
+            float s3[3] = {rng.next(), rng.next(), rng.next()};
+            if (guided) (void) guide_sample_reuse(cx.sc, s3);
+            Vec3f dir;
+            if (secondary_edge_rays<FL>(cx.sc, s3, p0, dir, edge)) {
+                d[0] = dir; d[1] = -dir;
+                m = 4u | (enters_any_box(cx.sc, p0, d[0]) ? 1u : 0u) | (enters_any_box(cx.sc, p0, d[1]) ? 2u : 0u);
+            }
+            mask[j] = m;
+        }
+        probe_push<2>(tq, m & 3u, p0, d, (uint32_t) (2 * j), edge);
+    }
+}
+
 template <int FL>
 __global__ __launch_bounds__(kBlock, 4) void k_secondary_edge_filter(LaunchCtx cx, long long i0, long long n, uint32_t *__restrict__ list, int *__restrict__ list_n,
-                                                                      unsigned long long *counters) {
+                                                                      unsigned long long *counters, ProbeView pv) {
     TraversalStack st; setup_lds(cx, st);
     uint32_t nrays = 0;
     const bool guided = cx.sc.d.guide_cmf != nullptr && cx.sc.d.num_guide_cells > 0;
     const long long nceil = (n + kBlock - 1) / kBlock * kBlock;
+    constexpr int kSeBuf = 256;
+    __shared__ uint32_t s_buf[kBlock / 64][kSeBuf];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int held = 0;                                    // wave-uniform: survivors waiting in this wave's buffer
+    auto flush = [&]() {
+        if (held == 0) return;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        int base = 0;
+        if (lane == 0) base = atomicAdd(list_n, held);
+        base = __shfl(base, 0, 64);
+        for (int i = lane; i < held; i += 64) list[base + i] = s_buf[wave][i];
+        __builtin_amdgcn_wave_barrier();
+        held = 0;
+    };
     for (long long j = (long long) blockIdx.x * kBlock + threadIdx.x; j < nceil; j += (long long) gridDim.x * kBlock) {
         bool keep = false;
-        if (j < n) {
+        bool probed = true;
+        if constexpr ((FL & kScenePre) != 0) {
+            // final pass of a traced launch: a slot that failed the geometric test in the probe pass evaluates nothing; the others find their tree hits
+            const uint32_t m = j < n ? pv.mask[j] : 0u;
+            probed = (m & 4u) != 0u;
+            if (probed) probe_load<2>(st, pv, j, m);
+        }
+        if (j < n && probed) {
             Rng rng; rng.init((uint64_t) (i0 + j), cx.jump);
             float s3[3] = {rng.next(), rng.next(), rng.next()};
             if (guided) (void) guide_sample_reuse(cx.sc, s3);
             keep = secondary_edge_survives<FL>(cx.sc, st, s3, nrays);
         }
+        // survivors are gathered per WAVE in LDS and appended with one atomic per kSeBuf / 2 of them: one atomic per wave and trip on the single
+        // counter was the kernel -- a million same-address L2 atomics at 3-5 ns each on the C4 shard (4 of its 12 ms), 0.26 of 0.89 ms on C3
         const unsigned long long mask = __ballot(keep);
         if (mask != 0ull) {
-            const int lane = threadIdx.x & 63, leader = __ffsll((long long) mask) - 1;
-            int base = 0;
-            if (lane == leader) base = atomicAdd(list_n, (int) __popcll(mask));
-            base = __shfl(base, leader, 64);
-            if (keep) list[base + __popcll(mask & ((1ull << lane) - 1ull))] = (uint32_t) j;
+            if (keep) s_buf[wave][held + (int) __popcll(mask & ((1ull << lane) - 1ull))] = (uint32_t) j;
+            held += (int) __popcll(mask);
         }
+        if (held > kSeBuf - 64) flush();
     }
+    flush();
     count_rays(counters, nrays);
 }
 
@@ -1227,7 +1333,27 @@ int secondary_edge_filter(psdr_scene_s *h, const LaunchCtx &cx, long long i0, lo
     int *cnt = reinterpret_cast<int *>(h->d_se_list);
     uint32_t *lst = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(h->d_se_list) + 256);
     HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(int), s));
-    hipLaunchKernelGGL(k_secondary_edge_filter<FL>, dim3(launch_blocks(h, n)), dim3(kBlock), lds_bytes(cx, h), s, cx, i0, n, lst, cnt, h->d_counters);
+    if constexpr ((FL & kSceneForest) != 0) {
+        if (traced_wavefront(h) && h->opt.probe != 0) {
+            // traced launch: probe pass -> dense trace kernel -> the filter on primitives + hit rows (C4 shard: 12.2 ms as one kernel)
+            ProbeBuffers pb;
+            if (int rc = probe_buffers(h, n, 2, pb, s)) return rc;
+            LaunchCtx cxp = cx;
+            plan_lds(h, cxp, 1 << 30);
+            cxp.sc.n_lnodes = cxp.sc.n_lbtris = cxp.sc.n_ltri = 0;
+            const TraceQueue tq{pb.req, pb.count, pb.sub_cap};
+            const int blocks = (launch_blocks(h, n) + kWfSub - 1) / kWfSub * kWfSub;
+            hipLaunchKernelGGL(k_se_probe<FL>, dim3(blocks), dim3(kBlock), cxp.off_stack, s, cxp, i0, n, tq, pb.mask);
+            HIP_TRY(hipGetLastError());
+            if (int rc = launch_wf_trace(h, pb.req, pb.count, pb.sub_cap, pb.hit, s, true)) return rc;
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_secondary_edge_filter<FL | kScenePre>), dim3(launch_blocks(h, n)), dim3(kBlock), cxp.off_stack, s, cxp, i0, n, lst, cnt, h->d_counters,
+                               ProbeView{pb.hit, pb.mask});
+            HIP_TRY(hipGetLastError());
+            *list = lst; *list_n = cnt;
+            return 0;
+        }
+    }
+    hipLaunchKernelGGL(k_secondary_edge_filter<FL>, dim3(launch_blocks(h, n)), dim3(kBlock), lds_bytes(cx, h), s, cx, i0, n, lst, cnt, h->d_counters, ProbeView{nullptr, nullptr});
     HIP_TRY(hipGetLastError());
     *list = lst; *list_n = cnt;
     return 0;

@@ -10,9 +10,9 @@ for c in $3; do
     f=$(find /tmp/abk_$v -name "*kernel_stats.csv" | head -1)
     python - "$f" "$v $c" <<'PY'
 import csv, sys
-rows = [r for r in csv.DictReader(open(sys.argv[1])) if "k_wf" in r["Name"] or "k_camera" in r["Name"]]
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if "anonymous namespace)::k_" in r["Name"] and "refit" not in r["Name"] and "bvh4" not in r["Name"] and "gather_top" not in r["Name"]]
 tot = sum(float(r["TotalDurationNs"]) for r in rows) / 6e6
-print("%-16s total %7.2f ms/call | " % (sys.argv[2], tot) + " | ".join("%s %.1f us x%d" % (r["Name"].split("::")[-1].split("(")[0][:28], float(r["AverageNs"]) / 1e3, int(r["Calls"]) // 6) for r in rows))
+print("%-16s total %7.2f ms/call | " % (sys.argv[2], tot) + " | ".join("%s %.1f us x%d" % (r["Name"].replace("void (anonymous namespace)::","").split("(")[0][:40], float(r["AverageNs"]) / 1e3, int(r["Calls"]) // 6) for r in rows))
 PY
   done
 done | tee -a $O/abk.txt

@@ -19,12 +19,29 @@ elif case == "c5":
     from psdr_cuda.fixtures import make_interior_scene
     sc = make_interior_scene(seed=0, n_objects=10, res=512, spp=16); sc.configure()
     o = _abi.make_opts(spp=16, integrator=_abi.INTEGRATOR_PATH, max_depth=3, flags=flags); n = 512 * 512 * 16
+elif case in ("c3f", "c3r", "c4r3"):
+    # the three-term DirectIntegrator workloads: C3 forward (K = 1, a translation of the bunny) / reverse at 512^2 spp 16; C4 shard reverse
+    from helpers import tangents_wrt
+    big = case == "c4r3"
+    res, spp = (1024, 512) if big else (512, 16)
+    sc, P = load_scene("cbox_bunny", res=res, spp=spp, sppe=spp, sppse=spp, translate=(1, (1.0, 0.0, 0.0)))
+    rng = dict(spp_range=(0, 64), sppe_range=(0, 64), sppse_range=(0, 64)) if big else {}
+    o = _abi.make_opts(spp=spp, sppe=spp, sppse=spp, **rng); n = res * res * (64 if big else spp) * 3
 else:
     sc, _ = load_scene("cbox_bunny", res=256, spp=64)
     o = _abi.make_opts(spp=64, integrator=_abi.INTEGRATOR_PATH, max_depth=3, flags=flags); n = 256 * 256 * 64
-g = GpuScene(sc.tables(0))
-g.render_c(o); torch.cuda.synchronize()
+tb = sc.tables(0)
+g = GpuScene(tb)
+if case == "c3f":
+    tan = tangents_wrt(tb, P)
+    run = lambda: g.render_d_fwd(o, [tan])
+elif case in ("c3r", "c4r3"):
+    adj = np.random.default_rng(0).random((tb["width"] * tb["height"], 3)).astype(np.float32)
+    run = lambda: g.render_d_rev(o, adj, with_image=False)
+else:
+    run = lambda: g.render_c(o)
+run(); torch.cuda.synchronize()
 ts = []
 for _ in range(reps):
-    t0 = time.perf_counter(); g.render_c(o); torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
-print("%s %s path3 renderC: %s ms (median %.2f), rays/slot %.2f" % (case, mode, " ".join("%.2f" % t for t in ts), sorted(ts)[len(ts) // 2], g.counters()[0] / n))
+    t0 = time.perf_counter(); run(); torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
+print("%s %s: %s ms (median %.2f), rays/slot %.2f" % (case, mode, " ".join("%.2f" % t for t in ts), sorted(ts)[len(ts) // 2], g.counters()[0] / n))
