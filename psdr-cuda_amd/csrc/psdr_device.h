@@ -1125,7 +1125,7 @@ PSDR_HD Vec3<M> Li(const SceneView &sc, const TVT &tv, TraversalStack &st, const
     // two forms have the same value and derivative, and the on-surface form p = p0 + u e1 + v e2 is used:
     // o + t d sits up to ~1e-4 off the wall (fp32 t at distance ~1000), which lets ~1e-3 of the grazing
     // continuation rays re-hit their own wall -- isolated O(1) sample flips between any two fp32 builds
-    Its<G> its = intersect<G>(sc, tv, st, ray, active, is_ad<G>() ? kSolidAngle : kDetached, nrays);
+    Its<G> its = intersect<G>(sc, tv, st, ray, active, is_ad<G>() ? kSolidAngle : kDetached, nrays, -1, -1, kPrePrimaryRay);
     active = active && its.valid;
     if (integ == PSDR_INTEGRATOR_FIELD) {
         if (!active) return zero3<M>();

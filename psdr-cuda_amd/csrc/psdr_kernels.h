@@ -88,6 +88,17 @@ __device__ __forceinline__ void count_rays(unsigned long long *counters, uint32_
     if ((threadIdx.x & 63) == 0 && s) atomicAdd(counters + (blockIdx.x % kRayCounters) * kRayCounterStride, (unsigned long long) s);
 }
 
+// Hit rows of a probe / trace / final launch (see k_se_probe): what the final pass of a kernel reads.
+struct ProbeView { const float4 *hit; const uint32_t *mask; };
+template <int NR>
+__device__ __forceinline__ void probe_load(TraversalStack &st, const ProbeView &pv, long long slot, uint32_t m) {
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        st.pre[r].tri = -1;
+        if ((m >> r) & 1u) { const float4 h = pv.hit[slot * NR + r]; st.pre[r] = Hit{__float_as_int(h.x), h.y, h.z, h.w}; }
+    }
+}
+
 // ------------------------------------------------------------------------------ k_camera
 // n = W*H*nsp slots of this shard, pixel-major: slot j -> pixel j / nsp, sample s_begin + j % nsp.
 // n <= INT_MAX (check_counts), so the division by the run-time nsp is a 32 x 32 -> 64 bit multiply by a host-computed
@@ -145,7 +156,7 @@ template <class G, class R, int INTEG, int FL, bool NOTREE = false> constexpr in
 template <class G, class R, int INTEG, int FL, bool NOTREE = false>
 __global__ __launch_bounds__(kBlock, (camera_waves<G, R, INTEG, FL, NOTREE>())) void k_camera(LaunchCtx cx, TV<R, FL> tv, int spp, int s_begin, SlotDiv nsp, long long n, float inv_spp,
                                                    float *__restrict__ img, float *__restrict__ dimg, long long plane,
-                                                   unsigned long long *counters) {
+                                                   unsigned long long *counters, long long j0, ProbeView pv) {
     constexpr int K = ad_traits<R>::K;
     constexpr int NV = 3 * (1 + K);
     TraversalStack st; setup_lds(cx, st, tv);
@@ -154,10 +165,12 @@ __global__ __launch_bounds__(kBlock, (camera_waves<G, R, INTEG, FL, NOTREE>())) 
     for (long long j = (long long) blockIdx.x * kBlock + threadIdx.x; j < nceil; j += (long long) gridDim.x * kBlock) {
         const bool in = j < n;
         int pixel = 0x7fffffff, s_in = 0;
-        if (in) slot_to_pixel(j, nsp, pixel, s_in);
+        if (in) slot_to_pixel(j0 + j, nsp, pixel, s_in);
         float v[NV];
 #pragma unroll
         for (int i = 0; i < NV; ++i) v[i] = 0.f;
+        // final pass of a probe / trace / final launch (DirectIntegrator(1, 1) on a two-level scene): the slot's tree hits
+        if constexpr ((FL & kScenePre) != 0) { if (in) probe_load<3>(st, pv, j, pv.mask[j]); }
         if (in) {
             const int s = s_begin + s_in;
             const uint64_t slot = (uint64_t) pixel * (uint64_t) spp + (uint64_t) s;
@@ -639,7 +652,6 @@ __global__ __launch_bounds__(kBlock, PSDR_WAVES_PE) void k_primary_edge(LaunchCt
 // enter a tree box; where the rays of a slot are known before any of them is traced, the launch becomes PROBE pass (the rays that enter a box
 // become requests of the dense trace kernel, psdr_hip.hip k_wf_trace; one mask word per slot says which) -> trace kernel -> FINAL pass = the same
 // kernel compiled with kScenePre: closest_hit tests the kernel-argument primitives and merges the hit row of the ray (TraversalStack::pre).
-struct ProbeView { const float4 *hit; const uint32_t *mask; };
 // The requests of one lane's rays: `want` bit r set = ray r (direction d[r], common origin o) becomes request dest0 + r; block b appends to
 // sub-queue b % kWfSub with one atomic per wave.  `edge` >= 0: a secondary edge whose adjacent faces both rays skip.
 template <int NR>
@@ -661,14 +673,6 @@ __device__ __forceinline__ void probe_push(const TraceQueue &q, uint32_t want, c
             q.req[2 * i + 1] = float4{d[r].x, d[r].y, d[r].z, __int_as_float(edge)};
         }
         base += (int) __popcll(m[r]);
-    }
-}
-template <int NR>
-__device__ __forceinline__ void probe_load(TraversalStack &st, const ProbeView &pv, long long slot, uint32_t m) {
-#pragma unroll
-    for (int r = 0; r < NR; ++r) {
-        st.pre[r].tri = -1;
-        if ((m >> r) & 1u) { const float4 h = pv.hit[slot * NR + r]; st.pre[r] = Hit{__float_as_int(h.x), h.y, h.z, h.w}; }
     }
 }
 __device__ __forceinline__ bool enters_any_box(const SceneView &sc, const Vec3f &o, const Vec3f &d) {
@@ -699,6 +703,36 @@ __global__ __launch_bounds__(kBlock, 6) void k_se_probe(LaunchCtx cx, long long 
             mask[j] = m;
         }
         probe_push<2>(tq, m & 3u, p0, d, (uint32_t) (2 * j), edge);
+    }
+}
+
+// Probe pass of a camera launch with DirectIntegrator(1, 1) on a two-level scene: the primary hit (its walk stays in this kernel: camera rays are
+// coherent) goes to hit row 3 j + 2, the vertex' two rays (classify_next: the draws and the sampling routines of direct_step) that enter a tree
+// box become trace requests for rows 3 j + 0 / 1; mask bits 0 / 1 / 2 say which rows the final pass reads.
+// (Measured and dropped: the same for the primary-edge kernels -- their Li evaluations start ON the silhouette of the mesh, nearly every ray walks the
+// tree anyway and the fused kernel loses little to divergence: C3 1.29 ms fused against 0.35 + 0.53 + 0.66 probe / trace / final, C4 shard 14.8 against 22.)
+template <int FL> __global__ __launch_bounds__(kBlock, PSDR_WAVES_C) void k_direct_probe(LaunchCtx cx, TangentView<0, FL> tv0, int spp, int s_begin, SlotDiv nsp, long long j0, long long n,
+                                                                                       TraceQueue tq, float4 *__restrict__ hit, uint32_t *__restrict__ mask, RngJump jump_next) {
+    TraversalStack st; setup_lds(cx, st, tv0);
+    uint32_t nrays = 0;
+    const long long nceil = (n + kBlock - 1) / kBlock * kBlock;
+    for (long long jj = (long long) blockIdx.x * kBlock + threadIdx.x; jj < nceil; jj += (long long) gridDim.x * kBlock) {
+        uint32_t m = 0; Vec3f p0(0.f), d[2] = {Vec3f(0.f), Vec3f(0.f)};
+        if (jj < n) {
+            int pixel, s_in;
+            slot_to_pixel(j0 + jj, nsp, pixel, s_in);
+            const uint32_t slot = (uint32_t) ((uint64_t) pixel * (uint64_t) spp + (uint64_t) (s_begin + s_in));
+            Its<float> next; next.tri = -1; next.hu = next.hv = 0.f;
+            Vec3f dir(0.f); bool alive = false;
+            (void) wavefront_primary_vertex<float>(cx.sc, tv0, st, cx.lp, cx.jump, pixel, slot, nrays, next, dir, alive);
+            if (alive) {
+                hit[3 * jj + 2] = float4{__int_as_float(next.tri), next.hu, next.hv, next.t};
+                m = 4u | (uint32_t) classify_next<true>(cx.sc, tv0, jump_next, slot, next, dir, &d[0], &d[1]);
+                p0 = next.p;
+            }
+            mask[jj] = m;
+        }
+        probe_push<2>(tq, m & 3u, p0, d, (uint32_t) (3 * jj), -1);
     }
 }
 
@@ -1023,7 +1057,8 @@ template <int FL, bool GEO, int INTEG> constexpr int rev_waves() {
 template <int FL, bool GEO, int INTEG, int STAGE = 0>
 __global__ __launch_bounds__(kBlock, (STAGE == 1 ? PSDR_WAVES_REV_VALUE : rev_waves<FL, GEO, INTEG>())) void k_camera_rev(LaunchCtx cx, DeviceSink<FL> sink_arg, int spp, int s_begin, SlotDiv nsp, long long j0,
                                                        long long n, float inv_spp, const float *__restrict__ adj_img, float *__restrict__ img,
-                                                       unsigned long long *counters, float *__restrict__ disk, long long disk_stride, float *__restrict__ deep, int disk_cf) {
+                                                       unsigned long long *counters, float *__restrict__ disk, long long disk_stride, float *__restrict__ deep, int disk_cf,
+                                                       ProbeView pv) {
     TraversalStack st; setup_lds(cx, st);
     typename std::conditional<reg_priv_kernel<FL, GEO, INTEG>() && STAGE != 1, RegPrivSink<FL>, DeviceSink<FL> &>::type sink(sink_arg);
     if (STAGE != 1) sink.begin(dyn_lds_floats(cx.off_sink));
@@ -1040,6 +1075,7 @@ __global__ __launch_bounds__(kBlock, (STAGE == 1 ? PSDR_WAVES_REV_VALUE : rev_wa
         rec.base = reinterpret_cast<float *>(psdr_dyn_lds + cx.off_pathrec) + threadIdx.x;
         if (INTEG != PSDR_INTEGRATOR_DIRECT && deep != nullptr) { rec.deep = deep; rec.deep_stride = gridDim.x * kBlock; rec.deep_col = blockIdx.x * kBlock + threadIdx.x; }
 #endif
+        if constexpr ((FL & kScenePre) != 0) { if (in) probe_load<3>(st, pv, jj, pv.mask[jj]); }
         if (in) {
             const int s = s_begin + s_in;
             const uint64_t slot = (uint64_t) pixel * (uint64_t) spp + (uint64_t) s;
@@ -1152,6 +1188,10 @@ inline int camera_blocks_per_cu(const psdr_scene_s *h, long long n) {
     const long long fit = n / ((long long) kBlock * h->num_cus * 2);
     return (int) std::max(16LL, std::min(64LL, fit));
 }
+// DirectIntegrator(1, 1) camera launches on a two-level scene run as probe pass + dense trace kernel + final pass (from 2^16 slots)
+inline bool probe_direct(const psdr_scene_s *h, const psdr_render_opts *o, long long n) {
+    return traced_wavefront(h) && h->opt.probe != 0 && o->bsdf_samples == 1 && o->light_samples == 1 && !(o->flags & PSDR_FLAG_FUSED) && n >= (1ll << 16);
+}
 template <class G, class R, int FL>
 int run_camera(psdr_scene_s *h, const psdr_render_opts *o, const TV<R, FL> &tv, float *img, float *dimg, hipStream_t s) {
     const long long WH = (long long) h->desc.width * h->desc.height;
@@ -1161,9 +1201,38 @@ int run_camera(psdr_scene_s *h, const psdr_render_opts *o, const TV<R, FL> &tv, 
     if (int rc = make_ctx(h, o, 0, cx)) return rc;
     const long long n = WH * nsp;
     h->slots[0] += (uint64_t) n;
+    // DirectIntegrator(1, 1) on a two-level scene: probe pass (primary hit + requests for the vertex' two rays that enter a tree box) -> dense trace
+    // kernel -> this kernel compiled with kScenePre (no tree walk: primitives + hit rows), chunk by chunk.  C3 forward geometry duals 1.31 -> 0.73 ms
+    // (0.21 + 0.19 + 0.33), C4 shard reverse 16.0 -> 14.0 ms
+    if constexpr ((FL & kSceneForest) != 0) {
+        if (o->integrator == PSDR_INTEGRATOR_DIRECT && probe_direct(h, o, n)) {
+            const TangentView<0, FL> tv0{};
+            TV<R, FL | kScenePre> tvp;
+            for (int k = 0; k < (ad_traits<R>::K > 0 ? ad_traits<R>::K : 1); ++k) tvp.t[k] = tv.t[k];
+            LaunchCtx cxp = cx;
+            plan_lds(h, cxp, 1 << 30);
+            cxp.sc.n_lnodes = cxp.sc.n_lbtris = cxp.sc.n_ltri = 0;
+            const long long chunk = std::min<long long>(n, 1ll << 25);
+            for (long long c0 = 0; c0 < n; c0 += chunk) {
+                const long long nc = std::min(chunk, n - c0);
+                ProbeBuffers pb;
+                if (int rc = probe_buffers(h, nc, 3, pb, s)) return rc;
+                const TraceQueue tq{pb.req, pb.count, pb.sub_cap};
+                const int blocks = (launch_blocks(h, nc) + kWfSub - 1) / kWfSub * kWfSub;
+                hipLaunchKernelGGL(k_direct_probe<FL>, dim3(blocks), dim3(kBlock), lds_bytes(cx, h), s, cx, tv0, o->spp, o->spp_begin, SlotDiv(nsp), c0, nc, tq, pb.hit, pb.mask,
+                                   make_rng_jump(o->rng_offset[0] + 2));
+                HIP_TRY(hipGetLastError());
+                if (int rc = launch_wf_trace(h, pb.req, pb.count, pb.sub_cap, pb.hit, s)) return rc;
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_camera<G, R, PSDR_INTEGRATOR_DIRECT, FL | kScenePre, false>), dim3(launch_blocks(h, nc, camera_blocks_per_cu(h, nc))), dim3(kBlock), cxp.off_stack, s,
+                                   cxp, tvp, o->spp, o->spp_begin, SlotDiv(nsp), nc, 1.f / (float) o->spp, img, dimg, WH * 3, h->d_counters, c0, ProbeView{pb.hit, pb.mask});
+                HIP_TRY(hipGetLastError());
+            }
+            return 0;
+        }
+    }
 #define PSDR_LAUNCH_CAMERA_T(INTEG, NOTREE)                                                                                        \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_camera<G, R, INTEG, FL, NOTREE>), dim3(launch_blocks(h, n, camera_blocks_per_cu(h, n))), dim3(kBlock), lds_bytes(cx, h), s, cx, tv, o->spp, \
-                       o->spp_begin, nsp, n, 1.f / (float) o->spp, img, dimg, WH * 3, h->d_counters)
+                       o->spp_begin, nsp, n, 1.f / (float) o->spp, img, dimg, WH * 3, h->d_counters, 0ll, ProbeView{nullptr, nullptr})
 #define PSDR_LAUNCH_CAMERA(INTEG) PSDR_LAUNCH_CAMERA_T(INTEG, ((FL & kSceneTiny) != 0))
     // scenes without a tree are served by their own flag sets (kSceneTiny): occupancy follows from FL alone
     switch (o->integrator) {
@@ -1473,7 +1542,7 @@ int render_rev(psdr_scene_s *h, const psdr_render_opts *o, const float *adj_img,
 #define PSDR_LAUNCH_REV_K(GEO, INTEG, STAGE, CX, BYTES, J0, N, IMG, DISK, STRIDE)                                                    \
         do { if ((BYTES) > 48 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_camera_rev<FL, GEO, INTEG, STAGE>), hipFuncAttributeMaxDynamicSharedMemorySize, (BYTES))); \
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_camera_rev<FL, GEO, INTEG, STAGE>), dim3(launch_blocks(h, (N))), dim3(kBlock), (BYTES), s, CX, sink, \
-                           o->spp, o->spp_begin, nsp, (long long) (J0), (long long) (N), 1.f / (float) o->spp, adj_img, IMG, h->d_counters, DISK, (long long) (STRIDE), deep, disk_cf); } while (0)
+                           o->spp, o->spp_begin, nsp, (long long) (J0), (long long) (N), 1.f / (float) o->spp, adj_img, IMG, h->d_counters, DISK, (long long) (STRIDE), deep, disk_cf, ProbeView{nullptr, nullptr}); } while (0)
 #define PSDR_LAUNCH_REV(GEO, INTEG) PSDR_LAUNCH_REV_K(GEO, INTEG, 0, cx, dyn_bytes, 0, n, out_img, (float *) nullptr, 0)
         // the value sweep of a split PathTracer launch on a two-level scene runs as the TRACED WAVEFRONT (dense trace kernel between the stages):
         // in the fused value kernel a wave pays its slowest lane's tree walk at every closest_hit (C4 shard: 29 ms of the 57; renderC by the
@@ -1481,6 +1550,8 @@ int render_rev(psdr_scene_s *h, const psdr_render_opts *o, const float *adj_img,
         bool wf_value = false;
         if constexpr ((FL & kSceneForest) != 0) wf_value = split && !no_tree && o->integrator == PSDR_INTEGRATOR_PATH && !deep_rec && traced_wavefront(h) && use_wavefront(h, o);
         const int disk_cf = wf_value ? 1 : 0;
+        bool direct_probe = false;
+        if constexpr ((FL & kSceneForest) != 0) direct_probe = !split && !no_tree && o->integrator == PSDR_INTEGRATOR_DIRECT && probe_direct(h, o, n);
         if (split) {
             // records of one chunk of slots live in a scratch buffer (2 + 5 depth words per slot; 2 + 8 depth from the wavefront); chunks bound its size
             const int words = kRevDiskHead + (wf_value ? kRevDiskPerVertexCf : kRevDiskPerVertex) * depth;
@@ -1508,6 +1579,38 @@ int render_rev(psdr_scene_s *h, const psdr_render_opts *o, const float *adj_img,
                 } else {
                     PSDR_LAUNCH_REV_K(true, PSDR_INTEGRATOR_DIRECT, 1, cx, dyn1, c0, nc, out_img, disk, chunk);
                     PSDR_LAUNCH_REV_K(true, PSDR_INTEGRATOR_DIRECT, 2, cx2, dyn_bytes, c0, nc, (float *) nullptr, disk, chunk);
+                }
+            }
+        } else if (direct_probe) {
+            if constexpr ((FL & kSceneForest) != 0) {
+                // DirectIntegrator(1, 1), one kernel, on a two-level scene: probe pass -> dense trace kernel -> the reverse kernel on primitives + hit rows
+                const TangentView<0, FL> tv0{};
+                DeviceSink<FL | kScenePre> sinkp{}; sinkp.g = sink.g; sinkp.L = sink.L;
+                LaunchCtx cxf;
+                if (int rc = make_ctx(h, o, 0, cxf)) return rc;                                   // the probe pass stages the scene like a forward kernel
+                LaunchCtx cxp = cx;                                                              // the final pass: record + cache, nothing of the tree, no stacks
+                plan_lds(h, cxp, 1 << 30);
+                cxp.sc.n_lnodes = cxp.sc.n_lbtris = cxp.sc.n_ltri = 0;
+                cxp.off_pathrec = cxp.off_stack; cxp.off_sink = cxp.off_pathrec + rec_bytes;
+                const int dyn_p = cxp.off_sink + cache_bytes;
+                const long long chunk = std::min<long long>(n, 1ll << 25);
+                for (long long c0 = 0; c0 < n; c0 += chunk) {
+                    const long long nc = std::min(chunk, n - c0);
+                    ProbeBuffers pb;
+                    if (int rc = probe_buffers(h, nc, 3, pb, s)) return rc;
+                    const TraceQueue tq{pb.req, pb.count, pb.sub_cap};
+                    const int blocks = (launch_blocks(h, nc) + kWfSub - 1) / kWfSub * kWfSub;
+                    hipLaunchKernelGGL(k_direct_probe<FL>, dim3(blocks), dim3(kBlock), lds_bytes(cxf, h), s, cxf, tv0, o->spp, o->spp_begin, SlotDiv(nsp), c0, nc, tq, pb.hit, pb.mask,
+                                       make_rng_jump(o->rng_offset[0] + 2));
+                    HIP_TRY(hipGetLastError());
+                    if (int rc = launch_wf_trace(h, pb.req, pb.count, pb.sub_cap, pb.hit, s)) return rc;
+#define PSDR_LAUNCH_REV_P(GEO)                                                                                                            \
+                    do { if (dyn_p > 48 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_camera_rev<FL | kScenePre, GEO, PSDR_INTEGRATOR_DIRECT, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, dyn_p)); \
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_camera_rev<FL | kScenePre, GEO, PSDR_INTEGRATOR_DIRECT, 0>), dim3(launch_blocks(h, nc)), dim3(kBlock), dyn_p, s, cxp, sinkp,  \
+                                       o->spp, o->spp_begin, nsp, c0, nc, 1.f / (float) o->spp, adj_img, out_img, h->d_counters, (float *) nullptr, 0ll, deep, 0, ProbeView{pb.hit, pb.mask}); } while (0)
+                    if (geo) PSDR_LAUNCH_REV_P(true); else PSDR_LAUNCH_REV_P(false);
+#undef PSDR_LAUNCH_REV_P
+                    HIP_TRY(hipGetLastError());
                 }
             }
         } else

@@ -552,7 +552,7 @@ PSDR_HD VertexOut vertex_eval(Sink &sink, const SceneView &sc, TraversalStack &s
         if (REPLAY && BACKWARD) h1.tri = rec.tri(k, 0);
         else {
             nrays++;
-            h1 = closest_hit<false, tree_mode<Sink::flags>()>(sc, st, ray1.o, ray1.d, INFINITY);
+            h1 = closest_hit<false, tree_mode<Sink::flags>()>(sc, st, ray1.o, ray1.d, INFINITY, -1, -1, kPreBsdfRay);
             if (REPLAY) rec.put_tri(k, 0, h1.tri);
         }
         if (h1.tri < 0) continue;
@@ -659,7 +659,7 @@ PSDR_HD VertexOut vertex_eval(Sink &sink, const SceneView &sc, TraversalStack &s
         if (REPLAY && BACKWARD) h2.tri = rec.tri(k, 1);
         else {
             nrays++;
-            h2 = closest_hit<false, tree_mode<Sink::flags>()>(sc, st, its.p, wo, INFINITY);
+            h2 = closest_hit<false, tree_mode<Sink::flags>()>(sc, st, its.p, wo, INFINITY, -1, -1, kPreLightRay);
             if (REPLAY) rec.put_tri(k, 1, h2.tri);
         }
         if (h2.tri < 0) continue;
@@ -850,7 +850,7 @@ PSDR_HD Vec3f camera_sample_reverse(RealSink &real_sink, PrimaryGrad &pg, PathRe
         nv = disk.geti(1);
     } else {
         nrays++;
-        h0 = closest_hit<false, tree_mode<RealSink::flags>()>(sc, st, ray.o, ray.d, INFINITY);
+        h0 = closest_hit<false, tree_mode<RealSink::flags>()>(sc, st, ray.o, ray.d, INFINITY, -1, -1, kPrePrimaryRay);
         if (h0.tri < 0) { if constexpr (STAGE == 1) disk.puti(0, -1); return Vec3f(0.f); }
     }
     pg.tri = h0.tri;
