@@ -227,7 +227,7 @@ int psdr_scene_destroy(psdr_scene_t h);
 /* Developer options of a handle -- the A/B switches of tools and tests (the reference has none: its strategies are fixed by OptiX and
    Enoki); the library reads NO environment variable.  Names (value): bvh_refit, tiny_scene, two_level, wf_binned, wf_traced, sort_edges,
    tiny_variants, sink_private (0 / 1); bvh_build (1 device, 0 host, -1 by size); wide (0: never the 4-wide tree in the render kernels);
-   rev_split, sedge_split (1 / 0 force, -1 default rule); probe (0: no probe / trace / final launches); blocks_per_cu, camera_blocks, lds_budget, sink_rep, bvh_maxleaf (integers, 0 =
+   rev_split, sedge_split (1 / 0 force, -1 default rule); probe (0: no probe / trace / final launches); chunk_log2 (slots per chunk of the chunked launches, 0 = default); blocks_per_cu, camera_blocks, lds_budget, sink_rep, bvh_maxleaf (integers, 0 =
    default where that makes sense); bvh_tcost (float).  Unknown names fail.  Options that change the tree take effect at the next psdr_bvh_build. */
 int psdr_scene_set_option(psdr_scene_t h, const char *name, double value);
 

@@ -941,6 +941,7 @@ int psdr_scene_set_option(psdr_scene_t h, const char *name, double value) {
     else if (n == "rev_split") h->opt.rev_split = iv;
     else if (n == "sedge_split") h->opt.sedge_split = iv;
     else if (n == "probe") h->opt.probe = iv;
+    else if (n == "chunk_log2") h->opt.chunk_log2 = std::max(0, std::min(30, iv));
     else if (n == "bvh_maxleaf") h->opt.bvh_maxleaf = std::max(1, std::min(8, iv));
     else if (n == "bvh_tcost") h->opt.bvh_tcost = (float) value;
     else return fail("psdr_scene_set_option: unknown option '" + n + "'");

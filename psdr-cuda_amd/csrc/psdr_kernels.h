@@ -1188,6 +1188,9 @@ inline int camera_blocks_per_cu(const psdr_scene_s *h, long long n) {
     const long long fit = n / ((long long) kBlock * h->num_cus * 2);
     return (int) std::max(16LL, std::min(64LL, fit));
 }
+// slots per chunk of the launches that keep per-slot state between kernels (wavefront streams, reverse-mode records, probe buffers): 2^log2_default,
+// or what psdr_scene_set_option("chunk_log2", ...) says (tests: chunk boundaries on small scenes)
+inline long long launch_chunk(const psdr_scene_s *h, int log2_default) { return 1ll << (h->opt.chunk_log2 > 0 ? h->opt.chunk_log2 : log2_default); }
 // DirectIntegrator(1, 1) camera launches on a two-level scene run as probe pass + dense trace kernel + final pass (from 2^16 slots)
 inline bool probe_direct(const psdr_scene_s *h, const psdr_render_opts *o, long long n) {
     return traced_wavefront(h) && h->opt.probe != 0 && o->bsdf_samples == 1 && o->light_samples == 1 && !(o->flags & PSDR_FLAG_FUSED) && n >= (1ll << 16);
@@ -1212,7 +1215,7 @@ int run_camera(psdr_scene_s *h, const psdr_render_opts *o, const TV<R, FL> &tv, 
             LaunchCtx cxp = cx;
             plan_lds(h, cxp, 1 << 30);
             cxp.sc.n_lnodes = cxp.sc.n_lbtris = cxp.sc.n_ltri = 0;
-            const long long chunk = std::min<long long>(n, 1ll << 25);
+            const long long chunk = std::min<long long>(n, launch_chunk(h, 25));
             for (long long c0 = 0; c0 < n; c0 += chunk) {
                 const long long nc = std::min(chunk, n - c0);
                 ProbeBuffers pb;
@@ -1249,7 +1252,7 @@ int run_camera(psdr_scene_s *h, const psdr_render_opts *o, const TV<R, FL> &tv, 
 
 // PathTracer interior term as a wavefront (see k_wf_camera / k_wf_bounce).  M = float or Dual<K>
 // with plain-fp32 geometry.
-constexpr long long kWfChunk = 1ll << 25;
+
 constexpr int kWfMaxDepth = 256;         // counter sets (use_wavefront: max_depth <= 250)
 // rec != nullptr: the launch is the VALUE SWEEP of a split reverse launch over the slots [rec->c0, rec->c0 + rec->nc) of the shard -- the traced
 // wavefront with REC kernels that leave the per-path records the adjoint kernel reads (WfRec); float only, two-level scenes only.
@@ -1270,7 +1273,7 @@ int run_camera_wavefront(psdr_scene_s *h, const psdr_render_opts *o, const TV<M,
     bool traced = false;
     if constexpr ((FL & kSceneForest) != 0) traced = traced_wavefront(h);
     const bool binned = !traced && (FL & kSceneForest) != 0 && h->n_blas > 0 && h->wf_binned;          // a two-level scene is a room (use_wavefront)
-    const long long cap = std::min(n, binned ? kWfChunk / 2 : kWfChunk);
+    const long long cap = std::min(n, binned ? launch_chunk(h, 24) : launch_chunk(h, 25));
     const int depth = o->max_depth;
     const size_t words = 8 + 6 * (1 + K) + (traced ? 8 : 0);          // traced: + the two hit rows of a record
     // plain: block b appends to sub-stream b % kWfSub, at most ceil(blocks / kWfSub) * trips * kBlock records each.
@@ -1555,7 +1558,7 @@ int render_rev(psdr_scene_s *h, const psdr_render_opts *o, const float *adj_img,
         if (split) {
             // records of one chunk of slots live in a scratch buffer (2 + 5 depth words per slot; 2 + 8 depth from the wavefront); chunks bound its size
             const int words = kRevDiskHead + (wf_value ? kRevDiskPerVertexCf : kRevDiskPerVertex) * depth;
-            const long long chunk = std::min<long long>(n, 1ll << 24);
+            const long long chunk = std::min<long long>(n, launch_chunk(h, 24));
             const size_t need = (size_t) chunk * words * sizeof(float);
             if (need > h->rev_bytes) {
                 if (h->d_rev) (void) hipFree(h->d_rev);
@@ -1593,7 +1596,7 @@ int render_rev(psdr_scene_s *h, const psdr_render_opts *o, const float *adj_img,
                 cxp.sc.n_lnodes = cxp.sc.n_lbtris = cxp.sc.n_ltri = 0;
                 cxp.off_pathrec = cxp.off_stack; cxp.off_sink = cxp.off_pathrec + rec_bytes;
                 const int dyn_p = cxp.off_sink + cache_bytes;
-                const long long chunk = std::min<long long>(n, 1ll << 25);
+                const long long chunk = std::min<long long>(n, launch_chunk(h, 25));
                 for (long long c0 = 0; c0 < n; c0 += chunk) {
                     const long long nc = std::min(chunk, n - c0);
                     ProbeBuffers pb;

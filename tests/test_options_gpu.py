@@ -33,3 +33,35 @@ def test_library_reads_no_environment_variable():
     out = subprocess.run(["strings", "-a", _abi.HIP_LIB_PATH], capture_output=True, text=True).stdout
     names = [l for l in out.splitlines() if l.startswith("PSDR_") and l.replace("_", "").isalnum() and l.isupper()]
     assert names == [], names
+
+
+@pytest.mark.parametrize("kind", ["path3", "direct11"])
+def test_chunked_and_sharded_launches_on_a_two_level_scene(kind):
+    """The launches that keep per-slot state between kernels -- traced wavefront streams, the per-path records of a split reverse launch, the hit rows of
+    probe / trace / final launches -- run chunk by chunk on large launches; `chunk_log2` makes them do so on a small scene: the same image, derivative
+    image and gradients as one chunk (same samples; the order of the float adds only).  And the sample shards of a multi-GPU job add up to the full render."""
+    from helpers import random_tangents, dot_tables, load_scene as ls
+    sc, P = ls("cbox_bunny", res=96, spp=16, sppe=8, sppse=8, translate=(1, (1.0, 0.3, 0.0)))
+    tb = sc.tables(0)
+    kw = dict(integrator=_abi.INTEGRATOR_PATH, max_depth=3) if kind == "path3" else dict(bsdf_samples=1, light_samples=1, sppe=8, sppse=8)
+    o = _abi.make_opts(spp=16, **kw)
+    adj = np.random.default_rng(5).random((96 * 96, 3)).astype(np.float32)
+    from helpers import tangents_wrt
+    tan = tangents_wrt(tb, P) if kind == "direct11" else {"texels": random_tangents(tb, ["texels"], seed=1)["texels"]}
+    want = ["tri_info", "texels"] + (["sec_edge", "prim_edge"] if kind == "direct11" else [])
+    res = {}
+    for name, opts in (("one", {}), ("chunks", {"chunk_log2": 14})):            # 147 456 slots: nine chunks of 2^14
+        g = GpuScene(tb, options=opts)
+        res[name] = (g.render_c(o), g.render_d_fwd(o, [tan])[1][0], g.render_d_rev(o, adj, want=want, with_image=False)[1], g.counters()[0])
+    a, b = res["one"], res["chunks"]
+    assert rel_l2(b[0], a[0]) < 1e-5 and rel_l2(b[1], a[1]) < 1e-4
+    for k in want:
+        assert rel_l2(b[2][k], a[2][k]) < 2e-4, (k, rel_l2(b[2][k], a[2][k]))
+    # shards: samples [0, 5), [5, 6), [6, 16) of every pixel (and of the edge samplers) add up to the full launch
+    g = GpuScene(tb)
+    full = g.render_c(o)
+    parts = 0
+    for r in ((0, 5), (5, 6), (6, 16)):
+        er = (r[0] // 2, r[1] // 2)
+        parts = parts + g.render_c(_abi.make_opts(spp=16, spp_range=r, **({**kw, "sppe_range": er, "sppse_range": er} if kind == "direct11" else kw)))
+    assert rel_l2(parts, full) < 1e-5
