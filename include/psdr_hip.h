@@ -315,6 +315,26 @@ int psdr_geo_prim_edges_fwd(int32_t E, const int32_t *edges, const uint8_t *face
 int psdr_geo_prim_edges_rev(int32_t E, const int32_t *edges, const float *v, const float *cam22, const float *a_rows8, float *a_v, float *a_w2s /* [16] */,
                             void *stream);
 
+/* The kept edges of a candidate table as a table of the SAME capacity, with the count left on the device (scene.cpp:219-244 and
+   perspective.cpp:96-111 compress the kept edges and build a DiscreteDistribution over their lengths, pmf.cpp:7-21, inside one Enoki trace;
+   an eager host chain would read the number of kept edges back to size the result).  rows [E][S], keep [E]; the weight of a row is its
+   word w0 (wn = 1) or the norm of words w0..w0+2 (wn = 3).  aux [E][aux_stride] 32-bit words of which the first A travel with the row
+   (A = 0: none).  Outputs: rows_out [E][S] / aux_out [E][A] = the kept rows in their order, zero behind them; pos [E] = the new row of
+   edge e or -1; pmf / cmf [E] = weight / sum and its running sum (cmf = 1 from the last kept row on, so a lower-bound search for u < 1
+   never leaves the kept rows; the host passes sum = 1); header [2] = {number of kept rows as int bits, sum of the weights}.
+   scratch: 4 * ceil(E / 1024) words.  _rev WRITES a_rows [E][S] (the adjoint of rows) from a_rows_out. */
+int psdr_geo_compact_edges_fwd(int32_t E, const float *rows, int32_t S, const uint8_t *keep, int32_t w0, int32_t wn, const void *aux, int32_t aux_stride, int32_t A,
+                               void *scratch, float *rows_out, void *aux_out, int32_t *pos, float *pmf, float *cmf, float *header, void *stream);
+int psdr_geo_compact_edges_rev(int32_t E, int32_t S, const int32_t *pos, const float *a_rows_out, float *a_rows, void *stream);
+/* Mesh areas and the emitter tables (scene.cpp:183-196, area.cpp:10-16, mesh.cpp:244-249) without a host round trip: face_offset [M + 1],
+   mesh_emitter [M] (-1: none), emitter_i [Ne][PSDR_EMITTER_I_STRIDE], radiance [Ne][3], env_weight [Ne] (< 0: an area light; otherwise the
+   sampling weight of the environment map).  Outputs: mesh_area [M]; emitter_f [Ne][PSDR_EMITTER_F_STRIDE]; emitter_pmf / emitter_cmf [Ne]
+   NORMALISED (the host passes emitter_sum = 1); face_pmf / face_cmf = the face-area distributions of the area lights' meshes at
+   emitter_i[.][3] (unnormalised, their sums in emitter_f[.][5]). */
+int psdr_geo_emitter_tables(int32_t M, const float *rows, int32_t row_stride, const int32_t *face_offset, const int32_t *mesh_emitter, int32_t Ne, const int32_t *emitter_i,
+                            const float *radiance, const float *env_weight, float *mesh_area, float *emitter_f, float *emitter_pmf, float *emitter_cmf, float *face_pmf,
+                            float *face_cmf, void *stream);
+
 /* Counters of the last render call on this handle (host values):
    [0] rays traced, [1] camera slots, [2] primary-edge slots, [3] secondary-edge slots. */
 int psdr_get_counters(psdr_scene_t h, uint64_t out[4]);

@@ -1264,7 +1264,8 @@ PSDR_HD int primary_edge_sample(const SceneView &sc, const TangentView<K, FL> &t
     const float px = pe[0] * (1.f - u) + pe[2] * u, py = pe[1] * (1.f - u) + pe[3] * u;
     const int W = sc.d.width, H = sc.d.height;
     const int ix = (int) floorf(px * (float) W), iy = (int) floorf(py * (float) H);
-    bool valid = ix >= 0 && ix < W && iy >= 0 && iy < H;
+    // (pmf > 0: a table built on the device keeps the capacity of the candidate list, zero rows behind the kept ones -- never drawn unless NO edge is kept)
+    bool valid = ix >= 0 && ix < W && iy >= 0 && iy < H && pmf > 0.f;
     const TangentView<0, FL> tv0{};
     if (sc.d.prim_edge_z != nullptr && valid) valid = primary_edge_point_visible(sc, tv0, st, k, u, px, py, nrays);
     // Li on the two sides of the edge (ray_n first, then ray_p: the order the reference draws them in,

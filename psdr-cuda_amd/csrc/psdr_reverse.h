@@ -1056,7 +1056,7 @@ PSDR_HD int primary_edge_reverse_values(const SceneView &sc, TraversalStack &st,
     const float px = pe[0] * (1.f - u) + pe[2] * u, py = pe[1] * (1.f - u) + pe[3] * u;
     const int W = sc.d.width, H = sc.d.height;
     const int ix = (int) floorf(px * (float) W), iy = (int) floorf(py * (float) H);
-    bool valid = ix >= 0 && ix < W && iy >= 0 && iy < H;
+    bool valid = ix >= 0 && ix < W && iy >= 0 && iy < H && pmf > 0.f;          // (pmf > 0: see primary_edge_sample)
     const TangentView<0, FL> tv0{};
     if (sc.d.prim_edge_z != nullptr && valid) valid = primary_edge_point_visible(sc, tv0, st, k, u, px, py, nrays);
     Vec3f L2[2];

@@ -64,6 +64,7 @@ __global__ __launch_bounds__(kB) void k_tri_rows(int T, const float *__restrict_
     }
     st3(r + 18, c * (1.f / len));
     r[21] = 0.5f * len;
+    for (int k = 22; k < stride; ++k) r[k] = 0.f;          // the padding words of a PSDR_TRI_STRIDE row
 }
 // adjoint, pass 1: the vertex-normal adjoints of the rows gathered into the adjoint of the per-vertex sums
 __global__ __launch_bounds__(kB) void k_tri_rows_rev_vn(int T, const int32_t *__restrict__ faces, const float *__restrict__ vsum, const float *__restrict__ a_rows,
@@ -237,6 +238,145 @@ __global__ __launch_bounds__(kB) void k_world_vertices_rev(int V, const float *_
                                    (m[2] * a.x + m[6] * a.y + m[10] * a.z - m[14] * ya) * iw});
 }
 
+// ------------------------------------------------------------- kept edges -> table + length distribution, count on the device
+// The reference compresses the kept edges and builds a DiscreteDistribution over their lengths inside one Enoki trace (scene.cpp:219-244,
+// perspective.cpp:96-111, pmf.cpp:7-21); an eager host chain has to read the NUMBER of kept edges back to size the compacted table.  Here the
+// table keeps its capacity E: the kept rows come first in their original order, the tail is zero, and the distribution is normalised on the
+// device (pmf / sum, cmf / sum, so the host passes sum = 1 without knowing it).  cmf[i] = 1 for i >= n - 1: the binary search of
+// sample_reuse (lower bound of u < 1) then never leaves the kept rows, exactly as over a table of n rows.  header = {n as int bits, sum}.
+constexpr int kS = 1024;
+struct ScanTmp { int wi[kS / 64]; float wf[kS / 64]; };
+// exclusive scan of flag, inclusive scan of w over the kS threads of the block (+ the block totals)
+__device__ __forceinline__ void block_scan(int flag, float w, int &excl, float &incl, int &btotal, float &bsum, ScanTmp &t) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int ci = flag; float cf = w;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int ui = __shfl_up(ci, off, 64); const float uf = __shfl_up(cf, off, 64);
+        if (lane >= off) { ci += ui; cf += uf; }
+    }
+    __syncthreads();                       // (t may still be read from an earlier call)
+    if (lane == 63) { t.wi[wave] = ci; t.wf[wave] = cf; }
+    __syncthreads();
+    int bi = 0; float bf = 0.f;
+    btotal = 0; bsum = 0.f;
+#pragma unroll
+    for (int k = 0; k < kS / 64; ++k) {
+        if (k == wave) { bi = btotal; bf = bsum; }
+        btotal += t.wi[k]; bsum += t.wf[k];
+    }
+    excl = bi + ci - flag; incl = bf + cf;
+}
+__device__ __forceinline__ float edge_weight(const float *row, int w0, int wn) {
+    if (wn == 1) return row[w0];
+    return sqrtf(row[w0] * row[w0] + row[w0 + 1] * row[w0 + 1] + row[w0 + 2] * row[w0 + 2]);
+}
+__global__ __launch_bounds__(kS) void k_compact_count(int E, const uint8_t *__restrict__ keep, const float *__restrict__ rows, int S, int w0, int wn,
+                                                      int *__restrict__ bc, float *__restrict__ bs) {
+    __shared__ ScanTmp t;
+    const int e = blockIdx.x * kS + threadIdx.x;
+    const int flag = e < E && keep[e] ? 1 : 0;
+    const float w = flag ? edge_weight(rows + (size_t) e * S, w0, wn) : 0.f;
+    int excl, btotal; float incl, bsum;
+    block_scan(flag, w, excl, incl, btotal, bsum, t);
+    if (threadIdx.x == 0) { bc[blockIdx.x] = btotal; bs[blockIdx.x] = bsum; }
+}
+__global__ __launch_bounds__(kS) void k_compact_top(int nb, const int *__restrict__ bc, const float *__restrict__ bs, int *__restrict__ bo, float *__restrict__ fo,
+                                                    float *__restrict__ header) {
+    __shared__ ScanTmp t;
+    int ci = 0; float cf = 0.f;
+    for (int base = 0; base < nb; base += kS) {
+        const int b = base + threadIdx.x;
+        const int c = b < nb ? bc[b] : 0; const float f = b < nb ? bs[b] : 0.f;
+        int excl, btotal; float incl, bsum;
+        block_scan(c, f, excl, incl, btotal, bsum, t);
+        if (b < nb) { bo[b] = ci + excl; fo[b] = cf + (incl - f); }
+        ci += btotal; cf += bsum;
+    }
+    if (threadIdx.x == 0) { header[0] = __int_as_float(ci); header[1] = cf; }
+}
+__global__ __launch_bounds__(kS) void k_compact_write(int E, const uint8_t *__restrict__ keep, const float *__restrict__ rows, int S, int w0, int wn,
+                                                      const uint32_t *__restrict__ aux, int aux_stride, int A, const int *__restrict__ bo, const float *__restrict__ fo,
+                                                      const float *__restrict__ header, float *__restrict__ rows_out, uint32_t *__restrict__ aux_out,
+                                                      int32_t *__restrict__ pos, float *__restrict__ pmf, float *__restrict__ cmf) {
+    __shared__ ScanTmp t;
+    const int e = blockIdx.x * kS + threadIdx.x;
+    const int flag = e < E && keep[e] ? 1 : 0;
+    const float *row = rows + (size_t) e * S;
+    const float w = flag ? edge_weight(row, w0, wn) : 0.f;
+    int excl, btotal; float incl, bsum;
+    block_scan(flag, w, excl, incl, btotal, bsum, t);
+    if (e >= E) return;
+    const int n = __float_as_int(header[0]);
+    const float total = header[1], inv = total > 0.f ? 1.f / total : 0.f;
+    if (flag) {
+        const int p = bo[blockIdx.x] + excl;
+        for (int c = 0; c < S; ++c) rows_out[(size_t) p * S + c] = row[c];
+        for (int c = 0; c < A; ++c) aux_out[(size_t) p * A + c] = aux[(size_t) e * aux_stride + c];
+        pmf[p] = w * inv;
+        cmf[p] = p >= n - 1 ? 1.f : (fo[blockIdx.x] + incl) * inv;
+        pos[e] = p;
+    } else pos[e] = -1;
+    if (e >= n) {                          // slot e of the tail
+        for (int c = 0; c < S; ++c) rows_out[(size_t) e * S + c] = 0.f;
+        for (int c = 0; c < A; ++c) aux_out[(size_t) e * A + c] = 0u;
+        pmf[e] = 0.f; cmf[e] = 1.f;
+    }
+}
+__global__ __launch_bounds__(kB) void k_compact_rev(int E, int S, const int32_t *__restrict__ pos, const float *__restrict__ a_out, float *__restrict__ a_rows) {
+    const long long i = (long long) blockIdx.x * kB + threadIdx.x;
+    if (i >= (long long) E * S) return;
+    const int e = (int) (i / S), c = (int) (i - (long long) e * S), p = pos[e];
+    a_rows[i] = p >= 0 ? a_out[(size_t) p * S + c] : 0.f;
+}
+
+// ------------------------------------------------------------------ mesh areas + emitter tables (scene.cpp:183-196, area.cpp:10-16)
+// One workgroup per mesh: its total area (Mesh::m_total_area, mesh.cpp:244-246) and, for the mesh of an area light, the face-area
+// distribution (mesh.cpp:248-249: pmf = areas, cmf = their inclusive prefix sum, at emitter_i[.][3] of the concatenated tables).
+__global__ __launch_bounds__(kS) void k_mesh_areas(const float *__restrict__ rows, int stride, const int32_t *__restrict__ face_offset, const int32_t *__restrict__ mesh_emitter,
+                                                   const int32_t *__restrict__ emitter_i, const float *__restrict__ env_weight, float *__restrict__ mesh_area,
+                                                   float *__restrict__ face_pmf, float *__restrict__ face_cmf) {
+    __shared__ ScanTmp t;
+    const int m = blockIdx.x, f0 = face_offset[m], f1 = face_offset[m + 1], em = mesh_emitter[m];
+    const bool distrb = em >= 0 && env_weight[em] < 0.f;
+    const int off = distrb ? emitter_i[4 * em + 3] : 0;
+    float carry = 0.f;
+    for (int base = f0; base < f1; base += kS) {
+        const int f = base + threadIdx.x;
+        const float a = f < f1 ? rows[(size_t) f * stride + 21] : 0.f;
+        int excl, btotal; float incl, bsum;
+        block_scan(0, a, excl, incl, btotal, bsum, t);
+        if (distrb && f < f1) { face_pmf[off + f - f0] = a; face_cmf[off + f - f0] = carry + incl; }
+        carry += bsum;
+    }
+    if (threadIdx.x == 0) mesh_area[m] = carry;
+}
+// Scene::m_emitters_distrb (scene.cpp:183-196): sampling weight of an area light = area * luminance(radiance) (area.cpp:10-16), of the
+// environment map the host-made env_weight; normalised here (pmf / sum, running cmf), so the host passes emitter_sum = 1.
+__global__ void k_emitter_rows(int Ne, const int32_t *__restrict__ emitter_i, const float *__restrict__ radiance, const float *__restrict__ env_weight,
+                               const float *__restrict__ mesh_area, const float *__restrict__ face_cmf, float *__restrict__ emitter_f, float *__restrict__ emitter_pmf,
+                               float *__restrict__ emitter_cmf) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float total = 0.f;
+    for (int e = 0; e < Ne; ++e) {
+        const float *r = radiance + 3 * e;
+        const float w = env_weight[e] >= 0.f ? env_weight[e] : mesh_area[emitter_i[4 * e]] * (r[0] * .2126f + r[1] * .7152f + r[2] * .0722f);
+        emitter_pmf[e] = w; total += w;
+    }
+    const float inv = 1.f / total;
+    float run = 0.f;
+    for (int e = 0; e < Ne; ++e) {
+        const bool env = env_weight[e] >= 0.f;
+        const float w = emitter_pmf[e] * inv, area = mesh_area[emitter_i[4 * e]];
+        run += w;
+        emitter_pmf[e] = w; emitter_cmf[e] = run;
+        float *o = emitter_f + PSDR_EMITTER_F_STRIDE * e;
+        o[0] = env ? 0.f : radiance[3 * e]; o[1] = env ? 0.f : radiance[3 * e + 1]; o[2] = env ? 0.f : radiance[3 * e + 2];
+        o[3] = w; o[4] = env ? 0.f : 1.f / area; o[5] = env ? 0.f : face_cmf[emitter_i[4 * e + 3] + emitter_i[4 * e + 2] - 1];
+        o[6] = 0.f; o[7] = 0.f;
+    }
+}
+
 inline dim3 grid(int n) { return dim3((unsigned) ((n + kB - 1) / kB)); }
 }  // namespace
 
@@ -299,6 +439,43 @@ int psdr_geo_prim_edges_fwd(int32_t E, const int32_t *edges, const uint8_t *face
 int psdr_geo_prim_edges_rev(int32_t E, const int32_t *edges, const float *v, const float *cam22, const float *a_rows8, float *a_v, float *a_w2s, void *stream) {
     if (E <= 0 || !edges || !v || !cam22 || !a_rows8 || !a_v || !a_w2s) return psdr_host::fail("psdr_geo_prim_edges_rev: invalid argument");
     hipLaunchKernelGGL(k_prim_edges_rev, grid(E), dim3(kB), 0, (hipStream_t) stream, E, edges, v, cam22, a_rows8, a_v, a_w2s);
+    TAB_TRY(hipGetLastError());
+    return 0;
+}
+
+int psdr_geo_compact_edges_fwd(int32_t E, const float *rows, int32_t S, const uint8_t *keep, int32_t w0, int32_t wn, const void *aux, int32_t aux_stride, int32_t A,
+                               void *scratch, float *rows_out, void *aux_out, int32_t *pos, float *pmf, float *cmf, float *header, void *stream) {
+    if (E <= 0 || !rows || S <= 0 || !keep || w0 < 0 || (wn != 1 && wn != 3) || w0 + wn > S || (A > 0 && (!aux || !aux_out || aux_stride < A)) || !scratch || !rows_out || !pos ||
+        !pmf || !cmf || !header)
+        return psdr_host::fail("psdr_geo_compact_edges_fwd: invalid argument");
+    hipStream_t s = (hipStream_t) stream;
+    const int nb = (E + kS - 1) / kS;
+    int *bc = (int *) scratch, *bo = bc + nb;
+    float *bs = (float *) (bo + nb), *fo = bs + nb;
+    hipLaunchKernelGGL(k_compact_count, dim3(nb), dim3(kS), 0, s, E, keep, rows, S, w0, wn, bc, bs);
+    hipLaunchKernelGGL(k_compact_top, dim3(1), dim3(kS), 0, s, nb, bc, bs, bo, fo, header);
+    hipLaunchKernelGGL(k_compact_write, dim3(nb), dim3(kS), 0, s, E, keep, rows, S, w0, wn, (const uint32_t *) aux, aux_stride, A, bo, fo, header, rows_out,
+                       (uint32_t *) aux_out, pos, pmf, cmf);
+    TAB_TRY(hipGetLastError());
+    return 0;
+}
+int psdr_geo_compact_edges_rev(int32_t E, int32_t S, const int32_t *pos, const float *a_rows_out, float *a_rows, void *stream) {
+    if (E <= 0 || S <= 0 || !pos || !a_rows_out || !a_rows) return psdr_host::fail("psdr_geo_compact_edges_rev: invalid argument");
+    const long long n = (long long) E * S;
+    hipLaunchKernelGGL(k_compact_rev, dim3((unsigned) ((n + kB - 1) / kB)), dim3(kB), 0, (hipStream_t) stream, E, S, pos, a_rows_out, a_rows);
+    TAB_TRY(hipGetLastError());
+    return 0;
+}
+
+int psdr_geo_emitter_tables(int32_t M, const float *rows, int32_t row_stride, const int32_t *face_offset, const int32_t *mesh_emitter, int32_t Ne, const int32_t *emitter_i,
+                            const float *radiance, const float *env_weight, float *mesh_area, float *emitter_f, float *emitter_pmf, float *emitter_cmf, float *face_pmf,
+                            float *face_cmf, void *stream) {
+    if (M <= 0 || !rows || row_stride < 22 || !face_offset || !mesh_emitter || !mesh_area || Ne < 0 ||
+        (Ne > 0 && (!emitter_i || !radiance || !env_weight || !emitter_f || !emitter_pmf || !emitter_cmf || !face_pmf || !face_cmf)))
+        return psdr_host::fail("psdr_geo_emitter_tables: invalid argument");
+    hipStream_t s = (hipStream_t) stream;
+    hipLaunchKernelGGL(k_mesh_areas, dim3(M), dim3(kS), 0, s, rows, row_stride, face_offset, mesh_emitter, emitter_i, env_weight, mesh_area, face_pmf, face_cmf);
+    if (Ne > 0) hipLaunchKernelGGL(k_emitter_rows, dim3(1), dim3(64), 0, s, Ne, emitter_i, radiance, env_weight, mesh_area, face_cmf, emitter_f, emitter_pmf, emitter_cmf);
     TAB_TRY(hipGetLastError());
     return 0;
 }

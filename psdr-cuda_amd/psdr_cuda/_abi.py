@@ -86,6 +86,7 @@ HIP_SYMBOLS = (
     "psdr_bvh_build", "psdr_bvh_stats", "psdr_scene_info", "psdr_trace", "psdr_render_c", "psdr_render_d_fwd", "psdr_render_d_rev",
     "psdr_guide_build", "psdr_get_counters",
     "psdr_geo_world_vertices_fwd", "psdr_geo_world_vertices_rev", "psdr_geo_tri_rows_fwd", "psdr_geo_tri_rows_rev", "psdr_geo_sec_edges_fwd", "psdr_geo_sec_edges_rev", "psdr_geo_prim_edges_fwd", "psdr_geo_prim_edges_rev",
+    "psdr_geo_compact_edges_fwd", "psdr_geo_compact_edges_rev", "psdr_geo_emitter_tables",
 )
 
 HIP_LIB_PATH = os.environ.get("PSDR_HIP_LIB") or os.path.join(PKG_ROOT, "lib", "libpsdr_hip.so")   # env override: kernel A/B experiments
@@ -125,6 +126,9 @@ def load_hip():
     lib.psdr_geo_sec_edges_rev.argtypes = [i32, vp, vp, vp, vp, i32, vp]
     lib.psdr_geo_prim_edges_fwd.argtypes = [i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp]
     lib.psdr_geo_prim_edges_rev.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp]
+    lib.psdr_geo_compact_edges_fwd.argtypes = [i32, vp, i32, vp, i32, i32, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.psdr_geo_compact_edges_rev.argtypes = [i32, i32, vp, vp, vp, vp]
+    lib.psdr_geo_emitter_tables.argtypes = [i32, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     for name in HIP_SYMBOLS:
         if name not in ("psdr_last_error", "psdr_version"):
             getattr(lib, name).restype = C.c_int

@@ -234,9 +234,29 @@ class DiscreteDistribution:
 
     def __init__(self):
         self.m_size = 0
-        self.m_sum = 0.0
+        self._sum, self._sum_dev = 0.0, None
         self.m_pmf = None
         self.m_cmf = None
+
+    # the sum may still be on the device (init_device): read when somebody asks
+    @property
+    def m_sum(self):
+        if self._sum_dev is not None:
+            self._sum, self._sum_dev = float(self._sum_dev.item()), None
+        return self._sum
+
+    @m_sum.setter
+    def m_sum(self, v):
+        self._sum, self._sum_dev = float(v), None
+
+    def init_device(self, pmf, cmf, total):
+        """tables built by a kernel (csrc/psdr_tables.hip); total: a host float, or a one-element device tensor that is read on first use"""
+        self.m_size = int(pmf.shape[0])
+        self.m_pmf, self.m_cmf = pmf, cmf
+        if isinstance(total, torch.Tensor):
+            self._sum_dev = total
+        else:
+            self.m_sum = total
 
     def init(self, pmf, total=None):
         """total: the sum of pmf when the caller already holds it on the host (Scene.configure reads every size and sum of a

@@ -268,7 +268,7 @@ class Integrator(Object):
         psdr_assert(scene.is_ready(), "Input scene must be configured!")
         psdr_assert(0 <= sensor_id < scene.num_sensors, "Invalid sensor id!")
         t0 = time.perf_counter()
-        tb = scene.tables(sensor_id)
+        tb = scene.tables(sensor_id, capacity=True)
         opts = self._opts(scene, with_edges=False)
         img, work = self._render_c(scene, tb, opts, None, defer_reduce=True)
         self._advance_rng(scene, opts)
@@ -283,7 +283,7 @@ class Integrator(Object):
         psdr_assert(scene.is_ready(), "Input scene must be configured!")
         psdr_assert(0 <= sensor_id < scene.num_sensors, "Invalid sensor id!")
         t0 = time.perf_counter()
-        tb = scene.tables(sensor_id)
+        tb = scene.tables(sensor_id, capacity=True)
         opts = self._opts(scene, with_edges=True)
         if not (scene._sensor_tables[sensor_id]["num_prim_edges"] > 0):
             opts.sppe = opts.sppe_begin = opts.sppe_end = 0
@@ -338,7 +338,7 @@ class DirectIntegrator(Integrator):
         psdr_assert(len(reso) == 4)
         cells = reso[0] * reso[1] * reso[2]
         psdr_assert(cells * reso[3] < 2 ** 31 - 1)
-        tb = scene.tables(sensor_id)
+        tb = scene.tables(sensor_id, capacity=True)
         lib, keep = self._prepare(scene, tb, None)
         mass = torch.zeros(cells, dtype=torch.float32, device="cuda")
         opts = self._opts(scene, with_edges=True)

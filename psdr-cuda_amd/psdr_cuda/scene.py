@@ -104,6 +104,19 @@ RoughConductorBSDF = RoughConductor
 # ---------------------------------------------------------------------------- emitters
 class Emitter(Object):
     _type_name = "Emitter"
+    _weight_host, _weight_dev = 1.0, None
+
+    # the sampling weight (emitter.h:27; normalised by Scene.configure, scene.cpp:183-196) stays on the device after a native configure():
+    # one element of the emitter distribution, read when somebody asks
+    @property
+    def m_sampling_weight(self):
+        if self._weight_dev is not None:
+            self._weight_host, self._weight_dev = float(self._weight_dev.item()), None
+        return self._weight_host
+
+    @m_sampling_weight.setter
+    def m_sampling_weight(self, v):
+        self._weight_host, self._weight_dev = float(v), None
 
 
 class AreaLight(Emitter):
@@ -266,6 +279,8 @@ class PerspectiveCamera(Sensor):
         """perspective.cpp:11-112 -> dict of tensors for this sensor (one call: reads the edge count and the distribution sum back itself;
         Scene.configure uses configure_begin / configure_finish around its batched read-back)."""
         st = self.configure_begin(scene)
+        if st.get("kind") == "device":
+            return st["out"]
         count = int(st["count_t"].item()) if st["count_t"] is not None else 0
         out = self.configure_finish(st, count)
         if st.get("sum_t") is not None:
@@ -296,9 +311,16 @@ class PerspectiveCamera(Sensor):
         c2s, s2c, c2s_t, s2c_t = self._lens
         # (inv_ex: torch.linalg.inv reads its error flag back -- a device-to-host read per configure() when the pose carries a gradient; the
         # pose was checked when it changed: the determinant test above)
-        w2s = c2s_t @ (self._pose_inv if self._pose_inv is not None else torch.linalg.inv_ex(tw)[0])
-        cam_pos = tw[:3, 3] / tw[3, 3]            # transform_pos(to_world, origin)
-        cam_dir = tw[:3, 2]                       # transform_dir(to_world, (0, 0, 1))
+        # a pose without a gradient under an unchanged lens: world_to_sample, the camera record and the 22 words the edge kernel reads stand
+        cam_key = (pose_key, lens_key) if self._pose_inv is not None else None
+        cached = getattr(self, "_cam_cache", None)
+        cached = cached if cached is not None and cam_key is not None and cached[0] == cam_key else None
+        if cached is not None:
+            w2s, cam_pos, cam_dir = cached[1], cached[2], cached[3]
+        else:
+            w2s = c2s_t @ (self._pose_inv if self._pose_inv is not None else torch.linalg.inv_ex(tw)[0])
+            cam_pos = tw[:3, 3] / tw[3, 3]            # transform_pos(to_world, origin)
+            cam_dir = tw[:3, 2]                       # transform_dir(to_world, (0, 0, 1))
 
         if getattr(self, "_cam_tail_key", None) != lens_key:
             def tp(x, y):
@@ -309,8 +331,12 @@ class PerspectiveCamera(Sensor):
             self._cam_tail_key = lens_key
             self._cam_tail = torch.tensor([inv_area] + [0.0] * (_abi.CAM_WORDS - 55), dtype=torch.float32, device=tw.device)
         # words 0..15 sample_to_camera, 16..31 to_world, 32..47 world_to_sample, 48..50 position, 51..53 direction, 54 1 / film area
-        cam = torch.cat([s2c_t.reshape(-1), tw.detach().reshape(-1), w2s.detach().reshape(-1), cam_pos.detach(), cam_dir.detach(), self._cam_tail])
-        out = {"cam": cam.contiguous(), "cam_to_world": tw, "prim_edge": None, "prim_cmf": None, "prim_pmf": None,
+        if cached is not None:
+            cam = cached[4]
+        else:
+            cam = torch.cat([s2c_t.reshape(-1), tw.detach().reshape(-1), w2s.detach().reshape(-1), cam_pos.detach(), cam_dir.detach(), self._cam_tail]).contiguous()
+            self._cam_cache = (cam_key, w2s, cam_pos, cam_dir, cam) if cam_key is not None else None
+        out = {"cam": cam, "cam_to_world": tw, "prim_edge": None, "prim_cmf": None, "prim_pmf": None,
                "prim_sum": 0.0, "num_prim_edges": 0, "prim_edge_z": None}
 
         # ---- primary-edge list, perspective.cpp:39-111
@@ -329,9 +355,16 @@ class PerspectiveCamera(Sensor):
                     e = e / ln.unsqueeze(-1)
                     return torch.cat([q0, q1, torch.stack([-e[:, 1], e[:, 0]], dim=-1), ln.unsqueeze(-1), torch.zeros_like(ln).unsqueeze(-1)], dim=-1)
                 r8, z4, keep8 = tables_native.prim_edges(bt["v_world"], w2s, bt["tri_info"], bt["tp"]["edges_i32"], bt["tp"]["edge_face_normals_u8"],
-                                                        cam_pos, cam_dir, film_records)
-                keep = keep8.bool()
-                st.update(kind="native", r8=r8, z4=z4, keep=keep, count_t=keep.sum().reshape(1))
+                                                        cam_pos, cam_dir, film_records, cam22=cam[32:54])
+                # the kept edges first, in a table of the same capacity; their number and the sum of their lengths stay on the device
+                # (csrc/psdr_tables.hip k_compact_*): no read-back, no host-sized gather
+                pe, zs, _pos, pmf, cmf, hdr = tables_native.compact_edges(r8, keep8, 6, 1, aux=z4, aux_cols=4)
+                E = int(pe.shape[0])
+                out.update(prim_edge=pe, prim_cmf=cmf, prim_pmf=pmf, prim_sum=1.0, num_prim_edges=E, prim_header=hdr)
+                if st["vis"]:
+                    out["prim_edge_z"] = zs.view(torch.float32)
+                self.m_enable_edges = True
+                st.update(kind="device")
             elif ei is not None:
                 tinfo, facen = bt["tri_info"], bt["tp"]["edge_face_normals"]
                 valid = ei[:, 3] >= 0
@@ -521,12 +554,32 @@ class Mesh(Object):
         self._face_uv_indices = None
         self._edge_indices = None       # numpy [E,5]
         self._edge_indices_dev = None
-        self.m_total_area = 0.0
-        self.m_inv_total_area = 0.0
+        self._area_host, self._area_dev = 0.0, None
         self._triangle_info = None
         self._vertex_positions = None
         self._sec_edge_info = None
         self._face_distrb_cache = None
+
+    # total area (mesh.cpp:244-246): Scene.configure leaves it on the device (one element of the native chain's area table); the host value
+    # is read when somebody asks
+    @property
+    def m_total_area(self):
+        if self._area_dev is not None:
+            self._area_host, self._area_dev = float(self._area_dev.item()), None
+        return self._area_host
+
+    @m_total_area.setter
+    def m_total_area(self, v):
+        self._area_host, self._area_dev = float(v), None
+
+    @property
+    def m_inv_total_area(self):
+        a = self.m_total_area
+        return 1.0 / a if a != 0.0 else 0.0
+
+    @m_inv_total_area.setter
+    def m_inv_total_area(self, v):          # derived from m_total_area
+        pass
 
     # -- loading ---------------------------------------------------------------
     def load(self, filename, verbose=False):
@@ -1085,11 +1138,14 @@ class Scene(Object):
         else:
             v_world = to_world(v_raw, mats)
         if tables_native.available(v_world):          # one forward (and one reverse) launch sequence on the HIP library
-            tri_info = tables_native.tri_rows(v_world, tp["faces_i32"], lambda v, f: process_mesh(v, f)[0])
+            # rows of PSDR_TRI_STRIDE words (padding zero): psdr_scene_desc::tri_info as it stands; the areas are summed with the emitter
+            # tables (_finish_native), nothing is read back
+            tri_info = tables_native.tri_rows(v_world, tp["faces_i32"], lambda v, f: process_mesh(v, f)[0], width=_abi.TRI_STRIDE)
+            self._areas_t = None
         else:
             tri_info, _ = process_mesh(v_world, tp["faces"])
-        # total areas: on the device until _mesh_areas_to_host (configure() reads every size and sum it needs back in ONE batch)
-        self._areas_t = torch.zeros(len(meshes), device=v_world.device).index_add(0, tp["tmesh"], tri_info[:, 21].detach())
+            # total areas: on the device until _mesh_areas_to_host (configure() reads every size and sum it needs back in ONE batch)
+            self._areas_t = torch.zeros(len(meshes), device=v_world.device).index_add(0, tp["tmesh"], tri_info[:, 21].detach())
         for i, m in enumerate(meshes):
             m._vertex_positions = v_world[tp["v_off"][i]:tp["v_off"][i + 1]]
             m._triangle_info = tri_info[tp["f_off"][i]:tp["f_off"][i + 1]]
@@ -1129,7 +1185,7 @@ class Scene(Object):
             return torch.cat([p0, e1, n0, n1, p2, is_b.to(torch.float32).unsqueeze(-1)], dim=-1)
         if tables_native.available(v_world):
             info, keep8 = tables_native.sec_edges(v_world, tri_info, tp["edges_i32"], records)
-            keep = keep8.bool()
+            return info, keep8          # _finish_native compacts on the device
         else:
             info = records(v_world, tri_info, ei)
             is_b = ei[:, 3] < 0           # (the filter on the gathered normals themselves, as this chain always evaluated it: the rounding of the
@@ -1297,6 +1353,8 @@ class Scene(Object):
         T = face_offset[-1]
         # secondary edges, scene.cpp:219-244: records and the coplanar filter's mask (no read-back yet)
         sec = self._secondary_edges(tp, v_world, tri_info22) if o.sppse > 0 else None
+        if tables_native.available(v_world):
+            return self._finish_native(d, tp, tri_info22, sec, sensor_states, key, alive, has_uv, t_start)
 
         # ---- ONE read-back for every size and sum the host needs from here on: mesh areas, the luminance of the area lights, the
         # sums of their face distributions, the numbers of kept secondary / primary edges
@@ -1441,6 +1499,127 @@ class Scene(Object):
                 self.log("%d secondary edges initialized." % tb["num_sec_edges"])
             self.log("Configured in %g seconds." % (time.perf_counter() - t_start))
 
+    def _finish_native(self, d, tp, tri_info, sec, sensor_states, key, alive, has_uv, t_start):
+        """The rest of configure() on a GPU: every count and sum stays on the device.  Edge tables keep the capacity of their candidate lists
+        (kept rows first, csrc/psdr_tables.hip k_compact_*), the distributions are normalised there (the descriptor's sums are 1), mesh areas
+        and the emitter tables come from one kernel pair; host attributes that mirror device values (Mesh.m_total_area,
+        AreaLight.m_sampling_weight, DiscreteDistribution.m_sum, the numbers of kept edges) are read on first use."""
+        o = self.opts
+        face_offset = tp["f_off"]
+        T = face_offset[-1]
+        self._sensor_tables = [st["out"] for st in sensor_states]
+        tb = {"tri_info": tri_info, "tri_mesh": tp["tri_mesh"], "num_tris": T, "tri_uv": None, "face_offset": face_offset, "device_counts": True}
+        if has_uv:
+            uvk = tuple(id(m._triangle_uv) for m in self.m_meshes)
+            if getattr(self, "_tri_uv_key", None) != uvk:               # the uv rows do not move with the vertices
+                uv_rows = [m._triangle_uv if m._triangle_uv is not None else torch.zeros(m.num_faces, 6, device=d) for m in self.m_meshes]
+                self._tri_uv_key = uvk
+                self._tri_uv_t = torch.cat([torch.cat(uv_rows, dim=0).detach(), torch.zeros(T, 2, device=d)], dim=-1).contiguous()
+            tb["tri_uv"] = self._tri_uv_t
+        mt = self._material_tables(d)
+        env_tex = mt.pop("env_tex")
+        tb.update(mt)
+
+        # ---- emitters, scene.cpp:183-196 + area.cpp:10-16: static ids once per topology, areas / weights / face distributions by kernel
+        Ne, M = len(self.m_emitters), len(self.m_meshes)
+        ekey = (tp["key"], tuple((id(e), id(e.m_mesh)) for e in self.m_emitters), tuple(id(m.m_emitter) for m in self.m_meshes))
+        if getattr(self, "_emit_static", None) is None or self._emit_static[0] != ekey:
+            em_ids = {id(e): i for i, e in enumerate(self.m_emitters)}
+            mesh_emitter = np.asarray([em_ids.get(id(m.m_emitter), -1) for m in self.m_meshes], dtype=np.int32)
+            ei_h = np.zeros((max(Ne, 1), _abi.EMITTER_I_STRIDE), dtype=np.int32)
+            coff = 0
+            for i, e in enumerate(self.m_emitters):
+                mi = self.m_meshes.index(e.m_mesh)
+                env = isinstance(e, EnvironmentMap)
+                ei_h[i] = [mi, face_offset[mi], e.m_mesh.num_faces, 0 if env else coff]
+                coff += 0 if env else e.m_mesh.num_faces
+            ints = torch.from_numpy(np.concatenate([mesh_emitter, ei_h.reshape(-1), np.asarray(face_offset, dtype=np.int32)])).to(d)
+            self._emit_static = (ekey, ints[:M], ints[M:M + ei_h.size].reshape(-1, _abi.EMITTER_I_STRIDE), ints[M + ei_h.size:], coff,
+                                 torch.full((max(Ne, 1),), -1.0, device=d))
+        _, mesh_emitter_t, ei_t, foff_t, n_face_words, no_env = self._emit_static
+        env_w = no_env
+        if self.m_emitter_env is not None:
+            self.m_emitter_env.configure()
+            env_w = torch.tensor([float(e.m_sampling_weight) if isinstance(e, EnvironmentMap) else -1.0 for e in self.m_emitters], dtype=torch.float32, device=d)
+        if Ne == 1 and not isinstance(self.m_emitters[0], EnvironmentMap):
+            rad = self.m_emitters[0].radiance.t.reshape(1, 3)
+        elif Ne:
+            rad = torch.stack([torch.zeros(3, device=d) if isinstance(e, EnvironmentMap) else e.radiance.t.reshape(3) for e in self.m_emitters])
+        else:
+            rad = torch.zeros(1, 3, device=d)
+        area, ef, epmf, ecmf, fpmf, fcmf = tables_native.emitter_tables(tri_info, foff_t, mesh_emitter_t, ei_t if Ne else None, rad.detach().contiguous().float(),
+                                                                        env_w, n_face_words)
+        for i, m in enumerate(self.m_meshes):
+            m._area_dev = area[i]
+        for i, e in enumerate(self.m_emitters):
+            e.m_ready = True
+            e._weight_dev = epmf[i]                        # normalised (scene.cpp:190-193 multiplies every weight by 1 / sum)
+        coff = 0
+        for i, e in enumerate(self.m_emitters):
+            if isinstance(e, EnvironmentMap):
+                continue
+            n = e.m_mesh.num_faces
+            fd = DiscreteDistribution(); fd.init_device(fpmf[coff:coff + n], fcmf[coff:coff + n], ef[i, 5])
+            e.m_mesh._face_distrb = fd
+            coff += n
+        tb["mesh_emitter"] = mesh_emitter_t
+        if Ne:
+            tb.update(emitter_f=ef, emitter_i=ei_t, emitter_rad=rad, emitter_cmf=ecmf, emitter_pmf=epmf, emitter_sum=1.0)
+        else:
+            z = torch.zeros(1, device=d)
+            tb.update(emitter_f=torch.zeros(1, _abi.EMITTER_F_STRIDE, device=d), emitter_i=ei_t, emitter_rad=rad, emitter_cmf=z, emitter_pmf=z, emitter_sum=0.0)
+        tb.update(face_cmf=fcmf, face_pmf=fpmf, num_emitters=Ne)
+        if self.m_emitter_env is not None:
+            env = self.m_emitter_env
+            cd = env._cell_distrb
+            tb.update(env_emitter=self.m_emitters.index(env), env_tex=env_tex, env_reso=list(env._cell_reso),
+                      env_f=env.record(), env_cmf=cd.m_cmf, env_pmf=cd.m_pmf, env_sum=cd.m_sum)
+        else:
+            tb.update(env_emitter=-1, env_tex=[0, 0, 0], env_reso=[0, 0], env_f=None, env_cmf=None, env_pmf=None, env_sum=0.0)
+
+        # ---- secondary edges: kept records first, normalised length distribution, adjacent faces alongside
+        if sec is not None:
+            se, faces, _pos, pmf, cmf, hdr = tables_native.compact_edges(sec[0], sec[1], 3, 3, aux=tp["edges_i32"][:, 2:4], aux_cols=2)
+            self._sec_edge_faces = faces
+            tb.update(sec_edge=se, sec_cmf=cmf, sec_pmf=pmf, sec_sum=1.0, num_sec_edges=int(se.shape[0]), sec_edge_faces=faces, sec_header=hdr)
+        else:
+            tb.update(sec_edge=None, sec_cmf=None, sec_pmf=None, sec_sum=0.0, num_sec_edges=0, sec_edge_faces=None)
+        self._version += 1
+        tb["version"] = self._version
+        tb["geo_version"] = self._version
+        self._tables = tb
+        self._edge_counts = None
+        self._configured = True
+        self._bvh_version = None
+        self._static_cache = (key, alive, dict(tb)) if key is not None else None
+        if o.log_level > 0:
+            self.log("AABB: [lower = %s, upper = %s]" % (self.m_lower.tolist(), self.m_upper.tolist()))
+            n_sec, n_prim = self._kept_edge_counts()
+            if o.sppe > 0:
+                self.log("(%s) primary edges initialized." % ", ".join(str(n) for n in n_prim))
+            if o.sppse > 0:
+                self.log("%d secondary edges initialized." % n_sec)
+            self.log("Configured in %g seconds." % (time.perf_counter() - t_start))
+
+    def _kept_edge_counts(self):
+        """(kept secondary edges, [kept primary edges per sensor]) of a native configure(): ONE read of the device headers, on first use."""
+        if getattr(self, "_edge_counts", None) is None:
+            hs = [self._tables["sec_header"][:1]] if self._tables.get("sec_header") is not None else []
+            hs += [st["prim_header"][:1] for st in self._sensor_tables if st.get("prim_header") is not None]
+            vals = torch.cat(hs).view(torch.int32).tolist() if hs else []
+            k = 0
+            n_sec = 0
+            if self._tables.get("sec_header") is not None:
+                n_sec = int(vals[0]); k = 1
+            n_prim = []
+            for st in self._sensor_tables:
+                if st.get("prim_header") is not None:
+                    n_prim.append(int(vals[k])); k += 1
+                else:
+                    n_prim.append(0)
+            self._edge_counts = (n_sec, n_prim)
+        return self._edge_counts
+
     def _resolve_aabb(self):
         pend = getattr(self, "_aabb_pending", None)
         if pend is not None:
@@ -1516,14 +1695,33 @@ class Scene(Object):
             "\n".join("  " + x.to_string() for x in arr) for arr in (self.m_sensors, self.m_bsdfs, self.m_meshes))
 
     # -- descriptor for the C ABI ------------------------------------------------
-    def tables(self, sensor_id=0):
-        """Flat dict of tensors for one sensor (scene tables + that sensor's camera/primary edges)."""
+    def tables(self, sensor_id=0, capacity=False):
+        """Flat dict of tensors for one sensor (scene tables + that sensor's camera/primary edges).  After a native configure() the edge tables
+        are stored at the capacity of their candidate lists with the kept rows first and the count on the device: capacity=True hands them out
+        as they stand (the render calls: no read-back), the default cuts them to the kept rows -- the tables the reference holds
+        (scene.cpp:219-244, perspective.cpp:96-111); that reads the counts once per configure()."""
         psdr_assert(self._configured, "Input scene must be configured!")
         psdr_assert(0 <= sensor_id < self.num_sensors, "Invalid sensor id!")
         t = dict(self._tables)
         t.update(self._sensor_tables[sensor_id])
         t["width"], t["height"] = self.opts.width, self.opts.height
         t["num_meshes"], t["num_bsdfs"] = len(self.m_meshes), len(self.m_bsdfs)
+        if t.get("device_counts") and not capacity:
+            n_sec, n_prim = self._kept_edge_counts()
+            if t.get("sec_header") is not None:
+                if n_sec > 0:
+                    t.update(sec_edge=t["sec_edge"][:n_sec], sec_cmf=t["sec_cmf"][:n_sec], sec_pmf=t["sec_pmf"][:n_sec],
+                             sec_edge_faces=t["sec_edge_faces"][:n_sec], num_sec_edges=n_sec)
+                else:
+                    t.update(sec_edge=None, sec_cmf=None, sec_pmf=None, sec_sum=0.0, num_sec_edges=0, sec_edge_faces=None)
+            if t.get("prim_header") is not None:
+                n = n_prim[sensor_id]
+                if n > 0:
+                    t.update(prim_edge=t["prim_edge"][:n], prim_cmf=t["prim_cmf"][:n], prim_pmf=t["prim_pmf"][:n], num_prim_edges=n)
+                    if t.get("prim_edge_z") is not None:
+                        t["prim_edge_z"] = t["prim_edge_z"][:n]
+                else:
+                    t.update(prim_edge=None, prim_cmf=None, prim_pmf=None, prim_sum=0.0, num_prim_edges=0, prim_edge_z=None)
         return t
 
 

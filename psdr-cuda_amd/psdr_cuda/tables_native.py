@@ -75,15 +75,15 @@ def world_vertices(v_raw, vmesh_i32, mats, ref_fn):
 
 class _TriRows(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, v, faces_i32, ref_fn):
+    def forward(ctx, v, faces_i32, ref_fn, width):
         lib = _abi.load_hip()
         vc = v.detach().contiguous().float()
         V, T = vc.shape[0], faces_i32.shape[0]
         vsum = torch.empty(V, 3, dtype=torch.float32, device=v.device)
-        rows = torch.empty(T, 22, dtype=torch.float32, device=v.device)
-        _abi.check(lib, lib.psdr_geo_tri_rows_fwd(V, T, vc.data_ptr(), faces_i32.data_ptr(), vsum.data_ptr(), rows.data_ptr(), 22, _stream()))
+        rows = torch.empty(T, width, dtype=torch.float32, device=v.device)
+        _abi.check(lib, lib.psdr_geo_tri_rows_fwd(V, T, vc.data_ptr(), faces_i32.data_ptr(), vsum.data_ptr(), rows.data_ptr(), width, _stream()))
         ctx.save_for_backward(v, faces_i32, vsum)
-        ctx.ref_fn = ref_fn
+        ctx.ref_fn, ctx.width = ref_fn, width
         return rows
 
     @staticmethod
@@ -93,21 +93,22 @@ class _TriRows(torch.autograd.Function):
             with torch.enable_grad():
                 vv = v.detach().requires_grad_(True) if not v.requires_grad else v
                 rows = ctx.ref_fn(vv, faces)
-                g, = torch.autograd.grad(rows, vv, a_rows, create_graph=True)
-            return g, None, None
+                g, = torch.autograd.grad(rows, vv, a_rows[:, :22], create_graph=True)
+            return g, None, None, None
         lib = _abi.load_hip()
         V, T = v.shape[0], faces.shape[0]
         a = a_rows.contiguous().float()
         a_v = torch.zeros(V, 3, dtype=torch.float32, device=v.device)
         a_vsum = torch.empty(V, 3, dtype=torch.float32, device=v.device)
-        _abi.check(lib, lib.psdr_geo_tri_rows_rev(V, T, v.detach().contiguous().data_ptr(), faces.data_ptr(), vsum.data_ptr(), a.data_ptr(), 22,
+        _abi.check(lib, lib.psdr_geo_tri_rows_rev(V, T, v.detach().contiguous().data_ptr(), faces.data_ptr(), vsum.data_ptr(), a.data_ptr(), ctx.width,
                                                   a_vsum.data_ptr(), a_v.data_ptr(), _stream()))
-        return a_v, None, None
+        return a_v, None, None, None
 
 
-def tri_rows(v_world, faces_i32, ref_fn):
-    """rows [T, 22] of process_mesh; ref_fn(v, faces) = the torch formulation (double backward, CPU)."""
-    return _TriRows.apply(v_world, faces_i32, ref_fn)
+def tri_rows(v_world, faces_i32, ref_fn, width=22):
+    """rows [T, width] of process_mesh (width 24 = PSDR_TRI_STRIDE: the rows as psdr_scene_desc::tri_info holds them, padding words zero);
+    ref_fn(v, faces) = the torch formulation [T, 22] (double backward, CPU)."""
+    return _TriRows.apply(v_world, faces_i32, ref_fn, width)
 
 
 class _SecEdges(torch.autograd.Function):
@@ -149,11 +150,12 @@ def sec_edges(v_world, rows, edges_i32, ref_fn):
 
 class _PrimEdges(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, v, w2s, rows, edges_i32, face_normals_u8, cam_pos, cam_dir, ref_fn):
+    def forward(ctx, v, w2s, rows, edges_i32, face_normals_u8, cam_pos, cam_dir, ref_fn, cam22):
         lib = _abi.load_hip()
         E = edges_i32.shape[0]
         vc, rc = v.detach().contiguous().float(), rows.detach().contiguous().float()
-        cam22 = torch.cat([w2s.detach().reshape(-1), cam_pos.detach().reshape(-1), cam_dir.detach().reshape(-1)]).float().contiguous()
+        if cam22 is None:
+            cam22 = torch.cat([w2s.detach().reshape(-1), cam_pos.detach().reshape(-1), cam_dir.detach().reshape(-1)]).float().contiguous()
         rows8 = torch.empty(E, 8, dtype=torch.float32, device=v.device)
         z4 = torch.empty(E, 4, dtype=torch.float32, device=v.device)
         keep = torch.empty(E, dtype=torch.uint8, device=v.device)
@@ -173,16 +175,80 @@ class _PrimEdges(torch.autograd.Function):
                 ww = w2s if w2s.requires_grad else w2s.detach().requires_grad_(True)
                 r8 = ctx.ref_fn(vv, ww, edges)
                 gv, gw = torch.autograd.grad(r8, (vv, ww), a_rows8, create_graph=True, allow_unused=True)
-            return gv, gw, None, None, None, None, None, None
+            return gv, gw, None, None, None, None, None, None, None
         lib = _abi.load_hip()
         a = a_rows8.contiguous().float()
         a_v = torch.zeros_like(v, dtype=torch.float32)
         a_w = torch.zeros(16, dtype=torch.float32, device=v.device)
         _abi.check(lib, lib.psdr_geo_prim_edges_rev(edges.shape[0], edges.data_ptr(), v.detach().contiguous().data_ptr(), cam22.data_ptr(), a.data_ptr(),
                                                     a_v.data_ptr(), a_w.data_ptr(), _stream()))
-        return a_v, a_w.reshape(4, 4), None, None, None, None, None, None
+        return a_v, a_w.reshape(4, 4), None, None, None, None, None, None, None
 
 
-def prim_edges(v_world, w2s, rows, edges_i32, face_normals_u8, cam_pos, cam_dir, ref_fn):
-    """(rows8 [E, 8], z4 [E, 4], keep [E]) for every candidate edge of one sensor; ref_fn(v, w2s, edges) -> rows8 (torch formulation)."""
-    return _PrimEdges.apply(v_world, w2s, rows, edges_i32, face_normals_u8, cam_pos, cam_dir, ref_fn)
+def prim_edges(v_world, w2s, rows, edges_i32, face_normals_u8, cam_pos, cam_dir, ref_fn, cam22=None):
+    """(rows8 [E, 8], z4 [E, 4], keep [E]) for every candidate edge of one sensor; ref_fn(v, w2s, edges) -> rows8 (torch formulation).
+    cam22: world_to_sample | position | direction as one contiguous detached tensor when the caller holds it (words 32..53 of the camera record)."""
+    return _PrimEdges.apply(v_world, w2s, rows, edges_i32, face_normals_u8, cam_pos, cam_dir, ref_fn, cam22)
+
+
+class _CompactEdges(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rows, keep_u8, w0, wn, aux, aux_cols):
+        lib = _abi.load_hip()
+        rc = rows.detach().contiguous().float()
+        E, S = rc.shape
+        dev = rows.device
+        A = int(aux_cols) if aux is not None else 0
+        rows_out = torch.empty(E, S, dtype=torch.float32, device=dev)
+        aux_out = torch.empty(E, max(A, 1), dtype=torch.int32, device=dev)
+        pos = torch.empty(E, dtype=torch.int32, device=dev)
+        dist = torch.empty(2 * E + 2, dtype=torch.float32, device=dev)              # pmf | cmf | header
+        scratch = torch.empty(4 * ((E + 1023) // 1024), dtype=torch.int32, device=dev)
+        _abi.check(lib, lib.psdr_geo_compact_edges_fwd(E, rc.data_ptr(), S, keep_u8.data_ptr(), int(w0), int(wn), aux.data_ptr() if A else None,
+                                                       aux.stride(0) if A else 0, A, scratch.data_ptr(), rows_out.data_ptr(), aux_out.data_ptr(), pos.data_ptr(),
+                                                       dist.data_ptr(), dist.data_ptr() + 4 * E, dist.data_ptr() + 8 * E, _stream()))
+        ctx.save_for_backward(pos)
+        ctx.mark_non_differentiable(aux_out, pos, dist)
+        return rows_out, aux_out, pos, dist
+
+    @staticmethod
+    def backward(ctx, a_out, _a_aux, _a_pos, _a_dist):
+        pos, = ctx.saved_tensors
+        if a_out.requires_grad:                          # double backward (forward-mode JVP): a differentiable gather
+            p = pos.long()
+            return torch.where((p >= 0).unsqueeze(-1), a_out[p.clamp(min=0)], torch.zeros_like(a_out)), None, None, None, None, None
+        lib = _abi.load_hip()
+        a = a_out.contiguous().float()
+        a_rows = torch.empty_like(a)
+        _abi.check(lib, lib.psdr_geo_compact_edges_rev(a.shape[0], a.shape[1], pos.data_ptr(), a.data_ptr(), a_rows.data_ptr(), _stream()))
+        return a_rows, None, None, None, None, None
+
+
+def compact_edges(rows, keep_u8, w0, wn, aux=None, aux_cols=0):
+    """The kept rows of a candidate edge table, in order, in a table of the same capacity E (zero behind them), their normalised length
+    distribution and the count -- all left on the device (csrc/psdr_tables.hip k_compact_*).  aux: an int32 / float32 tensor [E, >= aux_cols]
+    whose first aux_cols words per row travel along (row stride = aux.stride(0), unit column stride).
+    Returns (rows_out [E, S], aux_out [E, aux_cols] int32 bits, pos [E] int32, pmf [E], cmf [E], header [2] = {count as int bits, sum})."""
+    E = rows.shape[0]
+    rows_out, aux_out, pos, dist = _CompactEdges.apply(rows, keep_u8, w0, wn, aux, aux_cols)
+    return rows_out, aux_out, pos, dist[:E], dist[E:2 * E], dist[2 * E:]
+
+
+def emitter_tables(rows, face_offset_i32, mesh_emitter_i32, emitter_i, radiance, env_weight, n_face_words):
+    """mesh areas [M] + emitter_f [Ne, 8], emitter_pmf / emitter_cmf [Ne] (normalised), face_pmf / face_cmf [n_face_words] on the device
+    (csrc/psdr_tables.hip k_mesh_areas, k_emitter_rows); nothing here carries a gradient (the reference detaches all of it)."""
+    lib = _abi.load_hip()
+    dev = rows.device
+    M, Ne = mesh_emitter_i32.shape[0], emitter_i.shape[0] if emitter_i is not None else 0
+    rc = rows.detach()
+    out = torch.empty(M + Ne * (_abi.EMITTER_F_STRIDE + 2) + 2 * max(n_face_words, 1), dtype=torch.float32, device=dev)
+    o = [0]
+    def take(n):
+        t = out[o[0]:o[0] + n]; o[0] += n
+        return t
+    area, ef, epmf, ecmf = take(M), take(Ne * _abi.EMITTER_F_STRIDE), take(Ne), take(Ne)
+    fpmf, fcmf = take(max(n_face_words, 1)), take(max(n_face_words, 1))
+    p = lambda t: t.data_ptr() if t is not None and t.numel() else None
+    _abi.check(lib, lib.psdr_geo_emitter_tables(M, rc.data_ptr(), rc.stride(0), face_offset_i32.data_ptr(), mesh_emitter_i32.data_ptr(), Ne, p(emitter_i),
+                                                p(radiance), p(env_weight), area.data_ptr(), p(ef), p(epmf), p(ecmf), fpmf.data_ptr(), fcmf.data_ptr(), _stream()))
+    return area, ef.reshape(Ne, _abi.EMITTER_F_STRIDE), epmf, ecmf, fpmf, fcmf

@@ -65,6 +65,9 @@ def test_native_tables_equal_the_torch_formulation(scene):
             if k == "sec_pmf":
                 continue                                                       # cmf / pmf follow from the rows
         assert x.shape == y.shape, k
+        if k.endswith("_pmf"):                    # the native chain normalises on the device (the descriptor's sum is 1), the torch chain keeps lengths + their sum
+            x, y = x.astype(np.float64) / x.astype(np.float64).sum(), y.astype(np.float64) / y.astype(np.float64).sum()
+            assert abs(float(ta[k].double().sum()) - 1.0) < 1e-5 and ta[k[:-3] + "sum"] == 1.0
         if x.dtype.kind in "iu":
             assert np.array_equal(x, y), k
         elif k == "prim_edge_z":
@@ -149,11 +152,120 @@ def test_world_vertices_kernel_equals_the_torch_chain_bit_for_bit_and_in_its_adj
     assert rel_l2(jvp.cpu().numpy(), jref.cpu().numpy()) < 1e-6
 
 
-def test_configure_reads_back_in_two_batches():
-    """Scene.configure with vertex gradients synchronises with the device twice (sizes and sums, then the edge-distribution sums) -- it used to read
-    seventeen values back one by one; torch's sync debug mode counts the synchronising calls"""
+def test_configure_never_waits_for_the_device_and_stays_under_twenty_launches():
+    """Scene.configure with vertex gradients: ZERO synchronising calls (torch's sync debug mode counts them; the numbers of kept edges, the
+    distribution sums, mesh areas and emitter weights stay on the device: csrc/psdr_tables.hip k_compact_*, k_mesh_areas, k_emitter_rows) and at most
+    20 device launches / copies (the reference's configure is one Enoki trace, scene.cpp:56-278).  Then a full optimisation
+    iteration -- configure, renderD, loss, backward -- without a single wait either."""
     import warnings
-    sc, v, _ = build("cbox_bunny", True, True)
+    from torch.profiler import profile, ProfilerActivity
+    sc, v, _ = build("cbox_bunny", True, False)
+    mesh = sc.param_map["Mesh[1]"]
+    integ = psdr_cuda.DirectIntegrator(1, 1)
+
+    def fresh():
+        vv = Vector3fD(ek.detach(mesh.vertex_positions)); ek.set_requires_gradient(vv); mesh.vertex_positions = vv
+        return vv
+    for _ in range(2):                                            # steady state: caches of the first configure() in place
+        fresh(); sc.configure()
+    fresh()
+    torch.cuda.synchronize()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        torch.cuda.set_sync_debug_mode("warn")
+        try:
+            with profile(activities=[ProfilerActivity.CUDA]) as prof:
+                sc.configure()
+                torch.cuda.set_sync_debug_mode("default")
+                torch.cuda.synchronize()
+            torch.cuda.set_sync_debug_mode("warn")
+            vv = fresh()
+            sc.configure()
+            img = integ.renderD(sc, 0)
+            ek.backward(FloatD._wrap(((img.t - 0.3) ** 2).sum().reshape(1)))
+            g = ek.gradient(vv)
+        finally:
+            torch.cuda.set_sync_debug_mode("default")
+    syncs = [x for x in w if "called a synchronizing" in str(x.message)]
+    assert len(syncs) == 0, [str(x.message)[:80] for x in syncs]
+    ev = [e for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA]
+    print("configure(): %d device launches / copies" % len(ev))
+    assert 0 < len(ev) <= 20, [e.name[:60] for e in ev]
+    assert float(g.t.abs().max()) > 0
+    # the public tables are cut to the kept rows (one read of the two counts), the render calls take the capacity tables
+    t, tc = sc.tables(0), sc.tables(0, capacity=True)
+    n_sec, n_prim = t["num_sec_edges"], t["num_prim_edges"]
+    assert 0 < n_sec < tc["num_sec_edges"] == tc["sec_edge"].shape[0] and 0 < n_prim < tc["num_prim_edges"]
+    assert t["sec_edge"].shape[0] == n_sec and torch.equal(t["sec_edge"], tc["sec_edge"][:n_sec])
+    assert float(tc["sec_edge"].detach()[n_sec:].abs().max()) == 0 and float(tc["sec_pmf"][n_sec:].abs().max()) == 0 and float(tc["sec_cmf"][n_sec - 1:].min()) == 1.0
+    assert float(tc["prim_pmf"][n_prim:].abs().max()) == 0 and float(tc["prim_cmf"][n_prim - 1:].min()) == 1.0 and float(tc["prim_pmf"][:n_prim].min()) > 0
+    assert tc["sec_sum"] == tc["prim_sum"] == tc["emitter_sum"] == 1.0
+    assert abs(float(tc["sec_pmf"].double().sum()) - 1) < 1e-5 and bool((tc["sec_cmf"][1:] >= tc["sec_cmf"][:-1]).all())
+
+
+def test_compaction_kernel_against_a_boolean_mask_select():
+    """psdr_geo_compact_edges_*: kept rows in order, aux words alongside, normalised pmf / cmf, count + sum header; adjoint = the scatter back"""
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for E in (1, 5, 1024, 1025, 70001):
+        rows = torch.randn(E, 16, device="cuda", generator=g)
+        keep = (torch.rand(E, device="cuda", generator=g) < (0.0 if E == 5 else 0.37)).to(torch.uint8)
+        aux = torch.randint(-5, 1 << 20, (E, 5), device="cuda", generator=g, dtype=torch.int32)
+        rows.requires_grad_(True)
+        out, aux_out, pos, pmf, cmf, hdr = tables_native.compact_edges(rows, keep, 3, 3, aux=aux[:, 2:4], aux_cols=2)
+        k = keep.bool()
+        n = int(k.sum())
+        assert int(hdr[:1].view(torch.int32)) == n
+        assert torch.equal(out[:n], rows[k]) and float(out[n:].abs().sum()) == 0
+        assert torch.equal(aux_out[:n], aux[k][:, 2:4]) and int(aux_out[n:].abs().sum()) == 0
+        ln = rows[k][:, 3:6].detach().double().norm(dim=1)
+        assert abs(float(hdr[1]) - float(ln.sum())) <= 1e-5 * max(float(ln.sum()), 1e-30)
+        if n:
+            assert rel_l2(pmf[:n].cpu().numpy(), (ln / ln.sum()).cpu().numpy()) < 1e-6
+            ref_cmf = torch.cumsum(ln / ln.sum(), 0)
+            assert float((cmf[:n - 1].double() - ref_cmf[:n - 1]).abs().max()) < 1e-5 if n > 1 else True
+        assert float(cmf[max(n - 1, 0):].min()) == 1.0 and float(pmf[n:].abs().sum()) == 0
+        idx = torch.nonzero(k).reshape(-1)
+        assert torch.equal(pos[k].long(), torch.arange(n, device="cuda")) and bool((pos[~k] == -1).all())
+        w = torch.randn(E, 16, device="cuda", generator=g)
+        (out * w).sum().backward()
+        ref = torch.zeros(E, 16, device="cuda")
+        ref[idx] = w[:n]
+        assert torch.equal(rows.grad, ref)
+
+
+def test_emitter_tables_kernel_against_the_host_formulation():
+    """psdr_geo_emitter_tables (mesh areas, normalised emitter weights, face distributions) against the eager chain's numbers (scene.cpp:183-196)"""
+    a, _, _ = build("bunny_light", True, False)
+    with tables_native.torch_formulation():
+        b, _, _ = build("bunny_light", False, False)
+    ta, tb = a.tables(0), b.tables(0)
+    for ma, mb in zip(a.m_meshes, b.m_meshes):
+        assert abs(ma.m_total_area / mb.m_total_area - 1) < 1e-5 and abs(ma.m_inv_total_area * ma.m_total_area - 1) < 1e-12
+    assert ta["num_emitters"] == tb["num_emitters"] >= 1
+    ea, eb = ta["emitter_f"].cpu().numpy(), tb["emitter_f"].cpu().numpy()
+    assert rel_l2(ea[:, :6], eb[:, :6]) < 1e-5
+    assert torch.equal(ta["emitter_i"].cpu(), tb["emitter_i"].cpu()) and torch.equal(ta["mesh_emitter"].cpu(), tb["mesh_emitter"].cpu())
+    assert rel_l2(ta["face_pmf"].cpu().numpy(), tb["face_pmf"].cpu().numpy()) < 1e-6 and rel_l2(ta["face_cmf"].cpu().numpy(), tb["face_cmf"].cpu().numpy()) < 1e-5
+    pa = ta["emitter_pmf"].double().cpu().numpy()
+    pb = tb["emitter_pmf"].double().cpu().numpy() / tb["emitter_sum"]
+    assert abs(pa.sum() - 1) < 1e-6 and rel_l2(pa, pb) < 1e-6 and ta["emitter_sum"] == 1.0
+    for x, y in zip(a.m_emitters, b.m_emitters):
+        assert abs(x.m_sampling_weight - y.m_sampling_weight) < 1e-6
+        fa, fb = x.m_mesh._face_distrb, y.m_mesh._face_distrb
+        assert fa.m_size == fb.m_size and abs(fa.m_sum / fb.m_sum - 1) < 1e-5
+
+
+def test_configure_reads_back_in_two_batches_on_the_eager_chain():
+    """The eager torch chain (tables_native.torch_formulation: the formulation the native chain is checked against) synchronises with the device twice
+    (sizes and sums, then the edge-distribution sums) -- it used to read seventeen values back one by one; torch's sync debug mode counts the calls"""
+    import warnings
+    with tables_native.torch_formulation():
+        _check_two_batches()
+
+
+def _check_two_batches():
+    import warnings
+    sc, v, _ = build("cbox_bunny", False, True)
     mesh = sc.param_map["Mesh[1]"]
     for _ in range(2):                                            # steady state: caches of the first configure() in place
         vv = Vector3fD(ek.detach(mesh.vertex_positions)); ek.set_requires_gradient(vv); mesh.vertex_positions = vv

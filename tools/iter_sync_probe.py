@@ -34,3 +34,14 @@ for e in prof.events():
 ka = prof.key_averages()
 print("blocking total %.2f ms; kernel launches %d; GPU kernel time %.2f ms" % (tot / 1e3, sum(e.count for e in ka if e.key in ("hipLaunchKernel", "hipExtModuleLaunchKernel", "hipModuleLaunchKernel")),
       sum(e.device_time_total for e in ka if e.device_time_total) / 1e3))
+if "--configure" in sys.argv:          # what configure() alone launches (the mesh still carries a gradient)
+    v = Vector3fD(ek.detach(mesh.vertex_positions)); ek.set_requires_gradient(v); mesh.vertex_positions = v
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        sc.configure(); torch.cuda.synchronize()
+    ev = [e for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA]
+    print("configure(): %d device events" % len(ev))
+    for e in ev:
+        print("  %7.1f us  %s" % (e.device_time_total, e.name[:150]))
+    cpu = [e for e in prof.events() if e.device_type == torch.autograd.DeviceType.CPU and e.name.startswith("aten::") and e.cpu_parent is None]
+    print("top-level aten ops: %d" % len(cpu))

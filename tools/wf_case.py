@@ -19,6 +19,15 @@ elif case == "c5":
     from psdr_cuda.fixtures import make_interior_scene
     sc = make_interior_scene(seed=0, n_objects=10, res=512, spp=16); sc.configure()
     o = _abi.make_opts(spp=16, integrator=_abi.INTEGRATOR_PATH, max_depth=3, flags=flags); n = 512 * 512 * 16
+elif case in ("c4pr", "c5pr"):
+    # PathTracer(3) reverse (triangle rows + texels): C4 shard / the 50 k-triangle interior
+    if case == "c4pr":
+        sc, _ = load_scene("cbox_bunny", res=1024, spp=512, sppe=0, sppse=0)
+        o = _abi.make_opts(spp=512, spp_range=(0, 64), integrator=_abi.INTEGRATOR_PATH, max_depth=3, flags=flags); n = 1024 * 1024 * 64
+    else:
+        from psdr_cuda.fixtures import make_interior_scene
+        sc = make_interior_scene(seed=0, n_objects=10, res=512, spp=16); sc.configure()
+        o = _abi.make_opts(spp=16, integrator=_abi.INTEGRATOR_PATH, max_depth=3, flags=flags); n = 512 * 512 * 16
 elif case in ("c3f", "c3r", "c4r3"):
     # the three-term DirectIntegrator workloads: C3 forward (K = 1, a translation of the bunny) / reverse at 512^2 spp 16; C4 shard reverse
     from helpers import tangents_wrt
@@ -38,6 +47,9 @@ if case == "c3f":
 elif case in ("c3r", "c4r3"):
     adj = np.random.default_rng(0).random((tb["width"] * tb["height"], 3)).astype(np.float32)
     run = lambda: g.render_d_rev(o, adj, with_image=False)
+elif case in ("c4pr", "c5pr"):
+    adj = np.random.default_rng(0).random((tb["width"] * tb["height"], 3)).astype(np.float32)
+    run = lambda: g.render_d_rev(o, adj, want=["tri_info", "texels"], with_image=False)
 else:
     run = lambda: g.render_c(o)
 run(); torch.cuda.synchronize()
