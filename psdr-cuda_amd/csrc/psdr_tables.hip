@@ -2,8 +2,8 @@
 // (process_mesh, reference src/shape/mesh.cpp:20-51), secondary-edge records of every candidate edge (Mesh::configure, mesh.cpp:251-270 +
 // the coplanar filter of scene.cpp:219-244) and primary-edge records of every candidate edge of a sensor (perspective.cpp:39-111), each
 // with its hand-written adjoint.  One forward and one reverse entry point per table (include/psdr_hip.h psdr_geo_*); the host mirror wraps
-// them in torch.autograd.Function objects (psdr_cuda/tables_native.py) and keeps only the compaction of the kept edges (a boolean-mask
-// select) and the small emitter / distribution bookkeeping in torch.  Replaces ~150 eager torch launches per configure() and ~250 in its
+// them in torch.autograd.Function objects (psdr_cuda/tables_native.py).  Round 4: the compaction of the kept edges, their length
+// distributions, mesh areas and the emitter tables are kernels here as well (k_compact_*, k_mesh_areas, k_emitter_rows): no count or sum travels to the host.  Replaces ~150 eager torch launches per configure() and ~250 in its
 // backward.  Everything is fp32; the scatter-adds into vertex / row adjoints are hardware global_atomic_add_f32.
 #include <hip/hip_runtime.h>
 #include <math.h>

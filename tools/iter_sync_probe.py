@@ -45,3 +45,11 @@ if "--configure" in sys.argv:          # what configure() alone launches (the me
         print("  %7.1f us  %s" % (e.device_time_total, e.name[:150]))
     cpu = [e for e in prof.events() if e.device_type == torch.autograd.DeviceType.CPU and e.name.startswith("aten::") and e.cpu_parent is None]
     print("top-level aten ops: %d" % len(cpu))
+if "--iteration" in sys.argv:          # every device event of one whole iteration, in order
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        step(); torch.cuda.synchronize()
+    ev = sorted([e for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA], key=lambda e: e.time_range.start)
+    print("iteration: %d device events, %.2f ms of device time" % (len(ev), sum(e.device_time_total for e in ev) / 1e3))
+    for e in ev:
+        print("  %7.1f us  %s" % (e.device_time_total, e.name[:130]))
