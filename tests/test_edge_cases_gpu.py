@@ -324,3 +324,28 @@ def test_render_fuzz_random_scenes(seed):
             lhs, rhs = float((adj.astype(np.float64) * dimg[0]).sum()), dot_tables(grads, tan)
             scale = float(np.abs(adj.astype(np.float64) * dimg[0]).sum())
             assert abs(lhs - rhs) <= 2e-2 * max(scale, 1e-6), (seed, kw, name, lhs, rhs, scale)
+
+
+def test_capacity_edge_table_without_a_kept_edge_renders_zeros_not_nan():
+    """A native configure() keeps the edge tables at the capacity of the candidate lists with the count on the device (csrc/psdr_tables.hip k_compact_*);
+    when NO edge is kept the table is all zero rows with pmf 0 / cmf 1.  The primary-edge kernels treat pmf 0 as an invalid draw and a zero
+    secondary-edge row fails its own validity test: the derivative image is the interior term alone, forward and reverse, and finite."""
+    sc, P = load_scene("cbox_bunny", res=32, spp=2, sppe=4, sppse=4, translate=(1, (1.0, 0.5, 0.0)))
+    from helpers import tangents_wrt
+    tb = dict(sc.tables(0, capacity=True))
+    tan = tangents_wrt(tb, P)
+    o_all = _abi.make_opts(spp=2, sppe=4, sppse=4, bsdf_samples=1, light_samples=1)
+    o_int = _abi.make_opts(spp=2, sppe=0, sppse=0, bsdf_samples=1, light_samples=1)
+    for k in ("prim_edge", "prim_pmf", "sec_edge", "sec_pmf"):
+        tb[k] = torch.zeros_like(tb[k].detach())
+    tb["prim_cmf"], tb["sec_cmf"] = torch.ones_like(tb["prim_cmf"]), torch.ones_like(tb["sec_cmf"])
+    g = GpuScene(tb)
+    _, d_all = g.render_d_fwd(o_all, [tan])
+    _, d_int = g.render_d_fwd(o_int, [tan])
+    assert np.isfinite(d_all[0]).all() and np.abs(d_int[0]).max() > 0
+    assert np.array_equal(d_all[0], d_int[0])
+    adj = np.random.default_rng(0).random((32 * 32, 3)).astype(np.float32)
+    _, ga = g.render_d_rev(o_all, adj, want=["tri_info", "sec_edge", "prim_edge"], with_image=False)
+    _, gi = g.render_d_rev(o_int, adj, want=["tri_info"], with_image=False)
+    assert all(np.isfinite(v).all() for v in ga.values())
+    assert np.abs(ga["sec_edge"]).max() == 0 and np.abs(ga["prim_edge"]).max() == 0 and rel_l2(ga["tri_info"], gi["tri_info"]) < 1e-6
