@@ -94,32 +94,93 @@ inline void pack_tiny_prims(const std::vector<float4> &tris, std::vector<float4>
 //   row 0 = (n, c0)   unit normal and n . p0:            t = -(n . o - c0) / (n . d)
 //   row 1 = (a1, c1)  dual basis vector of e1, a1 . p0 + 1/2:  s - 1/2 = a1 . (o + t d) - c1
 //   row 2 = (a2, c2)  dual basis vector of e2, a2 . p0:  the second plane coordinate likewise
+//   row 3 = (bound on (s - 1/2) + (t - 1/2): 1 parallelogram / 0 triangle, ids, -, -)
 // (a1 = e2 x n / |e1 x e2|, a2 = n x e1 / |e1 x e2| with the unit normal: a1 . e1 = a2 . e2 = 1, a1 . e2 = a2 . e1 = 0) -- 17 VALU
-// operations per test against Moeller-Trumbore's 31 (psdr_device.h tiny_prim_test), and meta = (ids, codeA, codeB, the bound on s + t as float bits: 2 for a parallelogram, 1 for a triangle).
-inline void tiny_plane_form(const std::vector<float4> &prims, float4 *rows, int32_t *meta) {
-    const int n = (int) prims.size() / 3;
-    for (int i = 0; i < n; ++i) {
-        const float4 &a = prims[(size_t) i * 3], &b = prims[(size_t) i * 3 + 1], &c = prims[(size_t) i * 3 + 2];
+// operations per test against Moeller-Trumbore's 31 (psdr_device.h tiny_prim_test), and meta = (ids, codeA, codeB, the bound as float bits).
+//
+// AXIS-ALIGNED RECTANGLES (round 4: the walls, floor, ceiling and light of a room) get a slab-style row instead, in one of kAaSlots FIXED
+// slots at the front of the arrays -- three per axis of the normal (slots 0-2: x, 3-5: y, 6-8: z; a fourth rectangle of an axis stays a
+// plane-form primitive), so that each slot's test is compiled for its axis and reads its row at a compile-time address.  With the plane
+// x_k = c and the in-plane axes (a, b) = the other two in ascending order:
+//   row 0 = (c, centre_a, centre_b, half extent along a)
+//   row 1 = (half extent along b, rho (float bits, low 4 bits = the slot), -, ids)
+//   row 2 = S, the 2 x 2 map from the test's coordinates (u', v') = (p_a - centre_a, p_b - centre_b) to (s - 1/2, t - 1/2) -- a signed,
+//           scaled permutation
+// aa_prim_test: t = (c - o_k) / d_k with the ray's three reciprocals, two FMAs and two subtractions for (u', v'), |u'| <= h_a, |v'| <= h_b:
+// 15 VALU and no v_rcp_f32 per test.  The second triangle of the pair is the half (s - 1/2) + (t - 1/2) > 0 = (S00 + S10) u' + (S01 + S11) v'
+// > 0; divided by B = S01 + S11 that is rho u' + v' > 0 (B > 0) or its complement (B < 0: the two triangles swap their places in ids / codes
+// here, so the kernels test one form).  aa_cnt = the slots in use per axis (x | y << 8 | z << 16); with any in use the plane-form
+// primitives start at row kAaSlots, otherwise at row 0.  Returns the number of rows in use (SceneView::n_tiny).
+inline int tiny_plane_form(const std::vector<float4> &prims_in, float4 *rows, int32_t *meta, int32_t *aa_cnt_out = nullptr, bool allow_aa = true) {
+    const int n = (int) prims_in.size() / 3;
+    struct Aa { int axis; double c, cu, cv, hu, hv, S[4]; };
+    auto bits = [](const float4 &r) { int32_t v; std::memcpy(&v, &r.w, 4); return v; };
+    auto classify = [&](const float4 &a, const float4 &b, const float4 &c, Aa &o) {
+        if (((uint32_t) bits(a) >> 16) == 0xffffu) return false;                      // a lone triangle
         const double p0[3] = {a.x, a.y, a.z}, e1[3] = {b.x, b.y, b.z}, e2[3] = {c.x, c.y, c.z};
-        double nn[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
-        const double len = std::sqrt(nn[0] * nn[0] + nn[1] * nn[1] + nn[2] * nn[2]);
-        double a1[3] = {0, 0, 0}, a2[3] = {0, 0, 0};
-        if (len > 0.0 && std::isfinite(len)) {
-            for (int k = 0; k < 3; ++k) nn[k] /= len;
-            const double x1[3] = {e2[1] * nn[2] - e2[2] * nn[1], e2[2] * nn[0] - e2[0] * nn[2], e2[0] * nn[1] - e2[1] * nn[0]};      // e2 x n
-            const double x2[3] = {nn[1] * e1[2] - nn[2] * e1[1], nn[2] * e1[0] - nn[0] * e1[2], nn[0] * e1[1] - nn[1] * e1[0]};      // n x e1
-            for (int k = 0; k < 3; ++k) { a1[k] = x1[k] / len; a2[k] = x2[k] / len; }
-        } else nn[0] = nn[1] = nn[2] = 0.0;                        // degenerate: n . d = 0 for every ray, never hit
-        auto dot3 = [](const double *x, const double *y) { return x[0] * y[0] + x[1] * y[1] + x[2] * y[2]; };
-        rows[i * 4] = float4{(float) nn[0], (float) nn[1], (float) nn[2], (float) dot3(nn, p0)};
-        rows[i * 4 + 1] = float4{(float) a1[0], (float) a1[1], (float) a1[2], (float) (dot3(a1, p0) + 0.5)};      // the test works on s - 1/2, t - 1/2
-        rows[i * 4 + 2] = float4{(float) a2[0], (float) a2[1], (float) a2[2], (float) (dot3(a2, p0) + 0.5)};
-        int32_t ids, codeA, codeB;
-        std::memcpy(&ids, &a.w, 4); std::memcpy(&codeA, &b.w, 4); std::memcpy(&codeB, &c.w, 4);
-        meta[i * 4] = ids; meta[i * 4 + 1] = codeA; meta[i * 4 + 2] = codeB; const float lim = ((uint32_t) ids >> 16) != 0xffffu ? 1.f : 0.f;           // bound on (s - 1/2) + (t - 1/2)
+        int i1 = -1, i2 = -1, n1 = 0, n2 = 0;
+        for (int k = 0; k < 3; ++k) { if (e1[k] != 0.0) { i1 = k; n1++; } if (e2[k] != 0.0) { i2 = k; n2++; } }
+        if (n1 != 1 || n2 != 1 || i1 == i2) return false;
+        for (int k = 0; k < 3; ++k) if (!std::isfinite(p0[k]) || !std::isfinite(e1[k]) || !std::isfinite(e2[k])) return false;
+        o.axis = 3 - i1 - i2;
+        const int ia = o.axis == 0 ? 1 : 0, ib = o.axis == 2 ? 1 : 2;
+        double ctr[3];
+        for (int k = 0; k < 3; ++k) ctr[k] = p0[k] + 0.5 * (e1[k] + e2[k]);
+        o.c = p0[o.axis]; o.cu = ctr[ia]; o.cv = ctr[ib];
+        o.hu = 0.5 * std::fabs(i1 == ia ? e1[ia] : e2[ia]); o.hv = 0.5 * std::fabs(i1 == ib ? e1[ib] : e2[ib]);
+        if (i1 == ia) { o.S[0] = 1.0 / e1[i1]; o.S[1] = 0.0; o.S[2] = 0.0; o.S[3] = 1.0 / e2[i2]; }
+        else          { o.S[0] = 0.0; o.S[1] = 1.0 / e1[i1]; o.S[2] = 1.0 / e2[i2]; o.S[3] = 0.0; }
+        return true;
+    };
+    // slot of every primitive: an axis-aligned rectangle takes the next free slot of its axis, the others follow in their order
+    std::vector<int> row_of((size_t) n, -1); std::vector<Aa> aa((size_t) n);
+    int cnt[3] = {0, 0, 0};
+    if (allow_aa && aa_cnt_out)
+        for (int i = 0; i < n; ++i) {
+            Aa &q = aa[(size_t) i];
+            if (classify(prims_in[(size_t) i * 3], prims_in[(size_t) i * 3 + 1], prims_in[(size_t) i * 3 + 2], q) && cnt[q.axis] < kAaPerAxis) row_of[(size_t) i] = q.axis * kAaPerAxis + cnt[q.axis]++;
+        }
+    const int n_aa = cnt[0] + cnt[1] + cnt[2];
+    int next = n_aa > 0 ? kAaSlots : 0;
+    for (int r = 0; r < next; ++r) { for (int q = 0; q < 4; ++q) { rows[r * 4 + q] = float4{0.f, 0.f, 0.f, 0.f}; meta[r * 4 + q] = 0; } rows[r * 4].w = -1.f; }   // an unused slot never hits
+    if (aa_cnt_out) *aa_cnt_out = cnt[0] | (cnt[1] << 8) | (cnt[2] << 16);
+    for (int src = 0; src < n; ++src) {
+        const bool is_aa = row_of[(size_t) src] >= 0;
+        const int i = is_aa ? row_of[(size_t) src] : next++;
+        const float4 &a = prims_in[(size_t) src * 3], &b = prims_in[(size_t) src * 3 + 1], &c = prims_in[(size_t) src * 3 + 2];
+        int32_t ids = bits(a), codeA = bits(b), codeB = bits(c);
+        const float lim = ((uint32_t) ids >> 16) != 0xffffu ? 1.f : 0.f;           // bound on (s - 1/2) + (t - 1/2)
+        if (is_aa) {
+            const Aa &q = aa[(size_t) src];
+            const double A = q.S[0] + q.S[2], B = q.S[1] + q.S[3];
+            if (B < 0.0) { ids = (int32_t) (((uint32_t) ids >> 16) | ((uint32_t) ids << 16)); std::swap(codeA, codeB); }
+            const float rho = (float) (A / B);
+            int32_t packed; std::memcpy(&packed, &rho, 4); packed = (packed & ~15) | i;
+            rows[i * 4] = float4{(float) q.c, (float) q.cu, (float) q.cv, (float) q.hu};
+            rows[i * 4 + 1] = float4{(float) q.hv, 0.f, 0.f, 0.f};
+            std::memcpy(&rows[i * 4 + 1].y, &packed, 4); std::memcpy(&rows[i * 4 + 1].w, &ids, 4);
+            rows[i * 4 + 2] = float4{(float) q.S[0], (float) q.S[1], (float) q.S[2], (float) q.S[3]};
+        } else {
+            const double p0[3] = {a.x, a.y, a.z}, e1[3] = {b.x, b.y, b.z}, e2[3] = {c.x, c.y, c.z};
+            double nn[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+            const double len = std::sqrt(nn[0] * nn[0] + nn[1] * nn[1] + nn[2] * nn[2]);
+            double a1[3] = {0, 0, 0}, a2[3] = {0, 0, 0};
+            if (len > 0.0 && std::isfinite(len)) {
+                for (int k = 0; k < 3; ++k) nn[k] /= len;
+                const double x1[3] = {e2[1] * nn[2] - e2[2] * nn[1], e2[2] * nn[0] - e2[0] * nn[2], e2[0] * nn[1] - e2[1] * nn[0]};      // e2 x n
+                const double x2[3] = {nn[1] * e1[2] - nn[2] * e1[1], nn[2] * e1[0] - nn[0] * e1[2], nn[0] * e1[1] - nn[1] * e1[0]};      // n x e1
+                for (int k = 0; k < 3; ++k) { a1[k] = x1[k] / len; a2[k] = x2[k] / len; }
+            } else nn[0] = nn[1] = nn[2] = 0.0;                        // degenerate: n . d = 0 for every ray, never hit
+            auto dot3 = [](const double *x, const double *y) { return x[0] * y[0] + x[1] * y[1] + x[2] * y[2]; };
+            rows[i * 4] = float4{(float) nn[0], (float) nn[1], (float) nn[2], (float) dot3(nn, p0)};
+            rows[i * 4 + 1] = float4{(float) a1[0], (float) a1[1], (float) a1[2], (float) (dot3(a1, p0) + 0.5)};      // the test works on s - 1/2, t - 1/2
+            rows[i * 4 + 2] = float4{(float) a2[0], (float) a2[1], (float) a2[2], (float) (dot3(a2, p0) + 0.5)};
+            rows[i * 4 + 3] = float4{lim, 0.f, 0.f, 0.f}; std::memcpy(&rows[i * 4 + 3].y, &ids, 4);
+        }
+        meta[i * 4] = ids; meta[i * 4 + 1] = codeA; meta[i * 4 + 2] = codeB;
         std::memcpy(&meta[i * 4 + 3], &lim, 4);
-        rows[i * 4 + 3] = float4{lim, 0.f, 0.f, 0.f}; std::memcpy(&rows[i * 4 + 3].y, &ids, 4);
     }
+    return next;
 }
 
 // ---------------------------------------------------------------------------- BVH builder

@@ -43,6 +43,8 @@ constexpr int kBvhStack = 40;     // builder guarantees depth <= kBvhStack - 2
 constexpr int kBlock = 256;
 
 constexpr int kTinyTris = 16;
+constexpr int kAaPerAxis = 3, kAaSlots = 3 * kAaPerAxis;   // slab-form rows of axis-aligned rectangles in front of the plane-form primitives (tiny_plane_form)
+constexpr int kTinyRows = kTinyTris + kAaSlots;
 constexpr int kMaxBlas = 16;
 constexpr int kMinBlasTris = 64;      // meshes below this size stay inline in the top level
 struct SceneView {
@@ -62,8 +64,9 @@ struct SceneView {
     // KERNEL ARGUMENTS and closest_hit tests all of them in order -- wave-uniform s_load from the kernarg
     // segment into SGPRs, no tree, no per-lane node fetches, no stack traffic, no divergence between lanes.
     int32_t n_tiny;
-    float4 tiny[kTinyTris * 4];                 // plane form: (n | c0), (a1 | c1), (a2 | c2), (bound, ids, -, -) per primitive: 64 bytes, ONE scalar load (tiny_plane_form)
-    int32_t tiny_meta[kTinyTris * 4];           // (ids, codeA, codeB, bound on s + t - 1 as float bits: 1 parallelogram / 0 triangle) per primitive
+    int32_t aa_cnt;                             // slab-form slots in use per axis (x | y << 8 | z << 16): rows 0 .. kAaSlots-1; the plane-form primitives then start at row kAaSlots (tiny_plane_form)
+    float4 tiny[kTinyRows * 4];                 // plane form: (n | c0), (a1 | c1), (a2 | c2), (bound, ids, -, -) per primitive: 64 bytes, ONE scalar load (tiny_plane_form)
+    int32_t tiny_meta[kTinyRows * 4];           // (ids, codeA, codeB, bound on s + t - 1 as float bits: 1 parallelogram / 0 triangle) per primitive
     // Two-level tree (psdr_bvh_build.h ForestBuilder; scenes of a few small meshes plus a few large ones -- a room with
     // objects): the triangles of the small meshes are the primitives above, every large mesh has its OWN tree in `nodes`,
     // and its box + root travel in the kernel arguments too.  A closest-hit query first tests the inline primitives
@@ -235,6 +238,9 @@ PSDR_HD void leaf_from_memory(const float4 *bt, int cnt, const Vec3f &o, const V
 #endif
 }
 
+#ifndef PSDR_AA_HOIST
+#define PSDR_AA_HOIST 0
+#endif
 #ifndef PSDR_TINY_UNROLL
 #define PSDR_TINY_UNROLL 6
 #endif
@@ -266,13 +272,29 @@ PSDR_HD void tiny_prim_test(const float4 &r0, const float4 &r1, const float4 &r2
     if (IGN) { const int id2 = __float_as_int_hd(r3.y); const bool quad = lim > 0.5f; const int id = (quad && u + v > 0.f) ? (int) ((uint32_t) id2 >> 16) : (id2 & 0xffff); hit = hit & (id != ig0) & (id != ig1); }
     best.t = hit ? t : best.t; best.u = hit ? u : best.u; best.v = hit ? v : best.v; best_i = hit ? i : best_i;
 }
+// An AXIS-ALIGNED RECTANGLE (tiny_plane_form: the plane x_AX = c, in-plane axes in ascending order, rows (c, centre_a, centre_b, h_a),
+// (h_b, rho | index, axis, ids)): the slab form -- t from ONE subtraction and the ray's reciprocal of that axis (three v_rcp_f32 per ray
+// instead of one per primitive), the hit point's two in-plane coordinates relative to the rectangle's centre against its half extents.
+// 15 VALU per test where the plane form takes 31 and a quarter-rate reciprocal.  best.(u, v) = the unscaled offsets; the winner's word
+// (rho | index) tells resolve_tiny_hit which half of the pair they fall in, the hit rows in LDS carry the scale (setup_lds).
+// d_AX = 0: inv = +-inf, t = +-inf or NaN (o on the plane) -- every comparison fails, as in the plane form.
+template <int AX, bool IGN = false>
+PSDR_HD void aa_prim_test(const float4 &ra, float hb, int packed, int id2, const Vec3f &o, const Vec3f &d, const Vec3f &inv, Hit &best, int &best_i, int ig0 = -1, int ig1 = -1) {
+    const float on = AX == 0 ? o.x : (AX == 1 ? o.y : o.z), in = AX == 0 ? inv.x : (AX == 1 ? inv.y : inv.z);
+    const float oa = AX == 0 ? o.y : o.x, da = AX == 0 ? d.y : d.x, ob = AX == 2 ? o.y : o.z, db = AX == 2 ? d.y : d.z;
+    const float t = (ra.x - on) * in;
+    const float u = (oa + t * da) - ra.y, v = (ob + t * db) - ra.z;
+    bool hit = (fabsf(u) <= ra.w) & (fabsf(v) <= hb) & (t >= kRayEpsilon) & (t < best.t);
+    if (IGN) { const int id = (u * __int_as_float_hd(packed) + v > 0.f) ? (int) ((uint32_t) id2 >> 16) : (id2 & 0xffff); hit = hit & (id != ig0) & (id != ig1); }
+    best.t = hit ? t : best.t; best.u = hit ? u : best.u; best.v = hit ? v : best.v; best_i = hit ? packed : best_i;
+}
 // The triangle and its barycentrics from the winning primitive's plane coordinates.  Per primitive and half (the second triangle of a
 // parallelogram is the half s + t > 1; a lone triangle fills both halves alike) eight words: the triangle id and the affine map
 // (u, v) = (k0, k3) + (k1, k2 | k4, k5) (s - 1/2, t - 1/2), coefficients small integers and halves (tiny_hit_row decodes them from the
 // 3-bit codes of pack_tiny_prims).  Device: the rows are staged in LDS by setup_lds, two 16-byte reads per ray (the decode itself was
 // ~35 VALU instructions per ray); host: decoded on the spot.
 constexpr int kTinyHitWords = 16;           // per primitive: two halves of (tri, k0, k1, k2, k3, k4, k5, -)
-PSDR_HD void tiny_hit_row(const int32_t *meta, int half, int32_t &tri, float k[6]) {
+PSDR_HD void tiny_hit_row(const int32_t *meta, int half, int32_t &tri, float k[6], const float *S = nullptr) {
     const int ids = meta[0];
     const bool quad = ((uint32_t) ids >> 16) != 0xffffu, second = quad && half != 0;
     const int code = second ? meta[2] : meta[1];
@@ -283,10 +305,22 @@ PSDR_HD void tiny_hit_row(const int32_t *meta, int half, int32_t &tri, float k[6
     // tiny_prim_test keeps the plane coordinates shifted by one half: fold the shift into the constant
     k[0] = c[0] + 0.5f * (c[1] + c[2]); k[1] = c[1]; k[2] = c[2];
     k[3] = c[3] + 0.5f * (c[4] + c[5]); k[4] = c[4]; k[5] = c[5];
+    if (S) {
+        // an axis-aligned rectangle: best.(u, v) are world offsets from its centre, (s - 1/2, t - 1/2) = S (u', v')
+        const float k1 = k[1], k2 = k[2], k4 = k[4], k5 = k[5];
+        k[1] = k1 * S[0] + k2 * S[2]; k[2] = k1 * S[1] + k2 * S[3];
+        k[4] = k4 * S[0] + k5 * S[2]; k[5] = k4 * S[1] + k5 * S[3];
+    }
 }
-PSDR_HD void resolve_tiny_hit(const SceneView &sc, Hit &best, int best_i) {
-    if (best_i < 0) return;                                         // no hit
-    const int half = best.u + best.v > 0.f ? 1 : 0;
+// best_i of closest_hit's primitive loops: a plane-form primitive leaves its row index (< kTinyRows), an axis-aligned rectangle its
+// (rho | slot) word -- the bits of a float of normal magnitude, never a small integer
+constexpr int kNoPrim = 63;
+PSDR_HD void resolve_tiny_hit(const SceneView &sc, Hit &best, int packed) {
+    if (packed == kNoPrim) return;                                  // no hit
+    const bool plane = (uint32_t) packed < (uint32_t) kNoPrim;
+    const float rho = plane ? 1.f : __int_as_float_hd(packed);      // the low four bits move rho by 2^-19 of itself: which triangle a point ON the diagonal belongs to
+    const int best_i = plane ? packed : (packed & 15);
+    const int half = best.u * rho + best.v > 0.f ? 1 : 0;
     float k[6];
 #if defined(__HIP_DEVICE_COMPILE__)
     const float4 *row = reinterpret_cast<const float4 *>(psdr_dyn_lds + sc.off_lprim) + best_i * (kTinyHitWords / 4) + half * 2;
@@ -294,7 +328,7 @@ PSDR_HD void resolve_tiny_hit(const SceneView &sc, Hit &best, int best_i) {
     best.tri = __float_as_int_hd(a.x);
     k[0] = a.y; k[1] = a.z; k[2] = a.w; k[3] = b.x; k[4] = b.y; k[5] = b.z;
 #else
-    tiny_hit_row(sc.tiny_meta + best_i * 4, half, best.tri, k);
+    tiny_hit_row(sc.tiny_meta + best_i * 4, half, best.tri, k, !plane ? &sc.tiny[best_i * 4 + 2].x : nullptr);
 #endif
     const float u = best.u, v = best.v;
     best.u = k[0] + (k[1] * u + k[2] * v);
@@ -454,22 +488,50 @@ PSDR_HD Hit closest_hit(const SceneView &sc, TraversalStack &st, const Vec3f &o,
     if (FOREST == 3 || FOREST == 2 || sc.n_tiny > 0 || forest) {
         // n_tiny PRIMITIVES (triangles, or parallelograms of two triangles: pack_tiny_prims), unrolled by 6 (the six
         // walls of the Cornell box): the scalar loads of the following primitives are in flight while one is tested
-        int best_i = -1;
-        // (one loop: a second loop over the triangles alone, starting at a run-time index, makes the compiler copy the primitive array from the
-        // kernel arguments to scratch in half of the kernels -- 2 KB per lane, C4 PathTracer(3) renderC 24 -> 54 ms -- and the two VALU
-        // instructions it saves per parallelogram bought no time on C2)
-        // One s_load_dwordx16 per primitive, unrolled by 6 (the six walls of the Cornell box).  Device: the rows are read through
-        // the kernel-argument segment pointer itself -- SceneView is the first member of the first argument of every kernel that traces
-        // (static_assert in psdr_host.h) -- because an index into the by-value struct that the compiler cannot fold makes it copy the whole
-        // struct to scratch in some kernels (2 KB per lane; C4 PathTracer(3) renderC 24 -> 54 ms when a second loop did that).
+        int best_i = kNoPrim;
+        // One s_load per primitive.  Device: the rows are read through the kernel-argument segment pointer itself -- SceneView is the first
+        // member of the first argument of every kernel that traces (static_assert in psdr_host.h) -- because an index into the by-value struct
+        // that the compiler cannot fold makes it copy the whole struct to scratch in some kernels (2 KB per lane; C4 PathTracer(3) renderC
+        // 24 -> 54 ms when a second loop did that).
 #if defined(__HIP_DEVICE_COMPILE__)
         typedef __attribute__((address_space(4))) const float4 kernarg_float4;
         const kernarg_float4 *rows = (kernarg_float4 *) ((__attribute__((address_space(4))) const char *) __builtin_amdgcn_kernarg_segment_ptr() + offsetof(SceneView, tiny));
 #else
         const float4 *rows = sc.tiny;
 #endif
+        // the axis-aligned rectangles: kAaPerAxis slots per axis at fixed rows, each tested by the instance compiled for its axis behind ONE
+        // wave-uniform branch on the axis' count; the rows in use are fetched together (the scalar loads are in flight while the first is tested)
+        const int aa_cnt = sc.aa_cnt;
+        if (aa_cnt != 0) {
+            float4 ra[kAaSlots]; float hb[kAaSlots]; int pk[kAaSlots], id2[kAaSlots];
+#pragma unroll
+            for (int i = 0; i < kAaSlots; ++i) {
+                ra[i] = rows[i * 4];
+                if (IGN) { const float4 r = rows[i * 4 + 1]; hb[i] = r.x; pk[i] = __float_as_int_hd(r.y); id2[i] = __float_as_int_hd(r.w); }
+                else {
+#if defined(__HIP_DEVICE_COMPILE__)
+                    const float2 r = *(__attribute__((address_space(4))) const float2 *) &rows[i * 4 + 1];
+#else
+                    const float2 r{rows[i * 4 + 1].x, rows[i * 4 + 1].y};
+#endif
+                    hb[i] = r.x; pk[i] = __float_as_int_hd(r.y); id2[i] = 0;
+                }
+            }
+#if defined(__HIP_DEVICE_COMPILE__) && PSDR_AA_HOIST
+            // keep the scalar loads up here (the compiler otherwise sinks each row's loads into its slot's branch, where the test waits for them)
+#pragma unroll
+            for (int i = 0; i < kAaSlots; ++i) asm volatile("" : "+s"(ra[i].x), "+s"(ra[i].y), "+s"(ra[i].z), "+s"(ra[i].w), "+s"(hb[i]), "+s"(pk[i]));
+#endif
+            const int cx = aa_cnt & 255, cy = (aa_cnt >> 8) & 255, cz = aa_cnt >> 16;
+#define PSDR_AA(AX, S) aa_prim_test<AX, IGN>(ra[S], hb[S], pk[S], id2[S], o, d, inv, best, best_i, ig0, ig1)
+            if (cx > 0) { PSDR_AA(0, 0); if (cx > 1) { PSDR_AA(0, 1); if (cx > 2) PSDR_AA(0, 2); } }
+            if (cy > 0) { PSDR_AA(1, 3); if (cy > 1) { PSDR_AA(1, 4); if (cy > 2) PSDR_AA(1, 5); } }
+            if (cz > 0) { PSDR_AA(2, 6); if (cz > 1) { PSDR_AA(2, 7); if (cz > 2) PSDR_AA(2, 8); } }
+#undef PSDR_AA
+        }
+        // the other primitives in plane form (triangles, or parallelograms of two triangles: pack_tiny_prims)
 #pragma unroll PSDR_TINY_UNROLL
-        for (int i = 0; i < sc.n_tiny; ++i) tiny_prim_test<IGN>(rows[i * 4], rows[i * 4 + 1], rows[i * 4 + 2], rows[i * 4 + 3], i, o, d, best, best_i, ig0, ig1);
+        for (int i = aa_cnt != 0 ? kAaSlots : 0; i < sc.n_tiny; ++i) tiny_prim_test<IGN>(rows[i * 4], rows[i * 4 + 1], rows[i * 4 + 2], rows[i * 4 + 3], i, o, d, best, best_i, ig0, ig1);
         resolve_tiny_hit(sc, best, best_i);
         if (FOREST == 3) {
             // the trees were walked beforehand (same leaf test, tmax = infinity): the closest tree hit replaces the primitive hit exactly where the

@@ -490,7 +490,7 @@ int lds_bytes(const LaunchCtx &cx, const psdr_scene_s *h) { return cx.off_stack 
 
 // the part of the tree that travels in the kernel arguments (tiny scenes, two-level trees)
 void fill_top(const psdr_scene_s *h, SceneView &sc) {
-    sc.n_tiny = h->n_tiny;
+    sc.n_tiny = h->n_tiny; sc.aa_cnt = h->n_tiny > 0 ? h->aa_cnt : 0;
     std::memcpy(sc.tiny, h->tiny, sizeof(h->tiny));
     std::memcpy(sc.tiny_meta, h->tiny_meta, sizeof(h->tiny_meta));
     sc.n_blas = h->n_blas;
@@ -761,7 +761,7 @@ int lbvh_build(psdr_scene_s *h, hipStream_t s, bool &fallback) {
     HIP_TRY(hipStreamSynchronize(s));            // `tris` dies at return
     h->hot_rows = (int) tris.size();
     h->root = 0; h->bvh_depth = info.depth; h->num_nodes = T - 1; h->num_btris = T;
-    h->n_tiny = 0; h->n_blas = 0; h->n_inline = 0;
+    h->n_tiny = 0; h->aa_cnt = 0; h->n_blas = 0; h->n_inline = 0;
     if (use_wide_tree(h, false)) {
         // the 4-wide tree over the device-built BVH2: its topology is decided on the host (one read-back of the node array; the collapse is
         // O(T)): 263 k triangles +~15 ms on top of the 2 ms device build -- only where a launch would walk it
@@ -925,6 +925,7 @@ int psdr_scene_set_option(psdr_scene_t h, const char *name, double value) {
     const std::string n(name);
     const int iv = (int) value;
     if (n == "bvh_refit") h->refit_enabled = iv != 0;                   // 0: rebuild the tree on the host at every psdr_bvh_build
+    else if (n == "aa_prims") { h->aa_enabled = iv != 0; h->have_bvh = false; }   // 0: every kernel-argument primitive in plane form (no slab rows)
     else if (n == "tiny_scene") h->tiny_enabled = iv != 0;              // 0: walk a tree even for <= 16 triangles
     else if (n == "two_level") h->two_level_enabled = iv != 0;          // 0: one tree over all triangles
     else if (n == "wf_binned") h->wf_binned = iv != 0;                  // 0: wavefront streams not binned by cost class (only without the trace kernel)
@@ -1058,8 +1059,7 @@ int psdr_bvh_build(psdr_scene_t h, void *stream) {
                 // (which then picks a single tree)
                 refit_fits = (int) prims.size() / 3 <= kTinyTris;
                 if (refit_fits) {
-                    h->n_tiny = (int) prims.size() / 3;
-                    tiny_plane_form(prims, h->tiny, h->tiny_meta);
+                    h->n_tiny = tiny_plane_form(prims, h->tiny, h->tiny_meta, &h->aa_cnt, h->aa_enabled);
                     for (int k = 0; k < h->n_blas; ++k) {
                         const float w = h->blas_lo[k].w;
                         h->blas_lo[k] = top[kMaxInlineTris * 3 + k]; h->blas_lo[k].w = w;
@@ -1153,10 +1153,9 @@ int psdr_bvh_build(psdr_scene_t h, void *stream) {
     h->bvh_depth = forest ? fb.max_depth : b.max_depth; h->num_nodes = (int) nodes.size(); h->num_btris = (int) btris.size() / 3;
     if (int rc = bvh4_build(h, nodes, forest ? fb.roots : std::vector<int32_t>{root}, forest, s)) return rc;
     h->have_bvh = true;
-    h->n_tiny = 0; h->n_blas = 0; h->n_inline = 0;
+    h->n_tiny = 0; h->aa_cnt = 0; h->n_blas = 0; h->n_inline = 0;
     if (forest) {
-        h->n_tiny = (int) top_prims.size() / 3;
-        tiny_plane_form(top_prims, h->tiny, h->tiny_meta);
+        h->n_tiny = tiny_plane_form(top_prims, h->tiny, h->tiny_meta, &h->aa_cnt, h->aa_enabled);
         h->n_inline = (int) fb.inline_ids.size();
         h->n_blas = (int) fb.roots.size();
         for (int k = 0; k < h->n_blas; ++k) {
@@ -1171,8 +1170,7 @@ int psdr_bvh_build(psdr_scene_t h, void *stream) {
     } else if (tiny) {
         std::vector<float4> prims;
         pack_tiny_prims(b.btris, prims);           // walls as parallelograms: half the tests
-        h->n_tiny = (int) prims.size() / 3;
-        tiny_plane_form(prims, h->tiny, h->tiny_meta);
+        h->n_tiny = tiny_plane_form(prims, h->tiny, h->tiny_meta, &h->aa_cnt, h->aa_enabled);
     }
     // what the refit path needs: the levels of the breadth-first node order, the padding, the reference area
     h->tree_tris = T; h->refits_since_build = 0; h->num_builds++; h->bvh_pad = forest ? fb.pad : b.pad;

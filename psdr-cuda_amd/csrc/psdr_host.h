@@ -51,7 +51,9 @@ __device__ __forceinline__ void setup_lds(const LaunchCtx &cx, TraversalStack &s
         for (int i = 0; i < sc.n_tiny; ++i) {
             int32_t tri; float k[6];
             const int w = threadIdx.x & 7;
-            tiny_hit_row(sc.tiny_meta + i * 4, (threadIdx.x >> 3) & 1, tri, k);
+            const float4 Sm = sc.tiny[i * 4 + 2];
+            const float S[4] = {Sm.x, Sm.y, Sm.z, Sm.w};
+            tiny_hit_row(sc.tiny_meta + i * 4, (threadIdx.x >> 3) & 1, tri, k, (sc.aa_cnt != 0 && i < kAaSlots) ? S : nullptr);
             const float val = w == 0 ? __int_as_float(tri) : (w == 1 ? k[0] : w == 2 ? k[1] : w == 3 ? k[2] : w == 4 ? k[3] : w == 5 ? k[4] : w == 6 ? k[5] : 0.f);
             if (threadIdx.x < kTinyHitWords) m[i * kTinyHitWords + threadIdx.x] = val;
         }
@@ -200,10 +202,10 @@ struct psdr_scene_s {
     size_t lbvh_bytes = 0;
 
     // tiny scenes: the leaf triangles as they travel in the kernel arguments (SceneView::tiny)
-    bool tiny_enabled = true;
-    int n_tiny = 0;
-    float4 tiny[kTinyTris * 4] = {};           // plane form (tiny_plane_form)
-    int32_t tiny_meta[kTinyTris * 4] = {};
+    bool tiny_enabled = true, aa_enabled = true;
+    int n_tiny = 0, aa_cnt = 0;     // rows in use / slab-form slots per axis
+    float4 tiny[kTinyRows * 4] = {};           // plane form / slab form of the first n_aa (tiny_plane_form)
+    int32_t tiny_meta[kTinyRows * 4] = {};
     // two-level tree (psdr_bvh_build.h ForestBuilder): boxes + roots of the per-mesh trees, as they travel in the
     // kernel arguments; d_top / d_inline_ids serve the refresh after a device refit
     bool two_level_enabled = true, refit_ok = true, wf_binned = true;

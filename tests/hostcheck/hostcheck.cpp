@@ -28,8 +28,7 @@ bool setup(HostScene &hs, const psdr_scene_desc *d) {
     if (d->num_tris <= kTinyTris && !(e && std::atoi(e) == 0)) {
         std::vector<float4> prims;
         pack_tiny_prims(hs.b.btris, prims);
-        hs.sc.n_tiny = (int32_t) (prims.size() / 3);
-        tiny_plane_form(prims, hs.sc.tiny, hs.sc.tiny_meta);
+        hs.sc.n_tiny = tiny_plane_form(prims, hs.sc.tiny, hs.sc.tiny_meta, &hs.sc.aa_cnt);
     }
     return true;
 }
