@@ -46,6 +46,7 @@ VALU_PEAK_WAVE_INSTS_PER_S = N_SIMD * CLOCK_HZ / 2.0          # 1.2288e12 wave-i
 # VALU lane-instructions one primitive test costs (Moeller-Trumbore with SGPR operands, csrc/psdr_device.h tiny_prim_test) and
 # the rest of a traced ray's share of its path vertex (hit reconstruction, sampling, shading): DESIGN.md section 3
 FLOOR_VALU_PER_PRIM_TEST, FLOOR_VALU_PER_RAY_REST = 31, 150          # plane-form primitive test as the ISA issues it: 20 arithmetic + 6 compare + 5 select
+FLOOR_VALU_PER_SLAB_TEST = 16                                        # axis-aligned rectangle in slab form: 6 arithmetic + 4 compare + 5 select + 1 move
 
 
 
@@ -647,8 +648,10 @@ def main():
     # algorithmic floor: VALU lane-instructions a traced ray NEEDS on this scene -- one test per PRIMITIVE the kernel holds (the 12 wall
     # triangles of the Cornell box are 6 parallelograms, psdr_bvh_build.h pack_tiny_prims) x 27 (Moeller-Trumbore with SGPR operands) +
     # ~150 for hit reconstruction, sampling and shading of its path vertex -- over the lane-instructions issued (64 per wave-instruction)
-    n_prims = int(_abi.scene_stats(w.sc._native).get("n_tiny", 0)) or int(w.tb["num_tris"])
-    floor_lane_insts = (n_prims * FLOOR_VALU_PER_PRIM_TEST + FLOOR_VALU_PER_RAY_REST) * float(dom_rays)
+    st = _abi.scene_stats(w.sc._native)
+    n_prims = int(st.get("n_tiny", 0)) or int(w.tb["num_tris"])
+    n_slab = int(st.get("n_slab", 0))
+    floor_lane_insts = (n_slab * FLOOR_VALU_PER_SLAB_TEST + (n_prims - n_slab) * FLOOR_VALU_PER_PRIM_TEST + FLOOR_VALU_PER_RAY_REST) * float(dom_rays)
     dpm = pmc.get(dom_key, {})
     wave_cycles = dpm.get("SQ_WAVE_CYCLES")
     roofline = {
@@ -657,7 +660,7 @@ def main():
         "unit": "G wave-instructions/s", "frac": None if achieved is None else round(achieved / VALU_PEAK_WAVE_INSTS_PER_S, 4),
         "peak_note": "1024 SIMD-32 units x 2.4 GHz / 2 cycles per wave64 VALU instruction (MI355X_MICROARCH.md)",
         "valu_wave_insts_per_launch": valu, "algorithmic_floor_frac": None if valu is None else round(floor_lane_insts / (valu * 64.0), 4),
-        "primitives_tested_per_ray": n_prims,
+        "primitives_tested_per_ray": n_prims, "slab_form_primitives": n_slab,
         "wait_any_frac": None if not wave_cycles or "SQ_WAIT_ANY" not in dpm else round(dpm["SQ_WAIT_ANY"] / wave_cycles, 4),
         "wait_inst_any_frac": None if not wave_cycles or "SQ_WAIT_INST_ANY" not in dpm else round(dpm["SQ_WAIT_INST_ANY"] / wave_cycles, 4),
         "valu_active_frac_of_wave_cycles": None if not wave_cycles or "SQ_ACTIVE_INST_VALU" not in dpm else round(dpm["SQ_ACTIVE_INST_VALU"] / wave_cycles, 4),

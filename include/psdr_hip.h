@@ -247,7 +247,7 @@ int psdr_bvh_build(psdr_scene_t h, void *stream);
 int psdr_bvh_stats(psdr_scene_t h, int32_t out[4]);
 /* out = { primitives carried in the kernel arguments (triangles or parallelograms), trees of a two-level scene,
    inline triangles of a two-level scene, leaf triangles in the tree(s), 1 if the tree was built on the device,
-   0, 0, 0 } -- what psdr_bvh_build chose for the current tables (diagnostics; bench.py prices its
+   how many of [0] are axis-aligned rectangles in slab form, 0, 0 } -- what psdr_bvh_build chose for the current tables (diagnostics; bench.py prices its
    per-ray arithmetic floor from [0]).  No reference counterpart: OptiX hides its acceleration structure. */
 int psdr_scene_info(psdr_scene_t h, int32_t out[8]);
 

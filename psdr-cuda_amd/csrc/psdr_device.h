@@ -238,9 +238,6 @@ PSDR_HD void leaf_from_memory(const float4 *bt, int cnt, const Vec3f &o, const V
 #endif
 }
 
-#ifndef PSDR_AA_HOIST
-#define PSDR_AA_HOIST 0
-#endif
 #ifndef PSDR_TINY_UNROLL
 #define PSDR_TINY_UNROLL 6
 #endif
@@ -500,7 +497,9 @@ PSDR_HD Hit closest_hit(const SceneView &sc, TraversalStack &st, const Vec3f &o,
         const float4 *rows = sc.tiny;
 #endif
         // the axis-aligned rectangles: kAaPerAxis slots per axis at fixed rows, each tested by the instance compiled for its axis behind ONE
-        // wave-uniform branch on the axis' count; the rows in use are fetched together (the scalar loads are in flight while the first is tested)
+        // wave-uniform branch on the axis' count.  (The compiler sinks each row's two scalar loads into its slot's branch; holding all rows in
+        // SGPRs up front costs 25 more spilled SGPRs and 10 % of the kernel, requesting a row while its predecessor is tested changes nothing at
+        // five waves per SIMD: profiles/r04_aa_slab_ab.txt)
         const int aa_cnt = sc.aa_cnt;
         if (aa_cnt != 0) {
             float4 ra[kAaSlots]; float hb[kAaSlots]; int pk[kAaSlots], id2[kAaSlots];
@@ -517,11 +516,6 @@ PSDR_HD Hit closest_hit(const SceneView &sc, TraversalStack &st, const Vec3f &o,
                     hb[i] = r.x; pk[i] = __float_as_int_hd(r.y); id2[i] = 0;
                 }
             }
-#if defined(__HIP_DEVICE_COMPILE__) && PSDR_AA_HOIST
-            // keep the scalar loads up here (the compiler otherwise sinks each row's loads into its slot's branch, where the test waits for them)
-#pragma unroll
-            for (int i = 0; i < kAaSlots; ++i) asm volatile("" : "+s"(ra[i].x), "+s"(ra[i].y), "+s"(ra[i].z), "+s"(ra[i].w), "+s"(hb[i]), "+s"(pk[i]));
-#endif
             const int cx = aa_cnt & 255, cy = (aa_cnt >> 8) & 255, cz = aa_cnt >> 16;
 #define PSDR_AA(AX, S) aa_prim_test<AX, IGN>(ra[S], hb[S], pk[S], id2[S], o, d, inv, best, best_i, ig0, ig1)
             if (cx > 0) { PSDR_AA(0, 0); if (cx > 1) { PSDR_AA(0, 1); if (cx > 2) PSDR_AA(0, 2); } }

@@ -1277,8 +1277,9 @@ int psdr_bvh_stats(psdr_scene_t h, int32_t out[4]) {
 
 int psdr_scene_info(psdr_scene_t h, int32_t out[8]) {
     if (!h || !out) return fail("psdr_scene_info: null argument");
-    out[0] = h->n_tiny; out[1] = h->n_blas; out[2] = h->n_inline; out[3] = h->num_btris; out[4] = h->lbvh ? 1 : 0;
-    out[5] = out[6] = out[7] = 0;
+    const int n_slab = (h->aa_cnt & 255) + ((h->aa_cnt >> 8) & 255) + (h->aa_cnt >> 16);
+    out[0] = h->n_tiny - (h->aa_cnt != 0 ? kAaSlots - n_slab : 0); out[1] = h->n_blas; out[2] = h->n_inline; out[3] = h->num_btris; out[4] = h->lbvh ? 1 : 0;
+    out[5] = n_slab; out[6] = out[7] = 0;
     return 0;
 }
 

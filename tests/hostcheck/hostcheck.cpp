@@ -57,6 +57,14 @@ int hostcheck_trace(const psdr_scene_desc *d, int m, const float *o, const float
     return 0;
 }
 
+// rows in use and slab-form slots per axis of a tiny scene's primitive list (tiny_plane_form)
+int hostcheck_tiny_layout(const psdr_scene_desc *d, int *out) {
+    HostScene hs;
+    if (!setup(hs, d)) return 1;
+    out[0] = hs.sc.n_tiny; out[1] = hs.sc.aa_cnt & 255; out[2] = (hs.sc.aa_cnt >> 8) & 255; out[3] = hs.sc.aa_cnt >> 16;
+    return 0;
+}
+
 // mode 0: renderC; mode 1: renderD forward (K = 1), all three terms
 int hostcheck_render(const psdr_scene_desc *d, const psdr_render_opts *o, int mode, const psdr_tangents *tan, float *img, float *dimg,
                      int nthreads) {

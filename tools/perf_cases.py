@@ -60,6 +60,9 @@ def main():
                     ow = _abi.make_opts(spp=64, integrator=_abi.INTEGRATOR_PATH, max_depth=3, flags=fl)
                     ms = timeit(lambda: g.render_d_fwd(ow, t3w))
                     print("C2 path3 %-9s renderD K=3 mat %8.2f ms  %7.0f Msamples/s" % (fn, ms, n / ms / 1e3))
+            t1 = [{"texels": torch.ones(tb["texels"].numel())}]
+            ms = timeit(lambda: g.render_d_fwd(o, t1))
+            print("C2 %-9s renderD fwd K=1 mat  %8.2f ms  %7.0f Msamples/s" % (name, ms, n / ms / 1e3))
             t3 = [{"texels": torch.eye(tb["texels"].numel())[c]} for c in range(3)]
             ms = timeit(lambda: g.render_d_fwd(o, t3))
             print("C2 %-9s renderD fwd K=3 mat  %8.2f ms  %7.0f Msamples/s" % (name, ms, n / ms / 1e3))
