@@ -1113,9 +1113,8 @@ PSDR_HD Vec3<M> direct_step(const SceneView &sc, const TVT &tv, TraversalStack &
     int bsdf_id = active ? Tab<TVT::flags>::mesh_bsdf(sc, its.mesh) : 0;
     if (bsdf_id < 0) { active = false; bsdf_id = 0; }      // bounding mesh of the environment map, direct.cpp:54-57
     const Bsdf<G, M> bsdf(sc, tv, bsdf_id);
-    for (int i = 0; i < nB; ++i) {
-        const float s[3] = {rng.next(), rng.next(), rng.next()};
-        if (!active) continue;
+    // one BSDF sample (direct.cpp:64-118) / one emitter sample (direct.cpp:120-160) at `its`
+    auto bsdf_sample = [&](const float (&s)[3], int i) {
         Vec3f wo_s; M pdf_s;
         bool a1 = bsdf.sample(sc, tv, its, s, active, wo_s, pdf_s);
         const Vec3f dir1 = val(its.sh.s) * wo_s.x + val(its.sh.t) * wo_s.y + val(its.sh.n) * wo_s.z;
@@ -1144,10 +1143,8 @@ PSDR_HD Vec3<M> direct_step(const SceneView &sc, const TVT &tv, TraversalStack &
             result = result + Le<M>(sc, tv, its1, true) * bsdf_val * w;
         }
         if (next_its && i == 0) { *next_its = its1; *next_f = bsdf_val; *next_valid = a_hit; }
-    }
-    for (int i = 0; i < nL; ++i) {
-        const float s0 = rng.next(), s1 = rng.next();
-        if (!active) continue;
+    };
+    auto light_sample = [&](float s0, float s1, int i) {
         const PosSample<G> ps = sample_emitter_position<G>(sc, tv, val(its.p), s0, s1, is_ad<G>());
         Vec3<G> wo = ps.p - its.p;
         const G d2 = dot(wo, wo), dist = safe_sqrt(d2);
@@ -1155,7 +1152,7 @@ PSDR_HD Vec3<M> direct_step(const SceneView &sc, const TVT &tv, TraversalStack &
         const RayT<G> ray1{its.p, wo};
         const Its<G> its1 = intersect<G>(sc, tv, st, ray1, ps.valid, form, nrays, -1, -1, kPreLightRay);
         if (light_tri && i == 0) *light_tri = its1.valid ? its1.tri : -1;          // the value sweep of a split reverse launch records it (psdr_reverse.h RevDisk)
-        if (!(its1.valid && val(its1.t) > val(dist) - kShadowEpsilon && emitter_of(sc, tv, its1) >= 0)) continue;
+        if (!(its1.valid && val(its1.t) > val(dist) - kShadowEpsilon && emitter_of(sc, tv, its1) >= 0)) return;
         const G Gv = abs_(dot(its1.n, -wo)) / d2;
         const Vec3<G> wl = its.sh.to_local(wo);
         const Vec3<M> bsdf_val = bsdf.eval(sc, tv, its, wl, true) * to_m<M>(Gv * ps.J / ps.pdf);
@@ -1164,6 +1161,27 @@ PSDR_HD Vec3<M> direct_step(const SceneView &sc, const TVT &tv, TraversalStack &
         M w(1.f / (float) nL);
         if (nB > 0) w = w * mis_weight(M(ps.pdf), pdf1);
         result = result + Le<M>(sc, tv, its1, true) * bsdf_val * w;
+    };
+    if (nB == 1 && nL == 1 && next_its != nullptr && ad_traits<M>::K <= 1) {
+        // a PathTracer vertex (one sample of each kind, the BSDF sample's hit is the path's next vertex): the five numbers are drawn in the
+        // reference's order, then the EMITTER sample is evaluated first -- its hit record dies with it, so the next vertex (~25 registers,
+        // with the BSDF value and pdf) is not alive across a second trace.  0 + a + b = 0 + b + a: the same sum, bit for bit.  C2 K = 1
+        // duals 55 -> 21 spilled VGPRs, 1.20 -> 1.14 ms; not for DirectIntegrator(1, 1) (nothing lives on: renderC 0.49 -> 0.52 ms) nor the
+        // K = 3 duals (1.71 -> 1.76 ms): profiles/r04_sample_order_ab.txt
+        const float s[3] = {rng.next(), rng.next(), rng.next()};
+        const float s0 = rng.next(), s1 = rng.next();
+        if (active) { light_sample(s0, s1, 0); bsdf_sample(s, 0); }
+        return result;
+    }
+    for (int i = 0; i < nB; ++i) {
+        const float s[3] = {rng.next(), rng.next(), rng.next()};
+        if (!active) continue;
+        bsdf_sample(s, i);
+    }
+    for (int i = 0; i < nL; ++i) {
+        const float s0 = rng.next(), s1 = rng.next();
+        if (!active) continue;
+        light_sample(s0, s1, i);
     }
     return result;
 }
