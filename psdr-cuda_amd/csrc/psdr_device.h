@@ -283,6 +283,7 @@ PSDR_HD void aa_prim_test(const float4 &ra, float hb, int packed, int id2, const
     const float u = (oa + t * da) - ra.y, v = (ob + t * db) - ra.z;
     bool hit = (fabsf(u) <= ra.w) & (fabsf(v) <= hb) & (t >= kRayEpsilon) & (t < best.t);
     if (IGN) { const int id = (u * __int_as_float_hd(packed) + v > 0.f) ? (int) ((uint32_t) id2 >> 16) : (id2 & 0xffff); hit = hit & (id != ig0) & (id != ig1); }
+    // (four selects: `if (hit) { ... }` -- exec-masked moves -- measured 4 % slower on renderC, 15 % on the K = 3 duals: profiles/r04_aa_ifhit_ab.txt)
     best.t = hit ? t : best.t; best.u = hit ? u : best.u; best.v = hit ? v : best.v; best_i = hit ? packed : best_i;
 }
 // The triangle and its barycentrics from the winning primitive's plane coordinates.  Per primitive and half (the second triangle of a
@@ -1162,12 +1163,12 @@ PSDR_HD Vec3<M> direct_step(const SceneView &sc, const TVT &tv, TraversalStack &
         if (nB > 0) w = w * mis_weight(M(ps.pdf), pdf1);
         result = result + Le<M>(sc, tv, its1, true) * bsdf_val * w;
     };
-    if (nB == 1 && nL == 1 && next_its != nullptr && ad_traits<M>::K <= 1) {
+    if (nB == 1 && nL == 1 && next_its != nullptr && ad_traits<M>::K <= 1 && !is_ad<G>()) {
         // a PathTracer vertex (one sample of each kind, the BSDF sample's hit is the path's next vertex): the five numbers are drawn in the
         // reference's order, then the EMITTER sample is evaluated first -- its hit record dies with it, so the next vertex (~25 registers,
         // with the BSDF value and pdf) is not alive across a second trace.  0 + a + b = 0 + b + a: the same sum, bit for bit.  C2 K = 1
         // duals 55 -> 21 spilled VGPRs, 1.20 -> 1.14 ms; not for DirectIntegrator(1, 1) (nothing lives on: renderC 0.49 -> 0.52 ms) nor the
-        // K = 3 duals (1.71 -> 1.76 ms): profiles/r04_sample_order_ab.txt
+        // K = 3 duals (1.71 -> 1.76 ms): profiles/r04_sample_order_ab.txt; the geometry duals (G = Dual) gain nothing and keep the plain order
         const float s[3] = {rng.next(), rng.next(), rng.next()};
         const float s0 = rng.next(), s1 = rng.next();
         if (active) { light_sample(s0, s1, 0); bsdf_sample(s, 0); }
@@ -1247,7 +1248,7 @@ template <class R> PSDR_HD Vec3<R> zero_nonfinite(const Vec3<R> &v) { return {ze
 // reports the BSDF-sampled continuation (next vertex record + throughput).
 template <class M, class TVT>
 PSDR_HD Vec3<M> wavefront_camera_vertex(const SceneView &sc, const TVT &tv, TraversalStack &st, const LiParams &lp, const RngJump &jump,
-                                        int pixel, uint64_t slot, uint32_t &nrays, Its<float> &next, Vec3<M> &beta, Vec3f &origin, bool &alive) {
+                                        int pixel, uint64_t slot, uint32_t &nrays, Its<float> &next, Vec3<M> &beta, Vec3f &origin, bool &alive, Rng *rng_after = nullptr) {
     Rng rng; rng.init(slot, jump);
     const float j0 = rng.next(), j1 = rng.next();
     const int W = sc.d.width;
@@ -1259,6 +1260,7 @@ PSDR_HD Vec3<M> wavefront_camera_vertex(const SceneView &sc, const TVT &tv, Trav
     Vec3<M> result = lp.hide_emitters ? zero3<M>() : Le<M>(sc, tv, its, true);
     bool nvalid = false;
     result = result + direct_step<float, M>(sc, tv, st, rng, its, true, 1, 1, nrays, &next, &beta, &nvalid);
+    if (rng_after) *rng_after = rng;           // the stream continues at the next vertex (classify_next)
     origin = its.p;
     if (nvalid) { const Vec3f b = val(beta); alive = b.x != 0.f || b.y != 0.f || b.z != 0.f; }
     return result;
@@ -1268,9 +1270,10 @@ PSDR_HD Vec3<M> wavefront_camera_vertex(const SceneView &sc, const TVT &tv, Trav
 // others (its sample streams continue behind the two pixel jitter draws: the stage-0 jump).
 template <class M, class TVT>
 PSDR_HD Vec3<M> wavefront_primary_vertex(const SceneView &sc, const TVT &tv, TraversalStack &st, const LiParams &lp, const RngJump &jump,
-                                         int pixel, uint64_t slot, uint32_t &nrays, Its<float> &next, Vec3f &dir, bool &alive) {
+                                         int pixel, uint64_t slot, uint32_t &nrays, Its<float> &next, Vec3f &dir, bool &alive, Rng *rng_after = nullptr) {
     Rng rng; rng.init(slot, jump);
     const float j0 = rng.next(), j1 = rng.next();
+    if (rng_after) *rng_after = rng;           // bounce stage 0 draws from here on (classify_next)
     const int W = sc.d.width;
     const float sx = ((float) (pixel % W) + j0) / (float) W, sy = ((float) (pixel / W) + j1) / (float) sc.d.height;
     const RayT<float> ray = primary_ray<float>(sc, tv, sx, sy);
@@ -1284,11 +1287,13 @@ PSDR_HD Vec3<M> wavefront_primary_vertex(const SceneView &sc, const TVT &tv, Tra
 // Wavefront mode, stage k >= 1: the direct step at a path vertex read back from the stream.
 template <class M, class TVT>
 PSDR_HD Vec3<M> wavefront_bounce_vertex(const SceneView &sc, const TVT &tv, TraversalStack &st, const RngJump &jump_k, uint64_t slot,
-                                        const Its<float> &its, uint32_t &nrays, Its<float> &next, Vec3<M> &f, bool &alive, int *light_tri = nullptr) {
+                                        const Its<float> &its, uint32_t &nrays, Its<float> &next, Vec3<M> &f, bool &alive, int *light_tri = nullptr,
+                                        Rng *rng_after = nullptr) {
     Rng rng; rng.init(slot, jump_k);
     bool nvalid = false;
     if (light_tri) *light_tri = -1;
     const Vec3<M> c = direct_step<float, M>(sc, tv, st, rng, its, true, 1, 1, nrays, &next, &f, &nvalid, light_tri);
+    if (rng_after) *rng_after = rng;           // five draws per vertex: the next stage's streams start here (classify_next)
     alive = nvalid;
     return c;
 }

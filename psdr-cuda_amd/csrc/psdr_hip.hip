@@ -65,8 +65,10 @@ static_assert(offsetof(TraceArgs, blas_lo) == 0, "k_wf_trace reads the boxes thr
 // OVF: the worst-case stack of the forest is deeper than the LDS columns -- entries beyond them live in a per-lane global column (rare: the deepest
 // stack of a ray on the bunny / the interior is 11 of 24 / 22 possible entries).
 // IGN: rays that start ON a secondary edge (the probe pass of a traced secondary-edge launch): rb.w = the edge, its adjacent faces are not hit.
-template <bool MULTI, bool OVF, bool IGN = false>
-__global__ __launch_bounds__(kTraceBlock) void k_wf_trace(TraceArgs a) {
+// WPE: resident waves per SIMD the instance is compiled for -- 4: one workgroup per CU with all of its LDS; 8: two workgroups per CU (<= 64
+// VGPRs), each with half of the LDS (shorter stack columns, the rest of the stacks in the overflow columns; fewer staged nodes)
+template <bool MULTI, bool OVF, bool IGN = false, int WPE = 4>
+__global__ __launch_bounds__(kTraceBlock, WPE) void k_wf_trace(TraceArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int32_t kDone = 0x7fffffff;
     {
@@ -820,15 +822,23 @@ int launch_wf_trace(psdr_scene_s *h, const float4 *req, const int32_t *count, lo
     std::memcpy(a.blas_hi, h->blas_hi, sizeof(a.blas_hi));
     for (int k = 0; k < h->n_blas; ++k) std::memcpy(&a.blas_hi[k].w, &h->blas_root4[k], 4);
     a.nodes4 = h->d_nodes4; a.btris = h->d_btris; a.req = req; a.count = count; a.hit = hit; a.sub_cap = sub_cap; a.n_blas = h->n_blas;
-    // LDS: stacks first in the budget (S + 1 columns: the unconditional stores of a node step may touch the entry above the top), the tree in the rest
-    const int S = std::min(h->stack_need4, kTraceStackMax);
+    // LDS: stacks first in the budget (S + 1 columns: the unconditional stores of a node step may touch the entry above the top), the tree in the rest.
+    // TWO workgroups per CU (8 waves per SIMD, <= 64 VGPRs), each with half of the LDS -- stack columns of 8 entries (deeper ones, rare, in the
+    // overflow columns), fewer staged nodes -- where the walk gains more from the second set of waves than it loses to the smaller staging:
+    // a forest that does not fit the LDS anyway (C5: trace stage 326 -> 307 us) or a large launch (C4 shard: 754 -> 690 us); the 4 M-slot launch on
+    // the bunny, whose whole tree fits one workgroup's LDS, is 2.5 % faster with one (profiles/r04_trace_wg2_abk.txt).  Option trace_wg2: -1 this
+    // rule, 0 never, n > 0 always with columns of n entries.
+    const int full_S = std::min(h->stack_need4, kTraceStackMax);
+    const bool tree_fits = (long long) h->num_nodes4 * kTraceNodeStride + (long long) (full_S + 1) * kTraceBlock * 4 + 1024 <= (long long) h->lds_limit;
+    const bool wg2 = !ign && h->lds_limit >= 160 * 1024 && (h->opt.trace_wg2 > 0 || (h->opt.trace_wg2 < 0 && (!tree_fits || sub_cap * kWfSub >= (1ll << 25))));
+    const int S = std::min(h->stack_need4, wg2 ? std::min(h->opt.trace_wg2 > 0 ? h->opt.trace_wg2 : 8, kTraceStackMax) : kTraceStackMax);
     const bool ovf = h->stack_need4 > S;
     const int stack_bytes = (S + 1) * kTraceBlock * 4;
-    const int room = h->lds_limit - 1024 - stack_bytes;                 // 1 KB: the kernel's static LDS
+    const int room = (wg2 ? h->lds_limit / 2 : h->lds_limit) - 1024 - stack_bytes;                 // 1 KB: the kernel's static LDS
     a.n_lnodes = std::max(0, std::min(h->num_nodes4, room / kTraceNodeStride));
     a.off_stack = a.n_lnodes * kTraceNodeStride;
     a.stack_entries = S;
-    const int grid = h->num_cus;
+    const int grid = wg2 ? 2 * h->num_cus : h->num_cus;
     if (ovf) {
         a.ovf_stride = grid * kTraceBlock;
         const size_t need = (size_t) a.ovf_stride * (size_t) (h->stack_need4 - S) * sizeof(int32_t);
@@ -841,11 +851,11 @@ int launch_wf_trace(psdr_scene_s *h, const float4 *req, const int32_t *count, lo
         a.ovf = h->d_trace_ovf;
     }
     const int dyn = a.off_stack + stack_bytes;
-#define PSDR_LAUNCH_TRACE_I(MULTI, OVF, IGN)                                                                                                                \
+#define PSDR_LAUNCH_TRACE_I(MULTI, OVF, IGN, WPE)                                                                                                           \
     do { static bool attr_set = false;                                                                                                                      \
-         if (!attr_set) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wf_trace<MULTI, OVF, IGN>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024)); attr_set = true; } \
-         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wf_trace<MULTI, OVF, IGN>), dim3(grid), dim3(kTraceBlock), dyn, s, a); } while (0)
-#define PSDR_LAUNCH_TRACE(MULTI, OVF) do { if (ign) PSDR_LAUNCH_TRACE_I(MULTI, OVF, true); else PSDR_LAUNCH_TRACE_I(MULTI, OVF, false); } while (0)
+         if (!attr_set) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wf_trace<MULTI, OVF, IGN, WPE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024)); attr_set = true; } \
+         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wf_trace<MULTI, OVF, IGN, WPE>), dim3(grid), dim3(kTraceBlock), dyn, s, a); } while (0)
+#define PSDR_LAUNCH_TRACE(MULTI, OVF) do { if (ign) PSDR_LAUNCH_TRACE_I(MULTI, OVF, true, 4); else if (wg2) PSDR_LAUNCH_TRACE_I(MULTI, OVF, false, 8); else PSDR_LAUNCH_TRACE_I(MULTI, OVF, false, 4); } while (0)
     if (h->n_blas > 1) { if (ovf) PSDR_LAUNCH_TRACE(true, true); else PSDR_LAUNCH_TRACE(true, false); }
     else { if (ovf) PSDR_LAUNCH_TRACE(false, true); else PSDR_LAUNCH_TRACE(false, false); }
 #undef PSDR_LAUNCH_TRACE_I
@@ -942,6 +952,7 @@ int psdr_scene_set_option(psdr_scene_t h, const char *name, double value) {
     else if (n == "rev_split") h->opt.rev_split = iv;
     else if (n == "sedge_split") h->opt.sedge_split = iv;
     else if (n == "probe") h->opt.probe = iv;
+    else if (n == "trace_wg2") h->opt.trace_wg2 = iv;                    // dense trace kernel as two workgroups per CU: -1 by forest and launch size, 0 never, n > 0 always (stack columns of n entries)
     else if (n == "chunk_log2") h->opt.chunk_log2 = std::max(0, std::min(30, iv));
     else if (n == "bvh_maxleaf") h->opt.bvh_maxleaf = std::max(1, std::min(8, iv));
     else if (n == "bvh_tcost") h->opt.bvh_tcost = (float) value;

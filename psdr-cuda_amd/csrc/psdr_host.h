@@ -157,6 +157,7 @@ struct psdr_scene_options {
     int sedge_split = -1;                  // secondary-edge term as filter + survivor kernel: 1 / 0 force, -1 from 2^18 slots
     int chunk_log2 = 0;                    // log2 of the slots per chunk of the chunked launches (0: 2^24 / 2^25)
     int probe = 1;                         // two-level scenes: fused kernels as probe pass + dense trace kernel + final pass where that is built (0: one kernel)
+    int trace_wg2 = -1;                    // the dense trace kernel as two workgroups per CU: -1 by forest and launch size, 0 never, n > 0 always (stack columns of n entries in LDS)
     int bvh_maxleaf = 4;                   // host SAH builder: leaf size limit (1..8)
     float bvh_tcost = 2.0f;                //                   cost of a node visit in triangle tests
 };

@@ -295,7 +295,7 @@ __device__ __forceinline__ void stream_push(const PathStream &out, bool alive, i
 // TRACED (the traced wavefront): the two directions are handed back -- they become the trace requests -- and the light ray is tested against the
 // boxes without its length too: closest_hit looks for the closest hit along the whole ray, and so does the trace kernel.
 template <bool TRACED = false, class TVT>
-__device__ __forceinline__ int classify_next(const SceneView &sc, const TVT &, const RngJump &jump_next, uint32_t slot, const Its<float> &next, const Vec3f &,
+__device__ __forceinline__ int classify_next(const SceneView &sc, const TVT &, Rng rng, const Its<float> &next, const Vec3f &,
                                              Vec3f *d_bsdf = nullptr, Vec3f *d_light = nullptr) {
     const TangentView<0, TVT::flags> tv0{};
     const Its<float> &its = next;
@@ -307,7 +307,9 @@ __device__ __forceinline__ int classify_next(const SceneView &sc, const TVT &, c
         for (int k = 0; k < sc.n_blas; ++k) { float te; any = any || blas_box(sc, k, o, inv, tmax, te); }
         return any;
     };
-    Rng rng; rng.init((uint64_t) slot, jump_next);
+    // `rng` = the stream of this slot where the stage that produced `next` left it: the next stage's jump is this stage's plus the draws it
+    // made (2 for the pixel jitter, 5 per path vertex: run_camera_wavefront), so the two TEA mixes of a second Rng::init (~290 VALU
+    // instructions per record, a fifth of a bounce stage) are not repeated
     const float s[3] = {rng.next(), rng.next(), rng.next()};
     const float s0 = rng.next(), s1 = rng.next();
     int cls = 0;
@@ -432,16 +434,17 @@ __global__ __launch_bounds__(kBlock, (is_ad<M>() ? 2 : PSDR_WF_WAVES)) void k_wf
         Vec3f origin(0.f), dir(0.f);
         bool alive = false;
         uint32_t slot = 0;
+        Rng rng_next; rng_next.state = rng_next.inc = 0;
         bool primary_only = false;
         if constexpr (TRACED) primary_only = want_next != 0;
         else if constexpr ((FL & kSceneForest) != 0) primary_only = out.binned != 0 && want_next;
         if (in) {
             slot = (uint32_t) ((uint64_t) pixel * (uint64_t) spp + (uint64_t) (s_begin + s_in));
             if (primary_only) {
-                r = wavefront_primary_vertex<M>(cx.sc, tv, st, cx.lp, cx.jump, pixel, slot, nrays, next, dir, alive);
+                r = wavefront_primary_vertex<M>(cx.sc, tv, st, cx.lp, cx.jump, pixel, slot, nrays, next, dir, alive, &rng_next);
                 beta = Vec3<M>{M(1.f), M(1.f), M(1.f)};
             } else {
-                r = wavefront_camera_vertex<M>(cx.sc, tv, st, cx.lp, cx.jump, pixel, slot, nrays, next, beta, origin, alive);
+                r = wavefront_camera_vertex<M>(cx.sc, tv, st, cx.lp, cx.jump, pixel, slot, nrays, next, beta, origin, alive, &rng_next);
                 if (alive) { Vec3f d = next.p - origin; const float t = norm(d); dir = d / t; }
             }
         }
@@ -452,10 +455,10 @@ __global__ __launch_bounds__(kBlock, (is_ad<M>() ? 2 : PSDR_WF_WAVES)) void k_wf
         if (want_next) {
             if constexpr (TRACED) {
                 Vec3f d_bsdf(0.f), d_light(0.f);
-                const int cls = alive ? classify_next<true>(cx.sc, tv, jump_next, slot, next, dir, &d_bsdf, &d_light) : 0;
+                const int cls = alive ? classify_next<true>(cx.sc, tv, rng_next, next, dir, &d_bsdf, &d_light) : 0;
                 stream_push_traced<M>(out, tq, alive, cls, pixel, slot, next, dir, beta, r, d_bsdf, d_light);
             } else if constexpr ((FL & kSceneForest) != 0) {
-                if (out.binned) stream_push_binned<M>(out, alive, alive ? classify_next(cx.sc, tv, jump_next, slot, next, dir) : 0, jj / kBlock, pixel, slot, next, dir, beta, r);
+                if (out.binned) stream_push_binned<M>(out, alive, alive ? classify_next(cx.sc, tv, rng_next, next, dir) : 0, jj / kBlock, pixel, slot, next, dir, beta, r);
                 else stream_push<M>(out, alive, pixel, slot, next, dir, beta, r);
             } else stream_push<M>(out, alive, pixel, slot, next, dir, beta, r);
         }
@@ -489,6 +492,7 @@ __device__ __forceinline__ void wf_bounce_record(const LaunchCtx &cx, const TV<M
     Its<float> next; next.tri = -1; next.hu = next.hv = 0.f;
     Vec3f dir(0.f);
     bool alive = false;
+    Rng rng_next; rng_next.state = rng_next.inc = 0;
     if (live) {
         pixel = raw.pixel; slot = raw.slot;
         const Vec3f din{raw.dx, raw.dy, raw.dz};
@@ -524,7 +528,7 @@ __device__ __forceinline__ void wf_bounce_record(const LaunchCtx &cx, const TV<M
 #pragma unroll
             for (int k = 0; k < (K > 0 ? K : 1); ++k) tvp.t[k] = tv.t[k];
             int light_tri = -1;
-            c = wavefront_bounce_vertex<M>(cx.sc, tvp, st, cx.jump, (uint64_t) slot, its, nrays, next, f, alive, REC ? &light_tri : nullptr);
+            c = wavefront_bounce_vertex<M>(cx.sc, tvp, st, cx.jump, (uint64_t) slot, its, nrays, next, f, alive, REC ? &light_tri : nullptr, &rng_next);
             if constexpr (REC) {
                 // vertex `stage` of this path: (c_k, f_k) and the triangles its two rays arrived at (the adjoint kernel re-intersects those)
                 float *col = wr.disk + wr.column(pixel, slot) + (long long) (kRevDiskHead + wr.stage * kRevDiskPerVertexCf) * wr.stride;
@@ -533,7 +537,7 @@ __device__ __forceinline__ void wf_bounce_record(const LaunchCtx &cx, const TV<M
                 col[3 * wr.stride] = fv.x; col[4 * wr.stride] = fv.y; col[5 * wr.stride] = fv.z;
                 col[6 * wr.stride] = __int_as_float(alive ? next.tri : -1); col[7 * wr.stride] = __int_as_float(light_tri);
             }
-        } else c = wavefront_bounce_vertex<M>(cx.sc, tv, st, cx.jump, (uint64_t) slot, its, nrays, next, f, alive);
+        } else c = wavefront_bounce_vertex<M>(cx.sc, tv, st, cx.jump, (uint64_t) slot, its, nrays, next, f, alive, nullptr, &rng_next);
         r = acc + beta * c;
         if (alive) {
             beta = beta * f;
@@ -556,10 +560,10 @@ __device__ __forceinline__ void wf_bounce_record(const LaunchCtx &cx, const TV<M
     if (want_next) {
         if constexpr (TRACED) {
             Vec3f d_bsdf(0.f), d_light(0.f);
-            const int cls = alive ? classify_next<true>(cx.sc, tv, jump_next, slot, next, dir, &d_bsdf, &d_light) : 0;
+            const int cls = alive ? classify_next<true>(cx.sc, tv, rng_next, next, dir, &d_bsdf, &d_light) : 0;
             stream_push_traced<M>(out, tq, alive, cls, pixel, slot, next, dir, beta, r, d_bsdf, d_light);
         } else if constexpr ((FL & kSceneForest) != 0) {
-            if (out.binned) stream_push_binned<M>(out, alive, alive ? classify_next(cx.sc, tv, jump_next, slot, next, dir) : 0, chunk, pixel, slot, next, dir, beta, r);
+            if (out.binned) stream_push_binned<M>(out, alive, alive ? classify_next(cx.sc, tv, rng_next, next, dir) : 0, chunk, pixel, slot, next, dir, beta, r);
             else stream_push<M>(out, alive, pixel, slot, next, dir, beta, r);
         } else stream_push<M>(out, alive, pixel, slot, next, dir, beta, r);
     }
@@ -724,10 +728,11 @@ template <int FL> __global__ __launch_bounds__(kBlock, PSDR_WAVES_C) void k_dire
             const uint32_t slot = (uint32_t) ((uint64_t) pixel * (uint64_t) spp + (uint64_t) (s_begin + s_in));
             Its<float> next; next.tri = -1; next.hu = next.hv = 0.f;
             Vec3f dir(0.f); bool alive = false;
-            (void) wavefront_primary_vertex<float>(cx.sc, tv0, st, cx.lp, cx.jump, pixel, slot, nrays, next, dir, alive);
+            Rng rng_next; rng_next.state = rng_next.inc = 0;
+            (void) wavefront_primary_vertex<float>(cx.sc, tv0, st, cx.lp, cx.jump, pixel, slot, nrays, next, dir, alive, &rng_next);
             if (alive) {
                 hit[3 * jj + 2] = float4{__int_as_float(next.tri), next.hu, next.hv, next.t};
-                m = 4u | (uint32_t) classify_next<true>(cx.sc, tv0, jump_next, slot, next, dir, &d[0], &d[1]);
+                m = 4u | (uint32_t) classify_next<true>(cx.sc, tv0, rng_next, next, dir, &d[0], &d[1]);
                 p0 = next.p;
             }
             mask[jj] = m;
