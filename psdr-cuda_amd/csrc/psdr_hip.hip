@@ -830,7 +830,7 @@ int launch_wf_trace(psdr_scene_s *h, const float4 *req, const int32_t *count, lo
     // rule, 0 never, n > 0 always with columns of n entries.
     const int full_S = std::min(h->stack_need4, kTraceStackMax);
     const bool tree_fits = (long long) h->num_nodes4 * kTraceNodeStride + (long long) (full_S + 1) * kTraceBlock * 4 + 1024 <= (long long) h->lds_limit;
-    const bool wg2 = !ign && h->lds_limit >= 160 * 1024 && (h->opt.trace_wg2 > 0 || (h->opt.trace_wg2 < 0 && (!tree_fits || sub_cap * kWfSub >= (1ll << 25))));
+    const bool wg2 = h->lds_limit >= 160 * 1024 && (h->opt.trace_wg2 > 0 || (h->opt.trace_wg2 < 0 && (!tree_fits || sub_cap * kWfSub >= (1ll << 25))));
     const int S = std::min(h->stack_need4, wg2 ? std::min(h->opt.trace_wg2 > 0 ? h->opt.trace_wg2 : 8, kTraceStackMax) : kTraceStackMax);
     const bool ovf = h->stack_need4 > S;
     const int stack_bytes = (S + 1) * kTraceBlock * 4;
@@ -855,7 +855,7 @@ int launch_wf_trace(psdr_scene_s *h, const float4 *req, const int32_t *count, lo
     do { static bool attr_set = false;                                                                                                                      \
          if (!attr_set) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wf_trace<MULTI, OVF, IGN, WPE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024)); attr_set = true; } \
          hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wf_trace<MULTI, OVF, IGN, WPE>), dim3(grid), dim3(kTraceBlock), dyn, s, a); } while (0)
-#define PSDR_LAUNCH_TRACE(MULTI, OVF) do { if (ign) PSDR_LAUNCH_TRACE_I(MULTI, OVF, true, 4); else if (wg2) PSDR_LAUNCH_TRACE_I(MULTI, OVF, false, 8); else PSDR_LAUNCH_TRACE_I(MULTI, OVF, false, 4); } while (0)
+#define PSDR_LAUNCH_TRACE(MULTI, OVF) do { if (ign) { if (wg2) PSDR_LAUNCH_TRACE_I(MULTI, OVF, true, 8); else PSDR_LAUNCH_TRACE_I(MULTI, OVF, true, 4); } else if (wg2) PSDR_LAUNCH_TRACE_I(MULTI, OVF, false, 8); else PSDR_LAUNCH_TRACE_I(MULTI, OVF, false, 4); } while (0)
     if (h->n_blas > 1) { if (ovf) PSDR_LAUNCH_TRACE(true, true); else PSDR_LAUNCH_TRACE(true, false); }
     else { if (ovf) PSDR_LAUNCH_TRACE(false, true); else PSDR_LAUNCH_TRACE(false, false); }
 #undef PSDR_LAUNCH_TRACE_I

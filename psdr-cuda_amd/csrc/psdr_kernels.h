@@ -626,8 +626,11 @@ __global__ __launch_bounds__(kBlock, (is_ad<M>() ? 2 : (TRACED ? PSDR_WF_WAVES_T
 #ifndef PSDR_WAVES_PE
 #define PSDR_WAVES_PE 4
 #endif
+// forward instances of the lean two-level variant (K = 1: 119 -> 96 VGPRs, 14 spilled) take a fifth wave: C3 three-term forward 2.85 -> 2.78 ms
+// (k_primary_edge 1 310 -> 1 248 us); the reverse kernel loses 3-11 % there, three waves lose everywhere (profiles/r04_occupancy_abk.txt)
+template <int K, int FL> constexpr int primary_edge_waves() { return ((FL & (kSceneEnv | kSceneRough)) == 0 && (FL & kSceneForest) != 0 && K == 1) ? PSDR_WAVES_PE + 1 : PSDR_WAVES_PE; }
 template <int K, int FL, int INTEG>
-__global__ __launch_bounds__(kBlock, PSDR_WAVES_PE) void k_primary_edge(LaunchCtx cx, TangentView<K, FL> tv, long long i0, long long n, float inv_sppe,
+__global__ __launch_bounds__(kBlock, (primary_edge_waves<K, FL>())) void k_primary_edge(LaunchCtx cx, TangentView<K, FL> tv, long long i0, long long n, float inv_sppe,
                                                          float *__restrict__ dimg, long long plane, unsigned long long *counters,
                                                          const uint32_t *__restrict__ order) {
     TraversalStack st; setup_lds(cx, st);

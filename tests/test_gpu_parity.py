@@ -300,3 +300,27 @@ def test_literal_form_flag_on_the_gpu(scene, mesh, res, spp):
     adj = torch_adj = None
     rc = lib.psdr_render_d_rev(g.h, C.byref(_abi.make_opts(flags=_abi.FLAG_LITERAL_FORMS, **kw)), C.c_void_p(8), None, C.byref(_abi.Grads()), None)
     assert rc != 0 and b"LITERAL" in lib.psdr_last_error()                     # forward-mode diagnostic only
+
+
+@pytest.mark.parametrize("scene", ["cbox_bunny", "interior"])
+def test_trace_kernel_workgroup_layouts_find_the_same_hits(scene):
+    """The dense trace kernel of the traced wavefront runs as one workgroup per CU with the whole LDS or as two with half of it each
+    (psdr_hip.hip launch_wf_trace, option trace_wg2: shorter stack columns -- the rest in the overflow columns -- and fewer staged node
+    rows).  Same walk, same leaf test: the same image whichever layout traces, down to stack columns of 2 entries (nearly every push of
+    a walk then lands in an overflow column)."""
+    if scene == "interior":
+        from psdr_cuda.fixtures import make_interior_scene
+        sc = make_interior_scene(seed=0, n_objects=10, res=96, spp=16); sc.configure()
+    else:
+        sc, _ = load_scene(scene, res=96, spp=16)
+    tb = sc.tables(0)
+    o = _abi.make_opts(integrator=_abi.INTEGRATOR_PATH, max_depth=3, spp=16, flags=_abi.FLAG_WAVEFRONT)
+    ref, rays = None, None
+    for wg2 in (0, 8, 2, -1):
+        g = GpuScene(tb, options={"trace_wg2": wg2})
+        img = g.render_c(o)
+        r = g.counters()[0]
+        if ref is None:
+            ref, rays = img, r
+        else:
+            assert rel_l2(img, ref) < 2e-6 and r == rays, (wg2, rel_l2(img, ref), r, rays)          # the order of the atomic splats only
