@@ -6,6 +6,7 @@
 #include "psdr_bvh_build.h"
 
 #include <cstdlib>
+#include <cstring>
 #include <rocprim/rocprim.hpp>
 
 namespace {
@@ -1031,8 +1032,20 @@ int psdr_bvh_build(psdr_scene_t h, void *stream) {
     const int T = h->desc.num_tris;
     // ---- refit: same triangle count as the tree on the device and the tree has not degraded
     const bool tiny = h->tiny_enabled && T <= kTinyTris;        // the triangles travel in the kernel arguments: host copy needed
+    // The host copy of emitter_i (LDS table sizes, two-level eligibility, hot gradient rows) is refreshed by the build paths below only: a
+    // refit must not run on when the emitter layout changed under an unchanged triangle count -- the kernels would stage too few entries of
+    // face_cmf / face_pmf.  One small device-to-host copy per refit candidate; a changed layout takes the full build.
+    bool emitters_same = (size_t) std::max(h->desc.num_emitters, 0) * PSDR_EMITTER_I_STRIDE == h->emitter_i.size();
+    if (emitters_same && !h->emitter_i.empty() && h->refit_enabled && !tiny && h->refit_ok && h->tree_tris == T && h->num_nodes > 0) {
+        std::vector<int32_t> now(h->emitter_i.size());
+        emitters_same = h->desc.emitter_i != nullptr;
+        if (emitters_same) {
+            HIP_TRY(copy_on_stream(now.data(), h->desc.emitter_i, now.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+            emitters_same = std::memcmp(now.data(), h->emitter_i.data(), now.size() * sizeof(int32_t)) == 0;
+        }
+    }
     const bool forest_stands = !(forest_tables(h) && !small_tables_fit(h));      // a two-level tree whose kernels could no longer stage the tables: rebuild as one tree
-    if (h->refit_enabled && !tiny && h->refit_ok && forest_stands && h->tree_tris == T && h->num_nodes > 0 && h->refits_since_build < kMaxRefits) {
+    if (h->refit_enabled && !tiny && h->refit_ok && emitters_same && forest_stands && h->tree_tris == T && h->num_nodes > 0 && h->refits_since_build < kMaxRefits) {
         float prev_area = h->built_area;
         if (h->refits_since_build > 0) {        // of the PREVIOUS refit (done long ago), read on the stream that wrote it
             HIP_TRY(hipMemcpyAsync(&prev_area, h->d_refit_area, sizeof(float), hipMemcpyDeviceToHost, h->refit_stream));

@@ -248,16 +248,31 @@ def look_at(origin, target, up):
     return m
 
 
+_NONZERO_STATIC = {}
+
+
+def _has_nonzero_static(device):
+    """Probed ONCE per device type on a dummy mask: whether torch.nonzero_static serves this device.  The real call is never wrapped in
+    try/except -- an asynchronous device error that surfaces there must not be swallowed by a fallback."""
+    key = device.type
+    if key not in _NONZERO_STATIC:
+        ok = hasattr(torch, "nonzero_static")
+        if ok:
+            try:
+                torch.nonzero_static(torch.ones(2, dtype=torch.bool, device=device), size=2)
+            except (RuntimeError, NotImplementedError):
+                ok = False
+        _NONZERO_STATIC[key] = ok
+    return _NONZERO_STATIC[key]
+
+
 def compact_indices(keep, count):
     """Indices of the True entries of `keep`, in order, when their number is already known on the host: no device-to-host read
     (a boolean-mask index reads the count back)."""
     if count == 0:
         return torch.zeros(0, dtype=torch.long, device=keep.device)
-    if hasattr(torch, "nonzero_static"):
-        try:
-            return torch.nonzero_static(keep, size=int(count)).reshape(-1)
-        except (RuntimeError, NotImplementedError):
-            pass
+    if _has_nonzero_static(keep.device):
+        return torch.nonzero_static(keep, size=int(count)).reshape(-1)
     pos = torch.cumsum(keep.to(torch.long), dim=0) - 1
     out = torch.empty(int(count) + 1, dtype=torch.long, device=keep.device)
     out.scatter_(0, torch.where(keep, pos, torch.full_like(pos, int(count))), torch.arange(keep.shape[0], device=keep.device))
@@ -1359,6 +1374,8 @@ class Scene(Object):
         # ---- ONE read-back for every size and sum the host needs from here on: mesh areas, the luminance of the area lights, the
         # sums of their face distributions, the numbers of kept secondary / primary edges
         area_lights = [e for e in self.m_emitters if not isinstance(e, EnvironmentMap)]
+        for e in area_lights:          # the reference's assertion (arealight.cpp configure), BEFORE the batched read-back dereferences the mesh
+            psdr_assert(e.m_mesh is not None and e.m_mesh.m_ready)
         parts = [self._areas_t]
         parts += [e._luminance_t() for e in area_lights]
         parts += [e.m_mesh._triangle_info[:, 21].detach().to(torch.float32).sum().reshape(1) for e in area_lights]
@@ -1522,6 +1539,8 @@ class Scene(Object):
 
         # ---- emitters, scene.cpp:183-196 + area.cpp:10-16: static ids once per topology, areas / weights / face distributions by kernel
         Ne, M = len(self.m_emitters), len(self.m_meshes)
+        for e in self.m_emitters:          # the reference's assertion (AreaLight::configure) before any table dereferences the emitter's mesh
+            psdr_assert(e.m_mesh is not None and e.m_mesh.m_ready)
         ekey = (tp["key"], tuple((id(e), id(e.m_mesh)) for e in self.m_emitters), tuple(id(m.m_emitter) for m in self.m_meshes))
         if getattr(self, "_emit_static", None) is None or self._emit_static[0] != ekey:
             em_ids = {id(e): i for i, e in enumerate(self.m_emitters)}
