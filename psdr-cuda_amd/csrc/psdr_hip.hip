@@ -579,7 +579,7 @@ SinkLayout make_sink_layout(const psdr_scene_s *h, const psdr_grads *g) {
     if (priv_on && L.hot_rows > 0 && h->desc.num_emitters > 0 && h->desc.env_emitter != 0) {
         const int32_t *ei = h->emitter_i.data();
         const int n = std::min(std::min(ei[2], 2), L.hot_rows);
-        for (int r = 0; r < n; ++r) { L.priv_tri[r] = ei[1] + r; L.priv_slot[r] = r; }
+        for (int r = 0; r < n; ++r) { L.priv_tri[r] = ei[1] + r; L.priv_slot[r] = h->hot_identity ? ei[1] + r : r; }
         L.priv_rows = n;
         if (n > 0) { L.priv_off = (L.rep * L.stride + 3) / 4 * 4; if (L.rad_n) L.priv_emitter = 0; }
     }
@@ -762,7 +762,7 @@ int lbvh_build(psdr_scene_s *h, hipStream_t s, bool &fallback) {
     hipLaunchKernelGGL(k_scatter_hot, dim3(1), dim3(256), 0, s, h->d_hot_map, h->d_hot_tris, (int) tris.size());
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s));            // `tris` dies at return
-    h->hot_rows = (int) tris.size();
+    h->hot_rows = (int) tris.size(); h->hot_identity = false;
     h->root = 0; h->bvh_depth = info.depth; h->num_nodes = T - 1; h->num_btris = T;
     h->n_tiny = 0; h->aa_cnt = 0; h->n_blas = 0; h->n_inline = 0;
     if (use_wide_tree(h, false)) {
@@ -1152,6 +1152,10 @@ int psdr_bvh_build(psdr_scene_t h, void *stream) {
         constexpr int kMaxHotRows = 200;
         std::vector<int32_t> map((size_t) T, -1), tris;
         auto add = [&](int t) { if (t >= 0 && t < T && map[t] < 0 && (int) tris.size() < kMaxHotRows) { map[t] = (int32_t) tris.size(); tris.push_back(t); } };
+        // a scene whose triangles travel in the kernel arguments caches EVERY row, slot = triangle: its kernels (flag kSceneTiny) address the
+        // row without the map, the range test and the global-atomic arm (DeviceSink::add_tri)
+        h->hot_identity = tiny;
+        if (tiny) for (int t = 0; t < T; ++t) add(t);
         for (int e = 0; e < h->desc.num_emitters; ++e) {
             const int32_t *ei = h->emitter_i.data() + (size_t) e * PSDR_EMITTER_I_STRIDE;
             for (int f = 0; f < ei[2] && f < 64; ++f) add(ei[1] + f);

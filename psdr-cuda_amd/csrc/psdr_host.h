@@ -226,6 +226,7 @@ struct psdr_scene_s {
     std::vector<int32_t> emitter_i;        // host copy of desc.emitter_i (the emitter meshes' rows are hot)
     int32_t *d_hot_map = nullptr, *d_hot_tris = nullptr;
     int hot_rows = 0;
+    bool hot_identity = false;             // every row cached, slot == triangle (scenes without a tree)
     size_t hot_cap = 0;
 
     // primary-edge slots sorted by pixel (psdr_hip.hip primary_edge_order)

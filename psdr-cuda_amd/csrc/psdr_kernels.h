@@ -857,6 +857,12 @@ __global__ __launch_bounds__(kBlock) void k_guide(LaunchCtx cx, int r0, int r1, 
     count_rays(counters, nrays);
 }
 
+#ifndef PSDR_TINY_DIRECT_ROWS
+#define PSDR_TINY_DIRECT_ROWS 1
+#endif
+#ifndef PSDR_SINK_CLASS_TEST
+#define PSDR_SINK_CLASS_TEST 1
+#endif
 template <int FL> struct DeviceSink {
     static constexpr int flags = FL;
     static constexpr bool has_env = (FL & kSceneEnv) != 0;
@@ -876,7 +882,14 @@ template <int FL> struct DeviceSink {
     __device__ __forceinline__ static void lds_add(lds_float *p, float v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 #endif
     float cam[16];
-    __device__ __forceinline__ static bool ok(float v) { return v != 0.f && isfinite(v); }
+    // finite and not zero: ONE v_cmp_class_f32 (normal numbers of either sign; denormals are flushed in these kernels) instead of two compares and an s_and
+    __device__ __forceinline__ static bool ok(float v) {
+#if PSDR_SINK_CLASS_TEST
+        return __builtin_amdgcn_classf(v, 0x108);
+#else
+        return v != 0.f && isfinite(v);
+#endif
+    }
     __device__ __forceinline__ void glob(float *base, size_t i, float v) const { if (base != nullptr && ok(v)) atomicAdd(base + i, v); }
     // The ~20 words of one vertex' row adjoint arrive one add_tri at a time: the tri -> cache slot lookup (a
     // global load that the compiler cannot hoist across the atomics) is remembered for the last triangle
@@ -884,6 +897,8 @@ template <int FL> struct DeviceSink {
     int last_tri, last_slot;
     __device__ __forceinline__ void add_tri(int tri, int word, float v) {
         if (g.g_tri_info == nullptr || !ok(v)) return;
+        // scenes without a tree: every row is cached at slot == triangle (render_rev checks it) -- no map lookup, no range test, no global-atomic arm
+        if constexpr ((FL & kSceneTiny) != 0 && PSDR_TINY_DIRECT_ROWS) { lds_add(lds + L.hot_off + tri * PSDR_TRI_STRIDE + word, v); return; }
         if (tri != last_tri) { last_tri = tri; last_slot = L.hot_rows ? L.hot_map[tri] : -1; }
         const int slot = last_slot;
         if (slot >= 0 && slot < L.hot_rows) lds_add(lds + L.hot_off + slot * PSDR_TRI_STRIDE + word, v);
@@ -1489,6 +1504,9 @@ int render_rev(psdr_scene_s *h, const psdr_render_opts *o, const float *adj_img,
     const long long WH = (long long) h->desc.width * h->desc.height;
     if (out_img) HIP_TRY(hipMemsetAsync(out_img, 0, sizeof(float) * WH * 3, s));
     DeviceSink<FL> sink{}; sink.g = *grads; sink.L = make_sink_layout(h, grads);
+    // the instances of scenes without a tree address a triangle's cached row directly (DeviceSink::add_tri): every row cached, slot == triangle
+    if ((FL & kSceneTiny) != 0 && PSDR_TINY_DIRECT_ROWS && grads->g_tri_info != nullptr && !(h->hot_identity && sink.L.hot_rows == h->desc.num_tris))
+        return fail("psdr_render_d_rev: the gradient cache of a scene without a tree does not hold every triangle row");
     const int nsp = o->spp_end - o->spp_begin;
     if (o->spp > 0 && nsp > 0) {
         LaunchCtx cx;

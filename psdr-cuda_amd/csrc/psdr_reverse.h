@@ -527,6 +527,13 @@ template <int FL> PSDR_HD Its<float> make_path_vertex(const SceneView &sc, const
 // other triangles (next vertex, emitter) is scattered straight into the sink.
 //   REPLAY (one BSDF and one light sample per vertex): the value sweep records the triangle each of the two
 //   rays arrived at in rec[k]; the BACKWARD sweep re-intersects that triangle instead of tracing again.
+// Order of the two estimators in the ADJOINT sweep of a replayed vertex (geometry sinks): 0 = BSDF sample first, 1 = light sample first, 2 = light
+// sample first in the rough-conductor instances only.  Measured (profiles/r04_rev_sink_ab.txt): the rough instances spill less with the light
+// sample first (adjoint kernel of the split launch 42 -> 15 spilled VGPRs; C5 DirectIntegrator reverse 3.14 -> 2.95 ms, PathTracer(3) 5.59 -> 5.46);
+// the diffuse ones do not spill either way and are level (C2 all gradients 5.32 = 5.32 ms; 240 -> 230 VGPRs, far from a third wave's 168).
+#ifndef PSDR_REV_LIGHT_FIRST
+#define PSDR_REV_LIGHT_FIRST 2
+#endif
 template <bool BACKWARD, bool REPLAY, class Sink>
 PSDR_HD VertexOut vertex_eval(Sink &sink, const SceneView &sc, TraversalStack &st, Rng &rng, const Its<float> &its, int nB, int nL,
                               const Vec3f &a_c, const Vec3f &a_f, VertexAdj &va, uint32_t &nrays, PathRec &rec, int k, RowAdj *next_row = nullptr) {
@@ -542,11 +549,12 @@ PSDR_HD VertexOut vertex_eval(Sink &sink, const SceneView &sc, TraversalStack &s
     brev.b.mc = &mat;
     const Bsdf<float, float> &bsdf = brev.b;
     if (REPLAY && !BACKWARD) { rec.put_tri(k, 0, -1); rec.put_tri(k, 1, -1); }
-    for (int i = 0; i < nB; ++i) {
-        const float s[3] = {rng.next(), rng.next(), rng.next()};
+    // The two estimators of a vertex as closures: the numbers are drawn in the reference's order (three for the BSDF sample, two for
+    // the light sample), the ORDER OF EVALUATION is the caller's below.
+    auto bsdf_term = [&](const int i, const float (&s)[3]) {
         Vec3f wo_s; float pdf_s;
         const bool ok = bsdf.sample(sc, tv0, its, s, true, wo_s, pdf_s);
-        if (!ok) continue;
+        if (!ok) return;
         const RayT<float> ray1{its.p, its.sh.to_world(wo_s)};
         Hit h1;
         if (REPLAY && BACKWARD) h1.tri = rec.tri(k, 0);
@@ -555,7 +563,7 @@ PSDR_HD VertexOut vertex_eval(Sink &sink, const SceneView &sc, TraversalStack &s
             h1 = closest_hit<false, tree_mode<Sink::flags>()>(sc, st, ray1.o, ray1.d, INFINITY, -1, -1, kPreBsdfRay);
             if (REPLAY) rec.put_tri(k, 0, h1.tri);
         }
-        if (h1.tri < 0) continue;
+        if (h1.tri < 0) return;
         const int tm = Tab<Sink::flags>::tri_mesh(sc, h1.tri), mesh1 = tm & ~PSDR_TRI_FACE_NORMALS;
         const TriRow<float> T1 = load_tri<float>(sc, tv0, h1.tri);
         if (REPLAY && BACKWARD) h1 = hit_on_triangle(h1.tri, T1.p0, T1.e1, T1.e2, ray1.o, ray1.d);
@@ -590,7 +598,7 @@ PSDR_HD VertexOut vertex_eval(Sink &sink, const SceneView &sc, TraversalStack &s
             out.c = out.c + Le1 * valv * w;
         }
         if (i == 0) { out.f = valv; out.next = make_path_vertex<Sink::flags>(sc, its.p, h1.tri, h1.u, h1.v, T1); out.next_valid = true; }
-        if (!BACKWARD) continue;
+        if (!BACKWARD) return;
         Vec3f a_val = a_c * Le1 * w;
         const float a_w = dot(a_c, Le1 * valv);
         if (i == 0) acc(a_val, a_f);
@@ -602,7 +610,7 @@ PSDR_HD VertexOut vertex_eval(Sink &sink, const SceneView &sc, TraversalStack &s
             const Vec3f gr = a_c * valv * w;
             sink.add_rad(e1, 0, gr.x); sink.add_rad(e1, 1, gr.y); sink.add_rad(e1, 2, gr.z);
         }
-        if (a_val.x == 0.f && a_val.y == 0.f && a_val.z == 0.f && a_w == 0.f && !le_dir) continue;
+        if (a_val.x == 0.f && a_val.y == 0.f && a_val.z == 0.f && a_w == 0.f && !le_dir) return;
         float a_pdf0 = a_w * dw_dpdf0;
         const Vec3f a_fv = a_val * cfac;
         const float a_cfac = dot(a_val, f);
@@ -628,9 +636,9 @@ PSDR_HD VertexOut vertex_eval(Sink &sink, const SceneView &sc, TraversalStack &s
         if (merge) acc_finite(next_row->p, a_dvec);
         else scatter_point(sink, h1.tri, h1.u, h1.v, a_dvec);
         acc(va.p, -a_dvec);
-    }
-    for (int i = 0; i < nL; ++i) {
-        const float s0 = rng.next(), s1 = rng.next();
+    };
+    auto light_term = [&](const int i, const float s0, const float s1) {
+        (void) i;
         float r0 = s0, r1 = s1;                                // mirrors sample_emitter_position
         int e = 0; float epdf = 1.f;
         if (sc.d.num_emitters > 1) e = sample_reuse(Tab<Sink::flags>::emitter_cmf(sc), Tab<Sink::flags>::emitter_pmf(sc), sc.d.emitter_sum, sc.d.num_emitters, r1, epdf);
@@ -662,14 +670,14 @@ PSDR_HD VertexOut vertex_eval(Sink &sink, const SceneView &sc, TraversalStack &s
             h2 = closest_hit<false, tree_mode<Sink::flags>()>(sc, st, its.p, wo, INFINITY, -1, -1, kPreLightRay);
             if (REPLAY) rec.put_tri(k, 1, h2.tri);
         }
-        if (h2.tri < 0) continue;
+        if (h2.tri < 0) return;
         const int tm2 = Tab<Sink::flags>::tri_mesh(sc, h2.tri), mesh2 = tm2 & ~PSDR_TRI_FACE_NORMALS;
         const int e2 = Tab<Sink::flags>::mesh_emitter(sc, mesh2);
         const TriRow<float> T2 = load_tri<float>(sc, tv0, h2.tri);
         if (REPLAY && BACKWARD) h2 = hit_on_triangle(h2.tri, T2.p0, T2.e1, T2.e2, its.p, wo);
         const Vec3f p2 = bary_point(T2.p0, T2.e1, T2.e2, h2.u, h2.v);
         const float t2 = norm(p2 - its.p);
-        if (!(t2 > dist - kShadowEpsilon && e2 >= 0)) continue;
+        if (!(t2 > dist - kShadowEpsilon && e2 >= 0)) return;
         const bool env2 = kEnv && e2 == sc.d.env_emitter;
         Vec3f Le2;
         // the forward pass looks the map up along the path-space direction to the HIT point p2 (its1.wi)
@@ -677,7 +685,7 @@ PSDR_HD VertexOut vertex_eval(Sink &sink, const SceneView &sc, TraversalStack &s
         if (env2) Le2 = env_eval_direction<float>(sc, tv0, dir2);
         else {
             const ShNormal sn2 = shading_normal(T2, (tm2 & PSDR_TRI_FACE_NORMALS) != 0, h2.u, h2.v);
-            if (!(-dot((p2 - its.p) / t2, sn2.n) > 0.f)) continue;         // Le = 0 from behind
+            if (!(-dot((p2 - its.p) / t2, sn2.n) > 0.f)) return;         // Le = 0 from behind
             const float *rr = Tab<Sink::flags>::emitter_f(sc, e2);
             Le2 = Vec3f{rr[0], rr[1], rr[2]};
         }
@@ -696,7 +704,7 @@ PSDR_HD VertexOut vertex_eval(Sink &sink, const SceneView &sc, TraversalStack &s
             dw_dpdf1 = (-2.f * a2 * pdf1 / (den * den)) / (float) nL;
         }
         out.c = out.c + Le2 * valv * w;
-        if (!BACKWARD) continue;
+        if (!BACKWARD) return;
         const Vec3f gr = a_c * valv * w;
         Vec3f a_wo(0.f);
         if (env2) {
@@ -731,6 +739,26 @@ PSDR_HD VertexOut vertex_eval(Sink &sink, const SceneView &sc, TraversalStack &s
         if (one_row) scatter_row(sink, etri, ba, bb, a_wov, wo * (-a_cosv), a_earea);
         else if (!env_s) scatter_point(sink, etri, ba, bb, a_wov);
         acc(va.p, -a_wov);
+    };
+    // geometry-adjoint sweeps only (the material sinks take no rows: their texel kernel at five waves lost 20 % to the order, 2.12 -> 2.60 ms)
+    if constexpr (REPLAY && BACKWARD && SinkTakesRows<Sink>::value && (PSDR_REV_LIGHT_FIRST == 1 || (PSDR_REV_LIGHT_FIRST == 2 && (Sink::flags & kSceneRough) != 0))) {
+        // one sample of each kind at most (REPLAY): the light sample is differentiated FIRST -- the BSDF sample leaves the next vertex
+        // (a whole hit record and its row adjoint) behind, which then is not alive across the light sample's chain.  Same five numbers;
+        // the vertex' accumulators start from zero, so their two addends commute.
+        float s[3] = {0.f, 0.f, 0.f}, s0 = 0.f, s1 = 0.f;
+        if (nB > 0) { s[0] = rng.next(); s[1] = rng.next(); s[2] = rng.next(); }
+        if (nL > 0) { s0 = rng.next(); s1 = rng.next(); }
+        if (nL > 0) light_term(0, s0, s1);
+        if (nB > 0) bsdf_term(0, s);
+    } else {
+        for (int i = 0; i < nB; ++i) {
+            const float s[3] = {rng.next(), rng.next(), rng.next()};
+            bsdf_term(i, s);
+        }
+        for (int i = 0; i < nL; ++i) {
+            const float s0 = rng.next(), s1 = rng.next();
+            light_term(i, s0, s1);
+        }
     }
     return out;
 }
