@@ -713,6 +713,8 @@ template <class R, class TVT> PSDR_HD Its<R> intersect(const SceneView &sc, cons
 template <class TVT> PSDR_HD Its<float> path_vertex_from_record(const SceneView &sc, const TVT &tv, int tri, float hu, float hv, const Vec3f &dir) {
     Its<float> its;
     its.valid = true; its.tri = tri; its.hu = hu; its.hv = hv; its.J = 1.f; its.t = 0.f;
+    // (measured and dropped: the texture-coordinate row fetched WITH the triangle row instead of after it -- one dependent round trip less in the
+    // bounce stage's chain, 1 344.7 = 1 344.3 us per C4 stage: the stage does not wait for a single trip, profiles/r04_flat_ab.txt)
     const int tm = Tab<TVT::flags>::tri_mesh(sc, tri);
     its.mesh = tm & ~PSDR_TRI_FACE_NORMALS;
     const TriRow<float> T = load_tri_f(sc, tv, tri);
@@ -1056,17 +1058,31 @@ template <class R, class TVT> PSDR_HD float emitter_position_pdf(const SceneView
 }
 
 // ---------------------------------------------------------------------------- camera
+// A word of a launch-constant table at a wave-uniform index, read through the CONSTANT address space: in a kernel that also writes global
+// memory (the reverse-mode kernels: gradient atomics) the compiler cannot prove a plain load invariant and fetches it per lane through the
+// vector memory path -- the camera record alone was 23 of the 53 vector loads per slot of the C2 all-gradients kernel.  Nothing a launch
+// reads this way is written by it (the camera's gradient goes to psdr_grads::g_cam_to_world).
+#ifndef PSDR_UNIFORM_WORD
+#define PSDR_UNIFORM_WORD 1
+#endif
+PSDR_HD float uniform_word(const float *tab, int i) {
+#if defined(__HIP_DEVICE_COMPILE__) && PSDR_UNIFORM_WORD
+    return ((const __attribute__((address_space(4))) float *) tab)[i];
+#else
+    return tab[i];
+#endif
+}
 // PerspectiveCamera::sample_primary_ray (src/sensor/perspective.cpp:120-136)
 template <class R, class TVT> PSDR_HD RayT<R> primary_ray(const SceneView &sc, const TVT &tv, float sx, float sy) {
     const float *m = sc.d.cam + PSDR_CAM_SAMPLE_TO_CAMERA;
     float v[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = m[r * 4] * sx + m[r * 4 + 1] * sy + m[r * 4 + 3];
+    for (int r = 0; r < 4; ++r) v[r] = uniform_word(m, r * 4) * sx + uniform_word(m, r * 4 + 1) * sy + uniform_word(m, r * 4 + 3);
     const float iw = 1.f / v[3];
     const Vec3f d = normalize(Vec3f{v[0] * iw, v[1] * iw, v[2] * iw});
     const float *c = sc.d.cam + PSDR_CAM_TO_WORLD;
     constexpr auto tm = &psdr_tangents::d_cam_to_world;
-    auto tw = [&](int r, int col) { return ldf<R>(c, tv, tm, r * 4 + col); };
+    auto tw = [&](int r, int col) { if constexpr (is_ad<R>()) return ldf<R>(c, tv, tm, r * 4 + col); else return R(uniform_word(c, r * 4 + col)); };
     RayT<R> ray;
     const R w = tw(3, 3);
     ray.o = Vec3<R>(tw(0, 3) / w, tw(1, 3) / w, tw(2, 3) / w);

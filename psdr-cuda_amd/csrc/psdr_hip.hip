@@ -91,7 +91,10 @@ __global__ __launch_bounds__(kTraceBlock, WPE) void k_wf_trace(TraceArgs a) {
     const int lane = threadIdx.x & 63;
     const int W = (int) gridDim.x * (kTraceBlock / 64);
     int next_b = __builtin_amdgcn_readfirstlane((int) blockIdx.x * (kTraceBlock / 64) + (int) (threadIdx.x >> 6));
-    int32_t *stack = reinterpret_cast<int32_t *>(psdr_dyn_lds + a.off_stack) + threadIdx.x;
+    // LDS-address-space pointer: with a generic one the compiler merges the two arms of the pop below ("LDS column or overflow column") into ONE
+    // flat_load_dword on a selected address -- every pop of the walk then takes the texture-address path and waits for vmcnt AND lgkmcnt
+    typedef __attribute__((address_space(3))) int32_t lds_int;
+    lds_int *stack = (lds_int *) reinterpret_cast<int32_t *>(psdr_dyn_lds + a.off_stack) + threadIdx.x;
     const int S = a.stack_entries;
     int32_t *ovf = OVF ? a.ovf + ((size_t) blockIdx.x * kTraceBlock + threadIdx.x) : nullptr;
     typedef __attribute__((address_space(4))) const float4 kernarg_float4;
@@ -108,7 +111,7 @@ __global__ __launch_bounds__(kTraceBlock, WPE) void k_wf_trace(TraceArgs a) {
     int blk_n = 0, consumed = 0;
     bool exhausted = false;                                        // wave-uniform: no request left for this wave
     auto pop = [&]() {
-        if (sp > 0) { --sp; cur = (!OVF || sp < S) ? stack[sp * kTraceBlock] : ovf[(size_t) (sp - S) * a.ovf_stride]; }
+        if (sp > 0) { --sp; if (!OVF || sp < S) cur = stack[sp * kTraceBlock]; else cur = ovf[(size_t) (sp - S) * a.ovf_stride]; }
         else cur = kDone;
     };
     // VOTE scheduling: every iteration the wave runs ONE step of the phase more of its lanes wait for -- a node step (lanes at an inner node)

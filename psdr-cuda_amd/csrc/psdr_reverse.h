@@ -428,12 +428,12 @@ template <class Sink> PSDR_HD void camera_ray_vjp(Sink &sink, const SceneView &s
     const float o3[3] = {ao.x, ao.y, ao.z}, d3[3] = {ad.x, ad.y, ad.z};
     {   // o = to_world[:,3] / w
         const float *c = sc.d.cam + PSDR_CAM_TO_WORLD;
-        const float iw = 1.f / c[15];
-        sink.add_cam(15, -(ao.x * c[3] + ao.y * c[7] + ao.z * c[11]) * iw * iw);
+        const float iw = 1.f / uniform_word(c, 15);
+        sink.add_cam(15, -(ao.x * uniform_word(c, 3) + ao.y * uniform_word(c, 7) + ao.z * uniform_word(c, 11)) * iw * iw);
     }
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
-        sink.add_cam(r * 4 + 3, o3[r] / sc.d.cam[PSDR_CAM_TO_WORLD + 15]);
+        sink.add_cam(r * 4 + 3, o3[r] / uniform_word(sc.d.cam, PSDR_CAM_TO_WORLD + 15));
         sink.add_cam(r * 4 + 0, d3[r] * dcam.x); sink.add_cam(r * 4 + 1, d3[r] * dcam.y); sink.add_cam(r * 4 + 2, d3[r] * dcam.z);
     }
 }
@@ -441,7 +441,7 @@ PSDR_HD Vec3f camera_space_dir(const SceneView &sc, float sx, float sy) {
     const float *m = sc.d.cam + PSDR_CAM_SAMPLE_TO_CAMERA;
     float v4[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) v4[r] = m[r * 4] * sx + m[r * 4 + 1] * sy + m[r * 4 + 3];
+    for (int r = 0; r < 4; ++r) v4[r] = uniform_word(m, r * 4) * sx + uniform_word(m, r * 4 + 1) * sy + uniform_word(m, r * 4 + 3);
     return normalize(Vec3f{v4[0] / v4[3], v4[1] / v4[3], v4[2] / v4[3]});
 }
 
