@@ -295,3 +295,32 @@ def test_two_level_tree_stands_only_while_the_mesh_level_tables_fit_its_kernels(
     g.set_guide(None)
     _abi.check(g.lib, g.lib.psdr_bvh_build(g.h, None))
     assert rel_l2(g.render_c(o), ref) < 1e-5
+
+
+def test_refit_is_not_taken_when_the_emitter_layout_changed():
+    """psdr_bvh_build refits while the triangle count stands -- but the host copy of emitter_i (LDS table sizes of the two-level kernels, hot
+    gradient rows) is refreshed by the build paths only: a changed emitter layout under an unchanged triangle count must take the
+    full build, and the handle must then render what a fresh handle on the same tables renders."""
+    sc, _ = load_scene("cbox_bunny", res=48, spp=8)
+    tb = sc.tables(0)
+    g = GpuScene(tb)
+    opt = _abi.make_opts(spp=8, bsdf_samples=1, light_samples=1)
+    g.render_c(opt)
+    b0 = bvh_stats(g)
+    # unchanged tables: a refit
+    _abi.check(g.lib, g.lib.psdr_bvh_build(g.h, None))
+    b1 = bvh_stats(g)
+    assert b1["builds"] == b0["builds"] and b1["refits"] == b0["refits"] + 1, (b0, b1)
+    # the area light keeps only its first triangle: same triangle table, another emitter_i row (written into the table the handle points at)
+    ei = next(t for t in g.keep if t.data_ptr() == int(g.desc.emitter_i))        # the int32 table the handle points at
+    ei = ei.view(-1, _abi.EMITTER_I_STRIDE)
+    assert int(ei[0, 2]) == 2
+    ei[0, 2] = 1
+    torch.cuda.synchronize()
+    _abi.check(g.lib, g.lib.psdr_bvh_build(g.h, None))
+    b2 = bvh_stats(g)
+    assert b2["builds"] == b1["builds"] + 1 and b2["refits"] == b1["refits"], (b1, b2)
+    tb_mod = dict(tb); tb_mod["emitter_i"] = ei.detach().cpu().clone()
+    fresh = GpuScene(tb_mod)
+    a, b = g.render_c(opt), fresh.render_c(opt)
+    assert np.isfinite(a).all() and a.mean() > 0 and rel_l2(a, b) < 1e-6, rel_l2(a, b)
