@@ -155,7 +155,7 @@ struct psdr_scene_options {
     int sink_private = 1;                  // lane-private accumulators for the emitter's rows
     int rev_split = -1;                    // reverse mode as value kernel + adjoint kernel: 1 / 0 force, -1 by scene and launch size
     int sedge_split = -1;                  // secondary-edge term as filter + survivor kernel: 1 / 0 force, -1 from 2^18 slots
-    int chunk_log2 = 0;                    // log2 of the slots per chunk of the chunked launches (0: 2^24 / 2^25)
+    int chunk_log2 = 0;                    // log2 of the slots per chunk of the chunked launches (0: 2^24 / 2^25, the traced wavefront 2^26)
     int probe = 1;                         // two-level scenes: fused kernels as probe pass + dense trace kernel + final pass where that is built (0: one kernel)
     int trace_wg2 = -1;                    // the dense trace kernel as two workgroups per CU: -1 by forest and launch size, 0 never, n > 0 always (stack columns of n entries in LDS)
     int bvh_maxleaf = 4;                   // host SAH builder: leaf size limit (1..8)

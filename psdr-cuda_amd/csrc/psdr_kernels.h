@@ -1296,7 +1296,10 @@ int run_camera_wavefront(psdr_scene_s *h, const psdr_render_opts *o, const TV<M,
     bool traced = false;
     if constexpr ((FL & kSceneForest) != 0) traced = traced_wavefront(h);
     const bool binned = !traced && (FL & kSceneForest) != 0 && h->n_blas > 0 && h->wf_binned;          // a two-level scene is a room (use_wavefront)
-    const long long cap = std::min(n, binned ? launch_chunk(h, 24) : launch_chunk(h, 25));
+    // chunk of the traced wavefront: 2^26 slots (240 B of workspace per slot: 16 GB of the 288) -- the stage kernels are persistent and pay their
+    // ramp-up and tail once per launch; the C4 shard (2^26 slots) as ONE chunk 14.3 -> 14.1 ms of kernel time, and every smaller chunk is slower
+    // still (2^24: 15.0, 2^22: 19.7, 2^20: 34.4 -- the streams staying inside the 256 MB last-level cache buys nothing; profiles/r04_chunk_sweep.txt)
+    const long long cap = std::min(n, binned ? launch_chunk(h, 24) : launch_chunk(h, traced ? 26 : 25));
     const int depth = o->max_depth;
     const size_t words = 8 + 6 * (1 + K) + (traced ? 8 : 0);          // traced: + the two hit rows of a record
     // plain: block b appends to sub-stream b % kWfSub, at most ceil(blocks / kWfSub) * trips * kBlock records each.
@@ -1584,7 +1587,9 @@ int render_rev(psdr_scene_s *h, const psdr_render_opts *o, const float *adj_img,
         if (split) {
             // records of one chunk of slots live in a scratch buffer (2 + 5 depth words per slot; 2 + 8 depth from the wavefront); chunks bound its size
             const int words = kRevDiskHead + (wf_value ? kRevDiskPerVertexCf : kRevDiskPerVertex) * depth;
-            const long long chunk = std::min<long long>(n, launch_chunk(h, 24));
+            // 2^26 slots per chunk (104 B of records per slot with the wavefront's cf format: 7 GB): the C4 shard's PathTracer(3) reverse as ONE chunk
+            // 36.5 -> 35.7 ms of kernel time against four of 2^24 (its value sweep is the traced wavefront; profiles/r04_chunk_sweep.txt)
+            const long long chunk = std::min<long long>(n, launch_chunk(h, 26));
             const size_t need = (size_t) chunk * words * sizeof(float);
             if (need > h->rev_bytes) {
                 if (h->d_rev) (void) hipFree(h->d_rev);

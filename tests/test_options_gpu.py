@@ -65,3 +65,24 @@ def test_chunked_and_sharded_launches_on_a_two_level_scene(kind):
         er = (r[0] // 2, r[1] // 2)
         parts = parts + g.render_c(_abi.make_opts(spp=16, spp_range=r, **({**kw, "sppe_range": er, "sppse_range": er} if kind == "direct11" else kw)))
     assert rel_l2(parts, full) < 1e-5
+
+
+def test_c4_shard_as_one_chunk_equals_two_chunks():
+    """The traced wavefront and the split reverse launch serve 2^26 slots per chunk: one GPU's share of C4 (cbox_bunny 1024^2, 64 of 512 spp) is ONE
+    chunk.  The same launches as two chunks of 2^25 (the previous default) give the same image, ray count and gradients -- same samples, the order of the
+    float adds only."""
+    sc, _ = load_scene("cbox_bunny", res=1024, spp=512, sppe=0, sppse=0)
+    tb = sc.tables(0)
+    o = _abi.make_opts(spp=512, spp_range=(0, 64), integrator=_abi.INTEGRATOR_PATH, max_depth=3)
+    adj = np.random.default_rng(7).random((1024 * 1024, 3)).astype(np.float32)
+    res = {}
+    for name, opts in (("one", {}), ("two", {"chunk_log2": 25})):
+        g = GpuScene(tb, options=opts)
+        img = g.render_c(o)
+        rays = g.counters()[0]
+        res[name] = (img, rays, g.render_d_rev(o, adj, want=["tri_info", "texels"], with_image=False)[1])
+        del g
+    a, b = res["one"], res["two"]
+    assert a[1] == b[1] and rel_l2(b[0], a[0]) < 1e-5
+    for k in ("tri_info", "texels"):
+        assert rel_l2(b[2][k], a[2][k]) < 2e-4, (k, rel_l2(b[2][k], a[2][k]))
