@@ -1213,6 +1213,9 @@ inline int camera_blocks_per_cu(const psdr_scene_s *h, long long n) {
 }
 // slots per chunk of the launches that keep per-slot state between kernels (wavefront streams, reverse-mode records, probe buffers): 2^log2_default,
 // or what psdr_scene_set_option("chunk_log2", ...) says (tests: chunk boundaries on small scenes)
+// workgroups per CU of the large launches that measured faster on a finer grid (traced wavefront stages, primary-edge reverse kernel, secondary-edge filter of a
+// two-level scene): 16, up to 40 where a workgroup still makes >= 8 trips of its grid-stride loop (profiles/r04_wf_grid_abk.txt)
+inline int big_launch_per_cu(const psdr_scene_s *h, long long n) { return (int) std::max(16LL, std::min(40LL, n / ((long long) kBlock * h->num_cus * 8))); }
 inline long long launch_chunk(const psdr_scene_s *h, int log2_default) { return 1ll << (h->opt.chunk_log2 > 0 ? h->opt.chunk_log2 : log2_default); }
 // DirectIntegrator(1, 1) camera launches on a two-level scene run as probe pass + dense trace kernel + final pass (from 2^16 slots)
 inline bool probe_direct(const psdr_scene_s *h, const psdr_render_opts *o, long long n) {
@@ -1304,7 +1307,11 @@ int run_camera_wavefront(psdr_scene_s *h, const psdr_render_opts *o, const TV<M,
     const size_t words = 8 + 6 * (1 + K) + (traced ? 8 : 0);          // traced: + the two hit rows of a record
     // plain: block b appends to sub-stream b % kWfSub, at most ceil(blocks / kWfSub) * trips * kBlock records each.
     // binned: the records of chunk c go to group c % kWfGroups of their class; a class can take all of a group
-    const long long max_blocks = ((long long) launch_blocks(h, cap) + kWfSub - 1) / kWfSub * kWfSub;   // >= the grid of any chunk
+    // grid of the traced wavefront's stage kernels: 16 workgroups per CU, up to 40 where a workgroup still makes >= 8 trips of its grid-stride loop (finer
+    // workgroups balance the stages' uneven records better: C4 shard, 2^26 slots, 13.99 -> 13.45 ms of kernel time at 40, 13.59 at 24, 13.65 at 80; C5's
+    // 2^22 slots are best at 10-16 and 9 % slower at 40 -- profiles/r04_wf_grid_abk.txt)
+    const auto wf_per_cu = [&](long long slots) { return traced ? big_launch_per_cu(h, slots) : 16; };
+    const long long max_blocks = ((long long) launch_blocks(h, cap, wf_per_cu(cap)) + kWfSub - 1) / kWfSub * kWfSub;   // >= the grid of any chunk
     const long long binned_sub_cap = (((cap + kBlock - 1) / kBlock + kWfSub) / kWfGroups + 2) * kBlock;
     const long long cap_alloc = ((binned ? binned_sub_cap * kWfSub : cap + max_blocks * kBlock) + 63) / 64 * 64;      // the hit rows are float4
     const size_t cnt_ints = (size_t) (kWfMaxDepth + 1) * kWfStageInts + (traced ? (size_t) (kWfMaxDepth + 1) * kWfSub * kWfCountStride : 0);
@@ -1340,7 +1347,7 @@ int run_camera_wavefront(psdr_scene_s *h, const psdr_render_opts *o, const TV<M,
         if (int rc = make_ctx(h, o, 0, cx)) return rc;
         HIP_TRY(hipMemsetAsync(cnt, 0, (size_t) (std::min(depth, kWfMaxDepth) + 1) * kWfStageInts * sizeof(int32_t), s));
         if (traced) HIP_TRY(hipMemsetAsync(req_cnt, 0, (size_t) (std::min(depth, kWfMaxDepth) + 1) * kWfSub * kWfCountStride * sizeof(int32_t), s));
-        const int blocks = (launch_blocks(h, cn) + kWfSub - 1) / kWfSub * kWfSub;
+        const int blocks = (launch_blocks(h, cn, wf_per_cu(cn)) + kWfSub - 1) / kWfSub * kWfSub;
         const long long trips = (cn + (long long) blocks * kBlock - 1) / ((long long) blocks * kBlock);
         st[0].sub_cap = st[1].sub_cap = binned ? binned_sub_cap : (blocks / kWfSub) * trips * kBlock;
         st[0].count = cnt;
@@ -1444,7 +1451,7 @@ int secondary_edge_filter(psdr_scene_s *h, const LaunchCtx &cx, long long i0, lo
             hipLaunchKernelGGL(k_se_probe<FL>, dim3(blocks), dim3(kBlock), cxp.off_stack, s, cxp, i0, n, tq, pb.mask);
             HIP_TRY(hipGetLastError());
             if (int rc = launch_wf_trace(h, pb.req, pb.count, pb.sub_cap, pb.hit, s, true)) return rc;
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_secondary_edge_filter<FL | kScenePre>), dim3(launch_blocks(h, n)), dim3(kBlock), cxp.off_stack, s, cxp, i0, n, lst, cnt, h->d_counters,
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_secondary_edge_filter<FL | kScenePre>), dim3(launch_blocks(h, n, big_launch_per_cu(h, n))), dim3(kBlock), cxp.off_stack, s, cxp, i0, n, lst, cnt, h->d_counters,
                                ProbeView{pb.hit, pb.mask});
             HIP_TRY(hipGetLastError());
             *list = lst; *list_n = cnt;
@@ -1681,7 +1688,7 @@ int render_rev(psdr_scene_s *h, const psdr_render_opts *o, const float *adj_img,
         const uint32_t *order = nullptr;
         if (int rc = primary_edge_order(h, cx, i0, n, &order, s)) return rc;
 #define PSDR_LAUNCH_PER(INTEG)                                                                                                       \
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_primary_edge_rev<FL, INTEG>), dim3(launch_blocks(h, n)), dim3(kBlock), lds_bytes(cx, h), s, cx, pe_sink, i0, n, \
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_primary_edge_rev<FL, INTEG>), dim3(launch_blocks(h, n, big_launch_per_cu(h, n))), dim3(kBlock), lds_bytes(cx, h), s, cx, pe_sink, i0, n, \
                            1.f / (float) o->sppe, adj_img, h->d_counters, order)
         switch (o->integrator) {
             case PSDR_INTEGRATOR_DIRECT: PSDR_LAUNCH_PER(PSDR_INTEGRATOR_DIRECT); break;
