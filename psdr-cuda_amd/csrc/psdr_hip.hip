@@ -869,9 +869,9 @@ int launch_wf_trace(psdr_scene_s *h, const float4 *req, const int32_t *count, lo
 }
 
 // hit rows [slots * rays_per_slot], one mask word per slot, the request queue (64 sub-queues, every ray can be a request) and its counters (zeroed here)
-int probe_buffers(psdr_scene_s *h, long long slots, int rays_per_slot, ProbeBuffers &pb, hipStream_t s) {
+int probe_buffers(psdr_scene_s *h, long long slots, int rays_per_slot, ProbeBuffers &pb, hipStream_t s, int per_cu) {
     const long long rays = slots * rays_per_slot;
-    const long long blocks = ((long long) launch_blocks(h, slots) + kWfSub - 1) / kWfSub * kWfSub;
+    const long long blocks = ((long long) launch_blocks(h, slots, per_cu) + kWfSub - 1) / kWfSub * kWfSub;
     const long long trips = (slots + blocks * kBlock - 1) / (blocks * kBlock);
     pb.sub_cap = (blocks / kWfSub) * trips * kBlock * rays_per_slot;          // block b appends to queue b % kWfSub
     const size_t cnt_bytes = (size_t) kWfSub * kWfCountStride * sizeof(int32_t);

@@ -276,7 +276,7 @@ bool traced_wavefront(const psdr_scene_s *h);
 int launch_wf_trace(psdr_scene_s *h, const float4 *req, const int32_t *count, long long sub_cap, float4 *hit, hipStream_t s, bool ign = false);
 // Probe / final launches of the fused kernels on two-level scenes (psdr_kernels.h): the buffers between the probe pass, the trace kernel and the final pass
 struct ProbeBuffers { float4 *hit; uint32_t *mask; float4 *req; int32_t *count; long long sub_cap; };
-int probe_buffers(psdr_scene_s *h, long long slots, int rays_per_slot, ProbeBuffers &pb, hipStream_t s);
+int probe_buffers(psdr_scene_s *h, long long slots, int rays_per_slot, ProbeBuffers &pb, hipStream_t s, int per_cu = 16);   // per_cu: workgroups per CU of the probe launch (sizes the request queues)
 SinkLayout make_sink_layout(const psdr_scene_s *h, const psdr_grads *g);
 inline int sink_bytes(const SinkLayout &L) { return (L.priv_rows > 0 && !L.priv_regs) ? (L.priv_off + kPrivWords * kBlock) * 4 : (L.rep * L.stride * 4 + 15) / 16 * 16; }
 int check_counts(const psdr_scene_s *h, const psdr_render_opts *o);

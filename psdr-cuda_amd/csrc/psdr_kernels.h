@@ -1245,9 +1245,10 @@ int run_camera(psdr_scene_s *h, const psdr_render_opts *o, const TV<R, FL> &tv, 
             for (long long c0 = 0; c0 < n; c0 += chunk) {
                 const long long nc = std::min(chunk, n - c0);
                 ProbeBuffers pb;
-                if (int rc = probe_buffers(h, nc, 3, pb, s)) return rc;
+                const int probe_per_cu = big_launch_per_cu(h, nc);          // k_direct_probe 951 -> 879 us at 40 per CU on the C4 shard (profiles/r04_wf_grid_abk.txt)
+                if (int rc = probe_buffers(h, nc, 3, pb, s, probe_per_cu)) return rc;
                 const TraceQueue tq{pb.req, pb.count, pb.sub_cap};
-                const int blocks = (launch_blocks(h, nc) + kWfSub - 1) / kWfSub * kWfSub;
+                const int blocks = (launch_blocks(h, nc, probe_per_cu) + kWfSub - 1) / kWfSub * kWfSub;
                 hipLaunchKernelGGL(k_direct_probe<FL>, dim3(blocks), dim3(kBlock), lds_bytes(cx, h), s, cx, tv0, o->spp, o->spp_begin, SlotDiv(nsp), c0, nc, tq, pb.hit, pb.mask,
                                    make_rng_jump(o->rng_offset[0] + 2));
                 HIP_TRY(hipGetLastError());
@@ -1638,9 +1639,10 @@ int render_rev(psdr_scene_s *h, const psdr_render_opts *o, const float *adj_img,
                 for (long long c0 = 0; c0 < n; c0 += chunk) {
                     const long long nc = std::min(chunk, n - c0);
                     ProbeBuffers pb;
-                    if (int rc = probe_buffers(h, nc, 3, pb, s)) return rc;
+                    const int probe_per_cu = big_launch_per_cu(h, nc);
+                    if (int rc = probe_buffers(h, nc, 3, pb, s, probe_per_cu)) return rc;
                     const TraceQueue tq{pb.req, pb.count, pb.sub_cap};
-                    const int blocks = (launch_blocks(h, nc) + kWfSub - 1) / kWfSub * kWfSub;
+                    const int blocks = (launch_blocks(h, nc, probe_per_cu) + kWfSub - 1) / kWfSub * kWfSub;
                     hipLaunchKernelGGL(k_direct_probe<FL>, dim3(blocks), dim3(kBlock), lds_bytes(cxf, h), s, cxf, tv0, o->spp, o->spp_begin, SlotDiv(nsp), c0, nc, tq, pb.hit, pb.mask,
                                        make_rng_jump(o->rng_offset[0] + 2));
                     HIP_TRY(hipGetLastError());
