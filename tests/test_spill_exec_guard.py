@@ -60,3 +60,37 @@ def test_product_library_is_free_of_the_defect():
     cos = cse.code_objects(lib)
     assert len(cos) >= 10                               # eight flag sets + the host unit + the table chain
     assert cse.check_library(lib, verbose=True) == []
+
+
+def test_guard_fails_closed_when_it_cannot_look(tmp_path, monkeypatch):
+    """a library without a readable code object, a failing objdump or an unparsable disassembly is an ERROR, never "0 hits"."""
+    import pytest
+    # (1) no gfx code object in the file (e.g. a compressed bundle this reader does not unpack)
+    empty = tmp_path / "nothing.o"
+    empty.write_bytes(b"\x7fELF" + b"\0" * 64 + b"CCOB" + b"\0" * 64)
+    with pytest.raises(cse.GuardError, match="code object"):
+        cse.check_library(str(empty), verbose=False)
+    # (2) fewer code objects than the caller knows the library must hold
+    lib = os.path.join(ROOT, "psdr-cuda_amd", "lib", "libpsdr_hip.so")
+    with pytest.raises(cse.GuardError):
+        cse.check_library(lib, verbose=False, min_code_objects=10 ** 6)
+    # (3) objdump fails
+    co = cse.code_objects(lib)[0]
+    bad = tmp_path / "objdump"
+    bad.write_text("#!/bin/sh\nexit 3\n"); bad.chmod(0o755)
+    monkeypatch.setattr(cse, "find_objdump", lambda: str(bad))
+    with pytest.raises(cse.GuardError, match="failed"):
+        cse._scan_code_object(co)
+    # (4) objdump succeeds but prints nothing the scanner understands
+    mute = tmp_path / "objdump2"
+    mute.write_text("#!/bin/sh\necho file format elf64-amdgpu\n"); mute.chmod(0o755)
+    monkeypatch.setattr(cse, "find_objdump", lambda: str(mute))
+    with pytest.raises(cse.GuardError, match="nothing parsed"):
+        cse._scan_code_object(co)
+
+
+def test_objdump_is_found_through_the_toolchain_not_a_fixed_path(monkeypatch):
+    p = cse.find_objdump()
+    assert os.path.isfile(p) and os.access(p, os.X_OK)
+    monkeypatch.setenv("ROCM_PATH", "/nonexistent")          # falls through to hipcc's tree / the default root
+    assert os.path.isfile(cse.find_objdump())

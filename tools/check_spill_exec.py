@@ -8,10 +8,32 @@ stale data of earlier kernels otherwise): a result that depends on the history o
 The check disassembles every gfx950 code object of the library and reports each `s_or_b64 exec, exec, s[..]` that (a) starts a basic block or
 follows only SGPR-spill / spill-store instructions from the start of one and (b) has a `scratch_store` between the block start and itself.
 usage: check_spill_exec.py <lib.so | dir of .s files> ; exit status 1 when a kernel is hit."""
-import os, re, struct, subprocess, sys, tempfile
+import os, re, shutil, struct, subprocess, sys, tempfile
 
-OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
 MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
+
+
+class GuardError(RuntimeError):
+    """The guard could not LOOK (no disassembler, no code object, objdump failed, nothing parsed): never the same thing as "0 hits"."""
+
+
+def find_objdump():
+    """llvm-objdump of the toolchain that built the library: $ROCM_PATH, the directory tree hipcc lives in, /opt/rocm, then PATH."""
+    roots = [os.environ.get("ROCM_PATH"), os.environ.get("HIP_PATH")]
+    hipcc = shutil.which("hipcc")
+    if hipcc:
+        roots.append(os.path.dirname(os.path.dirname(os.path.realpath(hipcc))))
+    roots.append("/opt/rocm")
+    for r in roots:
+        if r:
+            for rel in ("lib/llvm/bin/llvm-objdump", "llvm/bin/llvm-objdump", "bin/llvm-objdump"):
+                c = os.path.join(r, rel)
+                if os.path.isfile(c) and os.access(c, os.X_OK):
+                    return c
+    c = shutil.which("llvm-objdump")
+    if c:
+        return c
+    raise GuardError("check_spill_exec: no llvm-objdump found (ROCM_PATH, hipcc's tree, /opt/rocm, PATH)")
 
 
 def code_objects(path):
@@ -128,15 +150,29 @@ def scan_asm(text):
 
 
 def _scan_code_object(co):
+    objdump = find_objdump()
     with tempfile.NamedTemporaryFile(suffix=".co") as f:
         f.write(co); f.flush()
-        text = subprocess.run([OBJDUMP, "-d", f.name], capture_output=True, text=True).stdout
-    return scan_disassembly(text)
+        r = subprocess.run([objdump, "-d", f.name], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise GuardError("check_spill_exec: %s -d failed (rc %d): %s" % (objdump, r.returncode, r.stderr.strip()[:400]))
+    # a code object that holds kernels must yield kernel symbols and instructions; an empty parse means the output format changed under the scanner
+    n_sym = len(re.findall(r"^[0-9a-f]+ <.+>:", r.stdout, re.M))
+    n_ins = len(re.findall(r"^\s+\S.*?//\s*[0-9A-Fa-f]+:", r.stdout, re.M))
+    if n_sym == 0 or n_ins == 0:
+        raise GuardError("check_spill_exec: nothing parsed from the disassembly of a %d-byte code object (%d symbols, %d instructions)" % (len(co), n_sym, n_ins))
+    return scan_disassembly(r.stdout)
 
 
-def check_library(path, verbose=True):
+def check_library(path, verbose=True, min_code_objects=1):
+    """Raises GuardError when the library cannot be inspected (fails CLOSED): no gfx code object found in `path` (e.g. a compressed 'CCOB' bundle
+    this reader does not unpack), fewer than `min_code_objects`, a failing objdump, or a disassembly without kernel symbols."""
     from concurrent.futures import ThreadPoolExecutor
     cos = code_objects(path)
+    if len(cos) < max(1, min_code_objects):
+        raw = open(path, "rb").read()
+        hint = " (compressed offload bundle 'CCOB' present: build with --no-offload-compress)" if b"CCOB" in raw else ""
+        raise GuardError("check_spill_exec: %s holds %d gfx code object(s), expected >= %d%s" % (path, len(cos), max(1, min_code_objects), hint))
     with ThreadPoolExecutor(max_workers=min(8, max(1, len(cos)))) as ex:
         res = list(ex.map(_scan_code_object, cos))
     hits = [(n,) + x for n, h in enumerate(res) for x in h]
