@@ -226,9 +226,12 @@ int psdr_scene_create(psdr_scene_t *out);
 int psdr_scene_destroy(psdr_scene_t h);
 /* Developer options of a handle -- the A/B switches of tools and tests (the reference has none: its strategies are fixed by OptiX and
    Enoki); the library reads NO environment variable.  Names (value): bvh_refit, tiny_scene, two_level, wf_binned, wf_traced, sort_edges,
-   tiny_variants, sink_private (0 / 1); bvh_build (1 device, 0 host, -1 by size); wide (0: never the 4-wide tree in the render kernels);
-   rev_split, sedge_split (1 / 0 force, -1 default rule); probe (0: no probe / trace / final launches); chunk_log2 (slots per chunk of the chunked launches, 0 = default); blocks_per_cu, camera_blocks, lds_budget, sink_rep, bvh_maxleaf (integers, 0 =
-   default where that makes sense); bvh_tcost (float).  Unknown names fail.  Options that change the tree take effect at the next psdr_bvh_build. */
+   tiny_variants, sink_private, aa_prims (0 / 1); bvh_build (1 device, 0 host, -1 by size); wide (0: never the 4-wide tree in the render kernels);
+   rev_split, sedge_split (1 / 0 force, -1 default rule); rev_vertex (1: the adjoint sweep of a split PathTracer launch as one launch per path
+   vertex, 0 default: one adjoint kernel); vrev_blocks (workgroups per CU of those launches); probe (0: no probe / trace / final launches);
+   trace_wg2 (dense trace kernel as two workgroups per CU: -1 by forest and launch size, 0 never, n > 0 always with stack columns of n entries);
+   chunk_log2 (slots per chunk of the chunked launches, 0 = default); blocks_per_cu, camera_blocks, lds_budget, sink_rep, bvh_maxleaf (integers,
+   0 = default where that makes sense); bvh_tcost (float).  Unknown names fail.  Options that change the tree take effect at the next psdr_bvh_build. */
 int psdr_scene_set_option(psdr_scene_t h, const char *name, double value);
 
 /* Replaces the table-publishing tail of Scene::configure (scene.cpp:199-244):

@@ -954,6 +954,8 @@ int psdr_scene_set_option(psdr_scene_t h, const char *name, double value) {
     else if (n == "sink_rep") h->opt.sink_rep = std::max(1, std::min(16, iv));
     else if (n == "sink_private") h->opt.sink_private = iv;
     else if (n == "rev_split") h->opt.rev_split = iv;
+    else if (n == "rev_vertex") h->opt.rev_vertex = iv;                  // 1: the adjoint sweep of a split PathTracer launch as a launch per path vertex (default 0: one adjoint kernel)
+    else if (n == "vrev_blocks") h->opt.vrev_blocks = iv;                // workgroups per CU of the per-vertex adjoint launches (0: default)
     else if (n == "sedge_split") h->opt.sedge_split = iv;
     else if (n == "probe") h->opt.probe = iv;
     else if (n == "trace_wg2") h->opt.trace_wg2 = iv;                    // dense trace kernel as two workgroups per CU: -1 by forest and launch size, 0 never, n > 0 always (stack columns of n entries)

@@ -154,6 +154,9 @@ struct psdr_scene_options {
     int sink_rep = 4;                      // copies of the LDS gradient cache at most
     int sink_private = 1;                  // lane-private accumulators for the emitter's rows
     int rev_split = -1;                    // reverse mode as value kernel + adjoint kernel: 1 / 0 force, -1 by scene and launch size
+    int rev_vertex = 0;                    // 1: adjoint sweep of a split PathTracer launch as one launch per path vertex (k_vertex_rev, round 5: built, measured SLOWER than the
+                                           // one adjoint kernel on C2 / C4 / C5 -- DESIGN.md round 5 -- and kept as an option); 0: one adjoint kernel
+    int vrev_blocks = 0;                   // workgroups per CU of those launches (0: 16)
     int sedge_split = -1;                  // secondary-edge term as filter + survivor kernel: 1 / 0 force, -1 from 2^18 slots
     int chunk_log2 = 0;                    // log2 of the slots per chunk of the chunked launches (0: 2^24 / 2^25, the traced wavefront 2^26)
     int probe = 1;                         // two-level scenes: fused kernels as probe pass + dense trace kernel + final pass where that is built (0: one kernel)

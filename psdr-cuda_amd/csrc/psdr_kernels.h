@@ -1130,6 +1130,150 @@ __global__ __launch_bounds__(kBlock, (STAGE == 1 ? PSDR_WAVES_REV_VALUE : rev_wa
     count_rays(counters, nrays);
 }
 
+// ---- adds of a whole wave SORTED BY KEY (convergent points only: all 64 lanes call).  An LDS float add costs ~3 cycles per ACTIVE LANE whatever the
+// addresses (tools/micro/lds_atomics2.hip), and the lanes of a wave land on a handful of rows (the walls of a room): the lanes are ranked by key
+// (one ballot per distinct key), values travel to their rank with ds_permute, a segmented scan inside every row of 16 lanes (four v_fmac with DPP
+// row_shr operands, masks computed once per key set) leaves each run's total in its last lane, and only those lanes add -- one LDS add per run of
+// equal keys and row of 16 instead of one per lane.
+template <int CTRL> __device__ __forceinline__ int dpp_mov_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
+template <int CTRL> __device__ __forceinline__ float dpp_mov_f(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true)); }
+struct WaveSort {
+    int to_bytes;          // this lane's entry travels to lane to_bytes / 4
+    int skey;              // key + 1 of the entry that arrived here (0: none)
+    float m1, m2, m4, m8;  // 1: the lane 1 / 2 / 4 / 8 to the left (same row of 16) holds the same key
+    bool tail;             // last lane of a run: it holds the run's total after the scan
+    __device__ __forceinline__ float total(float v) const {
+        float s = __int_as_float(__builtin_amdgcn_ds_permute(to_bytes, __float_as_int(v)));
+        s = fmaf(dpp_mov_f<0x111>(s), m1, s); s = fmaf(dpp_mov_f<0x112>(s), m2, s); s = fmaf(dpp_mov_f<0x114>(s), m4, s); s = fmaf(dpp_mov_f<0x118>(s), m8, s);
+        return s;
+    }
+};
+// key >= 0: this lane has an entry; the caller checked that at least one lane does
+__device__ __forceinline__ WaveSort wave_sort_keys(int key) {
+    const int lane = threadIdx.x & 63;
+    const unsigned long long part = __ballot(key >= 0), below = (1ull << lane) - 1ull;
+    unsigned long long rem = part;
+    int rank = 0, base = 0;
+    while (rem) {
+        const int t = __builtin_amdgcn_readlane(key, __ffsll((long long) rem) - 1);
+        const unsigned long long same = __ballot(key == t);
+        if (key == t) rank = base + (int) __popcll(same & below);
+        base += (int) __popcll(same);
+        rem &= ~same;
+    }
+    if (key < 0) rank = base + (int) __popcll(~part & below);                 // a full permutation: the lanes without an entry fill the tail
+    WaveSort ws;
+    ws.to_bytes = rank << 2;
+    ws.skey = __builtin_amdgcn_ds_permute(ws.to_bytes, key + 1);
+    const int k = ws.skey;
+    ws.m1 = (k != 0 && dpp_mov_i<0x111>(k) == k) ? 1.f : 0.f; ws.m2 = (k != 0 && dpp_mov_i<0x112>(k) == k) ? 1.f : 0.f;
+    ws.m4 = (k != 0 && dpp_mov_i<0x114>(k) == k) ? 1.f : 0.f; ws.m8 = (k != 0 && dpp_mov_i<0x118>(k) == k) ? 1.f : 0.f;
+    ws.tail = k != 0 && dpp_mov_i<0x101>(k) != k;                              // row_shl:1 -- the lane to the right (0 at the end of a row of 16)
+    return ws;
+}
+// One complete row adjoint per lane (tri < 0: none): position at (u, v), face normal, area -- the 13 words of scatter_row.
+template <class S> __device__ __forceinline__ void sink_add_row_wave(S &sink, int tri, float u, float v, const RowAdj &r) {
+    bool valid = tri >= 0 && sink.g.g_tri_info != nullptr;
+    if (__ballot(valid) == 0ull) return;
+    const Vec3f p{S::finite(r.p.x), S::finite(r.p.y), S::finite(r.p.z)}, fn{S::finite(r.fn.x), S::finite(r.fn.y), S::finite(r.fn.z)};
+    const float area = S::finite(r.area);
+    if (valid && sink.add_row(tri, u, v, p, fn, area)) valid = false;          // the emitter's rows: lane-private accumulators
+    int slot = -1;
+    if (valid) {
+        if constexpr ((S::flags & kSceneTiny) != 0 && PSDR_TINY_DIRECT_ROWS) slot = tri;
+        else { slot = sink.L.hot_rows ? sink.L.hot_map[tri] : -1; if (slot >= sink.L.hot_rows) slot = -1; }
+    }
+    const float w[kPrivRowWords] = {p.x, p.y, p.z, u * p.x, u * p.y, u * p.z, v * p.x, v * p.y, v * p.z, fn.x, fn.y, fn.z, area};
+    if (valid && slot < 0) {
+        // a row outside the cache (the triangles of the large meshes): one hardware atomic per word, as DeviceSink::add_tri
+#pragma unroll
+        for (int i = 0; i < kPrivRowWords; ++i) if (w[i] != 0.f) atomicAdd(sink.g.g_tri_info + (size_t) tri * PSDR_TRI_STRIDE + (i < 9 ? i : i + 9), w[i]);
+    }
+    if (__ballot(slot >= 0) == 0ull) return;
+    const WaveSort ws = wave_sort_keys(slot);
+    typename S::lds_float *row = sink.lds + sink.L.hot_off + (ws.skey - 1) * PSDR_TRI_STRIDE;
+#pragma unroll
+    for (int i = 0; i < kPrivRowWords; ++i) {
+        const float t = ws.total(slot >= 0 ? w[i] : 0.f);
+        if (ws.tail && t != 0.f) S::lds_add(row + (i < 9 ? i : i + 9), t);
+    }
+}
+// The adjoint of one RGB texel per lane (key = its index in the texel pool; < 0: none).
+template <class S> __device__ __forceinline__ void sink_add_texel3_wave(S &sink, int key, const float (&tex)[3]) {
+    if (sink.g.g_texels == nullptr) return;
+    const bool valid = key >= 0;
+    if (__ballot(valid) == 0ull) return;
+    if (!sink.L.tex_n) {
+        if (valid) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) if (S::ok(tex[c])) atomicAdd(sink.g.g_texels + key + c, tex[c]);
+        }
+        return;
+    }
+    const WaveSort ws = wave_sort_keys(valid ? key : -1);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float t = ws.total(valid ? S::finite(tex[c]) : 0.f);
+        if (ws.tail && t != 0.f) S::lds_add(sink.lds + sink.L.tex_off + (ws.skey - 1) + c, t);
+    }
+}
+
+// The adjoint sweep of a split PathTracer launch, ONE PATH VERTEX PER LAUNCH (psdr_reverse.h vertex_reverse_first / _next): launch k
+// reads the value sweep's record and the state column the launch of vertex k - 1 left, hands its row / texel adjoints to the sorted adds above and
+// writes the state of vertex k + 1.  No path record in LDS, no traversal, no loop over the path: the live state is one vertex.
+//   KIND 0: primary vertex; 1: vertex k >= 1 (and the pending rows of the paths that ended at vertex k - 1); 2: the position adjoint vertex 1 sends back
+//   through the primary vertex' Moeller-Trumbore / camera chain (primary_position_reverse).
+#ifndef PSDR_WAVES_VREV
+#define PSDR_WAVES_VREV 3
+#endif
+#ifndef PSDR_WAVES_VREV_NEXT
+#define PSDR_WAVES_VREV_NEXT 3
+#endif
+#ifndef PSDR_VREV_REG_PRIV
+#define PSDR_VREV_REG_PRIV 1
+#endif
+template <int FL> constexpr bool vrev_reg_priv() { return PSDR_VREV_REG_PRIV && reg_priv_kernel<FL, true, PSDR_INTEGRATOR_PATH>(); }
+template <int FL, int KIND> constexpr int vrev_waves() { return KIND == 2 ? 4 : (KIND == 1 ? PSDR_WAVES_VREV_NEXT : PSDR_WAVES_VREV); }
+template <int FL, int KIND>
+__global__ __launch_bounds__(kBlock, (vrev_waves<FL, KIND>())) void k_vertex_rev(LaunchCtx cx, DeviceSink<FL> sink_arg, int spp, int s_begin, SlotDiv nsp, long long j0, long long n, float inv_spp,
+                                                                                const float *__restrict__ adj_img, float *__restrict__ disk, long long stride, float *__restrict__ state,
+                                                                                int k, int suffix) {
+    TraversalStack st; setup_lds(cx, st);
+    typename std::conditional<vrev_reg_priv<FL>() && KIND != 2, RegPrivSink<FL>, DeviceSink<FL> &>::type sink(sink_arg);
+    sink.begin(dyn_lds_floats(cx.off_sink));
+    const long long nceil = (n + kBlock - 1) / kBlock * kBlock;
+    for (long long jj = (long long) blockIdx.x * kBlock + threadIdx.x; jj < nceil; jj += (long long) gridDim.x * kBlock) {
+        const bool in = jj < n;
+        PrimaryGrad pg; pg.clear();
+        PendingScatter ps; ps.clear();
+        if (in) {
+            int pixel, s_in;
+            slot_to_pixel(j0 + jj, nsp, pixel, s_in);
+            const uint64_t slot = (uint64_t) pixel * (uint64_t) spp + (uint64_t) (s_begin + s_in);
+            const RevDisk dk{disk + jj, stride, 0}, sk{state + jj, stride, 0};
+            if constexpr (KIND == 2) primary_position_reverse(sink, pg, cx.sc, cx.jump, pixel, slot, dk, sk);
+            else {
+                const float *a = adj_img + (size_t) pixel * 3;
+                const Vec3f adj{a[0] * inv_spp, a[1] * inv_spp, a[2] * inv_spp};
+                if constexpr (KIND == 0) vertex_reverse_first(sink, pg, ps, cx.sc, st, cx.lp, cx.jump, pixel, slot, adj, dk, sk, suffix != 0);
+                else vertex_reverse_next(sink, ps, cx.sc, st, cx.jump, slot, adj, dk, sk, k);
+            }
+        }
+        // every lane of the wave is here: the primary-triangle row (lanes share their pixel: one add per run of lanes on the same triangle) ...
+        if (KIND != 1 && sink.g.g_tri_info != nullptr) {
+            const bool head = wave_run_sum<kPrimaryWords, (FL & kSceneRough) == 0 || PSDR_DPP_ALWAYS>(pg.tri, pg.w);
+            if (head && pg.tri >= 0) {
+#pragma unroll
+                for (int w = 0; w < kPrimaryWords; ++w) sink.add_tri(pg.tri, w, pg.w[w]);
+            }
+        }
+        // ... and the rows / the texel the launch completed, sorted by row
+        if constexpr (KIND == 1) { sink_add_row_wave(sink, ps.a_tri, ps.a_u, ps.a_v, ps.a); sink_add_row_wave(sink, ps.b_tri, ps.b_u, ps.b_v, ps.b); }
+        if constexpr (KIND != 2) sink_add_texel3_wave(sink, ps.tex_key, ps.tex);
+    }
+    sink.end();
+}
+
 // The primary-edge term only produces gradients of the edge table (the two Li values are detached): a sink
 // without the LDS gradient cache, so the kernel is not held at 2 workgroups per CU by 24 KB of static LDS.
 // The long edges of a scene (the box walls) take most of the length-weighted samples, the slots are pixel-sorted, so wave after wave
@@ -1550,6 +1694,8 @@ int render_rev(psdr_scene_s *h, const psdr_render_opts *o, const float *adj_img,
         // large tree (3.8 -> 3.3 ms; bunny scenes 2.0 -> 2.4); the 12-triangle box neither way
         const bool worth = o->integrator == PSDR_INTEGRATOR_PATH ? o->max_depth >= 2 : h->num_nodes >= 16384;
         const bool split = geo && replayable && split_env != 0 && (split_env == 1 || (has_tree && worth && n >= (1ll << 20)));
+        // adjoint sweep of a split PathTracer launch vertex by vertex (k_vertex_rev): psdr_scene_set_option("rev_vertex", 0) keeps the one adjoint kernel
+        const bool vrev = split && o->integrator == PSDR_INTEGRATOR_PATH && h->opt.rev_vertex != 0;
         // adjoint kernel of a split launch: nothing of the tree staged, no stacks -- only what plan_lds places without any room (the hit rows of
         // the kernel-argument primitives and the small tables of the two-level / tiny instances, Tab<FL>::lds_small), then record and cache
         // the PathTracer's geometry-adjoint kernels keep the lane-private emitter accumulators in registers (RegPrivSink): no LDS block, never switched off
@@ -1589,12 +1735,13 @@ int render_rev(psdr_scene_s *h, const psdr_render_opts *o, const float *adj_img,
         // wavefront: 16 ms)
         bool wf_value = false;
         if constexpr ((FL & kSceneForest) != 0) wf_value = split && !no_tree && o->integrator == PSDR_INTEGRATOR_PATH && !deep_rec && traced_wavefront(h) && use_wavefront(h, o);
-        const int disk_cf = wf_value ? 1 : 0;
+        const int disk_cf = wf_value ? 1 : (vrev ? 2 : 0);
         bool direct_probe = false;
         if constexpr ((FL & kSceneForest) != 0) direct_probe = !split && !no_tree && o->integrator == PSDR_INTEGRATOR_DIRECT && probe_direct(h, o, n);
         if (split) {
             // records of one chunk of slots live in a scratch buffer (2 + 5 depth words per slot; 2 + 8 depth from the wavefront); chunks bound its size
-            const int words = kRevDiskHead + (wf_value ? kRevDiskPerVertexCf : kRevDiskPerVertex) * depth;
+            const int rec_words = kRevDiskHead + ((wf_value || vrev) ? kRevDiskPerVertexCf : kRevDiskPerVertex) * depth;
+            const int words = rec_words + (vrev ? kRevStateWords : 0);       // + the state column the per-vertex adjoint launches hand on
             // 2^26 slots per chunk (104 B of records per slot with the wavefront's cf format: 7 GB): the C4 shard's PathTracer(3) reverse as ONE chunk
             // 36.5 -> 35.7 ms of kernel time against four of 2^24 (its value sweep is the traced wavefront; profiles/r04_chunk_sweep.txt)
             const long long chunk = std::min<long long>(n, launch_chunk(h, 26));
@@ -1617,6 +1764,26 @@ int render_rev(psdr_scene_s *h, const psdr_render_opts *o, const float *adj_img,
                         }
                     } else
                     PSDR_LAUNCH_REV_K(true, PSDR_INTEGRATOR_PATH, 1, cx, dyn1, c0, nc, out_img, disk, chunk);
+                    if (vrev) {
+                        // launch k = the adjoint of path vertex k (psdr_reverse.h vertex_reverse_first / _next): record + state column in, state column out
+                        LaunchCtx cxv = cx2;
+                        cxv.off_sink = no_tree ? cx.off_pathrec : base2;             // no path record in LDS: the gradient cache starts where it would
+                        const int dyn_v = cxv.off_sink + cache_bytes;
+                        float *state = disk + (size_t) rec_words * chunk;
+                        const int vblocks = launch_blocks(h, nc, h->opt.vrev_blocks > 0 ? h->opt.vrev_blocks : 16);
+#define PSDR_LAUNCH_VREV(KIND, KK)                                                                                                                           \
+                        do { if (dyn_v > 48 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_vertex_rev<FL, KIND>), hipFuncAttributeMaxDynamicSharedMemorySize, dyn_v)); \
+                        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_vertex_rev<FL, KIND>), dim3(vblocks), dim3(kBlock), dyn_v, s, cxv, sink, o->spp, o->spp_begin, SlotDiv(nsp), c0, nc,     \
+                                           1.f / (float) o->spp, adj_img, disk, chunk, state, (KK), wf_value ? 1 : 0); HIP_TRY(hipGetLastError()); } while (0)
+                        PSDR_LAUNCH_VREV(0, 0);
+                        // launches 1 .. depth: vertex k of the paths that have one; launch `depth` only flushes the rows still pending
+                        for (int kv = 1; kv <= depth; ++kv) {
+                            cxv.jump = make_rng_jump(o->rng_offset[0] + 2 + 5 * (uint64_t) kv);
+                            PSDR_LAUNCH_VREV(1, kv);
+                            if (kv == 1 && depth > 1) { cxv.jump = cx.jump; PSDR_LAUNCH_VREV(2, 0); }     // vertex 1's position adjoint through the primary vertex' chain
+                        }
+#undef PSDR_LAUNCH_VREV
+                    } else
                     PSDR_LAUNCH_REV_K(true, PSDR_INTEGRATOR_PATH, 2, cx2, dyn_bytes, c0, nc, (float *) nullptr, disk, chunk);
                 } else {
                     PSDR_LAUNCH_REV_K(true, PSDR_INTEGRATOR_DIRECT, 1, cx, dyn1, c0, nc, out_img, disk, chunk);

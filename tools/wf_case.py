@@ -28,6 +28,10 @@ elif case in ("c4pr", "c5pr"):
         from psdr_cuda.fixtures import make_interior_scene
         sc = make_interior_scene(seed=0, n_objects=10, res=512, spp=16); sc.configure()
         o = _abi.make_opts(spp=16, integrator=_abi.INTEGRATOR_PATH, max_depth=3, flags=flags); n = 512 * 512 * 16
+elif case == "c2ra":
+    # C2 (cbox 512^2 spp 64, no tree) PathTracer(3) reverse, every gradient table
+    sc, _ = load_scene("cbox", res=512, spp=64)
+    o = _abi.make_opts(spp=64, integrator=_abi.INTEGRATOR_PATH, max_depth=3, flags=flags); n = 512 * 512 * 64
 elif case in ("c3f", "c3r", "c4r3"):
     # the three-term DirectIntegrator workloads: C3 forward (K = 1, a translation of the bunny) / reverse at 512^2 spp 16; C4 shard reverse
     from helpers import tangents_wrt
@@ -50,6 +54,9 @@ elif case in ("c3r", "c4r3"):
 elif case in ("c4pr", "c5pr"):
     adj = np.random.default_rng(0).random((tb["width"] * tb["height"], 3)).astype(np.float32)
     run = lambda: g.render_d_rev(o, adj, want=["tri_info", "texels"], with_image=False)
+elif case == "c2ra":
+    adj = np.random.default_rng(0).random((tb["width"] * tb["height"], 3)).astype(np.float32)
+    run = lambda: g.render_d_rev(o, adj, want=["texels", "emitter_rad", "tri_info", "cam_to_world"], with_image=False)
 else:
     run = lambda: g.render_c(o)
 run(); torch.cuda.synchronize()
