@@ -68,6 +68,7 @@ def parse():
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-tree-scenes", action="store_true", help="skip the tree_scenes block (BASELINE configs 3-5 at one GPU's share)")
     ap.add_argument("--tree-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-c4-strong", action="store_true", help="skip the c4_strong block (BASELINE configs[3]: cbox_bunny 1024^2, global spp 512 sharded over the ranks)")
     return ap.parse_args()
 
 
@@ -194,6 +195,27 @@ def timed(fn, n):
     return float(np.mean(ms))
 
 
+TORCHRUN_VARS = ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "ROLE_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                 "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS", "TORCHELASTIC_USE_AGENT_STORE", "TORCH_NCCL_ASYNC_ERROR_HANDLING",
+                 "PSDR_FORCE_COLLECTIVES", "PSDR_BENCH_ONE_GPU")
+
+
+def child_env(local_rank=0):
+    """Environment of a counter-pass child (rocprofv3 -- python bench.py --*-child): ONE process on this rank's GPU, whatever launched the parent -- the
+    torchrun variables are stripped (the child must not try to join the job's process group) and the device is pinned."""
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in TORCHRUN_VARS:
+        env.pop(k, None)
+    vis = os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("CUDA_VISIBLE_DEVICES"))
+    if vis:
+        ids = [x for x in vis.split(",") if x != ""]
+        env["HIP_VISIBLE_DEVICES"] = ids[local_rank] if local_rank < len(ids) else ids[0]
+    else:
+        env["HIP_VISIBLE_DEVICES"] = str(local_rank)
+    env.pop("CUDA_VISIBLE_DEVICES", None)
+    return env
+
+
 def pmc_passes(args):
     """VALU wave-instructions and HBM bytes per launch of the dominant kernels, measured NOW: this script re-runs
     itself (--pmc-child: a few kernel-only launches) under `rocprofv3 --pmc`, one pass per counter group, and parses
@@ -204,7 +226,7 @@ def pmc_passes(args):
         return {}
     out = {}
     tmp = tempfile.mkdtemp(prefix="psdr_pmc_", dir="/tmp")
-    env = dict(os.environ, TMPDIR="/tmp")
+    env = child_env(getattr(args, "local_rank", 0))
     try:
         for group in ("SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES", "FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(tmp, group.split()[0])
@@ -238,7 +260,7 @@ def pmc_passes_c4(args, res, spp):
     if not exe:
         return None
     tmp = tempfile.mkdtemp(prefix="psdr_pmc4_", dir="/tmp")
-    env = dict(os.environ, TMPDIR="/tmp")
+    env = child_env(getattr(args, "local_rank", 0))
     cnt, dur, launches = {}, {}, {}
     try:
         for group in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -253,7 +275,7 @@ def pmc_passes_c4(args, res, spp):
                 for r in csv.DictReader(open(f)):
                     n = r.get("Kernel_Name", "")
                     if "k_wf_" in n and r.get("Counter_Name") == group:
-                        k = "k_wf_camera" if "k_wf_camera" in n else "k_wf_bounce"
+                        k = "k_wf_camera" if "k_wf_camera" in n else ("k_wf_trace" if "k_wf_trace" in n else "k_wf_bounce")
                         cnt.setdefault(k, {}).setdefault(group, 0.0); cnt[k][group] += float(r["Counter_Value"])
                         if group == "FETCH_SIZE":
                             launches[k] = launches.get(k, 0) + 1
@@ -262,7 +284,7 @@ def pmc_passes_c4(args, res, spp):
                     for r in csv.DictReader(open(f)):
                         n = r.get("Kernel_Name", "")
                         if "k_wf_" in n:
-                            k = "k_wf_camera" if "k_wf_camera" in n else "k_wf_bounce"
+                            k = "k_wf_camera" if "k_wf_camera" in n else ("k_wf_trace" if "k_wf_trace" in n else "k_wf_bounce")
                             dur[k] = dur.get(k, 0.0) + (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
@@ -271,6 +293,9 @@ def pmc_passes_c4(args, res, spp):
         if "FETCH_SIZE" in c and "WRITE_SIZE" in c and dur.get(k):
             b = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
             out[k] = {"launches": launches.get(k), "seconds": round(dur[k], 6), "hbm_bytes": b, "GBps": round(b / dur[k] / 1e9, 1), "hbm_measured_frac": round(b / dur[k] / HBM_BPS, 4)}
+    if out:
+        tb, ts = sum(v["hbm_bytes"] for v in out.values()), sum(v["seconds"] for v in out.values())
+        out["all_wavefront_kernels"] = {"seconds": round(ts, 6), "hbm_bytes": tb, "GBps": round(tb / ts / 1e9, 1), "hbm_measured_frac": round(tb / ts / HBM_BPS, 4)}
     return out or None
 
 
@@ -313,11 +338,18 @@ class TreeScenes:
         for k in ("tri_info", "texels"):
             tb4p[k] = tb4p[k].detach().requires_grad_(True)
         self.cases.append(("c4_shard_path3_rev", n4, lambda sc=sc4, tb=tb4p, o=o, a=adj4: self.integ._render_rev(sc, tb, o, None, a), sc4))
+        # forward mode with GEOMETRY tangents (a translation of the bunny: the reference harness' AD mode, run_test.py:126-129) through the PathTracer
+        tan4 = self._translation_tangents(sc4, tb4)
+        tb4t = sc4.tables(0)
+        self.cases.append(("c4_shard_path3_fwd_geo", n4, lambda sc=sc4, tb=tb4t, o=o, t=tan4: self.integ._render_fwd(sc, tb, o, None, [t]), sc4))
         sc5 = make_interior_scene(seed=0, n_objects=10, res=512, spp=16)
         sc5.configure()
         tb5 = sc5.tables(0)
         o5 = _abi.make_opts(integrator=_abi.INTEGRATOR_PATH, max_depth=3, spp=16)
         self.cases.append(("c5_path3_renderC", 512 * 512 * 16, lambda sc=sc5, tb=tb5, o=o5: self.integ._render_c(sc, tb, o, None), sc5))
+        tan5 = self._translation_tangents(sc5, tb5, mesh=sc5.m_meshes[8])
+        tb5t = sc5.tables(0)
+        self.cases.append(("c5_path3_fwd_geo", 512 * 512 * 16, lambda sc=sc5, tb=tb5t, o=o5, t=tan5: self.integ._render_fwd(sc, tb, o, None, [t]), sc5))
         # C3: forward mode, the tangent tables of a unit translation of the bunny along x (every table row that moves with the mesh)
         sc3 = bunny(512, 16, 16, 16)
         tb3 = sc3.tables(0)
@@ -326,13 +358,13 @@ class TreeScenes:
         tb3 = sc3.tables(0)                                     # the tables of the configure() that carries P (same values)
         self.cases.append(("c3_direct_fwd3", 3 * 512 * 512 * 16, lambda sc=sc3, tb=tb3, o=o3, t=tan3: self.integ._render_fwd(sc, tb, o, None, [t]), sc3))
 
-    def _translation_tangents(self, sc, tb):
-        """d table / d P for Mesh[1] (the bunny) translated by P along x: JVP of the table chain through a second configure."""
+    def _translation_tangents(self, sc, tb, mesh=None):
+        """d table / d P for Mesh[1] (the bunny; or `mesh`) translated by P along x: JVP of the table chain through a second configure."""
         import enoki as ek
         from enoki.cuda_autodiff import Float32 as FloatD, Vector3f as Vector3fD, Matrix4f as Matrix4fD
         P = FloatD(0.)
         ek.set_requires_gradient(P)
-        sc.param_map["Mesh[1]"].set_transform(Matrix4fD.translate(Vector3fD([1.0, 0.0, 0.0]) * P))
+        (mesh if mesh is not None else sc.param_map["Mesh[1]"]).set_transform(Matrix4fD.translate(Vector3fD([1.0, 0.0, 0.0]) * P))
         sc.configure()
         tbd = sc.tables(0)
         from enoki._array import _jvp_wrt
@@ -370,40 +402,59 @@ def tree_scenes(args):
     if exe and not args.no_pmc:
         tmp = tempfile.mkdtemp(prefix="psdr_tree_", dir="/tmp")
         try:
-            cmd = [exe, "--pmc", "SQ_INSTS_VALU", "--kernel-trace", "--output-format", "csv", "-d", tmp, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--tree-child"]
-            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300, check=True)
-            disp = {}
-            for f in glob.glob(os.path.join(tmp, "**", "*kernel_trace.csv"), recursive=True):
-                for r in csv.DictReader(open(f)):
-                    disp[r["Dispatch_Id"]] = [r["Kernel_Name"], int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), 0.0]
-            for f in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
-                for r in csv.DictReader(open(f)):
-                    if r.get("Counter_Name") == "SQ_INSTS_VALU" and r["Dispatch_Id"] in disp:
-                        disp[r["Dispatch_Id"]][3] += float(r["Counter_Value"])
-            rows = sorted(disp.values(), key=lambda x: x[1])
-            seg, segs = [], []
-            for r in rows:
-                if "spin_kernel" in r[0]:
-                    segs.append(seg); seg = []
-                else:
-                    seg.append(r)
-            segs = segs[1:]                                     # [0] = the warm-up calls in front of the first separator
-            for (name, _, _, _), sg in zip(ts.cases, segs):
-                agg = {}
-                for kn, _, d, v in sg:
-                    if "k_" in kn and "at::native" not in kn and "rocprim" not in kn:
-                        a = agg.setdefault(kn, [0.0, 0.0, 0]); a[0] += d; a[1] += v; a[2] += 1
-                if agg:
-                    kn, (d, v, c) = max(agg.items(), key=lambda kv: kv[1][0])
-                    short = kn.replace("void (anonymous namespace)::", "").split("(")[0]
-                    out[name]["dominant_kernel"] = {"name": short, "launches": c, "ms_under_profiler": round(d / 1e6, 3), "valu_wave_insts": v,
-                                                    "valu_issue_frac": round(v / (d * 1e-9) / VALU_PEAK_WAVE_INSTS_PER_S, 4) if d else None}
+            per_case = {}                                         # case -> kernel -> [duration ns, {counter: value}, launches]
+            for group in ("SQ_INSTS_VALU", "FETCH_SIZE", "WRITE_SIZE"):
+                d = os.path.join(tmp, group)
+                cmd = [exe, "--pmc", group, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--tree-child"]
+                subprocess.run(cmd, cwd="/tmp", env=child_env(getattr(args, "local_rank", 0)), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=400, check=True)
+                disp = {}
+                for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+                    for r in csv.DictReader(open(f)):
+                        disp[r["Dispatch_Id"]] = [r["Kernel_Name"], int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), 0.0]
+                for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                    for r in csv.DictReader(open(f)):
+                        if r.get("Counter_Name") == group and r["Dispatch_Id"] in disp:
+                            disp[r["Dispatch_Id"]][3] += float(r["Counter_Value"])
+                rows = sorted(disp.values(), key=lambda x: x[1])
+                seg, segs = [], []
+                for r in rows:
+                    if "spin_kernel" in r[0]:
+                        segs.append(seg); seg = []
+                    else:
+                        seg.append(r)
+                segs = segs[1:]                                     # [0] = the warm-up calls in front of the first separator
+                for (name, _, _, _), sg in zip(ts.cases, segs):
+                    agg = per_case.setdefault(name, {})
+                    for kn, _, dd, v in sg:
+                        if "k_" in kn and "at::native" not in kn and "rocprim" not in kn:
+                            a = agg.setdefault(kn, [0.0, {}, 0])
+                            a[1][group] = a[1].get(group, 0.0) + v
+                            if group == "SQ_INSTS_VALU":
+                                a[0] += dd; a[2] += 1
+            for name, agg in per_case.items():
+                if not agg:
+                    continue
+                kn, (dd, c, n) = max(agg.items(), key=lambda kv: kv[1][0])
+                short = kn.replace("void (anonymous namespace)::", "").split("(")[0]
+                v = c.get("SQ_INSTS_VALU", 0.0)
+                out[name]["dominant_kernel"] = {"name": short, "launches": n, "ms_under_profiler": round(dd / 1e6, 3), "valu_wave_insts": v,
+                                                "valu_issue_frac": round(v / (dd * 1e-9) / VALU_PEAK_WAVE_INSTS_PER_S, 4) if dd else None}
+                # measured HBM traffic of ALL library kernels of the call against 8 TB/s: the north star's roofline for the wavefront launches
+                tot_ns = sum(a[0] for a in agg.values())
+                if tot_ns and all("FETCH_SIZE" in a[1] and "WRITE_SIZE" in a[1] for a in agg.values()):
+                    tot_b = sum((2.0 * a[1]["FETCH_SIZE"] + a[1]["WRITE_SIZE"]) * 1024.0 for a in agg.values())
+                    out[name]["hbm"] = {"bytes_per_call": tot_b, "kernel_ms_under_profiler": round(tot_ns / 1e6, 3), "GBps": round(tot_b / (tot_ns * 1e-9) / 1e9, 1),
+                                        "hbm_measured_frac": round(tot_b / (tot_ns * 1e-9) / HBM_BPS, 4),
+                                        "per_kernel": {k.replace("void (anonymous namespace)::", "").split("(")[0]: {"launches": a[2], "ms": round(a[0] / 1e6, 3),
+                                                       "hbm_measured_frac": round((2.0 * a[1]["FETCH_SIZE"] + a[1]["WRITE_SIZE"]) * 1024.0 / (a[0] * 1e-9) / HBM_BPS, 4) if a[0] else None}
+                                                       for k, a in sorted(agg.items(), key=lambda kv: -kv[1][0])[:6]}}
         except Exception as e:
             out["pmc_error"] = repr(e)
         finally:
             shutil.rmtree(tmp, ignore_errors=True)
     out["note"] = ("C-ABI launches on ONE GPU, median of 3 (HIP events); Grays_per_s = rays traced / time; dominant_kernel = the kernel with the largest summed duration of "
-                   "the workload, its SQ_INSTS_VALU over its duration against 1228.8 G wave-instructions/s (rocprofv3 --pmc pass of this script)")
+                   "the workload, its SQ_INSTS_VALU over its duration against 1228.8 G wave-instructions/s; hbm = (2 * FETCH_SIZE + WRITE_SIZE) KiB of all library kernels of the call over their "
+                   "summed duration against 8 TB/s (rocprofv3 --pmc passes of this script, one per counter)")
     return out
 
 
@@ -501,7 +552,9 @@ def run_c4(args, world, rank, local_rank, dist, devices, rccl):
     T = int(sc.tables(0)["num_tris"])
     # the wavefront stages' stream traffic against the HBM roofline: measured on one GPU's share of the 8-GPU job (64 spp: the launch size at
     # which the library runs the class-binned wavefront), record size 44 + 12 K bytes + 3 (1 + K) accumulator words per live path and stage
-    wf = pmc_passes_c4(args, res, max(spp // 8, 1)) if (rank == 0 and world == 1 and not args.no_pmc) else None
+    wf = pmc_passes_c4(args, res, max(spp // 8, 1)) if (rank == 0 and not args.no_pmc) else None
+    if dist and world > 1:
+        dist.barrier()
     grad_words = T * 24 + int(sc.tables(0)["texels"].numel())
     if rank == 0:
         gv = out[1].numpy()
@@ -521,6 +574,74 @@ def run_c4(args, world, rank, local_rank, dist, devices, rccl):
             "wavefront_traffic": None if wf is None else {"workload": "renderC of one rank's share of the 8-GPU job (%d spp), two calls" % max(spp // 8, 1), "kernels": wf,
                                                            "stream_record_bytes": 44 + 12, "note": "(2 * FETCH_SIZE + WRITE_SIZE) KiB per kernel summed over its launches / its summed duration / 8 TB/s (rocprofv3 --pmc, one pass per counter)"},
         }))
+
+
+def c4_strong(args, world, rank, dist, rccl, wait_all):
+    """BASELINE configs[3] beside the headline at EVERY world size (north star: "Mpath-samples/s reported at 1/2/4/8 GPUs with achieved-HBM-fraction"):
+    cbox_bunny 1024x1024, GLOBAL spp = sppe = sppse = 512 sharded over the ranks (strong scaling), step = PathTracer(3).renderC + configure +
+    DirectIntegrator(1,1).renderD (three terms) + enoki.backward w.r.t. the bunny's vertex positions and the albedo texels, through the surface; the
+    wavefront kernels' measured HBM traffic (rank 0's share under rocprofv3 --pmc) against 8 TB/s."""
+    import enoki as ek
+    import psdr_cuda
+    from enoki.cuda_autodiff import Float32 as FloatD, Vector3f as Vector3fD
+    from psdr_cuda.fixtures import scene_path
+    res, spp, steps = 1024, 512, 2
+    sc = psdr_cuda.Scene()
+    sc.load_file(scene_path("cbox_bunny"), False)
+    sc.opts.width = sc.opts.height = res
+    sc.opts.spp, sc.opts.sppe, sc.opts.sppse, sc.opts.log_level = spp, spp, spp, 0
+    integ = psdr_cuda.PathTracer(max_depth=3)
+    integ_d = psdr_cuda.DirectIntegrator(1, 1)
+    refl = sc.param_map["BSDF[0]"].reflectance
+    base = ek.detach(refl.data)
+    mesh = sc.param_map["Mesh[1]"]
+    v0 = ek.detach(mesh.vertex_positions)
+    sc.configure()
+
+    def step():
+        img = integ.renderC(sc)
+        r = Vector3fD(base); ek.set_requires_gradient(r); refl.data = r
+        v = Vector3fD(v0); ek.set_requires_gradient(v); mesh.vertex_positions = v
+        sc.configure()
+        imgD = integ_d.renderD(sc)
+        ek.backward(FloatD._wrap(imgD.t.sum().reshape(1)))
+        return img, ek.gradient(v), ek.gradient(r)
+
+    step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist:
+        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    tb = sc.tables(0)
+    T = int(tb["num_tris"])
+    grad_words = T * 24 + int(tb["texels"].numel())
+    finite = bool(np.isfinite(out[1].numpy()).all())
+    wf = None
+    if rank == 0 and not args.no_pmc:
+        wf = pmc_passes_c4(args, res, max(spp // world, 1))
+    wait_all()
+    if rank != 0:
+        return None
+    return {"workload": "cbox_bunny %dx%d GLOBAL spp = sppe = sppse = %d sharded over %d rank(s) (%d per GPU): PathTracer(3).renderC + configure + DirectIntegrator(1,1).renderD "
+                        "(interior + primary-edge + secondary-edge terms) + enoki.backward w.r.t. the bunny's vertex positions and the albedo texels" % (res, res, spp, world, spp // world),
+            "scaling": "strong", "steps": steps, "warmup": 1, "ms_per_step": round(dt / steps * 1e3, 3), "value": round(2.0 * res * res * spp * steps / dt / 1e6, 2),
+            "unit": "Mpath-samples/s (2 W H spp camera slots per step; the step also evaluates W H (sppe + sppse) boundary slots)", "world_size": world, "global_spp": spp,
+            "triangles": T, "allreduce_bytes_per_step": 0 if dist is None else int(2 * res * res * 3 * 4 + grad_words * 4),
+            "allreduces_per_step": "[image] (renderC), [image] (renderD primal), [triangle-row || texel gradients]", "rccl_version": rccl, "grad_finite": finite,
+            "wavefront_hbm": None if wf is None else {"workload": "PathTracer(3).renderC of rank 0's share (%d spp), two calls under rocprofv3 --pmc" % max(spp // world, 1), "kernels": wf,
+                                                      "note": "(2 * FETCH_SIZE + WRITE_SIZE) KiB per kernel summed over its launches / its summed duration / 8 TB/s"}}
 
 
 def main():
@@ -561,6 +682,18 @@ def main():
             so.bind(("127.0.0.1", 0))
             port = so.getsockname()[1]
         dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+
+    args.local_rank = local_rank
+    side = None
+    if dist and world > 1:
+        # host-side barrier (gloo): the other ranks wait here -- no spinning collective on their GPUs, no RCCL watchdog -- while rank 0 runs the counter
+        # passes (child processes under rocprofv3) and the single-GPU side blocks
+        from datetime import timedelta
+        side = dist.new_group(backend="gloo", timeout=timedelta(hours=2))
+
+    def wait_all():
+        if side is not None:
+            dist.barrier(group=side)
 
     devices, rccl = rank_devices(dist, local_rank)
     if args.config == "c4":
@@ -638,7 +771,8 @@ def main():
                        "reverse_step = configure + renderD + enoki.backward (primal launch + psdr_render_d_rev); reverse_all_step = the same with gradients of the albedo, the light's radiance, a wall's vertices and the camera pose"}
 
     # ---- roofline of the dominant kernel: VALU issue (not HBM: the path state lives in registers)
-    pmc = {} if (args.no_pmc or rank != 0 or world != 1) else pmc_passes(args)
+    # (rank 0 at ANY world size: the child is one process on rank 0's GPU with this rank's per-GPU workload; the other ranks wait at wait_all() below)
+    pmc = {} if (args.no_pmc or rank != 0) else pmc_passes(args)
     dom_key, dom_ms, dom_name = ("d", ms_d1, "k_camera<float, Dual<1>, PATH> (renderD fwd)") if ms_d1 >= ms_c else ("c", ms_c, "k_camera<float, float, PATH> (renderC)")
     dom_rays = rays_d if dom_key == "d" else rays_c
     valu = pmc.get(dom_key, {}).get("SQ_INSTS_VALU")
@@ -675,64 +809,76 @@ def main():
                           for k, v in pmc.items() if k != dom_key},
     }
 
+    from psdr_cuda.integrator import solo
     cpu, grad = None, None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        sys.path.insert(0, os.path.join(ROOT, "oracle"))
-        import oracle
-        import psdr_cuda
-        from psdr_cuda.fixtures import scene_path
-        # ---- CPU baseline: the oracle (a port of the reference's estimator) on the host cores, bounded sample
-        w.kernel_setup(1)
-        tbc = {k: (v.detach().cpu() if isinstance(v, torch.Tensor) else v) for k, v in w.tb.items()}
-        cspp = 2
-        o = _abi.make_opts(integrator=_abi.INTEGRATOR_PATH, max_depth=args.max_depth, spp=cspp)
-        cores = os.cpu_count() or 1
-        tt = torch.zeros_like(tbc["texels"]); tt[0:3] = 1.0
-        oracle.render(tbc, _abi.make_opts(integrator=_abi.INTEGRATOR_PATH, max_depth=args.max_depth, spp=1), nthreads=cores)
-        c0 = time.perf_counter()
-        reps = 0
-        while time.perf_counter() - c0 < 10.0:
-            oracle.render(tbc, o, nthreads=cores)
-            oracle.render(tbc, o, mode=1, tangents={"texels": tt}, nthreads=cores)
-            reps += 1
-        cdt = time.perf_counter() - c0
-        cpu = {"value": round(2.0 * args.res * args.res * cspp * reps / cdt / 1e6, 4), "unit": "Mpath-samples/s", "cores": cores, "kind": "port",
-               "sample": "%d x (renderC + renderD fwd K=1) of the same scene at %dx%d spp=%d, oracle fp32, %d threads" % (reps, args.res, args.res, cspp, cores)}
-        # ---- the metric's parity half: d image / d albedo, HIP vs the oracle on the same sample streams, at a size the
-        # oracle finishes in a second.  Three references: fp32 in the product's forms, fp32 in the reference's literal
-        # forms, fp64 literal (= the exact value of the reference's estimator).  tests/ hold the full parity suite.
-        gres, gspp = 64, 8
-        sc2 = psdr_cuda.Scene()
-        sc2.load_file(scene_path(args.scene), False)
-        sc2.opts.width = sc2.opts.height = gres
-        sc2.opts.spp, sc2.opts.sppe, sc2.opts.sppse, sc2.opts.log_level = gspp, 0, 0, 0
-        sc2.configure()
-        tb2 = sc2.tables(0)
-        o2 = w.integ._opts(sc2, with_edges=False)
-        ts2 = []
-        for c in range(3):
-            t = torch.zeros_like(tb2["texels"]); t[c] = 1.0
-            ts2.append([None, t, None, None, None, None, None])
-        _, dimgs = w.integ._render_fwd(sc2, tb2, o2, None, ts2)
+    if rank == 0 and not args.no_cpu_baseline:
+      with solo():                                       # rank 0 alone: no sharding, no collective in the render calls of this block
+          sys.path.insert(0, os.path.join(ROOT, "oracle"))
+          import oracle
+          import psdr_cuda
+          from psdr_cuda.fixtures import scene_path
+          # ---- CPU baseline: the oracle (a port of the reference's estimator) on the host cores, bounded sample
+          w.kernel_setup(1)
+          tbc = {k: (v.detach().cpu() if isinstance(v, torch.Tensor) else v) for k, v in w.tb.items()}
+          cspp = 2
+          o = _abi.make_opts(integrator=_abi.INTEGRATOR_PATH, max_depth=args.max_depth, spp=cspp)
+          cores = os.cpu_count() or 1
+          tt = torch.zeros_like(tbc["texels"]); tt[0:3] = 1.0
+          oracle.render(tbc, _abi.make_opts(integrator=_abi.INTEGRATOR_PATH, max_depth=args.max_depth, spp=1), nthreads=cores)
+          c0 = time.perf_counter()
+          reps = 0
+          while time.perf_counter() - c0 < 10.0:
+              oracle.render(tbc, o, nthreads=cores)
+              oracle.render(tbc, o, mode=1, tangents={"texels": tt}, nthreads=cores)
+              reps += 1
+          cdt = time.perf_counter() - c0
+          cpu = {"value": round(2.0 * args.res * args.res * cspp * reps / cdt / 1e6, 4), "unit": "Mpath-samples/s", "cores": cores, "kind": "port",
+                 "sample": "%d x (renderC + renderD fwd K=1) of the same scene at %dx%d spp=%d, oracle fp32, %d threads" % (reps, args.res, args.res, cspp, cores)}
+          # ---- the metric's parity half: d image / d albedo, HIP vs the oracle on the same sample streams, at a size the
+          # oracle finishes in a second.  Three references: fp32 in the product's forms, fp32 in the reference's literal
+          # forms, fp64 literal (= the exact value of the reference's estimator).  tests/ hold the full parity suite.
+          gres, gspp = 64, 8
+          sc2 = psdr_cuda.Scene()
+          sc2.load_file(scene_path(args.scene), False)
+          sc2.opts.width = sc2.opts.height = gres
+          sc2.opts.spp, sc2.opts.sppe, sc2.opts.sppse, sc2.opts.log_level = gspp, 0, 0, 0
+          sc2.configure()
+          tb2 = sc2.tables(0)
+          o2 = w.integ._opts(sc2, with_edges=False)
+          ts2 = []
+          for c in range(3):
+              t = torch.zeros_like(tb2["texels"]); t[c] = 1.0
+              ts2.append([None, t, None, None, None, None, None])
+          _, dimgs = w.integ._render_fwd(sc2, tb2, o2, None, ts2)
 
-        def worst(**kw):
-            r = 0.0
-            for c in range(3):
-                ref = oracle.render(tb2, o2, mode=1, tangents={"texels": ts2[c][1]}, **kw)[1].reshape(-1).astype(np.float64)
-                got = dimgs[c].cpu().numpy().astype(np.float64)
-                r = max(r, float(np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-30)))
-            return round(r, 8)
-        grad = {"rel_l2": worst(precision=1, reference_form=True), "bound": 1e-3,
-                "rel_l2_vs_fp32_same_forms": worst(precision=0), "rel_l2_vs_fp32_reference_forms": worst(precision=0, reference_form=True),
-                "check": "d image / d albedo(r,g,b), %s %dx%d spp=%d PathTracer(max_depth=%d), HIP vs CPU oracle on the same sample streams; rel_l2 = against "
-                         "fp64 in the reference's literal forms" % (args.scene, gres, gres, gspp, args.max_depth)}
+          def worst(**kw):
+              r = 0.0
+              for c in range(3):
+                  ref = oracle.render(tb2, o2, mode=1, tangents={"texels": ts2[c][1]}, **kw)[1].reshape(-1).astype(np.float64)
+                  got = dimgs[c].cpu().numpy().astype(np.float64)
+                  r = max(r, float(np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-30)))
+              return round(r, 8)
+          grad = {"rel_l2": worst(precision=1, reference_form=True), "bound": 1e-3,
+                  "rel_l2_vs_fp32_same_forms": worst(precision=0), "rel_l2_vs_fp32_reference_forms": worst(precision=0, reference_form=True),
+                  "check": "d image / d albedo(r,g,b), %s %dx%d spp=%d PathTracer(max_depth=%d), HIP vs CPU oracle on the same sample streams; rel_l2 = against "
+                           "fp64 in the reference's literal forms" % (args.scene, gres, gres, gspp, args.max_depth)}
 
     trees = None
-    if rank == 0 and world == 1 and not args.no_tree_scenes:
+    if rank == 0 and not args.no_tree_scenes:
         try:
-            trees = tree_scenes(args)
+            with solo():
+                trees = tree_scenes(args)
         except Exception as e:                                  # reported as missing, never as a number
             trees = {"error": repr(e)}
+    wait_all()
+    # ---- BASELINE configs[3] as a strong-scaling block, every rank takes part
+    strong = None
+    if not args.no_c4_strong:
+        try:
+            strong = c4_strong(args, world, rank, dist, rccl, wait_all)
+        except Exception as e:
+            strong = {"error": repr(e)}
+            wait_all()
     if rank == 0:
         out = {
             "metric": "Mpath-samples/s renderC+renderD, cbox 512x512 spp=64; grad rel-L2 vs ref",
@@ -746,7 +892,7 @@ def main():
                        "allreduce_bytes_per_step": 0 if world == 1 else int(args.res * args.res * 3 * 4 * 3),
                        "parallelism": "spp-shard x%d, one all-reduce per render call ([image] for renderC, [image || derivative image] for renderD)" % world},
             "surface": surface, "kernel_only": kernel_only,
-            "roofline": roofline, "cpu_baseline": cpu, "grad_rel_l2": grad, "tree_scenes": trees,
+            "roofline": roofline, "cpu_baseline": cpu, "grad_rel_l2": grad, "tree_scenes": trees, "c4_strong": strong,
         }
         print(json.dumps(out))
     if dist:

@@ -654,6 +654,7 @@ template <class R> PSDR_HD void moeller_trumbore(const Vec3<R> &p0, const Vec3<R
 }
 
 enum HitForm { kDetached = 0, kPathSpace = 1, kSolidAngle = 2 };
+template <class R, class TVT> PSDR_HD Its<R> its_from_hit(const SceneView &sc, const TVT &tv, const Hit &h, const RayT<R> &ray, HitForm form);
 
 // Scene::ray_intersect<ad, path_space> (src/scene/scene.cpp:290-384)
 //   kDetached  : C types; barycentrics from the traversal, J = 1
@@ -670,6 +671,14 @@ template <class R, class TVT> PSDR_HD Its<R> intersect(const SceneView &sc, cons
     const Hit h = (ig0 >= 0 || ig1 >= 0) ? closest_hit<true, F>(sc, st, val(ray.o), val(ray.d), INFINITY, ig0, ig1, pre_slot)
                                          : closest_hit<false, F>(sc, st, val(ray.o), val(ray.d), INFINITY, -1, -1, pre_slot);
     if (h.tri < 0) return its;
+    return its_from_hit<R>(sc, tv, h, ray, form);
+}
+// The hit record of a KNOWN hit (triangle + traversal barycentrics): everything intersect() derives behind its closest_hit.  The geometry-dual
+// stages of the traced wavefront rebuild a path vertex with it from its stream record -- the same arithmetic, hence the same vertex and tangents,
+// as the fused kernel's `its = nits`.
+template <class R, class TVT> PSDR_HD Its<R> its_from_hit(const SceneView &sc, const TVT &tv, const Hit &h, const RayT<R> &ray, HitForm form) {
+    Its<R> its;
+    its.J = R(1.f); its.t = R(INFINITY);
     its.valid = true; its.tri = h.tri; its.hu = h.u; its.hv = h.v;
     const int tm = Tab<TVT::flags>::tri_mesh(sc, h.tri);
     its.mesh = tm & ~PSDR_TRI_FACE_NORMALS;
@@ -1286,12 +1295,13 @@ PSDR_HD Vec3<M> wavefront_camera_vertex(const SceneView &sc, const TVT &tv, Trav
 // others (its sample streams continue behind the two pixel jitter draws: the stage-0 jump).
 template <class M, class TVT>
 PSDR_HD Vec3<M> wavefront_primary_vertex(const SceneView &sc, const TVT &tv, TraversalStack &st, const LiParams &lp, const RngJump &jump,
-                                         int pixel, uint64_t slot, uint32_t &nrays, Its<float> &next, Vec3f &dir, bool &alive, Rng *rng_after = nullptr) {
+                                         int pixel, uint64_t slot, uint32_t &nrays, Its<float> &next, Vec3f &dir, bool &alive, Rng *rng_after = nullptr, float *sxy = nullptr) {
     Rng rng; rng.init(slot, jump);
     const float j0 = rng.next(), j1 = rng.next();
     if (rng_after) *rng_after = rng;           // bounce stage 0 draws from here on (classify_next)
     const int W = sc.d.width;
     const float sx = ((float) (pixel % W) + j0) / (float) W, sy = ((float) (pixel / W) + j1) / (float) sc.d.height;
+    if (sxy) { sxy[0] = sx; sxy[1] = sy; }     // the geometry-dual stages rebuild the camera ray (with its tangents) from the film position
     const RayT<float> ray = primary_ray<float>(sc, tv, sx, sy);
     const Its<float> its = intersect<float>(sc, tv, st, ray, true, kDetached, nrays);
     alive = its.valid;
@@ -1299,6 +1309,14 @@ PSDR_HD Vec3<M> wavefront_primary_vertex(const SceneView &sc, const TVT &tv, Tra
     next = its;
     { const Vec3f d = its.p - ray.o; dir = d / norm(d); }      // the direction intersect() derives wi from
     return lp.hide_emitters ? zero3<M>() : Le<M>(sc, tv, its, true);
+}
+// Plain-float copy of a hit record that carries tangents (classify_next aims the next vertex' rays with it).
+template <class G> PSDR_HD Its<float> detach_its(const Its<G> &a) {
+    Its<float> r;
+    r.valid = a.valid; r.tri = a.tri; r.mesh = a.mesh; r.hu = a.hu; r.hv = a.hv;
+    r.wi = val(a.wi); r.p = val(a.p); r.n = val(a.n); r.t = val(a.t); r.J = val(a.J); r.uvx = val(a.uvx); r.uvy = val(a.uvy);
+    r.sh.s = val(a.sh.s); r.sh.t = val(a.sh.t); r.sh.n = val(a.sh.n);
+    return r;
 }
 // Wavefront mode, stage k >= 1: the direct step at a path vertex read back from the stream.
 template <class M, class TVT>

@@ -405,6 +405,21 @@ int bvh4_refill(psdr_scene_s *h, hipStream_t s);
 int bvh4_build(psdr_scene_s *h, const std::vector<BvhNode> &nodes, const std::vector<int32_t> &roots2, bool forest, hipStream_t s);
 int fail(const std::string &m) { g_err = m; return 1; }
 
+int scratch_reserve(void **buf, size_t *have, size_t need, hipStream_t s, const char *what) {
+    if (need <= *have) return 0;
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    // what the old block gives back counts as free; keep 256 MB of headroom for the runtime
+    if (need > free_b + *have || free_b + *have - need < (256ull << 20))
+        return fail(std::string("psdr: the ") + what + " needs " + std::to_string(need >> 20) + " MB of device memory, " + std::to_string((free_b + *have) >> 20) +
+                    " MB are free on this device (of " + std::to_string(total_b >> 20) + " MB): render fewer samples per call (spp range) or set the option chunk_log2");
+    if (*buf) HIP_TRY(hipFreeAsync(*buf, s));
+    *buf = nullptr; *have = 0;
+    HIP_TRY(hipMallocAsync(buf, need, s));
+    *have = need;
+    return 0;
+}
+
 // Grid of the grid-stride kernels: at most per_cu workgroups per CU (16 by default; the forward camera kernels
 // choose theirs, psdr_kernels.h camera_blocks_per_cu; the reverse kernels zero and flush a gradient cache per
 // workgroup and are flat between 8 and 24).
@@ -625,12 +640,7 @@ int primary_edge_order(psdr_scene_s *h, const LaunchCtx &cx, long long i0, long 
     uint32_t *nul = nullptr;
     HIP_TRY(rocprim::radix_sort_pairs(nullptr, temp, nul, nul, nul, nul, (size_t) n, 0, end_bit, s));
     const size_t need = 4 * sizeof(uint32_t) * (size_t) n + temp + 256;
-    if (need > h->sort_bytes) {
-        if (h->d_sort) (void) hipFree(h->d_sort);
-        h->d_sort = nullptr; h->sort_bytes = 0;
-        HIP_TRY(hipMalloc(&h->d_sort, need));
-        h->sort_bytes = need;
-    }
+    if (int rc = scratch_reserve(&h->d_sort, &h->sort_bytes, need, s, "primary-edge sort scratch")) return rc;
     uint32_t *k_in = reinterpret_cast<uint32_t *>(h->d_sort), *k_out = k_in + n, *v_in = k_out + n, *v_out = v_in + n;
     void *tmp = reinterpret_cast<void *>((reinterpret_cast<uintptr_t>(v_out + n) + 255) & ~(uintptr_t) 255);
     hipLaunchKernelGGL(k_primary_edge_keys, dim3((unsigned) ((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, cx.sc, cx.jump, i0, n, k_in, v_in);
@@ -846,12 +856,7 @@ int launch_wf_trace(psdr_scene_s *h, const float4 *req, const int32_t *count, lo
     if (ovf) {
         a.ovf_stride = grid * kTraceBlock;
         const size_t need = (size_t) a.ovf_stride * (size_t) (h->stack_need4 - S) * sizeof(int32_t);
-        if (need > h->trace_ovf_bytes) {
-            if (h->d_trace_ovf) (void) hipFree(h->d_trace_ovf);
-            h->d_trace_ovf = nullptr; h->trace_ovf_bytes = 0;
-            HIP_TRY(hipMalloc(&h->d_trace_ovf, need));
-            h->trace_ovf_bytes = need;
-        }
+        if (int rc = scratch_reserve(reinterpret_cast<void **>(&h->d_trace_ovf), &h->trace_ovf_bytes, need, s, "trace kernel's overflow stack columns")) return rc;
         a.ovf = h->d_trace_ovf;
     }
     const int dyn = a.off_stack + stack_bytes;
@@ -876,12 +881,7 @@ int probe_buffers(psdr_scene_s *h, long long slots, int rays_per_slot, ProbeBuff
     pb.sub_cap = (blocks / kWfSub) * trips * kBlock * rays_per_slot;          // block b appends to queue b % kWfSub
     const size_t cnt_bytes = (size_t) kWfSub * kWfCountStride * sizeof(int32_t);
     const size_t need = cnt_bytes + (size_t) rays * sizeof(float4) + (((size_t) slots * 4 + 255) & ~(size_t) 255) + (size_t) 2 * pb.sub_cap * kWfSub * sizeof(float4);
-    if (need > h->probe_bytes) {
-        if (h->d_probe) (void) hipFree(h->d_probe);
-        h->d_probe = nullptr; h->probe_bytes = 0;
-        HIP_TRY(hipMalloc(&h->d_probe, need));
-        h->probe_bytes = need;
-    }
+    if (int rc = scratch_reserve(&h->d_probe, &h->probe_bytes, need, s, "probe buffers (hit rows, masks, trace requests)")) return rc;
     char *p = reinterpret_cast<char *>(h->d_probe);
     pb.count = reinterpret_cast<int32_t *>(p); p += cnt_bytes;
     pb.hit = reinterpret_cast<float4 *>(p); p += (size_t) rays * sizeof(float4);
@@ -954,6 +954,7 @@ int psdr_scene_set_option(psdr_scene_t h, const char *name, double value) {
     else if (n == "sink_rep") h->opt.sink_rep = std::max(1, std::min(16, iv));
     else if (n == "sink_private") h->opt.sink_private = iv;
     else if (n == "rev_split") h->opt.rev_split = iv;
+    else if (n == "wf_geo") h->opt.wf_geo = iv;                          // 0: geometry tangents of the PathTracer always through the fused kernel
     else if (n == "rev_vertex") h->opt.rev_vertex = iv;                  // 1: the adjoint sweep of a split PathTracer launch as a launch per path vertex (default 0: one adjoint kernel)
     else if (n == "vrev_blocks") h->opt.vrev_blocks = iv;                // workgroups per CU of the per-vertex adjoint launches (0: default)
     else if (n == "sedge_split") h->opt.sedge_split = iv;

@@ -154,6 +154,7 @@ struct psdr_scene_options {
     int sink_rep = 4;                      // copies of the LDS gradient cache at most
     int sink_private = 1;                  // lane-private accumulators for the emitter's rows
     int rev_split = -1;                    // reverse mode as value kernel + adjoint kernel: 1 / 0 force, -1 by scene and launch size
+    int wf_geo = 1;                        // PathTracer forward mode with geometry tangents on a two-level scene as the traced wavefront (k_wfg_*); 0: the fused kernel
     int rev_vertex = 0;                    // 1: adjoint sweep of a split PathTracer launch as one launch per path vertex (k_vertex_rev, round 5: built, measured SLOWER than the
                                            // one adjoint kernel on C2 / C4 / C5 -- DESIGN.md round 5 -- and kept as an option); 0: one adjoint kernel
     int vrev_blocks = 0;                   // workgroups per CU of those launches (0: 16)
@@ -267,6 +268,11 @@ constexpr int kWfSub = 64, kWfCountStride = 32;
 
 namespace psdr_host {
 int fail(const std::string &m);
+// Growth of a per-handle scratch buffer INSIDE a render call: stream-ordered (hipFreeAsync / hipMallocAsync on the call's stream --
+// no device-wide synchronise on the hot path of the first large call or after a size change), and refused with a clear message when the device does
+// not have the memory (the traced wavefront takes 16 GB for a 2^26-slot chunk: fine for eight ranks on eight GPUs, not for two processes on one).
+int scratch_reserve(void **buf, size_t *have, size_t need, hipStream_t s, const char *what);
+inline int workspace_reserve(psdr_scene_s *h, size_t need, hipStream_t s) { return scratch_reserve(&h->d_ws, &h->ws_bytes, need, s, "wavefront workspace (path-state streams + trace requests)"); }
 int launch_blocks(const psdr_scene_s *h, long long n, int per_cu = 16);
 int plan_lds(const psdr_scene_s *h, LaunchCtx &cx, int reserved = 0);
 int lds_bytes(const LaunchCtx &cx, const psdr_scene_s *h);

@@ -22,11 +22,31 @@ from .scene import make_desc
 _AD_KEYS = _abi.TANGENT_FIELDS
 
 
+_SOLO = 0
+
+
+class solo:
+    """`with integrator.solo():` -- render calls inside the block run on THIS rank alone: no spp sharding, no collective.  For work only one rank of a
+    multi-rank job does while the others wait (bench.py: rank 0's counter passes and single-GPU side blocks at any world size)."""
+
+    def __enter__(self):
+        global _SOLO
+        _SOLO += 1
+        return self
+
+    def __exit__(self, *exc):
+        global _SOLO
+        _SOLO -= 1
+        return False
+
+
 def _dist():
     """torch.distributed when the job has more than one rank.  PSDR_FORCE_COLLECTIVES=1 returns it at world size 1 too: every collective of a
     render call then EXECUTES (over RCCL when the group's backend is nccl) on a one-GPU box -- tests/test_rccl_single_rank_gpu.py."""
     import os
     import torch.distributed as dist
+    if _SOLO:
+        return None
     if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("PSDR_FORCE_COLLECTIVES") == "1"):
         return dist
     return None

@@ -105,6 +105,18 @@ def test_config5_path_tracer_and_geometry_gradients_against_the_oracle():
     assert rel_l2(fimg, rimg) < 1e-3
     assert abs(a_fwd - b) < 2e-4 * scale, (a_fwd, b, scale)          # measured 2.6e-6
     assert flips(fd[0], rd, 2e-3) < 5e-3 and rel_l2(fd[0], rd) < 1e-3          # measured 0 / 1.8e-5
+    # ---- (ii b) the same tangent through the PathTracer: geometry duals of the traced wavefront (round 5: k_wfg_camera / k_wfg_bounce on the rough-conductor,
+    # 4-wide-tree instances of flag set 6) against the oracle and against the fused kernel
+    op = _abi.make_opts(integrator=_abi.INTEGRATOR_PATH, max_depth=3, spp=spp, rng_offset=(11, 0, 0))
+    _, pd_ref = oracle.render(tb, op, mode=1, tangents=tan)
+    _, pd_w = g.render_d_fwd(_abi.make_opts(integrator=_abi.INTEGRATOR_PATH, max_depth=3, spp=spp, rng_offset=(11, 0, 0), flags=_abi.FLAG_WAVEFRONT), [tan]); rays_w = g.counters()[0]
+    _, pd_f = g.render_d_fwd(_abi.make_opts(integrator=_abi.INTEGRATOR_PATH, max_depth=3, spp=spp, rng_offset=(11, 0, 0), flags=_abi.FLAG_FUSED), [tan]); rays_f = g.counters()[0]
+    bp = float((adj * pd_ref).sum()); sp = float(np.abs(adj * pd_ref).sum())
+    print("C5 PathTracer(3) geometry duals: <A, dI> oracle %+.6e  wavefront %+.6e  fused %+.6e (sum|A dI| %.3e); pixels off by > 2e-3: wavefront %.2e fused %.2e; rays %d / %d"
+          % (bp, float((adj * pd_w[0]).sum()), float((adj * pd_f[0]).sum()), sp, flips(pd_w[0], pd_ref, 2e-3), flips(pd_f[0], pd_ref, 2e-3), rays_w, rays_f))
+    assert np.abs(pd_ref).max() > 0 and abs(rays_w - rays_f) <= 1e-4 * rays_f
+    assert abs(float((adj * pd_w[0]).sum()) - bp) < 2e-3 * sp and flips(pd_w[0], pd_ref, 2e-3) < 1e-2
+    assert flips(pd_w[0], pd_f[0], 2e-3) < 1e-2
     # ---- (iii) reverse mode of the same samples projected on the tangent
     _, grads = g.render_d_rev(od, adj.astype(np.float32), want=["tri_info", "sec_edge", "prim_edge"], with_image=False)
     a_rev = dot_tables(grads, {k: v for k, v in tan.items() if v is not None})

@@ -110,6 +110,65 @@ def test_render_d_fwd_matches_oracle(scene, mesh, kind):
     assert rel_l2(dimg[0], ref_d) < 1e-3, rel_l2(dimg[0], ref_d)
 
 
+@pytest.mark.parametrize("scene,mesh,depth,res,spp", [("cbox_bunny", 1, 3, 128, 8), ("cbox_bunny", 1, 5, 96, 8), ("cbox_bunny", 0, 3, 96, 8)])
+def test_path_tracer_geometry_duals_through_the_traced_wavefront(scene, mesh, depth, res, spp):
+    """Round 5: renderD + enoki.forward w.r.t. a geometry parameter -- the only AD mode the reference's harness uses,
+    examples/run_test.py:126-129 -- on a two-level scene runs the PathTracer as the TRACED WAVEFRONT with dual-number stages (csrc/psdr_kernels.h
+    k_wfg_camera / k_wfg_bounce: the trace kernel stays float, every vertex is re-derived differentiably from its stream record as scene.cpp:346-368
+    does from the OptiX hit).  >= 2^16 slots so that the library picks the wavefront by itself.  Against the oracle (the translation of the bunny / of a
+    wall: image 1e-4, derivative image 1e-3 up to the isolated samples of a tree scene) and against the fused kernel on the same samples."""
+    assert res * res * spp >= 1 << 16
+    sc, P = load_scene(scene, res=res, spp=spp, sppe=0, sppse=0, translate=(mesh, (1.0, 0.5, 0.25)))
+    tb = sc.tables(0)
+    tan = tangents_wrt(tb, P)
+    kw = dict(integrator=_abi.INTEGRATOR_PATH, max_depth=depth, spp=spp, rng_offset=(3, 0, 0))
+    g = GpuScene(tb)
+    img_w, d_w = g.render_d_fwd(_abi.make_opts(flags=_abi.FLAG_WAVEFRONT, **kw), [tan]); rays_w = g.counters()[0]
+    img_f, d_f = g.render_d_fwd(_abi.make_opts(flags=_abi.FLAG_FUSED, **kw), [tan]); rays_f = g.counters()[0]
+    img_0, d_0 = g.render_d_fwd(_abi.make_opts(**kw), [tan])                       # the library's own choice: the wavefront
+    g.set_option("wf_geo", 0)
+    img_x, d_x = g.render_d_fwd(_abi.make_opts(flags=_abi.FLAG_WAVEFRONT, **kw), [tan])   # option off: the fused kernel whatever the flag says
+    assert np.abs(d_w[0]).max() > 0 and np.isfinite(d_w[0]).all()
+    assert rel_l2(img_0, img_w) < 2e-6 and rel_l2(d_0[0], d_w[0]) < 2e-5, (rel_l2(img_0, img_w), rel_l2(d_0[0], d_w[0]))
+    assert rel_l2(img_x, img_f) < 2e-6 and rel_l2(d_x[0], d_f[0]) < 2e-5
+    # separately compiled fp32 kernels: isolated samples resolve an epsilon-sized tie the other way (test_wavefront_and_fused_agree_on_tree_scenes...)
+    bad = np.abs(d_w[0] - d_f[0]).max(1) > 1e-4 * (1.0 + np.abs(d_f[0]).max(1))
+    print("%s mesh %d depth %d: wavefront vs fused: image %.2e, derivative %.2e, pixels apart %d of %d, rays %d / %d" % (
+        scene, mesh, depth, rel_l2(img_w, img_f), rel_l2(d_w[0], d_f[0]), bad.sum(), bad.size, rays_w, rays_f))
+    assert abs(rays_w - rays_f) <= 1e-4 * rays_f and bad.mean() < 2e-3
+    assert rel_l2(d_w[0][~bad], d_f[0][~bad]) < 1e-3
+    ref_img, ref_d = oracle.render(tb, _abi.make_opts(**kw), mode=1, tangents=tan)
+    badr = np.abs(d_w[0] - ref_d).max(1) > 1e-3 * (1.0 + np.abs(ref_d).max(1))
+    print("    vs oracle: image %.2e, derivative %.2e (outside %d isolated pixels: %.2e); fused vs oracle %.2e" % (
+        rel_l2(img_w, ref_img), rel_l2(d_w[0], ref_d), badr.sum(), rel_l2(d_w[0][~badr], ref_d[~badr]), rel_l2(d_f[0], ref_d)))
+    assert rel_l2(img_w, ref_img) < 1e-3 and badr.mean() < 2e-3 and rel_l2(d_w[0][~badr], ref_d[~badr]) < 1e-3
+    assert rel_l2(d_w[0], ref_d) < 2.0 * max(rel_l2(d_f[0], ref_d), 5e-4)           # no worse than the kernel it replaces
+
+
+def test_path_tracer_geometry_duals_wavefront_k3_and_camera_pose():
+    """K = 3 tangent sets in one pass (a translation of the bunny, a translation of a wall, a material tangent riding along) and the camera pose as the
+    geometry parameter: each derivative image equals the K = 1 launch of its set, and the fused kernel's."""
+    import torch
+    from helpers import random_tangents
+    res, spp = 96, 8
+    sc, P = load_scene("cbox_bunny", res=res, spp=spp, translate=(1, (0.0, 1.0, 0.0)))
+    tb = sc.tables(0)
+    t_mesh = tangents_wrt(tb, P)
+    t_cam = random_tangents(tb, ["cam_to_world"])
+    t_mix = random_tangents(tb, ["tri_info", "texels", "emitter_rad"])
+    kw = dict(integrator=_abi.INTEGRATOR_PATH, max_depth=3, spp=spp, rng_offset=(9, 0, 0))
+    g = GpuScene(tb)
+    img3, d3 = g.render_d_fwd(_abi.make_opts(flags=_abi.FLAG_WAVEFRONT, **kw), [t_mesh, t_cam, t_mix])
+    for i, t in enumerate((t_mesh, t_cam, t_mix)):
+        _, d1 = g.render_d_fwd(_abi.make_opts(flags=_abi.FLAG_WAVEFRONT, **kw), [t])
+        _, df = g.render_d_fwd(_abi.make_opts(flags=_abi.FLAG_FUSED, **kw), [t])
+        bad = np.abs(d1[0] - df[0]).max(1) > 1e-4 * (1.0 + np.abs(df[0]).max(1))
+        print("set %d: K=3 vs K=1 %.2e, wavefront vs fused %.2e (%d pixels apart)" % (i, rel_l2(d3[i], d1[0]), rel_l2(d1[0], df[0]), bad.sum()))
+        assert np.abs(d1[0]).max() > 0
+        assert rel_l2(d3[i], d1[0]) < 1e-4
+        assert bad.mean() < 2e-3 and rel_l2(d1[0][~bad], df[0][~bad]) < 1e-3
+
+
 def test_render_d_albedo_k3():
     """d image / d (r,g,b) of BSDF[0].reflectance in one K=3 pass == three K=1 oracle passes."""
     import torch

@@ -92,13 +92,26 @@ def test_bench_relaunches_itself_for_two_ranks():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PSDR_BENCH_ONE_GPU="1")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-pmc", "--no-cpu-baseline"],
-                       env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=2400, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["world_size"] == 2 and d["value"] > 0
+    # the N > 1 line answers the north star -- rank 0 ran the counter passes and the single-GPU side blocks while rank 1 waited,
+    # and every rank took part in the strong-scaling block of BASELINE configs[3]
+    assert d["roofline"]["frac"] is not None and 0.05 < d["roofline"]["frac"] < 1.0, d["roofline"]
+    assert d["cpu_baseline"] is not None and d["cpu_baseline"]["value"] > 0 and d["grad_rel_l2"]["rel_l2"] < 1e-3
+    ts = d["tree_scenes"]
+    assert "error" not in ts and "pmc_error" not in ts, ts
+    for k in ("c4_shard_path3_renderC", "c4_shard_path3_rev", "c4_shard_path3_fwd_geo", "c5_path3_renderC", "c5_path3_fwd_geo", "c3_direct_fwd3"):
+        assert ts[k]["ms"] > 0 and ts[k]["dominant_kernel"]["valu_issue_frac"] > 0, (k, ts.get(k))
+    assert 0.0 < ts["c4_shard_path3_renderC"]["hbm"]["hbm_measured_frac"] < 1.0
+    c4 = d["c4_strong"]
+    assert "error" not in c4, c4
+    assert c4["world_size"] == 2 and c4["scaling"] == "strong" and c4["ms_per_step"] > 0 and c4["allreduce_bytes_per_step"] > 2 * 1024 * 1024 * 12 and c4["grad_finite"]
+    assert 0.0 < c4["wavefront_hbm"]["kernels"]["all_wavefront_kernels"]["hbm_measured_frac"] < 1.0
 
 
 if __name__ == "__main__":

@@ -1,5 +1,5 @@
 #!/bin/bash
-# per-dispatch durations + a few counters of the k_vertex_rev / k_camera_rev launches of one wf_case workload: r05_disp.sh <tag> <case> [PSDR_OPTIONS]
+# per-dispatch durations + a few counters of selected launches of one wf_case workload: r05_disp.sh <tag> <case> [PSDR_OPTIONS] [kernel name substrings, "|"-separated]
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/$1; mkdir -p $O; cd /tmp
 export PSDR_OPTIONS=$3
@@ -8,7 +8,7 @@ for PASS in "SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_
   rm -rf /tmp/dp_$N
   rocprofv3 --pmc $PASS --kernel-trace --output-format csv -d /tmp/dp_$N -o p -- python $R/tools/wf_case.py $2 default 1 > /tmp/dp_$N.log 2>&1
 done
-python - "$2 $3" <<'PY' | tee -a $O/disp.txt
+python - "$2 $3" "${4:-k_vertex_rev|k_camera_rev}" <<'PY' | tee -a $O/disp.txt
 import csv, glob, sys, collections
 print("##", sys.argv[1])
 rows = {}
@@ -25,7 +25,7 @@ for d in glob.glob("/tmp/dp_*"):
             did = r["Dispatch_Id"]
             if did not in kt: continue
             n = kt[did][0]
-            if "k_vertex_rev" not in n and "k_camera_rev" not in n: continue
+            if not any(w in n for w in sys.argv[2].split("|")): continue
             e = rows.setdefault(idx[did], {"name": n.replace("void (anonymous namespace)::", "").split("(")[0], "us": []})
             e["us"].append(kt[did][2] / 1e3)
             e[r["Counter_Name"]] = e.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])

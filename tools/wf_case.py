@@ -28,6 +28,20 @@ elif case in ("c4pr", "c5pr"):
         from psdr_cuda.fixtures import make_interior_scene
         sc = make_interior_scene(seed=0, n_objects=10, res=512, spp=16); sc.configure()
         o = _abi.make_opts(spp=16, integrator=_abi.INTEGRATOR_PATH, max_depth=3, flags=flags); n = 512 * 512 * 16
+elif case in ("c4fg", "c5fg"):
+    # PathTracer(3) renderD forward, K = 1 geometry tangents (a translation of one object): C4 shard / the 50 k-triangle interior
+    from helpers import tangents_wrt
+    if case == "c4fg":
+        sc, P = load_scene("cbox_bunny", res=1024, spp=512, sppe=0, sppse=0, translate=(1, (1.0, 0.0, 0.0)))
+        o = _abi.make_opts(spp=512, spp_range=(0, 64), integrator=_abi.INTEGRATOR_PATH, max_depth=3, flags=flags); n = 1024 * 1024 * 64
+    else:
+        import enoki as ek
+        from enoki.cuda_autodiff import Float32 as FloatD, Vector3f as Vector3fD, Matrix4f as Matrix4fD
+        from psdr_cuda.fixtures import make_interior_scene
+        sc = make_interior_scene(seed=0, n_objects=10, res=512, spp=16)
+        P = FloatD(0.); ek.set_requires_gradient(P)
+        sc.m_meshes[8].set_transform(Matrix4fD.translate(Vector3fD([1.0, 0.4, -0.3]) * P)); sc.configure()
+        o = _abi.make_opts(spp=16, integrator=_abi.INTEGRATOR_PATH, max_depth=3, flags=flags); n = 512 * 512 * 16
 elif case == "c2ra":
     # C2 (cbox 512^2 spp 64, no tree) PathTracer(3) reverse, every gradient table
     sc, _ = load_scene("cbox", res=512, spp=64)
@@ -45,7 +59,7 @@ else:
     o = _abi.make_opts(spp=64, integrator=_abi.INTEGRATOR_PATH, max_depth=3, flags=flags); n = 256 * 256 * 64
 tb = sc.tables(0)
 g = GpuScene(tb)
-if case == "c3f":
+if case in ("c3f", "c4fg", "c5fg"):
     tan = tangents_wrt(tb, P)
     run = lambda: g.render_d_fwd(o, [tan])
 elif case in ("c3r", "c4r3"):
