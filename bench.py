@@ -68,6 +68,7 @@ def parse():
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-tree-scenes", action="store_true", help="skip the tree_scenes block (BASELINE configs 3-5 at one GPU's share)")
     ap.add_argument("--tree-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--hip-lib", default=None, help=argparse.SUPPRESS)          # developer: another build of libpsdr_hip.so (tools/build_variant_lib.sh)
     ap.add_argument("--no-c4-strong", action="store_true", help="skip the c4_strong block (BASELINE configs[3]: cbox_bunny 1024^2, global spp 512 sharded over the ranks)")
     return ap.parse_args()
 
@@ -646,6 +647,9 @@ def c4_strong(args, world, rank, dist, rccl, wait_all):
 
 def main():
     args = parse()
+    if args.hip_lib:
+        from psdr_cuda import _abi as _abi0
+        _abi0.use_library(args.hip_lib)
     if args.tree_child:
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a GPU")

@@ -112,6 +112,10 @@ template <int K, int FLAGS = kSceneRough> struct TangentView {
     static constexpr int flags = FLAGS, k = K;
     static constexpr bool has_env = (FLAGS & kSceneEnv) != 0, has_rough = (FLAGS & kSceneRough) != 0, forest = (FLAGS & kSceneForest) != 0, tiny = (FLAGS & kSceneTiny) != 0;
     psdr_tangents t[K > 0 ? K : 1];
+    // one bit per triangle: some tangent set moves this row of tri_info (render_fwd computes it per launch, psdr_kernels.h k_tangent_live); nullptr:
+    // unknown.  A translation of one mesh leaves the rows of every other mesh at rest -- in a room the walls, where most path vertices land -- and
+    // load_tri then fetches the 22 value words only instead of 22 + 22 K.
+    const uint32_t *live = nullptr;
 };
 
 struct Hit { int tri; float u, v, t; };
@@ -617,8 +621,20 @@ template <class TVT> PSDR_HD TriRow<float> load_tri_f(const SceneView &sc, const
     t.fn = {r[4].z, r[4].w, r[5].x}; t.area = r[5].y;
     return t;
 }
+#ifndef PSDR_TANGENT_LIVE
+#define PSDR_TANGENT_LIVE 1
+#endif
 template <class R, class TVT> PSDR_HD TriRow<R> load_tri(const SceneView &sc, const TVT &tv, int id) {
     if constexpr (!is_ad<R>()) return load_tri_f(sc, tv, id);
+    if constexpr (is_ad<R>() && PSDR_TANGENT_LIVE) {
+        if (tv.live != nullptr && ((tv.live[id >> 5] >> (id & 31)) & 1u) == 0u) {
+            const TriRow<float> f = load_tri_f(sc, tv, id);          // a row at rest: six 16-byte loads, zero tangents
+            TriRow<R> t;
+            t.p0 = lift<R>(f.p0); t.e1 = lift<R>(f.e1); t.e2 = lift<R>(f.e2); t.n0 = lift<R>(f.n0); t.n1 = lift<R>(f.n1); t.n2 = lift<R>(f.n2);
+            t.fn = lift<R>(f.fn); t.area = R(f.area);
+            return t;
+        }
+    }
     const size_t o = (size_t) id * PSDR_TRI_STRIDE;
     const float *a = sc.d.tri_info;
     constexpr auto m = &psdr_tangents::d_tri_info;

@@ -954,6 +954,7 @@ int psdr_scene_set_option(psdr_scene_t h, const char *name, double value) {
     else if (n == "sink_rep") h->opt.sink_rep = std::max(1, std::min(16, iv));
     else if (n == "sink_private") h->opt.sink_private = iv;
     else if (n == "rev_split") h->opt.rev_split = iv;
+    else if (n == "tangent_live") h->opt.tangent_live = iv;              // 0: forward-mode kernels load the tangents of every triangle row (no liveness mask)
     else if (n == "wf_geo") h->opt.wf_geo = iv;                          // 0: geometry tangents of the PathTracer always through the fused kernel
     else if (n == "rev_vertex") h->opt.rev_vertex = iv;                  // 1: the adjoint sweep of a split PathTracer launch as a launch per path vertex (default 0: one adjoint kernel)
     else if (n == "vrev_blocks") h->opt.vrev_blocks = iv;                // workgroups per CU of the per-vertex adjoint launches (0: default)
@@ -976,6 +977,7 @@ int psdr_scene_destroy(psdr_scene_t h) {
     if (h->d_refit_area) (void) hipFree(h->d_refit_area);
     if (h->d_sort) (void) hipFree(h->d_sort);
     if (h->d_ws) (void) hipFree(h->d_ws);
+    if (h->d_live) (void) hipFree(h->d_live);
     if (h->d_hot_map) (void) hipFree(h->d_hot_map);
     if (h->d_hot_tris) (void) hipFree(h->d_hot_tris);
     if (h->d_top) (void) hipFree(h->d_top);

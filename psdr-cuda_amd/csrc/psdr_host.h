@@ -154,6 +154,7 @@ struct psdr_scene_options {
     int sink_rep = 4;                      // copies of the LDS gradient cache at most
     int sink_private = 1;                  // lane-private accumulators for the emitter's rows
     int rev_split = -1;                    // reverse mode as value kernel + adjoint kernel: 1 / 0 force, -1 by scene and launch size
+    int tangent_live = 1;                  // forward mode with geometry tangents: one bit per triangle "some tangent set moves this row" (TangentView::live); 0: every row loads its tangents
     int wf_geo = 1;                        // PathTracer forward mode with geometry tangents on a two-level scene as the traced wavefront (k_wfg_*); 0: the fused kernel
     int rev_vertex = 0;                    // 1: adjoint sweep of a split PathTracer launch as one launch per path vertex (k_vertex_rev, round 5: built, measured SLOWER than the
                                            // one adjoint kernel on C2 / C4 / C5 -- DESIGN.md round 5 -- and kept as an option); 0: one adjoint kernel
@@ -257,6 +258,9 @@ struct psdr_scene_s {
     // wavefront PathTracer: path-state streams + stream counters
     void *d_ws = nullptr;
     size_t ws_bytes = 0;
+    // forward mode, geometry tangents: liveness bits of the tri_info rows (TangentView::live)
+    void *d_live = nullptr;
+    size_t live_bytes = 0;
     // probe / final launches: hit rows, masks, trace requests
     void *d_probe = nullptr;
     size_t probe_bytes = 0;

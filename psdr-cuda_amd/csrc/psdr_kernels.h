@@ -530,6 +530,7 @@ __device__ __forceinline__ void wf_bounce_record(const LaunchCtx &cx, const TV<M
             TV<M, FL | kScenePre> tvp;
 #pragma unroll
             for (int k = 0; k < (K > 0 ? K : 1); ++k) tvp.t[k] = tv.t[k];
+            tvp.live = tv.live;
             int light_tri = -1;
             c = wavefront_bounce_vertex<M>(cx.sc, tvp, st, cx.jump, (uint64_t) slot, its, nrays, next, f, alive, REC ? &light_tri : nullptr, &rng_next);
             if constexpr (REC) {
@@ -671,12 +672,15 @@ __device__ __forceinline__ void stream_push_traced_geo(const PathStream &out, co
         q.req[2 * r + 1] = float4{d_light.x, d_light.y, d_light.z, __int_as_float(-1)};
     }
 }
+// waves per SIMD of the dual-number stages: the lean (diffuse) instances need 172 VGPRs at two waves and take a third with a handful of spills (C4 shard
+// 32.9 -> 31.3 ms), the rough-conductor instances lose 13 % there (C5 3.71 -> 4.21 ms): profiles/r05_geo_wavefront_abk.txt
 #ifndef PSDR_WFG_WAVES
-#define PSDR_WFG_WAVES 2
+#define PSDR_WFG_WAVES 0
 #endif
+template <int FL> constexpr int wfg_waves() { return PSDR_WFG_WAVES > 0 ? PSDR_WFG_WAVES : (((FL & kSceneRough) != 0) ? 2 : 3); }
 // Camera stage: the primary hit (its walk stays in the kernel: camera rays are coherent), the emitter seen directly, the requests of bounce stage 0.
 template <int K, int FL>
-__global__ __launch_bounds__(kBlock, PSDR_WFG_WAVES) void k_wfg_camera(LaunchCtx cx, TangentView<K, FL> tv, int spp, int s_begin, SlotDiv nsp, long long j0, long long n, float inv_spp,
+__global__ __launch_bounds__(kBlock, (wfg_waves<FL>())) void k_wfg_camera(LaunchCtx cx, TangentView<K, FL> tv, int spp, int s_begin, SlotDiv nsp, long long j0, long long n, float inv_spp,
                                                                       float *__restrict__ img, float *__restrict__ dimg, long long plane, PathStream out, unsigned long long *counters, TraceQueue tq) {
     using M = Dual<K>;
     TraversalStack st; setup_lds(cx, st, tv);
@@ -707,7 +711,7 @@ __global__ __launch_bounds__(kBlock, PSDR_WFG_WAVES) void k_wfg_camera(LaunchCtx
 }
 // Bounce stage k: FIRST = the primary vertex (solid-angle form from the film position), else a path-space vertex.
 template <int K, int FL, bool FIRST>
-__global__ __launch_bounds__(kBlock, PSDR_WFG_WAVES) void k_wfg_bounce(LaunchCtx cx, TangentView<K, FL> tv, float inv_spp, float *__restrict__ img, float *__restrict__ dimg, long long plane,
+__global__ __launch_bounds__(kBlock, (wfg_waves<FL>())) void k_wfg_bounce(LaunchCtx cx, TangentView<K, FL> tv, float inv_spp, float *__restrict__ img, float *__restrict__ dimg, long long plane,
                                                                       PathStream in, PathStream out, int want_next, unsigned long long *counters, TraceQueue tq) {
     using M = Dual<K>;
     using G = Dual<K>;
@@ -716,6 +720,7 @@ __global__ __launch_bounds__(kBlock, PSDR_WFG_WAVES) void k_wfg_bounce(LaunchCtx
     TV<M, FL | kScenePre> tvp;
 #pragma unroll
     for (int k = 0; k < K; ++k) tvp.t[k] = tv.t[k];
+    tvp.live = tv.live;
     const int sub = blockIdx.x % kWfSub, per = gridDim.x / kWfSub;
     const long long in_base = (long long) sub * in.sub_cap;
     const int n = in.count[sub * kWfCountStride];
@@ -845,18 +850,36 @@ __device__ __forceinline__ bool enters_any_box(const SceneView &sc, const Vec3f 
     return any;
 }
 
+// Guiding-grid build through the filter launches (guide_launch): slot j = (round r = j / n, sample stream l = j % n) of the n = cells x per streams
+// of DirectIntegrator::preprocess_secondary_edges (direct.cpp:166-204); stream l draws three numbers per round, stratified into its cell.
+struct GuideGrid { int r0, r1, r2, per, n; float scale; };          // n == 0: an ordinary secondary-edge launch
+__device__ __forceinline__ void guide_slot_sample(const GuideGrid &gg, long long j, float s3[3], int &cell) {
+    const int r = (int) (j / gg.n), l = (int) (j - (long long) r * gg.n);
+    cell = l / gg.per;
+    const int c0 = cell / (gg.r1 * gg.r2), rem = cell - c0 * gg.r1 * gg.r2, c1 = rem / gg.r2, c2 = rem - c1 * gg.r2;
+    Rng rng; rng.init((uint64_t) l, rng_jump_hd(3ull * (uint64_t) r));
+    s3[0] = rng.next(); s3[1] = rng.next(); s3[2] = rng.next();
+    s3[0] = (s3[0] + (float) c0) * (1.f / (float) gg.r0);
+    s3[1] = (s3[1] + (float) c1) * (1.f / (float) gg.r1);
+    s3[2] = (s3[2] + (float) c2) * (1.f / (float) gg.r2);
+}
 // Probe pass of the secondary-edge filter: mask bit 2 = the slot passes the geometric part of the test (everything else never traces), bits 0 / 1 =
 // its ray towards the emitter sample / away from it enters a tree box.
 template <int FL>
-__global__ __launch_bounds__(kBlock, 6) void k_se_probe(LaunchCtx cx, long long i0, long long n, TraceQueue tq, uint32_t *__restrict__ mask) {
+__global__ __launch_bounds__(kBlock, 6) void k_se_probe(LaunchCtx cx, long long i0, long long n, TraceQueue tq, uint32_t *__restrict__ mask, GuideGrid gg) {
+    // slots [i0, i0 + n) of the launch; hit rows, masks and request destinations are relative to i0 (one chunk of the launch)
     TraversalStack st; setup_lds(cx, st);
     const bool guided = cx.sc.d.guide_cmf != nullptr && cx.sc.d.num_guide_cells > 0;
     const long long nceil = (n + kBlock - 1) / kBlock * kBlock;
     for (long long j = (long long) blockIdx.x * kBlock + threadIdx.x; j < nceil; j += (long long) gridDim.x * kBlock) {
         uint32_t m = 0; Vec3f p0(0.f), d[2] = {Vec3f(0.f), Vec3f(0.f)}; int edge = -1;
         if (j < n) {
-            Rng rng; rng.init((uint64_t) (i0 + j), cx.jump);
-            float s3[3] = {rng.next(), rng.next(), rng.next()};
+            float s3[3];
+            if (gg.n > 0) { int cell; guide_slot_sample(gg, i0 + j, s3, cell); }
+            else {
+                Rng rng; rng.init((uint64_t) (i0 + j), cx.jump);
+                s3[0] = rng.next(); s3[1] = rng.next(); s3[2] = rng.next();
+            }
             if (guided) (void) guide_sample_reuse(cx.sc, s3);
             Vec3f dir;
             if (secondary_edge_rays<FL>(cx.sc, s3, p0, dir, edge)) {
@@ -902,7 +925,8 @@ template <int FL> __global__ __launch_bounds__(kBlock, PSDR_WAVES_C) void k_dire
 
 template <int FL>
 __global__ __launch_bounds__(kBlock, 4) void k_secondary_edge_filter(LaunchCtx cx, long long i0, long long n, uint32_t *__restrict__ list, int *__restrict__ list_n,
-                                                                      unsigned long long *counters, ProbeView pv) {
+                                                                      unsigned long long *counters, ProbeView pv, GuideGrid gg, long long list_base) {
+    // slots [i0, i0 + n); the survivor list takes list_base + j (the slot's index in the whole launch: several chunks append to one list)
     TraversalStack st; setup_lds(cx, st);
     uint32_t nrays = 0;
     const bool guided = cx.sc.d.guide_cmf != nullptr && cx.sc.d.num_guide_cells > 0;
@@ -932,8 +956,12 @@ __global__ __launch_bounds__(kBlock, 4) void k_secondary_edge_filter(LaunchCtx c
             if (probed) probe_load<2>(st, pv, j, m);
         }
         if (j < n && probed) {
-            Rng rng; rng.init((uint64_t) (i0 + j), cx.jump);
-            float s3[3] = {rng.next(), rng.next(), rng.next()};
+            float s3[3];
+            if (gg.n > 0) { int cell; guide_slot_sample(gg, i0 + j, s3, cell); }
+            else {
+                Rng rng; rng.init((uint64_t) (i0 + j), cx.jump);
+                s3[0] = rng.next(); s3[1] = rng.next(); s3[2] = rng.next();
+            }
             if (guided) (void) guide_sample_reuse(cx.sc, s3);
             keep = secondary_edge_survives<FL>(cx.sc, st, s3, nrays);
         }
@@ -941,7 +969,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_secondary_edge_filter(LaunchCtx c
         // counter was the kernel -- a million same-address L2 atomics at 3-5 ns each on the C4 shard (4 of its 12 ms), 0.26 of 0.89 ms on C3
         const unsigned long long mask = __ballot(keep);
         if (mask != 0ull) {
-            if (keep) s_buf[wave][held + (int) __popcll(mask & ((1ull << lane) - 1ull))] = (uint32_t) j;
+            if (keep) s_buf[wave][held + (int) __popcll(mask & ((1ull << lane) - 1ull))] = (uint32_t) (list_base + j);
             held += (int) __popcll(mask);
         }
         if (held > kSeBuf - 64) flush();
@@ -1009,6 +1037,27 @@ __global__ __launch_bounds__(kBlock) void k_guide(LaunchCtx cx, int r0, int r1, 
         }
         if (nrounds > 1) acc /= (float) nrounds;
         if (acc != 0.f) atomicAdd(mass + cell, acc);
+    }
+    count_rays(counters, nrays);
+}
+
+// The guiding-grid build as filter + survivors (two-level scenes): the slots of ALL rounds pass the probe / dense trace / filter launches of the
+// secondary-edge term (a few per cent survive the first two rays of eval_secondary_edge); this kernel evaluates the survivors and adds their mass.
+template <int FL>
+__global__ __launch_bounds__(kBlock) void k_guide_survivors(LaunchCtx cx, GuideGrid gg, const uint32_t *__restrict__ list, const int *__restrict__ list_n, float *__restrict__ mass,
+                                                            unsigned long long *counters) {
+    TraversalStack st; setup_lds(cx, st);
+    uint32_t nrays = 0;
+    const TangentView<0, FL> tv0{};
+    const int n = *list_n;
+    for (int jj = blockIdx.x * kBlock + threadIdx.x; jj < n; jj += gridDim.x * kBlock) {
+        float s3[3]; int cell;
+        guide_slot_sample(gg, (long long) list[jj], s3, cell);
+        Vec3f v;
+        secondary_edge_sample<float>(cx.sc, tv0, st, s3, v, nrays, false);          // the filter traced (and counted) the first two rays
+        v = zero_nonfinite(v);
+        const float a = fmaxf(v.x, fmaxf(v.y, v.z)) * gg.scale;                     // hmax(value0 / per) / nrounds
+        if (a != 0.f) atomicAdd(mass + cell, a);
     }
     count_rays(counters, nrays);
 }
@@ -1538,6 +1587,7 @@ int run_camera(psdr_scene_s *h, const psdr_render_opts *o, const TV<R, FL> &tv, 
             const TangentView<0, FL> tv0{};
             TV<R, FL | kScenePre> tvp;
             for (int k = 0; k < (ad_traits<R>::K > 0 ? ad_traits<R>::K : 1); ++k) tvp.t[k] = tv.t[k];
+            tvp.live = tv.live;
             LaunchCtx cxp = cx;
             plan_lds(h, cxp, 1 << 30);
             cxp.sc.n_lnodes = cxp.sc.n_lbtris = cxp.sc.n_ltri = 0;
@@ -1791,11 +1841,16 @@ int run_camera_wavefront_geo(psdr_scene_s *h, const psdr_render_opts *o, const T
 }
 
 // Filter pass of a split secondary-edge launch: *list / *list_n on the device, nullptr when the launch is too small to split.
+// gg (guide_launch): the slots are those of a guiding-grid build.  On a two-level scene the pass runs as probe -> dense trace kernel -> filter on
+// primitives + hit rows, in CHUNKS of 2^25 slots that append to one list (the probe buffers are ~100 B per slot: 6.7 GB for the C4 shard in one piece --
+// ADVICE r4; a chunk's buffers are 3.3 GB and reused).
 template <int FL>
-int secondary_edge_filter(psdr_scene_s *h, const LaunchCtx &cx, long long i0, long long n, const uint32_t **list, const int **list_n, hipStream_t s) {
+int secondary_edge_filter(psdr_scene_s *h, const LaunchCtx &cx, long long i0, long long n, const uint32_t **list, const int **list_n, hipStream_t s, const GuideGrid *ggp = nullptr) {
     *list = nullptr; *list_n = nullptr;
+    const GuideGrid gg = ggp ? *ggp : GuideGrid{0, 0, 0, 0, 0, 0.f};
     const int split_env = h->opt.sedge_split;
-    if (split_env == 0 || (split_env < 0 && n < (1ll << 18)) || n > 0x7fffffffLL) return 0;
+    if (!ggp && (split_env == 0 || (split_env < 0 && n < (1ll << 18)))) return 0;
+    if (n > 0x7fffffffLL) return ggp ? fail("psdr_guide_build: more than 2^31 (stream, round) slots") : 0;
     const size_t need = 256 + (size_t) n * sizeof(uint32_t);
     if (int rc = scratch_reserve(&h->d_se_list, &h->se_list_bytes, need, s, "secondary-edge survivor list")) return rc;
     int *cnt = reinterpret_cast<int *>(h->d_se_list);
@@ -1804,27 +1859,49 @@ int secondary_edge_filter(psdr_scene_s *h, const LaunchCtx &cx, long long i0, lo
     if constexpr ((FL & kSceneForest) != 0) {
         if (traced_wavefront(h) && h->opt.probe != 0) {
             // traced launch: probe pass -> dense trace kernel -> the filter on primitives + hit rows (C4 shard: 12.2 ms as one kernel)
-            ProbeBuffers pb;
-            if (int rc = probe_buffers(h, n, 2, pb, s)) return rc;
             LaunchCtx cxp = cx;
             plan_lds(h, cxp, 1 << 30);
             cxp.sc.n_lnodes = cxp.sc.n_lbtris = cxp.sc.n_ltri = 0;
-            const TraceQueue tq{pb.req, pb.count, pb.sub_cap};
-            const int blocks = (launch_blocks(h, n) + kWfSub - 1) / kWfSub * kWfSub;
-            hipLaunchKernelGGL(k_se_probe<FL>, dim3(blocks), dim3(kBlock), cxp.off_stack, s, cxp, i0, n, tq, pb.mask);
-            HIP_TRY(hipGetLastError());
-            if (int rc = launch_wf_trace(h, pb.req, pb.count, pb.sub_cap, pb.hit, s, true)) return rc;
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_secondary_edge_filter<FL | kScenePre>), dim3(launch_blocks(h, n, big_launch_per_cu(h, n))), dim3(kBlock), cxp.off_stack, s, cxp, i0, n, lst, cnt, h->d_counters,
-                               ProbeView{pb.hit, pb.mask});
-            HIP_TRY(hipGetLastError());
+            const long long chunk = std::min<long long>(n, launch_chunk(h, 25));
+            for (long long c0 = 0; c0 < n; c0 += chunk) {
+                const long long nc = std::min(chunk, n - c0);
+                ProbeBuffers pb;
+                if (int rc = probe_buffers(h, nc, 2, pb, s)) return rc;
+                const TraceQueue tq{pb.req, pb.count, pb.sub_cap};
+                const int blocks = (launch_blocks(h, nc) + kWfSub - 1) / kWfSub * kWfSub;
+                hipLaunchKernelGGL(k_se_probe<FL>, dim3(blocks), dim3(kBlock), cxp.off_stack, s, cxp, i0 + c0, nc, tq, pb.mask, gg);
+                HIP_TRY(hipGetLastError());
+                if (int rc = launch_wf_trace(h, pb.req, pb.count, pb.sub_cap, pb.hit, s, true)) return rc;
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_secondary_edge_filter<FL | kScenePre>), dim3(launch_blocks(h, nc, big_launch_per_cu(h, nc))), dim3(kBlock), cxp.off_stack, s, cxp, i0 + c0, nc, lst, cnt,
+                                   h->d_counters, ProbeView{pb.hit, pb.mask}, gg, c0);
+                HIP_TRY(hipGetLastError());
+            }
             *list = lst; *list_n = cnt;
             return 0;
         }
     }
-    hipLaunchKernelGGL(k_secondary_edge_filter<FL>, dim3(launch_blocks(h, n)), dim3(kBlock), lds_bytes(cx, h), s, cx, i0, n, lst, cnt, h->d_counters, ProbeView{nullptr, nullptr});
+    hipLaunchKernelGGL(k_secondary_edge_filter<FL>, dim3(launch_blocks(h, n)), dim3(kBlock), lds_bytes(cx, h), s, cx, i0, n, lst, cnt, h->d_counters, ProbeView{nullptr, nullptr}, gg, 0ll);
     HIP_TRY(hipGetLastError());
     *list = lst; *list_n = cnt;
     return 0;
+}
+
+// One bit per triangle: does any of the K tangent sets move its tri_info row (TangentView::live)?  One thread per triangle, one ballot per wave.
+struct TangentRows { const float *p[3]; };
+__global__ __launch_bounds__(kBlock) void k_tangent_live(TangentRows tr, int K, int T, uint32_t *__restrict__ live) {
+    const int tri = blockIdx.x * kBlock + threadIdx.x;
+    bool any = false;
+    if (tri < T) {
+        for (int k = 0; k < K; ++k) {
+            const float *p = tr.p[k];
+            if (p == nullptr) continue;
+            const float4 *q = reinterpret_cast<const float4 *>(p + (size_t) tri * PSDR_TRI_STRIDE);
+#pragma unroll
+            for (int i = 0; i < PSDR_TRI_STRIDE / 4; ++i) { const float4 v = q[i]; any = any || v.x != 0.f || v.y != 0.f || v.z != 0.f || v.w != 0.f; }
+        }
+    }
+    const unsigned long long m = __ballot(any);
+    if ((threadIdx.x & 63) == 0 && tri < T) { live[tri >> 5] = (uint32_t) m; live[(tri >> 5) + 1] = (uint32_t) (m >> 32); }
 }
 
 template <int K, int FL>
@@ -1837,6 +1914,17 @@ int render_fwd(psdr_scene_s *h, const psdr_render_opts *o, const psdr_tangents *
     // geometry stays in plain fp32 when only material / emitter tables carry tangents
     bool geo = false;
     for (int k = 0; k < K; ++k) geo = geo || tangents[k].d_tri_info || tangents[k].d_cam_to_world;
+    if (geo && PSDR_TANGENT_LIVE && h->opt.tangent_live != 0) {
+        static_assert(K <= 3, "TangentRows holds three sets");
+        const int T = h->desc.num_tris;
+        const size_t need = ((size_t) (T + 63) / 64 * 2 + 2) * sizeof(uint32_t);
+        if (int rc = scratch_reserve(&h->d_live, &h->live_bytes, need, s, "tangent liveness mask")) return rc;
+        TangentRows tr{};
+        for (int k = 0; k < K; ++k) tr.p[k] = tangents[k].d_tri_info;
+        hipLaunchKernelGGL(k_tangent_live, dim3((unsigned) ((T + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, tr, K, T, reinterpret_cast<uint32_t *>(h->d_live));
+        HIP_TRY(hipGetLastError());
+        tv.live = reinterpret_cast<const uint32_t *>(h->d_live);
+    }
     bool geo_wavefront = false;
     if constexpr ((FL & kSceneForest) != 0) geo_wavefront = geo && h->opt.wf_geo != 0 && traced_wavefront(h) && use_wavefront(h, o);
     if (geo_wavefront) {
@@ -2107,6 +2195,19 @@ int render_rev(psdr_scene_s *h, const psdr_render_opts *o, const float *adj_img,
 
 template <int FL>
 int guide_launch(psdr_scene_s *h, LaunchCtx &cx, const int32_t reso[4], int nrounds, long long n, float *out_mass, hipStream_t s) {
+    // two-level scenes: all (stream, round) slots through the filter launches of the secondary-edge term (probe -> dense trace kernel -> filter), the
+    // survivors evaluated by k_guide_survivors -- k_guide walks the trees per lane for every one of its nrounds x 2+ rays although a few per cent of the
+    // samples get past the first two (the reference's size: 40000 x 5 x 5 cells x 2 streams x 32 rounds = 64 M samples on cbox_bunny)
+    if constexpr ((FL & kSceneForest) != 0) {
+        if (traced_wavefront(h) && h->opt.probe != 0 && n * (long long) nrounds <= 0x7fffffffLL && n * (long long) nrounds >= (1ll << 18)) {
+            const GuideGrid gg{reso[0], reso[1], reso[2], reso[3], (int) n, 1.f / ((float) reso[3] * (float) nrounds)};
+            const uint32_t *list = nullptr; const int *list_n = nullptr;
+            if (int rc = secondary_edge_filter<FL>(h, cx, 0, n * nrounds, &list, &list_n, s, &gg)) return rc;
+            hipLaunchKernelGGL(k_guide_survivors<FL>, dim3(launch_blocks(h, std::max(n * nrounds / 16, 1ll << 16))), dim3(kBlock), lds_bytes(cx, h), s, cx, gg, list, list_n, out_mass, h->d_counters);
+            HIP_TRY(hipGetLastError());
+            return 0;
+        }
+    }
     hipLaunchKernelGGL(k_guide<FL>, dim3(launch_blocks(h, n)), dim3(kBlock), lds_bytes(cx, h), s, cx, reso[0], reso[1], reso[2], reso[3], nrounds, n,
                        out_mass, h->d_counters);
     HIP_TRY(hipGetLastError());

@@ -243,6 +243,15 @@ struct Rng {
         state = j.mult * state + inc * j.plus_unit;
     }
 };
+// (mult, plus_unit) for a jump of `delta` draws (pcg32 advance with inc = 1), on the device too (log2(delta) steps)
+PSDR_HD RngJump rng_jump_hd(uint64_t delta) {
+    uint64_t cur_mult = Rng::MULT, cur_plus = 1, acc_mult = 1, acc_plus = 0;
+    while (delta > 0) {
+        if (delta & 1) { acc_mult *= cur_mult; acc_plus = acc_plus * cur_mult + cur_plus; }
+        cur_plus = (cur_mult + 1) * cur_plus; cur_mult *= cur_mult; delta >>= 1;
+    }
+    return {acc_mult, acc_plus};
+}
 // host: (mult, plus_unit) for a jump of `delta` draws (pcg32 advance with inc = 1)
 inline RngJump make_rng_jump(uint64_t delta) {
     uint64_t cur_mult = Rng::MULT, cur_plus = 1, acc_mult = 1, acc_plus = 0;

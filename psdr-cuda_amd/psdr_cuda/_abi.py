@@ -89,7 +89,17 @@ HIP_SYMBOLS = (
     "psdr_geo_compact_edges_fwd", "psdr_geo_compact_edges_rev", "psdr_geo_emitter_tables",
 )
 
-HIP_LIB_PATH = os.environ.get("PSDR_HIP_LIB") or os.path.join(PKG_ROOT, "lib", "libpsdr_hip.so")   # env override: kernel A/B experiments
+HIP_LIB_PATH = os.path.join(PKG_ROOT, "lib", "libpsdr_hip.so")   # the in-tree build; the package reads NO environment variable
+
+
+def use_library(path):
+    """Developer hook (tools/, tests/conftest.py: A/B runs of tools/build_variant_lib.sh builds): load THIS build of libpsdr_hip.so instead of the
+    in-tree one.  Must be called before the first render call of the process."""
+    global HIP_LIB_PATH
+    if _hip is not None:
+        raise RuntimeError("psdr_cuda._abi.use_library: the library is already loaded (%s)" % HIP_LIB_PATH)
+    HIP_LIB_PATH = os.path.abspath(path)
+
 
 _hip = None
 

@@ -19,7 +19,13 @@ def _stream():
 
 import os
 
-_enabled = os.environ.get("PSDR_NATIVE_TABLES", "1") != "0"          # 0: the eager torch chain everywhere (A/B, tools)
+_enabled = True          # set_enabled(False) (tests, tools): the eager torch chain everywhere.  The package reads no environment variable.
+
+
+def set_enabled(on):
+    """Test / tool hook: False = Scene.configure() builds the triangle / edge tables with the eager torch chain instead of the psdr_geo_* kernels."""
+    global _enabled
+    _enabled = bool(on)
 
 
 def available(t):

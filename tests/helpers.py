@@ -12,6 +12,11 @@ from enoki._array import _jvp_wrt
 from enoki.cuda_autodiff import Float32 as FloatD, Vector3f as Vector3fD, Matrix4f as Matrix4fD
 from psdr_cuda import _abi
 from psdr_cuda.fixtures import scene_path
+
+# developer switch of the TEST / TOOL drivers (the package itself reads no environment variable): PSDR_HIP_LIB=<path> runs the tests and tools on
+# another build of the library (tools/build_variant_lib.sh: A/B runs inside one gpurun call)
+if os.environ.get("PSDR_HIP_LIB") and _abi._hip is None:
+    _abi.use_library(os.environ["PSDR_HIP_LIB"])
 from psdr_cuda.scene import make_desc
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
