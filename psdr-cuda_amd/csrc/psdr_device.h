@@ -670,7 +670,7 @@ template <class R> PSDR_HD void moeller_trumbore(const Vec3<R> &p0, const Vec3<R
 }
 
 enum HitForm { kDetached = 0, kPathSpace = 1, kSolidAngle = 2 };
-template <class R, class TVT> PSDR_HD Its<R> its_from_hit(const SceneView &sc, const TVT &tv, const Hit &h, const RayT<R> &ray, HitForm form);
+template <class R, class TVT> PSDR_HD void fill_its_from_hit(Its<R> &its, const SceneView &sc, const TVT &tv, const Hit &h, const RayT<R> &ray, HitForm form);
 
 // Scene::ray_intersect<ad, path_space> (src/scene/scene.cpp:290-384)
 //   kDetached  : C types; barycentrics from the traversal, J = 1
@@ -687,14 +687,20 @@ template <class R, class TVT> PSDR_HD Its<R> intersect(const SceneView &sc, cons
     const Hit h = (ig0 >= 0 || ig1 >= 0) ? closest_hit<true, F>(sc, st, val(ray.o), val(ray.d), INFINITY, ig0, ig1, pre_slot)
                                          : closest_hit<false, F>(sc, st, val(ray.o), val(ray.d), INFINITY, -1, -1, pre_slot);
     if (h.tri < 0) return its;
-    return its_from_hit<R>(sc, tv, h, ray, form);
+    fill_its_from_hit<R>(its, sc, tv, h, ray, form);
+    return its;
 }
 // The hit record of a KNOWN hit (triangle + traversal barycentrics): everything intersect() derives behind its closest_hit.  The geometry-dual
 // stages of the traced wavefront rebuild a path vertex with it from its stream record -- the same arithmetic, hence the same vertex and tangents,
-// as the fused kernel's `its = nits`.
+// as the fused kernel's `its = nits`.  (intersect() fills ITS OWN record through fill_its_from_hit: with a second record returned by value the
+// compiler kept parts of it in scratch -- 21 scratch instructions in the C2 renderC kernel, +2.4 % instructions, 4x the counter traffic.)
 template <class R, class TVT> PSDR_HD Its<R> its_from_hit(const SceneView &sc, const TVT &tv, const Hit &h, const RayT<R> &ray, HitForm form) {
     Its<R> its;
     its.J = R(1.f); its.t = R(INFINITY);
+    fill_its_from_hit<R>(its, sc, tv, h, ray, form);
+    return its;
+}
+template <class R, class TVT> PSDR_HD void fill_its_from_hit(Its<R> &its, const SceneView &sc, const TVT &tv, const Hit &h, const RayT<R> &ray, HitForm form) {
     its.valid = true; its.tri = h.tri; its.hu = h.u; its.hv = h.v;
     const int tm = Tab<TVT::flags>::tri_mesh(sc, h.tri);
     its.mesh = tm & ~PSDR_TRI_FACE_NORMALS;
@@ -730,7 +736,6 @@ template <class R, class TVT> PSDR_HD Its<R> its_from_hit(const SceneView &sc, c
         its.uvx = (q[2] - q[0]) * bu + ((q[4] - q[0]) * bv + q[0]);
         its.uvy = (q[3] - q[1]) * bu + ((q[5] - q[1]) * bv + q[1]);
     } else { its.uvx = R(0.f); its.uvy = R(0.f); }
-    return its;
 }
 
 // Path vertex rebuilt from its stream record (wavefront mode): triangle id, detached barycentrics and
@@ -1146,9 +1151,31 @@ struct LiParams {                 // uniform per launch
 // next_* report the FIRST BSDF-sampled vertex so the build-defined PathTracer can
 // continue the path from it.  The D-mode forms (path-space hits, BSDF re-evaluated from the hit
 // points, detached G in the pdfs) are used whenever the result type M carries tangents.
-template <class G, class M, class TVT>
+// NI: the record type the caller wants the BSDF-sampled next vertex in -- Its<G> (the fused kernels continue the path from it), or Its<float> where only
+// its plain values are needed (the geometry-dual stages of the traced wavefront: a 196-byte Its<Dual<1>> handed out through the pointer went through
+// scratch, store and reload: 300 B of scratch traffic per record, 20 of the stage's 30 GB)
+// Member-wise copy of a hit record (scalars only).  `*next = its1` on an Its<Dual<K>> is lowered to a 196-byte memcpy that the optimiser does NOT split
+// into registers again: the record went to scratch and came back (12 scratch_store_dwordx4 + ~25 loads per path vertex of every geometry-dual kernel).
+template <class R> PSDR_HD void copy_its(Its<R> &d, const Its<R> &a) {
+    d.valid = a.valid; d.tri = a.tri; d.mesh = a.mesh; d.hu = a.hu; d.hv = a.hv;
+    d.wi.x = a.wi.x; d.wi.y = a.wi.y; d.wi.z = a.wi.z; d.p.x = a.p.x; d.p.y = a.p.y; d.p.z = a.p.z; d.n.x = a.n.x; d.n.y = a.n.y; d.n.z = a.n.z;
+    d.t = a.t; d.J = a.J; d.uvx = a.uvx; d.uvy = a.uvy;
+    d.sh.s.x = a.sh.s.x; d.sh.s.y = a.sh.s.y; d.sh.s.z = a.sh.s.z; d.sh.t.x = a.sh.t.x; d.sh.t.y = a.sh.t.y; d.sh.t.z = a.sh.t.z;
+    d.sh.n.x = a.sh.n.x; d.sh.n.y = a.sh.n.y; d.sh.n.z = a.sh.n.z;
+}
+template <class NI, class G> PSDR_HD NI its_cast(const Its<G> &a) {
+    if constexpr (std::is_same<NI, Its<G>>::value) { if constexpr (is_ad<G>()) { NI r; copy_its(r, a); return r; } else return a; }
+    else {
+        Its<float> r;
+        r.valid = a.valid; r.tri = a.tri; r.mesh = a.mesh; r.hu = a.hu; r.hv = a.hv;
+        r.wi = val(a.wi); r.p = val(a.p); r.n = val(a.n); r.t = val(a.t); r.J = val(a.J); r.uvx = val(a.uvx); r.uvy = val(a.uvy);
+        r.sh.s = val(a.sh.s); r.sh.t = val(a.sh.t); r.sh.n = val(a.sh.n);
+        return r;
+    }
+}
+template <class G, class M, class TVT, class NI = Its<G>>
 PSDR_HD Vec3<M> direct_step(const SceneView &sc, const TVT &tv, TraversalStack &st, Rng &rng, const Its<G> &its, bool active, int nB,
-                            int nL, uint32_t &nrays, Its<G> *next_its, Vec3<M> *next_f, bool *next_valid, int *light_tri = nullptr) {
+                            int nL, uint32_t &nrays, NI *next_its, Vec3<M> *next_f, bool *next_valid, int *light_tri = nullptr) {
     constexpr bool ad = is_ad<M>();
     constexpr HitForm form = is_ad<G>() ? kPathSpace : kDetached;
     Vec3<M> result = zero3<M>();
@@ -1184,7 +1211,7 @@ PSDR_HD Vec3<M> direct_step(const SceneView &sc, const TVT &tv, TraversalStack &
             if (nL > 0) w = w * mis_weight(pdf0, M(emitter_position_pdf(sc, tv, val(its.p), its1)));
             result = result + Le<M>(sc, tv, its1, true) * bsdf_val * w;
         }
-        if (next_its && i == 0) { *next_its = its1; *next_f = bsdf_val; *next_valid = a_hit; }
+        if (next_its && i == 0) { *next_its = its_cast<NI>(its1); *next_f = bsdf_val; *next_valid = a_hit; }
     };
     auto light_sample = [&](float s0, float s1, int i) {
         const PosSample<G> ps = sample_emitter_position<G>(sc, tv, val(its.p), s0, s1, is_ad<G>());
@@ -1256,7 +1283,7 @@ PSDR_HD Vec3<M> Li(const SceneView &sc, const TVT &tv, TraversalStack &st, const
     }
     Vec3<M> result = lp.hide_emitters ? zero3<M>() : Le<M>(sc, tv, its, active);
     if (integ == PSDR_INTEGRATOR_DIRECT)
-        return result + direct_step<G, M>(sc, tv, st, rng, its, active, lp.bsdf_samples, lp.light_samples, nrays, nullptr, nullptr, nullptr);
+        return result + direct_step<G, M>(sc, tv, st, rng, its, active, lp.bsdf_samples, lp.light_samples, nrays, (Its<G> *) nullptr, nullptr, nullptr);
     Vec3<M> beta(1.f);
     for (int depth = 0; depth < lp.max_depth; ++depth) {
         Its<G> nits; Vec3<M> nf; bool nvalid = false;
@@ -1265,7 +1292,8 @@ PSDR_HD Vec3<M> Li(const SceneView &sc, const TVT &tv, TraversalStack &st, const
             result = result + beta * c;
             active = nvalid;
             if (active) {
-                beta = beta * nf; its = nits;
+                beta = beta * nf;
+                if constexpr (is_ad<G>()) copy_its(its, nits); else its = nits;          // (member-wise: see copy_its)
                 const Vec3f b = val(beta);
                 if (!(b.x != 0.f || b.y != 0.f || b.z != 0.f)) active = false;
             }

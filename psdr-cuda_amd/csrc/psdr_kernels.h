@@ -760,8 +760,8 @@ __global__ __launch_bounds__(kBlock, (wfg_waves<FL>())) void k_wfg_bounce(Launch
                 its = its_from_hit<G>(cx.sc, tvp, hk, ray, kPathSpace);
             }
             Rng rng; rng.init((uint64_t) slot, cx.jump);
-            Its<G> next; Vec3<M> f = zero3<M>(); bool nvalid = false;
-            const Vec3<M> c = direct_step<G, M>(cx.sc, tvp, st, rng, its, true, 1, 1, nrays, &next, &f, &nvalid);
+            Vec3<M> f = zero3<M>(); bool nvalid = false;
+            const Vec3<M> c = direct_step<G, M>(cx.sc, tvp, st, rng, its, true, 1, 1, nrays, &nextf, &f, &nvalid);          // the next vertex as plain values (its_cast)
             rng_next = rng;
             r = acc + beta * c;
             alive = nvalid;
@@ -769,7 +769,7 @@ __global__ __launch_bounds__(kBlock, (wfg_waves<FL>())) void k_wfg_bounce(Launch
                 beta = beta * f;
                 const Vec3f b = val(beta);
                 alive = b.x != 0.f || b.y != 0.f || b.z != 0.f;
-                nextf = detach_its(next); prevp = its.p;
+                prevp = its.p;
             }
         }
         const bool goes_on = want_next && alive;
