@@ -1421,8 +1421,10 @@ PSDR_HD int primary_edge_sample(const SceneView &sc, const TangentView<K, FL> &t
     const float px = pe[0] * (1.f - u) + pe[2] * u, py = pe[1] * (1.f - u) + pe[3] * u;
     const int W = sc.d.width, H = sc.d.height;
     const int ix = (int) floorf(px * (float) W), iy = (int) floorf(py * (float) H);
-    // (pmf > 0: a table built on the device keeps the capacity of the candidate list, zero rows behind the kept ones -- never drawn unless NO edge is kept)
-    bool valid = ix >= 0 && ix < W && iy >= 0 && iy < H && pmf > 0.f;
+    // (pmf > 0: a table built on the device keeps the capacity of the candidate list, zero rows behind the kept ones -- never drawn unless NO edge is kept;
+    //  pe[6] > 0: a capacity-ONE table whose only candidate was dropped still "draws" its zero row with pmf 1 -- sample_reuse's size == 1 shortcut -- and its
+    //  length 0 would make the pdf infinite: ADVICE r4)
+    bool valid = ix >= 0 && ix < W && iy >= 0 && iy < H && pmf > 0.f && pe[6] > 0.f;
     const TangentView<0, FL> tv0{};
     if (sc.d.prim_edge_z != nullptr && valid) valid = primary_edge_point_visible(sc, tv0, st, k, u, px, py, nrays);
     // Li on the two sides of the edge (ray_n first, then ray_p: the order the reference draws them in,

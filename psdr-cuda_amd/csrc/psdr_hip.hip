@@ -956,6 +956,7 @@ int psdr_scene_set_option(psdr_scene_t h, const char *name, double value) {
     else if (n == "rev_split") h->opt.rev_split = iv;
     else if (n == "tangent_live") h->opt.tangent_live = iv;              // 0: forward-mode kernels load the tangents of every triangle row (no liveness mask)
     else if (n == "wf_geo") h->opt.wf_geo = iv;                          // 0: geometry tangents of the PathTracer always through the fused kernel
+    else if (n == "rev_sorted") h->opt.rev_sorted = iv;                  // 0: the reverse camera kernels scatter every row adjoint on the spot (no deferred, sorted adds)
     else if (n == "rev_vertex") h->opt.rev_vertex = iv;                  // 1: the adjoint sweep of a split PathTracer launch as a launch per path vertex (default 0: one adjoint kernel)
     else if (n == "vrev_blocks") h->opt.vrev_blocks = iv;                // workgroups per CU of the per-vertex adjoint launches (0: default)
     else if (n == "sedge_split") h->opt.sedge_split = iv;

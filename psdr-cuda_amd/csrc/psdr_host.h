@@ -138,7 +138,10 @@ struct SinkLayout {
     int priv_off, priv_rows;                 // priv_rows = 0: off
     int priv_tri[2], priv_slot[2], priv_emitter;
     int priv_regs;                           // 1: the kernel keeps these accumulators in REGISTERS (psdr_kernels.h RegPrivSink): no LDS block behind the cache
+    // deferred row adjoints (DeviceSink::defer_row): pend_rows columns of kPendWords words per lane behind everything else (0: off -- rows are scattered on the spot)
+    int pend_off, pend_rows;
 };
+constexpr int kPendWords = 10;               // triangle, (u, v), position (3), face normal (3), area
 constexpr int kPrivRowWords = 13;            // position (p0, e1, e2: 9), face normal (3), area (1)
 constexpr int kPrivWords = 2 * kPrivRowWords + 3;
 
@@ -156,6 +159,7 @@ struct psdr_scene_options {
     int rev_split = -1;                    // reverse mode as value kernel + adjoint kernel: 1 / 0 force, -1 by scene and launch size
     int tangent_live = 1;                  // forward mode with geometry tangents: one bit per triangle "some tangent set moves this row" (TangentView::live); 0: every row loads its tangents
     int wf_geo = 1;                        // PathTracer forward mode with geometry tangents on a two-level scene as the traced wavefront (k_wfg_*); 0: the fused kernel
+    int rev_sorted = 1;                    // reverse camera kernels with geometry gradients: complete row adjoints wait in LDS and leave sorted by row at the slot's end (0: scattered on the spot)
     int rev_vertex = 0;                    // 1: adjoint sweep of a split PathTracer launch as one launch per path vertex (k_vertex_rev, round 5: built, measured SLOWER than the
                                            // one adjoint kernel on C2 / C4 / C5 -- DESIGN.md round 5 -- and kept as an option); 0: one adjoint kernel
     int vrev_blocks = 0;                   // workgroups per CU of those launches (0: 16)
@@ -291,7 +295,10 @@ int launch_wf_trace(psdr_scene_s *h, const float4 *req, const int32_t *count, lo
 struct ProbeBuffers { float4 *hit; uint32_t *mask; float4 *req; int32_t *count; long long sub_cap; };
 int probe_buffers(psdr_scene_s *h, long long slots, int rays_per_slot, ProbeBuffers &pb, hipStream_t s, int per_cu = 16);   // per_cu: workgroups per CU of the probe launch (sizes the request queues)
 SinkLayout make_sink_layout(const psdr_scene_s *h, const psdr_grads *g);
-inline int sink_bytes(const SinkLayout &L) { return (L.priv_rows > 0 && !L.priv_regs) ? (L.priv_off + kPrivWords * kBlock) * 4 : (L.rep * L.stride * 4 + 15) / 16 * 16; }
+inline int sink_bytes_base(const SinkLayout &L) { return (L.priv_rows > 0 && !L.priv_regs) ? (L.priv_off + kPrivWords * kBlock) * 4 : (L.rep * L.stride * 4 + 15) / 16 * 16; }
+inline int sink_bytes(const SinkLayout &L) { return L.pend_rows > 0 ? (L.pend_off + L.pend_rows * kPendWords * kBlock) * 4 : sink_bytes_base(L); }
+// reserve the deferred-row block behind the cache and the private block: call when the layout is otherwise final
+inline void sink_reserve_pending(SinkLayout &L, int rows) { L.pend_rows = 0; L.pend_off = (sink_bytes_base(L) / 4 + 3) / 4 * 4; L.pend_rows = rows; }
 int check_counts(const psdr_scene_s *h, const psdr_render_opts *o);
 int begin_call(psdr_scene_s *h, hipStream_t s);
 int primary_edge_order(psdr_scene_s *h, const LaunchCtx &cx, long long i0, long long n, const uint32_t **order, hipStream_t s);

@@ -1135,13 +1135,30 @@ template <int FL> struct DeviceSink {
         if (L.rad_n) lds_add(lds + L.rad_off + e * 3 + c, v); else atomicAdd(g.g_emitter_rad + e * 3 + c, v);
     }
     __device__ __forceinline__ void add_cam(int word, float v) { if (ok(v)) cam[word] += v; }
+    // Complete row adjoints wait in a per-lane LDS column (plain stores, one column per lane: conflict-free) until the kernel's convergent point, where
+    // flush_pending_wave adds them sorted by row (sink_add_row_wave).  L.pend_rows == 0 (the launch reserved no block) or a full column: scatter now.
+    int n_pending;
+    __device__ __forceinline__ void defer_row(int tri, float u, float v, const RowAdj &r) {
+        if (g.g_tri_info == nullptr) return;
+        if (L.pend_rows == 0 || n_pending >= L.pend_rows) {
+            // (as scatter_row, spelled out: psdr_reverse.h's template is declared behind this header's includes)
+            const float w[kPrivRowWords] = {r.p.x, r.p.y, r.p.z, u * r.p.x, u * r.p.y, u * r.p.z, v * r.p.x, v * r.p.y, v * r.p.z, r.fn.x, r.fn.y, r.fn.z, r.area};
+#pragma unroll
+            for (int i = 0; i < kPrivRowWords; ++i) add_tri(tri, i < 9 ? i : i + 9, w[i]);
+            return;
+        }
+        lds_float *q = lds0 + L.pend_off + threadIdx.x + n_pending * (kPendWords * kBlock);
+        q[0] = __int_as_float(tri); q[kBlock] = u; q[2 * kBlock] = v;
+        q[3 * kBlock] = r.p.x; q[4 * kBlock] = r.p.y; q[5 * kBlock] = r.p.z; q[6 * kBlock] = r.fn.x; q[7 * kBlock] = r.fn.y; q[8 * kBlock] = r.fn.z; q[9 * kBlock] = r.area;
+        ++n_pending;
+    }
     __device__ __forceinline__ void add_env(int word, float v) const { if (L.env_n && ok(v)) lds_add(lds + L.env_off + word, v); }
     __device__ __forceinline__ void add_sedge(int e, int word, float v) const { glob(g.g_sec_edge, (size_t) e * PSDR_SEDGE_STRIDE + word, v); }
     __device__ __forceinline__ void add_pedge(int e, int word, float v) const { glob(g.g_prim_edge, (size_t) e * PSDR_PEDGE_STRIDE + word, v); }
 
     __device__ __forceinline__ void begin(float *cache) {
         lds0 = (lds_float *) cache;
-        last_tri = -1; last_slot = -1;
+        last_tri = -1; last_slot = -1; n_pending = 0;
         lds = lds0 + (threadIdx.x & (L.rep - 1)) * L.stride;
         for (int i = threadIdx.x; i < L.rep * L.stride; i += kBlock) lds0[i] = 0.f;
         priv = lds0 + L.priv_off + threadIdx.x;
@@ -1251,6 +1268,9 @@ template <int FL> struct RegPrivSink : DeviceSink<FL> {
         Base::end();
     }
 };
+// (Measured and dropped, round 5: the texel triples of the material-only reverse kernels summed per vertex in registers, parked in a per-lane LDS column and
+// added sorted by texel at the slot's end -- TexDeferSink.  The texel kernel sits on a spill cliff at five waves: the five registers of the open entry alone took
+// C2's texel gradient from 2.05 to 2.45 ms with the deferral switched OFF at run time, 2.96 ms with it on: profiles/r05_rev_sorted_abk.txt.)
 // which kernels keep them in registers: the host (render_rev) sets SinkLayout::priv_regs by the same rule
 // (not the rough-conductor instances: their adjoint kernel already fills 256 VGPRs and spilled 180 more with the accumulators: C5 7.75 -> 8.27 ms.
 // The wrong camera gradient round 3 saw in that configuration was the compiler's spill-placement defect, DESIGN.md "the order-dependent gradient")
@@ -1321,6 +1341,8 @@ __global__ __launch_bounds__(kBlock, (STAGE == 1 ? PSDR_WAVES_REV_VALUE : rev_wa
                 for (int w = 0; w < kPrimaryWords; ++w) sink.add_tri(pg.tri, w, pg.w[w]);
             }
         }
+        // the complete row adjoints of this slot's path vertices (camera_sample_reverse -> complete_row -> DeviceSink::defer_row), sorted by row
+        if constexpr (STAGE != 1 && GEO) sink_flush_pending_wave(sink);
         if (STAGE != 2 && img != nullptr) {
             const bool head = wave_segmented_sum<3>(pixel, v);
             if (head && in) {
@@ -1421,6 +1443,23 @@ template <class S> __device__ __forceinline__ void sink_add_texel3_wave(S &sink,
         const float t = ws.total(valid ? S::finite(tex[c]) : 0.f);
         if (ws.tail && t != 0.f) S::lds_add(sink.lds + sink.L.tex_off + (ws.skey - 1) + c, t);
     }
+}
+
+// The rows a lane deferred during its slot (DeviceSink::defer_row), added sorted by row at the kernel's convergent point: round r takes every lane's r-th row.
+template <class S> __device__ __forceinline__ void sink_flush_pending_wave(S &sink) {
+    if (sink.L.pend_rows == 0) return;
+    for (int r = 0; r < sink.L.pend_rows; ++r) {
+        const bool has = r < sink.n_pending;
+        if (__ballot(has) == 0ull) break;
+        int tri = -1; float u = 0.f, v = 0.f; RowAdj row; row.clear();
+        if (has) {
+            const typename S::lds_float *q = sink.lds0 + sink.L.pend_off + threadIdx.x + r * (kPendWords * kBlock);
+            tri = __float_as_int(q[0]); u = q[kBlock]; v = q[2 * kBlock];
+            row.p.x = q[3 * kBlock]; row.p.y = q[4 * kBlock]; row.p.z = q[5 * kBlock]; row.fn.x = q[6 * kBlock]; row.fn.y = q[7 * kBlock]; row.fn.z = q[8 * kBlock]; row.area = q[9 * kBlock];
+        }
+        sink_add_row_wave(sink, tri, u, v, row);
+    }
+    sink.n_pending = 0;
 }
 
 // The adjoint sweep of a split PathTracer launch, ONE PATH VERTEX PER LAUNCH (psdr_reverse.h vertex_reverse_first / _next): launch k
@@ -2017,6 +2056,20 @@ int render_rev(psdr_scene_s *h, const psdr_render_opts *o, const float *adj_img,
             const int floor_bytes = (split ? base2 : plan_lds(h, probe, 1 << 30)) + rec_bytes;                  // (tables +) stacks only + record
             if (!sink.L.priv_regs && sink.L.priv_rows > 0 && floor_bytes + sink_bytes(sink.L) > h->lds_limit / wg_per_cu) { sink.L.priv_rows = 0; sink.L.priv_emitter = -1; }
         }
+        // deferred row adjoints (DeviceSink::defer_row -> sorted adds at the slot's end): one column per path vertex behind the primary one, where the
+        // block does not cost a resident workgroup
+        sink.L.pend_rows = 0; sink.L.pend_off = 0;
+        // (rows: measured on the PathTracer only -- C2 all gradients 5.28 -> 4.99 ms, the C4 shard's adjoint kernel 19.5 -> 18.7; the DirectIntegrator's
+        // single deferred row is level to 3 % slower: profiles/r05_rev_sorted_abk.txt)
+        if (geo && h->opt.rev_sorted != 0 && !vrev && grads->g_tri_info != nullptr && o->integrator == PSDR_INTEGRATOR_PATH) {
+            LaunchCtx probe = cx;
+            const int floor_bytes = (split ? base2 : plan_lds(h, probe, 1 << 30)) + rec_bytes;
+            for (int rows = std::min(depth, 4); rows >= 1; --rows) {
+                SinkLayout t = sink.L;
+                sink_reserve_pending(t, rows);
+                if (floor_bytes + sink_bytes(t) <= h->lds_limit / wg_per_cu) { sink.L = t; break; }
+            }
+        }
         const int cache_bytes = sink_bytes(sink.L);
         plan_lds(h, cx, split ? rec_bytes : rec_bytes + cache_bytes);   // stage less of the scene: the record (+ cache) live in LDS too
         cx.off_pathrec = lds_bytes(cx, h);
@@ -2174,6 +2227,7 @@ int render_rev(psdr_scene_s *h, const psdr_render_opts *o, const float *adj_img,
         const long long i0 = WH * o->sppse_begin, n = WH * (o->sppse_end - o->sppse_begin);
         h->slots[2] += (uint64_t) n;
         sink.L.priv_rows = 0; sink.L.priv_emitter = -1;            // boundary samples land on the emitter once per slot: no private rows
+        sink.L.pend_rows = 0; sink.L.pend_off = 0;                 // (nothing deferred in this kernel)
         const int cache_bytes = sink_bytes(sink.L);
         plan_lds(h, cx, cache_bytes);
         cx.off_sink = lds_bytes(cx, h);

@@ -80,6 +80,15 @@ template <class Sink> PSDR_HD void scatter_row(Sink &sink, int tri, float u, flo
     sink.add_tri(tri, 21, aarea);
 }
 
+// A sink may DEFER a complete row adjoint to a convergent point of its kernel (DeviceSink::defer_row: the row waits in a per-lane LDS column and
+// leaves sorted by row with the other lanes' rows, psdr_kernels.h sink_add_row_wave); every other sink scatters it on the spot.
+template <class Sink, class = void> struct SinkDefersRows : std::false_type {};
+template <class Sink> struct SinkDefersRows<Sink, std::void_t<decltype(std::declval<Sink &>().defer_row(0, 0.f, 0.f, std::declval<const RowAdj &>()))>> : std::true_type {};
+template <class Sink> PSDR_HD void complete_row(Sink &sink, int tri, float u, float v, const RowAdj &r) {
+    if constexpr (SinkDefersRows<Sink>::value) sink.defer_row(tri, u, v, r);
+    else scatter_row(sink, tri, u, v, r.p, r.fn, r.area);
+}
+
 // Gradient sink interface (duck-typed): add_tri(tri, word, g), add_texel(idx, g), add_rad(e, c, g),
 // add_cam(word, g), add_sedge(edge, word, g), add_pedge(edge, word, g).
 
@@ -1020,9 +1029,9 @@ PSDR_HD Vec3f camera_sample_reverse(RealSink &real_sink, PrimaryGrad &pg, PathRe
     {
         Its<float> cur = its;
         Vec3f beta(1.f);
-        Vec3f prev_p = its.p;        // vertex k-1: position and where its pending point adjoint goes
+        Vec3f prev_p = its.p;        // vertex k-1: position and where its pending row adjoint goes
         int prev_tri = -1; float prev_u = 0.f, prev_v = 0.f;
-        Vec3f pend_p(0.f);           // adjoint of p_{k-1} still waiting for the direction chain of vertex k
+        RowAdj pend; pend.clear();            // row adjoint of vertex k-1, complete but for the position adjoint the direction chain of vertex k sends back
         RowAdj row_cur; row_cur.clear();      // row of vertex k, fed by the BSDF sample of iteration k-1
         for (int k = 0; k < nv; ++k) {
             const Vec3f a_c = adj * beta;
@@ -1032,15 +1041,16 @@ PSDR_HD Vec3f camera_sample_reverse(RealSink &real_sink, PrimaryGrad &pg, PathRe
             const VertexOut vo = replay ? vertex_eval<true, true, SweepSink>(sweep, sc, st, rng, cur, nB, nL, a_c, a_f, k == 0 ? va0 : va, nrays, rec, k, &row_next)
                                         : vertex_eval<true, false, SweepSink>(sweep, sc, st, rng, cur, nB, nL, a_c, a_f, k == 0 ? va0 : va, nrays, rec, k, &row_next);
             if (k >= 1) {
+                // a vertex' row leaves ONCE and COMPLETE (position, face normal, area: complete_row) -- one iteration late, when its successor's direction
+                // chain has sent its position adjoint back; a sink that defers rows (DeviceSink) adds them sorted by row at the kernel's convergent point
                 const Vec3f a_prev = path_vertex_backward(sweep, sc, cur, prev_p, va, row_cur);
                 if (k == 1) acc(va0.p, a_prev);
-                else { acc_finite(pend_p, a_prev); scatter_point(sweep, prev_tri, prev_u, prev_v, pend_p); }
-                flush_row_normal_area(sweep, cur.tri, row_cur);
-                pend_p = row_cur.p;
+                else { acc_finite(pend.p, a_prev); complete_row(sweep, prev_tri, prev_u, prev_v, pend); }
+                pend = row_cur;
             }
             if (!vo.next_valid || k + 1 >= nv) {
-                if (k >= 1) scatter_point(sweep, cur.tri, cur.hu, cur.hv, pend_p);
-                if (vo.next_valid) scatter_row(sweep, vo.next.tri, vo.next.hu, vo.next.hv, row_next.p, row_next.fn, row_next.area);
+                if (k >= 1) complete_row(sweep, cur.tri, cur.hu, cur.hv, pend);
+                if (vo.next_valid) complete_row(sweep, vo.next.tri, vo.next.hu, vo.next.hv, row_next);
                 break;
             }
             beta = beta * vo.f;
@@ -1342,7 +1352,7 @@ PSDR_HD int primary_edge_reverse_values(const SceneView &sc, TraversalStack &st,
     const float px = pe[0] * (1.f - u) + pe[2] * u, py = pe[1] * (1.f - u) + pe[3] * u;
     const int W = sc.d.width, H = sc.d.height;
     const int ix = (int) floorf(px * (float) W), iy = (int) floorf(py * (float) H);
-    bool valid = ix >= 0 && ix < W && iy >= 0 && iy < H && pmf > 0.f;          // (pmf > 0: see primary_edge_sample)
+    bool valid = ix >= 0 && ix < W && iy >= 0 && iy < H && pmf > 0.f && pe[6] > 0.f;          // (pmf > 0, length > 0: see primary_edge_sample)
     const TangentView<0, FL> tv0{};
     if (sc.d.prim_edge_z != nullptr && valid) valid = primary_edge_point_visible(sc, tv0, st, k, u, px, py, nrays);
     Vec3f L2[2];

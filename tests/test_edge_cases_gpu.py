@@ -349,3 +349,33 @@ def test_capacity_edge_table_without_a_kept_edge_renders_zeros_not_nan():
     _, gi = g.render_d_rev(o_int, adj, want=["tri_info"], with_image=False)
     assert all(np.isfinite(v).all() for v in ga.values())
     assert np.abs(ga["sec_edge"]).max() == 0 and np.abs(ga["prim_edge"]).max() == 0 and rel_l2(ga["tri_info"], gi["tri_info"]) < 1e-6
+
+
+def test_capacity_ONE_edge_tables_whose_only_candidate_was_dropped():
+    """ADVICE r4: with ONE candidate edge and none kept, DiscreteDistribution::sample_reuse takes its size == 1 shortcut and "draws" the zero row with
+    pmf 1 -- the primary-edge kernels must not turn its zero length into an infinite pdf (primary_edge_sample: length > 0), the zero secondary-edge row
+    fails its own validity test.  Forward and reverse: the interior term alone, finite."""
+    sc, P = load_scene("cbox_bunny", res=32, spp=2, sppe=4, sppse=4, translate=(1, (1.0, 0.5, 0.0)))
+    from helpers import tangents_wrt
+    tb = dict(sc.tables(0, capacity=True))
+    tan = dict(tangents_wrt(tb, P))
+    tb["prim_edge"] = torch.zeros_like(tb["prim_edge"][:1].detach()); tb["prim_pmf"] = torch.zeros(1); tb["prim_cmf"] = torch.ones(1); tb["num_prim_edges"] = 1
+    tb["sec_edge"] = torch.zeros_like(tb["sec_edge"][:1].detach()); tb["sec_pmf"] = torch.zeros(1); tb["sec_cmf"] = torch.ones(1); tb["num_sec_edges"] = 1
+    if tb.get("prim_edge_z") is not None:
+        tb["prim_edge_z"] = tb["prim_edge_z"][:1]
+    if tb.get("sec_edge_faces") is not None:
+        tb["sec_edge_faces"] = tb["sec_edge_faces"][:1]
+    for k in ("prim_edge", "sec_edge"):
+        if tan.get(k) is not None:
+            tan[k] = tan[k][:1]
+    o_all = _abi.make_opts(spp=2, sppe=4, sppse=4, bsdf_samples=1, light_samples=1)
+    o_int = _abi.make_opts(spp=2, sppe=0, sppse=0, bsdf_samples=1, light_samples=1)
+    g = GpuScene(tb)
+    _, d_all = g.render_d_fwd(o_all, [tan])
+    _, d_int = g.render_d_fwd(o_int, [tan])
+    assert np.isfinite(d_all[0]).all() and np.abs(d_int[0]).max() > 0
+    assert np.array_equal(d_all[0], d_int[0])
+    adj = np.random.default_rng(0).random((32 * 32, 3)).astype(np.float32)
+    _, ga = g.render_d_rev(o_all, adj, want=["tri_info", "sec_edge", "prim_edge"], with_image=False)
+    assert all(np.isfinite(v).all() for v in ga.values())
+    assert np.abs(ga["sec_edge"]).max() == 0 and np.abs(ga["prim_edge"]).max() == 0

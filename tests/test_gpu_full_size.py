@@ -110,6 +110,33 @@ def test_c4_one_gpu_share_of_1024x1024_spp512():
     assert bad.mean() < 0.005 and rel_l2(a[~bad], b[~bad]) < 1e-3, (bad.mean(), rel_l2(a[~bad], b[~bad]))
 
 
+def test_c4_share_path_tracer_geometry_duals_at_full_size():
+    """BASELINE config 4's PathTracer with the reference harness' AD mode (renderD + enoki.forward w.r.t. a translation of the bunny,
+    examples/run_test.py:126-129) on one GPU's share at its stated size: 1024 x 1024, 64 of 512 spp = 67 M slots through the traced wavefront with
+    dual-number stages (round 5).  Size-independent properties: the share's derivative image is the sum of its sub-shards' (the all-reduce identity; the
+    second sub-shard crosses nothing the first one touched), it equals the fused kernel's on the same samples up to isolated pixels, it is finite and
+    non-zero exactly where the bunny or its shadow / reflections are, and the primal image riding along equals renderC's."""
+    from helpers import tangents_wrt
+    sc, P = load_scene("cbox_bunny", res=1024, spp=512, sppe=0, sppse=0, translate=(1, (1.0, 0.5, 0.25)))
+    tb = sc.tables(0)
+    tan = tangents_wrt(tb, P)
+    g = GpuScene(tb)
+    kw = dict(integrator=_abi.INTEGRATOR_PATH, max_depth=3, spp=512)
+    img, d = g.render_d_fwd(_abi.make_opts(spp_range=(64, 128), **kw), [tan])
+    assert g.counters()[1] == 1024 * 1024 * 64
+    assert np.isfinite(d[0]).all() and np.abs(d[0]).max() > 0
+    ref_img = g.render_c(_abi.make_opts(spp_range=(64, 128), **kw))
+    assert rel_l2(img, ref_img) < 3e-4                               # separately compiled fp32 kernels (float stages / dual stages): isolated samples, measured 3.3e-5
+    ia, da = g.render_d_fwd(_abi.make_opts(spp_range=(64, 96), **kw), [tan])
+    ib, db = g.render_d_fwd(_abi.make_opts(spp_range=(96, 128), **kw), [tan])
+    assert rel_l2(da[0] + db[0], d[0]) < 1e-5 and rel_l2(ia + ib, img) < 1e-5
+    _, df = g.render_d_fwd(_abi.make_opts(spp_range=(64, 128), flags=_abi.FLAG_FUSED, **kw), [tan])
+    bad = np.abs(d[0] - df[0]).max(1) > 1e-3 * (np.abs(df[0]).max(1) + 1e-3 * np.abs(df[0]).max())
+    print("C4 share, PathTracer(3) geometry duals: wavefront vs fused derivative image rel-L2 %.2e, pixels apart %d of %d" % (rel_l2(d[0], df[0]), bad.sum(), bad.size))
+    assert bad.mean() < 2e-3 and rel_l2(d[0][~bad], df[0][~bad]) < 1e-3
+    assert abs(float(d[0].astype(np.float64).sum()) - float(df[0].astype(np.float64).sum())) < 1e-3 * float(np.abs(df[0].astype(np.float64)).sum())
+
+
 @pytest.mark.parametrize("res,spp", [(128, 1), (128, 4)])
 def test_c1_literal_size_direct_render_c(res, spp):
     """BASELINE config C1 at its literal size: cbox 128x128, spp = 1, DirectIntegrator.renderC (the reference's CPU-runnable plumbing case)."""

@@ -42,8 +42,8 @@ elif case in ("c4fg", "c5fg"):
         P = FloatD(0.); ek.set_requires_gradient(P)
         sc.m_meshes[8].set_transform(Matrix4fD.translate(Vector3fD([1.0, 0.4, -0.3]) * P)); sc.configure()
         o = _abi.make_opts(spp=16, integrator=_abi.INTEGRATOR_PATH, max_depth=3, flags=flags); n = 512 * 512 * 16
-elif case == "c2ra":
-    # C2 (cbox 512^2 spp 64, no tree) PathTracer(3) reverse, every gradient table
+elif case in ("c2ra", "c2rt"):
+    # C2 (cbox 512^2 spp 64, no tree) PathTracer(3) reverse: every gradient table / the texels only
     sc, _ = load_scene("cbox", res=512, spp=64)
     o = _abi.make_opts(spp=64, integrator=_abi.INTEGRATOR_PATH, max_depth=3, flags=flags); n = 512 * 512 * 64
 elif case in ("c3f", "c3r", "c4r3"):
@@ -68,9 +68,9 @@ elif case in ("c3r", "c4r3"):
 elif case in ("c4pr", "c5pr"):
     adj = np.random.default_rng(0).random((tb["width"] * tb["height"], 3)).astype(np.float32)
     run = lambda: g.render_d_rev(o, adj, want=["tri_info", "texels"], with_image=False)
-elif case == "c2ra":
+elif case in ("c2ra", "c2rt"):
     adj = np.random.default_rng(0).random((tb["width"] * tb["height"], 3)).astype(np.float32)
-    run = lambda: g.render_d_rev(o, adj, want=["texels", "emitter_rad", "tri_info", "cam_to_world"], with_image=False)
+    run = lambda: g.render_d_rev(o, adj, want=["texels", "emitter_rad", "tri_info", "cam_to_world"] if case == "c2ra" else ["texels"], with_image=False)
 else:
     run = lambda: g.render_c(o)
 run(); torch.cuda.synchronize()
