@@ -47,3 +47,47 @@ def test_two_rank_spp_sharding_equals_single_process(tmp_path):
     n = img.size
     assert rel_l2(got[:n], img.reshape(-1)) < 1e-6
     assert rel_l2(got[n:], dimg.reshape(-1)) < 1e-5 and np.abs(dimg).max() > 0
+
+
+def _solo_worker(rank, world, port, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in ("psdr-cuda_amd", "oracle", "tests"):
+        sys.path.insert(0, os.path.join(root, p))
+    from datetime import timedelta
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    side = dist.new_group(backend="gloo", timeout=timedelta(minutes=5))        # bench.py's host-side barrier group
+    import psdr_cuda
+    from psdr_cuda import integrator as I
+    from helpers import load_scene
+    sc, _ = load_scene("cbox", res=8, spp=6)
+    integ = psdr_cuda.PathTracer(3)
+    sharded = integ._opts(sc, with_edges=False)
+    res = {"sharded": (sharded.spp_begin, sharded.spp_end), "dist_outside": I._dist() is not None}
+    if rank == 0:
+        # what bench.py does with rank 0's side blocks at N > 1: the whole sample range, no collective -- the other rank is NOT in here
+        with I.solo():
+            o = integ._opts(sc, with_edges=False)
+            res["solo"] = (o.spp_begin, o.spp_end)
+            res["dist_inside"] = I._dist() is not None
+            with I.solo():                                                       # nests
+                pass
+            res["dist_nested_exit"] = I._dist() is not None
+        res["dist_after"] = I._dist() is not None
+    dist.barrier(group=side)                                                     # the others wait here meanwhile
+    if rank == 0:
+        import json
+        json.dump(res, open(out_path, "w"))
+    dist.destroy_process_group()
+
+
+def test_solo_block_runs_one_rank_without_sharding_or_collectives(tmp_path):
+    """bench.py at N > 1: rank 0 runs its counter passes and single-GPU side blocks inside `psdr_cuda.integrator.solo()` while the
+    other ranks wait at a gloo barrier -- inside the block a render call covers the whole sample range and issues no collective."""
+    import json
+    out = str(tmp_path / "solo.json")
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_solo_worker, args=(2, port, out), nprocs=2, join=True)
+    r = json.load(open(out))
+    assert r["sharded"] == [0, 3] and r["dist_outside"] and r["dist_after"]
+    assert r["solo"] == [0, 6] and not r["dist_inside"] and not r["dist_nested_exit"]
