@@ -170,6 +170,12 @@ typedef struct psdr_scene_desc {
    |its1.p - p1| < ShadowEpsilon (direct.cpp:262).  psdr_render_c / psdr_render_d_fwd only (reverse mode has no literal-form adjoint):
    makes the difference between the two forms measurable on the device against the oracle's reference_form. */
 #define PSDR_FLAG_LITERAL_FORMS 4
+/* psdr_render_c only: the caller is going to differentiate THIS render in reverse mode (renderD + enoki.backward: the primal image first, the adjoint image
+   later).  Where the following psdr_render_d_rev would run a split launch whose value sweep is exactly this render -- PathTracer on a two-level scene, the
+   traced wavefront, one chunk of slots -- the render runs with recording stages and the per-path records stay on the handle; a psdr_render_d_rev with the
+   same options, the same tables (psdr_scene_set_tables with an identical descriptor in between is fine; the caller must not have overwritten them in
+   place) and out_img = NULL then runs its adjoint kernel only (C4 shard: 15.6 of its 34.5 ms).  Ignored wherever that does not apply. */
+#define PSDR_FLAG_KEEP_RECORDS 8
 
 /* One render call = Integrator::renderC / renderD on one shard of the sample
    slots (src/integrator/integrator.cpp:13-119, src/integrator/direct.cpp). */
@@ -227,7 +233,8 @@ int psdr_scene_destroy(psdr_scene_t h);
 /* Developer options of a handle -- the A/B switches of tools and tests (the reference has none: its strategies are fixed by OptiX and
    Enoki); the library reads NO environment variable.  Names (value): bvh_refit, tiny_scene, two_level, wf_binned, wf_traced, sort_edges,
    tiny_variants, sink_private, aa_prims (0 / 1); bvh_build (1 device, 0 host, -1 by size); wide (0: never the 4-wide tree in the render kernels);
-   rev_split, sedge_split (1 / 0 force, -1 default rule); rev_vertex (1: the adjoint sweep of a split PathTracer launch as one launch per path
+   rev_split, sedge_split (1 / 0 force, -1 default rule); keep_records (0: PSDR_FLAG_KEEP_RECORDS is ignored); rev_sorted (0: reverse PathTracer kernels
+   scatter row adjoints on the spot); wf_geo (0: PathTracer geometry tangents through the fused kernel); tangent_live (0: no liveness mask); rev_vertex (1: the adjoint sweep of a split PathTracer launch as one launch per path
    vertex, 0 default: one adjoint kernel); vrev_blocks (workgroups per CU of those launches); probe (0: no probe / trace / final launches);
    trace_wg2 (dense trace kernel as two workgroups per CU: -1 by forest and launch size, 0 never, n > 0 always with stack columns of n entries);
    chunk_log2 (slots per chunk of the chunked launches, 0 = default); blocks_per_cu, camera_blocks, lds_budget, sink_rep, bvh_maxleaf (integers,

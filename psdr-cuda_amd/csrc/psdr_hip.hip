@@ -956,6 +956,7 @@ int psdr_scene_set_option(psdr_scene_t h, const char *name, double value) {
     else if (n == "rev_split") h->opt.rev_split = iv;
     else if (n == "tangent_live") h->opt.tangent_live = iv;              // 0: forward-mode kernels load the tangents of every triangle row (no liveness mask)
     else if (n == "wf_geo") h->opt.wf_geo = iv;                          // 0: geometry tangents of the PathTracer always through the fused kernel
+    else if (n == "keep_records") h->opt.keep_records = iv;              // 0: psdr_render_c ignores PSDR_FLAG_KEEP_RECORDS
     else if (n == "rev_sorted") h->opt.rev_sorted = iv;                  // 0: the reverse camera kernels scatter every row adjoint on the spot (no deferred, sorted adds)
     else if (n == "rev_vertex") h->opt.rev_vertex = iv;                  // 1: the adjoint sweep of a split PathTracer launch as a launch per path vertex (default 0: one adjoint kernel)
     else if (n == "vrev_blocks") h->opt.vrev_blocks = iv;                // workgroups per CU of the per-vertex adjoint launches (0: default)
@@ -966,6 +967,7 @@ int psdr_scene_set_option(psdr_scene_t h, const char *name, double value) {
     else if (n == "bvh_maxleaf") h->opt.bvh_maxleaf = std::max(1, std::min(8, iv));
     else if (n == "bvh_tcost") h->opt.bvh_tcost = (float) value;
     else return fail("psdr_scene_set_option: unknown option '" + n + "'");
+    h->kept.valid = false;                  // records kept under other options are not reused
     if (n == "tiny_scene" || n == "two_level" || n == "bvh_build" || n == "wide" || n == "bvh_maxleaf" || n == "bvh_tcost" || n == "tiny_variants") h->have_bvh = false;
     return 0;
 }
@@ -1022,6 +1024,7 @@ int psdr_scene_set_tables(psdr_scene_t h, const psdr_scene_desc *desc) {
     if (h->have_tables && (d.tri_info != h->desc.tri_info || d.num_tris != h->desc.num_tris)) h->have_bvh = false;
     // psdr_bvh_build keeps a host copy of emitter_i (hot gradient rows, the LDS table block of tiny scenes): new emitter tables need it again
     if (h->have_tables && (d.emitter_i != h->desc.emitter_i || d.num_emitters != h->desc.num_emitters)) h->have_bvh = false;
+    if (!h->have_tables || std::memcmp(&h->desc, &d, sizeof(d)) != 0) { ++h->tables_gen; h->kept.valid = false; }
     h->desc = d;
     // material_mask = 0: unknown -> serve every BSDF type
     h->has_rough = d.material_mask == 0 || (d.material_mask & (1u << PSDR_BSDF_ROUGHCONDUCTOR)) != 0;

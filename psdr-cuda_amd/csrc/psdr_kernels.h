@@ -2004,6 +2004,25 @@ int render_fwd(psdr_scene_s *h, const psdr_render_opts *o, const psdr_tangents *
     return 0;
 }
 
+// Does the reverse launch of these camera slots with geometry gradients run its value sweep as the traced wavefront with recording stages (render_rev)?
+// Then psdr_render_c(PSDR_FLAG_KEEP_RECORDS) can BE that value sweep.  One rule, used by both.
+template <int FL> bool rev_value_sweep_is_wavefront(const psdr_scene_s *h, const psdr_render_opts *o, long long n) {
+    if constexpr ((FL & kSceneForest) == 0) return false;
+    if (o->integrator != PSDR_INTEGRATOR_PATH) return false;
+    const int depth = std::min(o->max_depth, kMaxRevDepthDeep);
+    const bool has_tree = h->num_nodes > 0 && (h->n_tiny == 0 || h->n_blas > 0);
+    const int split_env = h->opt.rev_split;
+    const bool split = split_env != 0 && (split_env == 1 || (has_tree && o->max_depth >= 2 && n >= (1ll << 20)));
+    return split && depth <= kMaxRevDepth && traced_wavefront(h) && use_wavefront(h, o);
+}
+inline bool same_camera_samples(const psdr_render_opts &a, const psdr_render_opts &b) {
+    return a.integrator == b.integrator && a.max_depth == b.max_depth && a.hide_emitters == b.hide_emitters && a.spp == b.spp && a.spp_begin == b.spp_begin &&
+           a.spp_end == b.spp_end && a.rng_offset[0] == b.rng_offset[0] && ((a.flags ^ b.flags) & (PSDR_FLAG_FUSED | PSDR_FLAG_WAVEFRONT)) == 0;
+}
+inline int rev_record_words(const psdr_scene_s *h, int depth, bool wavefront_or_vertex) {
+    return kRevDiskHead + (wavefront_or_vertex ? kRevDiskPerVertexCf : kRevDiskPerVertex) * depth + (h->opt.rev_vertex != 0 ? kRevStateWords : 0);
+}
+
 template <int FL>
 int render_rev(psdr_scene_s *h, const psdr_render_opts *o, const float *adj_img, float *out_img, const psdr_grads *grads, hipStream_t s) {
     const long long WH = (long long) h->desc.width * h->desc.height;
@@ -2094,23 +2113,32 @@ int render_rev(psdr_scene_s *h, const psdr_render_opts *o, const float *adj_img,
         // wavefront: 16 ms)
         bool wf_value = false;
         if constexpr ((FL & kSceneForest) != 0) wf_value = split && !no_tree && o->integrator == PSDR_INTEGRATOR_PATH && !deep_rec && traced_wavefront(h) && use_wavefront(h, o);
+        // (rev_value_sweep_is_wavefront states the same rule for psdr_render_c's PSDR_FLAG_KEEP_RECORDS; `geo` and the option rev_split == 1 on a scene
+        // without a tree are the caller's side of it)
         const int disk_cf = wf_value ? 1 : (vrev ? 2 : 0);
         bool direct_probe = false;
         if constexpr ((FL & kSceneForest) != 0) direct_probe = !split && !no_tree && o->integrator == PSDR_INTEGRATOR_DIRECT && probe_direct(h, o, n);
         if (split) {
             // records of one chunk of slots live in a scratch buffer (2 + 5 depth words per slot; 2 + 8 depth from the wavefront); chunks bound its size
             const int rec_words = kRevDiskHead + ((wf_value || vrev) ? kRevDiskPerVertexCf : kRevDiskPerVertex) * depth;
-            const int words = rec_words + (vrev ? kRevStateWords : 0);       // + the state column the per-vertex adjoint launches hand on
+            const int words = rec_words + ((vrev || h->opt.rev_vertex != 0) ? kRevStateWords : 0);       // + the state column the per-vertex adjoint launches hand on
             // 2^26 slots per chunk (104 B of records per slot with the wavefront's cf format: 7 GB): the C4 shard's PathTracer(3) reverse as ONE chunk
             // 36.5 -> 35.7 ms of kernel time against four of 2^24 (its value sweep is the traced wavefront; profiles/r04_chunk_sweep.txt)
             const long long chunk = std::min<long long>(n, launch_chunk(h, 26));
             const size_t need = (size_t) chunk * words * sizeof(float);
+            if (need > h->rev_bytes) h->kept.valid = false;          // the buffer is about to be replaced
             if (int rc = scratch_reserve(&h->d_rev, &h->rev_bytes, need, s, "per-path records of the split reverse launch")) return rc;
             float *disk = reinterpret_cast<float *>(h->d_rev);
+            // the records psdr_render_c(PSDR_FLAG_KEEP_RECORDS) left of exactly these samples on exactly these tables: the value sweep is already there
+            const bool reuse = wf_value && h->kept.valid && h->kept.gen == h->tables_gen && h->kept.n == n && chunk >= n && out_img == nullptr &&
+                               same_camera_samples(h->kept.o, *o) && need <= h->rev_bytes;
+            if (!reuse || vrev) h->kept.valid = false;          // this launch overwrites them (or its per-vertex launches turn (c, f) into suffix radiances in place)
             for (long long c0 = 0; c0 < n; c0 += chunk) {
                 const long long nc = std::min(chunk, n - c0);
                 if (o->integrator == PSDR_INTEGRATOR_PATH) {
-                    if (wf_value) {
+                    if (wf_value && reuse) {
+                        // (nothing: the adjoint kernel below reads the kept records)
+                    } else if (wf_value) {
                         if constexpr ((FL & kSceneForest) != 0) {
                             const TangentView<0, FL> tv0{};
                             const WfRecArgs ra{disk, chunk, c0, nc};
@@ -2271,6 +2299,21 @@ int guide_launch(psdr_scene_s *h, LaunchCtx &cx, const int32_t reso[4], int nrou
 template <int FL>
 int render_c_launch(psdr_scene_s *h, const psdr_render_opts *o, float *out_img, hipStream_t s) {
     const TangentView<0, FL> tv0{};
+    if constexpr ((FL & kSceneForest) != 0) {
+        // PSDR_FLAG_KEEP_RECORDS: this render IS the value sweep of the reverse launch that follows (render_rev: wf_value) -- recording stages, records kept
+        const long long n = (long long) h->desc.width * h->desc.height * (o->spp_end - o->spp_begin);
+        if ((o->flags & PSDR_FLAG_KEEP_RECORDS) != 0 && h->opt.keep_records != 0 && o->spp > 0 && n > 0 && n <= launch_chunk(h, 26) && rev_value_sweep_is_wavefront<FL>(h, o, n)) {
+            const int depth = std::min(o->max_depth, kMaxRevDepthDeep);
+            const size_t need = (size_t) n * rev_record_words(h, depth, true) * sizeof(float);
+            h->kept.valid = false;
+            if (int rc = scratch_reserve(&h->d_rev, &h->rev_bytes, need, s, "per-path records of the split reverse launch")) return rc;
+            const WfRecArgs ra{reinterpret_cast<float *>(h->d_rev), n, 0, n};
+            if (int rc = run_camera_wavefront<float, FL>(h, o, tv0, out_img, nullptr, s, &ra)) return rc;
+            h->slots[0] += (uint64_t) n;
+            h->kept.valid = true; h->kept.o = *o; h->kept.gen = h->tables_gen; h->kept.n = n;
+            return 0;
+        }
+    }
     if (use_wavefront(h, o)) return run_camera_wavefront<float, FL>(h, o, tv0, out_img, nullptr, s);
     return run_camera<float, float, FL>(h, o, tv0, out_img, nullptr, s);
 }

@@ -26,7 +26,7 @@ BSDF_DIFFUSE, BSDF_ROUGHCONDUCTOR = 0, 1
 SLOT_REFLECTANCE, SLOT_ALPHA_U, SLOT_ALPHA_V, SLOT_ETA, SLOT_K = range(5)
 CAM_SAMPLE_TO_CAMERA, CAM_TO_WORLD, CAM_WORLD_TO_SAMPLE, CAM_POS, CAM_DIR, CAM_INV_AREA = 0, 16, 32, 48, 51, 54
 INTEGRATOR_DIRECT, INTEGRATOR_PATH, INTEGRATOR_FIELD = 0, 1, 2
-FLAG_FUSED, FLAG_WAVEFRONT, FLAG_LITERAL_FORMS = 1, 2, 4
+FLAG_FUSED, FLAG_WAVEFRONT, FLAG_LITERAL_FORMS, FLAG_KEEP_RECORDS = 1, 2, 4, 8
 FIELDS = {"silhouette": 0, "position": 1, "depth": 2, "geoNormal": 3, "shNormal": 4, "uv": 5}
 
 _fp = C.c_void_p  # all table pointers travel as raw addresses

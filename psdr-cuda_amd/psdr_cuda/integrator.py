@@ -143,7 +143,10 @@ class _RenderFn(torch.autograd.Function):
     def forward(ctx, node, *inputs):
         ctx.node = node
         ctx.present = [t is not None for t in inputs]
-        img = node.integrator._render_c(node.scene, node.tb, node.opts, node.guide, interior_only=True)
+        # this primal render is going to be differentiated in reverse mode: where the reverse launch would repeat it as its value sweep (PathTracer on a
+        # two-level scene), it runs with recording stages and the backward call below runs the adjoint kernel only (PSDR_FLAG_KEEP_RECORDS)
+        geo = any(t is not None and t.requires_grad for t, k in zip(inputs, _AD_KEYS) if k in ("tri_info", "cam_to_world"))
+        img = node.integrator._render_c(node.scene, node.tb, node.opts, node.guide, interior_only=True, keep_records=geo)
         return img.reshape(-1, 3)
 
     @staticmethod
@@ -223,8 +226,11 @@ class Integrator(Object):
             scene._bvh_version = stamp
         return lib, keep
 
-    def _render_c(self, scene, tb, opts, guide, interior_only=False, defer_reduce=False):
+    def _render_c(self, scene, tb, opts, guide, interior_only=False, defer_reduce=False, keep_records=False):
         lib, keep = self._prepare(scene, tb, guide)
+        if keep_records and self._kind == _abi.INTEGRATOR_PATH:
+            opts = type(opts).from_buffer_copy(opts)
+            opts.flags |= _abi.FLAG_KEEP_RECORDS
         img = torch.empty(tb["width"] * tb["height"] * 3, dtype=torch.float32, device="cuda")
         _abi.check(lib, lib.psdr_render_c(scene._native, C.byref(opts), img.data_ptr(), _stream_ptr()))
         self._counters(lib, scene)

@@ -227,3 +227,78 @@ def test_partial_tail_wave_gradients_equal_the_host_run(scene, kw):
         assert np.abs(gh[n]).max() > 0, n
         # bunny: isolated edge-on triangles (see test_dot_product_identity_gpu)
         assert rel_l2(gg[n], gh[n]) < (2e-2 if "bunny" in scene else 1e-3), (n, rel_l2(gg[n], gh[n]))
+
+
+@pytest.mark.gpu
+def test_render_c_keeps_the_value_sweep_records_for_the_reverse_call():
+    """renderD + enoki.backward renders the primal image first (the loss needs it) and differentiates it later; on a two-level scene the reverse launch of a
+    PathTracer would then repeat that render as its value sweep (the traced wavefront with recording stages).  psdr_render_c(PSDR_FLAG_KEEP_RECORDS) runs
+    the recording stages right away and the psdr_render_d_rev of the same samples on the same tables runs its adjoint kernel only: same image, same
+    gradients, NO ray traced by the reverse call.  Anything that changes the samples or the tables in between falls back to the full launch."""
+    from helpers import GpuScene, load_scene, rel_l2
+    res, spp = 256, 16                                          # 2^20 slots: where the library splits the reverse launch by itself
+    sc, _ = load_scene("cbox_bunny", res=res, spp=spp)
+    tb = sc.tables(0)
+    kw = dict(integrator=_abi.INTEGRATOR_PATH, max_depth=3, spp=spp, rng_offset=(7, 0, 0))
+    adj = np.random.default_rng(5).random((res * res, 3)).astype(np.float32)
+    names = ["tri_info", "texels", "emitter_rad", "cam_to_world"]
+    g = GpuScene(tb)
+    img_plain = g.render_c(_abi.make_opts(**kw)); rays_c = g.counters()[0]
+    _, g_plain = g.render_d_rev(_abi.make_opts(**kw), adj, want=names, with_image=False); rays_plain = g.counters()[0]
+    assert rays_plain == rays_c > 0                              # the reverse call traced the whole value sweep
+    img_keep = g.render_c(_abi.make_opts(flags=_abi.FLAG_KEEP_RECORDS, **kw))
+    assert g.counters()[0] == rays_c and rel_l2(img_keep, img_plain) < 1e-6
+    _, g_keep = g.render_d_rev(_abi.make_opts(**kw), adj, want=names, with_image=False)
+    assert g.counters()[0] == 0, g.counters()                    # adjoint kernel only: the replayed hits are not traced
+    for k in names:
+        assert np.abs(g_plain[k]).max() > 0 and rel_l2(g_keep[k], g_plain[k]) < 1e-5, (k, rel_l2(g_keep[k], g_plain[k]))
+    # the records serve the same samples again (they are read-only) ...
+    _, g_again = g.render_d_rev(_abi.make_opts(**kw), adj, want=names, with_image=False)
+    assert g.counters()[0] == 0 and rel_l2(g_again["tri_info"], g_plain["tri_info"]) < 1e-5
+    # ... but not other samples, not a call that wants the image, not other tables, not after an option changed
+    g.render_d_rev(_abi.make_opts(**dict(kw, rng_offset=(9, 0, 0))), adj, want=names, with_image=False)
+    assert g.counters()[0] > 0
+    g.render_c(_abi.make_opts(flags=_abi.FLAG_KEEP_RECORDS, **kw))
+    img_r, _ = g.render_d_rev(_abi.make_opts(**kw), adj, want=names, with_image=True)
+    assert g.counters()[0] == rays_c and rel_l2(img_r, img_plain) < 3e-4
+    g.render_c(_abi.make_opts(flags=_abi.FLAG_KEEP_RECORDS, **kw))
+    g.tb["texels"] = g.tb["texels"].clone(); g.set_guide(None)   # a new table pointer: psdr_scene_set_tables installs a different descriptor
+    _, g_new = g.render_d_rev(_abi.make_opts(**kw), adj, want=names, with_image=False)
+    assert g.counters()[0] == rays_c and rel_l2(g_new["tri_info"], g_plain["tri_info"]) < 1e-5
+    g.render_c(_abi.make_opts(flags=_abi.FLAG_KEEP_RECORDS, **kw))
+    g.set_option("keep_records", 1)
+    g.render_d_rev(_abi.make_opts(**kw), adj, want=names, with_image=False)
+    assert g.counters()[0] == rays_c
+    g.set_option("keep_records", 0)
+    g.render_c(_abi.make_opts(flags=_abi.FLAG_KEEP_RECORDS, **kw))
+    g.render_d_rev(_abi.make_opts(**kw), adj, want=names, with_image=False)
+    assert g.counters()[0] == rays_c                             # flag ignored
+
+
+@pytest.mark.gpu
+def test_surface_backward_reuses_the_primal_render_of_a_path_tracer():
+    """The same through the drop-in surface (docs/inverse_diff_render.rst: renderD, a torch loss on the image, enoki.backward): the vertex gradient of the bunny
+    with and without the kept records, and the reverse call's ray counter."""
+    import enoki as ek
+    import psdr_cuda
+    from enoki.cuda_autodiff import Float32 as FloatD, Vector3f as Vector3fD
+    from psdr_cuda.fixtures import scene_path
+    out = {}
+    for keep in (1, 0):
+        sc = psdr_cuda.Scene()
+        sc.load_file(scene_path("cbox_bunny"), False)
+        sc.native_options = {"keep_records": keep}
+        sc.opts.width = sc.opts.height = 256
+        sc.opts.spp, sc.opts.sppe, sc.opts.sppse, sc.opts.log_level = 16, 0, 0, 0
+        integ = psdr_cuda.PathTracer(3)
+        mesh = sc.param_map["Mesh[1]"]
+        v = Vector3fD(ek.detach(mesh.vertex_positions)); ek.set_requires_gradient(v); mesh.vertex_positions = v
+        sc.configure()
+        img = integ.renderD(sc)
+        loss = (img.t * img.t).sum().reshape(1)                  # the primal image is looked at here: rendered with PSDR_FLAG_KEEP_RECORDS
+        ek.backward(FloatD._wrap(loss))
+        out[keep] = (ek.gradient(v).numpy().copy(), integ.last_counters[0], img.numpy().copy())
+    (ga, rays_a, ia), (gb, rays_b, ib) = out[1], out[0]
+    assert rays_a == 0 and rays_b > 0, (rays_a, rays_b)
+    assert np.abs(gb).max() > 0 and np.isfinite(ga).all()
+    assert np.linalg.norm(ga - gb) < 1e-4 * np.linalg.norm(gb) and np.linalg.norm(ia - ib) < 1e-6 * np.linalg.norm(ib)
