@@ -305,6 +305,8 @@ def pmc_passes_c4(args, res, spp):
 #   c4_shard_path3_renderC      cbox_bunny 1024^2, 64 of the 512 spp (one of eight GPUs), PathTracer(3) renderC
 #   c4_shard_direct_rev3        the same shard, DirectIntegrator(1,1) renderD + backward with all three terms (spp = sppe = sppse share), triangle rows + texels
 #   c4_shard_path3_rev          the same shard, PathTracer(3) renderD + backward (interior term), triangle rows + texels
+#   c4_shard_path3_primal_then_rev   psdr_render_c(PSDR_FLAG_KEEP_RECORDS) + psdr_render_d_rev: one optimisation step's kernels (the reverse call reuses the records; its rays = 0)
+#   c4_shard_path3_fwd_geo, c5_path3_fwd_geo   PathTracer(3) renderD forward, K = 1 geometry tangents (a translation of one object): the traced wavefront with dual-number stages
 #   c5_path3_renderC            50 k-triangle interior with rough conductors, 512^2 spp 16, PathTracer(3) renderC
 #   c3_direct_fwd3              cbox_bunny 512^2 spp = sppe = sppse = 16, renderD forward (K = 1: a translation of the bunny), three terms
 class TreeScenes:
@@ -339,6 +341,11 @@ class TreeScenes:
         for k in ("tri_info", "texels"):
             tb4p[k] = tb4p[k].detach().requires_grad_(True)
         self.cases.append(("c4_shard_path3_rev", n4, lambda sc=sc4, tb=tb4p, o=o, a=adj4: self.integ._render_rev(sc, tb, o, None, a), sc4))
+        # what renderD + enoki.backward costs per optimisation step: the primal render (the loss needs the image) with PSDR_FLAG_KEEP_RECORDS, then the reverse
+        # call, which finds the value sweep's records on the handle and runs its adjoint kernel only (round 5)
+        self.path_integ = psdr_cuda.PathTracer(3)
+        self.cases.append(("c4_shard_path3_primal_then_rev", n4, lambda sc=sc4, tb=tb4p, o=o, a=adj4: (self.path_integ._render_c(sc, tb, o, None, keep_records=True),
+                                                                                                      self.path_integ._render_rev(sc, tb, o, None, a)), sc4))
         # forward mode with GEOMETRY tangents (a translation of the bunny: the reference harness' AD mode, run_test.py:126-129) through the PathTracer
         tan4 = self._translation_tangents(sc4, tb4)
         tb4t = sc4.tables(0)
@@ -379,7 +386,10 @@ class TreeScenes:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(); fn(); e1.record(); torch.cuda.synchronize()
             ms.append(e0.elapsed_time(e1))
-        return sorted(ms)[1], int(self.integ.last_counters[0])
+        rays = self.integ.last_counters
+        if "primal_then_rev" in name:
+            rays = self.path_integ.last_counters              # of the reverse call: 0 rays when it reused the primal render's records
+        return sorted(ms)[1], int(rays[0])
 
 
 def tree_child():
