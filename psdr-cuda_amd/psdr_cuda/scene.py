@@ -1718,7 +1718,11 @@ class Scene(Object):
         """Flat dict of tensors for one sensor (scene tables + that sensor's camera/primary edges).  After a native configure() the edge tables
         are stored at the capacity of their candidate lists with the kept rows first and the count on the device: capacity=True hands them out
         as they stand (the render calls: no read-back), the default cuts them to the kept rows -- the tables the reference holds
-        (scene.cpp:219-244, perspective.cpp:96-111); that reads the counts once per configure()."""
+        (scene.cpp:219-244, perspective.cpp:96-111); that reads the counts once per configure().
+        NORMALISED FORM of a native configure(): `sec_pmf` / `prim_pmf` are divided by their sum and `sec_cmf` / `prim_cmf` run to 1 (so `sec_sum = prim_sum = 1.0`,
+        where the reference's tables hold lengths and their total); the true summed length stays on the device in `sec_header[1]` / `prim_header[1]` (a float;
+        `[0]` = the number of kept rows as integer bits).  A table in which NO edge is kept is all zero rows with pmf 0: the kernels treat pmf 0 -- and, for a capacity-one
+        table, length 0 -- as an invalid draw (csrc/psdr_device.h primary_edge_sample; tests/test_edge_cases_gpu.py)."""
         psdr_assert(self._configured, "Input scene must be configured!")
         psdr_assert(0 <= sensor_id < self.num_sensors, "Invalid sensor id!")
         t = dict(self._tables)

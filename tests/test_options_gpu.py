@@ -1,4 +1,6 @@
 """psdr_scene_set_option: the developer switches of a handle (the library reads no environment variable)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -27,6 +29,23 @@ def test_unknown_option_fails_and_known_ones_switch_strategies():
         assert bad.mean() < 2e-3 and rel_l2(b[~bad], a[~bad]) < 1e-4, (opts, bad.mean())
 
 
+def test_every_option_the_header_names_is_accepted():
+    """include/psdr_hip.h lists the developer options of a handle; psdr_scene_set_option must know each of them (two were missing from the list)."""
+    import re
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "psdr_hip.h")).read()
+    block = hdr[hdr.index("Developer options of a handle"):hdr.index("int psdr_scene_set_option")]
+    names = set(re.findall(r"\b([a-z][a-z0-9]*(?:_[a-z0-9]+)+|wide|probe)\b", block)) - {"psdr_scene_set_option", "psdr_bvh_build", "per_cu", "psdr_hip"}
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "psdr-cuda_amd", "csrc", "psdr_hip.hip")).read()
+    known = set(re.findall(r'n == "([a-z0-9_]+)"', src[src.index("int psdr_scene_set_option"):src.index("int psdr_scene_destroy")]))
+    assert known <= names | {"emitter_layout"}, sorted(known - names)           # every option the library accepts is documented
+    sc, _ = load_scene("cbox", res=16, spp=2)
+    g = GpuScene(sc.tables(0))
+    for n in sorted(known):
+        assert g.lib.psdr_scene_set_option(g.h, n.encode(), 1.0) == 0, n
+    for n in sorted(names & known):
+        assert g.lib.psdr_scene_set_option(g.h, n.encode(), 0.0) == 0, n
+
+
 def test_library_reads_no_environment_variable():
     """No PSDR_* name survives in the binary (17 getenv knobs lived in the hot host path)."""
     import subprocess
@@ -48,13 +67,17 @@ def test_chunked_and_sharded_launches_on_a_two_level_scene(kind):
     adj = np.random.default_rng(5).random((96 * 96, 3)).astype(np.float32)
     from helpers import tangents_wrt
     tan = tangents_wrt(tb, P) if kind == "direct11" else {"texels": random_tangents(tb, ["texels"], seed=1)["texels"]}
+    tan_geo = tangents_wrt(tb, P)                   # path3: the PathTracer's geometry duals -- the traced wavefront with dual-number stages (round 5) -- chunk by chunk too
     want = ["tri_info", "texels"] + (["sec_edge", "prim_edge"] if kind == "direct11" else [])
     res = {}
     for name, opts in (("one", {}), ("chunks", {"chunk_log2": 14})):            # 147 456 slots: nine chunks of 2^14
         g = GpuScene(tb, options=opts)
-        res[name] = (g.render_c(o), g.render_d_fwd(o, [tan])[1][0], g.render_d_rev(o, adj, want=want, with_image=False)[1], g.counters()[0])
+        res[name] = (g.render_c(o), g.render_d_fwd(o, [tan])[1][0], g.render_d_rev(o, adj, want=want, with_image=False)[1], g.counters()[0],
+                     g.render_d_fwd(_abi.make_opts(spp=16, flags=_abi.FLAG_WAVEFRONT, **kw), [tan_geo])[1][0] if kind == "path3" else None)
     a, b = res["one"], res["chunks"]
     assert rel_l2(b[0], a[0]) < 1e-5 and rel_l2(b[1], a[1]) < 1e-4
+    if kind == "path3":
+        assert np.abs(a[4]).max() > 0 and rel_l2(b[4], a[4]) < 1e-4, rel_l2(b[4], a[4])
     for k in want:
         assert rel_l2(b[2][k], a[2][k]) < 2e-4, (k, rel_l2(b[2][k], a[2][k]))
     # shards: samples [0, 5), [5, 6), [6, 16) of every pixel (and of the edge samplers) add up to the full launch
