@@ -64,6 +64,27 @@ def run_sequence():
     ek.backward(FloatD._wrap((wgt * (img.t - 0.3) ** 2).sum().reshape(1)))
     out["d_rev_img"] = img.numpy()
     out["g_refl"], out["g_vert"] = ek.gradient(refl.data).numpy(), ek.gradient(v).numpy()
+    # round 5, PathTracer on a two-level scene at a size where the library picks its wavefront launches by itself (2^20 slots per rank at two ranks):
+    # geometry tangents through the traced wavefront with dual-number stages, then renderD + backward whose reverse call reuses the primal render's records
+    sc = scene("cbox_bunny", 32, 0, 0, res=256)
+    P = FloatD(0.)
+    ek.set_requires_gradient(P)
+    sc.param_map["Mesh[1]"].set_transform(Matrix4fD.translate(Vector3fD([0.5, 1.0, 0.0]) * P))
+    sc.configure()
+    pt = psdr_cuda.PathTracer(3)
+    img = pt.renderD(sc, 0)
+    ek.forward(P, free_graph=True)
+    out["pt_fwd_img"], out["pt_fwd_grad"] = img.numpy(), ek.gradient(img).numpy()
+    sc = scene("cbox_bunny", 32, 0, 0, res=256)
+    mesh = sc.param_map["Mesh[1]"]
+    v = Vector3fD(ek.detach(mesh.vertex_positions))
+    ek.set_requires_gradient(v)
+    mesh.vertex_positions = v
+    sc.configure()
+    img = pt.renderD(sc, 0)
+    ek.backward(FloatD._wrap((img.t * img.t).sum().reshape(1)))
+    out["pt_rev_img"], out["pt_g_vert"] = img.numpy(), ek.gradient(v).numpy()
+    out["pt_rev_rays"] = np.array([pt.last_counters[0]])               # 0: the reverse call ran its adjoint kernel only (PSDR_FLAG_KEEP_RECORDS)
     return out
 
 
@@ -96,9 +117,13 @@ def test_two_ranks_on_one_gpu_reproduce_the_single_process_results(tmp_path):
     ref = run_sequence()
     for k, v in ref.items():
         assert got[k].shape == v.shape, k
-        tol = 1e-4 if k.startswith("g_") else 2e-5          # same samples, different grouping of the fp32 sums / atomics
+        if k == "pt_rev_rays":
+            continue
+        tol = 1e-4 if k.startswith("g_") else (3e-4 if k in ("pt_fwd_grad", "pt_g_vert") else 2e-5)          # same samples, different grouping of the fp32 sums / atomics
         assert rel_l2(got[k], v) < tol, (k, rel_l2(got[k], v))
     assert np.abs(ref["d_fwd_grad"]).max() > 0 and np.abs(ref["g_vert"]).max() > 0 and np.abs(ref["g_refl"]).min() > 0
+    assert np.abs(ref["pt_fwd_grad"]).max() > 0 and np.abs(ref["pt_g_vert"]).max() > 0
+    assert int(ref["pt_rev_rays"][0]) == 0 and int(got["pt_rev_rays"][0]) == 0          # one process and each of two ranks: the reverse call reused the primal render's records
 
 
 if __name__ == "__main__":
