@@ -4,12 +4,10 @@
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/$1; mkdir -p $O; cd /tmp
 NAME=$2_$3
-(rocprofv3 -L 2>/dev/null || rocprofv3-avail list 2>/dev/null) | grep -o "\b\(TA\|TCP\|TD\|GRBM\|SQ_INST_CYCLES\|SQ_INSTS_FLAT\|SQ_ACTIVE_INST\|SQ_INST_LEVEL\|SQ_WAIT_INST\)_[A-Za-z0-9_]*" | sort -u > $O/counters_avail.txt
-wc -l $O/counters_avail.txt
-for PASS in "GRBM_GUI_ACTIVE TA_TA_BUSY_sum TA_BUSY_avr TA_FLAT_READ_WAVEFRONTS_sum TA_FLAT_WRITE_WAVEFRONTS_sum" "TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_ADDR_STALLED_BY_TD_CYCLES_sum" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TCC_ATOMIC_WITH_RET_REQ_sum" "TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_TA_TCP_STATE_READ_sum TCP_GATE_EN1_sum TCP_GATE_EN2_sum" "TD_TD_BUSY_sum TD_TC_STALL_sum TD_LOAD_WAVEFRONT_sum" "TCP_TOTAL_ACCESSES_sum TCP_TOTAL_READ_sum TCP_TOTAL_WRITE_sum TCP_TOTAL_ATOMIC_WITH_RET_sum" "SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INST_CYCLES_VMEM SQ_WAIT_INST_ANY SQ_INSTS_FLAT"; do
+for PASS in "GRBM_GUI_ACTIVE GRBM_TA_BUSY TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum" "TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_FLAT_WAVEFRONTS_sum" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum" "TCP_GATE_EN1_sum TCP_TCP_LATENCY_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TA_TCP_STATE_READ_sum" "TD_TD_BUSY_sum TD_TC_STALL_sum TD_LOAD_WAVEFRONT_sum" "TCP_TAGRAM0_REQ_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_REQUEST_sum" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VMEM_RD SQ_INST_CYCLES_VMEM_RD SQ_INST_LEVEL_VMEM SQ_ACTIVE_INST_VMEM"; do
   N=$(echo $PASS | cut -d' ' -f1)
   rm -rf /tmp/ta_${NAME}_$N
-  timeout 600 rocprofv3 --pmc $PASS --kernel-trace --output-format csv -d /tmp/ta_${NAME}_$N -o p -- python $R/tools/wf_case.py $2 $3 2 > /tmp/ta_${NAME}_$N.log 2>&1 || tail -3 /tmp/ta_${NAME}_$N.log
+  timeout 600 rocprofv3 --pmc $PASS --kernel-trace --output-format csv -d /tmp/ta_${NAME}_$N -o p -- python $R/tools/wf_case.py $2 $3 1 > /tmp/ta_${NAME}_$N.log 2>&1 || tail -3 /tmp/ta_${NAME}_$N.log
 done
 python - <<PY | tee -a $O/ta_rows.txt
 import csv, glob, collections
@@ -28,7 +26,7 @@ for d in glob.glob("/tmp/ta_${NAME}_*"):
             k = r["Kernel_Name"]
             if "k_" in k and "native" not in k:
                 dur[k] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"]); nl[k] += 1
-print("## ${NAME}: counters summed over all launches of the workload's calls (wf_case.py runs the call 3 times)")
+print("## ${NAME}: counters summed over all launches of the workload's calls (wf_case.py runs the call twice)")
 for k, c in cnt.items():
     short = k.replace("void (anonymous namespace)::", "").replace("psdr::", "").split("(")[0][:60] or "k_trace"
     print("%-60s launches %d total %.3f ms | " % (short, nl[k], dur[k] * 1e-6) + " ".join("%s=%.4g" % kv for kv in sorted(c.items())))
