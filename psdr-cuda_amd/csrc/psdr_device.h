@@ -151,9 +151,25 @@ template <int FL> struct Tab {
 
 // Traversal stack: LDS on the device (one column per lane: conflict-free, no scratch traffic),
 // a plain array on the host (tests).
+// -DPSDR_STAGE_CLOCKS (developer build, tools/r05_clk.sh): where the waves of one kernel spend their wall time.  A mark drains the memory counters and
+// reads s_memtime; the per-phase sums of all waves land behind the ray counters (psdr_get_counters prints them).  Off: the macros are empty.
+#ifdef PSDR_STAGE_CLOCKS
+struct StageClk { unsigned long long t[12]; unsigned long long last; };
+// the clocks of a wave live in LDS (one StageClk per wave, written by the first active lane): no register of the instrumented kernel stays live for them
+#define PSDR_CLK_MARK_P(clk, i) do { if (clk) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+    if ((int) (threadIdx.x & 63) == __ffsll((long long) __ballot(1)) - 1) { (clk)->t[i] += now_ - (clk)->last; (clk)->last = now_; } } } while (0)
+#define PSDR_CLK_MARK_ST(st, i) PSDR_CLK_MARK_P((st).clk, i)
+#else
+#define PSDR_CLK_MARK_P(clk, i) do { } while (0)
+#define PSDR_CLK_MARK_ST(st, i) do { } while (0)
+#endif
 struct TraversalStack {
     // kScenePre instances: the closest TREE hits of the vertex' two rays (tri < 0: none), found beforehand by the dense trace kernel
     Hit pre[3];
+#ifdef PSDR_STAGE_CLOCKS
+    StageClk *clk = nullptr;
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
     int32_t *base;   // &lds[threadIdx.x], stride kBlock
     __device__ __forceinline__ void put(int i, int32_t v) { base[i * kBlock] = v; }

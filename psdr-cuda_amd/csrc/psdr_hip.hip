@@ -1331,6 +1331,15 @@ int psdr_get_counters(psdr_scene_t h, uint64_t out[4]) {
     HIP_TRY(hipMemcpyAsync(all, h->d_counters, sizeof(all), hipMemcpyDeviceToHost, h->last_stream));
     HIP_TRY(hipStreamSynchronize(h->last_stream));
     for (int i = 0; i < kRayCounters; ++i) c[0] += all[i * kRayCounterStride];
+#ifdef PSDR_STAGE_CLOCKS
+    {   // developer build: the phase clocks of the traced bounce stage (psdr_kernels.h PSDR_CLK_MARK), summed over the waves of the last call
+        unsigned long long ph[12] = {0};
+        for (int i = 0; i < kRayCounters; ++i) for (int k = 0; k < 12; ++k) ph[k] += all[i * kRayCounterStride + 1 + k];
+        std::fprintf(stderr, "stage clocks:");
+        for (int k = 0; k < 12; ++k) std::fprintf(stderr, " %llu", ph[k]);
+        std::fprintf(stderr, "\n");
+    }
+#endif
     out[0] = c[0]; out[1] = h->slots[0]; out[2] = h->slots[1]; out[3] = h->slots[2];
     return 0;
 }

@@ -353,10 +353,20 @@ __device__ __forceinline__ void stream_push_binned(const PathStream &out, bool a
     }
 }
 
+// -DPSDR_STAGE_CLOCKS (psdr_device.h): the marks of the traced bounce stage travel as an extra argument
+#ifdef PSDR_STAGE_CLOCKS
+#define PSDR_CLK_ARG , StageClk *clk = nullptr
+#define PSDR_CLK_PASS , clk
+#define PSDR_CLK_MARK(i) PSDR_CLK_MARK_P(clk, i)
+#else
+#define PSDR_CLK_ARG
+#define PSDR_CLK_PASS
+#define PSDR_CLK_MARK(i) do { } while (0)
+#endif
 // Traced wavefront: plain sub-streams (block b -> sub-stream b % kWfSub, like stream_push) + the trace requests of the record's two rays.
 template <class M>
 __device__ __forceinline__ void stream_push_traced(const PathStream &out, const TraceQueue &q, bool alive, int cls, int pixel, uint32_t slot, const Its<float> &next,
-                                                   const Vec3f &dir, const Vec3<M> &beta, const Vec3<M> &acc, const Vec3f &d_bsdf, const Vec3f &d_light) {
+                                                   const Vec3f &dir, const Vec3<M> &beta, const Vec3<M> &acc, const Vec3f &d_bsdf, const Vec3f &d_light PSDR_CLK_ARG) {
     const unsigned long long mask = __ballot(alive);
     if (mask == 0ull) return;
     const int lane = threadIdx.x & 63, sub = blockIdx.x % kWfSub, leader = __ffsll((long long) mask) - 1;
@@ -368,6 +378,7 @@ __device__ __forceinline__ void stream_push_traced(const PathStream &out, const 
         if (n1 + n2 > 0) rbase = atomicAdd(q.count + sub * kWfCountStride, n1 + n2);
     }
     base = __shfl(base, leader, 64); rbase = __shfl(rbase, leader, 64);
+    PSDR_CLK_MARK(6);
     if (!alive) return;
     const unsigned long long below = (1ull << lane) - 1ull;
     const long long i = (long long) sub * out.sub_cap + base + __popcll(mask & below);
@@ -488,8 +499,9 @@ template <class M, int FL, bool TRACED = false, bool REC = false>
 __device__ __forceinline__ void wf_bounce_record(const LaunchCtx &cx, const TV<M, FL> &tv, TraversalStack &st, float inv_spp, float *__restrict__ img,
                                                  float *__restrict__ dimg, long long plane, const PathStream &in, const PathStream &out, int want_next,
                                                  const RngJump &jump_next, bool live, long long j, long long chunk, uint32_t &nrays, const TraceQueue &tq,
-                                                 const WfRec &wr, const WfRaw &raw) {
+                                                 const WfRec &wr, const WfRaw &raw PSDR_CLK_ARG) {
     constexpr int K = ad_traits<M>::K;
+    PSDR_CLK_MARK(0);                            // the record has arrived (and the stores of the trip before it have left)
     int pixel = -1; uint32_t slot = 0;
     Vec3<M> r = zero3<M>(), beta = zero3<M>();
     Its<float> next; next.tri = -1; next.hu = next.hv = 0.f;
@@ -525,7 +537,9 @@ __device__ __forceinline__ void wf_bounce_record(const LaunchCtx &cx, const TV<M
             if (cls & 1) { const float4 h = in.hit[2 * j]; st.pre[kPreBsdfRay] = Hit{__float_as_int(h.x), h.y, h.z, h.w}; }
             if (cls & 2) { const float4 h = in.hit[2 * j + 1]; st.pre[kPreLightRay] = Hit{__float_as_int(h.x), h.y, h.z, h.w}; }
         }
+        PSDR_CLK_MARK(1);                        // hit rows
         const Its<float> its = path_vertex_from_record(cx.sc, tv, tri_word & kWfTriMask, raw.hu, raw.hv, din);
+        PSDR_CLK_MARK(2);                        // the vertex rebuilt from its triangle row
         if constexpr (TRACED) {
             TV<M, FL | kScenePre> tvp;
 #pragma unroll
@@ -550,6 +564,7 @@ __device__ __forceinline__ void wf_bounce_record(const LaunchCtx &cx, const TV<M
             Vec3f d = next.p - its.p; const float t = norm(d); dir = d / t;
         }
     }
+    PSDR_CLK_MARK(3);                            // direct_step with the traced hits
     const bool goes_on = want_next && alive;
     if constexpr (REC) {
         if (live && !goes_on) {
@@ -561,11 +576,14 @@ __device__ __forceinline__ void wf_bounce_record(const LaunchCtx &cx, const TV<M
         }
     }
     splat_runs<M>(pixel, live && !goes_on, zero_nonfinite(r), inv_spp, img, dimg, plane);
+    PSDR_CLK_MARK(4);                            // splat of the paths that end here
     if (want_next) {
         if constexpr (TRACED) {
             Vec3f d_bsdf(0.f), d_light(0.f);
             const int cls = alive ? classify_next<true>(cx.sc, tv, rng_next, next, dir, &d_bsdf, &d_light) : 0;
-            stream_push_traced<M>(out, tq, alive, cls, pixel, slot, next, dir, beta, r, d_bsdf, d_light);
+            PSDR_CLK_MARK(5);                    // the next vertex' two rays aimed
+            stream_push_traced<M>(out, tq, alive, cls, pixel, slot, next, dir, beta, r, d_bsdf, d_light PSDR_CLK_PASS);
+            PSDR_CLK_MARK(7);                    // record + requests stored (drained: a developer build waits for its stores here)
         } else if constexpr ((FL & kSceneForest) != 0) {
             if (out.binned) stream_push_binned<M>(out, alive, alive ? classify_next(cx.sc, tv, rng_next, next, dir) : 0, chunk, pixel, slot, next, dir, beta, r);
             else stream_push<M>(out, alive, pixel, slot, next, dir, beta, r);
@@ -619,9 +637,22 @@ __global__ __launch_bounds__(kBlock, (is_ad<M>() ? 2 : (TRACED ? PSDR_WF_WAVES_T
         const int n = in.count[sub * kWfCountStride];
         // (measured and dropped: fetching the NEXT trip's record while the current one is processed -- 1 571 against 1 548 us per C4 stage: the stage does
         // not wait for its record)
+#ifdef PSDR_STAGE_CLOCKS
+        __shared__ StageClk s_ck[kBlock / 64];
+        StageClk &ck = s_ck[threadIdx.x >> 6];
+        const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+        if ((threadIdx.x & 63) == 0) { for (int i = 0; i < 12; ++i) ck.t[i] = 0; ck.last = t_begin; }
+        StageClk *clk = REC ? nullptr : &ck;          // a recording stage shares its call with the adjoint kernel, whose clocks the call then reports
+#endif
         for (int base = (blockIdx.x / kWfSub) * kBlock; base < n; base += per * kBlock)
             wf_bounce_record<M, FL, TRACED, REC>(cx, tv, st, inv_spp, img, dimg, plane, in, out, want_next, jump_next, base + (int) threadIdx.x < n, in_base + base + threadIdx.x,
-                                                 base / kBlock, nrays, tq, wr, wf_load_raw(in, in_base + base + threadIdx.x, base + (int) threadIdx.x < n));
+                                                 base / kBlock, nrays, tq, wr, wf_load_raw(in, in_base + base + threadIdx.x, base + (int) threadIdx.x < n) PSDR_CLK_PASS);
+#ifdef PSDR_STAGE_CLOCKS
+        if ((threadIdx.x & 63) == 0 && !REC) {
+            ck.t[11] = __builtin_amdgcn_s_memtime() - t_begin;       // wave lifetime inside the loop
+            for (int i = 0; i < 12; ++i) atomicAdd(counters + (blockIdx.x % kRayCounters) * kRayCounterStride + 1 + i, ck.t[i]);
+        }
+#endif
     }
     count_rays(counters, nrays);
 }
@@ -1312,6 +1343,13 @@ __global__ __launch_bounds__(kBlock, (STAGE == 1 ? PSDR_WAVES_REV_VALUE : rev_wa
     if (STAGE != 1) sink.begin(dyn_lds_floats(cx.off_sink));
     uint32_t nrays = 0;
     const long long nceil = (n + kBlock - 1) / kBlock * kBlock;
+#ifdef PSDR_STAGE_CLOCKS
+    __shared__ StageClk s_ck[kBlock / 64];
+    StageClk &ck = s_ck[threadIdx.x >> 6];
+    const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+    if ((threadIdx.x & 63) == 0) { for (int i = 0; i < 12; ++i) ck.t[i] = 0; ck.last = t_begin; }
+    if (STAGE == 2 && GEO) st.clk = &ck;
+#endif
     for (long long jj = (long long) blockIdx.x * kBlock + threadIdx.x; jj < nceil; jj += (long long) gridDim.x * kBlock) {
         const bool in = jj < n;
         int pixel = 0x7fffffff, s_in = 0;
@@ -1341,8 +1379,10 @@ __global__ __launch_bounds__(kBlock, (STAGE == 1 ? PSDR_WAVES_REV_VALUE : rev_wa
                 for (int w = 0; w < kPrimaryWords; ++w) sink.add_tri(pg.tri, w, pg.w[w]);
             }
         }
+        PSDR_CLK_MARK_ST(st, 6);          // the primary triangle's row (wave run sums)
         // the complete row adjoints of this slot's path vertices (camera_sample_reverse -> complete_row -> DeviceSink::defer_row), sorted by row
         if constexpr (STAGE != 1 && GEO) sink_flush_pending_wave(sink);
+        PSDR_CLK_MARK_ST(st, 7);          // the parked rows added sorted
         if (STAGE != 2 && img != nullptr) {
             const bool head = wave_segmented_sum<3>(pixel, v);
             if (head && in) {
@@ -1354,6 +1394,15 @@ __global__ __launch_bounds__(kBlock, (STAGE == 1 ? PSDR_WAVES_REV_VALUE : rev_wa
         }
     }
     if (STAGE != 1) sink.end();
+#ifdef PSDR_STAGE_CLOCKS
+    if (st.clk) {
+        PSDR_CLK_MARK_ST(st, 8);          // the gradient cache flushed
+        if ((threadIdx.x & 63) == 0) {
+            ck.t[11] = __builtin_amdgcn_s_memtime() - t_begin;
+            for (int i = 0; i < 12; ++i) atomicAdd(counters + (blockIdx.x % kRayCounters) * kRayCounterStride + 1 + i, ck.t[i]);
+        }
+    }
+#endif
     count_rays(counters, nrays);
 }
 

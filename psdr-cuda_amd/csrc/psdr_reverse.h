@@ -917,6 +917,7 @@ PSDR_HD Vec3f camera_sample_reverse(RealSink &real_sink, PrimaryGrad &pg, PathRe
     its.uvx = q ? (q[2] - q[0]) * bu + ((q[4] - q[0]) * bv + q[0]) : 0.f;
     its.uvy = q ? (q[3] - q[1]) * bu + ((q[5] - q[1]) * bv + q[1]) : 0.f;
 
+    PSDR_CLK_MARK_ST(st, 0);                    // record head + the primary vertex rebuilt
     VertexAdj va0; va0.clear();                 // adjoints of the primary vertex; its solid-angle chain runs last
     Vec3f result(0.f);
     const int integ = INTEG >= 0 ? INTEG : lp.integrator;
@@ -1025,6 +1026,7 @@ PSDR_HD Vec3f camera_sample_reverse(RealSink &real_sink, PrimaryGrad &pg, PathRe
         }
     }
 
+    PSDR_CLK_MARK_ST(st, 1);                    // the path record read, suffix radiances
     // ---- sweep 2: replay the same random numbers, differentiate vertex by vertex
     {
         Its<float> cur = its;
@@ -1040,6 +1042,7 @@ PSDR_HD Vec3f camera_sample_reverse(RealSink &real_sink, PrimaryGrad &pg, PathRe
             RowAdj row_next; row_next.clear();
             const VertexOut vo = replay ? vertex_eval<true, true, SweepSink>(sweep, sc, st, rng, cur, nB, nL, a_c, a_f, k == 0 ? va0 : va, nrays, rec, k, &row_next)
                                         : vertex_eval<true, false, SweepSink>(sweep, sc, st, rng, cur, nB, nL, a_c, a_f, k == 0 ? va0 : va, nrays, rec, k, &row_next);
+            PSDR_CLK_MARK_ST(st, 2 + (k > 0 ? 1 : 0));      // vertex_eval backward: vertex 0 / the others
             if (k >= 1) {
                 // a vertex' row leaves ONCE and COMPLETE (position, face normal, area: complete_row) -- one iteration late, when its successor's direction
                 // chain has sent its position adjoint back; a sink that defers rows (DeviceSink) adds them sorted by row at the kernel's convergent point
@@ -1048,6 +1051,7 @@ PSDR_HD Vec3f camera_sample_reverse(RealSink &real_sink, PrimaryGrad &pg, PathRe
                 else { acc_finite(pend.p, a_prev); complete_row(sweep, prev_tri, prev_u, prev_v, pend); }
                 pend = row_cur;
             }
+            PSDR_CLK_MARK_ST(st, 4);            // the direction chain back to the vertex behind, its row parked
             if (!vo.next_valid || k + 1 >= nv) {
                 if (k >= 1) complete_row(sweep, cur.tri, cur.hu, cur.hv, pend);
                 if (vo.next_valid) complete_row(sweep, vo.next.tri, vo.next.hu, vo.next.hv, row_next);
@@ -1085,6 +1089,7 @@ PSDR_HD Vec3f camera_sample_reverse(RealSink &real_sink, PrimaryGrad &pg, PathRe
         scatter_vec(sink, tri_b, 0, ma.p0 + va0.p); scatter_vec(sink, tri_b, 3, ma.e1 + va0.p * bu_b); scatter_vec(sink, tri_b, 6, ma.e2 + va0.p * bv_b);
         camera_ray_vjp(sink, sc, dcam_b, ma.o, a_d + ma.d);
     }
+    PSDR_CLK_MARK_ST(st, 5);                    // the primary vertex' chain
     return result;
 }
 

@@ -39,13 +39,26 @@ __device__ __forceinline__ V3 normalize_vjp(V3 y, float len, V3 ay) { const floa
 
 // ------------------------------------------------------------------ TriangleInfo rows (process_mesh, mesh.cpp:20-51)
 // pass 1: per face, the un-normalised normal cross(e1, e2) added to its three vertices (area-weighted vertex normals: mesh.cpp:33-41 sums
-// face_normal * area and divides by the summed area before normalising -- the same direction)
-__global__ __launch_bounds__(kB) void k_face_accum(int T, const float *__restrict__ v, const int32_t *__restrict__ faces, float *__restrict__ vsum) {
+// face_normal * area and divides by the summed area before normalising -- the same direction).
+// The sums are accumulated in DOUBLE (hardware global_atomic_add_f64) and rounded to fp32 once: a double holds the sum of fp32 terms whose
+// exponents span less than 29 bits EXACTLY, so the rounded sum does not depend on the order the atomics land in.  With fp32 atomics the vertex
+// normals moved in their last bit from one configure() to the next, and a path tracer turns that into samples that flip at a silhouette: the
+// same scene rendered twice differed by 1e-3 in a pixel, the bunny's vertex gradient by 5e-4 rel-L2 (tools/r05_clk.sh, round 5).
+__global__ __launch_bounds__(kB) void k_face_accum(int T, const float *__restrict__ v, const int32_t *__restrict__ faces, double *__restrict__ dsum) {
     const int t = blockIdx.x * kB + threadIdx.x;
     if (t >= T) return;
-    const int i0 = faces[3 * t], i1 = faces[3 * t + 1], i2 = faces[3 * t + 2];
-    const V3 p0 = ld3(v + 3 * (size_t) i0), c = cross(ld3(v + 3 * (size_t) i1) - p0, ld3(v + 3 * (size_t) i2) - p0);
-    add3(vsum + 3 * (size_t) i0, c); add3(vsum + 3 * (size_t) i1, c); add3(vsum + 3 * (size_t) i2, c);
+    const int id[3] = {faces[3 * t], faces[3 * t + 1], faces[3 * t + 2]};
+    const V3 p0 = ld3(v + 3 * (size_t) id[0]), c = cross(ld3(v + 3 * (size_t) id[1]) - p0, ld3(v + 3 * (size_t) id[2]) - p0);
+    for (int k = 0; k < 3; ++k) {
+        double *d = dsum + 3 * (size_t) id[k];
+        if (c.x != 0.f) atomicAdd(d, (double) c.x);
+        if (c.y != 0.f) atomicAdd(d + 1, (double) c.y);
+        if (c.z != 0.f) atomicAdd(d + 2, (double) c.z);
+    }
+}
+__global__ __launch_bounds__(kB) void k_vsum_round(int n, const double *__restrict__ dsum, float *__restrict__ vsum) {
+    const int i = blockIdx.x * kB + threadIdx.x;
+    if (i < n) vsum[i] = (float) dsum[i];
 }
 // pass 2: the 22-word rows p0 e1 e2 n0 n1 n2 face_normal face_area (types.h:135-146)
 __global__ __launch_bounds__(kB) void k_tri_rows(int T, const float *__restrict__ v, const int32_t *__restrict__ faces, const float *__restrict__ vsum,
@@ -401,8 +414,16 @@ int psdr_geo_world_vertices_rev(int32_t V, const float *v_raw, const int32_t *vm
 int psdr_geo_tri_rows_fwd(int32_t V, int32_t T, const float *v, const int32_t *faces, float *vsum, float *rows, int32_t row_stride, void *stream) {
     if (V <= 0 || T <= 0 || !v || !faces || !vsum || !rows || row_stride < 22) return psdr_host::fail("psdr_geo_tri_rows_fwd: invalid argument");
     hipStream_t s = (hipStream_t) stream;
-    TAB_TRY(hipMemsetAsync(vsum, 0, sizeof(float) * 3 * (size_t) V, s));
-    hipLaunchKernelGGL(k_face_accum, grid(T), dim3(kB), 0, s, T, v, faces, vsum);
+    // the double accumulators live in the row table until the rows are written (24 V <= 72 T bytes of its >= 88 T; a mesh with more unused
+    // vertices than that takes a stream-ordered scratch)
+    const size_t acc_bytes = sizeof(double) * 3 * (size_t) V;
+    double *dsum = reinterpret_cast<double *>(rows);
+    const bool own = acc_bytes > sizeof(float) * (size_t) row_stride * (size_t) T || (reinterpret_cast<uintptr_t>(rows) & 7u) != 0;
+    if (own) TAB_TRY(hipMallocAsync(reinterpret_cast<void **>(&dsum), acc_bytes, s));
+    TAB_TRY(hipMemsetAsync(dsum, 0, acc_bytes, s));
+    hipLaunchKernelGGL(k_face_accum, grid(T), dim3(kB), 0, s, T, v, faces, dsum);
+    hipLaunchKernelGGL(k_vsum_round, grid(3 * V), dim3(kB), 0, s, 3 * V, dsum, vsum);
+    if (own) TAB_TRY(hipFreeAsync(dsum, s));
     hipLaunchKernelGGL(k_tri_rows, grid(T), dim3(kB), 0, s, T, v, faces, vsum, rows, row_stride);
     TAB_TRY(hipGetLastError());
     return 0;

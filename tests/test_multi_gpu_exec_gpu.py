@@ -119,7 +119,7 @@ def test_two_ranks_on_one_gpu_reproduce_the_single_process_results(tmp_path):
         assert got[k].shape == v.shape, k
         if k == "pt_rev_rays":
             continue
-        tol = 1e-4 if k.startswith("g_") else ({"pt_fwd_grad": 3e-4, "pt_g_vert": 2e-3}.get(k, 2e-5))          # same samples, different grouping of the fp32 sums / atomics (the bunny's vertex gradient of a three-bounce loss is a sum of 10^3-10^4 cancelling terms per vertex: 5e-4 observed between two runs)
+        tol = 1e-4 if k.startswith("g_") or k in ("pt_fwd_grad", "pt_g_vert") else 2e-5          # same samples, different grouping of the fp32 sums / atomics (3e-7 between two runs of one process since the table chain is reproducible: tests/test_tables_native_gpu.py)
         assert rel_l2(got[k], v) < tol, (k, rel_l2(got[k], v))
     assert np.abs(ref["d_fwd_grad"]).max() > 0 and np.abs(ref["g_vert"]).max() > 0 and np.abs(ref["g_refl"]).min() > 0
     assert np.abs(ref["pt_fwd_grad"]).max() > 0 and np.abs(ref["pt_g_vert"]).max() > 0

@@ -152,6 +152,24 @@ def test_world_vertices_kernel_equals_the_torch_chain_bit_for_bit_and_in_its_adj
     assert rel_l2(jvp.cpu().numpy(), jref.cpu().numpy()) < 1e-6
 
 
+def test_configure_and_render_are_reproducible_from_one_scene_object_to_the_next():
+    """Two FRESH scenes of the same file in one process: the table chain must produce the SAME bits (the vertex normals are sums over the faces around a
+    vertex -- accumulated in double so that the order of the atomics cannot show, csrc/psdr_tables.hip k_face_accum; with fp32 atomics 12 000 words of the
+    cbox_bunny rows moved in their last bit from one configure() to the next and a PathTracer pixel with them by 3e-4), and so must the image."""
+    imgs, rows, edges = [], [], []
+    for _ in range(3):
+        sc, _, _ = build("cbox_bunny", True, True)
+        t = sc.tables(0)
+        rows.append(t["tri_info"].detach().cpu().numpy().copy()); edges.append(t["sec_edge"].detach().cpu().numpy().copy())
+        sc.opts.spp = 8
+        imgs.append(psdr_cuda.PathTracer(3).renderC(sc, 0).numpy().copy())
+    for k in (1, 2):
+        assert rows[k].shape == rows[0].shape and int((rows[k] != rows[0]).sum()) == 0, int((rows[k] != rows[0]).sum())
+        assert edges[k].shape == edges[0].shape and int((edges[k] != edges[0]).sum()) == 0
+        # same tables, same sample streams: what is left is the order of the image atomics
+        assert float(np.abs(imgs[k] - imgs[0]).max()) <= 2e-5 * max(1.0, float(np.abs(imgs[0]).max())), float(np.abs(imgs[k] - imgs[0]).max())
+
+
 def test_configure_never_waits_for_the_device_and_stays_under_twenty_launches():
     """Scene.configure with vertex gradients: ZERO synchronising calls (torch's sync debug mode counts them; the numbers of kept edges, the
     distribution sums, mesh areas and emitter weights stay on the device: csrc/psdr_tables.hip k_compact_*, k_mesh_areas, k_emitter_rows) and at most

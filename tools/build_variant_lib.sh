@@ -11,7 +11,9 @@ cd $ROOT/psdr-cuda_amd/csrc
 ALL="0 1 2 3 4 6 8 10"
 #   ONLY=host: rebuild the host unit (psdr_hip.hip: C ABI, k_trace, k_wf_trace) only
 if [ -n "${ONLY:-}" ]; then cp $ROOT/psdr-cuda_amd/lib/obj/*.o $obj/; rm -f $obj/*_defect.o; SET="$ONLY"; else SET="$ALL"; fi
-if [ "${ONLY:-}" = "host" ]; then SET=""; hipcc $FLAGS "$@" -c psdr_hip.hip -o $obj/host.o & fi
+#   ONLY="4 host": both
+for v in $SET; do if [ "$v" = "host" ]; then hipcc $FLAGS "$@" -c psdr_hip.hip -o $obj/host.o & fi; done
+SET=$(echo $SET | sed "s/host//")
 for v in $SET; do hipcc $FLAGS "$@" -DPSDR_VARIANT_FLAGS=$v -c psdr_variant.hip -o $obj/variant$v.o & done
 if [ -z "${ONLY:-}" ]; then hipcc $FLAGS "$@" -c psdr_hip.hip -o $obj/host.o & hipcc $FLAGS "$@" -c psdr_tables.hip -o $obj/tables.o & fi
 wait
