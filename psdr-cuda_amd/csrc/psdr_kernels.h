@@ -1348,7 +1348,7 @@ __global__ __launch_bounds__(kBlock, (STAGE == 1 ? PSDR_WAVES_REV_VALUE : rev_wa
     StageClk &ck = s_ck[threadIdx.x >> 6];
     const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
     if ((threadIdx.x & 63) == 0) { for (int i = 0; i < 12; ++i) ck.t[i] = 0; ck.last = t_begin; }
-    if (STAGE == 2 && GEO) st.clk = &ck;
+    if (STAGE != 1 && GEO) st.clk = &ck;          // STAGE 0 (both sweeps in one kernel): phase 1 is the value sweep
 #endif
     for (long long jj = (long long) blockIdx.x * kBlock + threadIdx.x; jj < nceil; jj += (long long) gridDim.x * kBlock) {
         const bool in = jj < n;
@@ -1411,6 +1411,9 @@ __global__ __launch_bounds__(kBlock, (STAGE == 1 ? PSDR_WAVES_REV_VALUE : rev_wa
 // (one ballot per distinct key), values travel to their rank with ds_permute, a segmented scan inside every row of 16 lanes (four v_fmac with DPP
 // row_shr operands, masks computed once per key set) leaves each run's total in its last lane, and only those lanes add -- one LDS add per run of
 // equal keys and row of 16 instead of one per lane.
+#ifndef PSDR_SORTED_ROWS_BATCHED
+#define PSDR_SORTED_ROWS_BATCHED 1
+#endif
 template <int CTRL> __device__ __forceinline__ int dpp_mov_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
 template <int CTRL> __device__ __forceinline__ float dpp_mov_f(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true)); }
 struct WaveSort {
@@ -1466,13 +1469,34 @@ template <class S> __device__ __forceinline__ void sink_add_row_wave(S &sink, in
         for (int i = 0; i < kPrivRowWords; ++i) if (w[i] != 0.f) atomicAdd(sink.g.g_tri_info + (size_t) tri * PSDR_TRI_STRIDE + (i < 9 ? i : i + 9), w[i]);
     }
     if (__ballot(slot >= 0) == 0ull) return;
+    // (measured and dropped: ranking by one ballot per POSSIBLE key in a loop of uniform length for the <= 32 rows of a scene without a tree -- 4.97 ms either way)
     const WaveSort ws = wave_sort_keys(slot);
     typename S::lds_float *row = sink.lds + sink.L.hot_off + (ws.skey - 1) * PSDR_TRI_STRIDE;
+#if PSDR_SORTED_ROWS_BATCHED
+    // the 13 words travel together: all permutes in flight at once, the 13 independent scans interleaved, then the adds of the run tails (word by word the
+    // wave waited for every permute and every scan alone: C2 all gradients 5.14 -> 4.97 ms, the C4 shard's reverse 35.0 -> 34.4; profiles/r05_rev_sorted_abk.txt)
+    float t[kPrivRowWords];
+#pragma unroll
+    for (int i = 0; i < kPrivRowWords; ++i) t[i] = __int_as_float(__builtin_amdgcn_ds_permute(ws.to_bytes, __float_as_int(slot >= 0 ? w[i] : 0.f)));
+#pragma unroll
+    for (int i = 0; i < kPrivRowWords; ++i) t[i] = fmaf(dpp_mov_f<0x111>(t[i]), ws.m1, t[i]);
+#pragma unroll
+    for (int i = 0; i < kPrivRowWords; ++i) t[i] = fmaf(dpp_mov_f<0x112>(t[i]), ws.m2, t[i]);
+#pragma unroll
+    for (int i = 0; i < kPrivRowWords; ++i) t[i] = fmaf(dpp_mov_f<0x114>(t[i]), ws.m4, t[i]);
+#pragma unroll
+    for (int i = 0; i < kPrivRowWords; ++i) t[i] = fmaf(dpp_mov_f<0x118>(t[i]), ws.m8, t[i]);
+    if (ws.tail) {
+#pragma unroll
+        for (int i = 0; i < kPrivRowWords; ++i) if (t[i] != 0.f) S::lds_add(row + (i < 9 ? i : i + 9), t[i]);
+    }
+#else
 #pragma unroll
     for (int i = 0; i < kPrivRowWords; ++i) {
         const float t = ws.total(slot >= 0 ? w[i] : 0.f);
         if (ws.tail && t != 0.f) S::lds_add(row + (i < 9 ? i : i + 9), t);
     }
+#endif
 }
 // The adjoint of one RGB texel per lane (key = its index in the texel pool; < 0: none).
 template <class S> __device__ __forceinline__ void sink_add_texel3_wave(S &sink, int key, const float (&tex)[3]) {
