@@ -185,6 +185,10 @@ class Workload:
         """every gradient table of the interior term at once: texels, emitter radiance, triangle rows (geometry), camera pose"""
         return self.kernel_rev(("texels", "emitter_rad", "tri_info", "cam_to_world"))
 
+    def kernel_c_keep(self):
+        """psdr_render_c with PSDR_FLAG_KEEP_RECORDS: the primal render as the value kernel of the reverse launch that follows (what renderD does when a geometry gradient is attached)"""
+        return self.integ._render_c(self.sc, self.tb, self.opts, None, keep_records=True)
+
 
 def timed(fn, n):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -770,14 +774,26 @@ def main():
     ms_rev = timed(w.kernel_rev, n_side)
     w.kernel_rev_all()
     ms_rev_all = timed(w.kernel_rev_all, n_side)
+    # the pair an optimisation step with a geometry gradient launches: recording primal render, then the adjoint kernel alone on its records
+    w.kernel_c_keep(); w.kernel_rev_all()
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    keep_ms = [[], []]
+    for _ in range(n_side):
+        e[0].record(); w.kernel_c_keep(); e[1].record(); w.kernel_rev_all(); e[2].record()
+        torch.cuda.synchronize()
+        keep_ms[0].append(e[0].elapsed_time(e[1])); keep_ms[1].append(e[1].elapsed_time(e[2]))
+    ms_c_keep, ms_rev_all_kept = float(np.mean(keep_ms[0])), float(np.mean(keep_ms[1]))
+    rays_rev_kept = w.integ.last_counters[0]
     w.kernel_setup(3)
     w.kernel_d()
     ms_d3 = timed(w.kernel_d, n_side)
     kernel_only = {"value": round(2.0 * slots_per_pass / ((ms_c + ms_d1) * 1e-3) / 1e6, 1), "unit": "Mpath-samples/s",
                    "render_c_ms": round(ms_c, 4), "render_d_fwd_k1_ms": round(ms_d1, 4), "render_d_fwd_k3_ms": round(ms_d3, 4),
                    "render_d_rev_ms": round(ms_rev, 4), "render_d_rev_all_ms": round(ms_rev_all, 4),
+                   "render_c_keep_records_ms": round(ms_c_keep, 4), "render_d_rev_all_on_kept_records_ms": round(ms_rev_all_kept, 4), "rays_of_rev_on_kept_records": int(rays_rev_kept),
                    "note": "psdr_render_c + psdr_render_d_fwd (K=1) launches of the same samples; K=3 = d/d(r,g,b) in one pass (round-1 headline form); "
-                           "rev = psdr_render_d_rev, texel gradient; rev_all = texels + emitter radiance + triangle rows (geometry) + camera pose"}
+                           "rev = psdr_render_d_rev, texel gradient; rev_all = texels + emitter radiance + triangle rows (geometry) + camera pose; "
+                           "keep_records pair = psdr_render_c(PSDR_FLAG_KEEP_RECORDS) as the value kernel + psdr_render_d_rev (all tables) as the adjoint kernel alone"}
     surface = {"ms_per_step": round(dt / args.steps * 1e3, 4), "configure_ms": round(ms_configure, 4),
                "reverse_step_ms": round(ms_rev_surface, 4),
                "reverse_all_step_ms": round(ms_rev_all_surface, 4) if ms_rev_all_surface is not None else None,

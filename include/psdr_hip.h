@@ -174,7 +174,10 @@ typedef struct psdr_scene_desc {
    later).  Where the following psdr_render_d_rev would run a split launch whose value sweep is exactly this render -- PathTracer on a two-level scene, the
    traced wavefront, one chunk of slots -- the render runs with recording stages and the per-path records stay on the handle; a psdr_render_d_rev with the
    same options, the same tables (psdr_scene_set_tables with an identical descriptor in between is fine; the caller must not have overwritten them in
-   place) and out_img = NULL then runs its adjoint kernel only (C4 shard: 15.6 of its 34.5 ms).  Ignored wherever that does not apply. */
+   place) and out_img = NULL then runs its adjoint kernel only (C4 shard: 15.6 of its 34.5 ms).  Where the wavefront does not apply (a scene without a
+   tree: the 12-triangle cbox) the PathTracer render runs as the value kernel of a split reverse launch instead (image + one record per path) and a
+   psdr_render_d_rev that asks for a geometry table (tri_info / cam_to_world) runs the adjoint kernel on it (cbox 512^2 x 64: 0.85 + 4.86 -> 1.25 + 4.0 ms).
+   Ignored wherever neither applies (other integrators, paths deeper than 8, more slots than one chunk, option rev_split = 0). */
 #define PSDR_FLAG_KEEP_RECORDS 8
 
 /* One render call = Integrator::renderC / renderD on one shard of the sample

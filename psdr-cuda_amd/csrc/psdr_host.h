@@ -260,7 +260,7 @@ struct psdr_scene_s {
     void *d_rev = nullptr;
     size_t rev_bytes = 0;
     // ... kept across calls by psdr_render_c(PSDR_FLAG_KEEP_RECORDS) for the psdr_render_d_rev of the same samples and tables
-    struct KeptRecords { bool valid = false; psdr_render_opts o{}; uint64_t gen = 0; long long n = 0; } kept;
+    struct KeptRecords { bool valid = false; psdr_render_opts o{}; uint64_t gen = 0; long long n = 0; int kind = 0; } kept;      // kind 1: the traced wavefront's records (c, f per vertex), 0: the value kernel's (suffix radiances)
     uint64_t tables_gen = 0;               // bumped whenever psdr_scene_set_tables installs a descriptor that differs from the current one
 
     // wavefront PathTracer: path-state streams + stream counters

@@ -1316,6 +1316,9 @@ template <int FL, bool GEO, int INTEG> constexpr bool reg_priv_kernel() { return
 #ifndef PSDR_WAVES_REV_VALUE
 #define PSDR_WAVES_REV_VALUE 3          // value kernel of a split reverse launch
 #endif
+#ifndef PSDR_WAVES_REV_VALUE_TINY
+#define PSDR_WAVES_REV_VALUE_TINY 3     // ... of a PathTracer on a scene without a tree: the recording primal render of psdr_render_c(PSDR_FLAG_KEEP_RECORDS)
+#endif
 #ifndef PSDR_WAVES_REV_MAT
 #define PSDR_WAVES_REV_MAT 3
 #endif
@@ -1334,7 +1337,7 @@ template <int FL, bool GEO, int INTEG> constexpr int rev_waves() {
 // workgroups per CU -- the tree walks are latency-bound and the adjoint code's registers hold the fused kernel at 2 -- writing a
 // record per path to `disk`; STAGE 2 = the adjoint sweep from that record: no traversal, no stacks in LDS.
 template <int FL, bool GEO, int INTEG, int STAGE = 0>
-__global__ __launch_bounds__(kBlock, (STAGE == 1 ? PSDR_WAVES_REV_VALUE : rev_waves<FL, GEO, INTEG>())) void k_camera_rev(LaunchCtx cx, DeviceSink<FL> sink_arg, int spp, int s_begin, SlotDiv nsp, long long j0,
+__global__ __launch_bounds__(kBlock, (STAGE == 1 ? (((FL & kSceneTiny) != 0 && INTEG == PSDR_INTEGRATOR_PATH) ? PSDR_WAVES_REV_VALUE_TINY : PSDR_WAVES_REV_VALUE) : rev_waves<FL, GEO, INTEG>())) void k_camera_rev(LaunchCtx cx, DeviceSink<FL> sink_arg, int spp, int s_begin, SlotDiv nsp, long long j0,
                                                        long long n, float inv_spp, const float *__restrict__ adj_img, float *__restrict__ img,
                                                        unsigned long long *counters, float *__restrict__ disk, long long disk_stride, float *__restrict__ deep, int disk_cf,
                                                        ProbeView pv) {
@@ -1365,8 +1368,8 @@ __global__ __launch_bounds__(kBlock, (STAGE == 1 ? PSDR_WAVES_REV_VALUE : rev_wa
         if (in) {
             const int s = s_begin + s_in;
             const uint64_t slot = (uint64_t) pixel * (uint64_t) spp + (uint64_t) s;
-            const float *a = adj_img + (size_t) pixel * 3;
-            const Vec3f adj{a[0] * inv_spp, a[1] * inv_spp, a[2] * inv_spp};
+            Vec3f adj(0.f);                  // the value kernel of a split launch has no use for it (and psdr_render_c's recording render has none)
+            if constexpr (STAGE != 1) { const float *a = adj_img + (size_t) pixel * 3; adj = Vec3f{a[0] * inv_spp, a[1] * inv_spp, a[2] * inv_spp}; }
             const RevDisk dk{disk + jj, disk_stride, disk_cf};
             const Vec3f r = camera_sample_reverse<GEO, INTEG, STAGE>(sink, pg, rec, cx.sc, st, cx.lp, cx.jump, pixel, slot, adj, nrays, dk);
             v[0] = r.x * inv_spp; v[1] = r.y * inv_spp; v[2] = r.z * inv_spp;
@@ -2096,9 +2099,17 @@ inline int rev_record_words(const psdr_scene_s *h, int depth, bool wavefront_or_
     return kRevDiskHead + (wavefront_or_vertex ? kRevDiskPerVertexCf : kRevDiskPerVertex) * depth + (h->opt.rev_vertex != 0 ? kRevStateWords : 0);
 }
 
+// value_only (psdr_render_c with PSDR_FLAG_KEEP_RECORDS where the traced wavefront does not apply -- a scene without a tree, a small launch): the PathTracer's
+// primal render runs as the VALUE KERNEL of a split reverse launch (k_camera_rev STAGE 1: image + one record per path, kept on the handle), and the
+// psdr_render_d_rev of the same samples runs its adjoint kernel (STAGE 2) only.  Returns 1 when that does not apply (the caller renders as usual).
 template <int FL>
-int render_rev(psdr_scene_s *h, const psdr_render_opts *o, const float *adj_img, float *out_img, const psdr_grads *grads, hipStream_t s) {
+int render_rev_impl(psdr_scene_s *h, const psdr_render_opts *o, const float *adj_img, float *out_img, const psdr_grads *grads, hipStream_t s, bool value_only) {
     const long long WH = (long long) h->desc.width * h->desc.height;
+    if (value_only) {
+        const long long nv = WH * (o->spp_end - o->spp_begin);
+        if (o->integrator != PSDR_INTEGRATOR_PATH || o->max_depth > kMaxRevDepth || o->max_depth < 1 || h->opt.rev_split == 0 || h->opt.rev_vertex != 0 || o->spp <= 0 || nv <= 0 ||
+            nv > launch_chunk(h, 26)) return 1;
+    }
     if (out_img) HIP_TRY(hipMemsetAsync(out_img, 0, sizeof(float) * WH * 3, s));
     DeviceSink<FL> sink{}; sink.g = *grads; sink.L = make_sink_layout(h, grads);
     // the instances of scenes without a tree address a triangle's cached row directly (DeviceSink::add_tri): every row cached, slot == triangle
@@ -2120,7 +2131,7 @@ int render_rev(psdr_scene_s *h, const psdr_render_opts *o, const float *adj_img,
             if (int rc = scratch_reserve(&h->d_rev_deep, &h->rev_deep_bytes, need, s, "deep path records of the reverse launch")) return rc;
             deep = reinterpret_cast<float *>(h->d_rev_deep);
         }
-        const bool geo = grads->g_tri_info != nullptr || grads->g_cam_to_world != nullptr;
+        const bool geo = value_only || grads->g_tri_info != nullptr || grads->g_cam_to_world != nullptr;
         const int wg_per_cu = (o->integrator == PSDR_INTEGRATOR_DIRECT && !(FL & kSceneRough)) ? 3 : 2;       // rev_waves<FL, true, INTEG>
         // Split launch: a scene with a tree to walk, geometry gradients (the register-heavy kernel), hits replayable.
         const int split_env = h->opt.rev_split;
@@ -2130,7 +2141,10 @@ int render_rev(psdr_scene_s *h, const psdr_render_opts *o, const float *adj_img,
         // 11.4 -> 9.4, PathTracer(6) 21 -> 12 / 13 -> 7.3 / 36 -> 20; the DirectIntegrator (three rays per slot) only gains on the
         // large tree (3.8 -> 3.3 ms; bunny scenes 2.0 -> 2.4); the 12-triangle box neither way
         const bool worth = o->integrator == PSDR_INTEGRATOR_PATH ? o->max_depth >= 2 : h->num_nodes >= 16384;
-        const bool split = geo && replayable && split_env != 0 && (split_env == 1 || (has_tree && worth && n >= (1ll << 20)));
+        // the records a recording psdr_render_c (value_only, above) left of exactly these samples on exactly these tables: this call is their adjoint kernel
+        const bool kept_fused = !value_only && geo && o->integrator == PSDR_INTEGRATOR_PATH && !deep_rec && h->opt.rev_vertex == 0 && split_env != 0 && h->kept.valid && h->kept.kind == 0 &&
+                                h->kept.gen == h->tables_gen && h->kept.n == n && out_img == nullptr && same_camera_samples(h->kept.o, *o) && n <= launch_chunk(h, 26);
+        const bool split = value_only || kept_fused || (geo && replayable && split_env != 0 && (split_env == 1 || (has_tree && worth && n >= (1ll << 20))));
         // adjoint sweep of a split PathTracer launch vertex by vertex (k_vertex_rev): psdr_scene_set_option("rev_vertex", 0) keeps the one adjoint kernel
         const bool vrev = split && o->integrator == PSDR_INTEGRATOR_PATH && h->opt.rev_vertex != 0;
         // adjoint kernel of a split launch: nothing of the tree staged, no stacks -- only what plan_lds places without any room (the hit rows of
@@ -2185,7 +2199,7 @@ int render_rev(psdr_scene_s *h, const psdr_render_opts *o, const float *adj_img,
         // in the fused value kernel a wave pays its slowest lane's tree walk at every closest_hit (C4 shard: 29 ms of the 57; renderC by the
         // wavefront: 16 ms)
         bool wf_value = false;
-        if constexpr ((FL & kSceneForest) != 0) wf_value = split && !no_tree && o->integrator == PSDR_INTEGRATOR_PATH && !deep_rec && traced_wavefront(h) && use_wavefront(h, o);
+        if constexpr ((FL & kSceneForest) != 0) wf_value = split && !value_only && !kept_fused && !no_tree && o->integrator == PSDR_INTEGRATOR_PATH && !deep_rec && traced_wavefront(h) && use_wavefront(h, o);
         // (rev_value_sweep_is_wavefront states the same rule for psdr_render_c's PSDR_FLAG_KEEP_RECORDS; `geo` and the option rev_split == 1 on a scene
         // without a tree are the caller's side of it)
         const int disk_cf = wf_value ? 1 : (vrev ? 2 : 0);
@@ -2203,13 +2217,13 @@ int render_rev(psdr_scene_s *h, const psdr_render_opts *o, const float *adj_img,
             if (int rc = scratch_reserve(&h->d_rev, &h->rev_bytes, need, s, "per-path records of the split reverse launch")) return rc;
             float *disk = reinterpret_cast<float *>(h->d_rev);
             // the records psdr_render_c(PSDR_FLAG_KEEP_RECORDS) left of exactly these samples on exactly these tables: the value sweep is already there
-            const bool reuse = wf_value && h->kept.valid && h->kept.gen == h->tables_gen && h->kept.n == n && chunk >= n && out_img == nullptr &&
+            const bool reuse = (wf_value ? h->kept.kind == 1 : kept_fused) && h->kept.valid && h->kept.gen == h->tables_gen && h->kept.n == n && chunk >= n && out_img == nullptr &&
                                same_camera_samples(h->kept.o, *o) && need <= h->rev_bytes;
             if (!reuse || vrev) h->kept.valid = false;          // this launch overwrites them (or its per-vertex launches turn (c, f) into suffix radiances in place)
             for (long long c0 = 0; c0 < n; c0 += chunk) {
                 const long long nc = std::min(chunk, n - c0);
                 if (o->integrator == PSDR_INTEGRATOR_PATH) {
-                    if (wf_value && reuse) {
+                    if (reuse) {
                         // (nothing: the adjoint kernel below reads the kept records)
                     } else if (wf_value) {
                         if constexpr ((FL & kSceneForest) != 0) {
@@ -2219,6 +2233,11 @@ int render_rev(psdr_scene_s *h, const psdr_render_opts *o, const float *adj_img,
                         }
                     } else
                     PSDR_LAUNCH_REV_K(true, PSDR_INTEGRATOR_PATH, 1, cx, dyn1, c0, nc, out_img, disk, chunk);
+                    if (value_only) {
+                        HIP_TRY(hipGetLastError());
+                        h->kept.valid = true; h->kept.o = *o; h->kept.gen = h->tables_gen; h->kept.n = n; h->kept.kind = 0;
+                        return 0;
+                    }
                     if (vrev) {
                         // launch k = the adjoint of path vertex k (psdr_reverse.h vertex_reverse_first / _next): record + state column in, state column out
                         LaunchCtx cxv = cx2;
@@ -2370,6 +2389,11 @@ int guide_launch(psdr_scene_s *h, LaunchCtx &cx, const int32_t reso[4], int nrou
 }
 
 template <int FL>
+int render_rev(psdr_scene_s *h, const psdr_render_opts *o, const float *adj_img, float *out_img, const psdr_grads *grads, hipStream_t s) {
+    return render_rev_impl<FL>(h, o, adj_img, out_img, grads, s, false);
+}
+
+template <int FL>
 int render_c_launch(psdr_scene_s *h, const psdr_render_opts *o, float *out_img, hipStream_t s) {
     const TangentView<0, FL> tv0{};
     if constexpr ((FL & kSceneForest) != 0) {
@@ -2383,9 +2407,16 @@ int render_c_launch(psdr_scene_s *h, const psdr_render_opts *o, float *out_img, 
             const WfRecArgs ra{reinterpret_cast<float *>(h->d_rev), n, 0, n};
             if (int rc = run_camera_wavefront<float, FL>(h, o, tv0, out_img, nullptr, s, &ra)) return rc;
             h->slots[0] += (uint64_t) n;
-            h->kept.valid = true; h->kept.o = *o; h->kept.gen = h->tables_gen; h->kept.n = n;
+            h->kept.valid = true; h->kept.o = *o; h->kept.gen = h->tables_gen; h->kept.n = n; h->kept.kind = 1;
             return 0;
         }
+    }
+    if ((o->flags & PSDR_FLAG_KEEP_RECORDS) != 0 && h->opt.keep_records != 0 && !use_wavefront(h, o)) {
+        // where the reverse launch that follows would run BOTH sweeps in one kernel (a scene without a tree: the headline's cbox): this render is its value
+        // kernel (render_rev value_only); 1 = does not apply
+        const psdr_grads none{};
+        const int rc = render_rev_impl<FL>(h, o, nullptr, out_img, &none, s, true);
+        if (rc != 1) return rc;
     }
     if (use_wavefront(h, o)) return run_camera_wavefront<float, FL>(h, o, tv0, out_img, nullptr, s);
     return run_camera<float, float, FL>(h, o, tv0, out_img, nullptr, s);

@@ -276,6 +276,46 @@ def test_render_c_keeps_the_value_sweep_records_for_the_reverse_call():
 
 
 @pytest.mark.gpu
+def test_render_c_keeps_records_on_a_scene_without_a_tree():
+    """PSDR_FLAG_KEEP_RECORDS where the traced wavefront does not apply (the headline's 12-triangle cbox): the reverse launch of a PathTracer runs both sweeps in ONE
+    kernel there, a third of it the value sweep.  With the flag psdr_render_c runs the VALUE KERNEL of a split launch (k_camera_rev STAGE 1: image + one record per
+    path) and the psdr_render_d_rev of the same samples its adjoint kernel only: same image, same gradients, no ray counted by the reverse call."""
+    from helpers import GpuScene, load_scene, rel_l2
+    res, spp = 128, 8
+    sc, _ = load_scene("cbox", res=res, spp=spp)
+    tb = sc.tables(0)
+    adj = np.random.default_rng(6).random((res * res, 3)).astype(np.float32)
+    names = ["tri_info", "texels", "emitter_rad", "cam_to_world"]
+    for depth in (1, 3):
+        kw = dict(integrator=_abi.INTEGRATOR_PATH, max_depth=depth, spp=spp, rng_offset=(3, 0, 0))
+        g = GpuScene(tb)
+        img_plain = g.render_c(_abi.make_opts(**kw)); rays_c = g.counters()[0]
+        _, g_plain = g.render_d_rev(_abi.make_opts(**kw), adj, want=names, with_image=False)
+        assert g.counters()[0] == rays_c > 0
+        img_keep = g.render_c(_abi.make_opts(flags=_abi.FLAG_KEEP_RECORDS, **kw))
+        assert g.counters()[0] == rays_c and rel_l2(img_keep, img_plain) < 1e-5, (g.counters(), rays_c, rel_l2(img_keep, img_plain))
+        _, g_keep = g.render_d_rev(_abi.make_opts(**kw), adj, want=names, with_image=False)
+        assert g.counters()[0] == 0, g.counters()                # the adjoint kernel re-intersects the recorded triangles: no ray
+        for k in names:
+            assert np.abs(g_plain[k]).max() > 0 and rel_l2(g_keep[k], g_plain[k]) < 1e-5, (depth, k, rel_l2(g_keep[k], g_plain[k]))
+        # texel-only gradients (no geometry table wanted) do not use the records; other samples neither
+        g.render_c(_abi.make_opts(flags=_abi.FLAG_KEEP_RECORDS, **kw))
+        _, g_tex = g.render_d_rev(_abi.make_opts(**kw), adj, want=["texels"], with_image=False)
+        assert g.counters()[0] == rays_c and rel_l2(g_tex["texels"], g_plain["texels"]) < 1e-5
+        g.render_c(_abi.make_opts(flags=_abi.FLAG_KEEP_RECORDS, **kw))
+        g.render_d_rev(_abi.make_opts(**dict(kw, rng_offset=(4, 0, 0))), adj, want=names, with_image=False)
+        assert g.counters()[0] > 0
+    # a path deeper than the LDS record holds: the flag is ignored, the reverse call runs both sweeps
+    kw = dict(integrator=_abi.INTEGRATOR_PATH, max_depth=10, spp=2, rng_offset=(3, 0, 0))
+    g = GpuScene(tb)
+    img_plain = g.render_c(_abi.make_opts(**kw)); rays_c = g.counters()[0]
+    img_keep = g.render_c(_abi.make_opts(flags=_abi.FLAG_KEEP_RECORDS, **kw))
+    assert rel_l2(img_keep, img_plain) < 1e-6
+    g.render_d_rev(_abi.make_opts(**kw), adj, want=names, with_image=False)
+    assert g.counters()[0] == rays_c
+
+
+@pytest.mark.gpu
 def test_surface_backward_reuses_the_primal_render_of_a_path_tracer():
     """The same through the drop-in surface (docs/inverse_diff_render.rst: renderD, a torch loss on the image, enoki.backward): the vertex gradient of the bunny
     with and without the kept records, and the reverse call's ray counter."""

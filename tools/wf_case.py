@@ -42,7 +42,7 @@ elif case in ("c4fg", "c5fg"):
         P = FloatD(0.); ek.set_requires_gradient(P)
         sc.m_meshes[8].set_transform(Matrix4fD.translate(Vector3fD([1.0, 0.4, -0.3]) * P)); sc.configure()
         o = _abi.make_opts(spp=16, integrator=_abi.INTEGRATOR_PATH, max_depth=3, flags=flags); n = 512 * 512 * 16
-elif case in ("c2ra", "c2rt"):
+elif case in ("c2ra", "c2rt", "c2keep"):
     # C2 (cbox 512^2 spp 64, no tree) PathTracer(3) reverse: every gradient table / the texels only
     sc, _ = load_scene("cbox", res=512, spp=64)
     o = _abi.make_opts(spp=64, integrator=_abi.INTEGRATOR_PATH, max_depth=3, flags=flags); n = 512 * 512 * 64
@@ -71,10 +71,19 @@ elif case in ("c4pr", "c5pr"):
 elif case in ("c2ra", "c2rt"):
     adj = np.random.default_rng(0).random((tb["width"] * tb["height"], 3)).astype(np.float32)
     run = lambda: g.render_d_rev(o, adj, want=["texels", "emitter_rad", "tri_info", "cam_to_world"] if case == "c2ra" else ["texels"], with_image=False)
+elif case == "c2keep":
+    # the pair of an optimisation step with geometry gradients on a scene without a tree: recording primal render + the adjoint kernel on its records
+    adj = np.random.default_rng(0).random((tb["width"] * tb["height"], 3)).astype(np.float32)
+    ok = _abi.make_opts(spp=64, integrator=_abi.INTEGRATOR_PATH, max_depth=3, flags=flags | _abi.FLAG_KEEP_RECORDS)
+    def run():
+        t0 = time.perf_counter(); g.render_c(ok); t1 = time.perf_counter()
+        g.render_d_rev(o, adj, want=["texels", "emitter_rad", "tri_info", "cam_to_world"], with_image=False)
+        run.parts = ((t1 - t0) * 1e3, (time.perf_counter() - t1) * 1e3)
 else:
     run = lambda: g.render_c(o)
 run(); torch.cuda.synchronize()
 ts = []
 for _ in range(reps):
     t0 = time.perf_counter(); run(); torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
-print("%s %s: %s ms (median %.2f), rays/slot %.2f" % (case, mode, " ".join("%.2f" % t for t in ts), sorted(ts)[len(ts) // 2], g.counters()[0] / n))
+print("%s %s: %s ms (median %.2f), rays/slot %.2f%s" % (case, mode, " ".join("%.2f" % t for t in ts), sorted(ts)[len(ts) // 2], g.counters()[0] / n,
+                                                         "  last call: render_c %.2f + render_d_rev %.2f ms" % run.parts if case == "c2keep" else ""))
