@@ -311,7 +311,8 @@ class PerspectiveCamera(Sensor):
         # the host, the inverse of a pose without gradient is a constant), what depends on the lens only when the lens changed
         pose_key = (id(tw), tw.data_ptr(), tw._version)
         if getattr(self, "_pose_key", None) != pose_key:
-            det = torch.det(tw[:3, :3].detach().double()).item()
+            # ONE 36-byte read-back and a host determinant: torch.det on the device is an LU factorisation plus a dozen pivot-sign kernels in front of the same read
+            det = float(np.linalg.det(tw.detach()[:3, :3].cpu().double().numpy()))
             psdr_assert(abs(det - 1.0) < 1e-4, "Sensor transformation should not involve scaling!")   # sensor.cpp:8-12
             self._pose_key, self._pose_inv = pose_key, (None if tw.requires_grad else torch.linalg.inv(tw))
             self._pose_alive = tw                  # the keyed tensor stays alive: its id / allocator block cannot be recycled under the key
