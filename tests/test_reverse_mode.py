@@ -316,7 +316,8 @@ def test_render_c_keeps_records_on_a_scene_without_a_tree():
 
 
 @pytest.mark.gpu
-def test_surface_backward_reuses_the_primal_render_of_a_path_tracer():
+@pytest.mark.parametrize("scene,mesh_key,res,spp", [("cbox_bunny", "Mesh[1]", 256, 16), ("cbox", "Mesh[0]", 128, 8)])
+def test_surface_backward_reuses_the_primal_render_of_a_path_tracer(scene, mesh_key, res, spp):
     """The same through the drop-in surface (docs/inverse_diff_render.rst: renderD, a torch loss on the image, enoki.backward): the vertex gradient of the bunny
     with and without the kept records, and the reverse call's ray counter."""
     import enoki as ek
@@ -326,12 +327,12 @@ def test_surface_backward_reuses_the_primal_render_of_a_path_tracer():
     out = {}
     for keep in (1, 0):
         sc = psdr_cuda.Scene()
-        sc.load_file(scene_path("cbox_bunny"), False)
+        sc.load_file(scene_path(scene), False)
         sc.native_options = {"keep_records": keep}
-        sc.opts.width = sc.opts.height = 256
-        sc.opts.spp, sc.opts.sppe, sc.opts.sppse, sc.opts.log_level = 16, 0, 0, 0
+        sc.opts.width = sc.opts.height = res
+        sc.opts.spp, sc.opts.sppe, sc.opts.sppse, sc.opts.log_level = spp, 0, 0, 0
         integ = psdr_cuda.PathTracer(3)
-        mesh = sc.param_map["Mesh[1]"]
+        mesh = sc.param_map[mesh_key]
         v = Vector3fD(ek.detach(mesh.vertex_positions)); ek.set_requires_gradient(v); mesh.vertex_positions = v
         sc.configure()
         img = integ.renderD(sc)
@@ -341,4 +342,5 @@ def test_surface_backward_reuses_the_primal_render_of_a_path_tracer():
     (ga, rays_a, ia), (gb, rays_b, ib) = out[1], out[0]
     assert rays_a == 0 and rays_b > 0, (rays_a, rays_b)
     assert np.abs(gb).max() > 0 and np.isfinite(ga).all()
-    assert np.linalg.norm(ga - gb) < 1e-4 * np.linalg.norm(gb) and np.linalg.norm(ia - ib) < 1e-6 * np.linalg.norm(ib)
+    # (a scene without a tree renders its recording primal image with the value kernel of a split launch: the same estimator in another kernel)
+    assert np.linalg.norm(ga - gb) < 1e-4 * np.linalg.norm(gb) and np.linalg.norm(ia - ib) < (1e-6 if scene == "cbox_bunny" else 1e-5) * np.linalg.norm(ib)
