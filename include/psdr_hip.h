@@ -236,7 +236,8 @@ int psdr_scene_destroy(psdr_scene_t h);
 /* Developer options of a handle -- the A/B switches of tools and tests (the reference has none: its strategies are fixed by OptiX and
    Enoki); the library reads NO environment variable.  Names (value): bvh_refit, tiny_scene, two_level, wf_binned, wf_traced, sort_edges,
    tiny_variants, sink_private, aa_prims (0 / 1); bvh_build (1 device, 0 host, -1 by size); wide (0: never the 4-wide tree in the render kernels);
-   rev_split, sedge_split (1 / 0 force, -1 default rule); keep_records (0: PSDR_FLAG_KEEP_RECORDS is ignored); rev_sorted (0: reverse PathTracer kernels
+   rev_split, sedge_split (1 / 0 force, -1 default rule); keep_records (0: PSDR_FLAG_KEEP_RECORDS is ignored); logd (0: PathTracer forward mode with tangents on
+   diffuse albedo texels only runs the dual-number kernel, never the log-derivative one); rev_sorted (0: reverse PathTracer kernels
    scatter row adjoints on the spot); wf_geo (0: PathTracer geometry tangents through the fused kernel); tangent_live (0: no liveness mask); rev_vertex (1: the adjoint sweep of a split PathTracer launch as one launch per path
    vertex, 0 default: one adjoint kernel); vrev_blocks (workgroups per CU of those launches); probe (0: no probe / trace / final launches);
    trace_wg2 (dense trace kernel as two workgroups per CU: -1 by forest and launch size, 0 never, n > 0 always with stack columns of n entries);

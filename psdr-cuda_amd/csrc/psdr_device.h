@@ -1329,6 +1329,73 @@ template <int K> PSDR_HD Dual<K> zero_nonfinite(const Dual<K> &x) {
 }
 template <class R> PSDR_HD Vec3<R> zero_nonfinite(const Vec3<R> &v) { return {zero_nonfinite(v.x), zero_nonfinite(v.y), zero_nonfinite(v.z)}; }
 
+// PathTracer, forward mode, tangents on DIFFUSE ALBEDO TEXELS ONLY (the headline's renderD w.r.t. the diffuse albedo, examples/run_test.py:126-129): a path's
+// contribution is a product of albedos times factors no tangent reaches (the cosine-hemisphere pdf, the MIS weights, the emitted radiance), so
+//     d/dP [ beta_k c_k ] = beta_k c_k * sum_{j <= k} (d rho_j / rho_j)          per channel,
+// and the whole estimator runs on PLAIN FLOATS with three running sums per tangent set instead of dual numbers through every BSDF value, weight and
+// throughput product (C2: the K = 1 kernel 0.99 -> see DESIGN.md round 5).  Exact wherever the albedo of a texel that carries a tangent is not zero;
+// the launch checks that on the device (psdr_kernels.h k_logd_check) and runs the dual-number kernel otherwise.  tv: the K tangent sets (texels only).
+template <int K, class TVT>
+PSDR_HD void albedo_logd(const SceneView &sc, const TVT &tv, const Its<float> &its, float (&g)[K][3]) {
+    const int bsdf_id = Tab<TVT::flags>::mesh_bsdf(sc, its.mesh);
+#pragma unroll
+    for (int k = 0; k < K; ++k) g[k][0] = g[k][1] = g[k][2] = 0.f;
+    if (bsdf_id < 0) return;
+    const Bsdf<float, Dual<K>> bsdf(sc, tv, bsdf_id);
+    const Vec3<Dual<K>> rho = bsdf.tex3(sc, tv, PSDR_SLOT_REFLECTANCE, its);
+    const float ix = rho.x.v != 0.f ? 1.f / rho.x.v : 0.f, iy = rho.y.v != 0.f ? 1.f / rho.y.v : 0.f, iz = rho.z.v != 0.f ? 1.f / rho.z.v : 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) { g[k][0] = rho.x.d[k] * ix; g[k][1] = rho.y.d[k] * iy; g[k][2] = rho.z.d[k] * iz; }
+}
+template <int K, class TVT>
+PSDR_HD Vec3<Dual<K>> li_path_logd(const SceneView &sc, const TVT &tv, TraversalStack &st, const LiParams &lp, Rng &rng, const RayT<float> &ray, uint32_t &nrays) {
+    const TangentView<0, TVT::flags> tv0{};
+    Its<float> its = intersect<float>(sc, tv0, st, ray, true, kDetached, nrays, -1, -1, kPrePrimaryRay);
+    bool active = its.valid;
+    Vec3f result = lp.hide_emitters ? Vec3f(0.f) : Le<float>(sc, tv0, its, active);
+    float rd[K][3], s[K][3];
+#pragma unroll
+    for (int k = 0; k < K; ++k) { rd[k][0] = rd[k][1] = rd[k][2] = 0.f; s[k][0] = s[k][1] = s[k][2] = 0.f; }
+    Vec3f beta(1.f);
+    for (int depth = 0; depth < lp.max_depth; ++depth) {
+        Its<float> nits; Vec3f nf; bool nvalid = false;
+        float g[K][3];
+        if (active) albedo_logd<K>(sc, tv, its, g);
+        const Vec3f c = direct_step<float, float>(sc, tv0, st, rng, its, active, 1, 1, nrays, &nits, &nf, &nvalid);
+        if (active) {
+            const Vec3f bc = beta * c;
+            result = result + bc;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                s[k][0] += g[k][0]; s[k][1] += g[k][1]; s[k][2] += g[k][2];
+                rd[k][0] = fmaf(bc.x, s[k][0], rd[k][0]); rd[k][1] = fmaf(bc.y, s[k][1], rd[k][1]); rd[k][2] = fmaf(bc.z, s[k][2], rd[k][2]);
+            }
+            active = nvalid;
+            if (active) {
+                beta = beta * nf;
+                its = nits;
+                if (!(beta.x != 0.f || beta.y != 0.f || beta.z != 0.f)) active = false;
+            }
+        }
+    }
+    Vec3<Dual<K>> out;
+    out.x.v = result.x; out.y.v = result.y; out.z.v = result.z;
+#pragma unroll
+    for (int k = 0; k < K; ++k) { out.x.d[k] = rd[k][0]; out.y.d[k] = rd[k][1]; out.z.d[k] = rd[k][2]; }
+    return out;
+}
+template <int K, class TVT>
+PSDR_HD Vec3<Dual<K>> camera_sample_logd(const SceneView &sc, const TVT &tv, TraversalStack &st, const LiParams &lp, const RngJump &jump, int pixel, uint64_t slot, uint32_t &nrays) {
+    Rng rng; rng.init(slot, jump);
+    const float j0 = rng.next(), j1 = rng.next();
+    const int W = sc.d.width;
+    const float sx = ((float) (pixel % W) + j0) / (float) W, sy = ((float) (pixel / W) + j1) / (float) sc.d.height;
+    const TangentView<0, TVT::flags> tv0{};
+    const RayT<float> ray = primary_ray<float>(sc, tv0, sx, sy);
+    return zero_nonfinite(li_path_logd<K>(sc, tv, st, lp, rng, ray, nrays));
+}
+
+
 // Wavefront mode, stage 0: camera ray, primary hit, Le and the direct step at the primary vertex;
 // reports the BSDF-sampled continuation (next vertex record + throughput).
 template <class M, class TVT>

@@ -956,6 +956,7 @@ int psdr_scene_set_option(psdr_scene_t h, const char *name, double value) {
     else if (n == "rev_split") h->opt.rev_split = iv;
     else if (n == "tangent_live") h->opt.tangent_live = iv;              // 0: forward-mode kernels load the tangents of every triangle row (no liveness mask)
     else if (n == "wf_geo") h->opt.wf_geo = iv;                          // 0: geometry tangents of the PathTracer always through the fused kernel
+    else if (n == "logd") h->opt.logd = iv;                              // 0: PathTracer forward mode never runs the log-derivative kernel
     else if (n == "keep_records") h->opt.keep_records = iv;              // 0: psdr_render_c ignores PSDR_FLAG_KEEP_RECORDS
     else if (n == "rev_sorted") h->opt.rev_sorted = iv;                  // 0: the reverse camera kernels scatter every row adjoint on the spot (no deferred, sorted adds)
     else if (n == "rev_vertex") h->opt.rev_vertex = iv;                  // 1: the adjoint sweep of a split PathTracer launch as a launch per path vertex (default 0: one adjoint kernel)
@@ -981,6 +982,7 @@ int psdr_scene_destroy(psdr_scene_t h) {
     if (h->d_sort) (void) hipFree(h->d_sort);
     if (h->d_ws) (void) hipFree(h->d_ws);
     if (h->d_live) (void) hipFree(h->d_live);
+    if (h->d_logd_bad) (void) hipFree(h->d_logd_bad);
     if (h->d_hot_map) (void) hipFree(h->d_hot_map);
     if (h->d_hot_tris) (void) hipFree(h->d_hot_tris);
     if (h->d_top) (void) hipFree(h->d_top);

@@ -159,6 +159,7 @@ struct psdr_scene_options {
     int rev_split = -1;                    // reverse mode as value kernel + adjoint kernel: 1 / 0 force, -1 by scene and launch size
     int tangent_live = 1;                  // forward mode with geometry tangents: one bit per triangle "some tangent set moves this row" (TangentView::live); 0: every row loads its tangents
     int wf_geo = 1;                        // PathTracer forward mode with geometry tangents on a two-level scene as the traced wavefront (k_wfg_*); 0: the fused kernel
+    int logd = 1;                          // PathTracer forward mode with tangents on diffuse albedo texels only: the log-derivative kernel (0: always dual numbers)
     int keep_records = 1;                  // psdr_render_c honours PSDR_FLAG_KEEP_RECORDS (0: ignored -- A/B, tests)
     int rev_sorted = 1;                    // reverse camera kernels with geometry gradients: complete row adjoints wait in LDS and leave sorted by row at the slot's end (0: scattered on the spot)
     int rev_vertex = 0;                    // 1: adjoint sweep of a split PathTracer launch as one launch per path vertex (k_vertex_rev, round 5: built, measured SLOWER than the
@@ -260,6 +261,7 @@ struct psdr_scene_s {
     void *d_rev = nullptr;
     size_t rev_bytes = 0;
     // ... kept across calls by psdr_render_c(PSDR_FLAG_KEEP_RECORDS) for the psdr_render_d_rev of the same samples and tables
+    void *d_logd_bad = nullptr; size_t logd_bad_bytes = 0;      // the log-derivative launches' gate flag
     struct KeptRecords { bool valid = false; psdr_render_opts o{}; uint64_t gen = 0; long long n = 0; int kind = 0; } kept;      // kind 1: the traced wavefront's records (c, f per vertex), 0: the value kernel's (suffix radiances)
     uint64_t tables_gen = 0;               // bumped whenever psdr_scene_set_tables installs a descriptor that differs from the current one
 

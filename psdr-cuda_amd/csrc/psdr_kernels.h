@@ -136,6 +136,9 @@ PSDR_HD void slot_to_pixel(long long j, const SlotDiv &nsp, int &pixel, int &s) 
 // the plain diffuse / area-light variant (FL == 0) is lean enough for one more wave: renderC 5 waves/SIMD (C2
 // PathTracer(3) 2.06 -> 1.89 ms), material duals of the PathTracer 4 (2.85 -> 2.66 ms); the rough-conductor
 // variants lose 10 % there (C5 renderC 5.0 -> 5.5 ms) and the DirectIntegrator K = 3 instance 20 %
+#ifndef PSDR_LOGD
+#define PSDR_LOGD 1
+#endif
 template <class G, class R, int INTEG, int FL, bool NOTREE = false> constexpr int camera_waves() {
     constexpr bool lean = (FL & (kSceneEnv | kSceneRough)) == 0;          // plain diffuse / area light (with or without a two-level tree)
     if (!is_ad<R>()) return lean ? PSDR_WAVES_C + 1 : PSDR_WAVES_C;
@@ -153,12 +156,20 @@ template <class G, class R, int INTEG, int FL, bool NOTREE = false> constexpr in
     if (lean && NOTREE && INTEG == PSDR_INTEGRATOR_PATH) return ad_traits<R>::K == 1 ? PSDR_WAVES_DM + 2 : PSDR_WAVES_DM + 1;
     return (lean && INTEG == PSDR_INTEGRATOR_PATH && ad_traits<R>::K == 1) ? PSDR_WAVES_DM + 1 : PSDR_WAVES_DM;
 }
+// Log-derivative launches (psdr_device.h li_path_logd): which k_camera instances they stand in for, and the gate word among the ray counters' padding
+// (zeroed with them at the start of every call; k_logd_check writes 1 = "every texel that carries a tangent has a non-zero albedo")
+constexpr int kLogdGateWord = kRayCounterStride - 1;
+template <class G, class R, int INTEG, int FL> constexpr bool logd_instance() {
+    return PSDR_LOGD && !is_ad<G>() && is_ad<R>() && INTEG == PSDR_INTEGRATOR_PATH && (FL & (kSceneRough | kSceneEnv | kScenePre)) == 0;
+}
 template <class G, class R, int INTEG, int FL, bool NOTREE = false>
 __global__ __launch_bounds__(kBlock, (camera_waves<G, R, INTEG, FL, NOTREE>())) void k_camera(LaunchCtx cx, TV<R, FL> tv, int spp, int s_begin, SlotDiv nsp, long long n, float inv_spp,
                                                    float *__restrict__ img, float *__restrict__ dimg, long long plane,
                                                    unsigned long long *counters, long long j0, ProbeView pv) {
     constexpr int K = ad_traits<R>::K;
     constexpr int NV = 3 * (1 + K);
+    // the dual-number PathTracer instances a log-derivative launch stands in for (k_camera_logd below): both are launched, the gate word says which one runs
+    if constexpr (logd_instance<G, R, INTEG, FL>()) { if (counters[kLogdGateWord] == 1ull) return; }
     TraversalStack st; setup_lds(cx, st, tv);
     uint32_t nrays = 0;
     const long long nceil = (n + kBlock - 1) / kBlock * kBlock;
@@ -180,6 +191,62 @@ __global__ __launch_bounds__(kBlock, (camera_waves<G, R, INTEG, FL, NOTREE>())) 
             for (int k = 0; k < K; ++k) {
                 v[3 + 3 * k] = tangent(r.x, k) * inv_spp; v[4 + 3 * k] = tangent(r.y, k) * inv_spp; v[5 + 3 * k] = tangent(r.z, k) * inv_spp;
             }
+        }
+        const bool head = wave_segmented_sum<NV>(pixel, v);
+        if (head && in) {
+            float *p = img + (size_t) pixel * 3;
+            if (v[0] != 0.f) atomicAdd(p, v[0]);
+            if (v[1] != 0.f) atomicAdd(p + 1, v[1]);
+            if (v[2] != 0.f) atomicAdd(p + 2, v[2]);
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                float *q = dimg + (size_t) k * plane + (size_t) pixel * 3;
+                if (v[3 + 3 * k] != 0.f) atomicAdd(q, v[3 + 3 * k]);
+                if (v[4 + 3 * k] != 0.f) atomicAdd(q + 1, v[4 + 3 * k]);
+                if (v[5 + 3 * k] != 0.f) atomicAdd(q + 2, v[5 + 3 * k]);
+            }
+        }
+    }
+    count_rays(counters, nrays);
+}
+
+// ---------------------------------------------------------------- log-derivative launches (round 5)
+// k_logd_check: the gate.  One thread per texel: a texel some tangent set moves must have an albedo the quotient d rho / rho can be formed with.
+template <int K>
+__global__ __launch_bounds__(kBlock) void k_logd_check(const float *__restrict__ texels, TangentView<K, 0> tv, int n, unsigned long long *counters, int *bad) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    bool b = false;
+    if (i < n) {
+        bool moved = false;
+#pragma unroll
+        for (int k = 0; k < K; ++k) moved = moved || tv.t[k].d_texels[i] != 0.f;
+        b = moved && !(fabsf(texels[i]) > 1e-20f);
+    }
+    if (__ballot(b) != 0ull && (threadIdx.x & 63) == 0) atomicOr(bad, 1);
+}
+__global__ void k_logd_gate(unsigned long long *counters, const int *bad) { if (threadIdx.x == 0 && blockIdx.x == 0) counters[kLogdGateWord] = *bad ? 0ull : 1ull; }
+// the camera kernel of a PathTracer whose tangents sit on diffuse albedo texels only: k_camera<float, Dual<K>, PATH, FL> with the estimator on plain floats
+template <int K, int FL, bool NOTREE>
+__global__ __launch_bounds__(kBlock, (camera_waves<float, Dual<K>, PSDR_INTEGRATOR_PATH, FL, NOTREE>())) void k_camera_logd(LaunchCtx cx, TV<Dual<K>, FL> tv, int spp, int s_begin, SlotDiv nsp,
+                                                   long long n, float inv_spp, float *__restrict__ img, float *__restrict__ dimg, long long plane, unsigned long long *counters) {
+    constexpr int NV = 3 * (1 + K);
+    if (counters[kLogdGateWord] != 1ull) return;
+    TraversalStack st; setup_lds(cx, st, tv);
+    uint32_t nrays = 0;
+    const long long nceil = (n + kBlock - 1) / kBlock * kBlock;
+    for (long long j = (long long) blockIdx.x * kBlock + threadIdx.x; j < nceil; j += (long long) gridDim.x * kBlock) {
+        const bool in = j < n;
+        int pixel = 0x7fffffff, s_in = 0;
+        if (in) slot_to_pixel(j, nsp, pixel, s_in);
+        float v[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = 0.f;
+        if (in) {
+            const uint64_t slot = (uint64_t) pixel * (uint64_t) spp + (uint64_t) (s_begin + s_in);
+            const Vec3<Dual<K>> r = camera_sample_logd<K>(cx.sc, tv, st, cx.lp, cx.jump, pixel, slot, nrays);
+            v[0] = r.x.v * inv_spp; v[1] = r.y.v * inv_spp; v[2] = r.z.v * inv_spp;
+#pragma unroll
+            for (int k = 0; k < K; ++k) { v[3 + 3 * k] = r.x.d[k] * inv_spp; v[4 + 3 * k] = r.y.d[k] * inv_spp; v[5 + 3 * k] = r.z.d[k] * inv_spp; }
         }
         const bool head = wave_segmented_sum<NV>(pixel, v);
         if (head && in) {
@@ -1723,6 +1790,28 @@ int run_camera(psdr_scene_s *h, const psdr_render_opts *o, const TV<R, FL> &tv, 
                 HIP_TRY(hipGetLastError());
             }
             return 0;
+        }
+    }
+    // PathTracer, material tangents on albedo texels only, a variant without rough conductors / environment map: the log-derivative kernel and, behind the
+    // same gate, the dual-number kernel (one of the two returns at once)
+    if constexpr (logd_instance<G, R, PSDR_INTEGRATOR_PATH, FL>()) {
+        constexpr int K = ad_traits<R>::K;
+        bool texels_only = o->integrator == PSDR_INTEGRATOR_PATH && h->opt.logd != 0 && h->desc.num_texels > 0 && h->desc.texels != nullptr;
+        for (int k = 0; k < K && texels_only; ++k) {
+            const psdr_tangents &t = tv.t[k];
+            texels_only = t.d_texels != nullptr && !t.d_tri_info && !t.d_emitter_rad && !t.d_cam_to_world && !t.d_sec_edge && !t.d_prim_edge && !t.d_env_f;
+        }
+        if (texels_only) {
+            if (int rc = scratch_reserve(&h->d_logd_bad, &h->logd_bad_bytes, sizeof(int), s, "log-derivative gate")) return rc;
+            int *bad = reinterpret_cast<int *>(h->d_logd_bad);
+            HIP_TRY(hipMemsetAsync(bad, 0, sizeof(int), s));
+            TangentView<K, 0> tvk;
+            for (int k = 0; k < K; ++k) tvk.t[k] = tv.t[k];
+            hipLaunchKernelGGL(k_logd_check<K>, dim3((unsigned) ((h->desc.num_texels + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, h->desc.texels, tvk, h->desc.num_texels, h->d_counters, bad);
+            hipLaunchKernelGGL(k_logd_gate, dim3(1), dim3(64), 0, s, h->d_counters, bad);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_camera_logd<K, FL, ((FL & kSceneTiny) != 0)>), dim3(launch_blocks(h, n, camera_blocks_per_cu(h, n))), dim3(kBlock), lds_bytes(cx, h), s, cx, tv,
+                               o->spp, o->spp_begin, SlotDiv(nsp), n, 1.f / (float) o->spp, img, dimg, WH * 3, h->d_counters);
+            HIP_TRY(hipGetLastError());
         }
     }
 #define PSDR_LAUNCH_CAMERA_T(INTEG, NOTREE)                                                                                        \

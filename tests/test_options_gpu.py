@@ -34,7 +34,7 @@ def test_every_option_the_header_names_is_accepted():
     import re
     hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "psdr_hip.h")).read()
     block = hdr[hdr.index("Developer options of a handle"):hdr.index("int psdr_scene_set_option")]
-    names = set(re.findall(r"\b([a-z][a-z0-9]*(?:_[a-z0-9]+)+|wide|probe)\b", block)) - {"psdr_scene_set_option", "psdr_bvh_build", "per_cu", "psdr_hip"}
+    names = set(re.findall(r"\b([a-z][a-z0-9]*(?:_[a-z0-9]+)+|wide|probe|logd)\b", block)) - {"psdr_scene_set_option", "psdr_bvh_build", "per_cu", "psdr_hip"}
     src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "psdr-cuda_amd", "csrc", "psdr_hip.hip")).read()
     known = set(re.findall(r'n == "([a-z0-9_]+)"', src[src.index("int psdr_scene_set_option"):src.index("int psdr_scene_destroy")]))
     assert known <= names | {"emitter_layout"}, sorted(known - names)           # every option the library accepts is documented
