@@ -1359,15 +1359,19 @@ PSDR_HD Vec3<Dual<K>> li_path_logd(const SceneView &sc, const TVT &tv, Traversal
     Vec3f beta(1.f);
     for (int depth = 0; depth < lp.max_depth; ++depth) {
         Its<float> nits; Vec3f nf; bool nvalid = false;
-        float g[K][3];
-        if (active) albedo_logd<K>(sc, tv, its, g);
+        if (active) {
+            // the vertex' own quotient joins the running sums BEFORE the estimator runs: nothing but the sums is alive across its two rays
+            float g[K][3];
+            albedo_logd<K>(sc, tv, its, g);
+#pragma unroll
+            for (int k = 0; k < K; ++k) { s[k][0] += g[k][0]; s[k][1] += g[k][1]; s[k][2] += g[k][2]; }
+        }
         const Vec3f c = direct_step<float, float>(sc, tv0, st, rng, its, active, 1, 1, nrays, &nits, &nf, &nvalid);
         if (active) {
             const Vec3f bc = beta * c;
             result = result + bc;
 #pragma unroll
             for (int k = 0; k < K; ++k) {
-                s[k][0] += g[k][0]; s[k][1] += g[k][1]; s[k][2] += g[k][2];
                 rd[k][0] = fmaf(bc.x, s[k][0], rd[k][0]); rd[k][1] = fmaf(bc.y, s[k][1], rd[k][1]); rd[k][2] = fmaf(bc.z, s[k][2], rd[k][2]);
             }
             active = nvalid;

@@ -139,6 +139,9 @@ PSDR_HD void slot_to_pixel(long long j, const SlotDiv &nsp, int &pixel, int &s) 
 #ifndef PSDR_LOGD
 #define PSDR_LOGD 1
 #endif
+#ifndef PSDR_LOGD_WAVES_K1
+#define PSDR_LOGD_WAVES_K1 0       // resident waves per SIMD of the K = 1 log-derivative kernel on a scene without a tree (0: those of the dual-number kernel it stands in for: 5);
+#endif                            // C2: 4 waves 1.05 ms, 5 (10 VGPRs spilled, 85 MB of counter traffic per launch) 0.953, 6 0.929 but 593 MB of scratch traffic: not adopted (profiles/r05_logd_waves.txt)
 template <class G, class R, int INTEG, int FL, bool NOTREE = false> constexpr int camera_waves() {
     constexpr bool lean = (FL & (kSceneEnv | kSceneRough)) == 0;          // plain diffuse / area light (with or without a two-level tree)
     if (!is_ad<R>()) return lean ? PSDR_WAVES_C + 1 : PSDR_WAVES_C;
@@ -227,7 +230,7 @@ __global__ __launch_bounds__(kBlock) void k_logd_check(const float *__restrict__
 __global__ void k_logd_gate(unsigned long long *counters, const int *bad) { if (threadIdx.x == 0 && blockIdx.x == 0) counters[kLogdGateWord] = *bad ? 0ull : 1ull; }
 // the camera kernel of a PathTracer whose tangents sit on diffuse albedo texels only: k_camera<float, Dual<K>, PATH, FL> with the estimator on plain floats
 template <int K, int FL, bool NOTREE>
-__global__ __launch_bounds__(kBlock, (camera_waves<float, Dual<K>, PSDR_INTEGRATOR_PATH, FL, NOTREE>())) void k_camera_logd(LaunchCtx cx, TV<Dual<K>, FL> tv, int spp, int s_begin, SlotDiv nsp,
+__global__ __launch_bounds__(kBlock, ((PSDR_LOGD_WAVES_K1 > 0 && K == 1 && NOTREE) ? PSDR_LOGD_WAVES_K1 : camera_waves<float, Dual<K>, PSDR_INTEGRATOR_PATH, FL, NOTREE>())) void k_camera_logd(LaunchCtx cx, TV<Dual<K>, FL> tv, int spp, int s_begin, SlotDiv nsp,
                                                    long long n, float inv_spp, float *__restrict__ img, float *__restrict__ dimg, long long plane, unsigned long long *counters) {
     constexpr int NV = 3 * (1 + K);
     if (counters[kLogdGateWord] != 1ull) return;
