@@ -317,7 +317,12 @@ def pmc_passes_c4(args, res, spp):
 #   c4_shard_path3_primal_then_rev   psdr_render_c(PSDR_FLAG_KEEP_RECORDS) + psdr_render_d_rev: one optimisation step's kernels (the reverse call reuses the records; its rays = 0)
 #   c4_shard_path3_fwd_geo, c5_path3_fwd_geo   PathTracer(3) renderD forward, K = 1 geometry tangents (a translation of one object): the traced wavefront with dual-number stages
 #   c5_path3_renderC            50 k-triangle interior with rough conductors, 512^2 spp 16, PathTracer(3) renderC
-#   c3_direct_fwd3              cbox_bunny 512^2 spp = sppe = sppse = 16, renderD forward (K = 1: a translation of the bunny), three terms
+#   c3_direct_fwd3              cbox_bunny 512^2 spp = sppe = sppse = 16, renderD forward (K = 1: a translation of the bunny), three terms -- 1/8 of configs[2]'s sample count, kept for continuity
+#   c3_bunny_rev3               BASELINE configs[2] AS WORDED: bunny_light 512^2, spp = sppe = sppse = 128, THROUGH THE SURFACE: configure + DirectIntegrator(1,1).renderD +
+#                               enoki.backward to ALL 2 503 x 3 vertex positions of the bunny (primal launch + three-term reverse launch + table-chain backward)
+#   c3_bunny_fwd3_translation   the same scene and counts, the harness' forward mode (run_test.py:126-129): P = FloatD(0), set_transform(translate(x) * P), configure, renderD, enoki.forward
+#   c5_rev_rough_vertices       BASELINE configs[4]'s gradient: the 50 k-triangle interior 512^2 spp 16, PathTracer(3) reverse w.r.t. the texel pool (every roughness / albedo texel)
+#                               and the triangle rows (vertices), psdr_render_d_rev
 class TreeScenes:
     def __init__(self):
         import psdr_cuda
@@ -326,6 +331,8 @@ class TreeScenes:
         self._abi = _abi
         self.integ = psdr_cuda.DirectIntegrator(1, 1)          # only its native plumbing is used: the options below name the integrator
         self.cases = []
+        self.size = {}                                         # row -> the workload's size in words (printed in the row)
+        self.counters_of = {}                                  # row -> the integrator object whose counters the row reads (default self.integ)
 
         def bunny(res, spp, sppe, sppse):
             sc = psdr_cuda.Scene()
@@ -374,6 +381,58 @@ class TreeScenes:
         tan3 = self._translation_tangents(sc3, tb3)
         tb3 = sc3.tables(0)                                     # the tables of the configure() that carries P (same values)
         self.cases.append(("c3_direct_fwd3", 3 * 512 * 512 * 16, lambda sc=sc3, tb=tb3, o=o3, t=tan3: self.integ._render_fwd(sc, tb, o, None, [t]), sc3))
+        self.size["c3_direct_fwd3"] = "cbox_bunny 512x512 spp = sppe = sppse = 16 (1/8 of BASELINE configs[2]'s sample count; another scene), forward K = 1, C-ABI launch"
+        self.size["c4_shard_path3_renderC"] = self.size["c4_shard_path3_rev"] = self.size["c4_shard_path3_primal_then_rev"] = self.size["c4_shard_path3_fwd_geo"] = \
+            "cbox_bunny 1024x1024, samples [0, 64) of the global 512 spp (one of eight GPUs), PathTracer(3), C-ABI launch"
+        self.size["c4_shard_direct_rev3"] = "cbox_bunny 1024x1024, samples [0, 64) of the global spp = sppe = sppse = 512, DirectIntegrator(1,1) three terms, C-ABI launch"
+        self.size["c5_path3_renderC"] = self.size["c5_path3_fwd_geo"] = "50 k-triangle interior (10 bunnies, rough conductors) 512x512 spp 16, PathTracer(3), C-ABI launch"
+        # ---- BASELINE configs[2] as worded, through the surface (examples/config.py:111-126 sizes; docs/inverse_diff_render.rst reverse mode)
+        import enoki as ek
+        from enoki.cuda_autodiff import Float32 as FloatD, Vector3f as Vector3fD, Matrix4f as Matrix4fD
+        sc3f = psdr_cuda.Scene()
+        sc3f.load_file(scene_path("bunny_light"), False)
+        sc3f.opts.width = sc3f.opts.height = 512
+        sc3f.opts.spp, sc3f.opts.sppe, sc3f.opts.sppse, sc3f.opts.log_level = 128, 128, 128, 0
+        m3 = sc3f.param_map["Mesh[0]"]
+        v3 = ek.detach(m3.vertex_positions)
+        sc3f.configure()
+        self.integ_c3 = psdr_cuda.DirectIntegrator(1, 1)
+        n3 = 512 * 512 * 128
+
+        def c3_rev():
+            v = Vector3fD(v3); ek.set_requires_gradient(v); m3.vertex_positions = v
+            sc3f.configure()
+            imgD = self.integ_c3.renderD(sc3f)
+            ek.backward(FloatD._wrap(imgD.t.sum().reshape(1)))
+            g = ek.gradient(v)
+            m3.vertex_positions = Vector3fD(v3)
+            return g
+        self.cases.append(("c3_bunny_rev3", 3 * n3, c3_rev, sc3f))
+        self.counters_of["c3_bunny_rev3"] = self.integ_c3
+        self.size["c3_bunny_rev3"] = ("bunny_light 512x512 spp = sppe = sppse = 128 (BASELINE configs[2]), through the surface: configure + DirectIntegrator(1,1).renderD + enoki.backward "
+                                      "to all %d x 3 vertex positions of Mesh[0] (primal launch, three-term psdr_render_d_rev, table-chain backward)" % int(v3.t.shape[0]))
+
+        def c3_fwd():
+            P = FloatD(0.); ek.set_requires_gradient(P)
+            m3.set_transform(Matrix4fD.translate(Vector3fD([1.0, 0.0, 0.0]) * P))
+            sc3f.configure()
+            imgD = self.integ_c3.renderD(sc3f)
+            ek.forward(P, free_graph=True)
+            g = ek.gradient(imgD)
+            m3.set_transform(np.eye(4, dtype=np.float32))          # the other row's configure() must not see P
+            return g
+        self.cases.append(("c3_bunny_fwd3_translation", 3 * n3, c3_fwd, sc3f))
+        self.counters_of["c3_bunny_fwd3_translation"] = self.integ_c3
+        self.size["c3_bunny_fwd3_translation"] = ("bunny_light 512x512 spp = sppe = sppse = 128, through the surface: the harness' forward mode (run_test.py:126-129) -- P = FloatD(0), "
+                                                  "Mesh[0].set_transform(translate(x) * P), configure, renderD, enoki.forward: ONE three-term forward-mode launch (K = 1)")
+        # ---- BASELINE configs[4]'s gradient: roughness + vertices, reverse mode
+        tb5g = dict(sc5.tables(0))
+        for k in ("tri_info", "texels"):
+            tb5g[k] = tb5g[k].detach().requires_grad_(True)
+        adj5 = torch.ones(512 * 512 * 3, device="cuda")
+        self.cases.append(("c5_rev_rough_vertices", 512 * 512 * 16, lambda sc=sc5, tb=tb5g, o=o5, a=adj5: self.integ._render_rev(sc, tb, o, None, a), sc5))
+        self.size["c5_rev_rough_vertices"] = ("50 k-triangle interior 512x512 spp 16, PathTracer(3) renderD reverse (psdr_render_d_rev) w.r.t. the texel pool (%d words: every roughness and "
+                                              "albedo) and all %d triangle rows (vertices)" % (int(tb5g["texels"].numel()), int(tb5g["num_tris"])))
 
     def _translation_tangents(self, sc, tb, mesh=None):
         """d table / d P for Mesh[1] (the bunny; or `mesh`) translated by P along x: JVP of the table chain through a second configure."""
@@ -395,7 +454,7 @@ class TreeScenes:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(); fn(); e1.record(); torch.cuda.synchronize()
             ms.append(e0.elapsed_time(e1))
-        rays = self.integ.last_counters
+        rays = self.counters_of.get(name, self.integ).last_counters
         if "primal_then_rev" in name:
             rays = self.path_integ.last_counters              # of the reverse call: 0 rays when it reused the primal render's records
         return sorted(ms)[1], int(rays[0])
@@ -417,7 +476,16 @@ def tree_scenes(args):
     out = {}
     for name, slots, fn, sc in ts.cases:
         ms, rays = ts.run(name, fn, sc)
-        out[name] = {"ms": round(ms, 3), "slots": slots, "rays": rays, "Grays_per_s": round(rays / ms / 1e6, 2), "Mslots_per_s": round(slots / ms / 1e3, 1)}
+        out[name] = {"size": ts.size.get(name), "ms": round(ms, 3), "slots": slots, "rays": rays, "Grays_per_s": round(rays / ms / 1e6, 2), "Mslots_per_s": round(slots / ms / 1e3, 1)}
+        try:
+            # floor of the call's arithmetic: every ray tests the scene's kernel-argument primitives once and pays its share of a path vertex; the tree walks are NOT
+            # in the floor (no closed form), so floor_time_frac is a LOWER bound of (time the arithmetic needs at the VALU peak) / (time taken)
+            st = ts._abi.scene_stats(sc._native)
+            n_prims, n_slab = int(st.get("n_tiny", 0)), int(st.get("n_slab", 0))
+            floor_lane = (n_slab * FLOOR_VALU_PER_SLAB_TEST + (n_prims - n_slab) * FLOOR_VALU_PER_PRIM_TEST + FLOOR_VALU_PER_RAY_REST) * float(rays)
+            out[name]["floor_time_frac_lower_bound"] = round(floor_lane / 64.0 / VALU_PEAK_WAVE_INSTS_PER_S / (ms * 1e-3), 4) if rays else None
+        except Exception:
+            out[name]["floor_time_frac_lower_bound"] = None
     exe = shutil.which("rocprofv3")
     if exe and not args.no_pmc:
         tmp = tempfile.mkdtemp(prefix="psdr_tree_", dir="/tmp")
@@ -472,7 +540,8 @@ def tree_scenes(args):
             out["pmc_error"] = repr(e)
         finally:
             shutil.rmtree(tmp, ignore_errors=True)
-    out["note"] = ("C-ABI launches on ONE GPU, median of 3 (HIP events); Grays_per_s = rays traced / time; dominant_kernel = the kernel with the largest summed duration of "
+    out["note"] = ("ONE GPU, median of 3 (HIP events); rows are C-ABI launches unless `size` says 'through the surface'; Grays_per_s = rays traced / time; floor_time_frac_lower_bound = "
+                   "(primitive tests + 150 VALU per ray, tree walks not counted) / 64 / VALU peak / time; dominant_kernel = the kernel with the largest summed duration of "
                    "the workload, its SQ_INSTS_VALU over its duration against 1228.8 G wave-instructions/s; hbm = (2 * FETCH_SIZE + WRITE_SIZE) KiB of all library kernels of the call over their "
                    "summed duration against 8 TB/s (rocprofv3 --pmc passes of this script, one per counter)")
     return out
@@ -596,22 +665,24 @@ def run_c4(args, world, rank, local_rank, dist, devices, rccl):
         }))
 
 
-def c4_strong(args, world, rank, dist, rccl, wait_all):
+def c4_strong(args, world, rank, dist, rccl, wait_all, one_integrator=False):
     """BASELINE configs[3] beside the headline at EVERY world size (north star: "Mpath-samples/s reported at 1/2/4/8 GPUs with achieved-HBM-fraction"):
     cbox_bunny 1024x1024, GLOBAL spp = sppe = sppse = 512 sharded over the ranks (strong scaling), step = PathTracer(3).renderC + configure +
-    DirectIntegrator(1,1).renderD (three terms) + enoki.backward w.r.t. the bunny's vertex positions and the albedo texels, through the surface; the
-    wavefront kernels' measured HBM traffic (rank 0's share under rocprofv3 --pmc) against 8 TB/s."""
+    renderD + enoki.backward w.r.t. the bunny's vertex positions and the albedo texels, through the surface; the wavefront kernels' measured HBM traffic
+    (rank 0's share under rocprofv3 --pmc) against 8 TB/s.  renderD's integrator: DirectIntegrator(1,1) with all three terms (the reference's own
+    configuration for geometry gradients), or -- one_integrator, configs[3] read literally: ONE integrator -- the same PathTracer(3)
+    (interior + primary-edge terms; the PathTracer has no secondary-edge term).  2 warm-up steps, 5 timed."""
     import enoki as ek
     import psdr_cuda
     from enoki.cuda_autodiff import Float32 as FloatD, Vector3f as Vector3fD
     from psdr_cuda.fixtures import scene_path
-    res, spp, steps = 1024, 512, 2
+    res, spp, steps, warm = 1024, 512, 5, 2
     sc = psdr_cuda.Scene()
     sc.load_file(scene_path("cbox_bunny"), False)
     sc.opts.width = sc.opts.height = res
     sc.opts.spp, sc.opts.sppe, sc.opts.sppse, sc.opts.log_level = spp, spp, spp, 0
     integ = psdr_cuda.PathTracer(max_depth=3)
-    integ_d = psdr_cuda.DirectIntegrator(1, 1)
+    integ_d = integ if one_integrator else psdr_cuda.DirectIntegrator(1, 1)
     refl = sc.param_map["BSDF[0]"].reflectance
     base = ek.detach(refl.data)
     mesh = sc.param_map["Mesh[1]"]
@@ -627,15 +698,19 @@ def c4_strong(args, world, rank, dist, rccl, wait_all):
         ek.backward(FloatD._wrap(imgD.t.sum().reshape(1)))
         return img, ek.gradient(v), ek.gradient(r)
 
-    step()
+    for _ in range(warm):
+        step()
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
+    per_step = []
     t0 = time.perf_counter()
     for _ in range(steps):
+        t1 = time.perf_counter()
         out = step()
-    torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        per_step.append((time.perf_counter() - t1) * 1e3)
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -649,15 +724,18 @@ def c4_strong(args, world, rank, dist, rccl, wait_all):
     grad_words = T * 24 + int(tb["texels"].numel())
     finite = bool(np.isfinite(out[1].numpy()).all())
     wf = None
-    if rank == 0 and not args.no_pmc:
+    if rank == 0 and not args.no_pmc and not one_integrator:
         wf = pmc_passes_c4(args, res, max(spp // world, 1))
     wait_all()
     if rank != 0:
         return None
-    return {"workload": "cbox_bunny %dx%d GLOBAL spp = sppe = sppse = %d sharded over %d rank(s) (%d per GPU): PathTracer(3).renderC + configure + DirectIntegrator(1,1).renderD "
-                        "(interior + primary-edge + secondary-edge terms) + enoki.backward w.r.t. the bunny's vertex positions and the albedo texels" % (res, res, spp, world, spp // world),
-            "scaling": "strong", "steps": steps, "warmup": 1, "ms_per_step": round(dt / steps * 1e3, 3), "value": round(2.0 * res * res * spp * steps / dt / 1e6, 2),
-            "unit": "Mpath-samples/s (2 W H spp camera slots per step; the step also evaluates W H (sppe + sppse) boundary slots)", "world_size": world, "global_spp": spp,
+    d_words = ("PathTracer(3).renderD (interior + primary-edge terms; it has no secondary-edge term)" if one_integrator else
+               "DirectIntegrator(1,1).renderD (interior + primary-edge + secondary-edge terms)")
+    return {"workload": "cbox_bunny %dx%d GLOBAL spp = sppe = sppse = %d sharded over %d rank(s) (%d per GPU): PathTracer(3).renderC + configure + %s "
+                        "+ enoki.backward w.r.t. the bunny's vertex positions and the albedo texels" % (res, res, spp, world, spp // world, d_words),
+            "scaling": "strong", "steps": steps, "warmup": warm, "ms_per_step": round(dt / steps * 1e3, 3),
+            "ms_per_step_min_max_this_rank": [round(min(per_step), 3), round(max(per_step), 3)], "value": round(2.0 * res * res * spp * steps / dt / 1e6, 2),
+            "unit": "Mpath-samples/s (2 W H spp camera slots per step; the step also evaluates the W H sppe (+ sppse) boundary slots)", "world_size": world, "global_spp": spp,
             "triangles": T, "allreduce_bytes_per_step": 0 if dist is None else int(2 * res * res * 3 * 4 + grad_words * 4),
             "allreduces_per_step": "[image] (renderC), [image] (renderD primal), [triangle-row || texel gradients]", "rccl_version": rccl, "grad_finite": finite,
             "wavefront_hbm": None if wf is None else {"workload": "PathTracer(3).renderC of rank 0's share (%d spp), two calls under rocprofv3 --pmc" % max(spp // world, 1), "kernels": wf,
@@ -706,6 +784,9 @@ def main():
             port = so.getsockname()[1]
         dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
 
+    if forced:
+        from psdr_cuda.integrator import force_collectives
+        force_collectives(True)
     args.local_rank = local_rank
     side = None
     if dist and world > 1:
@@ -831,6 +912,9 @@ def main():
         "unit": "G wave-instructions/s", "frac": None if achieved is None else round(achieved / VALU_PEAK_WAVE_INSTS_PER_S, 4),
         "peak_note": "1024 SIMD-32 units x 2.4 GHz / 2 cycles per wave64 VALU instruction (MI355X_MICROARCH.md)",
         "valu_wave_insts_per_launch": valu, "algorithmic_floor_frac": None if valu is None else round(floor_lane_insts / (valu * 64.0), 4),
+        "floor_time_frac": None if valu is None else round(floor_lane_insts / 64.0 / VALU_PEAK_WAVE_INSTS_PER_S / (dom_ms * 1e-3), 4),
+        "floor_time_note": "floor_time_frac = (time the algorithmic floor needs at the VALU peak) / kernel time = algorithmic_floor_frac x frac: the useful-work fraction; `frac` alone is an ISSUE rate "
+                           "(a kernel that issues fewer instructions for the same result lowers it)",
         "primitives_tested_per_ray": n_prims, "slab_form_primitives": n_slab,
         "wait_any_frac": None if not wave_cycles or "SQ_WAIT_ANY" not in dpm else round(dpm["SQ_WAIT_ANY"] / wave_cycles, 4),
         "wait_inst_any_frac": None if not wave_cycles or "SQ_WAIT_INST_ANY" not in dpm else round(dpm["SQ_WAIT_INST_ANY"] / wave_cycles, 4),
@@ -909,12 +993,17 @@ def main():
             trees = {"error": repr(e)}
     wait_all()
     # ---- BASELINE configs[3] as a strong-scaling block, every rank takes part
-    strong = None
+    strong, strong_one = None, None
     if not args.no_c4_strong:
         try:
             strong = c4_strong(args, world, rank, dist, rccl, wait_all)
         except Exception as e:
             strong = {"error": repr(e)}
+            wait_all()
+        try:
+            strong_one = c4_strong(args, world, rank, dist, rccl, wait_all, one_integrator=True)
+        except Exception as e:
+            strong_one = {"error": repr(e)}
             wait_all()
     if rank == 0:
         out = {
@@ -929,7 +1018,7 @@ def main():
                        "allreduce_bytes_per_step": 0 if world == 1 else int(args.res * args.res * 3 * 4 * 3),
                        "parallelism": "spp-shard x%d, one all-reduce per render call ([image] for renderC, [image || derivative image] for renderD)" % world},
             "surface": surface, "kernel_only": kernel_only,
-            "roofline": roofline, "cpu_baseline": cpu, "grad_rel_l2": grad, "tree_scenes": trees, "c4_strong": strong,
+            "roofline": roofline, "cpu_baseline": cpu, "grad_rel_l2": grad, "tree_scenes": trees, "c4_strong": strong, "c4_strong_one_integrator": strong_one,
         }
         print(json.dumps(out))
     if dist:

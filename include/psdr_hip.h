@@ -238,8 +238,8 @@ int psdr_scene_destroy(psdr_scene_t h);
    tiny_variants, sink_private, aa_prims (0 / 1); bvh_build (1 device, 0 host, -1 by size); wide (0: never the 4-wide tree in the render kernels);
    rev_split, sedge_split (1 / 0 force, -1 default rule); keep_records (0: PSDR_FLAG_KEEP_RECORDS is ignored); logd (0: PathTracer forward mode with tangents on
    diffuse albedo texels only runs the dual-number kernel, never the log-derivative one); rev_sorted (0: reverse PathTracer kernels
-   scatter row adjoints on the spot); wf_geo (0: PathTracer geometry tangents through the fused kernel); tangent_live (0: no liveness mask); rev_vertex (1: the adjoint sweep of a split PathTracer launch as one launch per path
-   vertex, 0 default: one adjoint kernel); vrev_blocks (workgroups per CU of those launches); probe (0: no probe / trace / final launches);
+   scatter row adjoints on the spot); wf_geo (0: PathTracer geometry tangents through the fused kernel); tangent_live (0: no liveness mask); occ_rows (0: the light rays of a scene without a tree test every kernel-argument primitive instead of
+   the ones that can lie between the path vertex and the emitter sample); probe (0: no probe / trace / final launches);
    trace_wg2 (dense trace kernel as two workgroups per CU: -1 by forest and launch size, 0 never, n > 0 always with stack columns of n entries);
    chunk_log2 (slots per chunk of the chunked launches, 0 = default); blocks_per_cu, camera_blocks, lds_budget, sink_rep, bvh_maxleaf (integers,
    0 = default where that makes sense); bvh_tcost (float).  Unknown names fail.  Options that change the tree take effect at the next psdr_bvh_build. */
@@ -254,8 +254,8 @@ int psdr_scene_set_tables(psdr_scene_t h, const psdr_scene_desc *desc);
    builds the BVH over tri_info (p0,e1,e2) of the current tables.  When the triangle count is
    unchanged since the last build (an optimisation loop moving vertices) the tree is refitted on
    the device instead of rebuilt (OptiX's build is a device build too); it is rebuilt when the
-   refitted boxes have grown by 30 % in area or after 64 refits.  PSDR_BVH_REFIT=0 in the
-   environment forces a rebuild every time. */
+   refitted boxes have grown by 30 % in area or after 64 refits.  psdr_scene_set_option(h, "bvh_refit", 0)
+   forces a rebuild every time (the library reads no environment variable). */
 int psdr_bvh_build(psdr_scene_t h, void *stream);
 /* out = { full builds, refits, inner nodes, tree depth } of this handle (diagnostics) */
 int psdr_bvh_stats(psdr_scene_t h, int32_t out[4]);

@@ -111,7 +111,7 @@ inline void pack_tiny_prims(const std::vector<float4> &tris, std::vector<float4>
 // > 0; divided by B = S01 + S11 that is rho u' + v' > 0 (B > 0) or its complement (B < 0: the two triangles swap their places in ids / codes
 // here, so the kernels test one form).  aa_cnt = the slots in use per axis (x | y << 8 | z << 16); with any in use the plane-form
 // primitives start at row kAaSlots, otherwise at row 0.  Returns the number of rows in use (SceneView::n_tiny).
-inline int tiny_plane_form(const std::vector<float4> &prims_in, float4 *rows, int32_t *meta, int32_t *aa_cnt_out = nullptr, bool allow_aa = true) {
+inline int tiny_plane_form(const std::vector<float4> &prims_in, float4 *rows, int32_t *meta, int32_t *aa_cnt_out = nullptr, bool allow_aa = true, std::vector<int> *row_of_prim = nullptr) {
     const int n = (int) prims_in.size() / 3;
     struct Aa { int axis; double c, cu, cv, hu, hv, S[4]; };
     auto bits = [](const float4 &r) { int32_t v; std::memcpy(&v, &r.w, 4); return v; };
@@ -179,8 +179,70 @@ inline int tiny_plane_form(const std::vector<float4> &prims_in, float4 *rows, in
         }
         meta[i * 4] = ids; meta[i * 4 + 1] = codeA; meta[i * 4 + 2] = codeB;
         std::memcpy(&meta[i * 4 + 3], &lim, 4);
+        if (row_of_prim) { row_of_prim->resize((size_t) n, -1); (*row_of_prim)[(size_t) src] = i; }
     }
     return next;
+}
+
+// Occluder rows of a scene without a tree (SceneView::occ, psdr_device.h closest_hit MASKED): for every triangle r and every EMITTER triangle e the rows of
+// the kernel-argument table a light ray from a point of r's primitive to a point of e's primitive has to test -- e's own primitive, plus every primitive P
+// whose supporting plane has corners of (r's primitive, e's primitive) strictly on BOTH sides: a segment whose end points lie in one closed half space of
+// P's plane does not cross it (a segment IN the plane gives n . d = 0: no hit in either test form).  Entries of a non-emitter e: all ones.  In a convex
+// room (the Cornell box of BASELINE configs 1 / 2) every entry is e's primitive alone.  Evaluated in double from the packed primitives (p0 | ids, e1, e2).
+// tol: a corner within tol of the plane counts as ON it (exact for the box: its corners are shared fp32 numbers).
+inline void tiny_occluder_rows(const std::vector<float4> &prims, const std::vector<int> &row_of_prim, int num_tris, const std::vector<char> &is_emitter_tri,
+                               std::vector<uint32_t> &occ) {
+    const int n = (int) prims.size() / 3;
+    occ.assign((size_t) num_tris * num_tris, 0xffffffffu);
+    struct P { double c[4][3]; int nc; double nrm[3], d; int tris[2]; int row; };
+    std::vector<P> ps((size_t) n);
+    double scale = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const float4 &a = prims[(size_t) i * 3], &b = prims[(size_t) i * 3 + 1], &c = prims[(size_t) i * 3 + 2];
+        int32_t ids; std::memcpy(&ids, &a.w, 4);
+        P &q = ps[(size_t) i];
+        const bool quad = ((uint32_t) ids >> 16) != 0xffffu;
+        q.tris[0] = ids & 0xffff; q.tris[1] = quad ? (int) ((uint32_t) ids >> 16) : -1;
+        const double p0[3] = {a.x, a.y, a.z}, e1[3] = {b.x, b.y, b.z}, e2[3] = {c.x, c.y, c.z};
+        q.nc = quad ? 4 : 3;
+        for (int k = 0; k < 3; ++k) { q.c[0][k] = p0[k]; q.c[1][k] = p0[k] + e1[k]; q.c[2][k] = p0[k] + e2[k]; q.c[3][k] = p0[k] + e1[k] + e2[k]; }
+        q.nrm[0] = e1[1] * e2[2] - e1[2] * e2[1]; q.nrm[1] = e1[2] * e2[0] - e1[0] * e2[2]; q.nrm[2] = e1[0] * e2[1] - e1[1] * e2[0];
+        const double len = std::sqrt(q.nrm[0] * q.nrm[0] + q.nrm[1] * q.nrm[1] + q.nrm[2] * q.nrm[2]);
+        for (int k = 0; k < 3; ++k) q.nrm[k] = len > 0.0 ? q.nrm[k] / len : 0.0;
+        q.d = q.nrm[0] * p0[0] + q.nrm[1] * p0[1] + q.nrm[2] * p0[2];
+        q.row = row_of_prim[(size_t) i];
+        for (int v = 0; v < q.nc; ++v) for (int k = 0; k < 3; ++k) scale = std::max(scale, std::fabs(q.c[v][k]));
+    }
+    const double tol = 1e-6 * std::max(scale, 1e-30);
+    for (int r = 0; r < n; ++r)
+        for (int e = 0; e < n; ++e) {
+            uint32_t m = 1u << ps[(size_t) e].row;
+            {   // r's primitive in e's plane (r == e, or a coplanar neighbour): such a ray runs IN the emitter's plane and never meets it (n . d = 0) -- the full
+                // search then reports whatever lies behind, and so must this one: every row
+                const P &q = ps[(size_t) e];
+                bool coplanar = true;
+                for (int v = 0; v < ps[(size_t) r].nc; ++v) {
+                    const double sd = q.nrm[0] * ps[(size_t) r].c[v][0] + q.nrm[1] * ps[(size_t) r].c[v][1] + q.nrm[2] * ps[(size_t) r].c[v][2] - q.d;
+                    coplanar = coplanar && std::fabs(sd) <= tol;
+                }
+                if (coplanar) m = 0xffffffffu;
+            }
+            for (int p = 0; p < n; ++p) {
+                if (p == e) continue;
+                const P &q = ps[(size_t) p];
+                double lo = 0.0, hi = 0.0;
+                bool finite = true;
+                auto side = [&](const P &x) { for (int v = 0; v < x.nc; ++v) { const double sd = q.nrm[0] * x.c[v][0] + q.nrm[1] * x.c[v][1] + q.nrm[2] * x.c[v][2] - q.d;
+                                                                          if (!std::isfinite(sd)) finite = false; lo = std::min(lo, sd); hi = std::max(hi, sd); } };
+                side(ps[(size_t) r]); side(ps[(size_t) e]);
+                if (!finite || (lo < -tol && hi > tol)) m |= 1u << q.row;             // corners on both sides (or nothing known): the plane may be crossed
+            }
+            for (int a = 0; a < 2; ++a)
+                for (int b = 0; b < 2; ++b) {
+                    const int tr = ps[(size_t) r].tris[a], te = ps[(size_t) e].tris[b];
+                    if (tr >= 0 && te >= 0 && tr < num_tris && te < num_tris && is_emitter_tri[(size_t) te]) occ[(size_t) tr * num_tris + te] = m;
+                }
+        }
 }
 
 // ---------------------------------------------------------------------------- BVH builder

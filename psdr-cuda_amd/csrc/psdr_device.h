@@ -80,6 +80,12 @@ struct SceneView {
     int32_t lt_trimesh, lt_meshbsdf, lt_meshemitter, lt_bsdf, lt_emf, lt_emi, lt_fcmf, lt_fpmf, lt_uv, lt_tex, lt_ecmf, lt_epmf;
     int32_t lt_nfaces, lt_end;                          // entries of face_cmf / face_pmf staged; end of the block (bytes)
     int32_t literal_forms;                              // PSDR_FLAG_LITERAL_FORMS: the reference's literal fp32 expressions (psdr_hip.h)
+    // Occluder rows of a scene without a tree (round 6; psdr_bvh_build.h tiny_occluder_rows): occ[r * num_tris + e] = the rows of `tiny` a light ray from a
+    // point of triangle r towards a point of EMITTER triangle e has to test -- e's own primitive plus every primitive whose plane separates a corner of
+    // r's primitive from a corner of e's (all ones where e is no emitter triangle).  In a convex room that is e's primitive alone: the light rays, 3 of a
+    // PathTracer(3) path's 7, test one primitive instead of six.  nullptr: every row.  lt_occ: its staged copy (kSceneTiny launches), < 0: none.
+    const uint32_t *occ;
+    int32_t lt_occ;
 };
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -497,8 +503,17 @@ PSDR_HD bool blas_box(const SceneView &sc, int k, const Vec3f &o, const Vec3f &i
 
 // FOREST: 2 = the instance serves scenes WITHOUT a tree only (kSceneTiny: the walk below is not even compiled), 1 = two-level scenes only,
 // 0 = never two-level (no box loop / per-tree walks in the code), -1 = decided at run time (k_trace, host tests).
-template <bool IGN = false, int FOREST = -1>
-PSDR_HD Hit closest_hit(const SceneView &sc, TraversalStack &st, const Vec3f &o, const Vec3f &d, float tmax, int ig0 = -1, int ig1 = -1, int pre_slot = 0) {
+// MASKED (kSceneTiny light rays, SceneView::occ): bit i of `rows` clear = row i of `tiny` cannot lie between this lane's origin and its target.  A row is
+// tested when ANY lane of the wave wants it (wave-uniform branch, scalar loads stay uniform); an extra test never changes a closest hit.
+PSDR_HD bool wave_any_hd(bool x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __ballot(x) != 0ull;
+#else
+    return x;
+#endif
+}
+template <bool IGN = false, int FOREST = -1, bool MASKED = false>
+PSDR_HD Hit closest_hit(const SceneView &sc, TraversalStack &st, const Vec3f &o, const Vec3f &d, float tmax, int ig0 = -1, int ig1 = -1, int pre_slot = 0, uint32_t rows = 0xffffffffu) {
     Hit best; best.tri = -1; best.u = best.v = -1.f;
     best.t = (tmax > 0.f && tmax < INFINITY) ? __int_as_float_hd(__float_as_int_hd(tmax) + 1) : tmax;   // accept t <= tmax
     const Vec3f inv{1.f / d.x, 1.f / d.y, 1.f / d.z};
@@ -513,9 +528,9 @@ PSDR_HD Hit closest_hit(const SceneView &sc, TraversalStack &st, const Vec3f &o,
         // 24 -> 54 ms when a second loop did that).
 #if defined(__HIP_DEVICE_COMPILE__)
         typedef __attribute__((address_space(4))) const float4 kernarg_float4;
-        const kernarg_float4 *rows = (kernarg_float4 *) ((__attribute__((address_space(4))) const char *) __builtin_amdgcn_kernarg_segment_ptr() + offsetof(SceneView, tiny));
+        const kernarg_float4 *prim_rows = (kernarg_float4 *) ((__attribute__((address_space(4))) const char *) __builtin_amdgcn_kernarg_segment_ptr() + offsetof(SceneView, tiny));
 #else
-        const float4 *rows = sc.tiny;
+        const float4 *prim_rows = sc.tiny;
 #endif
         // the axis-aligned rectangles: kAaPerAxis slots per axis at fixed rows, each tested by the instance compiled for its axis behind ONE
         // wave-uniform branch on the axis' count.  (The compiler sinks each row's two scalar loads into its slot's branch; holding all rows in
@@ -526,19 +541,19 @@ PSDR_HD Hit closest_hit(const SceneView &sc, TraversalStack &st, const Vec3f &o,
             float4 ra[kAaSlots]; float hb[kAaSlots]; int pk[kAaSlots], id2[kAaSlots];
 #pragma unroll
             for (int i = 0; i < kAaSlots; ++i) {
-                ra[i] = rows[i * 4];
-                if (IGN) { const float4 r = rows[i * 4 + 1]; hb[i] = r.x; pk[i] = __float_as_int_hd(r.y); id2[i] = __float_as_int_hd(r.w); }
+                ra[i] = prim_rows[i * 4];
+                if (IGN) { const float4 r = prim_rows[i * 4 + 1]; hb[i] = r.x; pk[i] = __float_as_int_hd(r.y); id2[i] = __float_as_int_hd(r.w); }
                 else {
 #if defined(__HIP_DEVICE_COMPILE__)
-                    const float2 r = *(__attribute__((address_space(4))) const float2 *) &rows[i * 4 + 1];
+                    const float2 r = *(__attribute__((address_space(4))) const float2 *) &prim_rows[i * 4 + 1];
 #else
-                    const float2 r{rows[i * 4 + 1].x, rows[i * 4 + 1].y};
+                    const float2 r{prim_rows[i * 4 + 1].x, prim_rows[i * 4 + 1].y};
 #endif
                     hb[i] = r.x; pk[i] = __float_as_int_hd(r.y); id2[i] = 0;
                 }
             }
             const int cx = aa_cnt & 255, cy = (aa_cnt >> 8) & 255, cz = aa_cnt >> 16;
-#define PSDR_AA(AX, S) aa_prim_test<AX, IGN>(ra[S], hb[S], pk[S], id2[S], o, d, inv, best, best_i, ig0, ig1)
+#define PSDR_AA(AX, S) do { if (!MASKED || wave_any_hd(((rows >> (S)) & 1u) != 0u)) aa_prim_test<AX, IGN>(ra[S], hb[S], pk[S], id2[S], o, d, inv, best, best_i, ig0, ig1); } while (0)
             if (cx > 0) { PSDR_AA(0, 0); if (cx > 1) { PSDR_AA(0, 1); if (cx > 2) PSDR_AA(0, 2); } }
             if (cy > 0) { PSDR_AA(1, 3); if (cy > 1) { PSDR_AA(1, 4); if (cy > 2) PSDR_AA(1, 5); } }
             if (cz > 0) { PSDR_AA(2, 6); if (cz > 1) { PSDR_AA(2, 7); if (cz > 2) PSDR_AA(2, 8); } }
@@ -546,7 +561,8 @@ PSDR_HD Hit closest_hit(const SceneView &sc, TraversalStack &st, const Vec3f &o,
         }
         // the other primitives in plane form (triangles, or parallelograms of two triangles: pack_tiny_prims)
 #pragma unroll PSDR_TINY_UNROLL
-        for (int i = aa_cnt != 0 ? kAaSlots : 0; i < sc.n_tiny; ++i) tiny_prim_test<IGN>(rows[i * 4], rows[i * 4 + 1], rows[i * 4 + 2], rows[i * 4 + 3], i, o, d, best, best_i, ig0, ig1);
+        for (int i = aa_cnt != 0 ? kAaSlots : 0; i < sc.n_tiny; ++i)
+            if (!MASKED || wave_any_hd(((rows >> i) & 1u) != 0u)) tiny_prim_test<IGN>(prim_rows[i * 4], prim_rows[i * 4 + 1], prim_rows[i * 4 + 2], prim_rows[i * 4 + 3], i, o, d, best, best_i, ig0, ig1);
         resolve_tiny_hit(sc, best, best_i);
         if (FOREST == 3) {
             // the trees were walked beforehand (same leaf test, tmax = infinity): the closest tree hit replaces the primitive hit exactly where the
@@ -693,18 +709,28 @@ template <class R, class TVT> PSDR_HD void fill_its_from_hit(Its<R> &its, const 
 //   kPathSpace : D types, barycentrics DETACHED (point rides on the moving triangle), J = A/detach(A)
 //   kSolidAngle: D types, differentiable Moeller-Trumbore on the chosen triangle, J = 1
 // ig0 / ig1 >= 0: triangles the ray must not hit (rays that start on a secondary edge, psdr_scene_desc::sec_edge_faces).
-template <class R, class TVT> PSDR_HD Its<R> intersect(const SceneView &sc, const TVT &tv, TraversalStack &st, const RayT<R> &ray,
-                                                       bool active, HitForm form, uint32_t &nrays, int ig0 = -1, int ig1 = -1, int pre_slot = 0) {
+template <class R, class TVT, bool MASKED = false> PSDR_HD Its<R> intersect(const SceneView &sc, const TVT &tv, TraversalStack &st, const RayT<R> &ray,
+                                                       bool active, HitForm form, uint32_t &nrays, int ig0 = -1, int ig1 = -1, int pre_slot = 0, uint32_t rows = 0xffffffffu) {
     Its<R> its;
     its.valid = false; its.tri = its.mesh = -1; its.J = R(1.f); its.t = R(INFINITY);
     if (!active) return its;
     nrays++;
     constexpr int F = tree_mode<TVT::flags>();
-    const Hit h = (ig0 >= 0 || ig1 >= 0) ? closest_hit<true, F>(sc, st, val(ray.o), val(ray.d), INFINITY, ig0, ig1, pre_slot)
-                                         : closest_hit<false, F>(sc, st, val(ray.o), val(ray.d), INFINITY, -1, -1, pre_slot);
+    Hit h;
+    if constexpr (MASKED) h = closest_hit<false, F, true>(sc, st, val(ray.o), val(ray.d), INFINITY, -1, -1, pre_slot, rows);
+    else h = (ig0 >= 0 || ig1 >= 0) ? closest_hit<true, F>(sc, st, val(ray.o), val(ray.d), INFINITY, ig0, ig1, pre_slot)
+                                    : closest_hit<false, F>(sc, st, val(ray.o), val(ray.d), INFINITY, -1, -1, pre_slot);
     if (h.tri < 0) return its;
     fill_its_from_hit<R>(its, sc, tv, h, ray, form);
     return its;
+}
+// the rows of SceneView::tiny a light ray from triangle tri_r to emitter triangle tri_e tests (SceneView::occ)
+PSDR_HD uint32_t occ_rows(const SceneView &sc, int tri_r, int tri_e) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (sc.lt_occ >= 0 && tri_e >= 0) ? PSDR_LDS_TABLE(uint32_t, sc.lt_occ)[tri_r * sc.d.num_tris + tri_e] : 0xffffffffu;
+#else
+    return (sc.occ != nullptr && tri_e >= 0) ? sc.occ[(size_t) tri_r * sc.d.num_tris + tri_e] : 0xffffffffu;
+#endif
 }
 // The hit record of a KNOWN hit (triangle + traversal barycentrics): everything intersect() derives behind its closest_hit.  The geometry-dual
 // stages of the traced wavefront rebuild a path vertex with it from its stream record -- the same arithmetic, hence the same vertex and tangents,
@@ -1000,7 +1026,7 @@ template <class G, class M> struct Bsdf {
 };
 
 // -------------------------------------------------------------------------- emitters
-template <class R> struct PosSample { Vec3<R> p, n; R J; float pdf; bool valid; };
+template <class R> struct PosSample { Vec3<R> p, n; R J; float pdf; bool valid; int tri; };          // tri: the emitter triangle the point lies on (-1: the environment map)
 
 // HyperCubeDistribution<2>::sample_reuse / pdf (src/core/cube_distrb.cpp:42-62) of the env-map cells;
 // cell (x, y) has index x * reso[1] + y (cube_distrb.cpp:19-26)
@@ -1052,6 +1078,7 @@ template <class R> PSDR_HD PosSample<R> env_sample_position(const SceneView &sc,
     ps.J = R(1.f);
     ps.pdf = pdf * Gv;
     ps.valid = true;
+    ps.tri = -1;
     return ps;
 }
 // EnvironmentMap::__sample_position_pdf (envmap.cpp:124-143), detached
@@ -1092,6 +1119,7 @@ PSDR_HD PosSample<R> sample_emitter_position(const SceneView &sc, const TVT &tv,
     ps.n = T.fn;
     ps.pdf = ef[4] * epdf;
     ps.valid = true;
+    ps.tri = ei[1] + f;
     return ps;
 }
 // Scene::emitter_position_pdf (scene.cpp:451-453) -> area.cpp:60-62 -> mesh.cpp:333-342, or envmap.cpp:124-143
@@ -1157,6 +1185,9 @@ PSDR_HD bool sample_direct(const SceneView &sc, const Vec3f &p, int &pixel, floa
 }
 
 // ------------------------------------------------------------------------ integrators
+#ifndef PSDR_OCC_ROWS
+#define PSDR_OCC_ROWS 1                 // kSceneTiny instances: light rays test the rows SceneView::occ names (0: every row -- A/B builds)
+#endif
 template <class R> PSDR_HD R mis_weight(const R &p1, const R &p2) { const R a = sqr(p1), b = sqr(p2); return a / (a + b); }  // direct.cpp:18-21
 
 struct LiParams {                 // uniform per launch
@@ -1235,7 +1266,12 @@ PSDR_HD Vec3<M> direct_step(const SceneView &sc, const TVT &tv, TraversalStack &
         const G d2 = dot(wo, wo), dist = safe_sqrt(d2);
         wo = wo / dist;
         const RayT<G> ray1{its.p, wo};
-        const Its<G> its1 = intersect<G>(sc, tv, st, ray1, ps.valid, form, nrays, -1, -1, kPreLightRay);
+        // a scene without a tree: only the rows that can lie between this vertex' primitive and the sampled emitter triangle (SceneView::occ)
+        auto trace_light = [&]() {
+            if constexpr (TVT::tiny && PSDR_OCC_ROWS) return intersect<G, TVT, true>(sc, tv, st, ray1, ps.valid, form, nrays, -1, -1, kPreLightRay, occ_rows(sc, its.tri, ps.tri));
+            else return intersect<G>(sc, tv, st, ray1, ps.valid, form, nrays, -1, -1, kPreLightRay);
+        };
+        const Its<G> its1 = trace_light();
         if (light_tri && i == 0) *light_tri = its1.valid ? its1.tri : -1;          // the value sweep of a split reverse launch records it (psdr_reverse.h RevDisk)
         if (!(its1.valid && val(its1.t) > val(dist) - kShadowEpsilon && emitter_of(sc, tv, its1) >= 0)) return;
         const G Gv = abs_(dot(its1.n, -wo)) / d2;

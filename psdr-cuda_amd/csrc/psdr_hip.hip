@@ -488,7 +488,7 @@ int plan_lds(const psdr_scene_s *h, LaunchCtx &cx, int reserved) {
     sc.off_lprim = off; off += h->n_tiny * kTinyHitWords * 4;          // hit rows of the kernel-argument primitives (resolve_tiny_hit)
     // the small tables of a scene without a tree (psdr_device.h Tab<FL>, staged by setup_lds): 16-byte aligned blocks
     sc.lt_trimesh = sc.lt_meshbsdf = sc.lt_meshemitter = sc.lt_bsdf = sc.lt_emf = sc.lt_emi = sc.lt_fcmf = sc.lt_fpmf = sc.lt_uv = sc.lt_tex = sc.lt_ecmf = sc.lt_epmf = -1;
-    sc.lt_nfaces = 0;
+    sc.lt_nfaces = 0; sc.lt_occ = -1; sc.occ = nullptr;
     const bool all_tables = tiny_tables_ok(h);
     if (all_tables || forest_tables(h)) {
         auto take = [&](int words) { const int o = off; off += (words * 4 + 15) / 16 * 16; return o; };
@@ -502,6 +502,7 @@ int plan_lds(const psdr_scene_s *h, LaunchCtx &cx, int reserved) {
         if (d.num_emitters > 1 && d.emitter_cmf && d.emitter_pmf) { sc.lt_ecmf = take(d.num_emitters); sc.lt_epmf = take(d.num_emitters); }
         if (all_tables && d.tri_uv) sc.lt_uv = take(d.num_tris * PSDR_TRIUV_STRIDE);
         if (d.num_texels > 0 && d.num_texels <= kLdsTexels) sc.lt_tex = take(d.num_texels * (1 + kLdsTexelTangents));      // value pool + up to 3 tangent pools (forward mode)
+        if (all_tables && h->have_occ && h->d_occ != nullptr) { sc.occ = h->d_occ; sc.lt_occ = take(d.num_tris * d.num_tris); }   // occluder rows of the light rays (<= 32 x 32 words)
     }
     sc.lt_end = off;
     cx.off_stack = off;
@@ -777,7 +778,7 @@ int lbvh_build(psdr_scene_s *h, hipStream_t s, bool &fallback) {
     HIP_TRY(hipStreamSynchronize(s));            // `tris` dies at return
     h->hot_rows = (int) tris.size(); h->hot_identity = false;
     h->root = 0; h->bvh_depth = info.depth; h->num_nodes = T - 1; h->num_btris = T;
-    h->n_tiny = 0; h->aa_cnt = 0; h->n_blas = 0; h->n_inline = 0;
+    h->n_tiny = 0; h->aa_cnt = 0; h->n_blas = 0; h->n_inline = 0; h->have_occ = false;
     if (use_wide_tree(h, false)) {
         // the 4-wide tree over the device-built BVH2: its topology is decided on the host (one read-back of the node array; the collapse is
         // O(T)): 263 k triangles +~15 ms on top of the 2 ms device build -- only where a launch would walk it
@@ -939,6 +940,7 @@ int psdr_scene_set_option(psdr_scene_t h, const char *name, double value) {
     const std::string n(name);
     const int iv = (int) value;
     if (n == "bvh_refit") h->refit_enabled = iv != 0;                   // 0: rebuild the tree on the host at every psdr_bvh_build
+    else if (n == "occ_rows") { h->opt.occ_rows = iv; h->have_bvh = false; }       // 0: the light rays of a scene without a tree test every row (A/B, tests)
     else if (n == "aa_prims") { h->aa_enabled = iv != 0; h->have_bvh = false; }   // 0: every kernel-argument primitive in plane form (no slab rows)
     else if (n == "tiny_scene") h->tiny_enabled = iv != 0;              // 0: walk a tree even for <= 16 triangles
     else if (n == "two_level") h->two_level_enabled = iv != 0;          // 0: one tree over all triangles
@@ -959,8 +961,6 @@ int psdr_scene_set_option(psdr_scene_t h, const char *name, double value) {
     else if (n == "logd") h->opt.logd = iv;                              // 0: PathTracer forward mode never runs the log-derivative kernel
     else if (n == "keep_records") h->opt.keep_records = iv;              // 0: psdr_render_c ignores PSDR_FLAG_KEEP_RECORDS
     else if (n == "rev_sorted") h->opt.rev_sorted = iv;                  // 0: the reverse camera kernels scatter every row adjoint on the spot (no deferred, sorted adds)
-    else if (n == "rev_vertex") h->opt.rev_vertex = iv;                  // 1: the adjoint sweep of a split PathTracer launch as a launch per path vertex (default 0: one adjoint kernel)
-    else if (n == "vrev_blocks") h->opt.vrev_blocks = iv;                // workgroups per CU of the per-vertex adjoint launches (0: default)
     else if (n == "sedge_split") h->opt.sedge_split = iv;
     else if (n == "probe") h->opt.probe = iv;
     else if (n == "trace_wg2") h->opt.trace_wg2 = iv;                    // dense trace kernel as two workgroups per CU: -1 by forest and launch size, 0 never, n > 0 always (stack columns of n entries)
@@ -985,6 +985,7 @@ int psdr_scene_destroy(psdr_scene_t h) {
     if (h->d_logd_bad) (void) hipFree(h->d_logd_bad);
     if (h->d_hot_map) (void) hipFree(h->d_hot_map);
     if (h->d_hot_tris) (void) hipFree(h->d_hot_tris);
+    if (h->d_occ) (void) hipFree(h->d_occ);
     if (h->d_top) (void) hipFree(h->d_top);
     if (h->d_inline_ids) (void) hipFree(h->d_inline_ids);
     if (h->d_lbvh) (void) hipFree(h->d_lbvh);
@@ -1195,7 +1196,7 @@ int psdr_bvh_build(psdr_scene_t h, void *stream) {
     h->bvh_depth = forest ? fb.max_depth : b.max_depth; h->num_nodes = (int) nodes.size(); h->num_btris = (int) btris.size() / 3;
     if (int rc = bvh4_build(h, nodes, forest ? fb.roots : std::vector<int32_t>{root}, forest, s)) return rc;
     h->have_bvh = true;
-    h->n_tiny = 0; h->aa_cnt = 0; h->n_blas = 0; h->n_inline = 0;
+    h->n_tiny = 0; h->aa_cnt = 0; h->n_blas = 0; h->n_inline = 0; h->have_occ = false;
     if (forest) {
         h->n_tiny = tiny_plane_form(top_prims, h->tiny, h->tiny_meta, &h->aa_cnt, h->aa_enabled);
         h->n_inline = (int) fb.inline_ids.size();
@@ -1211,8 +1212,28 @@ int psdr_bvh_build(psdr_scene_t h, void *stream) {
         if (h->n_inline) HIP_TRY(copy_on_stream(h->d_inline_ids, fb.inline_ids.data(), sizeof(int32_t) * (size_t) h->n_inline, hipMemcpyHostToDevice, s));
     } else if (tiny) {
         std::vector<float4> prims;
+        std::vector<int> row_of_prim;
         pack_tiny_prims(b.btris, prims);           // walls as parallelograms: half the tests
-        h->n_tiny = tiny_plane_form(prims, h->tiny, h->tiny_meta, &h->aa_cnt, h->aa_enabled);
+        h->n_tiny = tiny_plane_form(prims, h->tiny, h->tiny_meta, &h->aa_cnt, h->aa_enabled, &row_of_prim);
+        // occluder rows of the light rays (SceneView::occ): which primitives can lie between a triangle and an emitter triangle
+        h->have_occ = false;
+        if (T <= 32 && h->n_tiny <= 32) {
+            std::vector<char> is_em((size_t) T, 0);
+            for (int e = 0; e < h->desc.num_emitters; ++e) {
+                const int32_t *ei = h->emitter_i.data() + (size_t) e * PSDR_EMITTER_I_STRIDE;
+                for (int f = 0; f < ei[2]; ++f) if (ei[1] + f >= 0 && ei[1] + f < T) is_em[(size_t) (ei[1] + f)] = 1;
+            }
+            std::vector<uint32_t> occ;
+            if (h->opt.occ_rows != 0) tiny_occluder_rows(prims, row_of_prim, T, is_em, occ);
+            else occ.assign((size_t) T * T, 0xffffffffu);
+            if (occ.size() > h->occ_cap) {
+                if (h->d_occ) (void) hipFree(h->d_occ);
+                h->occ_cap = std::max<size_t>(occ.size(), 32 * 32);
+                HIP_TRY(hipMalloc(&h->d_occ, h->occ_cap * sizeof(uint32_t)));
+            }
+            HIP_TRY(copy_on_stream(h->d_occ, occ.data(), occ.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+            h->have_occ = true;
+        }
     }
     // what the refit path needs: the levels of the breadth-first node order, the padding, the reference area
     h->tree_tris = T; h->refits_since_build = 0; h->num_builds++; h->bvh_pad = forest ? fb.pad : b.pad;

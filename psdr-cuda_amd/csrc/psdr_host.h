@@ -79,6 +79,7 @@ __device__ __forceinline__ void setup_lds(const LaunchCtx &cx, TraversalStack &s
         stage(sc.lt_fpmf, sc.d.face_pmf, sc.lt_nfaces);
         stage(sc.lt_uv, sc.d.tri_uv, sc.d.num_tris * PSDR_TRIUV_STRIDE);
         stage(sc.lt_tex, sc.d.texels, sc.d.num_texels);
+        stage(sc.lt_occ, sc.occ, sc.d.num_tris * sc.d.num_tris);
     }
     st.base = reinterpret_cast<int32_t *>(psdr_dyn_lds + cx.off_stack) + threadIdx.x;
     __syncthreads();
@@ -159,12 +160,10 @@ struct psdr_scene_options {
     int rev_split = -1;                    // reverse mode as value kernel + adjoint kernel: 1 / 0 force, -1 by scene and launch size
     int tangent_live = 1;                  // forward mode with geometry tangents: one bit per triangle "some tangent set moves this row" (TangentView::live); 0: every row loads its tangents
     int wf_geo = 1;                        // PathTracer forward mode with geometry tangents on a two-level scene as the traced wavefront (k_wfg_*); 0: the fused kernel
+    int occ_rows = 1;                      // scenes without a tree: light rays test only the rows that can lie between the vertex and the emitter sample (0: every row; takes effect at the next psdr_bvh_build)
     int logd = 1;                          // PathTracer forward mode with tangents on diffuse albedo texels only: the log-derivative kernel (0: always dual numbers)
     int keep_records = 1;                  // psdr_render_c honours PSDR_FLAG_KEEP_RECORDS (0: ignored -- A/B, tests)
     int rev_sorted = 1;                    // reverse camera kernels with geometry gradients: complete row adjoints wait in LDS and leave sorted by row at the slot's end (0: scattered on the spot)
-    int rev_vertex = 0;                    // 1: adjoint sweep of a split PathTracer launch as one launch per path vertex (k_vertex_rev, round 5: built, measured SLOWER than the
-                                           // one adjoint kernel on C2 / C4 / C5 -- DESIGN.md round 5 -- and kept as an option); 0: one adjoint kernel
-    int vrev_blocks = 0;                   // workgroups per CU of those launches (0: 16)
     int sedge_split = -1;                  // secondary-edge term as filter + survivor kernel: 1 / 0 force, -1 from 2^18 slots
     int chunk_log2 = 0;                    // log2 of the slots per chunk of the chunked launches (0: 2^24 / 2^25, the traced wavefront 2^26)
     int probe = 1;                         // two-level scenes: fused kernels as probe pass + dense trace kernel + final pass where that is built (0: one kernel)
@@ -236,6 +235,7 @@ struct psdr_scene_s {
     // reverse-mode gradient sink: triangle rows cached in LDS (chosen at build time)
     std::vector<int32_t> emitter_i;        // host copy of desc.emitter_i (the emitter meshes' rows are hot)
     int32_t *d_hot_map = nullptr, *d_hot_tris = nullptr;
+    uint32_t *d_occ = nullptr; size_t occ_cap = 0; bool have_occ = false;      // occluder rows of a scene without a tree (SceneView::occ; psdr_bvh_build), [num_tris^2]
     int hot_rows = 0;
     bool hot_identity = false;             // every row cached, slot == triangle (scenes without a tree)
     size_t hot_cap = 0;

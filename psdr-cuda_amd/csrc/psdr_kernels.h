@@ -1181,12 +1181,7 @@ template <int FL> struct DeviceSink {
     typedef __attribute__((address_space(3))) float lds_float;
     lds_float *lds;       // THIS lane's copy of the cache (lane & (rep - 1))
     lds_float *lds0;      // copy 0
-#ifdef PSDR_EXP_CHEAP_SINK      // experiment: what the kernel costs when the LDS adds are free (one register add keeps the adjoint chain alive)
-    mutable float exp_acc = 0.f;
-    __device__ __forceinline__ void lds_add(lds_float *p, float v) const { exp_acc += v + __builtin_bit_cast(float, (int) (size_t) p); }
-#else
     __device__ __forceinline__ static void lds_add(lds_float *p, float v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-#endif
     float cam[16];
     // finite and not zero: ONE v_cmp_class_f32 (normal numbers of either sign; denormals are flushed in these kernels) instead of two compares and an s_and
     __device__ __forceinline__ static bool ok(float v) {
@@ -1272,9 +1267,6 @@ template <int FL> struct DeviceSink {
         __syncthreads();
     }
     __device__ __forceinline__ void end() {
-#ifdef PSDR_EXP_CHEAP_SINK
-        if (exp_acc == 123.456f) lds0[0] = exp_acc;
-#endif
         if (g.g_cam_to_world != nullptr) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
@@ -1571,26 +1563,6 @@ template <class S> __device__ __forceinline__ void sink_add_row_wave(S &sink, in
     }
 #endif
 }
-// The adjoint of one RGB texel per lane (key = its index in the texel pool; < 0: none).
-template <class S> __device__ __forceinline__ void sink_add_texel3_wave(S &sink, int key, const float (&tex)[3]) {
-    if (sink.g.g_texels == nullptr) return;
-    const bool valid = key >= 0;
-    if (__ballot(valid) == 0ull) return;
-    if (!sink.L.tex_n) {
-        if (valid) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) if (S::ok(tex[c])) atomicAdd(sink.g.g_texels + key + c, tex[c]);
-        }
-        return;
-    }
-    const WaveSort ws = wave_sort_keys(valid ? key : -1);
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const float t = ws.total(valid ? S::finite(tex[c]) : 0.f);
-        if (ws.tail && t != 0.f) S::lds_add(sink.lds + sink.L.tex_off + (ws.skey - 1) + c, t);
-    }
-}
-
 // The rows a lane deferred during its slot (DeviceSink::defer_row), added sorted by row at the kernel's convergent point: round r takes every lane's r-th row.
 template <class S> __device__ __forceinline__ void sink_flush_pending_wave(S &sink) {
     if (sink.L.pend_rows == 0) return;
@@ -1606,62 +1578,6 @@ template <class S> __device__ __forceinline__ void sink_flush_pending_wave(S &si
         sink_add_row_wave(sink, tri, u, v, row);
     }
     sink.n_pending = 0;
-}
-
-// The adjoint sweep of a split PathTracer launch, ONE PATH VERTEX PER LAUNCH (psdr_reverse.h vertex_reverse_first / _next): launch k
-// reads the value sweep's record and the state column the launch of vertex k - 1 left, hands its row / texel adjoints to the sorted adds above and
-// writes the state of vertex k + 1.  No path record in LDS, no traversal, no loop over the path: the live state is one vertex.
-//   KIND 0: primary vertex; 1: vertex k >= 1 (and the pending rows of the paths that ended at vertex k - 1); 2: the position adjoint vertex 1 sends back
-//   through the primary vertex' Moeller-Trumbore / camera chain (primary_position_reverse).
-#ifndef PSDR_WAVES_VREV
-#define PSDR_WAVES_VREV 3
-#endif
-#ifndef PSDR_WAVES_VREV_NEXT
-#define PSDR_WAVES_VREV_NEXT 3
-#endif
-#ifndef PSDR_VREV_REG_PRIV
-#define PSDR_VREV_REG_PRIV 1
-#endif
-template <int FL> constexpr bool vrev_reg_priv() { return PSDR_VREV_REG_PRIV && reg_priv_kernel<FL, true, PSDR_INTEGRATOR_PATH>(); }
-template <int FL, int KIND> constexpr int vrev_waves() { return KIND == 2 ? 4 : (KIND == 1 ? PSDR_WAVES_VREV_NEXT : PSDR_WAVES_VREV); }
-template <int FL, int KIND>
-__global__ __launch_bounds__(kBlock, (vrev_waves<FL, KIND>())) void k_vertex_rev(LaunchCtx cx, DeviceSink<FL> sink_arg, int spp, int s_begin, SlotDiv nsp, long long j0, long long n, float inv_spp,
-                                                                                const float *__restrict__ adj_img, float *__restrict__ disk, long long stride, float *__restrict__ state,
-                                                                                int k, int suffix) {
-    TraversalStack st; setup_lds(cx, st);
-    typename std::conditional<vrev_reg_priv<FL>() && KIND != 2, RegPrivSink<FL>, DeviceSink<FL> &>::type sink(sink_arg);
-    sink.begin(dyn_lds_floats(cx.off_sink));
-    const long long nceil = (n + kBlock - 1) / kBlock * kBlock;
-    for (long long jj = (long long) blockIdx.x * kBlock + threadIdx.x; jj < nceil; jj += (long long) gridDim.x * kBlock) {
-        const bool in = jj < n;
-        PrimaryGrad pg; pg.clear();
-        PendingScatter ps; ps.clear();
-        if (in) {
-            int pixel, s_in;
-            slot_to_pixel(j0 + jj, nsp, pixel, s_in);
-            const uint64_t slot = (uint64_t) pixel * (uint64_t) spp + (uint64_t) (s_begin + s_in);
-            const RevDisk dk{disk + jj, stride, 0}, sk{state + jj, stride, 0};
-            if constexpr (KIND == 2) primary_position_reverse(sink, pg, cx.sc, cx.jump, pixel, slot, dk, sk);
-            else {
-                const float *a = adj_img + (size_t) pixel * 3;
-                const Vec3f adj{a[0] * inv_spp, a[1] * inv_spp, a[2] * inv_spp};
-                if constexpr (KIND == 0) vertex_reverse_first(sink, pg, ps, cx.sc, st, cx.lp, cx.jump, pixel, slot, adj, dk, sk, suffix != 0);
-                else vertex_reverse_next(sink, ps, cx.sc, st, cx.jump, slot, adj, dk, sk, k);
-            }
-        }
-        // every lane of the wave is here: the primary-triangle row (lanes share their pixel: one add per run of lanes on the same triangle) ...
-        if (KIND != 1 && sink.g.g_tri_info != nullptr) {
-            const bool head = wave_run_sum<kPrimaryWords, (FL & kSceneRough) == 0 || PSDR_DPP_ALWAYS>(pg.tri, pg.w);
-            if (head && pg.tri >= 0) {
-#pragma unroll
-                for (int w = 0; w < kPrimaryWords; ++w) sink.add_tri(pg.tri, w, pg.w[w]);
-            }
-        }
-        // ... and the rows / the texel the launch completed, sorted by row
-        if constexpr (KIND == 1) { sink_add_row_wave(sink, ps.a_tri, ps.a_u, ps.a_v, ps.a); sink_add_row_wave(sink, ps.b_tri, ps.b_u, ps.b_v, ps.b); }
-        if constexpr (KIND != 2) sink_add_texel3_wave(sink, ps.tex_key, ps.tex);
-    }
-    sink.end();
 }
 
 // The primary-edge term only produces gradients of the edge table (the two Li values are detached): a sink
@@ -2187,8 +2103,8 @@ inline bool same_camera_samples(const psdr_render_opts &a, const psdr_render_opt
     return a.integrator == b.integrator && a.max_depth == b.max_depth && a.hide_emitters == b.hide_emitters && a.spp == b.spp && a.spp_begin == b.spp_begin &&
            a.spp_end == b.spp_end && a.rng_offset[0] == b.rng_offset[0] && ((a.flags ^ b.flags) & (PSDR_FLAG_FUSED | PSDR_FLAG_WAVEFRONT)) == 0;
 }
-inline int rev_record_words(const psdr_scene_s *h, int depth, bool wavefront_or_vertex) {
-    return kRevDiskHead + (wavefront_or_vertex ? kRevDiskPerVertexCf : kRevDiskPerVertex) * depth + (h->opt.rev_vertex != 0 ? kRevStateWords : 0);
+inline int rev_record_words(const psdr_scene_s *, int depth, bool wavefront) {
+    return kRevDiskHead + (wavefront ? kRevDiskPerVertexCf : kRevDiskPerVertex) * depth;
 }
 
 // value_only (psdr_render_c with PSDR_FLAG_KEEP_RECORDS where the traced wavefront does not apply -- a scene without a tree, a small launch): the PathTracer's
@@ -2199,7 +2115,7 @@ int render_rev_impl(psdr_scene_s *h, const psdr_render_opts *o, const float *adj
     const long long WH = (long long) h->desc.width * h->desc.height;
     if (value_only) {
         const long long nv = WH * (o->spp_end - o->spp_begin);
-        if (o->integrator != PSDR_INTEGRATOR_PATH || o->max_depth > kMaxRevDepth || o->max_depth < 1 || h->opt.rev_split == 0 || h->opt.rev_vertex != 0 || o->spp <= 0 || nv <= 0 ||
+        if (o->integrator != PSDR_INTEGRATOR_PATH || o->max_depth > kMaxRevDepth || o->max_depth < 1 || h->opt.rev_split == 0 || o->spp <= 0 || nv <= 0 ||
             nv > launch_chunk(h, 26)) return 1;
     }
     if (out_img) HIP_TRY(hipMemsetAsync(out_img, 0, sizeof(float) * WH * 3, s));
@@ -2234,11 +2150,9 @@ int render_rev_impl(psdr_scene_s *h, const psdr_render_opts *o, const float *adj
         // large tree (3.8 -> 3.3 ms; bunny scenes 2.0 -> 2.4); the 12-triangle box neither way
         const bool worth = o->integrator == PSDR_INTEGRATOR_PATH ? o->max_depth >= 2 : h->num_nodes >= 16384;
         // the records a recording psdr_render_c (value_only, above) left of exactly these samples on exactly these tables: this call is their adjoint kernel
-        const bool kept_fused = !value_only && geo && o->integrator == PSDR_INTEGRATOR_PATH && !deep_rec && h->opt.rev_vertex == 0 && split_env != 0 && h->kept.valid && h->kept.kind == 0 &&
+        const bool kept_fused = !value_only && geo && o->integrator == PSDR_INTEGRATOR_PATH && !deep_rec && split_env != 0 && h->kept.valid && h->kept.kind == 0 &&
                                 h->kept.gen == h->tables_gen && h->kept.n == n && out_img == nullptr && same_camera_samples(h->kept.o, *o) && n <= launch_chunk(h, 26);
         const bool split = value_only || kept_fused || (geo && replayable && split_env != 0 && (split_env == 1 || (has_tree && worth && n >= (1ll << 20))));
-        // adjoint sweep of a split PathTracer launch vertex by vertex (k_vertex_rev): psdr_scene_set_option("rev_vertex", 0) keeps the one adjoint kernel
-        const bool vrev = split && o->integrator == PSDR_INTEGRATOR_PATH && h->opt.rev_vertex != 0;
         // adjoint kernel of a split launch: nothing of the tree staged, no stacks -- only what plan_lds places without any room (the hit rows of
         // the kernel-argument primitives and the small tables of the two-level / tiny instances, Tab<FL>::lds_small), then record and cache
         // the PathTracer's geometry-adjoint kernels keep the lane-private emitter accumulators in registers (RegPrivSink): no LDS block, never switched off
@@ -2259,7 +2173,7 @@ int render_rev_impl(psdr_scene_s *h, const psdr_render_opts *o, const float *adj
         sink.L.pend_rows = 0; sink.L.pend_off = 0;
         // (rows: measured on the PathTracer only -- C2 all gradients 5.28 -> 4.99 ms, the C4 shard's adjoint kernel 19.5 -> 18.7; the DirectIntegrator's
         // single deferred row is level to 3 % slower: profiles/r05_rev_sorted_abk.txt)
-        if (geo && h->opt.rev_sorted != 0 && !vrev && grads->g_tri_info != nullptr && o->integrator == PSDR_INTEGRATOR_PATH) {
+        if (geo && h->opt.rev_sorted != 0 && grads->g_tri_info != nullptr && o->integrator == PSDR_INTEGRATOR_PATH) {
             LaunchCtx probe = cx;
             const int floor_bytes = (split ? base2 : plan_lds(h, probe, 1 << 30)) + rec_bytes;
             for (int rows = std::min(depth, 4); rows >= 1; --rows) {
@@ -2294,13 +2208,12 @@ int render_rev_impl(psdr_scene_s *h, const psdr_render_opts *o, const float *adj
         if constexpr ((FL & kSceneForest) != 0) wf_value = split && !value_only && !kept_fused && !no_tree && o->integrator == PSDR_INTEGRATOR_PATH && !deep_rec && traced_wavefront(h) && use_wavefront(h, o);
         // (rev_value_sweep_is_wavefront states the same rule for psdr_render_c's PSDR_FLAG_KEEP_RECORDS; `geo` and the option rev_split == 1 on a scene
         // without a tree are the caller's side of it)
-        const int disk_cf = wf_value ? 1 : (vrev ? 2 : 0);
+        const int disk_cf = wf_value ? 1 : 0;
         bool direct_probe = false;
         if constexpr ((FL & kSceneForest) != 0) direct_probe = !split && !no_tree && o->integrator == PSDR_INTEGRATOR_DIRECT && probe_direct(h, o, n);
         if (split) {
             // records of one chunk of slots live in a scratch buffer (2 + 5 depth words per slot; 2 + 8 depth from the wavefront); chunks bound its size
-            const int rec_words = kRevDiskHead + ((wf_value || vrev) ? kRevDiskPerVertexCf : kRevDiskPerVertex) * depth;
-            const int words = rec_words + ((vrev || h->opt.rev_vertex != 0) ? kRevStateWords : 0);       // + the state column the per-vertex adjoint launches hand on
+            const int words = kRevDiskHead + (wf_value ? kRevDiskPerVertexCf : kRevDiskPerVertex) * depth;
             // 2^26 slots per chunk (104 B of records per slot with the wavefront's cf format: 7 GB): the C4 shard's PathTracer(3) reverse as ONE chunk
             // 36.5 -> 35.7 ms of kernel time against four of 2^24 (its value sweep is the traced wavefront; profiles/r04_chunk_sweep.txt)
             const long long chunk = std::min<long long>(n, launch_chunk(h, 26));
@@ -2311,7 +2224,7 @@ int render_rev_impl(psdr_scene_s *h, const psdr_render_opts *o, const float *adj
             // the records psdr_render_c(PSDR_FLAG_KEEP_RECORDS) left of exactly these samples on exactly these tables: the value sweep is already there
             const bool reuse = (wf_value ? h->kept.kind == 1 : kept_fused) && h->kept.valid && h->kept.gen == h->tables_gen && h->kept.n == n && chunk >= n && out_img == nullptr &&
                                same_camera_samples(h->kept.o, *o) && need <= h->rev_bytes;
-            if (!reuse || vrev) h->kept.valid = false;          // this launch overwrites them (or its per-vertex launches turn (c, f) into suffix radiances in place)
+            if (!reuse) h->kept.valid = false;          // this launch overwrites them
             for (long long c0 = 0; c0 < n; c0 += chunk) {
                 const long long nc = std::min(chunk, n - c0);
                 if (o->integrator == PSDR_INTEGRATOR_PATH) {
@@ -2330,26 +2243,6 @@ int render_rev_impl(psdr_scene_s *h, const psdr_render_opts *o, const float *adj
                         h->kept.valid = true; h->kept.o = *o; h->kept.gen = h->tables_gen; h->kept.n = n; h->kept.kind = 0;
                         return 0;
                     }
-                    if (vrev) {
-                        // launch k = the adjoint of path vertex k (psdr_reverse.h vertex_reverse_first / _next): record + state column in, state column out
-                        LaunchCtx cxv = cx2;
-                        cxv.off_sink = no_tree ? cx.off_pathrec : base2;             // no path record in LDS: the gradient cache starts where it would
-                        const int dyn_v = cxv.off_sink + cache_bytes;
-                        float *state = disk + (size_t) rec_words * chunk;
-                        const int vblocks = launch_blocks(h, nc, h->opt.vrev_blocks > 0 ? h->opt.vrev_blocks : 16);
-#define PSDR_LAUNCH_VREV(KIND, KK)                                                                                                                           \
-                        do { if (dyn_v > 48 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_vertex_rev<FL, KIND>), hipFuncAttributeMaxDynamicSharedMemorySize, dyn_v)); \
-                        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_vertex_rev<FL, KIND>), dim3(vblocks), dim3(kBlock), dyn_v, s, cxv, sink, o->spp, o->spp_begin, SlotDiv(nsp), c0, nc,     \
-                                           1.f / (float) o->spp, adj_img, disk, chunk, state, (KK), wf_value ? 1 : 0); HIP_TRY(hipGetLastError()); } while (0)
-                        PSDR_LAUNCH_VREV(0, 0);
-                        // launches 1 .. depth: vertex k of the paths that have one; launch `depth` only flushes the rows still pending
-                        for (int kv = 1; kv <= depth; ++kv) {
-                            cxv.jump = make_rng_jump(o->rng_offset[0] + 2 + 5 * (uint64_t) kv);
-                            PSDR_LAUNCH_VREV(1, kv);
-                            if (kv == 1 && depth > 1) { cxv.jump = cx.jump; PSDR_LAUNCH_VREV(2, 0); }     // vertex 1's position adjoint through the primary vertex' chain
-                        }
-#undef PSDR_LAUNCH_VREV
-                    } else
                     PSDR_LAUNCH_REV_K(true, PSDR_INTEGRATOR_PATH, 2, cx2, dyn_bytes, c0, nc, (float *) nullptr, disk, chunk);
                 } else {
                     PSDR_LAUNCH_REV_K(true, PSDR_INTEGRATOR_DIRECT, 1, cx, dyn1, c0, nc, out_img, disk, chunk);

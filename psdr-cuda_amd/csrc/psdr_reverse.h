@@ -493,9 +493,9 @@ struct PathRec {
 // vertex the suffix radiance T_{k+1} and the two triangles its rays arrived at.  One column per path, word w at p[w * stride].
 // cf = 1 (the value sweep ran as the TRACED WAVEFRONT, psdr_kernels.h): per vertex (c_k, f_k, tri, tri) as the stage that evaluated the vertex
 // left them; the adjoint kernel forms the suffix radiances itself.
-// cf = 2 (value kernel of a split launch whose adjoint sweep runs vertex by vertex, vertex_reverse below): the wavefront's per-vertex layout with the
-// suffix radiance T_{k+1} already in place of c_k; words 8, 9 (barycentrics of the next vertex) are the adjoint launches' own.
-constexpr int kRevDiskHead = 2, kRevDiskPerVertex = 5, kRevDiskPerVertexCf = 10;
+// (Round 5 also built the adjoint sweep as one launch per path vertex on a 10-word layout with a 23-word state column: parity-green, 1.3-1.5x slower than the one
+// adjoint kernel on C2 / C4 / C5 -- profiles/r05_vertex_rev_*.txt, DESIGN.md round 5 -- and removed in round 6.)
+constexpr int kRevDiskHead = 2, kRevDiskPerVertex = 5, kRevDiskPerVertexCf = 8;
 struct RevDisk {
     float *p; long long stride; int cf = 0;
     PSDR_HD void put(int w, float v) const { p[(long long) w * stride] = v; }
@@ -973,9 +973,6 @@ PSDR_HD Vec3f camera_sample_reverse(RealSink &real_sink, PrimaryGrad &pg, PathRe
             if (!(beta.x != 0.f || beta.y != 0.f || beta.z != 0.f)) break;
         }
     }
-#ifdef PSDR_EXP_VALUE_ONLY
-    return result;
-#endif
     // masked(value, ~isfinite(value)) = 0 (integrator.cpp:87): a zeroed sample has no gradient either
     if constexpr (STAGE != 2) {
         if (!(isfinite(result.x) && isfinite(result.y) && isfinite(result.z))) { if constexpr (STAGE == 1) disk.puti(0, -1); return zero_nonfinite(result); }
@@ -992,14 +989,6 @@ PSDR_HD Vec3f camera_sample_reverse(RealSink &real_sink, PrimaryGrad &pg, PathRe
     }
     if constexpr (STAGE == 1) {
         disk.puti(0, h0.tri); disk.puti(1, nv);
-        if (disk.cf == 2) {
-            for (int k = 0; k < nv; ++k) {
-                const int w = kRevDiskHead + k * kRevDiskPerVertexCf;
-                disk.put(w, rec.get(k, 0)); disk.put(w + 1, rec.get(k, 1)); disk.put(w + 2, rec.get(k, 2));
-                disk.puti(w + 6, rec.tri(k, 0)); disk.puti(w + 7, rec.tri(k, 1));
-            }
-            return result;
-        }
         for (int k = 0; k < nv; ++k) {
             const int w = kRevDiskHead + k * kRevDiskPerVertex;
             disk.put(w, rec.get(k, 0)); disk.put(w + 1, rec.get(k, 1)); disk.put(w + 2, rec.get(k, 2));
@@ -1091,254 +1080,6 @@ PSDR_HD Vec3f camera_sample_reverse(RealSink &real_sink, PrimaryGrad &pg, PathRe
     }
     PSDR_CLK_MARK_ST(st, 5);                    // the primary vertex' chain
     return result;
-}
-
-// ------------------------------------------------------------------ the adjoint sweep, ONE PATH VERTEX PER LAUNCH (round 5)
-// camera_sample_reverse<.., STAGE 2> holds a whole path's adjoint state in one kernel: 230-240 VGPRs, two waves per SIMD, 0.22-0.27 of the VALU issue
-// peak with 0.5-0.6 of the wave cycles waiting, half of its time with the LDS pipe busy on float atomics at ~3 cycles per active lane
-// (profiles/r04_s8_summary.txt).  Here the adjoint of vertex k is its own launch (psdr_kernels.h k_vertex_rev): the value sweep's record in, that
-// vertex' table adjoints out, and what the NEXT vertex' launch needs carried in a per-path state column -- what Enoki's backward does for the
-// gathers at scene.cpp:300 / integrator.cpp:32-60, cut at the path vertices.  All lanes of a wave reach the end of a launch's loop body together,
-// so the triangle-row and texel adds of a vertex are handed back to the kernel (PendingScatter) and leave SORTED BY ROW: one LDS add per run of
-// equal rows instead of one per lane (DeviceSink::add_row_wave).
-//   record (RevDisk, cf layouts): head = (primary triangle | -1, vertex count nv); vertex j = (T_{j+1} | c_j, f_j, triangle of vertex j + 1 | -1, triangle the
-//           light ray arrived at, barycentrics of vertex j + 1: written by the launch of vertex j from its replayed hit).  The launch of vertex 0 turns
-//           (c_j, f_j) into suffix radiances first when the value sweep left them raw (`suffix`: the traced wavefront's recording stages).
-//   state:  beta_k (3) | row adjoint of vertex k from the BSDF sample of vertex k - 1: position, face normal, area (7) | pending row adjoint of vertex
-//           k - 1: position (3), face normal + area (4) | position of vertex k - 1 (3) | the position adjoint vertex 1 sends to the primary vertex (3).
-//           A vertex' row is touched ONCE, by the launch behind it.
-//   launch 0: the primary vertex (camera ray, solid-angle form) and its own chain;  launch k = 1 .. depth: vertex k of the paths that have one, the
-//   pending rows of the paths that ended at vertex k - 1;  primary_position_reverse (after launch 1): the position adjoint vertex 1 sends back to
-//   the primary vertex through Moeller-Trumbore and the camera ray -- the chains are linear, so that addend runs through them alone.
-constexpr int kRevStateWords = 23;
-struct ReplayTris {
-    int t0, t1;
-    PSDR_HD int tri(int, int which) const { return which ? t1 : t0; }
-    PSDR_HD void put_tri(int, int, int) {}
-};
-// What a launch leaves for the kernel's convergent point: complete row adjoints (position at (u, v), face normal, area) and the adjoint of one RGB texel.
-struct PendingScatter {
-    int a_tri, b_tri, tex_key; float a_u, a_v, b_u, b_v;
-    RowAdj a, b; float tex[3];
-    PSDR_HD void clear() { a_tri = b_tri = tex_key = -1; a_u = a_v = b_u = b_v = 0.f; a.clear(); b.clear(); tex[0] = tex[1] = tex[2] = 0.f; }
-};
-// Routes the first RGB texel a vertex' BSDF adjoints touch (both estimators of a vertex evaluate the same BSDF: a 1 x 1 albedo is all of it) into
-// PendingScatter; every other add goes straight to the real sink.
-template <class Sink> struct DeferTexelSink {
-    static constexpr int flags = Sink::flags;
-    static constexpr bool has_env = Sink::has_env;
-    Sink &real; PendingScatter &ps;
-    PSDR_HD DeferTexelSink(Sink &r, PendingScatter &p) : real(r), ps(p) {}
-    PSDR_HD void add_texel(int i, float v) {
-        if (!(v != 0.f && isfinite(v))) return;
-        if (ps.tex_key < 0) ps.tex_key = i;
-        const int d = i - ps.tex_key;
-        if (d >= 0 && d < 3) { ps.tex[0] += d == 0 ? v : 0.f; ps.tex[1] += d == 1 ? v : 0.f; ps.tex[2] += d == 2 ? v : 0.f; }
-        else real.add_texel(i, v);
-    }
-    PSDR_HD void add_tri(int t, int w, float v) { real.add_tri(t, w, v); }
-    PSDR_HD bool add_row(int t, float u, float v, const Vec3f &ap, const Vec3f &afn, float aa) { return real.add_row(t, u, v, ap, afn, aa); }
-    PSDR_HD void add_rad(int e, int c, float v) { real.add_rad(e, c, v); }
-    PSDR_HD void add_cam(int w, float v) { real.add_cam(w, v); }
-    PSDR_HD void add_env(int w, float v) { real.add_env(w, v); }
-    PSDR_HD void add_sedge(int e, int w, float v) { real.add_sedge(e, w, v); }
-    PSDR_HD void add_pedge(int e, int w, float v) { real.add_pedge(e, w, v); }
-};
-
-// Launch 0: the primary vertex.
-template <class RealSink>
-PSDR_HD void vertex_reverse_first(RealSink &real_sink, PrimaryGrad &pg, PendingScatter &ps, const SceneView &sc, TraversalStack &st, const LiParams &lp, const RngJump &jump,
-                                  int pixel, uint64_t slot, const Vec3f &adj, const RevDisk &disk, const RevDisk &state, bool suffix) {
-    pg.clear();
-    const int tri0 = disk.geti(0);
-    if (tri0 < 0) return;
-    const int nv = disk.geti(1);
-    constexpr int FL = RealSink::flags;
-    using Sink = PrimarySink<RealSink>;
-    Sink sink(real_sink, pg);
-    DeferTexelSink<RealSink> sweep(real_sink, ps);
-    const TangentView<0, FL> tv0{};
-    const int wk = kRevDiskHead;
-    uint32_t nrays = 0;
-    Vec3f Tn(0.f);                                       // T_1
-    if (1 < nv) {
-        if (suffix) {
-            Vec3f T(0.f);
-            for (int j = nv - 1; j >= 1; --j) {
-                const int w = kRevDiskHead + j * kRevDiskPerVertexCf;
-                const Vec3f cj{disk.get(w), disk.get(w + 1), disk.get(w + 2)}, fj{disk.get(w + 3), disk.get(w + 4), disk.get(w + 5)};
-                disk.put(w, T.x); disk.put(w + 1, T.y); disk.put(w + 2, T.z);
-                T = cj + fj * T;
-            }
-            Tn = T;
-        } else Tn = Vec3f{disk.get(wk), disk.get(wk + 1), disk.get(wk + 2)};
-    }
-    ReplayTris rt{disk.geti(wk + 6), disk.geti(wk + 7)};
-    Rng rng; rng.init(slot, jump);
-    const float j0 = rng.next(), j1 = rng.next();
-    const int W = sc.d.width;
-    const float sx = ((float) (pixel % W) + j0) / (float) W, sy = ((float) (pixel / W) + j1) / (float) sc.d.height;
-    pg.tri = tri0;
-    Its<float> cur;
-    Vec3f a_d_le0(0.f);
-    {
-        const RayT<float> ray = primary_ray<float>(sc, tv0, sx, sy);
-        const int tm0 = Tab<FL>::tri_mesh(sc, tri0);
-        const bool face0 = (tm0 & PSDR_TRI_FACE_NORMALS) != 0;
-        const TriRow<float> T0 = load_tri<float>(sc, tv0, tri0);
-        const Hit h0 = hit_on_triangle(tri0, T0.p0, T0.e1, T0.e2, ray.o, ray.d);       // the leaf test's arithmetic: the traversal's (u, v)
-        float bu, bv, t0;
-        moeller_trumbore(T0.p0, T0.e1, T0.e2, ray, bu, bv, t0);                        // solid-angle form (scene.cpp:355-376)
-        cur.p = bary_point(T0.p0, T0.e1, T0.e2, bu, bv);
-        cur.valid = true; cur.tri = tri0; cur.mesh = tm0 & ~PSDR_TRI_FACE_NORMALS; cur.hu = h0.u; cur.hv = h0.v;
-        cur.n = T0.fn; cur.J = 1.f; cur.t = t0;
-        const ShNormal sn0 = shading_normal(T0, face0, bu, bv);
-        cur.sh = Frame<float>(sn0.n);
-        cur.wi = cur.sh.to_local(-ray.d);
-        const float *q = sc.d.tri_uv ? Tab<FL>::tri_uv(sc, tri0) : nullptr;
-        cur.uvx = q ? (q[2] - q[0]) * bu + ((q[4] - q[0]) * bv + q[0]) : 0.f;
-        cur.uvy = q ? (q[3] - q[1]) * bu + ((q[5] - q[1]) * bv + q[1]) : 0.f;
-        // the emitter seen directly (camera_sample_reverse)
-        const int e0 = Tab<FL>::mesh_emitter(sc, cur.mesh);
-        const bool env0 = Sink::has_env && !lp.hide_emitters && e0 >= 0 && e0 == sc.d.env_emitter;
-        const bool le0 = !lp.hide_emitters && e0 >= 0 && !env0 && cur.wi.z > 0.f;
-        if (le0) { sweep.add_rad(e0, 0, adj.x); sweep.add_rad(e0, 1, adj.y); sweep.add_rad(e0, 2, adj.z); }
-        if (env0) { if constexpr (Sink::has_env) a_d_le0 = env_eval_vjp(sweep, sc, ray.d, adj); }
-    }
-    const Vec3f a_c = adj;
-    const Vec3f a_f = (1 < nv) ? a_c * Tn : Vec3f(0.f);
-    VertexAdj va; va.clear();
-    RowAdj row_next; row_next.clear();
-    const VertexOut vo = vertex_eval<true, true, DeferTexelSink<RealSink>, ReplayTris>(sweep, sc, st, rng, cur, 1, 1, a_c, a_f, va, nrays, rt, 0, &row_next);
-    // what launch 1 needs: the throughput, the row adjoint of vertex 1 so far, where vertex 0 is, vertex 1's barycentrics (the replayed hit's)
-    if (vo.next_valid) {
-        const Vec3f beta = vo.f;
-        state.put(0, beta.x); state.put(1, beta.y); state.put(2, beta.z);
-        state.put(3, row_next.p.x); state.put(4, row_next.p.y); state.put(5, row_next.p.z);
-        state.put(6, row_next.fn.x); state.put(7, row_next.fn.y); state.put(8, row_next.fn.z); state.put(9, row_next.area);
-        state.put(17, cur.p.x); state.put(18, cur.p.y); state.put(19, cur.p.z);
-        disk.put(wk + 8, vo.next.hu); disk.put(wk + 9, vo.next.hv);
-    }
-    {
-        // the primary vertex' own chain (wi = to_local(-d), frame(sh_n(bu, bv)), uv(bu, bv), p, (bu, bv, t) = MT(tri0, ray)), REBUILT behind the vertex'
-        // estimators as in camera_sample_reverse: not live across them
-        int tri_b = tri0;
-#if defined(__HIP_DEVICE_COMPILE__)
-        asm volatile("" : "+v"(tri_b));
-#endif
-        const Vec3f dcam_b = camera_space_dir(sc, sx, sy);
-        const RayT<float> ray_b = primary_ray<float>(sc, tv0, sx, sy);
-        const TriRow<float> Tb = load_tri<float>(sc, tv0, tri_b);
-        const bool face0 = (Tab<FL>::tri_mesh(sc, tri_b) & PSDR_TRI_FACE_NORMALS) != 0;
-        float bu_b, bv_b, t_b;
-        moeller_trumbore(Tb.p0, Tb.e1, Tb.e2, ray_b, bu_b, bv_b, t_b);
-        const ShNormal sn_b = shading_normal(Tb, face0, bu_b, bv_b);
-        const Frame<float> sh_b(sn_b.n);
-        const float *qb = sc.d.tri_uv ? Tab<FL>::tri_uv(sc, tri_b) : nullptr;
-        const Vec3f a_d = a_d_le0 - (sh_b.s * va.wi.x + sh_b.t * va.wi.y + sh_b.n * va.wi.z);
-        acc(va.s, ray_b.d * (-va.wi.x)); acc(va.t, ray_b.d * (-va.wi.y)); acc(va.n, ray_b.d * (-va.wi.z));
-        const Vec3f a_shn = va.n + frame_vjp(sn_b.n, va.s, va.t);
-        float abu = dot(va.p, Tb.e1), abv = dot(va.p, Tb.e2);
-        shading_normal_vjp(sink, tri_b, Tb, sn_b, bu_b, bv_b, a_shn, abu, abv);
-        if (qb) { abu += va.u * (qb[2] - qb[0]) + va.v * (qb[3] - qb[1]); abv += va.u * (qb[4] - qb[0]) + va.v * (qb[5] - qb[1]); }
-        const MtAdj ma = mt_vjp(Tb.p0, Tb.e1, Tb.e2, ray_b, abu, abv, 0.f);
-        scatter_vec(sink, tri_b, 0, ma.p0 + va.p); scatter_vec(sink, tri_b, 3, ma.e1 + va.p * bu_b); scatter_vec(sink, tri_b, 6, ma.e2 + va.p * bv_b);
-        camera_ray_vjp(sink, sc, dcam_b, ma.o, a_d + ma.d);
-    }
-}
-
-// Launch k = 1 .. depth.  k < nv: vertex k.  k == nv: the path ended at vertex k - 1 -- its pending row and the row adjoint its BSDF sample left on the
-// vertex it found go out.  `jump` = the sample stream at vertex k (offset + 2 + 5 k draws).
-template <class RealSink>
-PSDR_HD void vertex_reverse_next(RealSink &real_sink, PendingScatter &ps, const SceneView &sc, TraversalStack &st, const RngJump &jump,
-                                 uint64_t slot, const Vec3f &adj, const RevDisk &disk, const RevDisk &state, int k) {
-    const int tri0 = disk.geti(0);
-    if (tri0 < 0) return;
-    const int nv = disk.geti(1);
-    if (k > nv) return;
-    constexpr int FL = RealSink::flags;
-    const TangentView<0, FL> tv0{};
-    const int wp = kRevDiskHead + (k - 1) * kRevDiskPerVertexCf;            // record of vertex k - 1: holds vertex k's triangle and barycentrics
-    const int tri_k = disk.geti(wp + 6);
-    if (tri_k < 0) return;                                                   // the BSDF sample of vertex k - 1 found nothing: no vertex k, nothing pending on it
-    const float hu = disk.get(wp + 8), hv = disk.get(wp + 9);
-    RowAdj row_cur;
-    row_cur.p = Vec3f{state.get(3), state.get(4), state.get(5)}; row_cur.fn = Vec3f{state.get(6), state.get(7), state.get(8)}; row_cur.area = state.get(9);
-    // the vertex behind (k - 1 >= 1): its triangle, barycentrics and pending row
-    int prev_tri = -1; float prev_u = 0.f, prev_v = 0.f;
-    RowAdj prev; prev.clear();
-    if (k >= 2) {
-        const int wq = kRevDiskHead + (k - 2) * kRevDiskPerVertexCf;
-        prev_tri = disk.geti(wq + 6); prev_u = disk.get(wq + 8); prev_v = disk.get(wq + 9);
-        prev.p = Vec3f{state.get(10), state.get(11), state.get(12)}; prev.fn = Vec3f{state.get(13), state.get(14), state.get(15)}; prev.area = state.get(16);
-    }
-    if (k == nv) {
-        // the path ended at vertex k - 1: the row adjoints still pending go out as they are
-        ps.a_tri = prev_tri; ps.a_u = prev_u; ps.a_v = prev_v; ps.a = prev;
-        ps.b_tri = tri_k; ps.b_u = hu; ps.b_v = hv; ps.b = row_cur;
-        return;
-    }
-    DeferTexelSink<RealSink> sweep(real_sink, ps);
-    const int wk = kRevDiskHead + k * kRevDiskPerVertexCf;
-    uint32_t nrays = 0;
-    const Vec3f Tn = (k + 1 < nv) ? Vec3f{disk.get(wk), disk.get(wk + 1), disk.get(wk + 2)} : Vec3f(0.f);
-    ReplayTris rt{disk.geti(wk + 6), disk.geti(wk + 7)};
-    const Vec3f beta{state.get(0), state.get(1), state.get(2)};
-    const Vec3f prev_p{state.get(17), state.get(18), state.get(19)};
-    Rng rng; rng.init(slot, jump);
-    const TriRow<float> Tk = load_tri<float>(sc, tv0, tri_k);
-    const Its<float> cur = make_path_vertex<FL>(sc, prev_p, tri_k, hu, hv, Tk);         // the arithmetic of the one-kernel sweep's `cur = vo.next`
-    const Vec3f a_c = adj * beta;
-    const Vec3f a_f = (k + 1 < nv) ? a_c * Tn : Vec3f(0.f);
-    VertexAdj va; va.clear();
-    RowAdj row_next; row_next.clear();
-    const VertexOut vo = vertex_eval<true, true, DeferTexelSink<RealSink>, ReplayTris>(sweep, sc, st, rng, cur, 1, 1, a_c, a_f, va, nrays, rt, k, &row_next);
-    const Vec3f a_prev = path_vertex_backward(sweep, sc, cur, prev_p, va, row_cur);    // row_cur: + this vertex' own position / face-normal adjoints
-    if (k >= 2) {
-        acc_finite(prev.p, a_prev);
-        ps.a_tri = prev_tri; ps.a_u = prev_u; ps.a_v = prev_v; ps.a = prev;            // vertex k - 1 is complete
-    }
-    if (k == 1) { state.put(20, a_prev.x); state.put(21, a_prev.y); state.put(22, a_prev.z); }    // -> primary_position_reverse
-    if (vo.next_valid) {
-        // handed on to launch k + 1: it evaluates vertex k + 1 (or flushes, when this was the path's last vertex) and completes this vertex' row
-        const Vec3f b2 = beta * vo.f;
-        state.put(0, b2.x); state.put(1, b2.y); state.put(2, b2.z);
-        state.put(3, row_next.p.x); state.put(4, row_next.p.y); state.put(5, row_next.p.z);
-        state.put(6, row_next.fn.x); state.put(7, row_next.fn.y); state.put(8, row_next.fn.z); state.put(9, row_next.area);
-        state.put(10, row_cur.p.x); state.put(11, row_cur.p.y); state.put(12, row_cur.p.z);
-        state.put(13, row_cur.fn.x); state.put(14, row_cur.fn.y); state.put(15, row_cur.fn.z); state.put(16, row_cur.area);
-        state.put(17, cur.p.x); state.put(18, cur.p.y); state.put(19, cur.p.z);
-        disk.put(wk + 8, vo.next.hu); disk.put(wk + 9, vo.next.hv);
-    } else {
-        // the BSDF sample found no vertex: nothing follows, this vertex' row goes out now
-        ps.b_tri = cur.tri; ps.b_u = cur.hu; ps.b_v = cur.hv; ps.b = row_cur;
-    }
-}
-
-// After launch 1: the position adjoint vertex 1's direction chain sends back to the PRIMARY vertex, p = p0 + bu e1 + bv e2 with (bu, bv, .) = MT(tri0, camera ray).
-template <class RealSink>
-PSDR_HD void primary_position_reverse(RealSink &real_sink, PrimaryGrad &pg, const SceneView &sc, const RngJump &jump, int pixel, uint64_t slot, const RevDisk &disk, const RevDisk &state) {
-    pg.clear();
-    const int tri0 = disk.geti(0);
-    if (tri0 < 0) return;
-    if (disk.geti(1) < 2) return;                        // no vertex 1 was evaluated
-    constexpr int FL = RealSink::flags;
-    PrimarySink<RealSink> sink(real_sink, pg);
-    const TangentView<0, FL> tv0{};
-    const Vec3f a_prev{state.get(20), state.get(21), state.get(22)};
-    Rng rng; rng.init(slot, jump);
-    const float j0 = rng.next(), j1 = rng.next();
-    const int W = sc.d.width;
-    const float sx = ((float) (pixel % W) + j0) / (float) W, sy = ((float) (pixel / W) + j1) / (float) sc.d.height;
-    pg.tri = tri0;
-    const Vec3f dcam = camera_space_dir(sc, sx, sy);
-    const RayT<float> ray = primary_ray<float>(sc, tv0, sx, sy);
-    const TriRow<float> T0 = load_tri<float>(sc, tv0, tri0);
-    float bu, bv, t0;
-    moeller_trumbore(T0.p0, T0.e1, T0.e2, ray, bu, bv, t0);
-    const MtAdj ma = mt_vjp(T0.p0, T0.e1, T0.e2, ray, dot(a_prev, T0.e1), dot(a_prev, T0.e2), 0.f);
-    scatter_vec(sink, tri0, 0, ma.p0 + a_prev); scatter_vec(sink, tri0, 3, ma.e1 + a_prev * bu); scatter_vec(sink, tri0, 6, ma.e2 + a_prev * bv);
-    camera_ray_vjp(sink, sc, dcam, ma.o, ma.d);
 }
 
 // One primary-edge slot in reverse mode (integrator.cpp:98-119): value = x_dot_n * dL / pdf / sppe with

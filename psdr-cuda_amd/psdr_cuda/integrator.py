@@ -23,11 +23,14 @@ _AD_KEYS = _abi.TANGENT_FIELDS
 
 
 _SOLO = 0
+_FORCE = False
+_DECIDED = []          # innermost first: the collective decision a deferred render (renderD's lazy image, its backward) was created under
 
 
 class solo:
     """`with integrator.solo():` -- render calls inside the block run on THIS rank alone: no spp sharding, no collective.  For work only one rank of a
-    multi-rank job does while the others wait (bench.py: rank 0's counter passes and single-GPU side blocks at any world size)."""
+    multi-rank job does while the others wait (bench.py: rank 0's counter passes and single-GPU side blocks at any world size).  A renderD issued inside
+    the block keeps that decision when its image / gradient is evaluated later, outside the block (_RenderNode.collective)."""
 
     def __enter__(self):
         global _SOLO
@@ -40,14 +43,38 @@ class solo:
         return False
 
 
+def force_collectives(on=True):
+    """Developer switch (a function: the package reads no environment variable): the render calls issue their collectives at world size 1 too, so that every
+    all-reduce of a render call EXECUTES on a one-GPU box -- over RCCL when the process group's backend is nccl (tests/test_rccl_single_rank_gpu.py; bench.py
+    turns it on when ITS environment holds PSDR_FORCE_COLLECTIVES=1)."""
+    global _FORCE
+    _FORCE = bool(on)
+
+
+class _decided:
+    """Evaluate a deferred render under the collective decision taken when renderD was called."""
+
+    def __init__(self, collective):
+        self.collective = bool(collective)
+
+    def __enter__(self):
+        _DECIDED.append(self.collective)
+        return self
+
+    def __exit__(self, *exc):
+        _DECIDED.pop()
+        return False
+
+
 def _dist():
-    """torch.distributed when the job has more than one rank.  PSDR_FORCE_COLLECTIVES=1 returns it at world size 1 too: every collective of a
-    render call then EXECUTES (over RCCL when the group's backend is nccl) on a one-GPU box -- tests/test_rccl_single_rank_gpu.py."""
-    import os
+    """torch.distributed when the render call takes part in the job's collectives: more than one rank (or force_collectives), not inside solo(), and -- for a
+    deferred render -- what was decided when renderD was called."""
     import torch.distributed as dist
+    if _DECIDED:
+        return dist if (_DECIDED[-1] and dist.is_available() and dist.is_initialized()) else None
     if _SOLO:
         return None
-    if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("PSDR_FORCE_COLLECTIVES") == "1"):
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _FORCE):
         return dist
     return None
 
@@ -71,12 +98,14 @@ class _RenderNode:
     def __init__(self, integrator, scene, sensor_id, tb, opts, guide):
         self.integrator, self.scene, self.sensor_id = integrator, scene, sensor_id
         self.tb, self.opts, self.guide = tb, opts, guide
+        self.collective = _dist() is not None          # the sharding of `opts` was fixed under this decision: the deferred launches keep it
 
     def input_tensors(self):
         return [self.tb.get(k) for k in _AD_KEYS] if self.tb is not None else [None] * len(_AD_KEYS)
 
     def render_forward(self, tangents):
-        img, dimgs = self.integrator._render_fwd(self.scene, self.tb, self.opts, self.guide, [tangents])
+        with _decided(self.collective):
+            img, dimgs = self.integrator._render_fwd(self.scene, self.tb, self.opts, self.guide, [tangents])
         self.primal = img.reshape(-1, 3)           # by-product of the forward-mode launch: renderD's value
         return dimgs[0].reshape(-1, 3)
 
@@ -146,13 +175,15 @@ class _RenderFn(torch.autograd.Function):
         # this primal render is going to be differentiated in reverse mode: where the reverse launch would repeat it as its value sweep (PathTracer on a
         # two-level scene), it runs with recording stages and the backward call below runs the adjoint kernel only (PSDR_FLAG_KEEP_RECORDS)
         geo = any(t is not None and t.requires_grad for t, k in zip(inputs, _AD_KEYS) if k in ("tri_info", "cam_to_world"))
-        img = node.integrator._render_c(node.scene, node.tb, node.opts, node.guide, interior_only=True, keep_records=geo)
+        with _decided(node.collective):
+            img = node.integrator._render_c(node.scene, node.tb, node.opts, node.guide, interior_only=True, keep_records=geo)
         return img.reshape(-1, 3)
 
     @staticmethod
     def backward(ctx, adj):
         node = ctx.node
-        grads = node.integrator._render_rev(node.scene, node.tb, node.opts, node.guide, adj.contiguous().reshape(-1))
+        with _decided(node.collective):
+            grads = node.integrator._render_rev(node.scene, node.tb, node.opts, node.guide, adj.contiguous().reshape(-1))
         out = [None]
         for k, present in zip(_AD_KEYS, ctx.present):
             out.append(grads.get(k) if present else None)

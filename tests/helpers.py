@@ -28,6 +28,27 @@ def rel_l2(a, b):
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
 
 
+def isolated_pixels_unbiased(a, ref, bad, label="", bias_bound=1e-3):
+    """Tree-scene tests compare two fp32 evaluations of the same estimator on the same random numbers and EXCLUDE the isolated pixels where one sample resolved an
+    epsilon-sized tie the other way (`bad`: boolean mask over pixels).  Excluding is only sound if those pixels are what that name says -- this is the net under the
+    exclusion: their SIGNED error must sum to nothing,
+        |sum_bad (a - ref)|  <=  3 sqrt(sum_bad (a - ref)^2) + 1e-6 sum|ref|       three sigma of a zero-mean flip model (independent flips of random sign)
+        |sum_bad (a - ref)|  <=  bias_bound * sum|ref|                              and negligible against the image
+    per colour channel.  A kernel bug confined to the excluded pixels (a rare branch that always loses or always gains energy) shows as a one-signed sum: with n
+    excluded pixels of similar error e it is n e against 3 sqrt(n) e.  Returns the worst ratio of the second bound (printed by the callers)."""
+    a, ref = np.asarray(a, np.float64).reshape(-1, 3), np.asarray(ref, np.float64).reshape(-1, 3)
+    bad = np.asarray(bad).reshape(-1)
+    tot = np.abs(ref).sum(axis=0) + 1e-30
+    if not bad.any():
+        return 0.0
+    e = (a - ref)[bad]
+    s, sig = e.sum(axis=0), np.sqrt((e * e).sum(axis=0))
+    worst = float((np.abs(s) / tot).max())
+    assert (np.abs(s) <= 3.0 * sig + 1e-6 * tot).all(), "%s: the %d excluded pixels are biased: signed sum %s against 3 sigma %s" % (label, int(bad.sum()), s, 3 * sig)
+    assert worst <= bias_bound, "%s: the %d excluded pixels carry %.2e of the image's energy in one direction" % (label, int(bad.sum()), worst)
+    return worst
+
+
 def load_scene(name, res=32, spp=8, sppe=0, sppse=0, translate=None, device=None):
     """Scene fixture at a small resolution.  translate = (mesh_id, direction): returns a scalar
     parameter P (FloatD, requires grad) that translates that mesh by direction * P."""

@@ -65,6 +65,33 @@ int hostcheck_tiny_layout(const psdr_scene_desc *d, int *out) {
     return 0;
 }
 
+// occluder rows of a scene without a tree as psdr_bvh_build computes them (psdr_bvh_build.h tiny_occluder_rows): occ[num_tris^2], row_of_tri[num_tris] = the
+// row of `tiny` that holds the triangle; emitter triangles from the caller's emitter_i table
+int hostcheck_occluder_rows(const psdr_scene_desc *d, uint32_t *occ_out, int *row_of_tri) {
+    HostScene hs;
+    if (!setup(hs, d)) return 1;
+    if (d->num_tris > kTinyTris) return 2;
+    std::vector<float4> prims;
+    std::vector<int> row_of_prim;
+    pack_tiny_prims(hs.b.btris, prims);
+    float4 rows[kTinyRows * 4]; int32_t meta[kTinyRows * 4]; int32_t aa = 0;
+    tiny_plane_form(prims, rows, meta, &aa, true, &row_of_prim);
+    std::vector<char> is_em((size_t) d->num_tris, 0);
+    for (int e = 0; e < d->num_emitters; ++e) {
+        const int32_t *ei = d->emitter_i + (size_t) e * PSDR_EMITTER_I_STRIDE;
+        for (int f = 0; f < ei[2]; ++f) if (ei[1] + f >= 0 && ei[1] + f < d->num_tris) is_em[(size_t) (ei[1] + f)] = 1;
+    }
+    std::vector<uint32_t> occ;
+    tiny_occluder_rows(prims, row_of_prim, d->num_tris, is_em, occ);
+    std::memcpy(occ_out, occ.data(), occ.size() * sizeof(uint32_t));
+    for (int i = 0; i < (int) prims.size() / 3; ++i) {
+        int32_t ids; std::memcpy(&ids, &prims[(size_t) i * 3].w, 4);
+        row_of_tri[ids & 0xffff] = row_of_prim[(size_t) i];
+        if (((uint32_t) ids >> 16) != 0xffffu) row_of_tri[(uint32_t) ids >> 16] = row_of_prim[(size_t) i];
+    }
+    return 0;
+}
+
 // mode 0: renderC; mode 1: renderD forward (K = 1), all three terms
 int hostcheck_render(const psdr_scene_desc *d, const psdr_render_opts *o, int mode, const psdr_tangents *tan, float *img, float *dimg,
                      int nthreads) {

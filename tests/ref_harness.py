@@ -1,0 +1,155 @@
+"""Counterpart of the reference's validation harness (examples/psdr_test.py, examples/run_test.py, examples/utils/differential.py, examples/config.py)
+for the test-suite: the SAME call sequences against the drop-in surface, written for this repository -- the scenario table below restates the numbers of
+examples/config.py:4-167 as data (scene file, integrator arguments, which parameter moves, sample counts, guiding grid, which meshes carry no edges).
+
+TEST INFRASTRUCTURE: imported by tests/test_reference_table_gpu.py only.
+"""
+import os
+
+import numpy as np
+
+import enoki as ek
+import psdr_cuda
+from enoki.cuda_autodiff import Float32 as FloatD, Matrix4f as Matrix4fD, Vector3f as Vector3fD
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REFDATA = os.path.join(HERE, "golden", "refdata", "data")          # the reference's examples/data files kept as input fixtures (scenes/*.xml, objects/tree, objects/cbox)
+
+GUIDE = {"reso": [40000, 5, 5, 2]}
+# examples/config.py:21-30 (AD_config3): ONE vertex of the emitter quad moves along -x
+_ONE_VERTEX = dict(type="vertex_transform", Mesh_ID=[0], Vertex_ID=[0], Vertex_dir=[[-50.0, 0.0, 0.0]], spp=16, sppe=8, sppse=64, guide=dict(GUIDE, nround=32))
+# examples/config.py:45-167, one row per scenario
+SCENARIOS = {
+    "cbox_MIS": dict(test_type="direct", scene_file="cbox_bunny.xml", npass=20, bsdf_samples=2, light_samples=2, orig=True, AD=_ONE_VERTEX, FD=dict(npass=512, eps=0.1)),
+    "cbox_bs": dict(test_type="direct", scene_file="cbox_bunny.xml", npass=100, bsdf_samples=5, light_samples=0, orig=True, AD=_ONE_VERTEX),
+    "cbox_es": dict(test_type="direct", scene_file="cbox_bunny.xml", npass=20, bsdf_samples=0, light_samples=2, orig=True, AD=_ONE_VERTEX),
+    "cbox_mutie": dict(test_type="direct", scene_file="cbox_bunny_mutiemitter.xml", npass=2, bsdf_samples=2, light_samples=2, orig=True),
+    "tree": dict(test_type="direct", scene_file="tree.xml", bsdf_samples=0, light_samples=2, orig=True,
+                 AD=dict(type="mesh_rotate", Mesh_ID=[1], axis=[[0., 0., 1.]], spp=0, sppe=0, sppse=64, guide=dict(GUIDE, nround=16), npass=32, no_edge=[0, 2]),
+                 FD=dict(npass=64, eps=0.01)),
+    "bunny_silhouette": dict(test_type="field", field_name="silhouette", scene_file="bunny.xml", orig=False,
+                             AD=dict(type="mesh_rotate", Mesh_ID=[0, 1], axis=[[0., 0.1, 0.], [0., -0.1, 0.]], spp=64, sppe=64, sppse=0), FD=dict(npass=20, eps=0.01)),
+    "bunny_env_1": dict(test_type="direct", scene_file="bunny_env.xml", bsdf_samples=4, light_samples=4, orig=True,
+                        AD=dict(type="envmap_rotate", Emitter_ID=0, axis=[0., 0.1, 0.], spp=64, sppe=0, sppse=0, npass=25), FD=dict(npass=25, eps=0.01)),
+    "bunny_env_2": dict(test_type="direct", scene_file="bunny_env_2.xml", bsdf_samples=2, light_samples=2, orig=True, npass=8,
+                        AD=dict(type="mesh_rotate", Mesh_ID=[0], axis=[[0., 0., 1.]], spp=4, sppe=4, sppse=64, npass=40, no_edge=[1]), FD=dict(npass=64, eps=0.01)),
+}
+
+
+def scene_file(name, tmp_dir):
+    """Path of the reference's scene file `name`.  The snapshot lacks objects/bunny/bunny.obj: where a file names it, a copy of the XML with
+    bunny_low.obj in its place (same object, 4 968 faces) is written to tmp_dir -- nothing else of the file changes."""
+    src = os.path.join(REFDATA, "scenes", name)
+    text = open(src).read()
+    if "bunny/bunny.obj" not in text:
+        return src
+    d = os.path.join(str(tmp_dir), "data", "scenes")
+    os.makedirs(d, exist_ok=True)
+    dst = os.path.join(d, name)
+    text = text.replace("bunny/bunny.obj", "bunny/bunny_low.obj")
+    for sub in ("./data/objects/cbox/", "./data/objects/tree/"):          # the copy lives elsewhere: the reference's own object files by absolute path
+        text = text.replace(sub, os.path.join(REFDATA, "objects", sub.rstrip("/").split("/")[-1]) + "/")
+    open(dst, "w").write(text)
+    return dst
+
+
+def make_integrator(args):
+    """psdr_test.py:13-74: the integrator of a scenario row"""
+    if args["test_type"] == "field":
+        return psdr_cuda.FieldExtractionIntegrator(args["field_name"])
+    return psdr_cuda.DirectIntegrator(bsdf_samples=args["bsdf_samples"], light_samples=args["light_samples"])
+
+
+def load(args, tmp_dir, res=None):
+    sc = psdr_cuda.Scene()
+    sc.load_file(scene_file(args["scene_file"], tmp_dir), False)
+    sc.opts.log_level = 0
+    if res is not None:
+        sc.opts.width = sc.opts.height = res
+    return sc
+
+
+# ---- utils/differential.py: how a scenario's parameter P enters the scene
+def apply_parameter(sc, ad, P, state):
+    t = ad["type"]
+    if t == "mesh_transform":
+        for m, d in zip(ad["Mesh_ID"], ad["Mesh_dir"]):
+            sc.param_map["Mesh[%d]" % m].set_transform(Matrix4fD.translate(Vector3fD(d) * P))
+    elif t == "mesh_rotate":
+        for m, a in zip(ad["Mesh_ID"], ad["axis"]):
+            sc.param_map["Mesh[%d]" % m].set_transform(Matrix4fD.rotate(Vector3fD(a), P))
+    elif t == "vertex_transform":
+        for m, v, d in zip(ad["Mesh_ID"], ad["Vertex_ID"], ad["Vertex_dir"]):
+            mesh = sc.param_map["Mesh[%d]" % m]
+            if m not in state:
+                state[m] = ek.detach(mesh.vertex_positions)
+            n = mesh.num_vertices
+            cols = [[0.] * n for _ in range(3)]
+            for c in range(3):
+                cols[c][v] = d[c]
+            mesh.vertex_positions = Vector3fD(state[m]) + Vector3fD(cols[0], cols[1], cols[2]) * P
+    elif t == "envmap_rotate":
+        sc.param_map["Emitter[%d]" % ad["Emitter_ID"]].set_transform(Matrix4fD.rotate(Vector3fD(ad["axis"]), P))
+    else:
+        raise RuntimeError("unknown parameter type " + t)
+
+
+def run_orig(integrator, sc, npass, on_pass=None):
+    """run_test.py:13-41: npass renderC calls averaged (sensor 0)"""
+    acc = None
+    for i in range(npass):
+        if on_pass:
+            on_pass(i, sc, integrator)
+        img = integrator.renderC(sc, 0).numpy().astype(np.float64)
+        acc = img if acc is None else acc + img
+    return acc / npass
+
+
+def prepare_ad(sc, ad):
+    """run_test.py:49-58: the sample counts of the AD dict, meshes without edges"""
+    for k in ("spp", "sppe", "sppse"):
+        if k in ad:
+            setattr(sc.opts, k, ad[k])
+    for i in ad.get("no_edge", []):
+        sc.param_map["Mesh[%d]" % i].enable_edges = False
+
+
+def run_ad(integrator, sc, ad, npass, on_pass=None, guide_rounds=None):
+    """run_test.py:44-147: per pass P = FloatD(0), the parameter applied, configure, (pass 0: guiding grid), renderD, enoki.forward, gradient image with
+    non-finite values zeroed; the passes averaged.  on_pass(i, sc, integrator, P) is called after configure() / guiding and before renderD (the test takes the
+    tables, the options and the guiding grid of the pass from it)."""
+    prepare_ad(sc, ad)
+    state, acc = {}, None
+    for i in range(npass):
+        P = FloatD(0.)
+        ek.set_requires_gradient(P)
+        apply_parameter(sc, ad, P, state)
+        sc.configure()
+        if i == 0 and "guide" in ad:
+            integrator.preprocess_secondary_edges(sc, 0, np.array(ad["guide"]["reso"]), guide_rounds if guide_rounds is not None else ad["guide"]["nround"])
+        if on_pass:
+            on_pass(i, sc, integrator, P)
+        img = integrator.renderD(sc, 0)
+        ek.forward(P, free_graph=True)
+        g = ek.gradient(img).numpy().astype(np.float64)
+        g[~np.isfinite(g)] = 0.
+        acc = g if acc is None else acc + g
+    return acc / npass
+
+
+def run_fd(integrator, args, tmp_dir, npass, res=None):
+    """run_test.py:150-231: two scenes at -eps / +eps, sppe = sppse = 0, npass renderC pairs, central difference"""
+    ad, eps = args["AD"], args["FD"]["eps"]
+    scs = []
+    for sgn in (-1.0, 1.0):
+        s = load(args, tmp_dir, res)
+        s.opts.sppe, s.opts.sppse = 0, 0
+        apply_parameter(s, ad, FloatD(sgn * eps), {})
+        s.configure()
+        scs.append(s)
+    acc = None
+    for _ in range(npass):
+        a = integrator.renderC(scs[0]).numpy().astype(np.float64)
+        b = integrator.renderC(scs[1]).numpy().astype(np.float64)
+        acc = (b - a) if acc is None else acc + (b - a)
+    return acc / (2.0 * eps * npass)

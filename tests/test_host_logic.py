@@ -369,8 +369,8 @@ def test_discrete_distribution_takes_a_known_total():
 
 def test_the_package_reads_no_environment_switch_but_the_documented_one():
     """PSDR_HIP_LIB / PSDR_NATIVE_TABLES were environment switches of the PRODUCT layer.  They are functions now
-    (psdr_cuda._abi.use_library, psdr_cuda.tables_native.set_enabled) that the test / tool drivers call; the only variable the package still looks at
-    is PSDR_FORCE_COLLECTIVES (README: the collectives of a render call at world size 1, for the single-rank RCCL test)."""
+    (psdr_cuda._abi.use_library, psdr_cuda.tables_native.set_enabled, psdr_cuda.integrator.force_collectives -- round 6) that the test / tool / bench drivers
+    call; the package looks at NO environment variable."""
     import glob
     import re
     pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "psdr-cuda_amd")
@@ -378,7 +378,7 @@ def test_the_package_reads_no_environment_switch_but_the_documented_one():
     for f in glob.glob(os.path.join(pkg, "**", "*.py"), recursive=True):
         for m in re.finditer(r"""environ(?:\.get)?\s*[\[(]\s*["']([A-Z_0-9]+)["']|getenv\(\s*["']([A-Z_0-9]+)["']""", open(f).read()):
             seen.add(m.group(1) or m.group(2))
-    assert seen <= {"PSDR_FORCE_COLLECTIVES"}, seen
-    from psdr_cuda import _abi, tables_native
-    assert callable(_abi.use_library) and callable(tables_native.set_enabled)
+    assert seen == set(), seen
+    from psdr_cuda import _abi, tables_native, integrator
+    assert callable(_abi.use_library) and callable(tables_native.set_enabled) and callable(integrator.force_collectives)
     assert _abi.HIP_LIB_PATH.endswith(os.path.join("psdr-cuda_amd", "lib", "libpsdr_hip.so")) or _abi._hip is not None

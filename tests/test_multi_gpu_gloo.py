@@ -73,7 +73,19 @@ def _solo_worker(rank, world, port, out_path):
             with I.solo():                                                       # nests
                 pass
             res["dist_nested_exit"] = I._dist() is not None
+            node_solo = I._RenderNode(integ, sc, 0, None, o, None)           # what renderD creates inside the block ...
         res["dist_after"] = I._dist() is not None
+        # ... and evaluates later, OUTSIDE it (the lazy image, its backward): the decision travels with the node
+        node_job = I._RenderNode(integ, sc, 0, None, sharded, None)
+        with I._decided(node_solo.collective):
+            res["deferred_solo_node"] = I._dist() is not None
+        with I.solo():
+            with I._decided(node_job.collective):
+                res["deferred_job_node_inside_solo"] = I._dist() is not None
+        I.force_collectives(True); res["forced_in_solo"] = [I._dist() is not None]
+        with I.solo():
+            res["forced_in_solo"].append(I._dist() is not None)
+        I.force_collectives(False)
     dist.barrier(group=side)                                                     # the others wait here meanwhile
     if rank == 0:
         import json
@@ -91,3 +103,4 @@ def test_solo_block_runs_one_rank_without_sharding_or_collectives(tmp_path):
     r = json.load(open(out))
     assert r["sharded"] == [0, 3] and r["dist_outside"] and r["dist_after"]
     assert r["solo"] == [0, 6] and not r["dist_inside"] and not r["dist_nested_exit"]
+    assert r["deferred_solo_node"] is False and r["deferred_job_node_inside_solo"] is True and r["forced_in_solo"] == [True, False]

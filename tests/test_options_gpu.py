@@ -111,3 +111,28 @@ def test_c4_shard_as_one_chunk_equals_two_chunks():
         assert a[1] == b[1] and rel_l2(b[0], a[0]) < 1e-5, other
         for k in ("tri_info", "texels"):
             assert rel_l2(b[2][k], a[2][k]) < 2e-4, (other, k, rel_l2(b[2][k], a[2][k]))
+
+
+@pytest.mark.parametrize("scene", ["cbox", "cbox_occluder", "cbox_rough", "cbox_uv"])
+def test_occluder_rows_do_not_change_a_single_sample(scene):
+    """Round 6: on a scene without a tree a light ray tests only the rows of the primitive table that can lie between its vertex and the emitter sample
+    (psdr_device.h closest_hit MASKED, psdr_bvh_build.h tiny_occluder_rows; tests/test_occluder_rows.py checks the table against brute force).  An extra
+    test never changes a closest hit, so with the table (default) and with all-ones rows (`occ_rows` 0) the SAME kernel returns the same image bit for bit --
+    renderC, forward mode and reverse mode, DirectIntegrator and PathTracer -- and traces the same number of rays."""
+    import torch
+    sc, _ = load_scene(scene, res=48, spp=16)
+    tb = sc.tables(0)
+    ga, gb = GpuScene(tb), GpuScene(tb, options={"occ_rows": 0})
+    for kw in (dict(integrator=_abi.INTEGRATOR_PATH, max_depth=4), dict(bsdf_samples=2, light_samples=2), dict(bsdf_samples=0, light_samples=1)):
+        o = _abi.make_opts(spp=16, rng_offset=(9, 0, 0), **kw)
+        a = ga.render_c(o); ra = ga.counters()[0]
+        b = gb.render_c(o); rb = gb.counters()[0]
+        assert ra == rb and np.array_equal(a, b), (scene, kw, rel_l2(a, b))
+    o = _abi.make_opts(spp=16, integrator=_abi.INTEGRATOR_PATH, max_depth=3)
+    t = {"texels": torch.rand(tb["texels"].shape, generator=torch.Generator().manual_seed(2))}
+    (ia, da), (ib, db) = ga.render_d_fwd(o, [t]), gb.render_d_fwd(o, [t])
+    assert np.array_equal(ia, ib) and np.array_equal(da[0], db[0])
+    adj = np.random.default_rng(5).random((48 * 48, 3)).astype(np.float32)
+    xa, xb = ga.render_d_rev(o, adj, want=["texels", "tri_info"])[1], gb.render_d_rev(o, adj, want=["texels", "tri_info"])[1]
+    for k in xa:
+        assert rel_l2(xb[k], xa[k]) < 1e-5, k                      # (float atomics: the order of the adds)

@@ -30,7 +30,9 @@ def main():
     torch.cuda.synchronize()
     assert t.cpu().tolist() == list(range(8))
     import psdr_cuda.integrator as integ
-    assert integ._dist() is dist                      # PSDR_FORCE_COLLECTIVES=1: the render calls will issue their collectives
+    assert integ._dist() is None                      # one rank: no collective unless asked for
+    integ.force_collectives(os.environ.get("PSDR_FORCE_COLLECTIVES") == "1")          # the test driver's switch; the package itself reads no environment variable
+    assert integ._dist() is dist                      # the render calls will issue their collectives
     calls = {"all_reduce": 0, "async": 0}
     real = dist.all_reduce
 

@@ -123,7 +123,6 @@ def test_split_reverse_launch_equals_the_fused_kernel(kind):
     # "0": one kernel; "1": value kernel + adjoint kernel; "w": the value sweep as the traced wavefront (two-level scenes, PathTracer: the default split)
     for mode in ("0", "1", "w"):
         g.set_option("rev_split", 0 if mode == "0" else 1)
-        g.set_option("rev_vertex", 0)                                       # the adjoint sweep as ONE kernel (round 4); per-vertex launches: the test below
         g.set_option("wf_traced", 1 if mode == "w" else 0)
         img, grads = g.render_d_rev(o, adj, want=["tri_info", "texels", "emitter_rad", "cam_to_world"])
         out[mode] = (img, grads, g.counters()[0])
@@ -140,44 +139,6 @@ def test_split_reverse_launch_equals_the_fused_kernel(kind):
     assert rel_l2(out["w"][0], out["0"][0]) < 3e-4                         # measured 4.7e-5 (three of 457 855 rays differ)
     for k in ("tri_info", "texels", "emitter_rad", "cam_to_world"):
         assert rel_l2(out["w"][1][k], out["0"][1][k]) < 1e-3, (k, rel_l2(out["w"][1][k], out["0"][1][k]))          # measured 1e-6 .. 1.1e-4
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("scene,depth,res,spp", [("cbox", 3, 64, 16), ("cbox", 1, 48, 8), ("cbox", 6, 48, 8), ("cbox_rough", 3, 48, 16), ("cbox_bunny", 3, 96, 8),
-                                                 ("cbox_bunny", 5, 64, 8), ("bunny_light", 3, 96, 8), ("cbox_uv", 3, 48, 16)])
-def test_per_vertex_adjoint_launches_equal_the_one_kernel_sweep(scene, depth, res, spp):
-    """Round 5: the adjoint sweep of a split PathTracer launch runs as ONE LAUNCH PER PATH VERTEX (csrc/psdr_kernels.h k_vertex_rev, psdr_reverse.h
-    vertex_reverse): the value sweep's record in, that vertex' table adjoints out, the running adjoint (throughput, the next vertex' pending row
-    adjoint, this vertex' pending position adjoint) carried in a 13-word state column.  The chains are linear, so the gradients are those of the
-    one-kernel sweep up to the order of the float adds -- on scenes without a tree (fused value kernel), two-level scenes (the value sweep is the traced
-    wavefront), a single tree, textured and rough-conductor materials, depths below / at / above the vertex kinds (0, 1, >= 2), odd chunk boundaries."""
-    from helpers import GpuScene, load_scene, rel_l2
-    sc, _ = load_scene(scene, res=res, spp=spp)
-    tb = sc.tables(0)
-    o = _abi.make_opts(spp=spp, integrator=_abi.INTEGRATOR_PATH, max_depth=depth, rng_offset=(5, 0, 0))
-    adj = np.random.default_rng(11).random((res * res, 3)).astype(np.float32)
-    names = ["tri_info", "texels", "emitter_rad", "cam_to_world"]
-    g = GpuScene(tb)
-    g.set_option("rev_split", 0)
-    img0, g0 = g.render_d_rev(o, adj, want=names)
-    out = {}
-    for mode, opts in (("split-one", dict(rev_split=1, rev_vertex=0)), ("vertex", dict(rev_split=1, rev_vertex=1)),
-                       ("vertex-chunks", dict(rev_split=1, rev_vertex=1, chunk_log2=11)), ("vertex-fused-value", dict(rev_split=1, rev_vertex=1, wf_traced=0))):
-        gm = GpuScene(tb, options=opts)
-        out[mode] = gm.render_d_rev(o, adj, want=names)
-        gm.close()
-    for mode, (img, grads) in out.items():
-        # against the one-kernel launch: the traced-wavefront value sweep of a two-level scene is a separately compiled fp32 kernel (isolated samples differ)
-        loose = "bunny" in scene
-        assert rel_l2(img, img0) < (3e-4 if loose else 1e-6), (mode, rel_l2(img, img0))
-        for k in names:
-            assert np.abs(g0[k]).max() > 0, k
-            assert rel_l2(grads[k], g0[k]) < (2e-3 if loose else 5e-5), (mode, k, rel_l2(grads[k], g0[k]))
-    # per-vertex launches against the one adjoint kernel ON THE SAME RECORDS: only the order of the adds differs
-    for k in names:
-        assert rel_l2(out["vertex"][1][k], out["split-one"][1][k]) < 5e-5, (k, rel_l2(out["vertex"][1][k], out["split-one"][1][k]))
-        assert rel_l2(out["vertex-chunks"][1][k], out["vertex"][1][k]) < 5e-5, (k, rel_l2(out["vertex-chunks"][1][k], out["vertex"][1][k]))
-    print(scene, depth, {m: {k: "%.1e" % rel_l2(out[m][1][k], g0[k]) for k in names} for m in out})
 
 
 @pytest.mark.gpu
