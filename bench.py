@@ -850,7 +850,8 @@ def main():
     try:
         ms_rev_all_surface = timed(w.surface_reverse_all_step, n_side)
     except Exception as e:                                   # a scene without these parameters: reported as missing, never as a number
-        print("surface reverse-all step skipped: %r" % (e,), file=sys.stderr)
+        import traceback
+        print("surface reverse-all step skipped: %r\n%s" % (e, traceback.format_exc()), file=sys.stderr)
         ms_rev_all_surface = None
     w.kernel_setup(1)
     for _ in range(3):

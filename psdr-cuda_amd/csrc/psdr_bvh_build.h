@@ -214,18 +214,26 @@ inline void tiny_occluder_rows(const std::vector<float4> &prims, const std::vect
         for (int v = 0; v < q.nc; ++v) for (int k = 0; k < 3; ++k) scale = std::max(scale, std::fabs(q.c[v][k]));
     }
     const double tol = 1e-6 * std::max(scale, 1e-30);
+    int n_emitter_prims = 0;
+    for (int i = 0; i < n; ++i) {
+        bool em = false;
+        for (int a = 0; a < 2; ++a) { const int t = ps[(size_t) i].tris[a]; em = em || (t >= 0 && t < num_tris && is_emitter_tri[(size_t) t]); }
+        n_emitter_prims += em ? 1 : 0;
+    }
     for (int r = 0; r < n; ++r)
         for (int e = 0; e < n; ++e) {
             uint32_t m = 1u << ps[(size_t) e].row;
-            {   // r's primitive in e's plane (r == e, or a coplanar neighbour): such a ray runs IN the emitter's plane and never meets it (n . d = 0) -- the full
-                // search then reports whatever lies behind, and so must this one: every row
+            {   // r's primitive in e's plane (r == e, or a coplanar neighbour): such a ray runs IN the emitter's plane and never meets it (n . d = 0); the full
+                // search reports whatever lies behind.  What a light ray's hit is USED for is "an emitter, at the sample's distance or beyond" (direct.cpp:138-141):
+                // with ONE emitter primitive in the scene nothing behind can be one, and e's row alone gives the same outcome (no contribution); with several
+                // the entry names every row
                 const P &q = ps[(size_t) e];
                 bool coplanar = true;
                 for (int v = 0; v < ps[(size_t) r].nc; ++v) {
                     const double sd = q.nrm[0] * ps[(size_t) r].c[v][0] + q.nrm[1] * ps[(size_t) r].c[v][1] + q.nrm[2] * ps[(size_t) r].c[v][2] - q.d;
                     coplanar = coplanar && std::fabs(sd) <= tol;
                 }
-                if (coplanar) m = 0xffffffffu;
+                if (coplanar && n_emitter_prims > 1) m = 0xffffffffu;
             }
             for (int p = 0; p < n; ++p) {
                 if (p == e) continue;

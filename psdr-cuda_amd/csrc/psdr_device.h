@@ -503,11 +503,20 @@ PSDR_HD bool blas_box(const SceneView &sc, int k, const Vec3f &o, const Vec3f &i
 
 // FOREST: 2 = the instance serves scenes WITHOUT a tree only (kSceneTiny: the walk below is not even compiled), 1 = two-level scenes only,
 // 0 = never two-level (no box loop / per-tree walks in the code), -1 = decided at run time (k_trace, host tests).
-// MASKED (kSceneTiny light rays, SceneView::occ): bit i of `rows` clear = row i of `tiny` cannot lie between this lane's origin and its target.  A row is
-// tested when ANY lane of the wave wants it (wave-uniform branch, scalar loads stay uniform); an extra test never changes a closest hit.
-PSDR_HD bool wave_any_hd(bool x) {
+// MASKED (kSceneTiny light rays, SceneView::occ): bit i of `rows` clear = row i of `tiny` cannot lie between the origin and the target.  `rows` is WAVE-UNIFORM
+// (wave_or_hd of the lanes' entries: a row is tested when any lane wants it -- an extra test never changes a closest hit), so a skipped row costs one scalar
+// bit test and the scalar loads of the tested ones stay uniform.
+PSDR_HD uint32_t wave_or_hd(uint32_t x) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return __ballot(x) != 0ull;
+    // one round per DISTINCT value among the active lanes (normally one: every lane names the light's row), all on the scalar unit
+    unsigned long long todo = __ballot(1);
+    uint32_t u = 0u;
+    while (todo != 0ull) {
+        const uint32_t f = (uint32_t) __builtin_amdgcn_readlane((int) x, __ffsll((long long) todo) - 1);
+        u |= f;
+        todo &= ~__ballot(x == f);
+    }
+    return u;
 #else
     return x;
 #endif
@@ -553,7 +562,7 @@ PSDR_HD Hit closest_hit(const SceneView &sc, TraversalStack &st, const Vec3f &o,
                 }
             }
             const int cx = aa_cnt & 255, cy = (aa_cnt >> 8) & 255, cz = aa_cnt >> 16;
-#define PSDR_AA(AX, S) do { if (!MASKED || wave_any_hd(((rows >> (S)) & 1u) != 0u)) aa_prim_test<AX, IGN>(ra[S], hb[S], pk[S], id2[S], o, d, inv, best, best_i, ig0, ig1); } while (0)
+#define PSDR_AA(AX, S) do { if (!MASKED || ((rows >> (S)) & 1u) != 0u) aa_prim_test<AX, IGN>(ra[S], hb[S], pk[S], id2[S], o, d, inv, best, best_i, ig0, ig1); } while (0)
             if (cx > 0) { PSDR_AA(0, 0); if (cx > 1) { PSDR_AA(0, 1); if (cx > 2) PSDR_AA(0, 2); } }
             if (cy > 0) { PSDR_AA(1, 3); if (cy > 1) { PSDR_AA(1, 4); if (cy > 2) PSDR_AA(1, 5); } }
             if (cz > 0) { PSDR_AA(2, 6); if (cz > 1) { PSDR_AA(2, 7); if (cz > 2) PSDR_AA(2, 8); } }
@@ -562,7 +571,7 @@ PSDR_HD Hit closest_hit(const SceneView &sc, TraversalStack &st, const Vec3f &o,
         // the other primitives in plane form (triangles, or parallelograms of two triangles: pack_tiny_prims)
 #pragma unroll PSDR_TINY_UNROLL
         for (int i = aa_cnt != 0 ? kAaSlots : 0; i < sc.n_tiny; ++i)
-            if (!MASKED || wave_any_hd(((rows >> i) & 1u) != 0u)) tiny_prim_test<IGN>(prim_rows[i * 4], prim_rows[i * 4 + 1], prim_rows[i * 4 + 2], prim_rows[i * 4 + 3], i, o, d, best, best_i, ig0, ig1);
+            if (!MASKED || ((rows >> i) & 1u) != 0u) tiny_prim_test<IGN>(prim_rows[i * 4], prim_rows[i * 4 + 1], prim_rows[i * 4 + 2], prim_rows[i * 4 + 3], i, o, d, best, best_i, ig0, ig1);
         resolve_tiny_hit(sc, best, best_i);
         if (FOREST == 3) {
             // the trees were walked beforehand (same leaf test, tmax = infinity): the closest tree hit replaces the primitive hit exactly where the
@@ -717,7 +726,7 @@ template <class R, class TVT, bool MASKED = false> PSDR_HD Its<R> intersect(cons
     nrays++;
     constexpr int F = tree_mode<TVT::flags>();
     Hit h;
-    if constexpr (MASKED) h = closest_hit<false, F, true>(sc, st, val(ray.o), val(ray.d), INFINITY, -1, -1, pre_slot, rows);
+    if constexpr (MASKED) h = closest_hit<false, F, true>(sc, st, val(ray.o), val(ray.d), INFINITY, -1, -1, pre_slot, wave_or_hd(rows));
     else h = (ig0 >= 0 || ig1 >= 0) ? closest_hit<true, F>(sc, st, val(ray.o), val(ray.d), INFINITY, ig0, ig1, pre_slot)
                                     : closest_hit<false, F>(sc, st, val(ray.o), val(ray.d), INFINITY, -1, -1, pre_slot);
     if (h.tri < 0) return its;

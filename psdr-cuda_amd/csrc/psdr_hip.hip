@@ -405,18 +405,60 @@ int bvh4_refill(psdr_scene_s *h, hipStream_t s);
 int bvh4_build(psdr_scene_s *h, const std::vector<BvhNode> &nodes, const std::vector<int32_t> &roots2, bool forest, hipStream_t s);
 int fail(const std::string &m) { g_err = m; return 1; }
 
+// Device memory a scratch buffer of this handle may grow to NOW: what the driver reports free, plus what the stream-ordered pool holds without using it (blocks
+// hipFreeAsync returned earlier: hipMallocAsync serves from them first), plus the block that is being replaced -- minus 64 MB of headroom for the runtime.
+static size_t scratch_available(size_t have) {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 0;
+    int dev = 0; hipMemPool_t pool = nullptr;
+    uint64_t reserved = 0, used = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess && pool != nullptr &&
+        hipMemPoolGetAttribute(pool, hipMemPoolAttrReservedMemCurrent, &reserved) == hipSuccess && hipMemPoolGetAttribute(pool, hipMemPoolAttrUsedMemCurrent, &used) == hipSuccess &&
+        reserved > used)
+        free_b += (size_t) (reserved - used);
+    (void) hipGetLastError();
+    const size_t gross = free_b + have, headroom = 64ull << 20;
+    return gross > headroom ? gross - headroom : 0;
+}
+// The largest chunk (a power-of-two fraction of `chunk`, at least 2^18 slots) whose per-slot workspace fits the device now: a launch whose default chunk
+// (2^26 slots: 16-30 GB of streams / records) does not fit -- torch's caching allocator or another process holds the memory -- runs in more, smaller chunks
+// instead of failing.
+long long fit_chunk(long long chunk, size_t bytes_per_slot, size_t fixed_bytes, size_t have) {
+    const size_t avail = scratch_available(have);
+    while (chunk > (1ll << 18) && (size_t) chunk * bytes_per_slot + fixed_bytes > avail && (size_t) chunk * bytes_per_slot + fixed_bytes > have) chunk >>= 1;
+    return chunk;
+}
+// A/B switch of the TLB experiment (option scratch_plain): blocks of >= 64 MB come from hipMalloc (one mapping the driver may back with
+// large fragments) instead of the stream-ordered pool.  Process-wide; such blocks are never handed back to the pool.
+static int g_scratch_plain = 0;
 int scratch_reserve(void **buf, size_t *have, size_t need, hipStream_t s, const char *what) {
     if (need <= *have) return 0;
-    size_t free_b = 0, total_b = 0;
-    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-    // what the old block gives back counts as free; keep 256 MB of headroom for the runtime
-    if (need > free_b + *have || free_b + *have - need < (256ull << 20))
-        return fail(std::string("psdr: the ") + what + " needs " + std::to_string(need >> 20) + " MB of device memory, " + std::to_string((free_b + *have) >> 20) +
-                    " MB are free on this device (of " + std::to_string(total_b >> 20) + " MB): render fewer samples per call (spp range) or set the option chunk_log2");
+    if (g_scratch_plain != 0 && (need >= (64ull << 20) || (*buf != nullptr && *have >= (64ull << 20)))) {
+        HIP_TRY(hipStreamSynchronize(s));
+        if (*buf) { if (*have >= (64ull << 20)) HIP_TRY(hipFree(*buf)); else HIP_TRY(hipFreeAsync(*buf, s)); }
+        *buf = nullptr; *have = 0;
+        if (hipMalloc(buf, need) != hipSuccess) { (void) hipGetLastError(); *buf = nullptr; return fail(std::string("psdr: could not allocate ") + std::to_string(need >> 20) + " MB for the " + what); }
+        *have = need;
+        return 0;
+    }
+    const size_t avail = scratch_available(*have);
+    if (need > avail)
+        return fail(std::string("psdr: the ") + what + " needs " + std::to_string(need >> 20) + " MB of device memory, " + std::to_string(avail >> 20) +
+                    " MB are available on this device: render fewer samples per call (spp range) or set the option chunk_log2");
+    // the new block first where both fit (a failure then leaves the old one in place), otherwise the old one goes first
+    void *nb = nullptr;
+    if (*buf != nullptr && need <= scratch_available(0)) {
+        if (hipMallocAsync(&nb, need, s) != hipSuccess) { (void) hipGetLastError(); nb = nullptr; }
+    }
     if (*buf) HIP_TRY(hipFreeAsync(*buf, s));
     *buf = nullptr; *have = 0;
-    HIP_TRY(hipMallocAsync(buf, need, s));
-    *have = need;
+    if (nb == nullptr) {
+        if (hipMallocAsync(&nb, need, s) != hipSuccess) {
+            (void) hipGetLastError();
+            return fail(std::string("psdr: could not allocate ") + std::to_string(need >> 20) + " MB of device memory for the " + what);
+        }
+    }
+    *buf = nb; *have = need;
     return 0;
 }
 
@@ -940,6 +982,9 @@ int psdr_scene_set_option(psdr_scene_t h, const char *name, double value) {
     const std::string n(name);
     const int iv = (int) value;
     if (n == "bvh_refit") h->refit_enabled = iv != 0;                   // 0: rebuild the tree on the host at every psdr_bvh_build
+    else if (n == "forest_min_inline") { h->forest_min_inline = iv; h->have_bvh = false; }   // a two-level tree needs at least this many inline triangles (default 6: walls around objects)
+    else if (n == "scratch_plain") g_scratch_plain = iv;                 // experiment: scratch blocks of >= 64 MB from hipMalloc instead of the stream-ordered pool (process-wide)
+    else if (n == "own_pixels") h->opt.own_pixels = iv;                  // 0: the camera kernels always add to the image with atomics
     else if (n == "occ_rows") { h->opt.occ_rows = iv; h->have_bvh = false; }       // 0: the light rays of a scene without a tree test every row (A/B, tests)
     else if (n == "aa_prims") { h->aa_enabled = iv != 0; h->have_bvh = false; }   // 0: every kernel-argument primitive in plane form (no slab rows)
     else if (n == "tiny_scene") h->tiny_enabled = iv != 0;              // 0: walk a tree even for <= 16 triangles
@@ -1045,6 +1090,7 @@ int psdr_bvh_build(psdr_scene_t h, void *stream) {
     if (!h || !h->have_tables) return fail("Scene not loaded yet!");
     hipStream_t s = (hipStream_t) stream;
     const int T = h->desc.num_tris;
+    h->kept.valid = false;                  // records of a value sweep belong to the tree they were traced with
     // ---- refit: same triangle count as the tree on the device and the tree has not degraded
     const bool tiny = h->tiny_enabled && T <= kTinyTris;        // the triangles travel in the kernel arguments: host copy needed
     // The host copy of emitter_i (LDS table sizes, two-level eligibility, hot gradient rows) is refreshed by the build paths below only: a
@@ -1145,7 +1191,7 @@ int psdr_bvh_build(psdr_scene_t h, void *stream) {
         pack_tiny_prims(fb.inline_tris, top_prims);
         // too many inline primitives: one tree.  Too few: nothing room-like to keep out of the trees (two bunnies and a light quad:
         // PathTracer(3) 2.9 ms on one tree against 3.1 on the forest) -- the two-level tree is for walls around objects
-        if ((int) top_prims.size() / 3 > kTinyTris || (int) fb.inline_tris.size() / 3 < 6) { forest = false; fb = ForestBuilder(); }
+        if ((int) top_prims.size() / 3 > kTinyTris || (int) fb.inline_tris.size() / 3 < h->forest_min_inline) { forest = false; fb = ForestBuilder(); }
     }
     if (!forest) { if (const char *err = b.run(rows.data(), T, root)) return fail(err); }
     std::vector<BvhNode> &nodes = forest ? fb.nodes : b.nodes;
@@ -1233,6 +1279,8 @@ int psdr_bvh_build(psdr_scene_t h, void *stream) {
             }
             HIP_TRY(copy_on_stream(h->d_occ, occ.data(), occ.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
             h->have_occ = true;
+            h->occ_max_rows = 0;                                     // the most rows any (triangle, emitter triangle) entry names (psdr_scene_info)
+            for (int r = 0; r < T; ++r) for (int e = 0; e < T; ++e) if (is_em[(size_t) e]) h->occ_max_rows = std::max(h->occ_max_rows, (int) __builtin_popcount(occ[(size_t) r * T + e] & ((1u << h->n_tiny) - 1u)));
         }
     }
     // what the refit path needs: the levels of the breadth-first node order, the padding, the reference area
@@ -1342,7 +1390,7 @@ int psdr_scene_info(psdr_scene_t h, int32_t out[8]) {
     if (!h || !out) return fail("psdr_scene_info: null argument");
     const int n_slab = (h->aa_cnt & 255) + ((h->aa_cnt >> 8) & 255) + (h->aa_cnt >> 16);
     out[0] = h->n_tiny - (h->aa_cnt != 0 ? kAaSlots - n_slab : 0); out[1] = h->n_blas; out[2] = h->n_inline; out[3] = h->num_btris; out[4] = h->lbvh ? 1 : 0;
-    out[5] = n_slab; out[6] = out[7] = 0;
+    out[5] = n_slab; out[6] = h->have_occ ? 1 : 0; out[7] = h->have_occ ? h->occ_max_rows : 0;
     return 0;
 }
 

@@ -160,6 +160,7 @@ struct psdr_scene_options {
     int rev_split = -1;                    // reverse mode as value kernel + adjoint kernel: 1 / 0 force, -1 by scene and launch size
     int tangent_live = 1;                  // forward mode with geometry tangents: one bit per triangle "some tangent set moves this row" (TangentView::live); 0: every row loads its tangents
     int wf_geo = 1;                        // PathTracer forward mode with geometry tangents on a two-level scene as the traced wavefront (k_wfg_*); 0: the fused kernel
+    int own_pixels = 1;                    // camera kernels store a pixel whose samples all sit in one wave (64 % samples per pixel == 0) instead of adding to it with atomics (0: always atomics)
     int occ_rows = 1;                      // scenes without a tree: light rays test only the rows that can lie between the vertex and the emitter sample (0: every row; takes effect at the next psdr_bvh_build)
     int logd = 1;                          // PathTracer forward mode with tangents on diffuse albedo texels only: the log-derivative kernel (0: always dual numbers)
     int keep_records = 1;                  // psdr_render_c honours PSDR_FLAG_KEEP_RECORDS (0: ignored -- A/B, tests)
@@ -235,7 +236,7 @@ struct psdr_scene_s {
     // reverse-mode gradient sink: triangle rows cached in LDS (chosen at build time)
     std::vector<int32_t> emitter_i;        // host copy of desc.emitter_i (the emitter meshes' rows are hot)
     int32_t *d_hot_map = nullptr, *d_hot_tris = nullptr;
-    uint32_t *d_occ = nullptr; size_t occ_cap = 0; bool have_occ = false;      // occluder rows of a scene without a tree (SceneView::occ; psdr_bvh_build), [num_tris^2]
+    uint32_t *d_occ = nullptr; size_t occ_cap = 0; bool have_occ = false; int occ_max_rows = 0;      // occluder rows of a scene without a tree (SceneView::occ; psdr_bvh_build), [num_tris^2]
     int hot_rows = 0;
     bool hot_identity = false;             // every row cached, slot == triangle (scenes without a tree)
     size_t hot_cap = 0;
@@ -274,6 +275,11 @@ struct psdr_scene_s {
     // probe / final launches: hit rows, masks, trace requests
     void *d_probe = nullptr;
     size_t probe_bytes = 0;
+    // psdr_bvh_build: a two-level tree only with at least this many inline triangles.  Rounds 2-5 kept scenes without something room-like (< 6 inline triangles: two
+    // bunnies, a light quad and a backdrop) on ONE tree -- measured on 4 M-slot PathTracer launches (2.9 against 3.1 ms).  At BASELINE configs[2]'s size every launch
+    // form that runs its tree walks in the dense trace kernel wins there too (bunny_light 512^2 x 128: DirectIntegrator three-term reverse 39.6 -> 33.9 ms, forward
+    // 40.8 -> 35.8, PathTracer(3) renderC 8.0 -> 6.2, PathTracer(3) reverse 25.2 -> 12.8; profiles/r06_bunny_light_forest.txt): default 0 since round 6
+    int forest_min_inline = 0;
 };
 
 constexpr int kRayCounters = 64, kRayCounterStride = 16;     // d_counters: 64 counters, 128 bytes apart
@@ -286,6 +292,7 @@ int fail(const std::string &m);
 // no device-wide synchronise on the hot path of the first large call or after a size change), and refused with a clear message when the device does
 // not have the memory (the traced wavefront takes 16 GB for a 2^26-slot chunk: fine for eight ranks on eight GPUs, not for two processes on one).
 int scratch_reserve(void **buf, size_t *have, size_t need, hipStream_t s, const char *what);
+long long fit_chunk(long long chunk, size_t bytes_per_slot, size_t fixed_bytes, size_t have);      // the largest power-of-two fraction of `chunk` whose workspace the device can hold now
 inline int workspace_reserve(psdr_scene_s *h, size_t need, hipStream_t s) { return scratch_reserve(&h->d_ws, &h->ws_bytes, need, s, "wavefront workspace (path-state streams + trace requests)"); }
 int launch_blocks(const psdr_scene_s *h, long long n, int per_cu = 16);
 int plan_lds(const psdr_scene_s *h, LaunchCtx &cx, int reserved = 0);

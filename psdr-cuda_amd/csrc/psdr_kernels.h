@@ -168,7 +168,9 @@ template <class G, class R, int INTEG, int FL> constexpr bool logd_instance() {
 template <class G, class R, int INTEG, int FL, bool NOTREE = false>
 __global__ __launch_bounds__(kBlock, (camera_waves<G, R, INTEG, FL, NOTREE>())) void k_camera(LaunchCtx cx, TV<R, FL> tv, int spp, int s_begin, SlotDiv nsp, long long n, float inv_spp,
                                                    float *__restrict__ img, float *__restrict__ dimg, long long plane,
-                                                   unsigned long long *counters, long long j0, ProbeView pv) {
+                                                   unsigned long long *counters, long long j0, ProbeView pv, int own) {
+    // own: every pixel's samples of this launch sit in ONE wave (64 % samples per pixel == 0, run_camera) -- the run's head lane STORES the pixel (the image was
+    // zeroed, the edge terms add to the derivative images afterwards) instead of three to twelve returning L2 atomics of 32 bytes each: C2 1.57 M atomics per launch
     constexpr int K = ad_traits<R>::K;
     constexpr int NV = 3 * (1 + K);
     // the dual-number PathTracer instances a log-derivative launch stands in for (k_camera_logd below): both are launched, the gate word says which one runs
@@ -198,15 +200,21 @@ __global__ __launch_bounds__(kBlock, (camera_waves<G, R, INTEG, FL, NOTREE>())) 
         const bool head = wave_segmented_sum<NV>(pixel, v);
         if (head && in) {
             float *p = img + (size_t) pixel * 3;
-            if (v[0] != 0.f) atomicAdd(p, v[0]);
-            if (v[1] != 0.f) atomicAdd(p + 1, v[1]);
-            if (v[2] != 0.f) atomicAdd(p + 2, v[2]);
+            if (own) {
+                p[0] = v[0]; p[1] = v[1]; p[2] = v[2];
 #pragma unroll
-            for (int k = 0; k < K; ++k) {
-                float *q = dimg + (size_t) k * plane + (size_t) pixel * 3;
-                if (v[3 + 3 * k] != 0.f) atomicAdd(q, v[3 + 3 * k]);
-                if (v[4 + 3 * k] != 0.f) atomicAdd(q + 1, v[4 + 3 * k]);
-                if (v[5 + 3 * k] != 0.f) atomicAdd(q + 2, v[5 + 3 * k]);
+                for (int k = 0; k < K; ++k) { float *q = dimg + (size_t) k * plane + (size_t) pixel * 3; q[0] = v[3 + 3 * k]; q[1] = v[4 + 3 * k]; q[2] = v[5 + 3 * k]; }
+            } else {
+                if (v[0] != 0.f) atomicAdd(p, v[0]);
+                if (v[1] != 0.f) atomicAdd(p + 1, v[1]);
+                if (v[2] != 0.f) atomicAdd(p + 2, v[2]);
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    float *q = dimg + (size_t) k * plane + (size_t) pixel * 3;
+                    if (v[3 + 3 * k] != 0.f) atomicAdd(q, v[3 + 3 * k]);
+                    if (v[4 + 3 * k] != 0.f) atomicAdd(q + 1, v[4 + 3 * k]);
+                    if (v[5 + 3 * k] != 0.f) atomicAdd(q + 2, v[5 + 3 * k]);
+                }
             }
         }
     }
@@ -231,7 +239,7 @@ __global__ void k_logd_gate(unsigned long long *counters, const int *bad) { if (
 // the camera kernel of a PathTracer whose tangents sit on diffuse albedo texels only: k_camera<float, Dual<K>, PATH, FL> with the estimator on plain floats
 template <int K, int FL, bool NOTREE>
 __global__ __launch_bounds__(kBlock, ((PSDR_LOGD_WAVES_K1 > 0 && K == 1 && NOTREE) ? PSDR_LOGD_WAVES_K1 : camera_waves<float, Dual<K>, PSDR_INTEGRATOR_PATH, FL, NOTREE>())) void k_camera_logd(LaunchCtx cx, TV<Dual<K>, FL> tv, int spp, int s_begin, SlotDiv nsp,
-                                                   long long n, float inv_spp, float *__restrict__ img, float *__restrict__ dimg, long long plane, unsigned long long *counters) {
+                                                   long long n, float inv_spp, float *__restrict__ img, float *__restrict__ dimg, long long plane, unsigned long long *counters, int own) {
     constexpr int NV = 3 * (1 + K);
     if (counters[kLogdGateWord] != 1ull) return;
     TraversalStack st; setup_lds(cx, st, tv);
@@ -254,15 +262,21 @@ __global__ __launch_bounds__(kBlock, ((PSDR_LOGD_WAVES_K1 > 0 && K == 1 && NOTRE
         const bool head = wave_segmented_sum<NV>(pixel, v);
         if (head && in) {
             float *p = img + (size_t) pixel * 3;
-            if (v[0] != 0.f) atomicAdd(p, v[0]);
-            if (v[1] != 0.f) atomicAdd(p + 1, v[1]);
-            if (v[2] != 0.f) atomicAdd(p + 2, v[2]);
+            if (own) {
+                p[0] = v[0]; p[1] = v[1]; p[2] = v[2];
 #pragma unroll
-            for (int k = 0; k < K; ++k) {
-                float *q = dimg + (size_t) k * plane + (size_t) pixel * 3;
-                if (v[3 + 3 * k] != 0.f) atomicAdd(q, v[3 + 3 * k]);
-                if (v[4 + 3 * k] != 0.f) atomicAdd(q + 1, v[4 + 3 * k]);
-                if (v[5 + 3 * k] != 0.f) atomicAdd(q + 2, v[5 + 3 * k]);
+                for (int k = 0; k < K; ++k) { float *q = dimg + (size_t) k * plane + (size_t) pixel * 3; q[0] = v[3 + 3 * k]; q[1] = v[4 + 3 * k]; q[2] = v[5 + 3 * k]; }
+            } else {
+                if (v[0] != 0.f) atomicAdd(p, v[0]);
+                if (v[1] != 0.f) atomicAdd(p + 1, v[1]);
+                if (v[2] != 0.f) atomicAdd(p + 2, v[2]);
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    float *q = dimg + (size_t) k * plane + (size_t) pixel * 3;
+                    if (v[3 + 3 * k] != 0.f) atomicAdd(q, v[3 + 3 * k]);
+                    if (v[4 + 3 * k] != 0.f) atomicAdd(q + 1, v[4 + 3 * k]);
+                    if (v[5 + 3 * k] != 0.f) atomicAdd(q + 2, v[5 + 3 * k]);
+                }
             }
         }
     }
@@ -1680,6 +1694,8 @@ int run_camera(psdr_scene_s *h, const psdr_render_opts *o, const TV<R, FL> &tv, 
     if (int rc = make_ctx(h, o, 0, cx)) return rc;
     const long long n = WH * nsp;
     h->slots[0] += (uint64_t) n;
+    // every pixel's samples of the launch in one wave: the camera kernels store their pixels instead of adding to them (k_camera `own`; chunks start at multiples of 2^24)
+    const int own = (h->opt.own_pixels != 0 && nsp <= 64 && 64 % nsp == 0) ? 1 : 0;
     // DirectIntegrator(1, 1) on a two-level scene: probe pass (primary hit + requests for the vertex' two rays that enter a tree box) -> dense trace
     // kernel -> this kernel compiled with kScenePre (no tree walk: primitives + hit rows), chunk by chunk.  C3 forward geometry duals 1.31 -> 0.73 ms
     // (0.21 + 0.19 + 0.33), C4 shard reverse 16.0 -> 14.0 ms
@@ -1705,7 +1721,7 @@ int run_camera(psdr_scene_s *h, const psdr_render_opts *o, const TV<R, FL> &tv, 
                 HIP_TRY(hipGetLastError());
                 if (int rc = launch_wf_trace(h, pb.req, pb.count, pb.sub_cap, pb.hit, s)) return rc;
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(k_camera<G, R, PSDR_INTEGRATOR_DIRECT, FL | kScenePre, false>), dim3(launch_blocks(h, nc, camera_blocks_per_cu(h, nc))), dim3(kBlock), cxp.off_stack, s,
-                                   cxp, tvp, o->spp, o->spp_begin, SlotDiv(nsp), nc, 1.f / (float) o->spp, img, dimg, WH * 3, h->d_counters, c0, ProbeView{pb.hit, pb.mask});
+                                   cxp, tvp, o->spp, o->spp_begin, SlotDiv(nsp), nc, 1.f / (float) o->spp, img, dimg, WH * 3, h->d_counters, c0, ProbeView{pb.hit, pb.mask}, own);
                 HIP_TRY(hipGetLastError());
             }
             return 0;
@@ -1713,6 +1729,7 @@ int run_camera(psdr_scene_s *h, const psdr_render_opts *o, const TV<R, FL> &tv, 
     }
     // PathTracer, material tangents on albedo texels only, a variant without rough conductors / environment map: the log-derivative kernel and, behind the
     // same gate, the dual-number kernel (one of the two returns at once)
+    bool gated = false;
     if constexpr (logd_instance<G, R, PSDR_INTEGRATOR_PATH, FL>()) {
         constexpr int K = ad_traits<R>::K;
         bool texels_only = o->integrator == PSDR_INTEGRATOR_PATH && h->opt.logd != 0 && h->desc.num_texels > 0 && h->desc.texels != nullptr;
@@ -1729,13 +1746,14 @@ int run_camera(psdr_scene_s *h, const psdr_render_opts *o, const TV<R, FL> &tv, 
             hipLaunchKernelGGL(k_logd_check<K>, dim3((unsigned) ((h->desc.num_texels + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, h->desc.texels, tvk, h->desc.num_texels, h->d_counters, bad);
             hipLaunchKernelGGL(k_logd_gate, dim3(1), dim3(64), 0, s, h->d_counters, bad);
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_camera_logd<K, FL, ((FL & kSceneTiny) != 0)>), dim3(launch_blocks(h, n, camera_blocks_per_cu(h, n))), dim3(kBlock), lds_bytes(cx, h), s, cx, tv,
-                               o->spp, o->spp_begin, SlotDiv(nsp), n, 1.f / (float) o->spp, img, dimg, WH * 3, h->d_counters);
+                               o->spp, o->spp_begin, SlotDiv(nsp), n, 1.f / (float) o->spp, img, dimg, WH * 3, h->d_counters, own);
             HIP_TRY(hipGetLastError());
+            gated = true;
         }
     }
 #define PSDR_LAUNCH_CAMERA_T(INTEG, NOTREE)                                                                                        \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_camera<G, R, INTEG, FL, NOTREE>), dim3(launch_blocks(h, n, camera_blocks_per_cu(h, n))), dim3(kBlock), lds_bytes(cx, h), s, cx, tv, o->spp, \
-                       o->spp_begin, nsp, n, 1.f / (float) o->spp, img, dimg, WH * 3, h->d_counters, 0ll, ProbeView{nullptr, nullptr})
+                       o->spp_begin, nsp, n, 1.f / (float) o->spp, img, dimg, WH * 3, h->d_counters, 0ll, ProbeView{nullptr, nullptr}, own)
 #define PSDR_LAUNCH_CAMERA(INTEG) PSDR_LAUNCH_CAMERA_T(INTEG, ((FL & kSceneTiny) != 0))
     // scenes without a tree are served by their own flag sets (kSceneTiny): occupancy follows from FL alone
     switch (o->integrator) {
@@ -1747,6 +1765,9 @@ int run_camera(psdr_scene_s *h, const psdr_render_opts *o, const TV<R, FL> &tv, 
 #undef PSDR_LAUNCH_CAMERA
 #undef PSDR_LAUNCH_CAMERA_T
     HIP_TRY(hipGetLastError());
+    // the gate word belongs to THIS kernel pair: closed again behind it, so that a later launch of a dual-number instance in the same call (another chunk, another
+    // tangent group) is not silenced by it
+    if (gated) HIP_TRY(hipMemsetAsync(h->d_counters + kLogdGateWord, 0, sizeof(unsigned long long), s));
     return 0;
 }
 
@@ -1776,9 +1797,10 @@ int run_camera_wavefront(psdr_scene_s *h, const psdr_render_opts *o, const TV<M,
     // chunk of the traced wavefront: 2^26 slots (240 B of workspace per slot: 16 GB of the 288) -- the stage kernels are persistent and pay their
     // ramp-up and tail once per launch; the C4 shard (2^26 slots) as ONE chunk 14.3 -> 14.1 ms of kernel time, and every smaller chunk is slower
     // still (2^24: 15.0, 2^22: 19.7, 2^20: 34.4 -- the streams staying inside the 256 MB last-level cache buys nothing; profiles/r04_chunk_sweep.txt)
-    const long long cap = std::min(n, binned ? launch_chunk(h, 24) : launch_chunk(h, traced ? 26 : 25));
     const int depth = o->max_depth;
     const size_t words = 8 + 6 * (1 + K) + (traced ? 8 : 0);          // traced: + the two hit rows of a record
+    // (a chunk that does not fit the device right now is halved until it does: fit_chunk; the records of a recording launch fix the chunk themselves)
+    const long long cap = rec ? n : std::min(n, fit_chunk(binned ? launch_chunk(h, 24) : launch_chunk(h, traced ? 26 : 25), 2 * words * 4 * 5 / 4 + (traced ? 80 : 0), 64u << 20, h->ws_bytes));
     // plain: block b appends to sub-stream b % kWfSub, at most ceil(blocks / kWfSub) * trips * kBlock records each.
     // binned: the records of chunk c go to group c % kWfGroups of their class; a class can take all of a group
     // grid of the traced wavefront's stage kernels: 16 workgroups per CU, up to 40 where a workgroup still makes >= 8 trips of its grid-stride loop (finer
@@ -1899,9 +1921,9 @@ int run_camera_wavefront_geo(psdr_scene_s *h, const psdr_render_opts *o, const T
     const int nsp = o->spp_end - o->spp_begin;
     if (o->spp <= 0 || nsp <= 0) return 0;
     const long long n = WH * nsp;
-    const long long cap = std::min(n, launch_chunk(h, 26));
     const int depth = o->max_depth;
     const size_t words = 8 + 6 * (1 + K) + 3 * K + 8;             // record + the tangents of the position behind it + the two hit rows
+    const long long cap = std::min(n, fit_chunk(launch_chunk(h, 26), 2 * words * 4 * 5 / 4 + 80, 64u << 20, h->ws_bytes));
     const auto wf_per_cu = [&](long long slots) { return big_launch_per_cu(h, slots); };
     const long long max_blocks = ((long long) launch_blocks(h, cap, wf_per_cu(cap)) + kWfSub - 1) / kWfSub * kWfSub;
     const long long cap_alloc = ((cap + max_blocks * kBlock) + 63) / 64 * 64;
@@ -2116,7 +2138,7 @@ int render_rev_impl(psdr_scene_s *h, const psdr_render_opts *o, const float *adj
     if (value_only) {
         const long long nv = WH * (o->spp_end - o->spp_begin);
         if (o->integrator != PSDR_INTEGRATOR_PATH || o->max_depth > kMaxRevDepth || o->max_depth < 1 || h->opt.rev_split == 0 || o->spp <= 0 || nv <= 0 ||
-            nv > launch_chunk(h, 26)) return 1;
+            nv > launch_chunk(h, 26) || nv > fit_chunk(std::max(nv, 1ll << 18), (size_t) (kRevDiskHead + kRevDiskPerVertex * o->max_depth) * 4, 64u << 20, h->rev_bytes)) return 1;
     }
     if (out_img) HIP_TRY(hipMemsetAsync(out_img, 0, sizeof(float) * WH * 3, s));
     DeviceSink<FL> sink{}; sink.g = *grads; sink.L = make_sink_layout(h, grads);
@@ -2214,9 +2236,11 @@ int render_rev_impl(psdr_scene_s *h, const psdr_render_opts *o, const float *adj
         if (split) {
             // records of one chunk of slots live in a scratch buffer (2 + 5 depth words per slot; 2 + 8 depth from the wavefront); chunks bound its size
             const int words = kRevDiskHead + (wf_value ? kRevDiskPerVertexCf : kRevDiskPerVertex) * depth;
+            // (kept records of exactly this launch on the handle: the buffer exists and holds them -- no sizing against the free memory)
+            const bool reuse_possible = h->kept.valid && h->kept.gen == h->tables_gen && h->kept.n == n && (size_t) n * words * sizeof(float) <= h->rev_bytes;
             // 2^26 slots per chunk (104 B of records per slot with the wavefront's cf format: 7 GB): the C4 shard's PathTracer(3) reverse as ONE chunk
             // 36.5 -> 35.7 ms of kernel time against four of 2^24 (its value sweep is the traced wavefront; profiles/r04_chunk_sweep.txt)
-            const long long chunk = std::min<long long>(n, launch_chunk(h, 26));
+            const long long chunk = std::min<long long>(n, reuse_possible ? launch_chunk(h, 26) : fit_chunk(launch_chunk(h, 26), (size_t) words * 4 + (wf_value ? 240 : 0), 128u << 20, h->rev_bytes + h->ws_bytes));
             const size_t need = (size_t) chunk * words * sizeof(float);
             if (need > h->rev_bytes) h->kept.valid = false;          // the buffer is about to be replaced
             if (int rc = scratch_reserve(&h->d_rev, &h->rev_bytes, need, s, "per-path records of the split reverse launch")) return rc;
@@ -2249,6 +2273,9 @@ int render_rev_impl(psdr_scene_s *h, const psdr_render_opts *o, const float *adj
                     PSDR_LAUNCH_REV_K(true, PSDR_INTEGRATOR_DIRECT, 2, cx2, dyn_bytes, c0, nc, (float *) nullptr, disk, chunk);
                 }
             }
+            // kept records are ONE-SHOT: the reverse call that consumed them clears them (a caller who rewrites tables in place under an unchanged descriptor and a
+            // repeated rng_offset must not meet the records of the old tables: ADVICE r5); the Python surface renders a recording primal before every backward
+            h->kept.valid = false;
         } else if (direct_probe) {
             if constexpr ((FL & kSceneForest) != 0) {
                 // DirectIntegrator(1, 1), one kernel, on a two-level scene: probe pass -> dense trace kernel -> the reverse kernel on primitives + hit rows
@@ -2384,8 +2411,12 @@ int render_c_launch(psdr_scene_s *h, const psdr_render_opts *o, float *out_img, 
     if constexpr ((FL & kSceneForest) != 0) {
         // PSDR_FLAG_KEEP_RECORDS: this render IS the value sweep of the reverse launch that follows (render_rev: wf_value) -- recording stages, records kept
         const long long n = (long long) h->desc.width * h->desc.height * (o->spp_end - o->spp_begin);
-        if ((o->flags & PSDR_FLAG_KEEP_RECORDS) != 0 && h->opt.keep_records != 0 && o->spp > 0 && n > 0 && n <= launch_chunk(h, 26) && rev_value_sweep_is_wavefront<FL>(h, o, n)) {
-            const int depth = std::min(o->max_depth, kMaxRevDepthDeep);
+        // (records + streams of the whole launch must fit the device NOW -- 104 + ~230 bytes per slot; otherwise the plain render below, and the reverse call runs its own,
+        // chunked value sweep: no failure for want of memory)
+        const int depth_k = std::min(o->max_depth, kMaxRevDepthDeep);
+        if ((o->flags & PSDR_FLAG_KEEP_RECORDS) != 0 && h->opt.keep_records != 0 && o->spp > 0 && n > 0 && n <= launch_chunk(h, 26) && rev_value_sweep_is_wavefront<FL>(h, o, n) &&
+            n <= fit_chunk(std::max(n, 1ll << 18), (size_t) rev_record_words(h, depth_k, true) * 4 + 240, 128u << 20, h->rev_bytes + h->ws_bytes)) {
+            const int depth = depth_k;
             const size_t need = (size_t) n * rev_record_words(h, depth, true) * sizeof(float);
             h->kept.valid = false;
             if (int rc = scratch_reserve(&h->d_rev, &h->rev_bytes, need, s, "per-path records of the split reverse launch")) return rc;

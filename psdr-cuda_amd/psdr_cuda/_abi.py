@@ -162,7 +162,7 @@ def scene_stats(handle):
     lib = load_hip()
     out = (C.c_int32 * 8)()
     check(lib, lib.psdr_scene_info(handle, out))
-    return {"n_tiny": out[0], "n_blas": out[1], "n_inline": out[2], "leaf_tris": out[3], "device_built": out[4], "n_slab": out[5]}
+    return {"n_tiny": out[0], "n_blas": out[1], "n_inline": out[2], "leaf_tris": out[3], "device_built": out[4], "n_slab": out[5], "occ_rows": out[6], "occ_max_rows": out[7]}
 
 
 def make_opts(integrator=INTEGRATOR_DIRECT, bsdf_samples=1, light_samples=1, max_depth=1, hide_emitters=False,

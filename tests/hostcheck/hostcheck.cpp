@@ -57,6 +57,19 @@ int hostcheck_trace(const psdr_scene_desc *d, int m, const float *o, const float
     return 0;
 }
 
+// the same search restricted to the rows a per-ray mask names (closest_hit MASKED: what the light rays of a scene without a tree run with SceneView::occ)
+int hostcheck_trace_rows(const psdr_scene_desc *d, int m, const float *o, const float *dir, const uint32_t *rows, int *tri, float *u, float *v, float *t) {
+    HostScene hs;
+    if (!setup(hs, d)) return 1;
+    if (hs.sc.n_tiny <= 0) return 2;
+    TraversalStack st;
+    for (int i = 0; i < m; ++i) {
+        Hit h = closest_hit<false, 2, true>(hs.sc, st, Vec3f{o[3 * i], o[3 * i + 1], o[3 * i + 2]}, Vec3f{dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]}, INFINITY, -1, -1, 0, rows[i]);
+        tri[i] = h.tri; u[i] = h.u; v[i] = h.v; t[i] = h.t;
+    }
+    return 0;
+}
+
 // rows in use and slab-form slots per axis of a tiny scene's primitive list (tiny_plane_form)
 int hostcheck_tiny_layout(const psdr_scene_desc *d, int *out) {
     HostScene hs;

@@ -46,7 +46,17 @@ def scene_file(name, tmp_dir):
     d = os.path.join(str(tmp_dir), "data", "scenes")
     os.makedirs(d, exist_ok=True)
     dst = os.path.join(d, name)
-    text = text.replace("bunny/bunny.obj", "bunny/bunny_low.obj")
+    # bunny.obj is the unit-size bunny the files scale by 35-40; bunny_low.obj comes at ~39x that size (psdr-cuda_amd/data/scenes/cbox_bunny.xml places it with
+    # scale 0.9 where the reference's cbox_bunny.xml has 35): the shape's <scale> is divided by 35 / 0.9, nothing else of the file changes
+    import re
+
+    def fix_shape(m):
+        blk = m.group(0)
+        if "bunny/bunny.obj" not in blk:
+            return blk
+        blk = blk.replace("bunny/bunny.obj", "bunny/bunny_low.obj")
+        return re.sub(r'(<scale[^>]*?)((?:\s+[xyz]\s*=\s*"[^"]*")+)', lambda s_: s_.group(1) + re.sub(r'"([^"]*)"', lambda v: '"%.6g"' % (float(v.group(1)) * 0.9 / 35.0), s_.group(2)), blk)
+    text = re.sub(r"<shape.*?</shape>", fix_shape, text, flags=re.S)
     for sub in ("./data/objects/cbox/", "./data/objects/tree/"):          # the copy lives elsewhere: the reference's own object files by absolute path
         text = text.replace(sub, os.path.join(REFDATA, "objects", sub.rstrip("/").split("/")[-1]) + "/")
     open(dst, "w").write(text)

@@ -46,6 +46,15 @@ elif case in ("c2ra", "c2rt", "c2keep"):
     # C2 (cbox 512^2 spp 64, no tree) PathTracer(3) reverse: every gradient table / the texels only
     sc, _ = load_scene("cbox", res=512, spp=64)
     o = _abi.make_opts(spp=64, integrator=_abi.INTEGRATOR_PATH, max_depth=3, flags=flags); n = 512 * 512 * 64
+elif case in ("blp", "blpr"):
+    # bunny_light 512^2 spp 128, PathTracer(3): renderC / reverse (rows + texels)
+    sc, _ = load_scene("bunny_light", res=512, spp=128)
+    o = _abi.make_opts(spp=128, integrator=_abi.INTEGRATOR_PATH, max_depth=3, flags=flags); n = 512 * 512 * 128
+elif case in ("blr", "blf", "blc"):
+    # BASELINE configs[2] as worded: bunny_light 512^2 spp = sppe = sppse = 128, DirectIntegrator(1,1): reverse (all tables) / forward K = 1 (a translation of Mesh[0]) / renderC
+    from helpers import tangents_wrt
+    sc, P = load_scene("bunny_light", res=512, spp=128, sppe=128, sppse=128, translate=(0, (1.0, 0.0, 0.0)))
+    o = _abi.make_opts(spp=128, sppe=128, sppse=128) if case != "blc" else _abi.make_opts(spp=128); n = 512 * 512 * 128 * (1 if case == "blc" else 3)
 elif case in ("c3f", "c3r", "c4r3"):
     # the three-term DirectIntegrator workloads: C3 forward (K = 1, a translation of the bunny) / reverse at 512^2 spp 16; C4 shard reverse
     from helpers import tangents_wrt
@@ -59,13 +68,13 @@ else:
     o = _abi.make_opts(spp=64, integrator=_abi.INTEGRATOR_PATH, max_depth=3, flags=flags); n = 256 * 256 * 64
 tb = sc.tables(0)
 g = GpuScene(tb)
-if case in ("c3f", "c4fg", "c5fg"):
+if case in ("c3f", "c4fg", "c5fg", "blf"):
     tan = tangents_wrt(tb, P)
     run = lambda: g.render_d_fwd(o, [tan])
-elif case in ("c3r", "c4r3"):
+elif case in ("c3r", "c4r3", "blr"):
     adj = np.random.default_rng(0).random((tb["width"] * tb["height"], 3)).astype(np.float32)
     run = lambda: g.render_d_rev(o, adj, with_image=False)
-elif case in ("c4pr", "c5pr"):
+elif case in ("c4pr", "c5pr", "blpr"):
     adj = np.random.default_rng(0).random((tb["width"] * tb["height"], 3)).astype(np.float32)
     run = lambda: g.render_d_rev(o, adj, want=["tri_info", "texels"], with_image=False)
 elif case in ("c2ra", "c2rt"):
