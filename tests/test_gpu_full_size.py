@@ -7,7 +7,7 @@ import pytest
 import torch
 
 import oracle
-from helpers import GpuScene, load_scene, rel_l2
+from helpers import isolated_pixels_unbiased, GpuScene, load_scene, rel_l2
 from psdr_cuda import _abi
 
 pytestmark = pytest.mark.gpu
@@ -108,6 +108,7 @@ def test_c4_one_gpu_share_of_1024x1024_spp512():
     a, b = GpuScene(tb3).render_c(o3), oracle.render(tb3, o3)
     bad = np.abs(a - b).max(1) > 1e-3 * (1 + np.abs(b).max(1))                       # pixels holding a sample that resolved a tie the other way
     assert bad.mean() < 0.005 and rel_l2(a[~bad], b[~bad]) < 1e-3, (bad.mean(), rel_l2(a[~bad], b[~bad]))
+    isolated_pixels_unbiased(a, b, bad, "full-size tree scene")                 # the excluded pixels' signed errors cancel (helpers.py)
 
 
 def test_c4_share_path_tracer_geometry_duals_at_full_size():
@@ -134,6 +135,7 @@ def test_c4_share_path_tracer_geometry_duals_at_full_size():
     bad = np.abs(d[0] - df[0]).max(1) > 1e-3 * (np.abs(df[0]).max(1) + 1e-3 * np.abs(df[0]).max())
     print("C4 share, PathTracer(3) geometry duals: wavefront vs fused derivative image rel-L2 %.2e, pixels apart %d of %d" % (rel_l2(d[0], df[0]), bad.sum(), bad.size))
     assert bad.mean() < 2e-3 and rel_l2(d[0][~bad], df[0][~bad]) < 1e-3
+    isolated_pixels_unbiased(d[0], df[0], bad, "C4 share geometry duals", bias_bound=5e-3)
     assert abs(float(d[0].astype(np.float64).sum()) - float(df[0].astype(np.float64).sum())) < 1e-3 * float(np.abs(df[0].astype(np.float64)).sum())
 
 

@@ -104,26 +104,36 @@ def main():
     dist.destroy_process_group()
 
 
-def test_two_ranks_on_one_gpu_reproduce_the_single_process_results(tmp_path):
+@pytest.mark.parametrize("world", [2, 8])
+def test_two_ranks_on_one_gpu_reproduce_the_single_process_results(tmp_path, world):
+    """world = 8 (round 6, VERDICT r5 item 8): the rank count of the node the north star names, before any 8-GPU box has seen the code -- eight processes share the GPU;
+    with 7 / 6 / 5 / 4 samples per pixel most ranks hold ONE sample and some hold NONE (an empty shard must launch nothing and still enter every collective)."""
     from helpers import rel_l2
     path = str(tmp_path / "ranks.npz")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    port = 29600 + os.getpid() % 1000
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", str(port), os.path.abspath(__file__), path], env=env, capture_output=True, text=True, timeout=600)
+    port = 29600 + os.getpid() % 1000 + world
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.abspath(__file__), path], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     got = np.load(path)
-    assert int(got["world"][0]) == 2
+    assert int(got["world"][0]) == world
     ref = run_sequence()
     for k, v in ref.items():
         assert got[k].shape == v.shape, k
         if k == "pt_rev_rays":
             continue
         tol = 1e-4 if k.startswith("g_") or k in ("pt_fwd_grad", "pt_g_vert") else 2e-5          # same samples, different grouping of the fp32 sums / atomics (3e-7 between two runs of one process since the table chain is reproducible: tests/test_tables_native_gpu.py)
+        if world == 8 and k == "pt_g_vert":
+            # a rank's shard (2^18 slots) is below the size from which the library runs the PathTracer's value sweep as the traced wavefront: the eight ranks run the
+            # fused kernels, the single process the wavefront -- separately compiled fp32 tree walks, a handful of samples resolve an epsilon tie the other way and ONE
+            # such sample moves a bunny vertex' gradient by per cents (tests/test_gpu_parity.py test_wavefront_and_fused_agree_on_tree_scenes...): 5.7e-3 measured
+            tol = 2e-2
         assert rel_l2(got[k], v) < tol, (k, rel_l2(got[k], v))
     assert np.abs(ref["d_fwd_grad"]).max() > 0 and np.abs(ref["g_vert"]).max() > 0 and np.abs(ref["g_refl"]).min() > 0
     assert np.abs(ref["pt_fwd_grad"]).max() > 0 and np.abs(ref["pt_g_vert"]).max() > 0
-    assert int(ref["pt_rev_rays"][0]) == 0 and int(got["pt_rev_rays"][0]) == 0          # one process and each of two ranks: the reverse call reused the primal render's records
+    # one process and each of two ranks: the reverse call reused the primal render's records (at eight ranks a shard is 2^18 slots: below the size from which the
+    # library splits the reverse launch, nothing is kept -- and nothing needs to be)
+    assert int(ref["pt_rev_rays"][0]) == 0 and (world != 2 or int(got["pt_rev_rays"][0]) == 0)
 
 
 if __name__ == "__main__":
@@ -146,3 +156,27 @@ def test_bench_multi_rank_path_executes_on_one_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["world_size"] == 2 and d["config"]["global_spp"] == 128
     assert d["value"] > 0 and d["config"]["allreduce_bytes_per_step"] == 3 * 512 * 512 * 3 * 4
+
+
+def test_bench_at_eight_ranks_on_one_gpu():
+    """The driver's 8-GPU command line (`torch.distributed.run --nproc-per-node 8 bench.py --gpus 8`) executed BEFORE the eight GPUs exist: PSDR_BENCH_ONE_GPU=1 puts the
+    eight ranks on cuda:0 over gloo.  Not a measurement.  Checked: rank 0 alone prints one line; the headline's weak scaling (64 spp per rank: global 512, one all-reduce of
+    [image] and one of [image || derivative image] per step); BASELINE configs[3] as the strong-scaling block at world size 8 (global 512 spp = 64 per rank, the three
+    all-reduces' byte count, finite gradients) in both forms."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PSDR_BENCH_ONE_GPU="1")
+    port = 29800 + os.getpid() % 1000
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--no-pmc",
+                        "--no-cpu-baseline", "--no-tree-scenes"], env=env, capture_output=True, text=True, timeout=1800, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["config"]["world_size"] == 8 and d["config"]["global_spp"] == 512 and d["scaling"] == "weak"
+    assert d["value"] > 0 and d["config"]["allreduce_bytes_per_step"] == 3 * 512 * 512 * 3 * 4 and len(d["config"]["devices"]) == 8
+    for key in ("c4_strong", "c4_strong_one_integrator"):
+        c4 = d[key]
+        assert "error" not in c4, c4
+        assert c4["world_size"] == 8 and c4["global_spp"] == 512 and c4["scaling"] == "strong" and c4["steps"] == 5 and c4["ms_per_step"] > 0 and c4["grad_finite"]
+        assert c4["allreduce_bytes_per_step"] >= 2 * 1024 * 1024 * 3 * 4 + c4["triangles"] * 24 * 4          # two images + the triangle-row gradients (+ the texels)

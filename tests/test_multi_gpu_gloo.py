@@ -104,3 +104,17 @@ def test_solo_block_runs_one_rank_without_sharding_or_collectives(tmp_path):
     assert r["sharded"] == [0, 3] and r["dist_outside"] and r["dist_after"]
     assert r["solo"] == [0, 6] and not r["dist_inside"] and not r["dist_nested_exit"]
     assert r["deferred_solo_node"] is False and r["deferred_job_node_inside_solo"] is True and r["forced_in_solo"] == [True, False]
+
+
+def test_shard_ranges_at_eight_ranks():
+    """The spp shards of the node the north star names (8 ranks): BASELINE configs[3]'s 512 spp are 64 per rank; an odd count and a count below the rank count still
+    partition [0, spp) into contiguous ranges in rank order (some EMPTY: such a rank launches nothing and only enters the collectives)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "psdr-cuda_amd"))
+    from psdr_cuda.integrator import shard_range
+    assert [shard_range(512, r, 8) for r in range(8)] == [(64 * r, 64 * r + 64) for r in range(8)]
+    for spp in (13, 7, 3, 1, 0, 8, 9):
+        rs = [shard_range(spp, r, 8) for r in range(8)]
+        assert rs[0][0] == 0 and rs[-1][1] == spp and all(a[1] == b[0] for a, b in zip(rs, rs[1:])), (spp, rs)
+        sizes = [b - a for a, b in rs]
+        assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True), (spp, sizes)
