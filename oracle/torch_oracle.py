@@ -372,12 +372,156 @@ def concentric_disk(sx, sy):
     return r * torch.cos(phi), r * torch.sin(phi)
 
 
-def diffuse_eval(tb, its, wo, ad):
-    rec = tb["bsdf_rec"].long()[tb["mesh_bsdf"].long()[its.mesh].clamp(min=0)]
+# ------------------------------------------------------------------------------ BSDFs
+BSDF_DIFFUSE, BSDF_ROUGHCONDUCTOR = 0, 1
+SLOT_REFLECTANCE, SLOT_ALPHA_U, SLOT_ALPHA_V, SLOT_ETA, SLOT_K = range(5)
+
+
+def _rec(tb, its):
+    return tb["bsdf_rec"].long()[tb["mesh_bsdf"].long()[its.mesh].clamp(min=0)]
+
+
+def _tex(tb, rec, slot, ch, ad):
+    """Bitmap::eval of a CONSTANT (1 x 1) texture, bitmap.cpp:41-48: the texel itself (AD to it).  Larger bitmaps are not restated here."""
     tex = tb["texels"] if ad else tb["texels"].detach()
-    rho = tex[rec[:, 1].unsqueeze(-1) + torch.arange(3)]
+    return tex[rec[:, 1 + 3 * slot].unsqueeze(-1) + torch.arange(ch)]
+
+
+def _check_constant_textures(tb):
+    rec = tb["bsdf_rec"].long()
+    for r in rec:
+        slots = (SLOT_REFLECTANCE,) if int(r[0]) == BSDF_DIFFUSE else (SLOT_REFLECTANCE, SLOT_ALPHA_U, SLOT_ALPHA_V, SLOT_ETA, SLOT_K)
+        assert all(int(r[2 + 3 * sl]) == 1 and int(r[3 + 3 * sl]) == 1 for sl in slots), "the torch oracle restates constant textures only"
+    assert int(tb.get("env_emitter", -1)) < 0, "the torch oracle has no environment map"
+
+
+def safe_sqrt(x): return torch.sqrt(x.clamp(min=0))
+
+
+def diffuse_eval(tb, its, wo, ad):
+    """diffuse.cpp:25-39"""
+    rho = _tex(tb, _rec(tb, its), SLOT_REFLECTANCE, 3, ad)
     ok = (its.wi[:, 2].detach() > 0) & (wo[:, 2].detach() > 0)
     return torch.where(ok.unsqueeze(-1), rho * (wo[:, 2] / math.pi).unsqueeze(-1), torch.zeros_like(rho))
+
+
+def ggx_D(m, au, av):
+    """GGXDistribution::eval, ggx.cpp:15-33"""
+    r = 1.0 / (math.pi * au * av * ((m[:, 0] / au) ** 2 + (m[:, 1] / av) ** 2 + m[:, 2] ** 2) ** 2)
+    return torch.where((r * m[:, 2]).detach() > 1e-5, r, torch.zeros_like(r))
+
+
+def ggx_g1(v, m, au, av):
+    """GGXDistribution::smith_g1, ggx.cpp:77-91"""
+    xy = (au * v[:, 0]) ** 2 + (av * v[:, 1]) ** 2
+    r = 2.0 / (1.0 + torch.sqrt(1.0 + xy / v[:, 2] ** 2))
+    r = torch.where(xy.detach() == 0, torch.ones_like(r), r)
+    return torch.where((dot(v, m) * v[:, 2]).detach() <= 0, torch.zeros_like(r), r)
+
+
+def ggx_visible_11(c, sx, sy):
+    """GGXDistribution::sample_visible_11, ggx.cpp:94-104"""
+    px, py = concentric_disk(sx, sy)
+    s = 0.5 * (1.0 + c)
+    a = safe_sqrt(1.0 - px * px)
+    py = a + (py - a) * s                                   # lerp(a, py, s)
+    z = safe_sqrt(1.0 - px * px - py * py)
+    sn = safe_sqrt(1.0 - c * c)
+    norm = 1.0 / (sn * py + c * z)
+    return (c * py - sn * z) * norm, px * norm
+
+
+def ggx_sample(wi, sx, sy, au, av):
+    """GGXDistribution::sample, ggx.cpp:37-74 (sin / cos of the azimuth: frame.h:100-116, guarded at sin^2 theta <= 4 Epsilon)"""
+    wp = normalize(torch.stack([au * wi[:, 0], av * wi[:, 1], wi[:, 2]], -1))
+    st2 = 1.0 - wp[:, 2] ** 2
+    small = st2.detach().abs() <= 4.0 * EPS
+    inv = 1.0 / torch.sqrt(torch.where(small, torch.ones_like(st2), st2))
+    sinp = torch.where(small, torch.zeros_like(st2), (wp[:, 1] * inv).clamp(-1.0, 1.0))
+    cosp = torch.where(small, torch.ones_like(st2), (wp[:, 0] * inv).clamp(-1.0, 1.0))
+    slx, sly = ggx_visible_11(wp[:, 2], sx, sy)
+    slx, sly = (cosp * slx - sinp * sly) * au, (sinp * slx + cosp * sly) * av
+    return normalize(torch.stack([-slx, -sly, torch.ones_like(slx)], -1))
+
+
+def fresnel_conductor(eta, k, c):
+    """fresnel<ad>(eta_r, eta_i, cos_theta_i), utils.h:148-164; eta, k [n, 3], c [n]"""
+    c = c.unsqueeze(-1)
+    c2 = c * c
+    s2 = 1.0 - c2
+    s4 = s2 * s2
+    t1 = eta * eta - k * k - s2
+    a2pb2 = safe_sqrt(t1 * t1 + 4.0 * (k * eta) ** 2)
+    a = safe_sqrt(0.5 * (a2pb2 + t1))
+    T1, T2 = a2pb2 + c2, 2.0 * c * a
+    rs = (T1 - T2) / (T1 + T2)
+    T3, T4 = a2pb2 * c2 + s4, T2 * s2
+    rp = rs * (T3 - T4) / (T3 + T4)
+    return 0.5 * (rs + rp)
+
+
+def _alphas(tb, rec, ad):
+    rough = rec[:, 0] == BSDF_ROUGHCONDUCTOR
+    au, av = _tex(tb, rec, SLOT_ALPHA_U, 1, ad)[:, 0], _tex(tb, rec, SLOT_ALPHA_V, 1, ad)[:, 0]
+    one = torch.ones(len(rec), dtype=F64)
+    return torch.where(rough, au, one), torch.where(rough, av, one), rough          # (other lanes: a harmless alpha; their results are never selected)
+
+
+def rough_eval(tb, its, wo, ad):
+    """RoughConductor::__eval, roughconductor.cpp:40-57 (the value includes cos theta_o)"""
+    rec = _rec(tb, its)
+    au, av, _ = _alphas(tb, rec, ad)
+    ci, co = its.wi[:, 2], wo[:, 2]
+    ok = (ci.detach() > 0) & (co.detach() > 0)
+    Hh = normalize(wo + its.wi)
+    D = ggx_D(Hh, au, av)
+    ok = ok & (D.detach() != 0)
+    G = ggx_g1(its.wi, Hh, au, av) * ggx_g1(wo, Hh, au, av)
+    res = D * G / (4.0 * ci)
+    F = fresnel_conductor(_tex(tb, rec, SLOT_ETA, 3, ad), _tex(tb, rec, SLOT_K, 3, ad), dot(its.wi, Hh))
+    val = F * res.unsqueeze(-1) * _tex(tb, rec, SLOT_REFLECTANCE, 3, ad)
+    return torch.where(ok.unsqueeze(-1), val, torch.zeros_like(val))
+
+
+def rough_pdf(tb, its, wo, ad):
+    """RoughConductor::__pdf, roughconductor.cpp:61-76: the mask is computed there and NOT applied"""
+    rec = _rec(tb, its)
+    au, av, _ = _alphas(tb, rec, ad)
+    m = normalize(wo + its.wi)
+    return ggx_D(m, au, av) * ggx_g1(its.wi, m, au, av) / (4.0 * its.wi[:, 2])
+
+
+def bsdf_sample(tb, its, s, active, ad):
+    """Diffuse::__sample (diffuse.cpp:42-57: the LAST two of the three numbers) / RoughConductor::__sample (roughconductor.cpp:79-92: the first two).
+    Returns the local direction, its pdf (keeps the derivative w.r.t. wi / alpha in D mode, as bs.pdf does) and the validity mask."""
+    rec = _rec(tb, its)
+    px, py = concentric_disk(s[1], s[2])
+    wz = safe_sqrt(1.0 - px * px - py * py)
+    wo_d = torch.stack([px, py, wz], -1)
+    pdf_d = wz / math.pi
+    ok_d = active & (its.wi[:, 2].detach() > 0)
+    au, av, rough = _alphas(tb, rec, ad)
+    if not bool(rough.any()):
+        return wo_d, pdf_d, ok_d
+    m = ggx_sample(its.wi, s[0], s[1], au, av)
+    wo_r = m * (2.0 * dot(its.wi, m)).unsqueeze(-1) - its.wi
+    pdf_r = rough_pdf(tb, its, wo_r, ad)
+    ok_r = active & (its.wi[:, 2].detach() > 0) & (pdf_r.detach() != 0) & (wo_r[:, 2].detach() > 0)
+    return torch.where(rough.unsqueeze(-1), wo_r, wo_d), torch.where(rough, pdf_r, pdf_d), torch.where(rough, ok_r, ok_d)
+
+
+def bsdf_eval(tb, its, wo, ad):
+    rough = _rec(tb, its)[:, 0] == BSDF_ROUGHCONDUCTOR
+    d = diffuse_eval(tb, its, wo, ad)
+    return torch.where(rough.unsqueeze(-1), rough_eval(tb, its, wo, ad), d) if bool(rough.any()) else d
+
+
+def bsdf_pdf(tb, its, wo, ad):
+    """Diffuse::__pdf from DETACHED cosines under its mask (diffuse.cpp:70-81); RoughConductor::__pdf"""
+    rough = _rec(tb, its)[:, 0] == BSDF_ROUGHCONDUCTOR
+    ok = (its.wi[:, 2].detach() > 0) & (wo[:, 2].detach() > 0)
+    d = torch.where(ok, wo[:, 2].detach() / math.pi, torch.zeros_like(wo[:, 2].detach()))
+    return torch.where(rough, rough_pdf(tb, its, wo, ad), d) if bool(rough.any()) else d
 
 
 def sample_emitter_position(tb, u0, u1, ad):
@@ -407,33 +551,30 @@ def Le(tb, its, ad):
     return torch.where(ok.unsqueeze(-1), r, torch.zeros_like(r))
 
 
-def Li(tb, rng, o, d, active, ad, B=1, L=1):
-    """DirectIntegrator::__Li, direct.cpp:47-163 (diffuse BSDFs, one area light)."""
-    its = intersect(tb, o, d, active, "solid" if ad else "C")
-    active = active & its.valid
-    result = Le(tb, its, ad)
+def direct_step(tb, rng, its, active, ad, B, L):
+    """The two loops of DirectIntegrator::__Li at the vertex `its` (direct.cpp:64-160).  Returns the gathered radiance and, of the FIRST BSDF sample, the vertex
+    it found, its throughput (already divided by the pdf) and whether it found one -- what the PathTracer continues with."""
+    result = torch.zeros(len(active), 3, dtype=F64)
     mode1 = "path" if ad else "C"
     ef = tb["emitter_f"]
-    for _ in range(B):
+    nxt = None
+    for i in range(B):
         s = [rng.next(), rng.next(), rng.next()]
-        px, py = concentric_disk(s[1], s[2])
-        wz = torch.sqrt((1.0 - px * px - py * py).clamp(min=0))
-        pdf_s = wz / math.pi
-        a1 = active & (its.wi[:, 2].detach() > 0)
-        dir1 = its.sh_s.detach() * px.unsqueeze(-1) + its.sh_t.detach() * py.unsqueeze(-1) + its.sh_n.detach() * wz.unsqueeze(-1)
+        wo_s, pdf_s, a1 = bsdf_sample(tb, its, s, active, ad)
+        wd = wo_s.detach()
+        dir1 = its.sh_s.detach() * wd[:, 0:1] + its.sh_t.detach() * wd[:, 1:2] + its.sh_n.detach() * wd[:, 2:3]
         its1 = intersect(tb, its.p, dir1, a1, mode1)
         a_hit = a1 & its1.valid
         a1 = a_hit & (its1.emitter >= 0)
         if ad:
             wo = (its1.p - its.p) / its1.t.unsqueeze(-1)
             wl = torch.stack([dot(wo, its.sh_s), dot(wo, its.sh_t), dot(wo, its.sh_n)], -1)
-            f = diffuse_eval(tb, its, wl, True)
+            f = bsdf_eval(tb, its, wl, True)
             G = dot(its1.n, -wo).abs() / its1.t ** 2
             pdf0 = pdf_s * G.detach()
             f = f * (G * its1.J / pdf0).unsqueeze(-1)
         else:
-            wl = torch.stack([px, py, wz], -1)
-            f = diffuse_eval(tb, its, wl, False)
+            f = bsdf_eval(tb, its, wd, False)
             G = dot(its1.n, -dir1).abs() / its1.t ** 2
             pdf0 = pdf_s * G
             f = f / pdf_s.unsqueeze(-1)
@@ -443,6 +584,8 @@ def Li(tb, rng, o, d, active, ad, B=1, L=1):
             w = w * pdf0 ** 2 / (pdf0 ** 2 + pe ** 2)
         c = Le(tb, its1, ad) * f * w.unsqueeze(-1)
         result = result + torch.where(a1.unsqueeze(-1), c, torch.zeros_like(c))
+        if i == 0:
+            nxt = (its1, torch.where(a_hit.unsqueeze(-1), f, torch.zeros_like(f)), a_hit)
     for _ in range(L):
         s0, s1 = rng.next(), rng.next()
         p, n, ppdf, J = sample_emitter_position(tb, s0, s1, ad)
@@ -454,14 +597,33 @@ def Li(tb, rng, o, d, active, ad, B=1, L=1):
         a1 = active & its1.valid & (its1.t.detach() > dist.detach() - SHADOW_EPS) & (its1.emitter >= 0)
         G = dot(its1.n, -wo).abs() / d2
         wl = torch.stack([dot(wo, its.sh_s), dot(wo, its.sh_t), dot(wo, its.sh_n)], -1)
-        f = diffuse_eval(tb, its, wl, ad) * (G * J / ppdf).unsqueeze(-1)
-        ok = (its.wi[:, 2].detach() > 0) & (wl[:, 2].detach() > 0)
-        pdf1 = torch.where(ok, wl[:, 2].detach() / math.pi, torch.zeros_like(d2)) * (G.detach() if ad else G)
+        f = bsdf_eval(tb, its, wl, ad) * (G * J / ppdf).unsqueeze(-1)
+        pdf1 = bsdf_pdf(tb, its, wl, ad) * (G.detach() if ad else G)
         w = torch.full_like(d2, 1.0 / L)
         if B > 0:
             w = w * ppdf ** 2 / (ppdf ** 2 + pdf1 ** 2)
         c = Le(tb, its1, ad) * f * w.unsqueeze(-1)
         result = result + torch.where(a1.unsqueeze(-1), c, torch.zeros_like(c))
+    return result, nxt
+
+
+def Li(tb, rng, o, d, active, ad, B=1, L=1, depth=0):
+    """DirectIntegrator::__Li, direct.cpp:47-163 (depth = 0), or the PathTracer of SURVEY App. F (depth >= 1: the one-bounce step iterated from the vertex its first
+    BSDF sample found; PathTracer(1) == DirectIntegrator(1, 1) sample for sample).  Diffuse and rough-conductor BSDFs with constant textures, one area light."""
+    its = intersect(tb, o, d, active, "solid" if ad else "C")
+    active = active & its.valid
+    result = Le(tb, its, ad)
+    if depth <= 0:
+        c, _ = direct_step(tb, rng, its, active, ad, B, L)
+        return result + torch.where(active.unsqueeze(-1), c, torch.zeros_like(c))
+    beta = torch.ones(len(active), 3, dtype=F64)
+    for _ in range(depth):
+        c, (its1, f, a_hit) = direct_step(tb, rng, its, active, ad, 1, 1)
+        result = result + torch.where(active.unsqueeze(-1), beta * c, torch.zeros_like(c))
+        active = active & a_hit
+        beta = torch.where(active.unsqueeze(-1), beta * f, beta)
+        active = active & (beta.detach() != 0).any(-1)
+        its = its1
     return result
 
 
@@ -479,10 +641,11 @@ def zero_nonfinite(v):
     return torch.where(ok, v, torch.zeros_like(v))
 
 
-def render(tb, spp=1, sppe=0, sppse=0, B=1, L=1, ad=False, rng_offset=(0, 0, 0)):
+def render(tb, spp=1, sppe=0, sppse=0, B=1, L=1, ad=False, rng_offset=(0, 0, 0), depth=0):
     """renderC (ad=False: image) or renderD (ad=True: image whose forward-mode tangent is the derivative image),
     integrator.cpp:64-119 + direct.cpp:207-221."""
     W, H = tb["width"], tb["height"]
+    _check_constant_textures(tb)
     img = torch.zeros(W * H * 3, dtype=F64)
     if spp > 0:
         slots = np.arange(W * H * spp)
@@ -491,7 +654,7 @@ def render(tb, spp=1, sppe=0, sppse=0, B=1, L=1, ad=False, rng_offset=(0, 0, 0))
         j0, j1 = rng.next(), rng.next()
         sx, sy = ((pix % W) + j0) / W, ((pix // W) + j1) / H
         o, d = primary_ray(tb, sx, sy, ad)
-        v = zero_nonfinite(Li(tb, rng, o, d, torch.ones(len(slots), dtype=torch.bool), ad, B, L)) / spp
+        v = zero_nonfinite(Li(tb, rng, o, d, torch.ones(len(slots), dtype=torch.bool), ad, B, L, depth)) / spp
         img = img + torch.zeros(W * H, 3, dtype=F64).index_add(0, pix, v).reshape(-1)
     if ad and sppe > 0 and tb["num_prim_edges"] > 0:
         slots = np.arange(W * H * sppe)
@@ -508,7 +671,7 @@ def render(tb, spp=1, sppe=0, sppse=0, B=1, L=1, ad=False, rng_offset=(0, 0, 0))
         Ls = []
         for sg in (-EDGE_EPS, EDGE_EPS):                       # ray_n first, then ray_p (integrator.cpp:107-112)
             o, d = primary_ray(tb, pd[:, 0] + sg * nrm[:, 0], pd[:, 1] + sg * nrm[:, 1], False)
-            Ls.append(Li(tb, rng, o, d, valid, False, B, L))
+            Ls.append(Li(tb, rng, o, d, valid, False, B, L, depth))
         dL = (Ls[0] - Ls[1]) / pdf.unsqueeze(-1)
         val = zero_nonfinite(xdn.unsqueeze(-1) * dL) / sppe
         val = val - val.detach()
@@ -561,7 +724,7 @@ def render(tb, spp=1, sppe=0, sppse=0, B=1, L=1, ad=False, rng_offset=(0, 0, 0))
         valid = valid & (sinphi > EPS) & (sinphi2 > EPS)
         d0 = -cd.detach()
         d0l = torch.stack([dot(d0, its1c.sh_s), dot(d0, its1c.sh_t), dot(d0, its1c.sh_n)], -1)
-        f = diffuse_eval(tb, its1c, d0l, False)
+        f = bsdf_eval(tb, its1c, d0l, False)
         corr = ((its1c.wi[:, 2] * dot(d0, its1c.n)) / (d0l[:, 2] * dot(dirv, its1c.n))).abs()
         value0 = f * corr.unsqueeze(-1) * Le(tb, its2, False) * (base_v * sensor_val / bpdf).unsqueeze(-1)
         nn = normalize(torch.cross(bn, proj, dim=1))

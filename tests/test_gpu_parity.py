@@ -434,7 +434,7 @@ def test_excluded_pixels_are_single_flipped_samples():
     tb = sc.tables(0)
     g = GpuScene(tb)
     counts, signed, total_bad = [], np.zeros(3), 0
-    for off in range(8):
+    for off in range(12):
         kw = dict(integrator=_abi.INTEGRATOR_PATH, max_depth=3, spp=spp, rng_offset=(11 * off, 0, 0))
         a, ref = g.render_c(_abi.make_opts(**kw)), oracle.render(tb, _abi.make_opts(**kw))
         bad = np.abs(a - ref).max(1) > 1e-3 * (1 + np.abs(ref).max(1))

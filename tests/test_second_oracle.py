@@ -144,3 +144,60 @@ def test_gpu_reproduces_the_torch_fixtures(name):
     img, dimg = GpuScene(tb).render_d_fwd(_abi.make_opts(spp=spp, sppe=sppe, sppse=sppse), [tangents_wrt(tb, P)])
     print("%s: GPU vs torch-oracle fixture: image rel-L2 %.2e, derivative image rel-L2 %.2e" % (name, rel_l2(img, g["img"]), rel_l2(dimg[0], g["dimg"])))
     assert rel_l2(img, g["img"]) < 1e-4 and rel_l2(dimg[0], g["dimg"]) < 1e-3
+
+
+@pytest.mark.parametrize("scene,mesh", [("cbox_rough", 0), ("cbox", 1)])
+def test_second_oracle_covers_rough_conductors_and_the_path_tracer(scene, mesh):
+    """Round 6: GGX / RoughConductor (ggx.cpp:9-106, roughconductor.cpp:40-92, the conductor Fresnel term utils.h:148-164) and the PathTracer loop
+     restated a SECOND time, in torch, from the reference's sources -- no line shared with the C++ oracle or the product.  Both oracles in fp64 on the
+    product's fp32 tables: renderC, renderD w.r.t. EVERY texel (albedo, roughness, eta, k: a random tangent) and w.r.t. a mesh translation (interior term through the
+    rough BSDF's sampling pdf and Fresnel term; all three terms for the DirectIntegrator), DirectIntegrator(1,1) / (2,2) and PathTracer(3)."""
+    res, spp = 10, 2
+    sc, P = load_scene(scene, res=res, spp=spp, sppe=2, sppse=2, translate=(mesh, (1.0, 0.5, 0.25)))
+    tb = sc.tables(0)
+    geo = {k: v for k, v in tangents_wrt(tb, P).items() if v is not None}
+    tbc = {k: (v.detach().cpu() if isinstance(v, torch.Tensor) else v) for k, v in tb.items()}
+    g = torch.Generator().manual_seed(3)
+    tex = {"texels": torch.rand(tbc["texels"].shape, generator=g) - 0.3}
+    if scene == "cbox_rough":
+        assert int((tbc["bsdf_rec"][:, 0] == _abi.BSDF_ROUGHCONDUCTOR).sum()) >= 1
+    for name, kw_t, kw_c in (("direct11", dict(B=1, L=1), dict(bsdf_samples=1, light_samples=1)), ("direct22", dict(B=2, L=2), dict(bsdf_samples=2, light_samples=2)),
+                             ("path3", dict(depth=3), dict(integrator=_abi.INTEGRATOR_PATH, max_depth=3))):
+        img = to.render({k: (v.double() if isinstance(v, torch.Tensor) and v.dtype == torch.float32 else v) for k, v in tbc.items()}, spp=spp, **kw_t).reshape(-1, 3).numpy()
+        ref = oracle.render(tb, _abi.make_opts(spp=spp, **kw_c), precision=1, reference_form=True)
+        assert ref.mean() > 0.05 and rel_l2(img, ref) < 1e-6, (name, rel_l2(img, ref))
+        for what, tan, edges in (("texels", tex, False), ("geometry", geo, name != "path3")):
+            se = 2 if edges else 0
+            a_img, a_d = to.render_d_from_tables(tbc, {k: v.detach().cpu() for k, v in tan.items()}, spp=spp, sppe=se, sppse=se, **kw_t)
+            b_img, b_d = oracle.render(tb, _abi.make_opts(spp=spp, sppe=se, sppse=se, **kw_c), mode=1, tangents=tan, precision=1, reference_form=True)
+            assert np.abs(b_d).max() > 1e-4, (name, what)
+            assert rel_l2(a_img.numpy(), b_img) < 1e-6 and rel_l2(a_d.numpy(), b_d) < 2e-6, (name, what, rel_l2(a_img.numpy(), b_img), rel_l2(a_d.numpy(), b_d))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(mtg.TABLE_CASES))
+def test_gpu_reproduces_the_torch_fixtures_of_rough_conductors_and_the_path_tracer(name):
+    """tests/golden/torch_cbox_rough_*.npz: the torch oracle's renderer (GGX, conductor Fresnel, the PathTracer loop: its own restatement) on the product's tables, image
+    and derivative image w.r.t. every texel.  The HIP kernels through the C ABI against them: an oracle-independent anchor for the rough-conductor path and the
+    PathTracer, like the diffuse fixtures above."""
+    from helpers import GpuScene
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    scene, res, spp, _, kw_c = mtg.TABLE_CASES[name]
+    sc, _ = load_scene(scene, res=res, spp=spp)
+    tb = sc.tables(0)
+    _close(tb["texels"], g["texels"], 1e-7)
+    tan = {"texels": mtg.texel_tangent(tb["texels"].numel())}
+    img, dimg = GpuScene(tb).render_d_fwd(_abi.make_opts(spp=spp, **kw_c), [tan])
+    print("%s: GPU vs torch-oracle fixture: image rel-L2 %.2e, derivative image rel-L2 %.2e" % (name, rel_l2(img, g["img"]), rel_l2(dimg[0], g["dimg"])))
+    assert rel_l2(img, g["img"]) < 1e-4 and rel_l2(dimg[0], g["dimg"]) < 1e-3
+
+
+@pytest.mark.parametrize("name", list(mtg.TABLE_CASES))
+def test_cpp_oracle_reproduces_the_torch_fixtures_of_rough_conductors(name):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    scene, res, spp, _, kw_c = mtg.TABLE_CASES[name]
+    sc, _ = load_scene(scene, res=res, spp=spp)
+    tb = sc.tables(0)
+    _close(tb["texels"], g["texels"], 1e-7)
+    img, dimg = oracle.render(tb, _abi.make_opts(spp=spp, **kw_c), mode=1, tangents={"texels": mtg.texel_tangent(tb["texels"].numel())}, precision=1, reference_form=True)
+    assert rel_l2(img, g["img"]) < 1e-6 and rel_l2(dimg, g["dimg"]) < 2e-6, (rel_l2(img, g["img"]), rel_l2(dimg, g["dimg"]))
