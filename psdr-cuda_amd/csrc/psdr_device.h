@@ -1194,6 +1194,9 @@ PSDR_HD bool sample_direct(const SceneView &sc, const Vec3f &p, int &pixel, floa
 }
 
 // ------------------------------------------------------------------------ integrators
+#ifndef PSDR_SKIP_UNLIT
+#define PSDR_SKIP_UNLIT 1               // light samples whose BSDF value is zero by its cosine tests are not traced (0: traced anyway -- A/B builds)
+#endif
 #ifndef PSDR_OCC_ROWS
 #define PSDR_OCC_ROWS 1                 // kSceneTiny instances: light rays test the rows SceneView::occ names (0: every row -- A/B builds)
 #endif
@@ -1275,16 +1278,19 @@ PSDR_HD Vec3<M> direct_step(const SceneView &sc, const TVT &tv, TraversalStack &
         const G d2 = dot(wo, wo), dist = safe_sqrt(d2);
         wo = wo / dist;
         const RayT<G> ray1{its.p, wo};
+        // An emitter sample below the vertex' horizon, or a vertex seen from behind: both BSDFs evaluate to zero there (diffuse.cpp:28-31, roughconductor.cpp:43-45:
+        // cos theta_i > 0 and cos theta_o > 0), whatever the ray would find -- it is not traced (round 6; on a bunny half of the light samples).  Same value, fewer rays.
+        const Vec3<G> wl = its.sh.to_local(wo);
+        const bool lit = PSDR_SKIP_UNLIT ? (val(wl.z) > 0.f && val(its.wi.z) > 0.f) : true;
         // a scene without a tree: only the rows that can lie between this vertex' primitive and the sampled emitter triangle (SceneView::occ)
         auto trace_light = [&]() {
-            if constexpr (TVT::tiny && PSDR_OCC_ROWS) return intersect<G, TVT, true>(sc, tv, st, ray1, ps.valid, form, nrays, -1, -1, kPreLightRay, occ_rows(sc, its.tri, ps.tri));
-            else return intersect<G>(sc, tv, st, ray1, ps.valid, form, nrays, -1, -1, kPreLightRay);
+            if constexpr (TVT::tiny && PSDR_OCC_ROWS) return intersect<G, TVT, true>(sc, tv, st, ray1, ps.valid && lit, form, nrays, -1, -1, kPreLightRay, occ_rows(sc, its.tri, ps.tri));
+            else return intersect<G>(sc, tv, st, ray1, ps.valid && lit, form, nrays, -1, -1, kPreLightRay);
         };
         const Its<G> its1 = trace_light();
         if (light_tri && i == 0) *light_tri = its1.valid ? its1.tri : -1;          // the value sweep of a split reverse launch records it (psdr_reverse.h RevDisk)
         if (!(its1.valid && val(its1.t) > val(dist) - kShadowEpsilon && emitter_of(sc, tv, its1) >= 0)) return;
         const G Gv = abs_(dot(its1.n, -wo)) / d2;
-        const Vec3<G> wl = its.sh.to_local(wo);
         const Vec3<M> bsdf_val = bsdf.eval(sc, tv, its, wl, true) * to_m<M>(Gv * ps.J / ps.pdf);
         M pdf1 = bsdf.pdf(sc, tv, its, wl, true);
         if constexpr (ad) pdf1 = pdf1 * val(Gv); else pdf1 = pdf1 * Gv;

@@ -412,7 +412,8 @@ __device__ __forceinline__ int classify_next(const SceneView &sc, const TVT &, R
         Vec3f wo = ps.p - its.p;
         const float dist = sqrtf(fmaxf(dot(wo, wo), 0.f));
         wo = wo / dist;
-        if (enters(its.p, wo, TRACED ? INFINITY : dist)) cls |= 2;
+        const bool lit = PSDR_SKIP_UNLIT ? (its.sh.to_local(wo).z > 0.f && its.wi.z > 0.f) : true;          // direct_step does not trace an unlit light sample
+        if (lit && enters(its.p, wo, TRACED ? INFINITY : dist)) cls |= 2;
         if (TRACED) *d_light = wo;
     }
     return cls;

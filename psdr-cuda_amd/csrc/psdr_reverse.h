@@ -675,6 +675,8 @@ PSDR_HD VertexOut vertex_eval(Sink &sink, const SceneView &sc, TraversalStack &s
         const float d2 = dot(wov, wov), dist = sqrtf(fmaxf(d2, 0.f));
         const Vec3f wo = wov / dist;
         Hit h2;
+        // (direct_step: a light sample the BSDF's cosine tests zero is not traced -- recorded as a miss)
+        if (PSDR_SKIP_UNLIT && !(REPLAY && BACKWARD) && !(its.sh.to_local(wo).z > 0.f && its.wi.z > 0.f)) { if (REPLAY) rec.put_tri(k, 1, -1); return; }
         if (REPLAY && BACKWARD) h2.tri = rec.tri(k, 1);
         else {
             nrays++;

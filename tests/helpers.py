@@ -28,6 +28,13 @@ def rel_l2(a, b):
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
 
 
+def same_rays(a, b):
+    """Ray counters of two launch forms of the same samples.  Since round 6 a light sample the BSDF's cosine tests zero is not traced; whether cos theta is > 0 is decided
+    on a vertex each form reconstructs with its own fp32 arithmetic (the fused kernel from the ray, a wavefront stage from its stream record, the adjoint sweep from its path
+    record), so a handful of samples per million sit on the other side of zero: equal to 1e-4, not to the ray."""
+    return abs(int(a) - int(b)) <= 1e-4 * max(int(a), int(b), 1)
+
+
 def isolated_pixels_unbiased(a, ref, bad, label="", bias_bound=1e-3):
     """Tree-scene tests compare two fp32 evaluations of the same estimator on the same random numbers and EXCLUDE the isolated pixels where one sample resolved an
     epsilon-sized tie the other way (`bad`: boolean mask over pixels).  Excluding is only sound if those pixels are what that name says -- this is the net under the
