@@ -239,7 +239,8 @@ int psdr_scene_destroy(psdr_scene_t h);
    rev_split, sedge_split (1 / 0 force, -1 default rule); keep_records (0: PSDR_FLAG_KEEP_RECORDS is ignored); logd (0: PathTracer forward mode with tangents on
    diffuse albedo texels only runs the dual-number kernel, never the log-derivative one); rev_sorted (0: reverse PathTracer kernels
    scatter row adjoints on the spot); wf_geo (0: PathTracer geometry tangents through the fused kernel); tangent_live (0: no liveness mask); forest_min_inline (inline triangles a two-level tree needs at least, default 6); scratch_plain (1: scratch blocks of 64 MB and more come from hipMalloc instead of the stream-ordered pool -- process-wide, an experiment on TLB reach);
-   own_pixels (0: the camera kernels always add to the image with atomics, also where one wave holds all samples of a pixel); occ_rows (0: the light rays of a scene without a tree test every kernel-argument primitive instead of
+   own_pixels (0: the camera kernels always add to the image with atomics, also where one wave holds all samples of a pixel); emitter_pretest (0: BSDF-sampled rays whose hit matters only on an emitter -- DirectIntegrator, a PathTracer path's last vertex -- are traced without
+   first meeting the emitters' primitives); occ_rows (0: the light rays of a scene without a tree test every kernel-argument primitive instead of
    the ones that can lie between the path vertex and the emitter sample); probe (0: no probe / trace / final launches);
    trace_wg2 (dense trace kernel as two workgroups per CU: -1 by forest and launch size, 0 never, n > 0 always with stack columns of n entries);
    chunk_log2 (slots per chunk of the chunked launches, 0 = default); blocks_per_cu, camera_blocks, lds_budget, sink_rep, bvh_maxleaf (integers,

@@ -184,6 +184,23 @@ inline int tiny_plane_form(const std::vector<float4> &prims_in, float4 *rows, in
     return next;
 }
 
+// SceneView::emit_rows: the rows of the kernel-argument table (tiny_plane_form's meta: ids = two 16-bit triangle ids, 0xffff = none) that hold an emitter triangle --
+// or 0 when some emitter triangle is NOT among them (a mesh light inside a tree: the pre-test of direct_step then does not apply).  aa_cnt: slab slots in use per axis.
+inline uint32_t tiny_emitter_rows(const int32_t *meta, int n_rows, int32_t aa_cnt, const std::vector<char> &is_emitter_tri) {
+    const int cnt[3] = {aa_cnt & 255, (aa_cnt >> 8) & 255, aa_cnt >> 16};
+    size_t want = 0, found = 0;
+    for (char c : is_emitter_tri) want += c ? 1 : 0;
+    uint32_t rows = 0;
+    for (int i = 0; i < n_rows && i < 32; ++i) {
+        if (aa_cnt != 0 && i < kAaSlots && (i % kAaPerAxis) >= cnt[i / kAaPerAxis]) continue;          // an unused slab slot
+        const uint32_t ids = (uint32_t) meta[i * 4];
+        const uint32_t t[2] = {ids & 0xffffu, ids >> 16};
+        for (int a = 0; a < 2; ++a)
+            if (t[a] != 0xffffu && t[a] < is_emitter_tri.size() && is_emitter_tri[t[a]]) { rows |= 1u << i; found++; }
+    }
+    return (want > 0 && found == want) ? rows : 0u;
+}
+
 // Occluder rows of a scene without a tree (SceneView::occ, psdr_device.h closest_hit MASKED): for every triangle r and every EMITTER triangle e the rows of
 // the kernel-argument table a light ray from a point of r's primitive to a point of e's primitive has to test -- e's own primitive, plus every primitive P
 // whose supporting plane has corners of (r's primitive, e's primitive) strictly on BOTH sides: a segment whose end points lie in one closed half space of

@@ -86,6 +86,10 @@ struct SceneView {
     // PathTracer(3) path's 7, test one primitive instead of six.  nullptr: every row.  lt_occ: its staged copy (kSceneTiny launches), < 0: none.
     const uint32_t *occ;
     int32_t lt_occ;
+    // Rows of `tiny` that hold an EMITTER triangle, when every emitter triangle of the scene is a kernel-argument primitive (0 otherwise: unknown).  A BSDF-sampled ray
+    // whose hit matters only if it is an emitter -- DirectIntegrator (direct.cpp:86-91: `active1 &= neq(its1.shape->emitter(), nullptr)`), the last vertex of a PathTracer
+    // path -- is tested against these rows first; if it meets none of them nothing along it can contribute and it is not traced (direct_step, round 6).
+    uint32_t emit_rows;
 };
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1194,6 +1198,9 @@ PSDR_HD bool sample_direct(const SceneView &sc, const Vec3f &p, int &pixel, floa
 }
 
 // ------------------------------------------------------------------------ integrators
+#ifndef PSDR_EMITTER_PRETEST
+#define PSDR_EMITTER_PRETEST 1          // BSDF-sampled rays that only matter if they end on an emitter are tested against the emitters' primitives first (0: always traced -- A/B builds)
+#endif
 #ifndef PSDR_SKIP_UNLIT
 #define PSDR_SKIP_UNLIT 1               // light samples whose BSDF value is zero by its cosine tests are not traced (0: traced anyway -- A/B builds)
 #endif
@@ -1234,7 +1241,7 @@ template <class NI, class G> PSDR_HD NI its_cast(const Its<G> &a) {
 }
 template <class G, class M, class TVT, class NI = Its<G>>
 PSDR_HD Vec3<M> direct_step(const SceneView &sc, const TVT &tv, TraversalStack &st, Rng &rng, const Its<G> &its, bool active, int nB,
-                            int nL, uint32_t &nrays, NI *next_its, Vec3<M> *next_f, bool *next_valid, int *light_tri = nullptr) {
+                            int nL, uint32_t &nrays, NI *next_its, Vec3<M> *next_f, bool *next_valid, int *light_tri = nullptr, bool emitter_only = false) {
     constexpr bool ad = is_ad<M>();
     constexpr HitForm form = is_ad<G>() ? kPathSpace : kDetached;
     Vec3<M> result = zero3<M>();
@@ -1246,6 +1253,13 @@ PSDR_HD Vec3<M> direct_step(const SceneView &sc, const TVT &tv, TraversalStack &
         Vec3f wo_s; M pdf_s;
         bool a1 = bsdf.sample(sc, tv, its, s, active, wo_s, pdf_s);
         const Vec3f dir1 = val(its.sh.s) * wo_s.x + val(its.sh.t) * wo_s.y + val(its.sh.n) * wo_s.z;
+        // emitter_only (the caller has no use for the hit unless it is an emitter): the ray against the emitters' primitives first -- the very tests the full search
+        // would run on those rows; a ray that meets none of them cannot end on an emitter, whatever lies along it: not traced.  (Not under an environment map: every
+        // ray that leaves the scene ends on its bounding mesh.  Two-level scenes only: where every ray costs six slab tests and nothing else -- the instances of a scene without a
+        // tree -- the second copy of the primitive loop costs more registers and code than the five tests it saves on one ray in seven: C2 18 800 against 19 400.)
+        if constexpr (!TVT::has_env && TVT::forest && PSDR_EMITTER_PRETEST && !is_ad<G>()) {          // (not in the geometry-dual instances: their largest kernel then spills in front of an exec restore, tools/check_spill_exec.py)
+            if (emitter_only && sc.emit_rows != 0u && a1) a1 = closest_hit<false, 2, true>(sc, st, val(its.p), dir1, INFINITY, -1, -1, 0, sc.emit_rows).tri >= 0;
+        }
         const RayT<G> ray1{its.p, lift<G>(dir1)};
         const Its<G> its1 = intersect<G>(sc, tv, st, ray1, a1, form, nrays, -1, -1, kPreBsdfRay);
         const bool a_hit = a1 && its1.valid;
@@ -1350,11 +1364,11 @@ PSDR_HD Vec3<M> Li(const SceneView &sc, const TVT &tv, TraversalStack &st, const
     }
     Vec3<M> result = lp.hide_emitters ? zero3<M>() : Le<M>(sc, tv, its, active);
     if (integ == PSDR_INTEGRATOR_DIRECT)
-        return result + direct_step<G, M>(sc, tv, st, rng, its, active, lp.bsdf_samples, lp.light_samples, nrays, (Its<G> *) nullptr, nullptr, nullptr);
+        return result + direct_step<G, M>(sc, tv, st, rng, its, active, lp.bsdf_samples, lp.light_samples, nrays, (Its<G> *) nullptr, nullptr, nullptr, nullptr, true);
     Vec3<M> beta(1.f);
     for (int depth = 0; depth < lp.max_depth; ++depth) {
         Its<G> nits; Vec3<M> nf; bool nvalid = false;
-        const Vec3<M> c = direct_step<G, M>(sc, tv, st, rng, its, active, 1, 1, nrays, &nits, &nf, &nvalid);
+        const Vec3<M> c = direct_step<G, M>(sc, tv, st, rng, its, active, 1, 1, nrays, &nits, &nf, &nvalid, nullptr, depth + 1 >= lp.max_depth);          // last vertex: nothing continues from its BSDF sample
         if (active) {
             result = result + beta * c;
             active = nvalid;
@@ -1417,7 +1431,7 @@ PSDR_HD Vec3<Dual<K>> li_path_logd(const SceneView &sc, const TVT &tv, Traversal
 #pragma unroll
             for (int k = 0; k < K; ++k) { s[k][0] += g[k][0]; s[k][1] += g[k][1]; s[k][2] += g[k][2]; }
         }
-        const Vec3f c = direct_step<float, float>(sc, tv0, st, rng, its, active, 1, 1, nrays, &nits, &nf, &nvalid);
+        const Vec3f c = direct_step<float, float>(sc, tv0, st, rng, its, active, 1, 1, nrays, &nits, &nf, &nvalid, nullptr, depth + 1 >= lp.max_depth);
         if (active) {
             const Vec3f bc = beta * c;
             result = result + bc;
@@ -1466,7 +1480,7 @@ PSDR_HD Vec3<M> wavefront_camera_vertex(const SceneView &sc, const TVT &tv, Trav
     if (!its.valid) return zero3<M>();
     Vec3<M> result = lp.hide_emitters ? zero3<M>() : Le<M>(sc, tv, its, true);
     bool nvalid = false;
-    result = result + direct_step<float, M>(sc, tv, st, rng, its, true, 1, 1, nrays, &next, &beta, &nvalid);
+    result = result + direct_step<float, M>(sc, tv, st, rng, its, true, 1, 1, nrays, &next, &beta, &nvalid, nullptr, lp.max_depth <= 1);
     if (rng_after) *rng_after = rng;           // the stream continues at the next vertex (classify_next)
     origin = its.p;
     if (nvalid) { const Vec3f b = val(beta); alive = b.x != 0.f || b.y != 0.f || b.z != 0.f; }
@@ -1504,11 +1518,11 @@ template <class G> PSDR_HD Its<float> detach_its(const Its<G> &a) {
 template <class M, class TVT>
 PSDR_HD Vec3<M> wavefront_bounce_vertex(const SceneView &sc, const TVT &tv, TraversalStack &st, const RngJump &jump_k, uint64_t slot,
                                         const Its<float> &its, uint32_t &nrays, Its<float> &next, Vec3<M> &f, bool &alive, int *light_tri = nullptr,
-                                        Rng *rng_after = nullptr) {
+                                        Rng *rng_after = nullptr, bool last = false) {
     Rng rng; rng.init(slot, jump_k);
     bool nvalid = false;
     if (light_tri) *light_tri = -1;
-    const Vec3<M> c = direct_step<float, M>(sc, tv, st, rng, its, true, 1, 1, nrays, &next, &f, &nvalid, light_tri);
+    const Vec3<M> c = direct_step<float, M>(sc, tv, st, rng, its, true, 1, 1, nrays, &next, &f, &nvalid, light_tri, last);
     if (rng_after) *rng_after = rng;           // five draws per vertex: the next stage's streams start here (classify_next)
     alive = nvalid;
     return c;

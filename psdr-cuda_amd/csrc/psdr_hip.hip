@@ -555,6 +555,7 @@ int lds_bytes(const LaunchCtx &cx, const psdr_scene_s *h) { return cx.off_stack 
 // the part of the tree that travels in the kernel arguments (tiny scenes, two-level trees)
 void fill_top(const psdr_scene_s *h, SceneView &sc) {
     sc.n_tiny = h->n_tiny; sc.aa_cnt = h->n_tiny > 0 ? h->aa_cnt : 0;
+    sc.emit_rows = (h->n_tiny > 0 && h->opt.emitter_pretest != 0) ? h->emit_rows : 0u;
     std::memcpy(sc.tiny, h->tiny, sizeof(h->tiny));
     std::memcpy(sc.tiny_meta, h->tiny_meta, sizeof(h->tiny_meta));
     sc.n_blas = h->n_blas;
@@ -820,7 +821,7 @@ int lbvh_build(psdr_scene_s *h, hipStream_t s, bool &fallback) {
     HIP_TRY(hipStreamSynchronize(s));            // `tris` dies at return
     h->hot_rows = (int) tris.size(); h->hot_identity = false;
     h->root = 0; h->bvh_depth = info.depth; h->num_nodes = T - 1; h->num_btris = T;
-    h->n_tiny = 0; h->aa_cnt = 0; h->n_blas = 0; h->n_inline = 0; h->have_occ = false;
+    h->n_tiny = 0; h->aa_cnt = 0; h->n_blas = 0; h->n_inline = 0; h->have_occ = false; h->emit_rows = 0;
     if (use_wide_tree(h, false)) {
         // the 4-wide tree over the device-built BVH2: its topology is decided on the host (one read-back of the node array; the collapse is
         // O(T)): 263 k triangles +~15 ms on top of the 2 ms device build -- only where a launch would walk it
@@ -985,6 +986,7 @@ int psdr_scene_set_option(psdr_scene_t h, const char *name, double value) {
     else if (n == "forest_min_inline") { h->forest_min_inline = iv; h->have_bvh = false; }   // a two-level tree needs at least this many inline triangles (default 6: walls around objects)
     else if (n == "scratch_plain") g_scratch_plain = iv;                 // experiment: scratch blocks of >= 64 MB from hipMalloc instead of the stream-ordered pool (process-wide)
     else if (n == "own_pixels") h->opt.own_pixels = iv;                  // 0: the camera kernels always add to the image with atomics
+    else if (n == "emitter_pretest") h->opt.emitter_pretest = iv;         // 0: BSDF-sampled rays that only matter on an emitter are traced like the others (A/B, tests)
     else if (n == "occ_rows") { h->opt.occ_rows = iv; h->have_bvh = false; }       // 0: the light rays of a scene without a tree test every row (A/B, tests)
     else if (n == "aa_prims") { h->aa_enabled = iv != 0; h->have_bvh = false; }   // 0: every kernel-argument primitive in plane form (no slab rows)
     else if (n == "tiny_scene") h->tiny_enabled = iv != 0;              // 0: walk a tree even for <= 16 triangles
@@ -1086,6 +1088,16 @@ static hipError_t copy_on_stream(void *dst, const void *src, size_t bytes, hipMe
     if (hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, s)) return e;
     return hipStreamSynchronize(s);
 }
+// SceneView::emit_rows from the handle's current primitive table and its host copy of the emitter table
+static void update_emit_rows(psdr_scene_s *h) {
+    std::vector<char> is_em((size_t) std::max(h->desc.num_tris, 0), 0);
+    for (int e = 0; e < h->desc.num_emitters && (size_t) (e + 1) * PSDR_EMITTER_I_STRIDE <= h->emitter_i.size(); ++e) {
+        const int32_t *ei = h->emitter_i.data() + (size_t) e * PSDR_EMITTER_I_STRIDE;
+        if (e == h->desc.env_emitter) { h->emit_rows = 0; return; }
+        for (int f = 0; f < ei[2]; ++f) if (ei[1] + f >= 0 && ei[1] + f < h->desc.num_tris) is_em[(size_t) (ei[1] + f)] = 1;
+    }
+    h->emit_rows = h->n_tiny > 0 ? tiny_emitter_rows(h->tiny_meta, h->n_tiny, h->aa_cnt, is_em) : 0u;
+}
 int psdr_bvh_build(psdr_scene_t h, void *stream) {
     if (!h || !h->have_tables) return fail("Scene not loaded yet!");
     hipStream_t s = (hipStream_t) stream;
@@ -1145,6 +1157,7 @@ int psdr_bvh_build(psdr_scene_t h, void *stream) {
                 refit_fits = (int) prims.size() / 3 <= kTinyTris;
                 if (refit_fits) {
                     h->n_tiny = tiny_plane_form(prims, h->tiny, h->tiny_meta, &h->aa_cnt, h->aa_enabled);
+                    update_emit_rows(h);
                     for (int k = 0; k < h->n_blas; ++k) {
                         const float w = h->blas_lo[k].w;
                         h->blas_lo[k] = top[kMaxInlineTris * 3 + k]; h->blas_lo[k].w = w;
@@ -1242,9 +1255,10 @@ int psdr_bvh_build(psdr_scene_t h, void *stream) {
     h->bvh_depth = forest ? fb.max_depth : b.max_depth; h->num_nodes = (int) nodes.size(); h->num_btris = (int) btris.size() / 3;
     if (int rc = bvh4_build(h, nodes, forest ? fb.roots : std::vector<int32_t>{root}, forest, s)) return rc;
     h->have_bvh = true;
-    h->n_tiny = 0; h->aa_cnt = 0; h->n_blas = 0; h->n_inline = 0; h->have_occ = false;
+    h->n_tiny = 0; h->aa_cnt = 0; h->n_blas = 0; h->n_inline = 0; h->have_occ = false; h->emit_rows = 0;
     if (forest) {
         h->n_tiny = tiny_plane_form(top_prims, h->tiny, h->tiny_meta, &h->aa_cnt, h->aa_enabled);
+        update_emit_rows(h);
         h->n_inline = (int) fb.inline_ids.size();
         h->n_blas = (int) fb.roots.size();
         for (int k = 0; k < h->n_blas; ++k) {
@@ -1261,6 +1275,7 @@ int psdr_bvh_build(psdr_scene_t h, void *stream) {
         std::vector<int> row_of_prim;
         pack_tiny_prims(b.btris, prims);           // walls as parallelograms: half the tests
         h->n_tiny = tiny_plane_form(prims, h->tiny, h->tiny_meta, &h->aa_cnt, h->aa_enabled, &row_of_prim);
+        update_emit_rows(h);
         // occluder rows of the light rays (SceneView::occ): which primitives can lie between a triangle and an emitter triangle
         h->have_occ = false;
         if (T <= 32 && h->n_tiny <= 32) {

@@ -161,6 +161,7 @@ struct psdr_scene_options {
     int tangent_live = 1;                  // forward mode with geometry tangents: one bit per triangle "some tangent set moves this row" (TangentView::live); 0: every row loads its tangents
     int wf_geo = 1;                        // PathTracer forward mode with geometry tangents on a two-level scene as the traced wavefront (k_wfg_*); 0: the fused kernel
     int own_pixels = 1;                    // camera kernels store a pixel whose samples all sit in one wave (64 % samples per pixel == 0) instead of adding to it with atomics (0: always atomics)
+    int emitter_pretest = 1;               // direct_step: BSDF-sampled rays whose hit matters only on an emitter meet the emitters' primitives first (SceneView::emit_rows); 0: off
     int occ_rows = 1;                      // scenes without a tree: light rays test only the rows that can lie between the vertex and the emitter sample (0: every row; takes effect at the next psdr_bvh_build)
     int logd = 1;                          // PathTracer forward mode with tangents on diffuse albedo texels only: the log-derivative kernel (0: always dual numbers)
     int keep_records = 1;                  // psdr_render_c honours PSDR_FLAG_KEEP_RECORDS (0: ignored -- A/B, tests)
@@ -279,6 +280,7 @@ struct psdr_scene_s {
     // bunnies, a light quad and a backdrop) on ONE tree -- measured on 4 M-slot PathTracer launches (2.9 against 3.1 ms).  At BASELINE configs[2]'s size every launch
     // form that runs its tree walks in the dense trace kernel wins there too (bunny_light 512^2 x 128: DirectIntegrator three-term reverse 39.6 -> 33.9 ms, forward
     // 40.8 -> 35.8, PathTracer(3) renderC 8.0 -> 6.2, PathTracer(3) reverse 25.2 -> 12.8; profiles/r06_bunny_light_forest.txt): default 0 since round 6
+    uint32_t emit_rows = 0;                // SceneView::emit_rows of the current tree (psdr_bvh_build)
     int forest_min_inline = 0;
 };
 

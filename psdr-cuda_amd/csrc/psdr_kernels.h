@@ -383,7 +383,7 @@ __device__ __forceinline__ void stream_push(const PathStream &out, bool alive, i
 // boxes without its length too: closest_hit looks for the closest hit along the whole ray, and so does the trace kernel.
 template <bool TRACED = false, class TVT>
 __device__ __forceinline__ int classify_next(const SceneView &sc, const TVT &, Rng rng, const Its<float> &next, const Vec3f &,
-                                             Vec3f *d_bsdf = nullptr, Vec3f *d_light = nullptr) {
+                                             Vec3f *d_bsdf = nullptr, Vec3f *d_light = nullptr, bool emitter_only = false, TraversalStack *stp = nullptr) {
     const TangentView<0, TVT::flags> tv0{};
     const Its<float> &its = next;
     const int bsdf_id = Tab<TVT::flags>::mesh_bsdf(sc, its.mesh);          // the staged copies (two-level instances), as every estimator reads them
@@ -404,7 +404,13 @@ __device__ __forceinline__ int classify_next(const SceneView &sc, const TVT &, R
     Vec3f wo_s; float pdf_s;
     if (bsdf.sample(sc, tv0, its, s, true, wo_s, pdf_s)) {
         const Vec3f d1 = its.sh.s * wo_s.x + its.sh.t * wo_s.y + its.sh.n * wo_s.z;
-        if (enters(its.p, d1, INFINITY)) cls |= 1;
+        // emitter_only (the stage that consumes the record has no use for the BSDF sample's hit unless it is an emitter: direct_step): a ray that meets no emitter
+        // primitive is not traced there -- no request for it
+        bool wanted = true;
+        if constexpr (!TVT::has_env && TVT::forest && PSDR_EMITTER_PRETEST) {
+            if (emitter_only && sc.emit_rows != 0u && stp != nullptr) wanted = closest_hit<false, 2, true>(sc, *stp, its.p, d1, INFINITY, -1, -1, 0, sc.emit_rows).tri >= 0;
+        }
+        if (wanted && enters(its.p, d1, INFINITY)) cls |= 1;
         if (TRACED) *d_bsdf = d1;
     }
     const PosSample<float> ps = sample_emitter_position<float>(sc, tv0, its.p, s0, s1, false);
@@ -522,6 +528,9 @@ __global__ __launch_bounds__(kBlock, (is_ad<M>() ? 2 : PSDR_WF_WAVES)) void k_wf
                                                         PathStream out, int want_next, unsigned long long *counters, RngJump jump_next, TraceQueue tq, WfRec wr) {
     TraversalStack st; setup_lds(cx, st, tv);
     uint32_t nrays = 0;
+    // want_next: bit 0 = surviving paths are pushed to `out`; bit 1 = the stage that consumes them is the path's LAST (its BSDF sample matters only if it ends on an emitter)
+    const bool next_last = (want_next & 2) != 0;
+    want_next &= 1;
     const long long nceil = (n + kBlock - 1) / kBlock * kBlock;
     for (long long jj = (long long) blockIdx.x * kBlock + threadIdx.x; jj < nceil; jj += (long long) gridDim.x * kBlock) {
         const bool in = jj < n;
@@ -554,10 +563,10 @@ __global__ __launch_bounds__(kBlock, (is_ad<M>() ? 2 : PSDR_WF_WAVES)) void k_wf
         if (want_next) {
             if constexpr (TRACED) {
                 Vec3f d_bsdf(0.f), d_light(0.f);
-                const int cls = alive ? classify_next<true>(cx.sc, tv, rng_next, next, dir, &d_bsdf, &d_light) : 0;
+                const int cls = alive ? classify_next<true>(cx.sc, tv, rng_next, next, dir, &d_bsdf, &d_light, next_last, &st) : 0;
                 stream_push_traced<M>(out, tq, alive, cls, pixel, slot, next, dir, beta, r, d_bsdf, d_light);
             } else if constexpr ((FL & kSceneForest) != 0) {
-                if (out.binned) stream_push_binned<M>(out, alive, alive ? classify_next(cx.sc, tv, rng_next, next, dir) : 0, jj / kBlock, pixel, slot, next, dir, beta, r);
+                if (out.binned) stream_push_binned<M>(out, alive, alive ? classify_next(cx.sc, tv, rng_next, next, dir, nullptr, nullptr, next_last, &st) : 0, jj / kBlock, pixel, slot, next, dir, beta, r);
                 else stream_push<M>(out, alive, pixel, slot, next, dir, beta, r);
             } else stream_push<M>(out, alive, pixel, slot, next, dir, beta, r);
         }
@@ -584,7 +593,7 @@ template <class M, int FL, bool TRACED = false, bool REC = false>
 __device__ __forceinline__ void wf_bounce_record(const LaunchCtx &cx, const TV<M, FL> &tv, TraversalStack &st, float inv_spp, float *__restrict__ img,
                                                  float *__restrict__ dimg, long long plane, const PathStream &in, const PathStream &out, int want_next,
                                                  const RngJump &jump_next, bool live, long long j, long long chunk, uint32_t &nrays, const TraceQueue &tq,
-                                                 const WfRec &wr, const WfRaw &raw PSDR_CLK_ARG) {
+                                                 const WfRec &wr, const WfRaw &raw, bool next_last PSDR_CLK_ARG) {
     constexpr int K = ad_traits<M>::K;
     PSDR_CLK_MARK(0);                            // the record has arrived (and the stores of the trip before it have left)
     int pixel = -1; uint32_t slot = 0;
@@ -631,7 +640,7 @@ __device__ __forceinline__ void wf_bounce_record(const LaunchCtx &cx, const TV<M
             for (int k = 0; k < (K > 0 ? K : 1); ++k) tvp.t[k] = tv.t[k];
             tvp.live = tv.live;
             int light_tri = -1;
-            c = wavefront_bounce_vertex<M>(cx.sc, tvp, st, cx.jump, (uint64_t) slot, its, nrays, next, f, alive, REC ? &light_tri : nullptr, &rng_next);
+            c = wavefront_bounce_vertex<M>(cx.sc, tvp, st, cx.jump, (uint64_t) slot, its, nrays, next, f, alive, REC ? &light_tri : nullptr, &rng_next, want_next == 0);
             if constexpr (REC) {
                 // vertex `stage` of this path: (c_k, f_k) and the triangles its two rays arrived at (the adjoint kernel re-intersects those)
                 float *col = wr.disk + wr.column(pixel, slot) + (long long) (kRevDiskHead + wr.stage * kRevDiskPerVertexCf) * wr.stride;
@@ -640,7 +649,7 @@ __device__ __forceinline__ void wf_bounce_record(const LaunchCtx &cx, const TV<M
                 col[3 * wr.stride] = fv.x; col[4 * wr.stride] = fv.y; col[5 * wr.stride] = fv.z;
                 col[6 * wr.stride] = __int_as_float(alive ? next.tri : -1); col[7 * wr.stride] = __int_as_float(light_tri);
             }
-        } else c = wavefront_bounce_vertex<M>(cx.sc, tv, st, cx.jump, (uint64_t) slot, its, nrays, next, f, alive, nullptr, &rng_next);
+        } else c = wavefront_bounce_vertex<M>(cx.sc, tv, st, cx.jump, (uint64_t) slot, its, nrays, next, f, alive, nullptr, &rng_next, want_next == 0);
         r = acc + beta * c;
         if (alive) {
             beta = beta * f;
@@ -665,12 +674,12 @@ __device__ __forceinline__ void wf_bounce_record(const LaunchCtx &cx, const TV<M
     if (want_next) {
         if constexpr (TRACED) {
             Vec3f d_bsdf(0.f), d_light(0.f);
-            const int cls = alive ? classify_next<true>(cx.sc, tv, rng_next, next, dir, &d_bsdf, &d_light) : 0;
+            const int cls = alive ? classify_next<true>(cx.sc, tv, rng_next, next, dir, &d_bsdf, &d_light, next_last, &st) : 0;
             PSDR_CLK_MARK(5);                    // the next vertex' two rays aimed
             stream_push_traced<M>(out, tq, alive, cls, pixel, slot, next, dir, beta, r, d_bsdf, d_light PSDR_CLK_PASS);
             PSDR_CLK_MARK(7);                    // record + requests stored (drained: a developer build waits for its stores here)
         } else if constexpr ((FL & kSceneForest) != 0) {
-            if (out.binned) stream_push_binned<M>(out, alive, alive ? classify_next(cx.sc, tv, rng_next, next, dir) : 0, chunk, pixel, slot, next, dir, beta, r);
+            if (out.binned) stream_push_binned<M>(out, alive, alive ? classify_next(cx.sc, tv, rng_next, next, dir, nullptr, nullptr, next_last, &st) : 0, chunk, pixel, slot, next, dir, beta, r);
             else stream_push<M>(out, alive, pixel, slot, next, dir, beta, r);
         } else stream_push<M>(out, alive, pixel, slot, next, dir, beta, r);
     }
@@ -686,6 +695,8 @@ __global__ __launch_bounds__(kBlock, (is_ad<M>() ? 2 : (TRACED ? PSDR_WF_WAVES_T
                                                         PathStream out, int want_next, unsigned long long *counters, RngJump jump_next, TraceQueue tq, WfRec wr) {
     TraversalStack st; setup_lds(cx, st, tv);
     uint32_t nrays = 0;
+    const bool next_last = (want_next & 2) != 0;          // (bits of want_next: k_wf_camera)
+    want_next &= 1;
     bool binned = false;
     if constexpr ((FL & kSceneForest) != 0 && !TRACED) binned = in.binned != 0;
     if (binned) {
@@ -713,7 +724,7 @@ __global__ __launch_bounds__(kBlock, (is_ad<M>() ? 2 : (TRACED ? PSDR_WF_WAVES_T
                 const int off = (c - s_pref[lo]) * kBlock + (int) threadIdx.x;
                 const bool live = off < in.count[lo * kWfCountStride];
                 wf_bounce_record<M, FL, false, false>(cx, tv, st, inv_spp, img, dimg, plane, in, out, want_next, jump_next, live, (long long) lo * in.sub_cap + off, c, nrays, tq, wr,
-                                                      wf_load_raw(in, (long long) lo * in.sub_cap + off, live));
+                                                      wf_load_raw(in, (long long) lo * in.sub_cap + off, live), next_last);
             }
         }
     } else {
@@ -731,7 +742,7 @@ __global__ __launch_bounds__(kBlock, (is_ad<M>() ? 2 : (TRACED ? PSDR_WF_WAVES_T
 #endif
         for (int base = (blockIdx.x / kWfSub) * kBlock; base < n; base += per * kBlock)
             wf_bounce_record<M, FL, TRACED, REC>(cx, tv, st, inv_spp, img, dimg, plane, in, out, want_next, jump_next, base + (int) threadIdx.x < n, in_base + base + threadIdx.x,
-                                                 base / kBlock, nrays, tq, wr, wf_load_raw(in, in_base + base + threadIdx.x, base + (int) threadIdx.x < n) PSDR_CLK_PASS);
+                                                 base / kBlock, nrays, tq, wr, wf_load_raw(in, in_base + base + threadIdx.x, base + (int) threadIdx.x < n), next_last PSDR_CLK_PASS);
 #ifdef PSDR_STAGE_CLOCKS
         if ((threadIdx.x & 63) == 0 && !REC) {
             ck.t[11] = __builtin_amdgcn_s_memtime() - t_begin;       // wave lifetime inside the loop
@@ -877,7 +888,7 @@ __global__ __launch_bounds__(kBlock, (wfg_waves<FL>())) void k_wfg_bounce(Launch
             }
             Rng rng; rng.init((uint64_t) slot, cx.jump);
             Vec3<M> f = zero3<M>(); bool nvalid = false;
-            const Vec3<M> c = direct_step<G, M>(cx.sc, tvp, st, rng, its, true, 1, 1, nrays, &nextf, &f, &nvalid);          // the next vertex as plain values (its_cast)
+            const Vec3<M> c = direct_step<G, M>(cx.sc, tvp, st, rng, its, true, 1, 1, nrays, &nextf, &f, &nvalid, nullptr, want_next == 0);          // the next vertex as plain values (its_cast)
             rng_next = rng;
             r = acc + beta * c;
             alive = nvalid;
@@ -1030,7 +1041,7 @@ template <int FL> __global__ __launch_bounds__(kBlock, PSDR_WAVES_C) void k_dire
             (void) wavefront_primary_vertex<float>(cx.sc, tv0, st, cx.lp, cx.jump, pixel, slot, nrays, next, dir, alive, &rng_next);
             if (alive) {
                 hit[3 * jj + 2] = float4{__int_as_float(next.tri), next.hu, next.hv, next.t};
-                m = 4u | (uint32_t) classify_next<true>(cx.sc, tv0, rng_next, next, dir, &d[0], &d[1]);
+                m = 4u | (uint32_t) classify_next<true>(cx.sc, tv0, rng_next, next, dir, &d[0], &d[1], true, &st);          // DirectIntegrator: the BSDF sample's hit matters only on an emitter
                 p0 = next.p;
             }
             mask[jj] = m;
@@ -1863,10 +1874,10 @@ int run_camera_wavefront(psdr_scene_s *h, const psdr_render_opts *o, const TV<M,
                 if (recording) {
                     if constexpr (K == 0)
                         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wf_camera<M, FL, true, true>), dim3(blocks), dim3(kBlock), lds_bytes(cx, h), s, cx, tv, o->spp, o->spp_begin, nsp, j0, cn,
-                                           inv_spp, img, dimg, WH * 3, st[0], 1, h->d_counters, make_rng_jump(o->rng_offset[0] + 2), tq, wr);
+                                           inv_spp, img, dimg, WH * 3, st[0], 1 | (depth == 1 ? 2 : 0), h->d_counters, make_rng_jump(o->rng_offset[0] + 2), tq, wr);
                 } else
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wf_camera<M, FL, true>), dim3(blocks), dim3(kBlock), lds_bytes(cx, h), s, cx, tv, o->spp, o->spp_begin, nsp, j0, cn,
-                                   inv_spp, img, dimg, WH * 3, st[0], 1, h->d_counters, make_rng_jump(o->rng_offset[0] + 2), tq, wr);
+                                   inv_spp, img, dimg, WH * 3, st[0], 1 | (depth == 1 ? 2 : 0), h->d_counters, make_rng_jump(o->rng_offset[0] + 2), tq, wr);
                 HIP_TRY(hipGetLastError());
                 for (int k = 0; k < depth; ++k) {
                     if (int rc = launch_wf_trace(h, tq.req, tq.count, tq.sub_cap, st[k & 1].hit, s)) return rc;
@@ -1877,10 +1888,10 @@ int run_camera_wavefront(psdr_scene_s *h, const psdr_render_opts *o, const TV<M,
                     if (recording) {
                         if constexpr (K == 0)
                             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wf_bounce<M, FL, true, true>), dim3(blocks), dim3(kBlock), dyn_p, s, cxp, tv, inv_spp, img, dimg, WH * 3,
-                                               st[k & 1], st[(k + 1) & 1], k + 1 < depth ? 1 : 0, h->d_counters, make_rng_jump(o->rng_offset[0] + 2 + 5 * (uint64_t) (k + 1)), tq, wr);
+                                               st[k & 1], st[(k + 1) & 1], (k + 1 < depth ? 1 : 0) | (k + 2 == depth ? 2 : 0), h->d_counters, make_rng_jump(o->rng_offset[0] + 2 + 5 * (uint64_t) (k + 1)), tq, wr);
                     } else
                     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wf_bounce<M, FL, true>), dim3(blocks), dim3(kBlock), dyn_p, s, cxp, tv, inv_spp, img, dimg, WH * 3,
-                                       st[k & 1], st[(k + 1) & 1], k + 1 < depth ? 1 : 0, h->d_counters, make_rng_jump(o->rng_offset[0] + 2 + 5 * (uint64_t) (k + 1)), tq, wr);
+                                       st[k & 1], st[(k + 1) & 1], (k + 1 < depth ? 1 : 0) | (k + 2 == depth ? 2 : 0), h->d_counters, make_rng_jump(o->rng_offset[0] + 2 + 5 * (uint64_t) (k + 1)), tq, wr);
                     HIP_TRY(hipGetLastError());
                 }
                 continue;
@@ -1890,25 +1901,25 @@ int run_camera_wavefront(psdr_scene_s *h, const psdr_render_opts *o, const TV<M,
             // camera stage = primary hit only; the direct step at the primary vertex is bounce stage 0 (binned like the rest):
             // stage k reads stream k & 1 (counter set k) and appends to stream (k + 1) & 1 (set k + 1)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wf_camera<M, FL>), dim3(blocks), dim3(kBlock), lds_bytes(cx, h), s, cx, tv, o->spp, o->spp_begin, nsp, j0, cn,
-                               inv_spp, img, dimg, WH * 3, st[0], 1, h->d_counters, make_rng_jump(o->rng_offset[0] + 2), tq, WfRec{});
+                               inv_spp, img, dimg, WH * 3, st[0], 1 | (depth == 1 ? 2 : 0), h->d_counters, make_rng_jump(o->rng_offset[0] + 2), tq, WfRec{});
             HIP_TRY(hipGetLastError());
             for (int k = 0; k < depth; ++k) {
                 st[(k + 1) & 1].count = cnt + (size_t) (k + 1) * kWfStageInts;
                 cx.jump = make_rng_jump(o->rng_offset[0] + 2 + 5 * (uint64_t) k);
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wf_bounce<M, FL>), dim3(blocks), dim3(kBlock), lds_bytes(cx, h), s, cx, tv, inv_spp, img, dimg, WH * 3,
-                                   st[k & 1], st[(k + 1) & 1], k + 1 < depth ? 1 : 0, h->d_counters, make_rng_jump(o->rng_offset[0] + 2 + 5 * (uint64_t) (k + 1)), tq, WfRec{});
+                                   st[k & 1], st[(k + 1) & 1], (k + 1 < depth ? 1 : 0) | (k + 2 == depth ? 2 : 0), h->d_counters, make_rng_jump(o->rng_offset[0] + 2 + 5 * (uint64_t) (k + 1)), tq, WfRec{});
                 HIP_TRY(hipGetLastError());
             }
             continue;
         }
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wf_camera<M, FL>), dim3(blocks), dim3(kBlock), lds_bytes(cx, h), s, cx, tv, o->spp, o->spp_begin, nsp, j0, cn,
-                           inv_spp, img, dimg, WH * 3, st[0], depth > 1 ? 1 : 0, h->d_counters, make_rng_jump(o->rng_offset[0] + 2 + 5), tq, WfRec{});
+                           inv_spp, img, dimg, WH * 3, st[0], (depth > 1 ? 1 : 0) | (depth == 2 ? 2 : 0), h->d_counters, make_rng_jump(o->rng_offset[0] + 2 + 5), tq, WfRec{});
         HIP_TRY(hipGetLastError());
         for (int k = 1; k < depth; ++k) {
             st[k & 1].count = cnt + (size_t) k * kWfStageInts;      // a fresh (zeroed) counter set per stage
             cx.jump = make_rng_jump(o->rng_offset[0] + 2 + 5 * (uint64_t) k);
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wf_bounce<M, FL>), dim3(blocks), dim3(kBlock), lds_bytes(cx, h), s, cx, tv, inv_spp, img, dimg, WH * 3,
-                               st[(k - 1) & 1], st[k & 1], k + 1 < depth ? 1 : 0, h->d_counters, make_rng_jump(o->rng_offset[0] + 2 + 5 * (uint64_t) (k + 1)), tq, WfRec{});
+                               st[(k - 1) & 1], st[k & 1], (k + 1 < depth ? 1 : 0) | (k + 2 == depth ? 2 : 0), h->d_counters, make_rng_jump(o->rng_offset[0] + 2 + 5 * (uint64_t) (k + 1)), tq, WfRec{});
             HIP_TRY(hipGetLastError());
         }
     }

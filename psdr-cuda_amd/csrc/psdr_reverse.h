@@ -547,7 +547,7 @@ template <int FL> PSDR_HD Its<float> make_path_vertex(const SceneView &sc, const
 #endif
 template <bool BACKWARD, bool REPLAY, class Sink, class Rec = PathRec>
 PSDR_HD VertexOut vertex_eval(Sink &sink, const SceneView &sc, TraversalStack &st, Rng &rng, const Its<float> &its, int nB, int nL,
-                              const Vec3f &a_c, const Vec3f &a_f, VertexAdj &va, uint32_t &nrays, Rec &rec, int k, RowAdj *next_row = nullptr) {
+                              const Vec3f &a_c, const Vec3f &a_f, VertexAdj &va, uint32_t &nrays, Rec &rec, int k, RowAdj *next_row = nullptr, bool emitter_only = false) {
     const TangentView<0, Sink::flags> tv0{};
     VertexOut out; out.c = Vec3f(0.f); out.f = Vec3f(0.f); out.next_valid = false;
     // the bounding mesh of the environment map has no BSDF (direct.cpp:54-57): nothing is gathered there and
@@ -570,8 +570,15 @@ PSDR_HD VertexOut vertex_eval(Sink &sink, const SceneView &sc, TraversalStack &s
         Hit h1;
         if (REPLAY && BACKWARD) h1.tri = rec.tri(k, 0);
         else {
-            nrays++;
-            h1 = closest_hit<false, tree_mode<Sink::flags>()>(sc, st, ray1.o, ray1.d, INFINITY, -1, -1, kPreBsdfRay);
+            // emitter_only (direct_step): the hit matters only on an emitter -- the emitters' primitives first, no trace for a ray that meets none of them
+            bool wanted = true;
+            if constexpr (!Sink::has_env && (Sink::flags & kSceneForest) != 0 && PSDR_EMITTER_PRETEST) {
+                if (emitter_only && sc.emit_rows != 0u) wanted = closest_hit<false, 2, true>(sc, st, ray1.o, ray1.d, INFINITY, -1, -1, 0, sc.emit_rows).tri >= 0;
+            }
+            if (wanted) {
+                nrays++;
+                h1 = closest_hit<false, tree_mode<Sink::flags>()>(sc, st, ray1.o, ray1.d, INFINITY, -1, -1, kPreBsdfRay);
+            } else h1.tri = -1;
             if (REPLAY) rec.put_tri(k, 0, h1.tri);
         }
         if (h1.tri < 0) return;
@@ -966,8 +973,9 @@ PSDR_HD Vec3f camera_sample_reverse(RealSink &real_sink, PrimaryGrad &pg, PathRe
         Its<float> cur = its;
         Vec3f beta(1.f);
         for (int k = 0; k < depth; ++k) {
-            const VertexOut vo = replay ? vertex_eval<false, true, NullSink<Sink::flags>>(ns, sc, st, r1, cur, nB, nL, Vec3f(0.f), Vec3f(0.f), dummy, nrays, rec, k)
-                                        : vertex_eval<false, false, NullSink<Sink::flags>>(ns, sc, st, r1, cur, nB, nL, Vec3f(0.f), Vec3f(0.f), dummy, nrays, rec, k);
+            const bool eo = direct || k + 1 >= depth;          // nothing continues from this vertex' BSDF sample: its hit matters only on an emitter
+            const VertexOut vo = replay ? vertex_eval<false, true, NullSink<Sink::flags>>(ns, sc, st, r1, cur, nB, nL, Vec3f(0.f), Vec3f(0.f), dummy, nrays, rec, k, nullptr, eo)
+                                        : vertex_eval<false, false, NullSink<Sink::flags>>(ns, sc, st, r1, cur, nB, nL, Vec3f(0.f), Vec3f(0.f), dummy, nrays, rec, k, nullptr, eo);
             rec.put_cf(k, vo.c, vo.f); nv = k + 1;
             result = result + beta * vo.c;
             if (!vo.next_valid) break;
@@ -1031,8 +1039,9 @@ PSDR_HD Vec3f camera_sample_reverse(RealSink &real_sink, PrimaryGrad &pg, PathRe
             const Vec3f a_f = (k + 1 < nv) ? a_c * rec.c(k) : Vec3f(0.f);
             VertexAdj va; va.clear();
             RowAdj row_next; row_next.clear();
-            const VertexOut vo = replay ? vertex_eval<true, true, SweepSink>(sweep, sc, st, rng, cur, nB, nL, a_c, a_f, k == 0 ? va0 : va, nrays, rec, k, &row_next)
-                                        : vertex_eval<true, false, SweepSink>(sweep, sc, st, rng, cur, nB, nL, a_c, a_f, k == 0 ? va0 : va, nrays, rec, k, &row_next);
+            const bool eo = direct || k + 1 >= depth;
+            const VertexOut vo = replay ? vertex_eval<true, true, SweepSink>(sweep, sc, st, rng, cur, nB, nL, a_c, a_f, k == 0 ? va0 : va, nrays, rec, k, &row_next, eo)
+                                        : vertex_eval<true, false, SweepSink>(sweep, sc, st, rng, cur, nB, nL, a_c, a_f, k == 0 ? va0 : va, nrays, rec, k, &row_next, eo);
             PSDR_CLK_MARK_ST(st, 2 + (k > 0 ? 1 : 0));      // vertex_eval backward: vertex 0 / the others
             if (k >= 1) {
                 // a vertex' row leaves ONCE and COMPLETE (position, face normal, area: complete_row) -- one iteration late, when its successor's direction

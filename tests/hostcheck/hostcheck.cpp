@@ -29,6 +29,14 @@ bool setup(HostScene &hs, const psdr_scene_desc *d) {
         std::vector<float4> prims;
         pack_tiny_prims(hs.b.btris, prims);
         hs.sc.n_tiny = tiny_plane_form(prims, hs.sc.tiny, hs.sc.tiny_meta, &hs.sc.aa_cnt);
+        // SceneView::emit_rows as psdr_bvh_build sets it (the estimators' emitter pre-test; the host check's TangentView flags carry neither kSceneTiny nor
+        // kSceneForest, so the estimators here do not USE it -- hostcheck_emitter_rows hands it to the tests)
+        std::vector<char> is_em((size_t) d->num_tris, 0);
+        for (int e = 0; e < d->num_emitters && d->emitter_i; ++e) {
+            const int32_t *ei = d->emitter_i + (size_t) e * PSDR_EMITTER_I_STRIDE;
+            for (int f = 0; f < ei[2]; ++f) if (ei[1] + f >= 0 && ei[1] + f < d->num_tris) is_em[(size_t) (ei[1] + f)] = 1;
+        }
+        hs.sc.emit_rows = tiny_emitter_rows(hs.sc.tiny_meta, hs.sc.n_tiny, hs.sc.aa_cnt, is_em);
     }
     return true;
 }
@@ -67,6 +75,13 @@ int hostcheck_trace_rows(const psdr_scene_desc *d, int m, const float *o, const 
         Hit h = closest_hit<false, 2, true>(hs.sc, st, Vec3f{o[3 * i], o[3 * i + 1], o[3 * i + 2]}, Vec3f{dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]}, INFINITY, -1, -1, 0, rows[i]);
         tri[i] = h.tri; u[i] = h.u; v[i] = h.v; t[i] = h.t;
     }
+    return 0;
+}
+
+int hostcheck_emitter_rows(const psdr_scene_desc *d, uint32_t *rows) {
+    HostScene hs;
+    if (!setup(hs, d)) return 1;
+    *rows = hs.sc.emit_rows;
     return 0;
 }
 
