@@ -236,7 +236,7 @@ def pmc_passes(args):
         for group in ("SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES", "FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(tmp, group.split()[0])
             cmd = [exe, "--pmc"] + group.split() + ["--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
-                   "--pmc-child", "--res", str(args.res), "--spp", str(args.spp), "--max-depth", str(args.max_depth), "--scene", args.scene]
+                   "--pmc-child", "--res", str(args.res), "--spp", str(args.spp), "--max-depth", str(args.max_depth), "--scene", args.scene] + lib_arg(args)
             try:
                 subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
             except Exception:
@@ -276,7 +276,7 @@ def pmc_passes_c4(args, res, spp):
         for group in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(tmp, group)
             cmd = [exe, "--pmc", group, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
-                   "--config", "c4", "--pmc-child", "--res", str(res), "--spp", str(spp), "--max-depth", str(args.max_depth)]
+                   "--config", "c4", "--pmc-child", "--res", str(res), "--spp", str(spp), "--max-depth", str(args.max_depth)] + lib_arg(args)
             try:
                 subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=400, check=True)
             except Exception:
@@ -493,7 +493,7 @@ def tree_scenes(args):
             per_case = {}                                         # case -> kernel -> [duration ns, {counter: value}, launches]
             for group in ("SQ_INSTS_VALU", "FETCH_SIZE", "WRITE_SIZE"):
                 d = os.path.join(tmp, group)
-                cmd = [exe, "--pmc", group, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--tree-child"]
+                cmd = [exe, "--pmc", group, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--tree-child"] + lib_arg(args)
                 subprocess.run(cmd, cwd="/tmp", env=child_env(getattr(args, "local_rank", 0)), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=400, check=True)
                 disp = {}
                 for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
@@ -740,6 +740,11 @@ def c4_strong(args, world, rank, dist, rccl, wait_all, one_integrator=False):
             "allreduces_per_step": "[image] (renderC), [image] (renderD primal), [triangle-row || texel gradients]", "rccl_version": rccl, "grad_finite": finite,
             "wavefront_hbm": None if wf is None else {"workload": "PathTracer(3).renderC of rank 0's share (%d spp), two calls under rocprofv3 --pmc" % max(spp // world, 1), "kernels": wf,
                                                       "note": "(2 * FETCH_SIZE + WRITE_SIZE) KiB per kernel summed over its launches / its summed duration / 8 TB/s"}}
+
+
+def lib_arg(args):
+    """the counter children measure the build the parent measures (developer runs with --hip-lib)"""
+    return ["--hip-lib", args.hip_lib] if getattr(args, "hip_lib", None) else []
 
 
 def main():
