@@ -916,23 +916,38 @@ __global__ __launch_bounds__(kBlock, (wfg_waves<FL>())) void k_wfg_bounce(Launch
 #endif
 // forward instances of the lean two-level variant (K = 1: 119 -> 96 VGPRs, 14 spilled) take a fifth wave: C3 three-term forward 2.85 -> 2.78 ms
 // (k_primary_edge 1 310 -> 1 248 us); the reverse kernel loses 3-11 % there, three waves lose everywhere (profiles/r04_occupancy_abk.txt)
-template <int K, int FL> constexpr int primary_edge_waves() { return ((FL & (kSceneEnv | kSceneRough)) == 0 && (FL & kSceneForest) != 0 && K == 1) ? PSDR_WAVES_PE + 1 : PSDR_WAVES_PE; }
+#ifndef PSDR_WAVES_PE_FWD
+#define PSDR_WAVES_PE_FWD (PSDR_WAVES_PE + 1)
+#endif
+template <int K, int FL> constexpr int primary_edge_waves() { return ((FL & (kSceneEnv | kSceneRough)) == 0 && (FL & kSceneForest) != 0 && K == 1) ? PSDR_WAVES_PE_FWD : PSDR_WAVES_PE; }
 template <int K, int FL, int INTEG>
 __global__ __launch_bounds__(kBlock, (primary_edge_waves<K, FL>())) void k_primary_edge(LaunchCtx cx, TangentView<K, FL> tv, long long i0, long long n, float inv_sppe,
                                                          float *__restrict__ dimg, long long plane, unsigned long long *counters,
                                                          const uint32_t *__restrict__ order) {
     TraversalStack st; setup_lds(cx, st);
     uint32_t nrays = 0;
-    for (long long j = (long long) blockIdx.x * kBlock + threadIdx.x; j < n; j += (long long) gridDim.x * kBlock) {
+    const long long nceil = (n + kBlock - 1) / kBlock * kBlock;
+    for (long long j = (long long) blockIdx.x * kBlock + threadIdx.x; j < nceil; j += (long long) gridDim.x * kBlock) {
         float tan[K][3];
-        const long long jj = order ? (long long) order[j] : j;          // pixel-sorted evaluation order (psdr_hip.hip)
-        const int pixel = primary_edge_sample<K, INTEG>(cx.sc, tv, st, cx.lp, cx.jump, (uint64_t) (i0 + jj), inv_sppe, tan, nrays);
-        if (pixel >= 0) {
+        int pixel = -1;
+        if (j < n) {
+            const long long jj = order ? (long long) order[j] : j;          // pixel-sorted evaluation order (psdr_hip.hip)
+            pixel = primary_edge_sample<K, INTEG>(cx.sc, tv, st, cx.lp, cx.jump, (uint64_t) (i0 + jj), inv_sppe, tan, nrays);
+        }
+        // pixel-sorted slots: the lanes of a wave mostly sit on ONE pixel of a silhouette -- 64 float atomics on one address serialise in L2 (bunny_light: the
+        // forward kernel 16.1 ms where the reverse kernel, which sums its runs of equal edges, takes 11.1).  One atomic per run of equal pixels.
+        float v[3 * K];
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v[3 * k + c] = pixel >= 0 ? tan[k][c] : 0.f;
+        const bool head = wave_run_sum<3 * K>(pixel, v);
+        if (head && pixel >= 0) {
 #pragma unroll
             for (int k = 0; k < K; ++k)
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
-                    if (tan[k][c] != 0.f) atomicAdd(dimg + (size_t) k * plane + (size_t) pixel * 3 + c, tan[k][c]);
+                    if (v[3 * k + c] != 0.f) atomicAdd(dimg + (size_t) k * plane + (size_t) pixel * 3 + c, v[3 * k + c]);
         }
     }
     count_rays(counters, nrays);

@@ -365,7 +365,7 @@ class PerspectiveCamera(Sensor):
                 # every candidate edge in ONE launch (csrc/psdr_tables.hip k_prim_edges): film records, 1 / depth rows, silhouette test
                 def film_records(v, m, edges):
                     edges = edges.long()
-                    q0, q1 = transform_pos(m, v[edges[:, 0]])[:, :2], transform_pos(m, v[edges[:, 1]])[:, :2]
+                    q0, q1 = transform_pos(m, v.index_select(0, edges[:, 0]))[:, :2], transform_pos(m, v.index_select(0, edges[:, 1]))[:, :2]
                     e = (q1 - q0).detach()
                     ln = torch.sqrt((e * e).sum(-1))
                     e = e / ln.unsqueeze(-1)
@@ -527,9 +527,11 @@ def build_edge_indices(faces, fname="<mesh>"):
 def process_mesh(verts, faces):
     """reference src/shape/mesh.cpp:20-51 -> (triangle_info [F,22], vertex_normals [V,3])."""
     f0, f1, f2 = faces[:, 0].long(), faces[:, 1].long(), faces[:, 2].long()
-    p0 = verts[f0]
-    e1 = verts[f1] - p0
-    e2 = verts[f2] - p0
+    # (index_select, not verts[f0]: its backward is an atomic index_add; advanced indexing goes back through torch's sort-based index_put(accumulate),
+    #  0.25 ms a call on the GPU -- 22 of them in one forward-mode step through the surface, tools/r06_index_sites.py)
+    p0 = verts.index_select(0, f0)
+    e1 = verts.index_select(0, f1) - p0
+    e2 = verts.index_select(0, f2) - p0
     fn = torch.cross(e1, e2, dim=-1)
     fa = torch.sqrt((fn * fn).sum(-1))
     vn = torch.zeros_like(verts)
@@ -538,7 +540,7 @@ def process_mesh(verts, faces):
         vn = vn.index_add(0, fi, fn)
         vw = vw.index_add(0, fi, fa)
     vn = _normalize(vn / vw.unsqueeze(-1))
-    n0, n1, n2 = vn[f0], vn[f1], vn[f2]
+    n0, n1, n2 = vn.index_select(0, f0), vn.index_select(0, f1), vn.index_select(0, f2)
     fn = fn / fa.unsqueeze(-1)
     fa = fa * 0.5
     return torch.cat([p0, e1, e2, n0, n1, n2, fn, fa.unsqueeze(-1)], dim=-1), vn
@@ -744,12 +746,13 @@ class Mesh(Object):
             ei = self._edge_indices_dev
             is_b = ei[:, 3] < 0
             vp, ti = self._vertex_positions, self._triangle_info
-            p0 = vp[ei[:, 0].long()]
-            e1 = vp[ei[:, 1].long()] - p0
-            n0 = ti[ei[:, 2].long(), 18:21]
+            fnr = ti[:, 18:21]
+            p0 = vp.index_select(0, ei[:, 0].long())
+            e1 = vp.index_select(0, ei[:, 1].long()) - p0
+            n0 = fnr.index_select(0, ei[:, 2].long())
             f1 = torch.where(is_b, torch.zeros_like(ei[:, 3]), ei[:, 3]).long()
-            n1 = ti[f1, 18:21] * (~is_b).unsqueeze(-1).to(torch.float32)
-            p2 = vp[ei[:, 4].long()]
+            n1 = fnr.index_select(0, f1) * (~is_b).unsqueeze(-1).to(torch.float32)
+            p2 = vp.index_select(0, ei[:, 4].long())
             keep = ((n0 * n1).sum(-1) < 1.0 - EdgeEpsilon).detach()
             info = torch.cat([p0, e1, n0, n1, p2, is_b.to(torch.float32).unsqueeze(-1)], dim=-1)
             self._sec_edge_info = info[keep]
@@ -1145,7 +1148,7 @@ class Scene(Object):
             self._mats_alive = parts if mats_key is not None else None        # keyed tensors stay alive (ids / blocks stay unique), as _static_key does
         v_raw = torch.cat([m._raw_positions() for m in meshes], dim=0)
         def to_world(v, mm):
-            mv = mm[tp["vmesh"]]                                                   # [V,4,4]
+            mv = mm.index_select(0, tp["vmesh"].long())                                                   # [V,4,4]
             h = (mv[:, :3, :3] * v.unsqueeze(1)).sum(-1) + mv[:, :3, 3]
             w = (mv[:, 3, :3] * v).sum(-1) + mv[:, 3, 3]
             return h / w.unsqueeze(-1)                                             # transform_pos, transform.h:84-88
@@ -1193,11 +1196,12 @@ class Scene(Object):
         def records(v, rows, edges):
             edges = edges.long()
             is_b = edges[:, 3] < 0
-            p0 = v[edges[:, 0]]
-            e1 = v[edges[:, 1]] - p0
-            n0 = rows[edges[:, 2], 18:21]
-            n1 = rows[torch.where(is_b, torch.zeros_like(edges[:, 3]), edges[:, 3]), 18:21] * (~is_b).unsqueeze(-1).to(torch.float32)
-            p2 = v[edges[:, 4]]
+            fnr = rows[:, 18:21]
+            p0 = v.index_select(0, edges[:, 0])
+            e1 = v.index_select(0, edges[:, 1]) - p0
+            n0 = fnr.index_select(0, edges[:, 2])
+            n1 = fnr.index_select(0, torch.where(is_b, torch.zeros_like(edges[:, 3]), edges[:, 3])) * (~is_b).unsqueeze(-1).to(torch.float32)
+            p2 = v.index_select(0, edges[:, 4])
             return torch.cat([p0, e1, n0, n1, p2, is_b.to(torch.float32).unsqueeze(-1)], dim=-1)
         if tables_native.available(v_world):
             info, keep8 = tables_native.sec_edges(v_world, tri_info, tp["edges_i32"], records)

@@ -222,7 +222,7 @@ class _CompactEdges(torch.autograd.Function):
         pos, = ctx.saved_tensors
         if a_out.requires_grad:                          # double backward (forward-mode JVP): a differentiable gather
             p = pos.long()
-            return torch.where((p >= 0).unsqueeze(-1), a_out[p.clamp(min=0)], torch.zeros_like(a_out)), None, None, None, None, None
+            return torch.where((p >= 0).unsqueeze(-1), a_out.index_select(0, p.clamp(min=0)), torch.zeros_like(a_out)), None, None, None, None, None
         lib = _abi.load_hip()
         a = a_out.contiguous().float()
         a_rows = torch.empty_like(a)
