@@ -374,7 +374,7 @@ __global__ __launch_bounds__(kBlock) void k_bvh4_fill(Bvh4Node *__restrict__ out
 // every slot (one draw + the edge CDF search) and a radix sort by pixel gives an order in which the lanes
 // of a wave share their pixel neighbourhood, like the interior term.  The image is the same sum.
 __global__ __launch_bounds__(kBlock) void k_primary_edge_keys(SceneView sc, RngJump jump, long long i0, long long n, uint32_t *__restrict__ keys,
-                                                              uint32_t *__restrict__ vals) {
+                                                              uint32_t *__restrict__ vals, uint32_t invalid_key) {
     const long long j = (long long) blockIdx.x * kBlock + threadIdx.x;
     if (j >= n) return;
     Rng rng; rng.init((uint64_t) (i0 + j), jump);
@@ -386,8 +386,8 @@ __global__ __launch_bounds__(kBlock) void k_primary_edge_keys(SceneView sc, RngJ
     const int ix = (int) floorf(px * (float) W), iy = (int) floorf(py * (float) H);
     const bool valid = ix >= 0 && ix < W && iy >= 0 && iy < H;
     // 8x8 pixel tiles, row-major inside: neighbours in the order are neighbours on the screen
-    const uint32_t tile = valid ? (uint32_t) ((iy >> 3) * ((W + 7) >> 3) + (ix >> 3)) : 0x3ffffffu;
-    keys[j] = valid ? ((tile << 6) | (uint32_t) (((iy & 7) << 3) | (ix & 7))) : 0xffffffffu;
+    const uint32_t tile = valid ? (uint32_t) ((iy >> 3) * ((W + 7) >> 3) + (ix >> 3)) : 0u;
+    keys[j] = valid ? ((tile << 6) | (uint32_t) (((iy & 7) << 3) | (ix & 7))) : invalid_key;          // (behind every pixel: primary_edge_order)
     vals[j] = (uint32_t) j;
 }
 
@@ -680,14 +680,20 @@ int primary_edge_order(psdr_scene_s *h, const LaunchCtx &cx, long long i0, long 
     *order = nullptr;
     if (!h->sort_edges || n < 65536 || n > 0x7fffffffLL) return 0;
     size_t temp = 0;
-    const unsigned end_bit = 32;
+    // key = (8x8 tile, pixel in the tile); a slot outside the film gets the one bit above them.  The sort runs over the bits the image needs (1024^2: 21 of 32)
+    const unsigned long long tiles = (unsigned long long) ((cx.sc.d.width + 7) >> 3) * (unsigned long long) ((cx.sc.d.height + 7) >> 3);
+    unsigned tile_bits = 0;
+    while ((1ull << tile_bits) < tiles) ++tile_bits;
+    if (tile_bits + 6 >= 32) return 0;                                    // (an image of > 2^25 tiles: natural order)
+    const unsigned end_bit = tile_bits + 7;
+    const uint32_t invalid_key = 1u << (tile_bits + 6);
     uint32_t *nul = nullptr;
     HIP_TRY(rocprim::radix_sort_pairs(nullptr, temp, nul, nul, nul, nul, (size_t) n, 0, end_bit, s));
     const size_t need = 4 * sizeof(uint32_t) * (size_t) n + temp + 256;
     if (int rc = scratch_reserve(&h->d_sort, &h->sort_bytes, need, s, "primary-edge sort scratch")) return rc;
     uint32_t *k_in = reinterpret_cast<uint32_t *>(h->d_sort), *k_out = k_in + n, *v_in = k_out + n, *v_out = v_in + n;
     void *tmp = reinterpret_cast<void *>((reinterpret_cast<uintptr_t>(v_out + n) + 255) & ~(uintptr_t) 255);
-    hipLaunchKernelGGL(k_primary_edge_keys, dim3((unsigned) ((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, cx.sc, cx.jump, i0, n, k_in, v_in);
+    hipLaunchKernelGGL(k_primary_edge_keys, dim3((unsigned) ((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, cx.sc, cx.jump, i0, n, k_in, v_in, invalid_key);
     HIP_TRY(hipGetLastError());
     HIP_TRY(rocprim::radix_sort_pairs(tmp, temp, k_in, k_out, v_in, v_out, (size_t) n, 0, end_bit, s));
     *order = v_out;
