@@ -1428,12 +1428,16 @@ template <int FL, bool GEO, int INTEG> constexpr bool reg_priv_kernel() { return
 // geometry adjoints: 2 waves/SIMD (248 VGPRs for the PathTracer, more for the rough-conductor variants); the
 // diffuse DirectIntegrator instance needs 187 and runs faster at 3 (C2 direct all gradients 4.1 -> 3.4 ms), the
 // others lose 50-100 % there to spills
+#ifndef PSDR_WAVES_REV_DIRECT_PRE
+#define PSDR_WAVES_REV_DIRECT_PRE 3     // final pass of the DirectIntegrator's camera term on a two-level scene (hits pre-traced: no walk, no stack)
+#endif
 template <int FL, bool GEO, int INTEG> constexpr int rev_waves() {
     if (!GEO) {
         if ((FL & (kSceneEnv | kSceneRough)) != 0) return PSDR_WAVES_REV_MAT;
         // plain diffuse variant: 130 VGPRs, C2 texel gradient 3.4 -> 2.8 ms at 4; its instance for scenes without a tree (117 VGPRs) at 5: 2.17 -> 2.09 ms
         return (FL & kSceneTiny) ? PSDR_WAVES_REV_MAT + 2 : PSDR_WAVES_REV_MAT + 1;
     }
+    if (INTEG == PSDR_INTEGRATOR_DIRECT && !(FL & kSceneRough) && (FL & kScenePre) != 0) return PSDR_WAVES_REV_DIRECT_PRE;
     return (INTEG == PSDR_INTEGRATOR_DIRECT && !(FL & kSceneRough)) ? 3 : PSDR_WAVES_REV;
 }
 // STAGE 0: value sweep + adjoint sweep per slot.  Split launch (tree scenes, render_rev): STAGE 1 = the value sweep alone at 3
