@@ -76,7 +76,7 @@ def test_scenario_of_the_reference_table_matches_the_oracle(name, tmp_path):
     isolated_pixels_unbiased(d, ref, bad, name, bias_bound=5e-3)
 
 
-@pytest.mark.parametrize("name", ["bunny_silhouette", "bunny_env_1"])
+@pytest.mark.parametrize("name", ["bunny_silhouette", "bunny_env_1", "cbox_MIS"])
 def test_scenario_ad_against_finite_differences_at_the_table_eps(name, tmp_path):
     """The reference's own validation (run_test.py run_ad / run_fd): the AD derivative image against central differences of renderC at the table's eps, both
     averaged over passes and compared on 16 x 16 pixel blocks (a coverage image moves by whole samples)."""
@@ -93,4 +93,58 @@ def test_scenario_ad_against_finite_differences_at_the_table_eps(name, tmp_path)
     err = np.linalg.norm(blk(d) - blk(fd)) / np.linalg.norm(blk(fd))
     print("%s: AD sum %.4g, FD sum %.4g (eps %g, %d passes), 16x16-block rel-L2 %.3f" % (name, d.sum(), fd.sum(), fdc["eps"], npass, err))
     assert np.isfinite(d).all() and np.abs(fd).max() > 0
-    assert err < 0.1, err                                            # measured 0.027 (bunny_silhouette), 0.031 (bunny_env_1)
+    assert err < 0.1, err                                            # measured 0.027 (bunny_silhouette), 0.031 (bunny_env_1), 0.006 (cbox_MIS)
+
+
+def _ad_fd_blocks(args, tmp_path, face_normals, mesh, res, npass_ad, npass_fd, nblk):
+    """AD and central-difference derivative images of a scenario row as nblk x nblk block sums, the moving mesh with face normals or the file's smooth ones"""
+    from enoki.cuda_autodiff import Float32 as FloatD
+
+    def load():
+        sc = H.load(args, tmp_path, res)
+        sc.param_map["Mesh[%d]" % mesh].use_face_normals = face_normals
+        return sc
+    sc = load()
+    W, Hh = sc.opts.width, sc.opts.height
+    d = H.run_ad(H.make_integrator(args), sc, args["AD"], npass_ad).reshape(Hh, W, 3)
+    integ, scs, eps = H.make_integrator(args), [], args["FD"]["eps"]
+    for sgn in (-1.0, 1.0):
+        s = load()
+        s.opts.sppe, s.opts.sppse = 0, 0
+        H.apply_parameter(s, args["AD"], FloatD(sgn * eps), {})
+        s.configure()
+        scs.append(s)
+    fd = 0
+    for _ in range(npass_fd):
+        fd = fd + (integ.renderC(scs[1]).numpy().astype(np.float64) - integ.renderC(scs[0]).numpy().astype(np.float64))
+    fd = (fd / (2 * eps * npass_fd)).reshape(Hh, W, 3)
+    bh, bw = Hh // nblk, W // nblk
+    blk = lambda a: a[:bh * nblk, :bw * nblk].reshape(nblk, bh, nblk, bw, 3).sum(axis=(1, 3, 4))
+    return blk(d), blk(fd)
+
+
+@pytest.mark.parametrize("name", ["cbox_bunny_translate", "bunny_env_2"])
+def test_moving_mesh_ad_meets_finite_differences_with_face_normals(name, tmp_path):
+    """Why `tree` and `bunny_env_2` are NOT in the AD-vs-FD list above, and what can be said instead (round 6, tools/r06_fd_normals_probe.py, tools/r06_fd_terms_probe.py).
+    `tree`: the table's AD row has spp = sppe = 0 -- the secondary-edge term alone -- while central differences see the whole derivative: not comparable.
+    `bunny_env_2` (the bunny rotated under an environment map) and any moving SMOOTH-shaded coarse mesh: AD and FD agree on the floor (shadow boundaries: the
+    secondary-edge term) and DISAGREE on the mesh's own pixels, stably in the pass count and in eps (measured: block rel-L2 0.25 for the translated bunny of
+    cbox_bunny.xml, 0.40 rotated, 0.8 under the environment map).  With interpolated normals the lighting cut-off of a surface point follows its FACE's horizon,
+    so the shading jumps across every mesh edge, and those jumps move across the film with the mesh; the reference puts non-silhouette edges into the primary-edge
+    table only for face-normal meshes (perspective.cpp:57-66), so for smooth meshes its estimator -- restated here -- has no boundary term for them.  That is a
+    property of the reference's estimator, not of this implementation: the SAME kernels with face normals on the moving mesh (every visible edge in the table)
+    meet central differences on the mesh's own pixels.  Asserted here; the smooth-normal gap is printed beside it."""
+    if name == "bunny_env_2":
+        args, mesh, res, nblk = dict(H.SCENARIOS[name]), 0, None, 5
+        args["AD"] = dict(args["AD"], spp=8, sppe=8)
+    else:
+        args = dict(test_type="direct", scene_file="cbox_bunny.xml", bsdf_samples=1, light_samples=1,
+                    AD=dict(type="mesh_transform", Mesh_ID=[1], Mesh_dir=[[1., 0., 0.]], spp=16, sppe=16, sppse=64), FD=dict(npass=64, eps=0.2))
+        mesh, res, nblk = 1, 128, 8
+    out = {}
+    for face in (True, False):
+        bd, bf = _ad_fd_blocks(args, tmp_path, face, mesh, res, 48, 96, nblk)
+        out[face] = float(np.linalg.norm(bd - bf) / np.linalg.norm(bf))
+    print("%s: AD vs FD over %dx%d blocks -- face normals on the moving mesh %.3f, the file's smooth normals %.3f" % (name, nblk, nblk, out[True], out[False]))
+    assert out[True] < (0.16 if name == "bunny_env_2" else 0.12), out          # measured 0.051 (cbox_bunny), 0.105 (bunny_env_2: 48 AD / 96 FD passes under a high-dynamic-range map)
+    assert out[False] > out[True], out          # (the estimator's missing term: if this ever closes, the sentence above is out of date)
