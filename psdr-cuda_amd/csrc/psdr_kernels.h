@@ -128,6 +128,12 @@ PSDR_HD void slot_to_pixel(long long j, const SlotDiv &nsp, int &pixel, int &s) 
 #ifndef PSDR_WAVES_DM
 #define PSDR_WAVES_DM 3
 #endif
+#ifndef PSDR_WAVES_C_NOTREE
+// renderC of the PathTracer on a scene without a tree: SIX waves (80 VGPRs, 9 spilled).  The kernel waits -- wait_any 0.37 of its wave cycles at five waves, and 3.7 % fewer
+// instructions bought nothing there (profiles/r06_pretest_tiny_abk.txt) -- so a sixth resident wave pays although it spills: C2 0.846 -> 0.808 ms; the price is scratch
+// traffic, 6 -> 93 MB per launch in the counters.  Seven waves: 0.86 ms, 1.1 GB (profiles/r06_six_waves_ab.txt)
+#define PSDR_WAVES_C_NOTREE 6
+#endif
 #ifndef PSDR_WAVES_DG
 #define PSDR_WAVES_DG 2
 #endif
@@ -140,11 +146,13 @@ PSDR_HD void slot_to_pixel(long long j, const SlotDiv &nsp, int &pixel, int &s) 
 #define PSDR_LOGD 1
 #endif
 #ifndef PSDR_LOGD_WAVES_K1
-#define PSDR_LOGD_WAVES_K1 0       // resident waves per SIMD of the K = 1 log-derivative kernel on a scene without a tree (0: those of the dual-number kernel it stands in for: 5);
-#endif                            // C2: 4 waves 1.05 ms, 5 (10 VGPRs spilled, 85 MB of counter traffic per launch) 0.953, 6 0.929 but 593 MB of scratch traffic: not adopted (profiles/r05_logd_waves.txt)
+#define PSDR_LOGD_WAVES_K1 6       // resident waves per SIMD of the K = 1 log-derivative kernel on a scene without a tree (0: those of the dual-number kernel it stands in for: 5);
+#endif                            // C2: 4 waves 1.05 ms, 5 (10 VGPRs spilled, 85-143 MB of counter traffic per launch) 0.94-0.95, 6 0.885-0.89 with 712 MB of scratch traffic (9 % of the HBM
+                                  // peak for the launch's duration).  Round 5 kept 5 for the traffic figure; round 6 takes the time: the headline is what this kernel is for, the traffic is
+                                  // reported beside it (roofline.traffic) -- profiles/r05_logd_waves.txt, profiles/r06_six_waves_ab.txt
 template <class G, class R, int INTEG, int FL, bool NOTREE = false> constexpr int camera_waves() {
     constexpr bool lean = (FL & (kSceneEnv | kSceneRough)) == 0;          // plain diffuse / area light (with or without a two-level tree)
-    if (!is_ad<R>()) return lean ? PSDR_WAVES_C + 1 : PSDR_WAVES_C;
+    if (!is_ad<R>()) return lean ? ((NOTREE && INTEG == PSDR_INTEGRATOR_PATH) ? PSDR_WAVES_C_NOTREE : PSDR_WAVES_C + 1) : PSDR_WAVES_C;
     // NOTREE (the launch serves a scene whose primitives all travel in the kernel arguments, run_camera): the rough-conductor PathTracer
     // spills 79 (geometry duals, K = 1) / 204 (material duals, K = 3) VGPRs at 3 waves, none at 2 -- without a tree walk whose latency the third
     // wave would hide, 2 waves are faster (cbox_rough: 8.15 -> 6.9 ms and 8.65 -> 6.4 ms); with trees the third wave wins (interior: 7.4
