@@ -68,6 +68,7 @@ def parse():
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-tree-scenes", action="store_true", help="skip the tree_scenes block (BASELINE configs 3-5 at one GPU's share)")
     ap.add_argument("--tree-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--native-option", action="append", default=[], help=argparse.SUPPRESS)          # developer: name=value, psdr_scene_set_option on the headline scene's handle (A/B runs)
     ap.add_argument("--hip-lib", default=None, help=argparse.SUPPRESS)          # developer: another build of libpsdr_hip.so (tools/build_variant_lib.sh)
     ap.add_argument("--no-c4-strong", action="store_true", help="skip the c4_strong block (BASELINE configs[3]: cbox_bunny 1024^2, global spp 512 sharded over the ranks)")
     return ap.parse_args()
@@ -94,6 +95,9 @@ class Workload:
         self.ek, self.FloatD, self.Vector3fD = ek, FloatD, Vector3fD
         sc = psdr_cuda.Scene()
         sc.load_file(scene_path(args.scene), False)
+        for kv in getattr(args, "native_option", []):
+            k, v = kv.split("=")
+            sc.native_options[k] = float(v)
         sc.opts.width = sc.opts.height = args.res
         sc.opts.spp = args.spp * world              # global spp; each rank renders its 1/world share
         sc.opts.sppe = sc.opts.sppse = 0            # albedo has no boundary term
@@ -744,7 +748,7 @@ def c4_strong(args, world, rank, dist, rccl, wait_all, one_integrator=False):
 
 def lib_arg(args):
     """the counter children measure the build the parent measures (developer runs with --hip-lib)"""
-    return ["--hip-lib", args.hip_lib] if getattr(args, "hip_lib", None) else []
+    return (["--hip-lib", args.hip_lib] if getattr(args, "hip_lib", None) else []) + [x for kv in getattr(args, "native_option", []) for x in ("--native-option", kv)]
 
 
 def main():
