@@ -989,7 +989,7 @@ int psdr_scene_set_option(psdr_scene_t h, const char *name, double value) {
     const std::string n(name);
     const int iv = (int) value;
     if (n == "bvh_refit") h->refit_enabled = iv != 0;                   // 0: rebuild the tree on the host at every psdr_bvh_build
-    else if (n == "forest_min_inline") { h->forest_min_inline = iv; h->have_bvh = false; }   // a two-level tree needs at least this many inline triangles (default 6: walls around objects)
+    else if (n == "forest_min_inline") { h->forest_min_inline = iv; h->have_bvh = false; }   // a two-level tree needs at least this many inline triangles (default 0 since round 6; 6 = only rooms: walls around objects)
     else if (n == "scratch_plain") g_scratch_plain = iv;                 // experiment: scratch blocks of >= 64 MB from hipMalloc instead of the stream-ordered pool (process-wide)
     else if (n == "own_pixels") h->opt.own_pixels = iv;                  // 0: the camera kernels always add to the image with atomics
     else if (n == "emitter_pretest") h->opt.emitter_pretest = iv;         // 0: BSDF-sampled rays that only matter on an emitter are traced like the others (A/B, tests)
