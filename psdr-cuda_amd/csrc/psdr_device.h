@@ -500,6 +500,68 @@ PSDR_HD void walk(const SceneView &sc, TraversalStack &st, const Vec3f &o, const
 #endif
 }
 
+// TWO rays from ONE origin through one walk (the two camera rays of a primary-edge sample: epsilon apart on the film, so they visit the same nodes).  The
+// walks are bound by the latency of their node fetches, not by the slab arithmetic: the pair pays each fetch, each stack round trip and each loop
+// iteration once and runs the slab / triangle tests of both rays on it.  A child is entered when either ray enters it (each ray prunes with its OWN closest
+// hit, so a ray that does not reach a box fails every test below it); every triangle that either single walk would test is tested for that ray here, hence
+// the same closest hit (ties between two triangles at the same distance may resolve in another order: the single walk orders children by its own ray).
+#ifndef PSDR_PE_PAIR
+#define PSDR_PE_PAIR 1
+#endif
+PSDR_HD void walk_tree_pair(const SceneView &sc, TraversalStack &st, const Vec3f &o, const Vec3f &dA, const Vec3f &invA, const Vec3f &dB, const Vec3f &invB, int32_t root,
+                            Hit &bestA, Hit &bestB) {
+    int sp = 0;
+    int32_t cur = root;
+    constexpr int32_t kDone = 0x7fffffff;
+    while (cur != kDone) {
+        while (cur >= 0 && cur != kDone) {
+            BvhNode n;
+#if defined(__HIP_DEVICE_COMPILE__)
+            if (cur < sc.n_lnodes) n = *reinterpret_cast<const BvhNode *>(psdr_dyn_lds + sc.off_lnodes + cur * kLdsNodeStride);
+            else
+#endif
+                n = sc.nodes[cur];
+            float a0, a1, b0, b1;
+            const bool hA0 = slab(n.lo0, n.hi0, o, invA, bestA.t, a0), hA1 = slab(n.lo1, n.hi1, o, invA, bestA.t, a1);
+            const bool hB0 = slab(n.lo0, n.hi0, o, invB, bestB.t, b0), hB1 = slab(n.lo1, n.hi1, o, invB, bestB.t, b1);
+            const bool h0 = hA0 || hB0, h1 = hA1 || hB1;
+            if (h0 && h1) {
+                const float t0 = fminf(hA0 ? a0 : INFINITY, hB0 ? b0 : INFINITY), t1 = fminf(hA1 ? a1 : INFINITY, hB1 ? b1 : INFINITY);
+                const bool first0 = t0 <= t1;
+                st.put(sp++, first0 ? n.c1 : n.c0);
+                cur = first0 ? n.c0 : n.c1;
+            } else if (h0 || h1) {
+                cur = h0 ? n.c0 : n.c1;
+            } else {
+                cur = sp > 0 ? st.get(--sp) : kDone;
+            }
+        }
+        if (cur == kDone) break;
+        {
+            const int enc = ~cur, first = enc >> 3, cnt = (enc & 7) + 1;
+#if defined(__HIP_DEVICE_COMPILE__)
+            if (first + cnt <= sc.n_lbtris) {                      // (two loops: an LDS pointer and a global one must not meet in one variable -- flat loads)
+                const float4 *lt = reinterpret_cast<const float4 *>(psdr_dyn_lds + sc.off_lbtris) + first * 3;
+                for (int i = 0; i < cnt; ++i) {
+                    const float4 ta = lt[i * 3], tb = lt[i * 3 + 1], tc = lt[i * 3 + 2];
+                    leaf_triangle_test<false>(ta, tb, tc, o, dA, bestA);
+                    leaf_triangle_test<false>(ta, tb, tc, o, dB, bestB);
+                }
+            } else
+#endif
+            {
+                const float4 *bt = sc.btris + (size_t) first * 3;
+                for (int i = 0; i < cnt; ++i) {
+                    const float4 ta = bt[i * 3], tb = bt[i * 3 + 1], tc = bt[i * 3 + 2];
+                    leaf_triangle_test<false>(ta, tb, tc, o, dA, bestA);
+                    leaf_triangle_test<false>(ta, tb, tc, o, dB, bestB);
+                }
+            }
+            cur = sp > 0 ? st.get(--sp) : kDone;
+        }
+    }
+}
+
 PSDR_HD bool blas_box(const SceneView &sc, int k, const Vec3f &o, const Vec3f &inv, float tmax, float &t_entry) {
     const float lo[3] = {sc.blas_lo[k].x, sc.blas_lo[k].y, sc.blas_lo[k].z}, hi[3] = {sc.blas_hi[k].x, sc.blas_hi[k].y, sc.blas_hi[k].z};
     return slab(lo, hi, o, inv, tmax, t_entry);
@@ -610,6 +672,24 @@ PSDR_HD Hit closest_hit(const SceneView &sc, TraversalStack &st, const Vec3f &o,
     }
     walk<IGN>(sc, st, o, d, inv, sc.root, sc.root4, best, ig0, ig1);
     return best;
+}
+
+// closest hits of two rays from one origin on a two-level scene whose kernels walk the BVH2 (pair_walk_ok): the kernel-argument primitives per ray (one
+// copy of that loop), then every tree either ray's segment enters through walk_tree_pair.  The trees are taken in table order (the single-ray search takes
+// the nearest box first): the closest hit does not depend on the order, only the pruning does, and these scenes hold one to a few trees.
+template <int FLAGS> constexpr bool pair_walk_ok() { return PSDR_PE_PAIR != 0 && tree_mode<FLAGS>() == 1 && PSDR_WIDE_TREE == 0; }
+PSDR_HD void closest_hit_pair(const SceneView &sc, TraversalStack &st, const Vec3f &o, const Vec3f &dA, const Vec3f &dB, Hit &hA, Hit &hB) {
+#pragma unroll 1
+    for (int r = 0; r < 2; ++r) {
+        const Hit h = closest_hit<false, 2>(sc, st, o, r ? dB : dA, INFINITY);
+        if (r) hB = h; else hA = h;
+    }
+    const Vec3f invA{1.f / dA.x, 1.f / dA.y, 1.f / dA.z}, invB{1.f / dB.x, 1.f / dB.y, 1.f / dB.z};
+    for (int k = 0; k < sc.n_blas; ++k) {
+        float te;
+        const bool eA = blas_box(sc, k, o, invA, hA.t, te), eB = blas_box(sc, k, o, invB, hB.t, te);
+        if (eA || eB) walk_tree_pair(sc, st, o, dA, invA, dB, invB, __float_as_int_hd(sc.blas_lo[k].w), hA, hB);
+    }
 }
 
 // ------------------------------------------------------------------------ table loads
@@ -1336,11 +1416,23 @@ PSDR_HD Vec3<M> direct_step(const SceneView &sc, const TVT &tv, TraversalStack &
     return result;
 }
 
+template <bool KNOWN, class G, class TVT>
+PSDR_HD Its<G> known_or_traced(const SceneView &sc, const TVT &tv, TraversalStack &st, const RayT<G> &ray, bool active, uint32_t &nrays, const Hit *primary) {
+    if constexpr (KNOWN) {
+        Its<G> its;
+        its.valid = false; its.tri = its.mesh = -1; its.J = G(1.f); its.t = G(INFINITY);
+        if (active) { nrays++; if (primary->tri >= 0) fill_its_from_hit<G>(its, sc, tv, *primary, ray, is_ad<G>() ? kSolidAngle : kDetached); }
+        return its;
+    } else {
+        (void) primary;
+        return intersect<G>(sc, tv, st, ray, active, is_ad<G>() ? kSolidAngle : kDetached, nrays, -1, -1, kPrePrimaryRay);
+    }
+}
 // DirectIntegrator::__Li (direct.cpp:47-163); FieldExtractionIntegrator::__Li (field.cpp:34-54);
 // PathTracer = iterated direct step (no reference implementation; depth 1 == DirectIntegrator(1,1)).
-template <class G, class M, int INTEG = -1, class TVT>
+template <class G, class M, int INTEG = -1, bool KNOWN = false, class TVT>
 PSDR_HD Vec3<M> Li(const SceneView &sc, const TVT &tv, TraversalStack &st, const LiParams &lp, Rng &rng, const RayT<G> &ray, bool active,
-                   uint32_t &nrays) {
+                   uint32_t &nrays, const Hit *primary = nullptr) {
     // INTEG >= 0: integrator fixed at compile time (the camera kernels are specialised per integrator so
     // the other integrators' code does not occupy registers / instruction cache); -1: run-time switch
     const int integ = INTEG >= 0 ? INTEG : lp.integrator;
@@ -1349,7 +1441,8 @@ PSDR_HD Vec3<M> Li(const SceneView &sc, const TVT &tv, TraversalStack &st, const
     // two forms have the same value and derivative, and the on-surface form p = p0 + u e1 + v e2 is used:
     // o + t d sits up to ~1e-4 off the wall (fp32 t at distance ~1000), which lets ~1e-3 of the grazing
     // continuation rays re-hit their own wall -- isolated O(1) sample flips between any two fp32 builds
-    Its<G> its = intersect<G>(sc, tv, st, ray, active, is_ad<G>() ? kSolidAngle : kDetached, nrays, -1, -1, kPrePrimaryRay);
+    // KNOWN: the closest hit of `ray` is *primary (closest_hit_pair found the two camera rays of a primary-edge sample in one walk)
+    Its<G> its = known_or_traced<KNOWN, G>(sc, tv, st, ray, active, nrays, primary);
     active = active && its.valid;
     if (integ == PSDR_INTEGRATOR_FIELD) {
         if (!active) return zero3<M>();
@@ -1558,6 +1651,12 @@ PSDR_HD bool primary_edge_point_visible(const SceneView &sc, const TVT &tv0, Tra
     return closest_hit<true, tree_mode<TVT::flags>()>(sc, st, ray.o, ray.d, tmax, __float_as_int_hd(z[2]), __float_as_int_hd(z[3])).tri < 0;
 }
 
+// the closest hits of the two camera rays of a primary-edge sample (the film point moved by -+ kEdgeEpsilon along the edge normal), one walk
+template <class TVT0>
+PSDR_HD void primary_edge_camera_hits(const SceneView &sc, const TVT0 &tv0, TraversalStack &st, float px, float py, float nx, float ny, Hit &h0, Hit &h1) {
+    const RayT<float> r0 = primary_ray<float>(sc, tv0, px - kEdgeEpsilon * nx, py - kEdgeEpsilon * ny), r1 = primary_ray<float>(sc, tv0, px + kEdgeEpsilon * nx, py + kEdgeEpsilon * ny);
+    closest_hit_pair(sc, st, r0.o, r0.d, r1.d, h0, h1);          // (a perspective camera: both rays leave its position)
+}
 // One primary-edge slot: Integrator::render_primary_edges (integrator.cpp:98-119) +
 // PerspectiveCamera::sample_primary_edge (perspective.cpp:158-200).  Returns the pixel (or -1);
 // tan[k][c] = d value / d P_k (the primal part is exactly zero: value -= detach(value)).
@@ -1582,11 +1681,25 @@ PSDR_HD int primary_edge_sample(const SceneView &sc, const TangentView<K, FL> &t
     // Li on the two sides of the edge (ray_n first, then ray_p: the order the reference draws them in,
     // integrator.cpp:107-112) -- one loop body, so the estimator is instantiated once
     Vec3f L2[2];
+    if constexpr (pair_walk_ok<FL>()) {
+        // two-level scenes: both camera rays through ONE walk (closest_hit_pair), then the estimator on each side's known hit
+        Hit hp0, hp1;
+        hp0.tri = hp1.tri = -1; hp0.u = hp0.v = hp0.t = hp1.u = hp1.v = hp1.t = 0.f;
+        if (valid) primary_edge_camera_hits(sc, tv0, st, px, py, nx, ny, hp0, hp1);
 #pragma unroll 1
-    for (int side = 0; side < 2; ++side) {
-        const float sg = side == 0 ? -kEdgeEpsilon : kEdgeEpsilon;
-        const RayT<float> ray = primary_ray<float>(sc, tv0, px + sg * nx, py + sg * ny);
-        L2[side] = Li<float, float, INTEG>(sc, tv0, st, lp, rng, ray, valid, nrays);
+        for (int side = 0; side < 2; ++side) {
+            const float sg = side == 0 ? -kEdgeEpsilon : kEdgeEpsilon;
+            const RayT<float> ray = primary_ray<float>(sc, tv0, px + sg * nx, py + sg * ny);
+            const Hit hs = side == 0 ? hp0 : hp1;
+            L2[side] = Li<float, float, INTEG, true>(sc, tv0, st, lp, rng, ray, valid, nrays, &hs);
+        }
+    } else {
+#pragma unroll 1
+        for (int side = 0; side < 2; ++side) {
+            const float sg = side == 0 ? -kEdgeEpsilon : kEdgeEpsilon;
+            const RayT<float> ray = primary_ray<float>(sc, tv0, px + sg * nx, py + sg * ny);
+            L2[side] = Li<float, float, INTEG>(sc, tv0, st, lp, rng, ray, valid, nrays);
+        }
     }
     if (!valid) return -1;
     const Vec3f Ln = L2[0], Lp = L2[1];

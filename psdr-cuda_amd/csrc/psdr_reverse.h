@@ -1113,11 +1113,25 @@ PSDR_HD int primary_edge_reverse_values(const SceneView &sc, TraversalStack &st,
     const TangentView<0, FL> tv0{};
     if (sc.d.prim_edge_z != nullptr && valid) valid = primary_edge_point_visible(sc, tv0, st, k, u, px, py, nrays);
     Vec3f L2[2];
+    if constexpr (pair_walk_ok<FL>()) {
+        // two-level scenes: both camera rays through ONE walk (closest_hit_pair), then the estimator on each side's known hit
+        Hit hp0, hp1;
+        hp0.tri = hp1.tri = -1; hp0.u = hp0.v = hp0.t = hp1.u = hp1.v = hp1.t = 0.f;
+        if (valid) primary_edge_camera_hits(sc, tv0, st, px, py, nx, ny, hp0, hp1);
 #pragma unroll 1
-    for (int side = 0; side < 2; ++side) {
-        const float sg = side == 0 ? -kEdgeEpsilon : kEdgeEpsilon;
-        const RayT<float> ray = primary_ray<float>(sc, tv0, px + sg * nx, py + sg * ny);
-        L2[side] = Li<float, float, INTEG>(sc, tv0, st, lp, rng, ray, valid, nrays);
+        for (int side = 0; side < 2; ++side) {
+            const float sg = side == 0 ? -kEdgeEpsilon : kEdgeEpsilon;
+            const RayT<float> ray = primary_ray<float>(sc, tv0, px + sg * nx, py + sg * ny);
+            const Hit hs = side == 0 ? hp0 : hp1;
+            L2[side] = Li<float, float, INTEG, true>(sc, tv0, st, lp, rng, ray, valid, nrays, &hs);
+        }
+    } else {
+#pragma unroll 1
+        for (int side = 0; side < 2; ++side) {
+            const float sg = side == 0 ? -kEdgeEpsilon : kEdgeEpsilon;
+            const RayT<float> ray = primary_ray<float>(sc, tv0, px + sg * nx, py + sg * ny);
+            L2[side] = Li<float, float, INTEG>(sc, tv0, st, lp, rng, ray, valid, nrays);
+        }
     }
     if (!valid) return -1;
     const Vec3f Ln = L2[0], Lp = L2[1];
