@@ -76,7 +76,7 @@ elif case in ("c3r", "c4r3", "blr"):
     run = lambda: g.render_d_rev(o, adj, with_image=False)
 elif case in ("c4pr", "c5pr", "blpr"):
     adj = np.random.default_rng(0).random((tb["width"] * tb["height"], 3)).astype(np.float32)
-    run = lambda: g.render_d_rev(o, adj, want=["tri_info", "texels"], with_image=False)
+    run = lambda: g.render_d_rev(o, adj, want=os.environ.get("WF_WANT", "tri_info,texels").split(","), with_image=False)          # WF_WANT: which gradient tables (A/B of what a table's adds cost)
 elif case in ("c2ra", "c2rt"):
     adj = np.random.default_rng(0).random((tb["width"] * tb["height"], 3)).astype(np.float32)
     run = lambda: g.render_d_rev(o, adj, want=["texels", "emitter_rad", "tri_info", "cam_to_world"] if case == "c2ra" else ["texels"], with_image=False)
